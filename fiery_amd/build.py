@@ -1,0 +1,53 @@
+"""Builds libfiery_hip.so (gfx950) in-tree with hipcc.  `python -m fiery_amd.build [--force]`."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
+OUT = os.path.join(HERE, 'libfiery_hip.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+
+# (source, extra flags).  lift_splat.hip: the index path must round like ATen's CPU kernels -> no FMA contraction.
+SOURCES = [
+    ('runtime.cpp', []),
+    ('lift_splat.hip', ['-ffp-contract=off']),
+    ('warp.hip', []),
+    ('conv_igemm.hip', []),
+    ('aux_ops.hip', []),
+]
+COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + INCLUDE, '-I' + CSRC, '-x', 'hip']
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    objdir = os.path.join(HERE, 'build')
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, 'common.h'), os.path.join(INCLUDE, 'fiery_hip.h')]
+    objs = []
+    for name, extra in SOURCES:
+        src = os.path.join(CSRC, name)
+        obj = os.path.join(objdir, name + '.o')
+        objs.append(obj)
+        if force or _stale(obj, [src] + headers):
+            cmd = [HIPCC] + COMMON + extra + ['-c', src, '-o', obj]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            subprocess.check_call(cmd)
+    if force or _stale(OUT, objs):
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

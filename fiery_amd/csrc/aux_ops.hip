@@ -1,0 +1,234 @@
+// Small HBM-bound helpers of the BEV stack for gfx950: reductions, poolings, resampling, broadcasts and
+// the layout changes at the API seams.  Each replaces a one-line ATen call of the reference (cited at
+// the entry points in include/fiery_hip.h); all are unit-stride on the pixel-major (NHWC) layout.
+#include "common.h"
+
+namespace fiery {
+namespace {
+
+constexpr int kMeanChunks = 64;
+
+// stage 1: grid (kMeanChunks, n_img); 256 threads = 4 pixel lanes x 64 channel lanes
+__global__ __launch_bounds__(256) void k_mean_partial(const float* __restrict__ in, int ld, long long img_stride, int HW,
+                                                      int C, float* __restrict__ partial) {
+    __shared__ float red[256];
+    const int chunk = blockIdx.x, img = blockIdx.y;
+    const int per = (HW + kMeanChunks - 1) / kMeanChunks;
+    const int p0 = chunk * per, p1 = min(HW, p0 + per);
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const float* base = in + static_cast<long long>(img) * img_stride;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int c = c0 + cl;
+        float s = 0.f;
+        if (c < C)
+            for (int p = p0 + pl; p < p1; p += 4) s += base[static_cast<long long>(p) * ld + c];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (pl == 0 && c < C)
+            partial[(static_cast<long long>(img) * kMeanChunks + chunk) * C + c] =
+                (red[cl] + red[64 + cl]) + (red[128 + cl] + red[192 + cl]);
+        __syncthreads();
+    }
+}
+
+__global__ void k_mean_final(const float* __restrict__ partial, int n_img, int C, float inv_count, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_img * C) return;
+    const int img = i / C, c = i - img * C;
+    float s = 0.f;
+    for (int k = 0; k < kMeanChunks; ++k) s += partial[(static_cast<long long>(img) * kMeanChunks + k) * C + c];
+    out[i] = s * inv_count;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == FIERY_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == FIERY_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    return v;
+}
+
+__global__ void k_rowwise_dense(const float* __restrict__ v, int v_ld, int rows, int n_in, const float* __restrict__ W,
+                                int w_ld, int w_col0, int n_out, const float* __restrict__ scale,
+                                const float* __restrict__ shift, int act, int accumulate, float* __restrict__ y, int y_ld) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * n_out) return;
+    const int r = i / n_out, o = i - r * n_out;
+    const float* wr = W + static_cast<long long>(o) * w_ld + w_col0;
+    const float* vr = v + static_cast<long long>(r) * v_ld;
+    float acc = 0.f;
+    for (int j = 0; j < n_in; ++j) acc = fmaf(wr[j], vr[j], acc);
+    float* dst = y + static_cast<long long>(r) * y_ld + o;
+    if (accumulate) {
+        *dst += acc;
+    } else {
+        const float sc = scale ? scale[o] : 1.f, sh = shift ? shift[o] : 0.f;
+        *dst = apply_act(fmaf(acc, sc, sh), act);
+    }
+}
+
+__global__ void k_maxpool2x2(const float* __restrict__ in, int in_ld, int H, int W, int C, int Ho, int Wo,
+                             float* __restrict__ out, int out_ld, long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = static_cast<int>(i % C);
+    long long r = i / C;
+    const int xo = static_cast<int>(r % Wo);
+    r /= Wo;
+    const int yo = static_cast<int>(r % Ho);
+    const int img = static_cast<int>(r / Ho);
+    const float* base = in + static_cast<long long>(img) * H * W * in_ld;
+    float m = -INFINITY;
+    for (int dy = 0; dy < 2; ++dy)
+        for (int dx = 0; dx < 2; ++dx) {
+            const int y = 2 * yo + dy, x = 2 * xo + dx;
+            // odd sizes were zero-padded by one row / column before pooling
+            const float v = (y < H && x < W) ? base[(static_cast<long long>(y) * W + x) * in_ld + c] : 0.f;
+            m = fmaxf(m, v);
+        }
+    out[((static_cast<long long>(img) * Ho + yo) * Wo + xo) * out_ld + c] = m;
+}
+
+// bilinear x2, align_corners=False: source = dst / 2 - 0.25 clamped at 0, upper neighbour clamped at the edge
+__global__ void k_upsample2x_add(const float* __restrict__ in, int in_ld, int H, int W, int C,
+                                 const float* __restrict__ shift, const float* __restrict__ skip, int skip_ld,
+                                 float* __restrict__ out, int out_ld, long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = static_cast<int>(i % C);
+    long long r = i / C;
+    const int Wo = 2 * W, Ho = 2 * H;
+    const int x = static_cast<int>(r % Wo);
+    r /= Wo;
+    const int y = static_cast<int>(r % Ho);
+    const int img = static_cast<int>(r / Ho);
+    const float sy = fmaxf(0.5f * (y + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * (x + 0.5f) - 0.5f, 0.f);
+    const int y0 = static_cast<int>(sy), x0 = static_cast<int>(sx);
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float ly = sy - y0, lx = sx - x0;
+    const float* base = in + static_cast<long long>(img) * H * W * in_ld + c;
+    const float v00 = base[(static_cast<long long>(y0) * W + x0) * in_ld], v01 = base[(static_cast<long long>(y0) * W + x1) * in_ld];
+    const float v10 = base[(static_cast<long long>(y1) * W + x0) * in_ld], v11 = base[(static_cast<long long>(y1) * W + x1) * in_ld];
+    const float up = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+    const long long po = (static_cast<long long>(img) * Ho + y) * Wo + x;
+    out[po * out_ld + c] = up + (shift ? shift[c] : 0.f) + skip[po * skip_ld + c];
+}
+
+__global__ void k_broadcast(const float* __restrict__ v, int v_ld, int HW, int C, float* __restrict__ out, int out_ld,
+                            long long out_img_stride, long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = static_cast<int>(i % C);
+    long long r = i / C;
+    const int p = static_cast<int>(r % HW);
+    const int img = static_cast<int>(r / HW);
+    out[img * out_img_stride + static_cast<long long>(p) * out_ld + c] = v[static_cast<long long>(img) * v_ld + c];
+}
+
+// 64-pixel tiles through LDS so both sides are unit-stride
+__global__ __launch_bounds__(256) void k_nchw_to_nhwc(const float* __restrict__ in, int C, int HW, float* __restrict__ out,
+                                                      int out_ld, long long out_img_stride) {
+    HIP_DYNAMIC_SHARED(float, tile)   // [64][C + 1]
+    const int img = blockIdx.y, p0 = blockIdx.x * 64;
+    const int npx = min(64, HW - p0);
+    const int row = C + 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* src = in + static_cast<long long>(img) * C * HW + p0;
+    for (int c = wave; c < C; c += 4)
+        if (lane < npx) tile[lane * row + c] = src[static_cast<long long>(c) * HW + lane];
+    __syncthreads();
+    float* dst = out + img * out_img_stride + static_cast<long long>(p0) * out_ld;
+    for (int i = threadIdx.x; i < npx * C; i += blockDim.x) {
+        const int px = i / C, c = i - px * C;
+        dst[static_cast<long long>(px) * out_ld + c] = tile[px * row + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_nhwc_to_nchw(const float* __restrict__ in, int in_ld, long long in_img_stride, int C,
+                                                      int HW, float* __restrict__ out) {
+    HIP_DYNAMIC_SHARED(float, tile)   // [64][C + 1]
+    const int img = blockIdx.y, p0 = blockIdx.x * 64;
+    const int npx = min(64, HW - p0);
+    const int row = C + 1;
+    const float* src = in + img * in_img_stride + static_cast<long long>(p0) * in_ld;
+    for (int i = threadIdx.x; i < npx * C; i += blockDim.x) {
+        const int px = i / C, c = i - px * C;
+        tile[px * row + c] = src[static_cast<long long>(px) * in_ld + c];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* dst = out + static_cast<long long>(img) * C * HW + p0;
+    for (int c = wave; c < C; c += 4)
+        if (lane < npx) dst[static_cast<long long>(c) * HW + lane] = tile[lane * row + c];
+}
+
+}  // namespace
+}  // namespace fiery
+
+using namespace fiery;
+
+extern "C" int fiery_spatial_mean(const float* in, int in_ld, int64_t in_img_stride, int n_img, int HW, int C, float* out,
+                                  float* workspace, fiery_stream_t stream) {
+    FIERY_REQUIRE(in && out && workspace && n_img > 0 && HW > 0 && C > 0 && in_ld >= C, "spatial_mean: bad argument");
+    hipLaunchKernelGGL(k_mean_partial, dim3(kMeanChunks, n_img), dim3(256), 0, as_stream(stream), in, in_ld,
+                       static_cast<long long>(in_img_stride), HW, C, workspace);
+    int rc = check_launch("spatial_mean(partial)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_mean_final, dim3(ceil_div(n_img * C, 256)), dim3(256), 0, as_stream(stream), workspace, n_img, C,
+                       1.0f / static_cast<float>(HW), out);
+    return check_launch("spatial_mean(final)");
+}
+
+extern "C" int fiery_rowwise_dense(const float* v, int v_ld, int rows, int n_in, const float* W, int w_ld, int w_col0,
+                                   int n_out, const float* scale, const float* shift, int act, int accumulate, float* y,
+                                   int y_ld, fiery_stream_t stream) {
+    FIERY_REQUIRE(v && W && y && rows > 0 && n_in > 0 && n_out > 0, "rowwise_dense: bad argument");
+    FIERY_REQUIRE(w_col0 >= 0 && w_col0 + n_in <= w_ld && v_ld >= n_in && y_ld >= n_out, "rowwise_dense: bad strides");
+    hipLaunchKernelGGL(k_rowwise_dense, dim3(ceil_div(rows * n_out, 128)), dim3(128), 0, as_stream(stream), v, v_ld, rows,
+                       n_in, W, w_ld, w_col0, n_out, scale, shift, act, accumulate, y, y_ld);
+    return check_launch("rowwise_dense");
+}
+
+extern "C" int fiery_maxpool2x2_nhwc(const float* in, int in_ld, int n_img, int H, int W, int C, float* out, int out_ld,
+                                     fiery_stream_t stream) {
+    FIERY_REQUIRE(in && out && n_img > 0 && H > 0 && W > 0 && C > 0, "maxpool: bad argument");
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const long long total = static_cast<long long>(n_img) * Ho * Wo * C;
+    hipLaunchKernelGGL(k_maxpool2x2, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), in, in_ld, H, W, C, Ho, Wo,
+                       out, out_ld, total);
+    return check_launch("maxpool2x2");
+}
+
+extern "C" int fiery_upsample2x_add_nhwc(const float* in, int in_ld, int n_img, int H, int W, int C, const float* shift,
+                                         const float* skip, int skip_ld, float* out, int out_ld, fiery_stream_t stream) {
+    FIERY_REQUIRE(in && skip && out && n_img > 0 && H > 0 && W > 0 && C > 0, "upsample2x_add: bad argument");
+    const long long total = static_cast<long long>(n_img) * 4 * H * W * C;
+    hipLaunchKernelGGL(k_upsample2x_add, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), in, in_ld, H, W, C,
+                       shift, skip, skip_ld, out, out_ld, total);
+    return check_launch("upsample2x_add");
+}
+
+extern "C" int fiery_broadcast_nhwc(const float* v, int v_ld, int n_img, int HW, int C, float* out, int out_ld,
+                                    int64_t out_img_stride, fiery_stream_t stream) {
+    FIERY_REQUIRE(v && out && n_img > 0 && HW > 0 && C > 0, "broadcast: bad argument");
+    const long long total = static_cast<long long>(n_img) * HW * C;
+    hipLaunchKernelGGL(k_broadcast, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), v, v_ld, HW, C, out, out_ld,
+                       static_cast<long long>(out_img_stride), total);
+    return check_launch("broadcast");
+}
+
+extern "C" int fiery_nchw_to_nhwc(const float* in, int n_img, int C, int HW, float* out, int out_ld, int64_t out_img_stride,
+                                  fiery_stream_t stream) {
+    FIERY_REQUIRE(in && out && n_img > 0 && C > 0 && HW > 0 && out_ld >= C, "nchw_to_nhwc: bad argument");
+    FIERY_REQUIRE(static_cast<size_t>(64) * (C + 1) * sizeof(float) <= 160 * 1024, "nchw_to_nhwc: too many channels");
+    hipLaunchKernelGGL(k_nchw_to_nhwc, dim3(ceil_div(HW, 64), n_img), dim3(256), static_cast<size_t>(64) * (C + 1) * sizeof(float),
+                       as_stream(stream), in, C, HW, out, out_ld, static_cast<long long>(out_img_stride));
+    return check_launch("nchw_to_nhwc");
+}
+
+extern "C" int fiery_nhwc_to_nchw(const float* in, int in_ld, int64_t in_img_stride, int n_img, int C, int HW, float* out,
+                                  fiery_stream_t stream) {
+    FIERY_REQUIRE(in && out && n_img > 0 && C > 0 && HW > 0 && in_ld >= C, "nhwc_to_nchw: bad argument");
+    FIERY_REQUIRE(static_cast<size_t>(64) * (C + 1) * sizeof(float) <= 160 * 1024, "nhwc_to_nchw: too many channels");
+    hipLaunchKernelGGL(k_nhwc_to_nchw, dim3(ceil_div(HW, 64), n_img), dim3(256), static_cast<size_t>(64) * (C + 1) * sizeof(float),
+                       as_stream(stream), in, in_ld, static_cast<long long>(in_img_stride), C, HW, out);
+    return check_launch("nhwc_to_nchw");
+}

@@ -1,0 +1,416 @@
+// Implicit-GEMM convolution on the gfx950 matrix cores, fp32 in / fp32 accumulate.
+//
+// Replaces the cuDNN conv2d/conv3d + batch_norm + activation (+ residual, + GRU gate arithmetic) call
+// chains of the reference's BEV stack (fiery/layers/convolutions.py:9-168, fiery/layers/temporal.py:10-281,
+// fiery/models/decoder.py:53-91).  One kernel covers 1x1, 3x3 (stride 1/2), 7x7 stride 2 and the causal
+// (kT,3,3) temporal convolutions: the GEMM is  out[pixel][cout] = sum_k A[pixel][k] * W[k][cout]  with
+// k = (tap, input channel), A gathered on the fly from pixel-major (NHWC) activations.
+//
+// Mapping to CDNA4:
+//   * v_mfma_f32_32x32x2_f32 - exact fp32 products, fp32 accumulate (the 1e-4 parity budget rules out
+//     bf16 for this configuration); 64 cycles per instruction per SIMD, so the matrix pipe is the
+//     bound and everything else is sized to stay out of its way.
+//   * workgroup = 4 wavefronts, tile = 128 pixels x BN couts (BN = 64: 2x2 wavefronts of 64x32;
+//     BN = 32: 4x1 wavefronts of 32x32), K advanced 32 at a time through double-buffered LDS, one
+//     barrier per step; global loads for step k+1 are in flight while step k runs on the MFMAs.
+//   * A tile is stored [pixel][32 k] with the 16-byte slot index XOR-ed by (pixel>>1)&7, so the
+//     ds_read_b128 of 32 consecutive pixels at one k-slot is bank-conflict free; each b128 feeds four
+//     MFMA k-steps (the K order inside a step is permuted identically for A and W).
+//   * the weight tile is pre-packed on the host side in exactly its LDS image: one contiguous 4/8 KiB
+//     copy per step.
+//   * input channels are a virtual concat of two tensors (GRU [x, h], temporal-block path concat), and
+//     the epilogue applies bias / folded BatchNorm / activation / residual / GRU gate math in registers.
+#include "common.h"
+
+namespace fiery {
+namespace {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128;   // output pixels per workgroup
+constexpr int BK = 32;    // k per LDS stage (4 units of 8 input channels)
+constexpr int kMaxCinUnits = 64;
+
+struct SrcP {
+    const float* ptr;
+    int ld, units;
+    long long bstride, tstride;
+};
+struct TensP {
+    float* ptr;
+    int ld;
+    long long istride;
+};
+struct ConvP {
+    SrcP src[2];
+    int Hin, Win, Hout, Wout, n_img, Tout, tout0, tinadd;
+    int kT, kH, kW, stride, padH, padW;
+    const float* w;
+    int cout_pad, k_chunks, n_units, cin_units;
+    const float* scale;
+    const float* shift;
+    const float* img_bias;
+    int act, epi, res_pre;
+    TensP res, out, out2, aux0, aux1;
+    int cout_store;
+    long long M;
+};
+
+__device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+template <int BN>
+__global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
+    constexpr int WN = BN / 32;            // wavefronts along couts
+    constexpr int WM = 4 / WN;             // wavefronts along pixels
+    constexpr int MT = BM / (32 * WM);     // 32-pixel MFMA tiles per wavefront
+    constexpr int BLOADS = (BK * BN / 4) / 256;
+
+    __shared__ float As[2][BM * BK];
+    __shared__ float Bs[2][BK * BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int wm = wv % WM, wn = wv / WM;
+    const int m = lane & 31, hi = lane >> 5;
+    const int tile_n = blockIdx.y;
+    const long long pix0 = static_cast<long long>(blockIdx.x) * BM;
+    const int HWout = p.Hout * p.Wout;
+
+    // ---- this thread's share of the A gather: one 16-byte slot of 4 pixels per stage ----------------
+    const int f4 = tid & 7;                // logical 16-byte slot inside the 32-k row
+    const int prow = tid >> 3;             // 0..31
+    int pb[4], pt[4], pys[4], pxs[4];
+    bool pvalid[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long gp = pix0 + prow + 32 * j;
+        pvalid[j] = gp < p.M;
+        const long long g = pvalid[j] ? gp : 0;
+        const int o = static_cast<int>(g / HWout);
+        const int rem = static_cast<int>(g - static_cast<long long>(o) * HWout);
+        const int y = rem / p.Wout, x = rem - y * p.Wout;
+        pb[j] = o / p.Tout;
+        pt[j] = o - pb[j] * p.Tout;
+        pys[j] = y * p.stride - p.padH;
+        pxs[j] = x * p.stride - p.padW;
+    }
+    const float* wtile = p.w + static_cast<long long>(tile_n) * p.k_chunks * (BK * BN);
+    const int khw = p.kH * p.kW;
+
+    float4 areg[4];
+    float4 breg0 = make_float4(0.f, 0.f, 0.f, 0.f), breg1 = breg0;   // named: an indexed array ends up in scratch
+
+    auto load_stage = [&](int chunk) {
+        const int u = chunk * 4 + (f4 >> 1);
+        const bool uvalid = u < p.n_units;
+        const int tap = uvalid ? u / p.cin_units : 0;
+        const int cc = uvalid ? u - tap * p.cin_units : 0;
+        const int dt = tap / khw;
+        const int r = tap - dt * khw;
+        const int dy = r / p.kW, dx = r - dy * p.kW;
+        const bool second = cc >= p.src[0].units;
+        SrcP sp;                                   // selects, not a runtime-indexed copy (that would go to scratch)
+        sp.ptr = second ? p.src[1].ptr : p.src[0].ptr;
+        sp.ld = second ? p.src[1].ld : p.src[0].ld;
+        sp.bstride = second ? p.src[1].bstride : p.src[0].bstride;
+        sp.tstride = second ? p.src[1].tstride : p.src[0].tstride;
+        const int choff = (cc - (second ? p.src[0].units : 0)) * 8 + (f4 & 1) * 4;
+        const int tshift = dt - (p.kT - 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int iy = pys[j] + dy, ix = pxs[j] + dx;
+            const bool ok = uvalid && pvalid[j] && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win &&
+                            (pt[j] + p.tout0 + tshift) >= 0;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                const float* a = sp.ptr + pb[j] * sp.bstride + (pt[j] + p.tinadd + tshift) * sp.tstride +
+                                 (static_cast<long long>(iy) * p.Win + ix) * sp.ld + choff;
+                v = *reinterpret_cast<const float4*>(a);
+            }
+            areg[j] = v;
+        }
+        const float4* wsrc = reinterpret_cast<const float4*>(wtile + static_cast<long long>(chunk) * (BK * BN));
+        breg0 = wsrc[tid];
+        if (BLOADS > 1) breg1 = wsrc[tid + 256];
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pl = prow + 32 * j;
+            const int slot = f4 ^ ((pl >> 1) & 7);
+            *reinterpret_cast<float4*>(&As[buf][pl * BK + slot * 4]) = areg[j];
+        }
+        *reinterpret_cast<float4*>(&Bs[buf][tid * 4]) = breg0;
+        if (BLOADS > 1) *reinterpret_cast<float4*>(&Bs[buf][(tid + 256) * 4]) = breg1;
+    };
+
+    v16f acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+
+    for (int chunk = 0; chunk < p.k_chunks; ++chunk) {
+        const int buf = chunk & 1;
+        const bool more = chunk + 1 < p.k_chunks;
+        if (more) load_stage(chunk + 1);          // global loads fly while the MFMAs below run
+
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float av[MT][4];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const int pl = wm * (32 * MT) + t * 32 + m;
+                const int slot = (2 * q + hi) ^ ((pl >> 1) & 7);
+                const float4 a4 = *reinterpret_cast<const float4*>(&As[buf][pl * BK + slot * 4]);
+                av[t][0] = a4.x;
+                av[t][1] = a4.y;
+                av[t][2] = a4.z;
+                av[t][3] = a4.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // this lane's k for the step: 8q + 4hi + j, for its A element and its W element alike
+                const float bv = Bs[buf][(8 * q + 4 * hi + j) * BN + wn * 32 + m];
+#pragma unroll
+                for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t][j], bv, acc[t], 0, 0, 0);
+            }
+        }
+
+        if (more) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds cout = co for 16 pixel rows of each tile ------------------------------
+    const int co = tile_n * BN + wn * 32 + m;
+    const float sc = p.scale[co], sh = p.shift[co];
+    const int half = p.cout_pad >> 1;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const long long gp = pix0 + wm * (32 * MT) + t * 32 + row;
+            if (gp >= p.M) continue;
+            const int o = static_cast<int>(gp / HWout);
+            const long long pp = gp - static_cast<long long>(o) * HWout;
+            float v = acc[t][r];
+            if (p.img_bias) v += p.img_bias[static_cast<long long>(o) * p.cout_pad + co];
+            v = fmaf(v, sc, sh);
+            if (p.epi == FIERY_EPI_PLAIN) {
+                if (co >= p.cout_store) continue;
+                if (p.res.ptr && p.res_pre) v += p.res.ptr[o * p.res.istride + pp * p.res.ld + co];
+                if (p.act == FIERY_ACT_RELU) v = fmaxf(v, 0.f);
+                else if (p.act == FIERY_ACT_SIGMOID) v = sigmoidf(v);
+                if (p.res.ptr && !p.res_pre) v += p.res.ptr[o * p.res.istride + pp * p.res.ld + co];
+                p.out.ptr[o * p.out.istride + pp * p.out.ld + co] = v;
+            } else if (p.epi == FIERY_EPI_GRU_GATES) {
+                const float g = sigmoidf(v);
+                if (co < half) {
+                    p.out.ptr[o * p.out.istride + pp * p.out.ld + co] = g;                       // update gate
+                } else {
+                    const int c2 = co - half;
+                    const float h = p.aux0.ptr[o * p.aux0.istride + pp * p.aux0.ld + c2];
+                    p.out2.ptr[o * p.out2.istride + pp * p.out2.ld + c2] = (1.0f - g) * h;       // (1 - reset) * state
+                }
+            } else {   // FIERY_EPI_GRU_OUT
+                if (co >= p.cout_store) continue;
+                const float ht = fmaxf(v, 0.f);
+                const float u = p.aux0.ptr[o * p.aux0.istride + pp * p.aux0.ld + co];
+                const float h = p.aux1.ptr[o * p.aux1.istride + pp * p.aux1.ld + co];
+                const float a = (1.0f - u) * h;
+                const float b = u * ht;
+                const float hn = a + b;
+                p.out.ptr[o * p.out.istride + pp * p.out.ld + co] = hn;
+                if (p.out2.ptr) p.out2.ptr[o * p.out2.istride + pp * p.out2.ld + co] = hn;
+            }
+        }
+    }
+}
+
+// ---- weight packing ------------------------------------------------------------------------------
+struct ChanInverse {
+    short ci[kMaxCinUnits * 8];   // padded channel position -> logical input channel, -1 = padding
+};
+
+__global__ void k_pack_weights(const float* __restrict__ w, int cout, int cin_total, int taps, ChanInverse inv,
+                               int cin_units, int bn, int k_chunks, long long total, float* __restrict__ packed) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int nn = static_cast<int>(i % bn);
+    long long r = i / bn;
+    const int kk = static_cast<int>(r % BK);
+    r /= BK;
+    const int chunk = static_cast<int>(r % k_chunks);
+    const int tile = static_cast<int>(r / k_chunks);
+    const int n = tile * bn + nn;
+    const int k = chunk * BK + kk;
+    const int u = k >> 3, ch = k & 7;
+    const int tap = u / cin_units, cc = u - tap * cin_units;
+    float v = 0.f;
+    if (n < cout && tap < taps) {
+        const int ci = inv.ci[cc * 8 + ch];
+        if (ci >= 0) v = w[(static_cast<long long>(n) * cin_total + ci) * taps + tap];
+    }
+    packed[i] = v;
+}
+
+struct Geometry {
+    int cout_pad, bn, n_tiles, k_chunks, n_units;
+};
+
+Geometry conv_geometry(int cout, int cin_units, int taps) {
+    Geometry g;
+    g.cout_pad = (cout + 31) / 32 * 32;
+    g.bn = (g.cout_pad % 64 == 0) ? 64 : 32;
+    g.n_tiles = g.cout_pad / g.bn;
+    g.n_units = cin_units * taps;
+    g.k_chunks = (g.n_units + 3) / 4;
+    return g;
+}
+
+// ---- final 1x1 heads, NCHW result ------------------------------------------------------------------
+struct HeadMeta {
+    int c_off[8];
+    unsigned char sigmoid[8];
+};
+
+// 64 pixels per workgroup.  The pixel-major tile is staged once through LDS (unit-stride reads), then
+// each lane owns a pixel and each wavefront a subset of the outputs, so the NCHW planes are written
+// with unit stride too.
+__global__ __launch_bounds__(256) void k_heads_1x1(const float* __restrict__ in, int in_ld, int HW, int C, int head_c,
+                                                   int n_out, const float* __restrict__ w, const float* __restrict__ bias,
+                                                   HeadMeta meta, float* __restrict__ out) {
+    HIP_DYNAMIC_SHARED(float, tile)   // [64][C + 1]
+    const int img = blockIdx.y;
+    const int p0 = blockIdx.x * 64;
+    const int npx = min(64, HW - p0);
+    const int row = C + 1;
+    const float* src = in + (static_cast<long long>(img) * HW + p0) * in_ld;
+    for (int i = threadIdx.x; i < npx * C; i += blockDim.x) {
+        const int px = i / C, c = i - px * C;
+        tile[px * row + c] = src[static_cast<long long>(px) * in_ld + c];
+    }
+    __syncthreads();
+    const int px = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (px >= npx) return;
+    for (int o = wave; o < n_out; o += 4) {
+        const float* wr = w + o * head_c;
+        const float* t = tile + px * row + meta.c_off[o];
+        float acc = bias[o];
+        for (int c = 0; c < head_c; ++c) acc = fmaf(wr[c], t[c], acc);
+        if (meta.sigmoid[o]) acc = sigmoidf(acc);
+        out[(static_cast<long long>(img) * n_out + o) * HW + p0 + px] = acc;
+    }
+}
+
+}  // namespace
+}  // namespace fiery
+
+using namespace fiery;
+
+extern "C" size_t fiery_conv_packed_floats(int cout, int cin_units, int taps) {
+    if (cout <= 0 || cin_units <= 0 || taps <= 0) return 0;
+    const Geometry g = conv_geometry(cout, cin_units, taps);
+    return static_cast<size_t>(g.n_tiles) * g.k_chunks * BK * g.bn;
+}
+
+extern "C" int fiery_conv_pack_weights(const float* w, int cout, int cin_total, int taps, const int32_t* chan_map,
+                                       int cin_units, float* packed, fiery_stream_t stream) {
+    FIERY_REQUIRE(w && chan_map && packed, "conv_pack_weights: null pointer");
+    FIERY_REQUIRE(cout > 0 && cin_total > 0 && taps > 0 && cin_units > 0, "conv_pack_weights: bad shape");
+    FIERY_REQUIRE(cin_units <= kMaxCinUnits, "conv_pack_weights: at most %d input channels", kMaxCinUnits * 8);
+    ChanInverse inv;
+    for (int i = 0; i < kMaxCinUnits * 8; ++i) inv.ci[i] = -1;
+    for (int ci = 0; ci < cin_total; ++ci) {
+        const int pos = chan_map[ci];
+        FIERY_REQUIRE(pos >= 0 && pos < cin_units * 8, "conv_pack_weights: chan_map[%d] = %d out of range", ci, pos);
+        FIERY_REQUIRE(inv.ci[pos] < 0, "conv_pack_weights: chan_map maps two channels to position %d", pos);
+        inv.ci[pos] = static_cast<short>(ci);
+    }
+    const Geometry g = conv_geometry(cout, cin_units, taps);
+    const long long total = static_cast<long long>(g.n_tiles) * g.k_chunks * BK * g.bn;
+    hipLaunchKernelGGL(k_pack_weights, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w, cout, cin_total,
+                       taps, inv, cin_units, g.bn, g.k_chunks, total, packed);
+    return check_launch("conv_pack_weights");
+}
+
+extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) {
+    FIERY_REQUIRE(d, "conv_fwd: null descriptor");
+    FIERY_REQUIRE(d->src[0].ptr && d->src[0].units > 0, "conv_fwd: source 0 missing");
+    FIERY_REQUIRE(d->src[1].units == 0 || d->src[1].ptr, "conv_fwd: source 1 missing");
+    FIERY_REQUIRE(d->weights && d->scale && d->shift && d->out.ptr, "conv_fwd: null pointer");
+    FIERY_REQUIRE(d->kT >= 1 && d->kH >= 1 && d->kW >= 1 && d->stride >= 1, "conv_fwd: bad kernel shape");
+    FIERY_REQUIRE(d->n_img_out > 0 && d->T_out > 0 && d->n_img_out % d->T_out == 0, "conv_fwd: bad image counts");
+    FIERY_REQUIRE(d->Hin > 0 && d->Win > 0 && d->Hout > 0 && d->Wout > 0, "conv_fwd: bad spatial shape");
+    FIERY_REQUIRE(d->cout_pad > 0 && d->cout_pad % 32 == 0, "conv_fwd: cout_pad must be a multiple of 32");
+    FIERY_REQUIRE(d->cout_store > 0 && d->cout_store <= d->cout_pad, "conv_fwd: bad cout_store");
+    for (int s = 0; s < 2; ++s) {
+        if (d->src[s].units == 0) continue;
+        FIERY_REQUIRE(aligned16(d->src[s].ptr) && d->src[s].ld % 4 == 0 && d->src[s].batch_stride % 4 == 0 &&
+                          d->src[s].time_stride % 4 == 0,
+                      "conv_fwd: source %d must be 16-byte aligned with strides in multiples of 4 floats", s);
+        FIERY_REQUIRE(d->src[s].ld >= d->src[s].units * 8, "conv_fwd: source %d narrower than its channel units", s);
+    }
+    const int cin_units = d->src[0].units + d->src[1].units;
+    FIERY_REQUIRE(cin_units <= kMaxCinUnits, "conv_fwd: too many input channels");
+    if (d->epi == FIERY_EPI_GRU_GATES) {
+        FIERY_REQUIRE(d->out2.ptr && d->aux0.ptr, "conv_fwd: GRU gate epilogue needs out2 and aux0");
+    } else if (d->epi == FIERY_EPI_GRU_OUT) {
+        FIERY_REQUIRE(d->aux0.ptr && d->aux1.ptr, "conv_fwd: GRU output epilogue needs aux0 and aux1");
+    } else {
+        FIERY_REQUIRE(d->epi == FIERY_EPI_PLAIN, "conv_fwd: unknown epilogue %d", d->epi);
+    }
+    const int taps = d->kT * d->kH * d->kW;
+    ConvP p;
+    for (int s = 0; s < 2; ++s)
+        p.src[s] = SrcP{d->src[s].ptr, d->src[s].ld, d->src[s].units, d->src[s].batch_stride, d->src[s].time_stride};
+    p.Hin = d->Hin; p.Win = d->Win; p.Hout = d->Hout; p.Wout = d->Wout;
+    p.n_img = d->n_img_out; p.Tout = d->T_out; p.tout0 = d->t_out0; p.tinadd = d->t_in_add;
+    p.kT = d->kT; p.kH = d->kH; p.kW = d->kW; p.stride = d->stride; p.padH = d->padH; p.padW = d->padW;
+    p.w = d->weights;
+    p.cout_pad = d->cout_pad;
+    p.cin_units = cin_units;
+    p.n_units = cin_units * taps;
+    p.k_chunks = (p.n_units + 3) / 4;
+    p.scale = d->scale; p.shift = d->shift; p.img_bias = d->img_bias;
+    p.act = d->act; p.epi = d->epi; p.res_pre = d->res_before_act;
+    p.res = TensP{d->res.ptr, d->res.ld, d->res.img_stride};
+    p.out = TensP{d->out.ptr, d->out.ld, d->out.img_stride};
+    p.out2 = TensP{d->out2.ptr, d->out2.ld, d->out2.img_stride};
+    p.aux0 = TensP{d->aux0.ptr, d->aux0.ld, d->aux0.img_stride};
+    p.aux1 = TensP{d->aux1.ptr, d->aux1.ld, d->aux1.img_stride};
+    p.cout_store = d->cout_store;
+    p.M = static_cast<long long>(d->n_img_out) * d->Hout * d->Wout;
+    const int bn = (d->cout_pad % 64 == 0) ? 64 : 32;
+    dim3 grid(ceil_div(p.M, BM), d->cout_pad / bn);
+    if (bn == 64) hipLaunchKernelGGL(k_conv_igemm<64>, grid, dim3(256), 0, as_stream(stream), p);
+    else hipLaunchKernelGGL(k_conv_igemm<32>, grid, dim3(256), 0, as_stream(stream), p);
+    return check_launch("conv_fwd");
+}
+
+extern "C" int fiery_heads_1x1_nchw(const float* in, int in_ld, int n_img, int HW, int C, int head_c, int n_out,
+                                    const float* w, const float* bias, const int32_t* c_off, const uint8_t* sigmoid,
+                                    float* out, fiery_stream_t stream) {
+    FIERY_REQUIRE(in && w && bias && c_off && sigmoid && out, "heads: null pointer");
+    FIERY_REQUIRE(n_out > 0 && n_out <= 8 && n_img > 0 && HW > 0 && C > 0 && in_ld >= C, "heads: bad shape");
+    FIERY_REQUIRE(head_c > 0 && head_c <= C, "heads: bad head width");
+    FIERY_REQUIRE(static_cast<size_t>(64) * (C + 1) * sizeof(float) <= 160 * 1024, "heads: too many channels");
+    HeadMeta meta;
+    for (int o = 0; o < 8; ++o) {
+        meta.c_off[o] = 0;
+        meta.sigmoid[o] = 0;
+    }
+    for (int o = 0; o < n_out; ++o) {
+        FIERY_REQUIRE(c_off[o] >= 0 && c_off[o] + head_c <= C, "heads: c_off[%d] out of range", o);
+        meta.c_off[o] = c_off[o];
+        meta.sigmoid[o] = sigmoid[o];
+    }
+    hipLaunchKernelGGL(k_heads_1x1, dim3(ceil_div(HW, 64), n_img), dim3(256), static_cast<size_t>(64) * (C + 1) * sizeof(float),
+                       as_stream(stream), in, in_ld, HW, C, head_c, n_out, w, bias, meta, out);
+    return check_launch("heads_1x1");
+}

@@ -1,0 +1,424 @@
+// Lift-Splat frustum-to-voxel pooling for gfx950 (MI355X).
+//
+// Replaces the ATen call sequence of the reference's `get_geometry` / `projection_to_birds_eye_view`
+// / `VoxelsSumming` (fiery/models/fiery.py:193-208, 221-273; fiery/utils/geometry.py:283-302).
+//
+// Design: the reference sorts 454k points per frame and prefix-sums 116 MB of
+// features.  Here nothing is sorted.  A prepass turns geometry into voxel ranks and classifies every
+// image *column* (fixed camera, depth, u; varying v) - for any roughly upright camera all the points of a
+// column land in the same voxel.  The pooling kernel owns one (frame, channel, voxel-tile) per
+// workgroup, keeps that tile of the output plane in LDS, streams the channel's feature plane exactly once
+// with unit-stride wavefront loads, reduces each column in registers and retires one LDS atomic per
+// column; the finished tile is written out with one coalesced pass.  HBM traffic is the algorithmic
+// minimum: every feature byte once, every output byte once.
+//
+// This translation unit is compiled with -ffp-contract=off: the index path must reproduce ATen's CPU
+// rounding (separate multiply and add, k ascending) bit for bit.
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace fiery {
+namespace {
+
+constexpr int kColEmpty = -1;   // no point of the column falls inside the grid
+constexpr int kColMixed = -2;   // the column touches more than one voxel (or is partly outside)
+
+struct GridParams {
+    float ox, oy, oz;
+    float rx, ry, rz;
+    int nx, ny, nz;
+};
+
+GridParams to_params(const fiery_bev_grid& g) {
+    return {g.origin[0], g.origin[1], g.origin[2], g.resolution[0], g.resolution[1], g.resolution[2],
+            g.dim[0], g.dim[1], g.dim[2]};
+}
+
+// ((g - origin) / resolution).long() with the reference's bounds mask (fiery.py:236-247): `.long()`
+// truncates toward zero, so anything in (-1, 0) lands in cell 0 and is kept.
+__device__ __forceinline__ bool quantise(float g, float origin, float res, int n, int& cell) {
+    const float s = (g - origin) / res;
+    // trunc(s) in [0, n)  <=>  -1 < s < n ; NaN fails both comparisons
+    if (s > -1.0f && s < static_cast<float>(n)) {
+        cell = static_cast<int>(s);
+        return true;
+    }
+    cell = (s != s) ? static_cast<int>(0x80000000u)
+                    : (s >= 2147483648.0f ? 0x7fffffff : (s <= -2147483648.0f ? static_cast<int>(0x80000000u)
+                                                                                : static_cast<int>(s)));
+    return false;
+}
+
+__device__ __forceinline__ int voxel_rank(float gx, float gy, float gz, const GridParams& p, int* idx3) {
+    int ix, iy, iz;
+    const bool kx = quantise(gx, p.ox, p.rx, p.nx, ix);
+    const bool ky = quantise(gy, p.oy, p.ry, p.ny, iy);
+    const bool kz = quantise(gz, p.oz, p.rz, p.nz, iz);
+    if (idx3) {
+        idx3[0] = ix;
+        idx3[1] = iy;
+        idx3[2] = iz;
+    }
+    return (kx && ky && kz) ? (ix * (p.ny * p.nz) + iy * p.nz + iz) : -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// camera matrices: M = R . K^-1, t
+// ------------------------------------------------------------------------------------------------
+__global__ void k_camera_matrices(const float* __restrict__ intrinsics, const float* __restrict__ extrinsics,
+                                  int n, float* __restrict__ cam) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* K = intrinsics + i * 9;
+    const float* E = extrinsics + i * 16;
+    float inv[9];
+    const float fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    const bool canonical = K[1] == 0.f && K[3] == 0.f && K[6] == 0.f && K[7] == 0.f && K[8] == 1.f &&
+                           fabsf(fx) >= fabsf(cx) && fabsf(fy) >= fabsf(cy) && fx != 0.f && fy != 0.f;
+    if (canonical) {
+        // What LAPACK (getrf + solve on the column-major view, no pivoting) returns for a zero-skew
+        // pinhole matrix: reciprocal-scaled multiplier for the first column, a division for the second.
+        const float rfx = 1.0f / fx;
+        const float rfy = 1.0f / fy;
+        inv[0] = rfx;  inv[1] = 0.f;  inv[2] = -(cx * rfx);
+        inv[3] = 0.f;  inv[4] = rfy;  inv[5] = -(cy / fy);
+        inv[6] = 0.f;  inv[7] = 0.f;  inv[8] = 1.f;
+    } else {
+        // general 3x3: adjugate / determinant (a few ulp from LAPACK; documented in DESIGN.md)
+        const float a = K[0], b = K[1], c = K[2], d = K[3], e = K[4], f = K[5], g = K[6], h = K[7], k = K[8];
+        const float A = e * k - f * h, B = -(d * k - f * g), C = d * h - e * g;
+        const float det = a * A + b * B + c * C;
+        const float r = 1.0f / det;
+        inv[0] = A * r;  inv[1] = -(b * k - c * h) * r;  inv[2] = (b * f - c * e) * r;
+        inv[3] = B * r;  inv[4] = (a * k - c * g) * r;   inv[5] = -(a * f - c * d) * r;
+        inv[6] = C * r;  inv[7] = -(a * h - b * g) * r;  inv[8] = (a * e - b * d) * r;
+    }
+    float* out = cam + i * 12;
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) {
+            // ATen's small-matmul CPU kernel: products and sums rounded one by one, k ascending
+            float acc = E[r * 4 + 0] * inv[0 * 3 + c];
+            acc = acc + E[r * 4 + 1] * inv[1 * 3 + c];
+            acc = acc + E[r * 4 + 2] * inv[2 * 3 + c];
+            out[r * 3 + c] = acc;
+        }
+        out[9 + r] = E[r * 4 + 3];
+    }
+}
+
+__device__ __forceinline__ void lift_point(const float* __restrict__ cam, float u, float v, float d,
+                                           float& gx, float& gy, float& gz) {
+    const float p0 = u * d, p1 = v * d;                      // fiery.py:202
+    float a;
+    a = cam[0] * p0;  a = a + cam[1] * p1;  a = a + cam[2] * d;  gx = a + cam[9];
+    a = cam[3] * p0;  a = a + cam[4] * p1;  a = a + cam[5] * d;  gy = a + cam[10];
+    a = cam[6] * p0;  a = a + cam[7] * p1;  a = a + cam[8] * d;  gz = a + cam[11];
+}
+
+__global__ void k_lift_geometry(const float* __restrict__ frustum, const float* __restrict__ cam,
+                                int n_cam, int points_per_cam, float* __restrict__ geometry) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const long long total = static_cast<long long>(n_cam) * points_per_cam;
+    if (i >= total) return;
+    const int c = static_cast<int>(i / points_per_cam);
+    const int p = static_cast<int>(i - static_cast<long long>(c) * points_per_cam);
+    const float* fr = frustum + 3ll * p;
+    float gx, gy, gz;
+    lift_point(cam + c * 12, fr[0], fr[1], fr[2], gx, gy, gz);
+    float* g = geometry + 3 * i;
+    g[0] = gx;
+    g[1] = gy;
+    g[2] = gz;
+}
+
+// ------------------------------------------------------------------------------------------------
+// integer path
+// ------------------------------------------------------------------------------------------------
+__global__ void k_voxel_index(const float* __restrict__ geometry, long long n, GridParams p,
+                              int* __restrict__ rank, int* __restrict__ idx) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* g = geometry + 3 * i;
+    int triple[3];
+    rank[i] = voxel_rank(g[0], g[1], g[2], p, idx ? triple : nullptr);
+    if (idx) {
+        idx[3 * i + 0] = triple[0];
+        idx[3 * i + 1] = triple[1];
+        idx[3 * i + 2] = triple[2];
+    }
+}
+
+// One thread per image column (frame*camera, d, w): ranks of its H points + the column class.
+__global__ void k_rank_columns(const float* __restrict__ geometry, int n_fc, int D, int H, int W, GridParams p,
+                               int* __restrict__ rank, int* __restrict__ coldesc) {
+    const long long col = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const long long n_cols = static_cast<long long>(n_fc) * D * W;
+    if (col >= n_cols) return;
+    const int w = static_cast<int>(col % W);
+    const long long fd = col / W;                          // (frame*camera)*D + d
+    const long long base = fd * H * W + w;                 // point index of (.., h = 0, w)
+    int first = -3;
+    bool uniform = true;
+    bool any = false;
+    for (int h = 0; h < H; ++h) {
+        const long long pt = base + static_cast<long long>(h) * W;
+        const float* g = geometry + 3 * pt;
+        const int r = voxel_rank(g[0], g[1], g[2], p, nullptr);
+        rank[pt] = r;
+        if (h == 0) first = r;
+        uniform = uniform && (r == first);
+        any = any || (r >= 0);
+    }
+    coldesc[col] = !any ? kColEmpty : ((uniform && first >= 0) ? first : kColMixed);
+}
+
+// ------------------------------------------------------------------------------------------------
+// pooling: one workgroup = (voxel tile, channel, frame)
+// ------------------------------------------------------------------------------------------------
+struct PoolStrides {
+    long long f, n, d, h, w, c;
+};
+
+// Accumulator cell of the LDS plane.  The default is an fp32 LDS atomic (ds_add_f32): sums of a voxel's
+// columns may be added in any order, so the last bit can differ between runs.  The reproducible mode
+// keeps a 64-bit fixed-point cell (2^-32 resolution, |sum| < 2^31): integer addition is associative, so
+// the result is bit-identical from run to run whatever the arrival order.
+template <bool kFixed> struct Cell;
+template <> struct Cell<false> {
+    using type = float;
+    static __device__ __forceinline__ void add(float* cell, float v) { atomicAdd(cell, v); }
+    static __device__ __forceinline__ float value(float c) { return c; }
+};
+template <> struct Cell<true> {
+    using type = unsigned long long;
+    static __device__ __forceinline__ void add(unsigned long long* cell, float v) {
+        atomicAdd(cell, static_cast<unsigned long long>(llrintf(v * 4294967296.0f)));
+    }
+    static __device__ __forceinline__ float value(unsigned long long c) {
+        return static_cast<float>(static_cast<double>(static_cast<long long>(c)) * (1.0 / 4294967296.0));
+    }
+};
+
+template <bool kFused, bool kFixed>
+__global__ __launch_bounds__(256) void k_voxel_pool(
+    const float* __restrict__ x, PoolStrides xs,            // unfused: the lifted tensor
+    const float* __restrict__ depth, const float* __restrict__ feat,   // fused: depth prob + features
+    const int* __restrict__ rank, const int* __restrict__ coldesc, float* __restrict__ out,
+    int n_cam, int D, int H, int W, int C, int n_vox, int tile_vox) {
+    using cell_t = typename Cell<kFixed>::type;
+    HIP_DYNAMIC_SHARED(unsigned char, pool_lds)
+    cell_t* plane = reinterpret_cast<cell_t*>(pool_lds);
+    const int tile = blockIdx.x, c = blockIdx.y, f = blockIdx.z;
+    const int v0 = tile * tile_vox;
+    const int v1 = min(v0 + tile_vox, n_vox);
+    const int span = v1 - v0;
+    for (int i = threadIdx.x; i < span; i += blockDim.x) plane[i] = cell_t(0);
+    __syncthreads();
+
+    const int n_cols = n_cam * D * W;
+    const int* cd = coldesc + static_cast<long long>(f) * n_cols;
+    const int HW = H * W;
+    for (int col = threadIdx.x; col < n_cols; col += blockDim.x) {
+        const int desc = cd[col];
+        if (desc == kColEmpty) continue;
+        if (desc >= 0 && (desc < v0 || desc >= v1)) continue;
+        const int w = col % W;
+        const int nd = col / W;
+        const int d = nd % D;
+        const int cam = nd / D;
+        // element (h) of this column lives at p[h * step]; fused: value = depth[h] * feature[h]
+        const float* p;
+        const float* q = nullptr;
+        long long step, qstep = 0;
+        if (kFused) {
+            p = depth + ((static_cast<long long>(f) * n_cam + cam) * D + d) * HW + w;
+            step = W;
+            q = feat + ((static_cast<long long>(f) * n_cam + cam) * C + c) * HW + w;
+            qstep = W;
+        } else {
+            p = x + f * xs.f + cam * xs.n + d * xs.d + w * xs.w + c * xs.c;
+            step = xs.h;
+        }
+        if (desc >= 0) {
+            float s = 0.f;
+            int h = 0;
+            for (; h + 4 <= H; h += 4) {
+                float a0 = p[(h + 0) * step], a1 = p[(h + 1) * step], a2 = p[(h + 2) * step], a3 = p[(h + 3) * step];
+                if (kFused) {
+                    a0 *= q[(h + 0) * qstep];
+                    a1 *= q[(h + 1) * qstep];
+                    a2 *= q[(h + 2) * qstep];
+                    a3 *= q[(h + 3) * qstep];
+                }
+                s += a0;
+                s += a1;
+                s += a2;
+                s += a3;
+            }
+            for (; h < H; ++h) s += kFused ? p[h * step] * q[h * qstep] : p[h * step];
+            Cell<kFixed>::add(&plane[desc - v0], s);
+        } else {
+            const int* rk = rank + ((static_cast<long long>(f) * n_cam + cam) * D + d) * HW + w;
+            int cur = -1;
+            float s = 0.f;
+            for (int h = 0; h < H; ++h) {
+                int r = rk[h * W];
+                if (r < v0 || r >= v1) r = -1;
+                if (r != cur) {
+                    if (cur >= 0) Cell<kFixed>::add(&plane[cur - v0], s);
+                    cur = r;
+                    s = 0.f;
+                }
+                if (cur >= 0) s += kFused ? p[h * step] * q[h * qstep] : p[h * step];
+            }
+            if (cur >= 0) Cell<kFixed>::add(&plane[cur - v0], s);
+        }
+    }
+    __syncthreads();
+    float* o = out + (static_cast<long long>(f) * C + c) * n_vox + v0;
+    for (int i = threadIdx.x; i < span; i += blockDim.x) o[i] = Cell<kFixed>::value(plane[i]);
+}
+
+}  // namespace
+}  // namespace fiery
+
+using namespace fiery;
+
+extern "C" int fiery_camera_matrices(const float* intrinsics, const float* extrinsics, int n_cameras,
+                                     float* cam, fiery_stream_t stream) {
+    FIERY_REQUIRE(intrinsics && extrinsics && cam && n_cameras > 0, "camera_matrices: null pointer or n <= 0");
+    hipLaunchKernelGGL(k_camera_matrices, dim3(ceil_div(n_cameras, 64)), dim3(64), 0, as_stream(stream),
+                       intrinsics, extrinsics, n_cameras, cam);
+    return check_launch("camera_matrices");
+}
+
+extern "C" int fiery_lift_geometry(const float* frustum, const float* cam, int n_cameras, int D, int H, int W,
+                                   float* geometry, fiery_stream_t stream) {
+    FIERY_REQUIRE(frustum && cam && geometry, "lift_geometry: null pointer");
+    FIERY_REQUIRE(n_cameras > 0 && D > 0 && H > 0 && W > 0, "lift_geometry: bad shape");
+    const int pts = D * H * W;
+    const long long total = static_cast<long long>(n_cameras) * pts;
+    hipLaunchKernelGGL(k_lift_geometry, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), frustum, cam,
+                       n_cameras, pts, geometry);
+    return check_launch("lift_geometry");
+}
+
+extern "C" int fiery_voxel_index(const float* geometry, int64_t n_points, const fiery_bev_grid* grid, int32_t* rank,
+                                 int32_t* idx, fiery_stream_t stream) {
+    FIERY_REQUIRE(geometry && grid && rank, "voxel_index: null pointer");
+    FIERY_REQUIRE(n_points >= 0, "voxel_index: negative size");
+    if (n_points == 0) return FIERY_OK;
+    hipLaunchKernelGGL(k_voxel_index, dim3(ceil_div(n_points, 256)), dim3(256), 0, as_stream(stream), geometry,
+                       static_cast<long long>(n_points), to_params(*grid), rank, idx);
+    return check_launch("voxel_index");
+}
+
+extern "C" size_t fiery_voxel_pool_workspace_bytes(int frames, int n_cameras, int D, int H, int W) {
+    const size_t points = static_cast<size_t>(frames) * n_cameras * D * H * W;
+    const size_t cols = static_cast<size_t>(frames) * n_cameras * D * W;
+    return (points + cols) * sizeof(int32_t) + 256;
+}
+
+namespace {
+
+int choose_tile(int n_vox, int requested, int cell_bytes) {
+    // LDS tile of the output plane.  40 KiB tiles keep four workgroups per CU resident (160 KiB LDS).
+    const int cap = 160000 / cell_bytes;            // 160,000 B: a whole 200x200 fp32 plane, one workgroup per CU
+    int tile = requested > 0 ? requested : 40960 / cell_bytes;
+    if (tile > cap) tile = cap;
+    if (tile > n_vox) tile = n_vox;
+    return tile;
+}
+
+int pool_common(bool fused, const float* x, const int64_t* xs, const float* depth, const float* feat,
+                const float* geometry, int frames, int n_cam, int D, int H, int W, int C,
+                const fiery_bev_grid* grid, float* out, void* workspace, size_t ws_bytes, int tile_voxels,
+                uint32_t flags, fiery_stream_t stream) {
+    FIERY_REQUIRE(geometry && grid && out && workspace, "voxel_pool: null pointer");
+    FIERY_REQUIRE(frames > 0 && n_cam > 0 && D > 0 && H > 0 && W > 0 && C > 0, "voxel_pool: bad shape");
+    FIERY_REQUIRE(grid->dim[2] == 1,
+                  "voxel_pool: bev_dimension[2] = %d; the reference only supports one z cell "
+                  "(fiery/models/fiery.py:268-271)", grid->dim[2]);
+    FIERY_REQUIRE(grid->dim[0] > 0 && grid->dim[1] > 0, "voxel_pool: empty grid");
+    FIERY_REQUIRE((flags & ~FIERY_POOL_DETERMINISTIC) == 0, "voxel_pool: unknown flags 0x%x", flags);
+    const size_t need = fiery_voxel_pool_workspace_bytes(frames, n_cam, D, H, W);
+    if (ws_bytes < need) return fail(FIERY_ENOMEM, "voxel_pool: workspace %zu B < required %zu B", ws_bytes, need);
+    const long long n_vox_ll = static_cast<long long>(grid->dim[0]) * grid->dim[1];
+    FIERY_REQUIRE(n_vox_ll < (1ll << 30), "voxel_pool: grid too large");
+    const int n_vox = static_cast<int>(n_vox_ll);
+    const long long points = static_cast<long long>(frames) * n_cam * D * H * W;
+    int* rank = static_cast<int*>(workspace);
+    int* coldesc = rank + points;
+    const long long n_cols_all = static_cast<long long>(frames) * n_cam * D * W;
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(k_rank_columns, dim3(ceil_div(n_cols_all, 256)), dim3(256), 0, s, geometry, frames * n_cam, D, H,
+                       W, to_params(*grid), rank, coldesc);
+    int rc = check_launch("rank_columns");
+    if (rc) return rc;
+    const bool fixed = (flags & FIERY_POOL_DETERMINISTIC) != 0;
+    const int cell_bytes = fixed ? 8 : 4;
+    const int tile = choose_tile(n_vox, tile_voxels, cell_bytes);
+    const int n_tiles = ceil_div(n_vox, tile);
+    const size_t lds = static_cast<size_t>(tile) * cell_bytes;
+    dim3 gridDim3(n_tiles, C, frames);
+    PoolStrides st{0, 0, 0, 0, 0, 0};
+    if (fused) {
+        FIERY_REQUIRE(depth && feat, "lift_splat: null pointer");
+    } else {
+        FIERY_REQUIRE(x && xs, "voxel_pool: null pointer");
+        st = PoolStrides{xs[0], xs[1], xs[2], xs[3], xs[4], xs[5]};
+    }
+#define FIERY_POOL_LAUNCH(FUSED, FIXED)                                                                          \
+    hipLaunchKernelGGL((k_voxel_pool<FUSED, FIXED>), gridDim3, dim3(256), lds, s, x, st, depth, feat, rank, coldesc, \
+                       out, n_cam, D, H, W, C, n_vox, tile)
+    if (fused && fixed) FIERY_POOL_LAUNCH(true, true);
+    else if (fused) FIERY_POOL_LAUNCH(true, false);
+    else if (fixed) FIERY_POOL_LAUNCH(false, true);
+    else FIERY_POOL_LAUNCH(false, false);
+#undef FIERY_POOL_LAUNCH
+    return check_launch("voxel_pool");
+}
+
+}  // namespace
+
+extern "C" int fiery_voxel_pool_fwd(const float* x, const int64_t* x_strides, const float* geometry, int frames,
+                                    int n_cameras, int D, int H, int W, int C, const fiery_bev_grid* grid, float* out,
+                                    void* workspace, size_t workspace_bytes, int tile_voxels, uint32_t flags,
+                                    fiery_stream_t stream) {
+    return pool_common(false, x, x_strides, nullptr, nullptr, geometry, frames, n_cameras, D, H, W, C, grid, out,
+                       workspace, workspace_bytes, tile_voxels, flags, stream);
+}
+
+extern "C" int fiery_lift_splat_fwd(const float* depth_prob, const float* features, const float* geometry, int frames,
+                                    int n_cameras, int D, int H, int W, int C, const fiery_bev_grid* grid, float* out,
+                                    void* workspace, size_t workspace_bytes, int tile_voxels, uint32_t flags,
+                                    fiery_stream_t stream) {
+    return pool_common(true, nullptr, nullptr, depth_prob, features, geometry, frames, n_cameras, D, H, W, C, grid, out,
+                       workspace, workspace_bytes, tile_voxels, flags, stream);
+}
+
+namespace fiery {
+namespace {
+__global__ void k_depth_softmax(const float* __restrict__ logits, int n, int D, int HW, float* __restrict__ prob) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= static_cast<long long>(n) * HW) return;
+    const int img = static_cast<int>(i / HW);
+    const int p = static_cast<int>(i - static_cast<long long>(img) * HW);
+    const float* in = logits + static_cast<long long>(img) * D * HW + p;
+    float* o = prob + static_cast<long long>(img) * D * HW + p;
+    float m = -INFINITY;
+    for (int d = 0; d < D; ++d) m = fmaxf(m, in[static_cast<long long>(d) * HW]);
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) s += expf(in[static_cast<long long>(d) * HW] - m);
+    for (int d = 0; d < D; ++d) o[static_cast<long long>(d) * HW] = expf(in[static_cast<long long>(d) * HW] - m) / s;
+}
+}  // namespace
+}  // namespace fiery
+
+extern "C" int fiery_depth_softmax(const float* logits, int n, int D, int HW, float* prob, fiery_stream_t stream) {
+    FIERY_REQUIRE(logits && prob && n > 0 && D > 0 && HW > 0, "depth_softmax: bad argument");
+    hipLaunchKernelGGL(fiery::k_depth_softmax, dim3(ceil_div(static_cast<long long>(n) * HW, 256)), dim3(256), 0,
+                       as_stream(stream), logits, n, D, HW, prob);
+    return check_launch("depth_softmax");
+}

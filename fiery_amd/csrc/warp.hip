@@ -1,0 +1,184 @@
+// Ego-motion warping of BEV feature maps for gfx950.
+//
+// Replaces `cumulative_warp_features` / `warp_features` and the pose algebra they call
+// (fiery/utils/geometry.py:82-157, 181-253): on the reference these are ~40 small ATen launches plus
+// affine_grid + grid_sample per past frame.  Here: one tiny kernel turns the ego-motion vectors into
+// sampling transforms, one HBM-bound kernel resamples every past frame and at the same time changes
+// the layout from the pooling kernel's channel-planes (NCHW) to the pixel-major layout (NHWC) the
+// implicit-GEMM convolutions read.
+#include "common.h"
+
+namespace fiery {
+namespace {
+
+constexpr int kMaxFrames = 16;
+
+__device__ void mat4_mul(const float* a, const float* b, float* out) {
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float acc = 0.f;
+            for (int k = 0; k < 4; ++k) acc += a[i * 4 + k] * b[k * 4 + j];
+            out[i * 4 + j] = acc;
+        }
+}
+
+// pose_vec2mat (geometry.py:143-157) with euler2mat's R = Rx.Ry.Rz (geometry.py:109-140)
+__device__ void pose_to_mat(const float* v, float* m) {
+    const float cx = cosf(v[3]), sx = sinf(v[3]);
+    const float cy = cosf(v[4]), sy = sinf(v[4]);
+    const float cz = cosf(v[5]), sz = sinf(v[5]);
+    const float X[9] = {1, 0, 0, 0, cx, -sx, 0, sx, cx};
+    const float Y[9] = {cy, 0, sy, 0, 1, 0, -sy, 0, cy};
+    const float Z[9] = {cz, -sz, 0, sz, cz, 0, 0, 0, 1};
+    float XY[9], R[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            float acc = 0.f;
+            for (int k = 0; k < 3; ++k) acc += X[i * 3 + k] * Y[k * 3 + j];
+            XY[i * 3 + j] = acc;
+        }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            float acc = 0.f;
+            for (int k = 0; k < 3; ++k) acc += XY[i * 3 + k] * Z[k * 3 + j];
+            R[i * 3 + j] = acc;
+        }
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) m[i * 4 + j] = R[i * 3 + j];
+        m[i * 4 + 3] = v[i];
+    }
+    m[12] = m[13] = m[14] = 0.f;
+    m[15] = 1.f;
+}
+
+__global__ void k_warp_params(const float* __restrict__ ego, int B, int S, float ext_x, float ext_y,
+                              float* __restrict__ theta) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float* th = theta + static_cast<long long>(b) * S * 6;
+    // the present frame is never resampled (geometry.py:245)
+    float* last = th + (S - 1) * 6;
+    last[0] = 1.f; last[1] = 0.f; last[2] = 0.f; last[3] = 0.f; last[4] = 1.f; last[5] = 0.f;
+    if (S == 1) return;
+    float cum[16], next[16], step[16];
+    pose_to_mat(ego + (static_cast<long long>(b) * S + (S - 2)) * 6, cum);
+    for (int t = S - 2; t >= 0; --t) {
+        // mat2pose_vec keeps (tx, ty) and rz = atan2(-M01, M00) (geometry.py:82-106); warp_features
+        // uses exactly those three (geometry.py:192-215)
+        const float rz = atan2f(-cum[1], cum[0]);
+        const float c = cosf(rz), s = sinf(rz);
+        float* o = th + t * 6;
+        o[0] = c;  o[1] = -s;  o[2] = cum[7] / ext_y;
+        o[3] = s;  o[4] = c;   o[5] = -(cum[3] / ext_x);
+        if (t > 0) {
+            pose_to_mat(ego + (static_cast<long long>(b) * S + (t - 1)) * 6, step);
+            mat4_mul(step, cum, next);
+            for (int i = 0; i < 16; ++i) cum[i] = next[i];
+        }
+    }
+}
+
+constexpr int kWarpTile = 64;   // pixels per workgroup (one row segment)
+constexpr int kMaxWarpImages = 256;
+
+// per-image "copy, do not resample" flags, passed by value as a kernel argument
+struct IdentityFlags {
+    unsigned char v[kMaxWarpImages];
+};
+
+// grid: (ceil(W / 64), H, n_img); 256 threads = 4 wavefronts.  Phase 1: wavefront w samples channels
+// w, w+4, ... with lanes along x (unit-stride reads of the NCHW planes for small rotations).  Phase 2:
+// the 64-pixel x C tile leaves LDS pixel-major with lanes along channels (unit-stride NHWC writes).
+__global__ __launch_bounds__(256) void k_bev_warp(const float* __restrict__ in, const float* __restrict__ theta,
+                                                  IdentityFlags identity, int C, int H, int W,
+                                                  float* __restrict__ out, int out_ld, long long out_img_stride) {
+    HIP_DYNAMIC_SHARED(float, tile)            // [kWarpTile][C + 1]
+    const int img = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * kWarpTile;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = x0 + lane;
+    const int row = C + 1;
+    const float* plane0 = in + static_cast<long long>(img) * C * H * W;
+    const bool copy = identity.v[img] != 0;
+
+    int ix0 = 0, iy0 = 0;
+    float w00 = 0.f, w01 = 0.f, w10 = 0.f, w11 = 0.f;
+    bool v00 = false, v01 = false, v10 = false, v11 = false;
+    if (x < W && !copy) {
+        const float* th = theta + img * 6;
+        // affine_grid, align_corners=False: pixel centres mapped to [-1, 1]
+        const float xn = (2.0f * x + 1.0f) / W - 1.0f;
+        const float yn = (2.0f * y + 1.0f) / H - 1.0f;
+        const float gx = th[0] * xn + th[1] * yn + th[2];
+        const float gy = th[3] * xn + th[4] * yn + th[5];
+        // grid_sample un-normalisation, align_corners=False
+        const float fx = ((gx + 1.0f) * W - 1.0f) * 0.5f;
+        const float fy = ((gy + 1.0f) * H - 1.0f) * 0.5f;
+        const float flx = floorf(fx), fly = floorf(fy);
+        ix0 = static_cast<int>(flx);
+        iy0 = static_cast<int>(fly);
+        const float tx = fx - flx, ty = fy - fly;
+        w00 = (1.f - tx) * (1.f - ty);  w01 = tx * (1.f - ty);
+        w10 = (1.f - tx) * ty;          w11 = tx * ty;
+        const bool xin0 = ix0 >= 0 && ix0 < W, xin1 = ix0 + 1 >= 0 && ix0 + 1 < W;
+        const bool yin0 = iy0 >= 0 && iy0 < H, yin1 = iy0 + 1 >= 0 && iy0 + 1 < H;
+        v00 = xin0 && yin0;  v01 = xin1 && yin0;  v10 = xin0 && yin1;  v11 = xin1 && yin1;
+    }
+    for (int c = wave; c < C; c += 4) {
+        float val = 0.f;
+        if (x < W) {
+            const float* pl = plane0 + static_cast<long long>(c) * H * W;
+            if (copy) {
+                val = pl[y * W + x];
+            } else {
+                // zeros padding: out-of-range corners contribute nothing
+                if (v00) val += w00 * pl[iy0 * W + ix0];
+                if (v01) val += w01 * pl[iy0 * W + ix0 + 1];
+                if (v10) val += w10 * pl[(iy0 + 1) * W + ix0];
+                if (v11) val += w11 * pl[(iy0 + 1) * W + ix0 + 1];
+            }
+        }
+        tile[lane * row + c] = val;
+    }
+    __syncthreads();
+    float* obase = out + static_cast<long long>(img) * out_img_stride + (static_cast<long long>(y) * W + x0) * out_ld;
+    const int npx = min(kWarpTile, W - x0);
+    for (int i = threadIdx.x; i < npx * C; i += blockDim.x) {
+        const int px = i / C, c = i - px * C;
+        obase[static_cast<long long>(px) * out_ld + c] = tile[px * row + c];
+    }
+}
+
+}  // namespace
+}  // namespace fiery
+
+using namespace fiery;
+
+extern "C" int fiery_warp_params(const float* future_egomotion, int B, int S, float extent_x, float extent_y,
+                                 float* theta, fiery_stream_t stream) {
+    FIERY_REQUIRE(future_egomotion && theta && B > 0 && S > 0, "warp_params: bad argument");
+    FIERY_REQUIRE(S <= kMaxFrames, "warp_params: at most %d frames", kMaxFrames);
+    FIERY_REQUIRE(extent_x != 0.f && extent_y != 0.f, "warp_params: zero spatial extent");
+    hipLaunchKernelGGL(k_warp_params, dim3(ceil_div(B, 64)), dim3(64), 0, as_stream(stream), future_egomotion, B, S,
+                       extent_x, extent_y, theta);
+    return check_launch("warp_params");
+}
+
+extern "C" int fiery_bev_warp_nchw_to_nhwc(const float* in, const float* theta, const uint8_t* identity, int n_img, int C,
+                                           int H, int W, float* out, int out_ld, int64_t out_img_stride,
+                                           fiery_stream_t stream) {
+    FIERY_REQUIRE(in && theta && out, "bev_warp: null pointer");
+    FIERY_REQUIRE(n_img > 0 && C > 0 && H > 0 && W > 0 && out_ld >= C, "bev_warp: bad shape");
+    FIERY_REQUIRE(static_cast<size_t>(kWarpTile) * (C + 1) * sizeof(float) <= 160 * 1024, "bev_warp: too many channels");
+    for (int i0 = 0; i0 < n_img; i0 += kMaxWarpImages) {
+        const int n = n_img - i0 < kMaxWarpImages ? n_img - i0 : kMaxWarpImages;
+        IdentityFlags flags;
+        for (int i = 0; i < kMaxWarpImages; ++i) flags.v[i] = (identity && i < n && identity[i0 + i]) ? 1 : 0;
+        hipLaunchKernelGGL(k_bev_warp, dim3(ceil_div(W, kWarpTile), H, n), dim3(256),
+                           static_cast<size_t>(kWarpTile) * (C + 1) * sizeof(float), as_stream(stream),
+                           in + static_cast<long long>(i0) * C * H * W, theta + static_cast<long long>(i0) * 6, flags, C, H, W,
+                           out + static_cast<long long>(i0) * out_img_stride, out_ld, static_cast<long long>(out_img_stride));
+        int rc = check_launch("bev_warp");
+        if (rc) return rc;
+    }
+    return FIERY_OK;
+}

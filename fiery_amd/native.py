@@ -1,0 +1,264 @@
+"""ctypes binding of libfiery_hip.so (include/fiery_hip.h).
+
+PyTorch is plumbing here: tensors supply device memory and the current HIP stream; every kernel is
+the hand-written gfx950 code in `fiery_amd/csrc`.  There is no fallback: if the shared library is not
+built, `get()` raises - a silently different code path would void every parity claim.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libfiery_hip.so')
+ABI_VERSION = 1
+
+c_float_p = C.POINTER(C.c_float)
+c_int32_p = C.POINTER(C.c_int32)
+c_int64_p = C.POINTER(C.c_int64)
+c_uint8_p = C.POINTER(C.c_uint8)
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+EPI_PLAIN, EPI_GRU_GATES, EPI_GRU_OUT = 0, 1, 2
+POOL_DETERMINISTIC = 1
+
+
+class BevGrid(C.Structure):
+    _fields_ = [('origin', C.c_float * 3), ('resolution', C.c_float * 3), ('dim', C.c_int32 * 3)]
+
+
+class ConvSrc(C.Structure):
+    _fields_ = [('ptr', C.c_void_p), ('ld', C.c_int32), ('units', C.c_int32),
+                ('batch_stride', C.c_int64), ('time_stride', C.c_int64)]
+
+
+class Nhwc(C.Structure):
+    _fields_ = [('ptr', C.c_void_p), ('ld', C.c_int32), ('img_stride', C.c_int64)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ('src', ConvSrc * 2),
+        ('Hin', C.c_int32), ('Win', C.c_int32), ('Hout', C.c_int32), ('Wout', C.c_int32),
+        ('n_img_out', C.c_int32), ('T_out', C.c_int32), ('t_out0', C.c_int32), ('t_in_add', C.c_int32),
+        ('kT', C.c_int32), ('kH', C.c_int32), ('kW', C.c_int32), ('stride', C.c_int32),
+        ('padH', C.c_int32), ('padW', C.c_int32),
+        ('weights', C.c_void_p), ('cout_pad', C.c_int32),
+        ('scale', C.c_void_p), ('shift', C.c_void_p), ('img_bias', C.c_void_p),
+        ('act', C.c_int32), ('epi', C.c_int32), ('res_before_act', C.c_int32),
+        ('res', Nhwc), ('out', Nhwc), ('cout_store', C.c_int32), ('out2', Nhwc),
+        ('aux0', Nhwc), ('aux1', Nhwc),
+    ]
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream_of(*tensors):
+    for t in tensors:
+        if t is not None and t.is_cuda:
+            return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return C.c_void_p(0)
+
+
+_SIGNATURES = {
+    'fiery_abi_version': (C.c_int, []),
+    'fiery_last_error': (C.c_char_p, []),
+    'fiery_camera_matrices': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'fiery_lift_geometry': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'fiery_voxel_index': (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(BevGrid), C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fiery_voxel_pool_workspace_bytes': (C.c_size_t, [C.c_int] * 5),
+    'fiery_voxel_pool_fwd': (C.c_int, [C.c_void_p, c_int64_p, C.c_void_p] + [C.c_int] * 6 +
+                             [C.POINTER(BevGrid), C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_void_p]),
+    'fiery_lift_splat_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6 +
+                             [C.POINTER(BevGrid), C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_void_p]),
+    'fiery_depth_softmax': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'fiery_warp_params': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    'fiery_bev_warp_nchw_to_nhwc': (C.c_int, [C.c_void_p, C.c_void_p, c_uint8_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
+    'fiery_conv_packed_floats': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'fiery_conv_pack_weights': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_int32_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'fiery_conv_fwd': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    'fiery_heads_1x1_nchw': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                       c_int32_p, c_uint8_p, C.c_void_p, C.c_void_p]),
+    'fiery_spatial_mean': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fiery_rowwise_dense': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'fiery_maxpool2x2_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'fiery_upsample2x_add_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                            C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'fiery_broadcast_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
+    'fiery_nchw_to_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
+    'fiery_nhwc_to_nchw': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class Lib:
+    """One loaded copy of the C-ABI library."""
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise NativeError(
+                f'{path} is missing: build the HIP extension first '
+                f'(`python -c "import __graft_entry__ as g; g.build()"` or `python -m fiery_amd.build`). '
+                f'There is deliberately no fallback path.')
+        self.path = path
+        self.dll = C.CDLL(path)
+        for name, (restype, argtypes) in _SIGNATURES.items():
+            fn = getattr(self.dll, name)          # AttributeError here = symbol missing from the build
+            fn.restype, fn.argtypes = restype, argtypes
+        got = self.dll.fiery_abi_version()
+        if got != ABI_VERSION:
+            raise NativeError(f'{path}: ABI version {got}, bindings expect {ABI_VERSION}; rebuild')
+
+    def check(self, rc):
+        if rc != 0:
+            raise NativeError(f'libfiery_hip: error {rc}: {self.dll.fiery_last_error().decode()}')
+
+    # -- lift -------------------------------------------------------------------------------------
+    def camera_matrices(self, intrinsics, extrinsics):
+        n = intrinsics.numel() // 9
+        cam = torch.empty(n, 12, dtype=torch.float32, device=intrinsics.device)
+        self.check(self.dll.fiery_camera_matrices(_ptr(intrinsics), _ptr(extrinsics), n, _ptr(cam), _stream_of(cam)))
+        return cam
+
+    def lift_geometry(self, frustum, cam):
+        d, h, w, _ = frustum.shape
+        n = cam.shape[0]
+        out = torch.empty(n, d, h, w, 3, dtype=torch.float32, device=cam.device)
+        self.check(self.dll.fiery_lift_geometry(_ptr(frustum), _ptr(cam), n, d, h, w, _ptr(out), _stream_of(out)))
+        return out
+
+    # -- splat ------------------------------------------------------------------------------------
+    def voxel_index(self, geometry, grid, want_idx=True):
+        n = geometry.numel() // 3
+        rank = torch.empty(n, dtype=torch.int32, device=geometry.device)
+        idx = torch.empty(n, 3, dtype=torch.int32, device=geometry.device) if want_idx else None
+        self.check(self.dll.fiery_voxel_index(_ptr(geometry), n, C.byref(grid), _ptr(rank), _ptr(idx), _stream_of(rank)))
+        return rank, idx
+
+    def pool_workspace(self, frames, n_cam, d, h, w, device):
+        nbytes = self.dll.fiery_voxel_pool_workspace_bytes(frames, n_cam, d, h, w)
+        return torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=device)
+
+    def voxel_pool(self, x, strides, geometry, frames, n_cam, d, h, w, c, grid, out=None, workspace=None,
+                   tile_voxels=0, flags=0):
+        if workspace is None:
+            workspace = self.pool_workspace(frames, n_cam, d, h, w, x.device)
+        if out is None:
+            out = torch.empty(frames, c, grid.dim[0], grid.dim[1], dtype=torch.float32, device=x.device)
+        xs = (C.c_int64 * 6)(*strides)
+        self.check(self.dll.fiery_voxel_pool_fwd(
+            _ptr(x), xs, _ptr(geometry), frames, n_cam, d, h, w, c, C.byref(grid), _ptr(out),
+            _ptr(workspace), workspace.numel() * 4, tile_voxels, flags, _stream_of(out)))
+        return out
+
+    def lift_splat(self, depth_prob, features, geometry, frames, n_cam, d, h, w, c, grid, out=None, workspace=None,
+                   tile_voxels=0, flags=0):
+        if workspace is None:
+            workspace = self.pool_workspace(frames, n_cam, d, h, w, features.device)
+        if out is None:
+            out = torch.empty(frames, c, grid.dim[0], grid.dim[1], dtype=torch.float32, device=features.device)
+        self.check(self.dll.fiery_lift_splat_fwd(
+            _ptr(depth_prob), _ptr(features), _ptr(geometry), frames, n_cam, d, h, w, c, C.byref(grid), _ptr(out),
+            _ptr(workspace), workspace.numel() * 4, tile_voxels, flags, _stream_of(out)))
+        return out
+
+    def depth_softmax(self, logits):
+        n, d = logits.shape[:2]
+        hw = logits[0, 0].numel()
+        out = torch.empty_like(logits)
+        self.check(self.dll.fiery_depth_softmax(_ptr(logits), n, d, hw, _ptr(out), _stream_of(out)))
+        return out
+
+    # -- warp -------------------------------------------------------------------------------------
+    def warp_params(self, future_egomotion, extent):
+        b, s, _ = future_egomotion.shape
+        theta = torch.empty(b, s, 6, dtype=torch.float32, device=future_egomotion.device)
+        self.check(self.dll.fiery_warp_params(_ptr(future_egomotion), b, s, float(extent[0]), float(extent[1]),
+                                              _ptr(theta), _stream_of(theta)))
+        return theta
+
+    def bev_warp_nchw_to_nhwc(self, x, theta, identity, out, out_ld, out_img_stride):
+        n, c, h, w = x.shape
+        ident = (C.c_uint8 * n)(*[1 if v else 0 for v in identity]) if identity is not None else None
+        self.check(self.dll.fiery_bev_warp_nchw_to_nhwc(_ptr(x), _ptr(theta), ident, n, c, h, w, _ptr(out), out_ld,
+                                                        out_img_stride, _stream_of(out)))
+
+    # -- conv -------------------------------------------------------------------------------------
+    def conv_pack_weights(self, w, cout, cin_total, taps, chan_map, cin_units):
+        n = self.dll.fiery_conv_packed_floats(cout, cin_units, taps)
+        packed = torch.empty(n, dtype=torch.float32, device=w.device)
+        cmap = (C.c_int32 * cin_total)(*chan_map)
+        self.check(self.dll.fiery_conv_pack_weights(_ptr(w), cout, cin_total, taps, cmap, cin_units, _ptr(packed),
+                                                    _stream_of(packed)))
+        return packed
+
+    def conv_fwd(self, desc, stream_tensor):
+        self.check(self.dll.fiery_conv_fwd(C.byref(desc), _stream_of(stream_tensor)))
+
+    def heads_1x1_nchw(self, x, in_ld, n_img, hw, c, head_c, w, bias, c_off, sigmoid, out):
+        n_out = len(c_off)
+        offs = (C.c_int32 * n_out)(*c_off)
+        sig = (C.c_uint8 * n_out)(*[1 if v else 0 for v in sigmoid])
+        self.check(self.dll.fiery_heads_1x1_nchw(_ptr(x), in_ld, n_img, hw, c, head_c, n_out, _ptr(w), _ptr(bias), offs, sig,
+                                                 _ptr(out), _stream_of(out)))
+
+    # -- helpers ----------------------------------------------------------------------------------
+    def spatial_mean(self, x, in_ld, in_img_stride, n_img, hw, c, out, workspace):
+        self.check(self.dll.fiery_spatial_mean(_ptr(x), in_ld, in_img_stride, n_img, hw, c, _ptr(out), _ptr(workspace),
+                                               _stream_of(out)))
+
+    def rowwise_dense(self, v, v_ld, rows, n_in, w, w_ld, w_col0, n_out, scale, shift, act, accumulate, y, y_ld):
+        self.check(self.dll.fiery_rowwise_dense(_ptr(v), v_ld, rows, n_in, _ptr(w), w_ld, w_col0, n_out, _ptr(scale),
+                                                _ptr(shift), act, int(accumulate), _ptr(y), y_ld, _stream_of(y)))
+
+    def maxpool2x2(self, x, in_ld, n_img, h, w, c, out, out_ld):
+        self.check(self.dll.fiery_maxpool2x2_nhwc(_ptr(x), in_ld, n_img, h, w, c, _ptr(out), out_ld, _stream_of(out)))
+
+    def upsample2x_add(self, x, in_ld, n_img, h, w, c, shift, skip, skip_ld, out, out_ld):
+        self.check(self.dll.fiery_upsample2x_add_nhwc(_ptr(x), in_ld, n_img, h, w, c, _ptr(shift), _ptr(skip), skip_ld,
+                                                      _ptr(out), out_ld, _stream_of(out)))
+
+    def broadcast(self, v, v_ld, n_img, hw, c, out, out_ld, out_img_stride):
+        self.check(self.dll.fiery_broadcast_nhwc(_ptr(v), v_ld, n_img, hw, c, _ptr(out), out_ld, out_img_stride,
+                                                 _stream_of(out)))
+
+    def nchw_to_nhwc(self, x, n_img, c, hw, out, out_ld, out_img_stride):
+        self.check(self.dll.fiery_nchw_to_nhwc(_ptr(x), n_img, c, hw, _ptr(out), out_ld, out_img_stride, _stream_of(out)))
+
+    def nhwc_to_nchw(self, x, in_ld, in_img_stride, n_img, c, hw, out):
+        self.check(self.dll.fiery_nhwc_to_nchw(_ptr(x), in_ld, in_img_stride, n_img, c, hw, _ptr(out), _stream_of(out)))
+
+
+def make_grid(origin, resolution, dim):
+    g = BevGrid()
+    for i in range(3):
+        g.origin[i] = float(origin[i])
+        g.resolution[i] = float(resolution[i])
+        g.dim[i] = int(dim[i])
+    return g
+
+
+_LIB = None
+
+
+def get():
+    """The product library; raises NativeError when it has not been built."""
+    global _LIB
+    if _LIB is None:
+        _LIB = Lib(LIB_PATH)
+    return _LIB
+
+
+def is_built():
+    return os.path.exists(LIB_PATH)

@@ -1,0 +1,240 @@
+/*
+ * fiery_hip.h - C ABI of libfiery_hip.so, the MI355X (gfx950) kernels behind the FIERY camera-to-BEV
+ * hot path.
+ *
+ * The reference (wayveai/fiery) has no native layer: this path is Python calling ATen operators.  Each
+ * entry point below replaces the ATen call sequence of the cited reference lines and is what a Python
+ * (ctypes) binding for that path binds - see INTEGRATION.md for the binding a maintainer would add.
+ *
+ * Conventions (all functions):
+ *   - plain pointers and sizes; device pointers unless the parameter is documented "host";
+ *   - return 0 on success, a negative FIERY_E* code otherwise; fiery_last_error() (host string,
+ *     thread-local) describes the last failure; nothing throws;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*); no call synchronises, allocates
+ *     or frees device memory - the caller owns every buffer including workspaces, so calls are
+ *     hipGraph-capturable and re-entrant across streams given distinct workspaces;
+ *   - fp32 tensors; "NHWC" tensors are addressed as base + image*img_stride + (y*W + x)*ld + channel.
+ */
+#ifndef FIERY_HIP_H
+#define FIERY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FIERY_ABI_VERSION 1
+
+#define FIERY_OK 0
+#define FIERY_EINVAL (-22)      /* bad argument (shape, alignment, null pointer) */
+#define FIERY_ENOMEM (-12)      /* workspace too small */
+#define FIERY_ELAUNCH (-5)      /* the HIP runtime rejected the launch */
+
+typedef void* fiery_stream_t;   /* hipStream_t */
+
+int fiery_abi_version(void);
+const char* fiery_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Lift: camera geometry            (reference: fiery/models/fiery.py:193-208 `get_geometry`)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Per camera: M = R . K^-1 (3x3) and t (3) -> cam[n][12] = {M row-major, t}.
+ * Replaces `rotation.matmul(torch.inverse(intrinsics))`, fiery.py:195,203.
+ * intrinsics [n][3][3], extrinsics [n][4][4] (camera->ego). */
+int fiery_camera_matrices(const float* intrinsics, const float* extrinsics, int n_cameras,
+                          float* cam, fiery_stream_t stream);
+
+/* geometry[n][D][H][W][3] = M_n . (u*d, v*d, d) + t_n for every frustum point.
+ * Replaces fiery.py:199-205.  frustum [D][H][W][3] = (u, v, depth) (fiery.py:109-128). */
+int fiery_lift_geometry(const float* frustum, const float* cam, int n_cameras, int D, int H, int W,
+                        float* geometry, fiery_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Splat: voxel pooling             (reference: fiery/models/fiery.py:221-273
+ *                                   `projection_to_birds_eye_view` + fiery/utils/geometry.py:283-302
+ *                                   `VoxelsSumming.forward`; LSS names voxel_pooling / QuickCumsum)
+ * ---------------------------------------------------------------------------------------------- */
+
+typedef struct {
+    float origin[3];      /* bev_start_position - bev_resolution / 2, evaluated in fp32 (fiery.py:236) */
+    float resolution[3];  /* bev_resolution   (geometry.py:53)                                        */
+    int32_t dim[3];       /* bev_dimension    (geometry.py:55-56); dim[2] must be 1 for pooling       */
+} fiery_bev_grid;
+
+/* Integer path only: for each of n_points positions, the voxel index triple (trunc toward zero, as
+ * `.long()`), and rank = ix*(Y*Z) + iy*Z + iz, or -1 when the point is outside the grid
+ * (fiery.py:236-256).  idx may be NULL.  Bit-exact against the reference by construction. */
+int fiery_voxel_index(const float* geometry, int64_t n_points, const fiery_bev_grid* grid /* host */,
+                      int32_t* rank, int32_t* idx /* [n_points][3] or NULL */, fiery_stream_t stream);
+
+/* Scratch needed by fiery_voxel_pool_fwd for this problem size. */
+size_t fiery_voxel_pool_workspace_bytes(int frames, int n_cameras, int D, int H, int W);
+
+#define FIERY_POOL_DETERMINISTIC 1u  /* flags: bit-reproducible sums (fixed order), slower */
+
+/* out[f][c][ix][iy] = sum of x over the points of frame f that fall in voxel (ix, iy, 0); voxels no
+ * point reaches are 0.
+ *   x        : logical [frames][n_cameras][D][H][W][C]; element (f,n,d,h,w,c) lives at
+ *              x + f*xs[0] + n*xs[1] + d*xs[2] + h*xs[3] + w*xs[4] + c*xs[5]   (xs = x_strides, host).
+ *              The encoder's native layout (n, C, D, H, W) - the permuted view fiery.py:214-219
+ *              returns - is the fast case (xs[4] == 1).
+ *   geometry : [frames][n_cameras][D][H][W][3] contiguous
+ *   out      : [frames][C][X][Y]
+ *   tile_voxels : voxels per LDS tile, 0 = choose.                                                */
+int fiery_voxel_pool_fwd(const float* x, const int64_t* x_strides /* host [6] */, const float* geometry,
+                         int frames, int n_cameras, int D, int H, int W, int C,
+                         const fiery_bev_grid* grid /* host */, float* out,
+                         void* workspace, size_t workspace_bytes, int tile_voxels, uint32_t flags,
+                         fiery_stream_t stream);
+
+/* Fused lift (x) splat: never materialises the (n, C, D, H, W) outer product.
+ * out[f][c][ix][iy] = sum over points of depth_prob[f][n][d][h][w] * features[f][n][c][h][w]
+ * (reference: fiery/models/encoder.py:99-100 followed by fiery.py:221-273).
+ * depth_prob [frames][n_cameras][D][H][W] (already soft-maxed over D), features [frames][n_cameras][C][H][W]. */
+int fiery_lift_splat_fwd(const float* depth_prob, const float* features, const float* geometry,
+                         int frames, int n_cameras, int D, int H, int W, int C,
+                         const fiery_bev_grid* grid /* host */, float* out,
+                         void* workspace, size_t workspace_bytes, int tile_voxels, uint32_t flags,
+                         fiery_stream_t stream);
+
+/* softmax over the depth axis: logits [n][D][HW] -> prob (reference: fiery/models/encoder.py:99). */
+int fiery_depth_softmax(const float* logits, int n, int D, int HW, float* prob, fiery_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Ego-motion warp                  (reference: fiery/utils/geometry.py:181-253
+ *                                   `cumulative_warp_features` / `warp_features`, :82-157 pose algebra)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* theta[b][s][6]: the 2x3 sampling transform warp_features builds (geometry.py:192-215) for frame s of
+ * batch b, i.e. flow[s] @ ... @ flow[S-2] reduced to (cos, -sin, ty/extent_y, sin, cos, -tx/extent_x);
+ * entries for s = S-1 are the identity.  future_egomotion [B][S][6]. */
+int fiery_warp_params(const float* future_egomotion, int B, int S, float extent_x, float extent_y,
+                      float* theta, fiery_stream_t stream);
+
+/* Bilinear grid-sample with zero padding, align_corners=False (geometry.py:219-220), reading NCHW
+ * [n_img][C][H][W] and writing NHWC (ld, img_stride as given).  Images whose `identity[i]` (host
+ * array, may be NULL) is non-zero are copied exactly (the present frame is never resampled,
+ * geometry.py:245). */
+int fiery_bev_warp_nchw_to_nhwc(const float* in, const float* theta /* [n_img][6] */,
+                                const uint8_t* identity /* host */, int n_img, int C, int H, int W,
+                                float* out, int out_ld, int64_t out_img_stride, fiery_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BEV convolution stack            (reference: fiery/layers/convolutions.py, fiery/layers/temporal.py,
+ *                                   fiery/models/{temporal_model,future_prediction,distributions,decoder}.py;
+ *                                   on CUDA these are cuDNN conv2d/conv3d + batch_norm + activation calls)
+ * ---------------------------------------------------------------------------------------------- */
+
+typedef struct {
+    const float* ptr;
+    int32_t ld;              /* floats between consecutive pixels                                  */
+    int32_t units;           /* 8-channel units taken from this source (0 = unused)               */
+    int64_t batch_stride;    /* floats between consecutive batch elements (output image / T_out)  */
+    int64_t time_stride;     /* floats between consecutive frames of one batch element            */
+} fiery_conv_src;
+
+typedef struct {
+    float* ptr;
+    int32_t ld;
+    int64_t img_stride;      /* floats between consecutive output images */
+} fiery_nhwc;
+
+#define FIERY_ACT_NONE 0
+#define FIERY_ACT_RELU 1
+#define FIERY_ACT_SIGMOID 2
+
+#define FIERY_EPI_PLAIN 0      /* out = act(acc*scale+shift [+res before act]) [+res after act]          */
+#define FIERY_EPI_GRU_GATES 1  /* channels [0,C/2): out=sigmoid -> update gate; [C/2,C): out2=(1-sigmoid)*aux0 */
+#define FIERY_EPI_GRU_OUT 2    /* h~=relu(..); out(=out2) = (1-aux0)*aux1 + aux0*h~   (layers/temporal.py:49-62) */
+
+/* One implicit-GEMM convolution with a fused epilogue, NHWC fp32, fp32 MFMA accumulate.
+ * Input channels are the virtual concatenation of src[0] and src[1] (8-channel units); the kernel
+ * taps are (kT, kH, kW) with causal zero padding in time (layers/temporal.py:65-85) and symmetric
+ * zero padding (padH, padW) in space.  Weights come pre-packed by fiery_conv_pack_weights. */
+typedef struct {
+    fiery_conv_src src[2];
+    int32_t Hin, Win, Hout, Wout;
+    int32_t n_img_out;                 /* = batch * T_out                                               */
+    int32_t T_out;                     /* frames per batch element in the output (1 for 2-D convs)      */
+    int32_t t_out0;                    /* absolute time of output frame 0                               */
+    int32_t t_in_add;                  /* t_out0 - (absolute time of frame 0 of the sources)            */
+    int32_t kT, kH, kW, stride, padH, padW;
+    const float* weights;              /* packed [n_tiles][k_chunks][32][BN]                            */
+    int32_t cout_pad;                  /* multiple of 32                                                */
+    const float* scale;                /* [cout_pad]                                                    */
+    const float* shift;                /* [cout_pad]                                                    */
+    const float* img_bias;             /* [n_img_out][cout_pad] added before scale, or NULL            */
+    int32_t act;
+    int32_t epi;
+    int32_t res_before_act;
+    fiery_nhwc res;                    /* residual, ptr NULL = none (const in practice)                */
+    fiery_nhwc out;
+    int32_t cout_store;                /* channels written to out (<= cout_pad)                         */
+    fiery_nhwc out2;                   /* second destination (GRU modes), ptr NULL = none               */
+    fiery_nhwc aux0, aux1;             /* GRU operands                                                   */
+} fiery_conv_desc;
+
+/* Packs a dense weight W[cout][cin_total][taps] (taps = kT*kH*kW, row-major as PyTorch stores conv
+ * weights) into the kernel's layout.  Input channel ci of the logical concat maps to padded position
+ * chan_map[ci] (host array, length cin_total); units0+units1 eight-channel units in total. */
+size_t fiery_conv_packed_floats(int cout, int cin_units, int taps);
+int fiery_conv_pack_weights(const float* w, int cout, int cin_total, int taps,
+                            const int32_t* chan_map /* host */, int cin_units,
+                            float* packed, fiery_stream_t stream);
+
+int fiery_conv_fwd(const fiery_conv_desc* desc /* host */, fiery_stream_t stream);
+
+/* Final 1x1 heads: out_nchw[img][o][y][x] = act_o(bias[o] + sum_{c<head_c} w[o][c] * in[img][y][x][c_off[o] + c])
+ * (fiery/models/decoder.py:30-51, the last conv (+ Sigmoid) of each head), NCHW result.
+ * `in` has C channels per pixel; n_out <= 8; c_off/sigmoid are host arrays of length n_out;
+ * w is [n_out][head_c] and bias [n_out] on device. */
+int fiery_heads_1x1_nchw(const float* in, int in_ld, int n_img, int HW, int C, int head_c, int n_out,
+                         const float* w, const float* bias, const int32_t* c_off /* host */,
+                         const uint8_t* sigmoid /* host */, float* out, fiery_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Small dense / pooling / resampling helpers of the stack
+ * ---------------------------------------------------------------------------------------------- */
+
+/* mean over the H*W pixels of each image: in NHWC -> out[n_img][C] (AdaptiveAvgPool2d(1),
+ * models/distributions.py:24; also the spatial part of the (2,H,W) pyramid average pool,
+ * layers/temporal.py:186-191).  workspace >= n_img*C*64 floats. */
+int fiery_spatial_mean(const float* in, int in_ld, int64_t in_img_stride, int n_img, int HW, int C,
+                       float* out, float* workspace, fiery_stream_t stream);
+
+/* y[r][o] = act(scale[o] * (sum_j W[o][w_col0 + j] * v[r][j]) + shift[o]) for small matrices
+ * (1x1 convs on per-image vectors: pyramid-pool branch, ego-pose channels, distribution head).
+ * W is [n_out][w_ld]; scale/shift may be NULL (1 / 0). */
+int fiery_rowwise_dense(const float* v, int v_ld, int rows, int n_in, const float* W, int w_ld, int w_col0,
+                        int n_out, const float* scale, const float* shift, int act, int accumulate,
+                        float* y, int y_ld, fiery_stream_t stream);
+
+/* 2x2 stride-2 max pooling, NHWC, odd sizes padded with one zero row/column first
+ * (layers/convolutions.py:150,166). */
+int fiery_maxpool2x2_nhwc(const float* in, int in_ld, int n_img, int H, int W, int C,
+                          float* out, int out_ld, fiery_stream_t stream);
+
+/* out = bilinear_x2(in) + shift[c] + skip  (align_corners=False; layers/convolutions.py:203-214 with
+ * the 1x1 conv and BN scale already applied at low resolution - both commute with the interpolation). */
+int fiery_upsample2x_add_nhwc(const float* in, int in_ld, int n_img, int H, int W, int C,
+                              const float* shift, const float* skip, int skip_ld,
+                              float* out, int out_ld, fiery_stream_t stream);
+
+/* out[img][p][c0 + c] = v[img][c] for every pixel (spatial broadcast of the latent sample,
+ * fiery/models/fiery.py:329-330). */
+int fiery_broadcast_nhwc(const float* v, int v_ld, int n_img, int HW, int C, float* out, int out_ld,
+                         int64_t out_img_stride, fiery_stream_t stream);
+
+/* layout changes at the API seams */
+int fiery_nchw_to_nhwc(const float* in, int n_img, int C, int HW, float* out, int out_ld,
+                       int64_t out_img_stride, fiery_stream_t stream);
+int fiery_nhwc_to_nchw(const float* in, int in_ld, int64_t in_img_stride, int n_img, int C, int HW,
+                       float* out, fiery_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FIERY_HIP_H */

@@ -1,0 +1,118 @@
+"""Import the reference's own Python modules from /root/reference on the CPU.
+
+TEST INFRASTRUCTURE.  Works only in the build container (the GPU box has no /root/reference);
+used by `tests/golden/make_golden.py` to produce the committed fixtures and by the
+`needs_reference` tests that pin `oracle/` against the reference code itself.
+
+The reference imports four third-party packages that are not installed offline
+(SURVEY.md Appendix A).  They are replaced in `sys.modules` by minimal stand-ins *before* the
+reference is imported; the reference's files are used unmodified and never copied.
+"""
+import os
+import sys
+import types
+
+REFERENCE_ROOT = os.environ.get('FIERY_REFERENCE_ROOT', '/root/reference')
+
+
+def reference_available():
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, 'fiery'))
+
+
+def _install_shims():
+    import torch.nn as nn
+    from fiery_amd import backbone, modules
+
+    if 'pyquaternion' not in sys.modules:
+        mod = types.ModuleType('pyquaternion')
+        mod.Quaternion = object           # imported at fiery/utils/geometry.py:5, used only by dataset code
+        sys.modules['pyquaternion'] = mod
+
+    if 'torchvision' not in sys.modules:
+        tv = types.ModuleType('torchvision')
+        transforms = types.ModuleType('torchvision.transforms')
+
+        class Normalize(nn.Module):   # base class of NormalizeInverse, fiery/utils/network.py:33
+            def __init__(self, mean, std):
+                super().__init__()
+                self.mean, self.std = mean, std
+
+        transforms.Normalize = Normalize
+        models = types.ModuleType('torchvision.models')
+        resnet = types.ModuleType('torchvision.models.resnet')
+
+        def resnet18(pretrained=False, zero_init_residual=False):
+            # fiery/models/decoder.py:10-17 only touches bn1, relu, layer1..3
+            holder = types.SimpleNamespace()
+            holder.bn1, holder.relu, holder.layer1, holder.layer2, holder.layer3 = \
+                _forwardable_resnet_stages(zero_init_residual)
+            return holder
+
+        resnet.resnet18 = resnet18
+        models.resnet = resnet
+        tv.transforms, tv.models = transforms, models
+        sys.modules.update({'torchvision': tv, 'torchvision.transforms': transforms,
+                            'torchvision.models': models, 'torchvision.models.resnet': resnet})
+
+    if 'efficientnet_pytorch' not in sys.modules:
+        eff = types.ModuleType('efficientnet_pytorch')
+        eff.EfficientNet = backbone.EfficientNet
+        sys.modules['efficientnet_pytorch'] = eff
+
+
+def _forwardable_resnet_stages(zero_init_residual):
+    """resnet18 bn1/relu/layer1-3 that can actually run (the product's holders carry weights only).
+
+    The BasicBlock arithmetic restated here is torchvision 0.8.1's published one:
+    relu(bn2(conv2(relu(bn1(conv1(x))))) + downsample(x)).
+    """
+    import torch.nn as nn
+    from fiery_amd import modules
+
+    class _Block(modules.BasicBlockWeights):
+        def forward(self, x):
+            identity = x if self.downsample is None else self.downsample(x)
+            out = self.relu(self.bn1(self.conv1(x)))
+            out = self.bn2(self.conv2(out))
+            return self.relu(out + identity)
+
+    bn1, relu, l1, l2, l3 = modules.resnet18_stages(zero_init_residual)
+    rebuilt = []
+    for layer in (l1, l2, l3):
+        blocks = []
+        for blk in layer:
+            new = _Block(blk.conv1.in_channels, blk.conv1.out_channels, blk.stride)
+            new.load_state_dict(blk.state_dict())
+            blocks.append(new)
+        rebuilt.append(nn.Sequential(*blocks))
+    return bn1, relu, rebuilt[0], rebuilt[1], rebuilt[2]
+
+
+_REF = None
+
+
+def load_reference():
+    """Returns a namespace with the reference modules (`fiery_model`, `geometry`, `temporal`, ...)."""
+    global _REF
+    if _REF is not None:
+        return _REF
+    if not reference_available():
+        raise RuntimeError(f'reference tree not found at {REFERENCE_ROOT}')
+    _install_shims()
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    import importlib
+    ns = types.SimpleNamespace()
+    ns.geometry = importlib.import_module('fiery.utils.geometry')
+    ns.network = importlib.import_module('fiery.utils.network')
+    ns.convolutions = importlib.import_module('fiery.layers.convolutions')
+    ns.temporal = importlib.import_module('fiery.layers.temporal')
+    ns.temporal_model = importlib.import_module('fiery.models.temporal_model')
+    ns.future_prediction = importlib.import_module('fiery.models.future_prediction')
+    ns.distributions = importlib.import_module('fiery.models.distributions')
+    ns.decoder = importlib.import_module('fiery.models.decoder')
+    ns.encoder = importlib.import_module('fiery.models.encoder')
+    ns.fiery_model = importlib.import_module('fiery.models.fiery')
+    ns.Fiery = ns.fiery_model.Fiery
+    _REF = ns
+    return ns

@@ -1,0 +1,166 @@
+"""The lift-splat kernel *sources* (fiery_amd/csrc/lift_splat.hip) executed on the CPU simulator and
+checked against the oracle.  Covers index arithmetic, column classification, LDS tiling and both
+accumulation modes without a GPU; the -m gpu tier repeats this through the real library at full size."""
+import numpy as np
+import pytest
+import torch
+
+from fiery_amd import native
+from fiery_amd.synthetic import camera_rig
+from oracle import lift_splat as ls
+
+
+def _grid(xb, yb, zb):
+    res, start, dim = ls.bev_parameters(xb, yb, zb)
+    origin = (start - res / np.float32(2.0)).astype(np.float32)
+    return native.make_grid(origin, res, dim), (res, start, dim)
+
+
+def _small_problem(seed, n_cam=2, D=5, H=6, W=10, C=3, frames=2, jitter=True):
+    frustum = ls.create_frustum((H * 8, W * 8), 8, [2.0, 2.0 + D * 3.0, 3.0])
+    assert frustum.shape == (D, H, W, 3)
+    intr, extr = camera_rig(n_cam, jitter=jitter)
+    intr = intr.clone()
+    intr[:, 0, 2] = W * 4.0            # principal point of the small image
+    intr[:, 1, 2] = H * 4.0
+    intr[:, 0, 0] = intr[:, 1, 1] = 60.0
+    intr = intr.unsqueeze(0).expand(frames, -1, -1, -1).contiguous()
+    extr = extr.unsqueeze(0).expand(frames, -1, -1, -1).contiguous()
+    gen = torch.Generator().manual_seed(seed)
+    lifted = torch.randn(frames, n_cam, C, D, H, W, generator=gen)
+    return frustum, intr, extr, lifted
+
+
+def test_camera_matrices_and_geometry_bit_exact(sim):
+    frustum, intr, extr, _ = _small_problem(0, n_cam=6)
+    cam = sim.camera_matrices(intr.reshape(-1, 3, 3).contiguous(), extr.reshape(-1, 4, 4).contiguous())
+    comb, trans = ls.camera_matrices(intr.numpy(), extr.numpy())
+    assert np.array_equal(cam[:, :9].numpy().reshape(-1, 3, 3), comb.reshape(-1, 3, 3))
+    assert np.array_equal(cam[:, 9:].numpy(), trans.reshape(-1, 3))
+    geo = sim.lift_geometry(torch.from_numpy(frustum), cam)
+    want = ls.get_geometry(frustum, intr.numpy(), extr.numpy()).reshape(geo.shape)
+    assert np.array_equal(geo.numpy(), want)
+
+
+def test_general_intrinsics_fall_back_to_adjugate(sim):
+    k = torch.tensor([[[300.0, 2.0, 310.0], [0.5, 280.0, 120.0], [0.0, 0.0, 1.0]]])
+    e = torch.eye(4).unsqueeze(0)
+    cam = sim.camera_matrices(k, e)
+    want = torch.inverse(k)[0]
+    assert torch.allclose(cam[0, :9].view(3, 3), want, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize('jitter', [True, False])
+def test_voxel_index_bit_exact(sim, jitter):
+    frustum, intr, extr, _ = _small_problem(1, jitter=jitter)
+    geo = ls.get_geometry(frustum, intr.numpy(), extr.numpy())
+    grid, (res, start, dim) = _grid([-20.0, 20.0, 0.5], [-20.0, 20.0, 0.5], [-10.0, 10.0, 20.0])
+    rank, idx = sim.voxel_index(torch.from_numpy(geo), grid)
+    idx_o, keep_o, rank_o = ls.voxel_indices(geo.reshape(-1, 3), res, start, dim)
+    got_rank = rank.numpy().astype(np.int64)
+    assert np.array_equal(got_rank >= 0, keep_o)
+    assert np.array_equal(got_rank[keep_o], rank_o[keep_o])
+    assert np.array_equal(idx.numpy().astype(np.int64)[keep_o], idx_o[keep_o])
+    # the reference's trunc-toward-zero band: some kept points sit in (-1, 0) cell units
+    assert keep_o.any()
+
+
+def test_voxel_index_special_values(sim):
+    grid, (res, start, dim) = _grid([-2.0, 2.0, 0.5], [-2.0, 2.0, 0.5], [-10.0, 10.0, 20.0])
+    origin = start - res / 2
+    pts = np.array([
+        [origin[0] - 0.25, 0.0, 0.0],      # in (-1, 0) cell units on x -> cell 0, kept
+        [origin[0] - 0.5, 0.0, 0.0],       # exactly -1 cell -> dropped
+        [origin[0] + 4.0, 0.0, 0.0],       # exactly nx cells -> dropped
+        [np.nan, 0.0, 0.0], [np.inf, 0.0, 0.0], [-np.inf, 0.0, 0.0], [0.0, 0.0, 1e30],
+        [0.0, 0.0, 0.0],
+    ], dtype=np.float32)
+    rank, _ = sim.voxel_index(torch.from_numpy(pts), grid)
+    _, keep, rank_o = ls.voxel_indices(pts, res, start, dim)
+    assert keep.tolist() == [True, False, False, False, False, False, False, True]
+    got = rank.numpy()
+    assert np.array_equal(got >= 0, keep)
+    assert np.array_equal(got[keep], rank_o[keep])
+
+
+@pytest.mark.parametrize('flags', [0, native.POOL_DETERMINISTIC])
+@pytest.mark.parametrize('tile', [0, 97])
+def test_voxel_pool_matches_oracle(sim, flags, tile):
+    frustum, intr, extr, lifted = _small_problem(2)
+    frames, n_cam, C, D, H, W = lifted.shape
+    geo = ls.get_geometry(frustum, intr.numpy(), extr.numpy())
+    grid, (res, start, dim) = _grid([-20.0, 20.0, 1.0], [-16.0, 16.0, 1.0], [-10.0, 10.0, 20.0])
+    # logical (f, n, d, h, w, c) strides of the encoder's native (f, n, C, D, H, W) layout
+    st = lifted.stride()
+    strides = (st[0], st[1], st[3], st[4], st[5], st[2])
+    out = sim.voxel_pool(lifted, strides, torch.from_numpy(geo), frames, n_cam, D, H, W, C, grid,
+                         tile_voxels=tile, flags=flags)
+    for f in range(frames):
+        pts = ls.lifted_to_points(lifted[f].numpy())
+        exact = ls.voxel_pool_exact(pts, geo[f].reshape(-1, 3), res, start, dim)
+        ref = ls.voxel_pool_reference(pts, geo[f].reshape(-1, 3), res, start, dim)
+        assert np.abs(out[f].numpy() - exact).max() < 5e-6
+        assert np.abs(out[f].numpy() - ref).max() < 1e-4
+        assert ((out[f].numpy() != 0) == (exact != 0)).all() or np.abs(exact[(out[f].numpy() != 0) != (exact != 0)]).max() < 1e-6
+
+
+def test_voxel_pool_point_major_layout_and_mixed_columns(sim):
+    """A rolled camera makes columns cross voxels (the slow, per-point branch); x given point-major."""
+    frustum, intr, extr, lifted = _small_problem(3, n_cam=2, frames=1)
+    roll = torch.tensor([[0.0, -1.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0], [0.0, 0.0, 1.0, 0.0], [0.0, 0.0, 0.0, 1.0]])
+    extr = extr.clone()
+    extr[:, 0] = extr[:, 0] @ roll        # camera 0 rotated 90 degrees about its optical axis
+    frames, n_cam, C, D, H, W = lifted.shape
+    geo = ls.get_geometry(frustum, intr.numpy(), extr.numpy())
+    grid, (res, start, dim) = _grid([-20.0, 20.0, 0.5], [-20.0, 20.0, 0.5], [-10.0, 10.0, 20.0])
+    x_pm = lifted.permute(0, 1, 3, 4, 5, 2).contiguous()      # (f, n, d, h, w, c) physically
+    out = sim.voxel_pool(x_pm, x_pm.stride(), torch.from_numpy(geo), frames, n_cam, D, H, W, C, grid)
+    pts = ls.lifted_to_points(lifted[0].numpy())
+    exact = ls.voxel_pool_exact(pts, geo[0].reshape(-1, 3), res, start, dim)
+    assert np.abs(out[0].numpy() - exact).max() < 5e-6
+
+
+def test_voxel_pool_empty_and_single_voxel(sim):
+    frustum, intr, extr, lifted = _small_problem(4, frames=1)
+    frames, n_cam, C, D, H, W = lifted.shape
+    geo = ls.get_geometry(frustum, intr.numpy(), extr.numpy())
+    st = lifted.stride()
+    strides = (st[0], st[1], st[3], st[4], st[5], st[2])
+    # grid far away from every point: all zeros
+    grid, _ = _grid([500.0, 510.0, 1.0], [500.0, 510.0, 1.0], [-10.0, 10.0, 20.0])
+    out = sim.voxel_pool(lifted, strides, torch.from_numpy(geo), frames, n_cam, D, H, W, C, grid)
+    assert out.abs().max() == 0
+    # one huge voxel swallowing everything: every channel sums all points
+    grid, (res, start, dim) = _grid([-1000.0, 1000.0, 2000.0], [-1000.0, 1000.0, 2000.0], [-1000.0, 1000.0, 2000.0])
+    out = sim.voxel_pool(lifted, strides, torch.from_numpy(geo), frames, n_cam, D, H, W, C, grid)
+    want = lifted[0].double().sum(dim=(0, 2, 3, 4))
+    assert torch.allclose(out[0, :, 0, 0].double(), want, atol=1e-4)
+
+
+def test_voxel_pool_rejects_multiple_z_cells(sim):
+    frustum, intr, extr, lifted = _small_problem(5, frames=1)
+    frames, n_cam, C, D, H, W = lifted.shape
+    geo = ls.get_geometry(frustum, intr.numpy(), extr.numpy())
+    grid, _ = _grid([-20.0, 20.0, 1.0], [-20.0, 20.0, 1.0], [-10.0, 10.0, 10.0])
+    st = lifted.stride()
+    with pytest.raises(native.NativeError, match='one z cell'):
+        sim.voxel_pool(lifted, (st[0], st[1], st[3], st[4], st[5], st[2]), torch.from_numpy(geo),
+                       frames, n_cam, D, H, W, C, grid)
+
+
+def test_fused_lift_splat_matches_unfused(sim):
+    frustum, intr, extr, _ = _small_problem(6)
+    frames, n_cam, D, H, W, C = 2, 2, 5, 6, 10, 4
+    gen = torch.Generator().manual_seed(7)
+    logits = torch.randn(frames * n_cam, D, H, W, generator=gen)
+    feats = torch.randn(frames * n_cam, C, H, W, generator=gen)
+    prob = sim.depth_softmax(logits)
+    assert torch.allclose(prob, logits.softmax(dim=1), atol=1e-6)
+    geo = ls.get_geometry(frustum, intr.numpy(), extr.numpy())
+    grid, (res, start, dim) = _grid([-20.0, 20.0, 1.0], [-16.0, 16.0, 1.0], [-10.0, 10.0, 20.0])
+    out = sim.lift_splat(prob, feats, torch.from_numpy(geo), frames, n_cam, D, H, W, C, grid)
+    lifted = (prob.unsqueeze(1) * feats.unsqueeze(2)).view(frames, n_cam, C, D, H, W)
+    for f in range(frames):
+        pts = ls.lifted_to_points(lifted[f].numpy())
+        exact = ls.voxel_pool_exact(pts, geo[f].reshape(-1, 3), res, start, dim)
+        assert np.abs(out[f].numpy() - exact).max() < 5e-6
