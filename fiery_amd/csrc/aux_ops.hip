@@ -9,14 +9,15 @@ namespace {
 constexpr int kMeanChunks = 64;
 
 // stage 1: grid (kMeanChunks, n_img); 256 threads = 4 pixel lanes x 64 channel lanes
-__global__ __launch_bounds__(256) void k_mean_partial(const float* __restrict__ in, int ld, long long img_stride, int HW,
-                                                      int C, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void k_mean_partial(const float* __restrict__ in, int ld, long long outer_stride,
+                                                      long long inner_stride, int n_inner, int HW, int C,
+                                                      float* __restrict__ partial) {
     __shared__ float red[256];
     const int chunk = blockIdx.x, img = blockIdx.y;
     const int per = (HW + kMeanChunks - 1) / kMeanChunks;
     const int p0 = chunk * per, p1 = min(HW, p0 + per);
     const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-    const float* base = in + static_cast<long long>(img) * img_stride;
+    const float* base = in + (img / n_inner) * outer_stride + (img % n_inner) * inner_stride;
     for (int c0 = 0; c0 < C; c0 += 64) {
         const int c = c0 + cl;
         float s = 0.f;
@@ -47,8 +48,9 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 __global__ void k_rowwise_dense(const float* __restrict__ v, int v_ld, int rows, int n_in, const float* __restrict__ W,
-                                int w_ld, int w_col0, int n_out, const float* __restrict__ scale,
-                                const float* __restrict__ shift, int act, int accumulate, float* __restrict__ y, int y_ld) {
+                                int w_ld, int w_col0, int n_out, float w_mul, const float* __restrict__ scale,
+                                const float* __restrict__ shift, int act, int accumulate, float lo, float hi,
+                                float* __restrict__ y, int y_ld) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * n_out) return;
     const int r = i / n_out, o = i - r * n_out;
@@ -57,12 +59,21 @@ __global__ void k_rowwise_dense(const float* __restrict__ v, int v_ld, int rows,
     float acc = 0.f;
     for (int j = 0; j < n_in; ++j) acc = fmaf(wr[j], vr[j], acc);
     float* dst = y + static_cast<long long>(r) * y_ld + o;
-    if (accumulate) {
-        *dst += acc;
-    } else {
-        const float sc = scale ? scale[o] : 1.f, sh = shift ? shift[o] : 0.f;
-        *dst = apply_act(fmaf(acc, sc, sh), act);
-    }
+    acc *= w_mul;
+    if (accumulate) acc += *dst;
+    const float sc = scale ? scale[o] : 1.f, sh = shift ? shift[o] : 0.f;
+    *dst = fminf(fmaxf(apply_act(fmaf(acc, sc, sh), act), lo), hi);
+}
+
+__global__ void k_latent_sample(const float* __restrict__ mu, const float* __restrict__ log_sigma,
+                                const float* __restrict__ noise, int ld, int rows, int n, float* __restrict__ sample,
+                                int sample_ld) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * n) return;
+    const int r = i / n, j = i - r * n;
+    const float eps = noise ? noise[static_cast<long long>(r) * ld + j] : 0.f;
+    sample[static_cast<long long>(r) * sample_ld + j] =
+        mu[static_cast<long long>(r) * ld + j] + expf(log_sigma[static_cast<long long>(r) * ld + j]) * eps;
 }
 
 __global__ void k_maxpool2x2(const float* __restrict__ in, int in_ld, int H, int W, int C, int Ho, int Wo,
@@ -165,26 +176,37 @@ __global__ __launch_bounds__(256) void k_nhwc_to_nchw(const float* __restrict__ 
 
 using namespace fiery;
 
-extern "C" int fiery_spatial_mean(const float* in, int in_ld, int64_t in_img_stride, int n_img, int HW, int C, float* out,
-                                  float* workspace, fiery_stream_t stream) {
-    FIERY_REQUIRE(in && out && workspace && n_img > 0 && HW > 0 && C > 0 && in_ld >= C, "spatial_mean: bad argument");
+extern "C" int fiery_spatial_mean(const float* in, int in_ld, int64_t outer_stride, int n_outer, int64_t inner_stride,
+                                  int n_inner, int n_pixels, int C, float* out, float* workspace, fiery_stream_t stream) {
+    FIERY_REQUIRE(in && out && workspace, "spatial_mean: null pointer");
+    FIERY_REQUIRE(n_outer > 0 && n_inner > 0 && n_pixels > 0 && C > 0 && in_ld >= C, "spatial_mean: bad shape");
+    const int n_img = n_outer * n_inner;
     hipLaunchKernelGGL(k_mean_partial, dim3(kMeanChunks, n_img), dim3(256), 0, as_stream(stream), in, in_ld,
-                       static_cast<long long>(in_img_stride), HW, C, workspace);
+                       static_cast<long long>(outer_stride), static_cast<long long>(inner_stride), n_inner, n_pixels, C,
+                       workspace);
     int rc = check_launch("spatial_mean(partial)");
     if (rc) return rc;
     hipLaunchKernelGGL(k_mean_final, dim3(ceil_div(n_img * C, 256)), dim3(256), 0, as_stream(stream), workspace, n_img, C,
-                       1.0f / static_cast<float>(HW), out);
+                       1.0f / static_cast<float>(n_pixels), out);
     return check_launch("spatial_mean(final)");
 }
 
 extern "C" int fiery_rowwise_dense(const float* v, int v_ld, int rows, int n_in, const float* W, int w_ld, int w_col0,
-                                   int n_out, const float* scale, const float* shift, int act, int accumulate, float* y,
-                                   int y_ld, fiery_stream_t stream) {
+                                   int n_out, float w_mul, const float* scale, const float* shift, int act, int accumulate,
+                                   float lo, float hi, float* y, int y_ld, fiery_stream_t stream) {
     FIERY_REQUIRE(v && W && y && rows > 0 && n_in > 0 && n_out > 0, "rowwise_dense: bad argument");
     FIERY_REQUIRE(w_col0 >= 0 && w_col0 + n_in <= w_ld && v_ld >= n_in && y_ld >= n_out, "rowwise_dense: bad strides");
     hipLaunchKernelGGL(k_rowwise_dense, dim3(ceil_div(rows * n_out, 128)), dim3(128), 0, as_stream(stream), v, v_ld, rows,
-                       n_in, W, w_ld, w_col0, n_out, scale, shift, act, accumulate, y, y_ld);
+                       n_in, W, w_ld, w_col0, n_out, w_mul, scale, shift, act, accumulate, lo, hi, y, y_ld);
     return check_launch("rowwise_dense");
+}
+
+extern "C" int fiery_latent_sample(const float* mu, const float* log_sigma, const float* noise, int ld, int rows, int n,
+                                   float* sample, int sample_ld, fiery_stream_t stream) {
+    FIERY_REQUIRE(mu && log_sigma && sample && rows > 0 && n > 0 && ld >= n && sample_ld >= n, "latent_sample: bad argument");
+    hipLaunchKernelGGL(k_latent_sample, dim3(ceil_div(rows * n, 128)), dim3(128), 0, as_stream(stream), mu, log_sigma, noise,
+                       ld, rows, n, sample, sample_ld);
+    return check_launch("latent_sample");
 }
 
 extern "C" int fiery_maxpool2x2_nhwc(const float* in, int in_ld, int n_img, int H, int W, int C, float* out, int out_ld,

@@ -1,0 +1,546 @@
+"""Execution plan of the camera-to-BEV hot path on libfiery_hip.so.
+
+`BevEngine` turns the weight holders of `fiery_amd.modules` into packed kernel operands once
+(BatchNorm folded, 1x1 siblings fused, concatenations replaced by channel placement) and then replays
+the reference's inference data flow (fiery/models/fiery.py:130-191) as a fixed list of kernel launches
+on the caller's HIP stream:
+
+  geometry -> voxel pooling -> ego-warp (+NCHW->NHWC) -> temporal blocks -> present/future distribution
+  -> SpatialGRU future prediction -> decoder -> heads (NHWC->NCHW)
+
+Work the reference computes and then discards is not computed: `TemporalModel` returns only its last
+time step (fiery/models/temporal_model.py:52), so block j only evaluates output frames >= j+1.
+Every intermediate lives in pixel-major (NHWC) buffers owned by this object; the library itself holds
+no device memory.  Inference (`model.eval()`) only - the backward kernels are a later row of the scope
+table.
+"""
+import torch
+import torch.nn as nn
+
+from . import native
+from .ops import Buf, ConvOp, fold_bn, identity_chan_map, round_up
+
+RELU, NONE, SIGMOID = native.ACT_RELU, native.ACT_NONE, native.ACT_SIGMOID
+
+
+def _w2d(conv):
+    """(Cout, Cin) matrix of a 1x1(x1) convolution."""
+    return conv.weight.detach().float().reshape(conv.weight.shape[0], conv.weight.shape[1])
+
+
+class _Bottleneck:
+    """fiery/layers/convolutions.py:64-168 as three (four with a projected skip) fused convolutions."""
+
+    def __init__(self, eng, mod, in_split=None):
+        lib, dev = eng.lib, eng.device
+        L = mod.layers
+        cin, mid, cout = mod.in_channels, mod.mid_channels, mod.out_channels
+        self.cin, self.mid, self.cout, self.down = cin, mid, cout, mod.downsample
+        if in_split is None:
+            in_split = (cin, 0)
+        c0, c1 = in_split
+        self.in_split = in_split
+        p0 = round_up(c0, 8)
+        cmap = identity_chan_map(c0) + identity_chan_map(c1, offset=p0)
+        units = (p0 // 8, round_up(c1, 8) // 8)
+        sc, sh = fold_bn(L.abn_down_project[0], mid)
+        self.conv1 = ConvOp(lib, L.conv_down_project.weight, cmap, units, sc, sh, dev, act=RELU)
+        sc, sh = fold_bn(L.abn[0], mid)
+        self.conv2 = ConvOp(lib, L.conv.weight, identity_chan_map(mid), (round_up(mid, 8) // 8, 0), sc, sh, dev,
+                            stride=2 if self.down else 1, act=RELU)
+        sc, sh = fold_bn(L.abn_up_project[0], cout)
+        self.conv3 = ConvOp(lib, L.conv_up_project.weight, identity_chan_map(mid), (round_up(mid, 8) // 8, 0), sc, sh,
+                            dev, act=RELU)
+        self.skip = None
+        if mod.projection is not None:
+            sc, sh = fold_bn(mod.projection.bn_skip_proj, cout)
+            self.skip = ConvOp(lib, mod.projection.conv_skip_proj.weight, identity_chan_map(cin),
+                               (round_up(cin, 8) // 8, 0), sc, sh, dev)
+
+    def out_hw(self, H, W):
+        return ((H + 1) // 2, (W + 1) // 2) if self.down else (H, W)
+
+    def run(self, eng, srcs, out, scratch):
+        """srcs: one Buf, or two for a split input; scratch: dict name -> Buf factory results."""
+        x = srcs[0]
+        n, H, W = x.n_img, x.H, x.W
+        Ho, Wo = self.out_hw(H, W)
+        t1 = scratch('bn_t1', n, H, W, self.mid)
+        self.conv1(list(srcs), t1)
+        t2 = scratch('bn_t2', n, Ho, Wo, self.mid)
+        self.conv2([t1], t2)
+        if self.skip is None:
+            assert len(srcs) == 1
+            self.conv3([t2], out, res=x)
+            return
+        if self.down:
+            pooled = scratch('bn_pool', n, Ho, Wo, self.cin)
+            off = 0
+            for s, c in zip(srcs, self.in_split):
+                if c:
+                    eng.lib.maxpool2x2(s, s.ld, n, H, W, s.C, pooled.slice(off, s.C), pooled.ld)
+                    off += s.C
+            skip_in = pooled
+        else:
+            assert len(srcs) == 1
+            skip_in = x
+        s2 = scratch('bn_skip', n, Ho, Wo, self.cout)
+        self.skip([skip_in], s2)
+        self.conv3([t2], out, res=s2)
+
+
+class _TemporalBlock:
+    """fiery/layers/temporal.py:218-281 for the output frames that are still alive downstream."""
+
+    def __init__(self, eng, tb, ego_channels):
+        lib, dev = eng.lib, eng.device
+        self.cin, self.cout, self.half = tb.in_channels, tb.out_channels, tb.half_channels
+        self.ego = ego_channels
+        self.cf = self.cin - ego_channels                     # channels that really vary in space
+        hp = self.hp = round_up(self.half, 8)
+        cf_pad = round_up(self.cf, 8)
+        paths = tb.convolution_paths
+        firsts = [paths[0][0], paths[1][0], paths[2]]
+        # three sibling 1x1x1 convolutions as one GEMM; each path's channels start on an 8-aligned column
+        wf = torch.zeros(3 * hp, self.cin)
+        sc = torch.zeros(3 * hp)
+        sh = torch.zeros(3 * hp)
+        for i, blk in enumerate(firsts):
+            wf[i * hp:i * hp + self.half] = _w2d(blk.conv).cpu()
+            s_, b_ = fold_bn(blk.norm, self.half)
+            sc[i * hp:i * hp + self.half], sh[i * hp:i * hp + self.half] = s_, b_
+        self.fused = ConvOp(lib, wf[:, :self.cf].reshape(3 * hp, self.cf, 1, 1), identity_chan_map(self.cf),
+                            (cf_pad // 8, 0), sc, sh, dev, act=RELU)
+        self.fused_ego_w = wf[:, self.cf:].contiguous().to(dev) if ego_channels else None
+        self.causal = []
+        for i in range(2):
+            cc = paths[i][1]
+            s_, b_ = fold_bn(cc.norm, self.half)
+            self.causal.append(ConvOp(lib, cc.conv.weight, identity_chan_map(self.half), (hp // 8, 0), s_, b_, dev,
+                                      pad=((cc.kernel_size[1] - 1) // 2, (cc.kernel_size[2] - 1) // 2), act=RELU))
+        agg = tb.aggregation[0]
+        wagg = _w2d(agg.conv).cpu()
+        cmap = ([i for i in range(self.half)] + [hp + i for i in range(self.half)] +
+                [2 * hp + i for i in range(self.half)])
+        s_, b_ = fold_bn(agg.norm, self.cout)
+        self.agg = ConvOp(lib, wagg[:, :3 * self.half].reshape(self.cout, 3 * self.half, 1, 1), cmap,
+                          (2 * hp // 8, hp // 8), s_, b_, dev, act=RELU)
+        self.pool = None
+        if tb.use_pyramid_pooling:
+            red = tb.reduction_channels
+            pconv = tb.pyramid_pooling.features[0].conv_bn_relu
+            s_, b_ = fold_bn(pconv.norm, red)
+            self.pool = dict(red=red, w=_w2d(pconv.conv).contiguous().to(dev), scale=s_.to(dev), shift=b_.to(dev),
+                             wagg=wagg[:, 3 * self.half:].contiguous().to(dev))
+        self.proj = None
+        if tb.projection is not None:
+            wp = _w2d(tb.projection[0]).cpu()
+            s_, b_ = fold_bn(tb.projection[1], self.cout)
+            self.proj = ConvOp(lib, wp[:, :self.cf].reshape(self.cout, self.cf, 1, 1), identity_chan_map(self.cf),
+                               (cf_pad // 8, 0), s_, b_, dev)
+            self.proj_ego_w = wp[:, self.cf:].contiguous().to(dev) if ego_channels else None
+
+    def run(self, eng, xin, t_in0, ego_in, B, S, tag):
+        """xin: frames t >= t_in0 of every batch element, images ordered (b, t).  Returns frames >= t_in0 + 1."""
+        lib, dev = eng.lib, eng.device
+        H, W = xin.H, xin.W
+        T_in = S - t_in0
+        T_out = T_in - 1
+        t_out0 = t_in0 + 1
+        hw_ld = H * W * xin.ld
+        hp = self.hp
+        # -- 1x1x1 siblings on every input frame
+        P = eng.buf(tag + 'P', B * T_in, H, W, 3 * hp)
+        bias = None
+        if self.ego:
+            bias = eng.vec(tag + 'fbias', B * T_in, self.fused.cout_pad)
+            rows = ego_in[:, t_in0:].reshape(B * T_in, self.ego).contiguous()
+            lib.rowwise_dense(rows, self.ego, B * T_in, self.ego, self.fused_ego_w, self.ego, 0, 3 * hp, None, None, NONE,
+                              False, bias, self.fused.cout_pad)
+        self.fused([xin], P, img_bias=bias)
+        # -- the two causal paths, output frames only
+        Q = eng.buf(tag + 'Q', B * T_out, H, W, 2 * hp)
+        p_ld = H * W * P.ld
+        for i, op in enumerate(self.causal):
+            op([(P.slice(i * hp, hp), T_in * p_ld, p_ld)], Q.slice(i * hp, hp), T_out=T_out, t_out0=t_out0, t_in_add=1)
+        # -- pyramid pooling branch: a per-frame vector, folded into the aggregation as a bias
+        agg_bias = None
+        if self.pool is not None:
+            red = self.pool['red']
+            mean = eng.vec(tag + 'mean', B * T_out, self.cf)
+            ws = eng.vec(tag + 'meanws', B * T_out, self.cf * 64)
+            # (2,H,W) average pooling with stride (1,H,W) and one frame of left padding that is excluded
+            # from the count: output frame t averages input frames t-1 and t (layers/temporal.py:186-191);
+            # t >= 1 here, so both exist: one pass over two adjacent frames of the (b, t) buffer.
+            lib.spatial_mean(xin, xin.ld, T_in * hw_ld, B, hw_ld, T_out, 2 * H * W, self.cf, mean, ws)
+            z = eng.vec(tag + 'z', B * T_out, round_up(red, 8))
+            last = not self.ego
+            lib.rowwise_dense(mean, mean.shape[1], B * T_out, self.cf, self.pool['w'], self.cin, 0, red,
+                              self.pool['scale'] if last else None, self.pool['shift'] if last else None,
+                              RELU if last else NONE, False, z, z.shape[1])
+            if self.ego:
+                # the ego-pose channels are constant over a frame: their window mean is the mean of two rows
+                prev = ego_in[:, t_out0 - 1:S - 1].reshape(B * T_out, self.ego).contiguous()
+                cur = ego_in[:, t_out0:].reshape(B * T_out, self.ego).contiguous()
+                lib.rowwise_dense(prev, self.ego, B * T_out, self.ego, self.pool['w'], self.cin, self.cf, red, None, None,
+                                  NONE, True, z, z.shape[1], w_mul=0.5)
+                lib.rowwise_dense(cur, self.ego, B * T_out, self.ego, self.pool['w'], self.cin, self.cf, red,
+                                  self.pool['scale'], self.pool['shift'], RELU, True, z, z.shape[1], w_mul=0.5)
+            agg_bias = eng.vec(tag + 'abias', B * T_out, self.agg.cout_pad)
+            lib.rowwise_dense(z, z.shape[1], B * T_out, red, self.pool['wagg'], red, 0, self.cout, None, None, NONE, False,
+                              agg_bias, self.agg.cout_pad)
+        # -- skip connection + aggregation (x + relu(bn(agg)), layers/temporal.py:276-280)
+        out = eng.buf(tag + 'O', B * T_out, H, W, self.cout)
+        q_ld = H * W * Q.ld
+        if self.proj is not None:
+            R = eng.buf(tag + 'R', B * T_out, H, W, self.cout)
+            pbias = None
+            if self.ego:
+                pbias = eng.vec(tag + 'pbias', B * T_out, self.proj.cout_pad)
+                cur = ego_in[:, t_out0:].reshape(B * T_out, self.ego).contiguous()
+                lib.rowwise_dense(cur, self.ego, B * T_out, self.ego, self.proj_ego_w, self.ego, 0, self.cout, None, None,
+                                  NONE, False, pbias, self.proj.cout_pad)
+            x_from_1 = Buf(xin.tensor, B * T_out, H, W, xin.C, xin.ld, xin.img_stride, xin.base_off + hw_ld)
+            self.proj([(x_from_1, T_in * hw_ld, hw_ld)], R, img_bias=pbias, T_out=T_out, t_out0=t_out0, t_in_add=0)
+            groups = [(0, B, R)]                               # one launch over every (b, t)
+        elif T_out == 1:
+            # identity skip, one live frame per batch element: a strided view of the input does it
+            groups = [(0, B, Buf(xin.tensor, B, H, W, xin.C, xin.ld, T_in * hw_ld, xin.base_off + hw_ld))]
+        else:
+            # identity skip with several live frames: the input's (b, t) strides differ from the output's
+            groups = [(b, 1, Buf(xin.tensor, T_out, H, W, xin.C, xin.ld, hw_ld, xin.base_off + (b * T_in + 1) * hw_ld))
+                      for b in range(B)]
+        for b0, nb, res in groups:
+            n_o = nb * T_out
+            q = Q.images(b0 * T_out, n_o)
+            p2 = Buf(P.tensor, n_o, H, W, hp, P.ld, P.img_stride, P.base_off + (b0 * T_in + 1) * p_ld + 2 * hp)
+            self.agg([(q, T_out * q_ld, q_ld), (p2, T_in * p_ld, p_ld)], out.images(b0 * T_out, n_o), res=res,
+                     img_bias=agg_bias[b0 * T_out:b0 * T_out + n_o] if agg_bias is not None else None,
+                     T_out=T_out, t_out0=t_out0, t_in_add=0)
+        return out
+
+
+class _Gru:
+    """fiery/layers/temporal.py:10-62: update|reset as one N=2h GEMM, gate arithmetic in the epilogues."""
+
+    def __init__(self, eng, g):
+        lib, dev = eng.lib, eng.device
+        cx, ch = g.input_size, g.hidden_size
+        assert ch % 16 == 0, 'hidden size must be a multiple of 16 for the fused gate GEMM'
+        self.cx, self.ch = cx, ch
+        cxp = round_up(cx, 8)
+        cmap = identity_chan_map(cx) + identity_chan_map(ch, offset=cxp)
+        units = (cxp // 8, ch // 8)
+        wg = torch.cat([g.conv_update.weight.detach(), g.conv_reset.weight.detach()], 0)
+        bg = torch.cat([g.conv_update.bias.detach(), g.conv_reset.bias.detach()], 0).float().cpu() + g.gru_bias_init
+        self.gates = ConvOp(lib, wg, cmap, units, torch.ones(2 * ch), bg, dev, epi=native.EPI_GRU_GATES)
+        sc, sh = fold_bn(g.conv_state_tilde.norm, ch)
+        self.tilde = ConvOp(lib, g.conv_state_tilde.conv.weight, cmap, units, sc, sh, dev, act=RELU,
+                            epi=native.EPI_GRU_OUT)
+
+
+class BevEngine:
+    def __init__(self, model, lib, device):
+        self.m, self.lib, self.device = model, lib, torch.device(device)
+        self._bufs = {}
+        cfg = model.cfg
+        self.rf, self.nf, self.latent = model.receptive_field, model.n_future, model.latent_dim
+        self.C = model.encoder_out_channels
+        self.egopose = bool(cfg.MODEL.TEMPORAL_MODEL.INPUT_EGOPOSE)
+        self.probabilistic = bool(cfg.PROBABILISTIC.ENABLED) and self.nf > 0
+        res = model.bev_resolution.detach().float().cpu().numpy()
+        start = model.bev_start_position.detach().float().cpu().numpy()
+        dim = model.bev_dimension.detach().cpu().numpy()
+        origin = (start - res / res.dtype.type(2.0)).astype('float32')        # fp32, as fiery.py:236 evaluates it
+        self.grid = native.make_grid(origin, res, dim)
+        self.X, self.Y = int(dim[0]), int(dim[1])
+        self.extent = model.spatial_extent
+        self.frustum = model.frustum.detach().float().contiguous().to(self.device)
+        self.pool_tile = 0
+        self.pool_flags = 0
+        self._build()
+
+    # -- plan ---------------------------------------------------------------------------------------
+    def _build(self):
+        m, dev, lib = self.m, self.device, self.lib
+        # temporal model
+        self.temporal = []
+        self.temporal_identity = not hasattr(m.temporal_model, 'model')
+        if not self.temporal_identity:
+            if any(not hasattr(s, 'convolution_paths') for s in m.temporal_model.model):
+                raise NotImplementedError('MODEL.TEMPORAL_MODEL.INBETWEEN_LAYERS > 0 is not supported by the HIP engine yet')
+            for j, tb in enumerate(m.temporal_model.model):
+                self.temporal.append(_TemporalBlock(self, tb, 6 if (self.egopose and j == 0) else 0))
+        elif self.egopose:
+            raise NotImplementedError('identity temporal model with INPUT_EGOPOSE is not supported by the HIP engine yet')
+        state_c = m.future_pred_in_channels
+        self.state_c = state_c
+        # distributions
+        self.present = self.future_dist = None
+        if self.probabilistic:
+            self.present = self._distribution_ops(m.present_distribution, (state_c, 0))
+            self.future_dist = self._distribution_ops(m.future_distribution,
+                                                      (state_c, self.nf * m.cfg.PROBABILISTIC.FUTURE_DIM))
+        # future prediction
+        if self.nf > 0:
+            fp = m.future_prediction
+            self.grus = [_Gru(self, g) for g in fp.spatial_grus]
+            self.res_blocks = [[_Bottleneck(self, b) for b in seq] for seq in fp.res_blocks]
+        # decoder
+        d = m.decoder
+        sc, sh = fold_bn(d.bn1, 64)
+        cin = d.in_channels
+        self.dec_first = ConvOp(lib, d.first_conv.weight, identity_chan_map(cin), (round_up(cin, 8) // 8, 0), sc, sh, dev,
+                                stride=2, act=RELU)
+        self.dec_layers = []
+        for layer in (d.layer1, d.layer2, d.layer3):
+            blocks = []
+            for blk in layer:
+                ci, co = blk.conv1.in_channels, blk.conv1.out_channels
+                s1, b1 = fold_bn(blk.bn1, co)
+                s2, b2 = fold_bn(blk.bn2, co)
+                ops = dict(conv1=ConvOp(lib, blk.conv1.weight, identity_chan_map(ci), (ci // 8, 0), s1, b1, dev,
+                                        stride=blk.stride, act=RELU),
+                           conv2=ConvOp(lib, blk.conv2.weight, identity_chan_map(co), (co // 8, 0), s2, b2, dev, act=RELU,
+                                        res_before_act=True),
+                           down=None, cout=co, stride=blk.stride)
+                if blk.downsample is not None:
+                    sd, bd = fold_bn(blk.downsample[1], co)
+                    ops['down'] = ConvOp(lib, blk.downsample[0].weight, identity_chan_map(ci), (ci // 8, 0), sd, bd, dev,
+                                         stride=blk.stride, pad=(0, 0))
+                blocks.append(ops)
+            self.dec_layers.append(blocks)
+        self.dec_ups = []
+        for up in (d.up3_skip, d.up2_skip, d.up1_skip):
+            conv, bn = up.upsample_layer[1], up.upsample_layer[2]
+            ci, co = conv.in_channels, conv.out_channels
+            sc, sh = fold_bn(bn, co)
+            # the 1x1 convolution and the BN scale commute with bilinear interpolation (its weights sum to
+            # one): run them at the low resolution, add the BN shift after upsampling
+            self.dec_ups.append(dict(conv=ConvOp(lib, conv.weight, identity_chan_map(ci), (ci // 8, 0), sc,
+                                                 torch.zeros(co), dev), shift=sh.to(dev), cout=co))
+        heads = [('segmentation', d.segmentation_head), ('instance_center', d.instance_center_head),
+                 ('instance_offset', d.instance_offset_head)]
+        if d.predict_future_flow:
+            heads.append(('instance_flow', d.instance_future_head))
+        self.head_names = [n for n, _ in heads]
+        wh = torch.cat([h[0].weight.detach() for _, h in heads], 0)
+        scs, shs = zip(*[fold_bn(h[1], cin) for _, h in heads])
+        self.heads_conv = ConvOp(lib, wh, identity_chan_map(cin), (round_up(cin, 8) // 8, 0), torch.cat(scs), torch.cat(shs),
+                                 dev, act=RELU)
+        self.heads_final = []
+        for i, (name, h) in enumerate(heads):
+            n_out = h[3].out_channels
+            self.heads_final.append(dict(name=name, w=_w2d(h[3]).contiguous().to(dev),
+                                         b=h[3].bias.detach().float().contiguous().to(dev), n_out=n_out,
+                                         sigmoid=len(h) > 4, c_off=i * cin))
+        self.head_c = cin
+
+    def _distribution_ops(self, dm, in_split):
+        blocks = []
+        split = in_split
+        for b in dm.encoder.model:
+            blocks.append(_Bottleneck(self, b, in_split=split))
+            split = None
+        conv = dm.last_conv[1]
+        return dict(blocks=blocks, w=_w2d(conv).contiguous().to(self.device),
+                    b=conv.bias.detach().float().contiguous().to(self.device),
+                    lo=float(dm.min_log_sigma), hi=float(dm.max_log_sigma), compress=dm.compress_dim)
+
+    # -- buffers ------------------------------------------------------------------------------------
+    def buf(self, name, n_img, H, W, C):
+        key = (name, n_img, H, W, round_up(C, 8))
+        b = self._bufs.get(key)
+        if b is None:
+            b = self._bufs[key] = Buf.alloc(n_img, H, W, C, self.device)
+        return b
+
+    def vec(self, name, rows, cols):
+        key = (name, rows, cols)
+        v = self._bufs.get(key)
+        if v is None:
+            v = self._bufs[key] = torch.zeros(rows, cols, dtype=torch.float32, device=self.device)
+        return v
+
+    def _scratch(self, prefix):
+        return lambda name, n, H, W, C: self.buf(prefix + name, n, H, W, C)
+
+    # -- stages -------------------------------------------------------------------------------------
+    def geometry(self, intrinsics, extrinsics):
+        """`get_geometry`: (F, n, 3, 3), (F, n, 4, 4) -> (F, n, D, fH, fW, 3)."""
+        f, n = intrinsics.shape[:2]
+        cam = self.lib.camera_matrices(intrinsics.reshape(-1, 3, 3).float().contiguous(),
+                                       extrinsics.reshape(-1, 4, 4).float().contiguous())
+        geo = self.lib.lift_geometry(self.frustum, cam)
+        return geo.view(f, n, *geo.shape[1:])
+
+    def pool(self, x, geometry):
+        """`projection_to_birds_eye_view`: x logical (F, n, D, h, w, C) of any strides -> (F, C, X, Y)."""
+        f, n, d, h, w, c = x.shape
+        ws = self._bufs.get(('poolws', f, n, d, h, w))
+        if ws is None:
+            ws = self._bufs[('poolws', f, n, d, h, w)] = self.lib.pool_workspace(f, n, d, h, w, x.device)
+        return self.lib.voxel_pool(x, x.stride(), geometry.contiguous(), f, n, d, h, w, c, self.grid, workspace=ws,
+                                   tile_voxels=self.pool_tile, flags=self.pool_flags)
+
+    def pool_fused(self, depth_logits, features, geometry):
+        """depth logits (F, n, D, h, w) + features (F, n, C, h, w) -> (F, C, X, Y) without the outer product."""
+        f, n, d, h, w = depth_logits.shape
+        c = features.shape[2]
+        prob = self.lib.depth_softmax(depth_logits.reshape(f * n, d, h, w).contiguous())
+        ws = self._bufs.get(('poolws', f, n, d, h, w))
+        if ws is None:
+            ws = self._bufs[('poolws', f, n, d, h, w)] = self.lib.pool_workspace(f, n, d, h, w, features.device)
+        return self.lib.lift_splat(prob, features.contiguous(), geometry.contiguous(), f, n, d, h, w, c, self.grid,
+                                   workspace=ws, tile_voxels=self.pool_tile, flags=self.pool_flags)
+
+    def _run_distribution(self, ops, srcs, tag):
+        lib = self.lib
+        x = list(srcs)
+        n = x[0].n_img
+        for i, blk in enumerate(ops['blocks']):
+            Ho, Wo = blk.out_hw(x[0].H, x[0].W)
+            out = self.buf(f'{tag}d{i}', n, Ho, Wo, blk.cout)
+            blk.run(self, x, out, self._scratch(f'{tag}d{i}'))
+            x = [out]
+        enc = x[0]
+        cd = ops['compress']
+        gap = self.vec(tag + 'gap', n, cd)
+        ws = self.vec(tag + 'gapws', n, cd * 64)
+        lib.spatial_mean(enc, enc.ld, enc.img_stride, n, 0, 1, enc.H * enc.W, cd, gap, ws)
+        L = self.latent
+        mu = torch.empty(n, 1, L, dtype=torch.float32, device=self.device)
+        log_sigma = torch.empty(n, 1, L, dtype=torch.float32, device=self.device)
+        lib.rowwise_dense(gap, gap.shape[1], n, cd, ops['w'], cd, 0, L, None, ops['b'], NONE, False, mu, L)
+        lib.rowwise_dense(gap, gap.shape[1], n, cd, ops['w'][L:], cd, 0, L, None, ops['b'][L:], NONE, False, log_sigma, L,
+                          lo=ops['lo'], hi=ops['hi'])
+        return mu, log_sigma
+
+    def bev_stack(self, bev, future_egomotion, future_distribution_inputs=None, noise=None):
+        """Everything after pooling.  bev: (B*S, C, X, Y) NCHW; future_egomotion (B, S, 6)."""
+        lib, dev = self.lib, self.device
+        S = self.rf
+        B = bev.shape[0] // S
+        H, W, C = self.X, self.Y, self.C
+        out = {}
+        ego = future_egomotion.float().contiguous()
+        # -- ego-warp + layout change ---------------------------------------------------------------
+        x0 = self.buf('x0', B * S, H, W, C)
+        theta = lib.warp_params(ego, self.extent)
+        identity = [(i % S) == S - 1 for i in range(B * S)]
+        lib.bev_warp_nchw_to_nhwc(bev.contiguous(), theta.view(B * S, 6), identity, x0.tensor, x0.ld, x0.img_stride)
+        # -- temporal model --------------------------------------------------------------------------
+        if self.temporal_identity:
+            present = x0.images(S - 1, B, step=S) if S > 1 else x0
+        else:
+            ego_in = None
+            if self.egopose:
+                ego_in = torch.cat([torch.zeros_like(ego[:, :1]), ego[:, :S - 1]], dim=1).contiguous()   # fiery.py:152-154
+            x = x0
+            for j, blk in enumerate(self.temporal):
+                x = blk.run(self, x, j, ego_in, B, S, f't{j}')
+            present = x                                   # (B images) = the last frame
+        # -- distributions ---------------------------------------------------------------------------
+        if self.nf > 0:
+            if self.probabilistic:
+                mu, log_sigma = self._run_distribution(self.present, [present], 'pd')
+                fmu = flog = None
+                if future_distribution_inputs is not None:
+                    lab = future_distribution_inputs[:, 1:].float().contiguous()
+                    lc = lab.shape[1] * lab.shape[2]
+                    labels = self.buf('labels', B, H, W, lc)
+                    lib.nchw_to_nhwc(lab.view(B, lc, H * W), B, lc, H * W, labels.tensor, labels.ld, labels.img_stride)
+                    fmu, flog = self._run_distribution(self.future_dist, [present, labels], 'fd')
+                out.update(present_mu=mu, present_log_sigma=log_sigma, future_mu=fmu, future_log_sigma=flog)
+                sample = self.vec('sample', B, self.latent)
+                nz = noise.float().contiguous().view(B, self.latent) if noise is not None else None
+                lib.latent_sample(mu, log_sigma, nz, self.latent, B, self.latent, sample, self.latent)
+                gx = self.buf('gru_x0', B, H, W, self.latent)
+                lib.broadcast(sample, self.latent, B, H * W, self.latent, gx.tensor, gx.ld, gx.img_stride)
+            else:
+                gx = self.buf('gru_x0', B, H, W, self.latent)       # zeros (fiery.py:175-176)
+            dec_in = self.buf('dec_in', B * (self.nf + 1), H, W, self.state_c)
+            self._future_prediction(gx, present, dec_in, B)
+            n_dec_t = self.nf + 1
+        else:
+            dec_in = present
+            n_dec_t = 1
+        out.update(self._decoder(dec_in, B, n_dec_t))
+        return out
+
+    def _future_prediction(self, gx, present, dec_in, B):
+        lib = self.lib
+        nf, H, W, ch = self.nf, present.H, present.W, self.state_c
+        # present state -> slot 0 of every batch element of the decoder input (plain copy)
+        dec_in.nhwc().view(B, nf + 1, H, W, -1)[:, 0].copy_(present.nhwc())
+        seq_in = None
+        n_blocks = len(self.grus)
+        for i, gru in enumerate(self.grus):
+            O = self.buf(f'gru{i}_O', B * nf, H, W, ch)
+            U = self.buf('gru_U', B, H, W, ch)
+            RH = self.buf('gru_RH', B, H, W, ch)
+            for t in range(nf):
+                x_t = gx if i == 0 else seq_in.images(t, B, step=nf)
+                h_t = present if t == 0 else O.images(t - 1, B, step=nf)
+                o_t = O.images(t, B, step=nf)
+                gru.gates([x_t, h_t], U, out2=RH, aux0=h_t)
+                gru.tilde([x_t, RH], o_t, aux0=U, aux1=h_t)
+            x = O
+            blocks = self.res_blocks[i]
+            for k, blk in enumerate(blocks):
+                last = (i == n_blocks - 1) and (k == len(blocks) - 1)
+                if not last:
+                    y = self.buf(f'res_{(k % 2)}', B * nf, H, W, ch)
+                    blk.run(self, [x], y, self._scratch('fp'))
+                    x = y
+                else:
+                    # the last convolution writes straight into frames 1.. of the decoder input, per batch element
+                    t1 = self.buf('fpbn_t1', B * nf, H, W, blk.mid)
+                    blk.conv1([x], t1)
+                    t2 = self.buf('fpbn_t2', B * nf, H, W, blk.mid)
+                    blk.conv2([t1], t2)
+                    for b in range(B):
+                        blk.conv3([t2.images(b * nf, nf)], dec_in.images(b * (nf + 1) + 1, nf), res=x.images(b * nf, nf))
+            seq_in = x
+        if not self.res_blocks[-1]:
+            dec_in.nhwc().view(B, nf + 1, H, W, -1)[:, 1:].copy_(seq_in.nhwc().view(B, nf, H, W, -1))
+
+    def _decoder(self, x, B, T):
+        lib = self.lib
+        n, H, W = x.n_img, x.H, x.W
+        skips = [x]
+        h1, w1 = self.dec_first.out_hw(H, W)
+        y = self.buf('dec_stem', n, h1, w1, 64)
+        self.dec_first([x], y)
+        for li, blocks in enumerate(self.dec_layers):
+            for bi, ops in enumerate(blocks):
+                ho, wo = ops['conv1'].out_hw(y.H, y.W)
+                t = self.buf(f'dec_l{li}_t', n, ho, wo, ops['cout'])
+                ops['conv1']([y], t)
+                ident = y
+                if ops['down'] is not None:
+                    ident = self.buf(f'dec_l{li}_ds', n, ho, wo, ops['cout'])
+                    ops['down']([y], ident)
+                o = self.buf(f'dec_l{li}_o{bi}', n, ho, wo, ops['cout'])
+                ops['conv2']([t], o, res=ident)
+                y = o
+            if li < 2:
+                skips.append(y)
+        for ui, up in enumerate(self.dec_ups):
+            skip = skips[2 - ui]
+            low = self.buf(f'dec_up{ui}_low', n, y.H, y.W, up['cout'])
+            up['conv']([y], low)
+            o = self.buf(f'dec_up{ui}', n, skip.H, skip.W, up['cout'])
+            lib.upsample2x_add(low, low.ld, n, low.H, low.W, up['cout'], up['shift'], skip, skip.ld, o, o.ld)
+            y = o
+        hb = self.buf('dec_heads', n, H, W, self.heads_conv.cout)
+        self.heads_conv([y], hb)
+        out = {}
+        for hd in self.heads_final:
+            res = torch.empty(n, hd['n_out'], H, W, dtype=torch.float32, device=self.device)
+            lib.heads_1x1_nchw(hb.slice(hd['c_off'], self.head_c), hb.ld, n, H * W, self.head_c, self.head_c,
+                               hd['w'], hd['b'], [0] * hd['n_out'], [hd['sigmoid']] * hd['n_out'], res)
+            out[hd['name']] = res.view(B, T, hd['n_out'], H, W)
+        if 'instance_flow' not in out:
+            out['instance_flow'] = None
+        return out

@@ -1,0 +1,260 @@
+"""`Fiery`: the drop-in boundary of the camera-to-BEV hot path.
+
+Same constructor, method names, argument meaning, return shapes, attributes and `state_dict` keys as
+the reference class (reference: fiery/models/fiery.py:13-339), so `trainer.py` / `evaluate.py` /
+`visualise.py` can import this class instead.  What differs is what runs underneath:
+
+* the image trunk (`encoder.backbone`, outside the hot-path scope) runs on stock PyTorch-ROCm ops;
+* everything from the lift head's outputs to the output dict runs on the hand-written gfx950 kernels
+  in libfiery_hip.so through `fiery_amd.engine.BevEngine`.  No ATen fallback exists for that part: if the
+  library is missing, or the model is on the CPU, or in training mode, the call raises.
+"""
+import torch
+import torch.nn as nn
+
+from . import native
+from .encoder import Encoder
+from .modules import (DecoderWeights, DistributionWeights, FuturePredictionWeights, TemporalIdentity,
+                      TemporalModelWeights, set_bn_momentum)
+
+
+def pack_sequence_dim(x):
+    """(B, S, ...) -> (B*S, ...)   reference: fiery/utils/network.py:5-7"""
+    b, s = x.shape[:2]
+    return x.view(b * s, *x.shape[2:])
+
+
+def unpack_sequence_dim(x, b, s):
+    """reference: fiery/utils/network.py:10-11"""
+    return x.view(b, s, *x.shape[1:])
+
+
+def calculate_birds_eye_view_parameters(x_bounds, y_bounds, z_bounds):
+    """`gen_dx_bx` (reference: fiery/utils/geometry.py:39-58): resolution, first cell centre, cell count
+    per axis; the count is a python-float quotient truncated by the long conversion."""
+    rows = (x_bounds, y_bounds, z_bounds)
+    bev_resolution = torch.tensor([row[2] for row in rows])
+    bev_start_position = torch.tensor([row[0] + row[2] / 2.0 for row in rows])
+    bev_dimension = torch.tensor([(row[1] - row[0]) / row[2] for row in rows], dtype=torch.long)
+    return bev_resolution, bev_start_position, bev_dimension
+
+
+class Fiery(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+
+        res, start, dim = calculate_birds_eye_view_parameters(cfg.LIFT.X_BOUND, cfg.LIFT.Y_BOUND, cfg.LIFT.Z_BOUND)
+        self.bev_resolution = nn.Parameter(res, requires_grad=False)
+        self.bev_start_position = nn.Parameter(start, requires_grad=False)
+        self.bev_dimension = nn.Parameter(dim, requires_grad=False)
+
+        self.encoder_downsample = cfg.MODEL.ENCODER.DOWNSAMPLE
+        self.encoder_out_channels = cfg.MODEL.ENCODER.OUT_CHANNELS
+        self.frustum = self.create_frustum()
+        self.depth_channels = self.frustum.shape[0]
+
+        if cfg.TIME_RECEPTIVE_FIELD == 1:
+            assert cfg.MODEL.TEMPORAL_MODEL.NAME == 'identity'
+        self.receptive_field = cfg.TIME_RECEPTIVE_FIELD
+        self.n_future = cfg.N_FUTURE_FRAMES
+        self.latent_dim = cfg.MODEL.DISTRIBUTION.LATENT_DIM
+        if cfg.MODEL.SUBSAMPLE:
+            assert cfg.DATASET.NAME == 'lyft'
+            self.receptive_field = 3
+            self.n_future = 5
+
+        self.spatial_extent = (cfg.LIFT.X_BOUND[1], cfg.LIFT.Y_BOUND[1])
+        self.bev_size = (self.bev_dimension[0].item(), self.bev_dimension[1].item())
+
+        self.encoder = Encoder(cfg=cfg.MODEL.ENCODER, D=self.depth_channels)
+
+        temporal_in = self.encoder_out_channels + (6 if cfg.MODEL.TEMPORAL_MODEL.INPUT_EGOPOSE else 0)
+        name = cfg.MODEL.TEMPORAL_MODEL.NAME
+        if name == 'identity':
+            self.temporal_model = TemporalIdentity(temporal_in, self.receptive_field)
+        elif name == 'temporal_block':
+            self.temporal_model = TemporalModelWeights(
+                temporal_in, self.receptive_field, input_shape=self.bev_size,
+                start_out_channels=cfg.MODEL.TEMPORAL_MODEL.START_OUT_CHANNELS,
+                extra_in_channels=cfg.MODEL.TEMPORAL_MODEL.EXTRA_IN_CHANNELS,
+                n_spatial_layers_between_temporal_layers=cfg.MODEL.TEMPORAL_MODEL.INBETWEEN_LAYERS,
+                use_pyramid_pooling=cfg.MODEL.TEMPORAL_MODEL.PYRAMID_POOLING)
+        else:
+            raise NotImplementedError(f'Temporal module {name}.')
+
+        self.future_pred_in_channels = self.temporal_model.out_channels
+        if self.n_future > 0:
+            if cfg.PROBABILISTIC.ENABLED:
+                lo, hi = cfg.MODEL.DISTRIBUTION.MIN_LOG_SIGMA, cfg.MODEL.DISTRIBUTION.MAX_LOG_SIGMA
+                self.present_distribution = DistributionWeights(self.future_pred_in_channels, self.latent_dim, lo, hi)
+                self.future_distribution = DistributionWeights(
+                    self.future_pred_in_channels + self.n_future * cfg.PROBABILISTIC.FUTURE_DIM, self.latent_dim, lo, hi)
+            self.future_prediction = FuturePredictionWeights(
+                in_channels=self.future_pred_in_channels, latent_dim=self.latent_dim,
+                n_gru_blocks=cfg.MODEL.FUTURE_PRED.N_GRU_BLOCKS, n_res_layers=cfg.MODEL.FUTURE_PRED.N_RES_LAYERS)
+
+        self.decoder = DecoderWeights(in_channels=self.future_pred_in_channels,
+                                      n_classes=len(cfg.SEMANTIC_SEG.WEIGHTS),
+                                      predict_future_flow=cfg.INSTANCE_FLOW.ENABLED)
+        set_bn_momentum(self, cfg.MODEL.BN_MOMENTUM)
+
+        self._engine = None
+        self._engine_key = None
+        self._lib = None          # tests substitute the CPU-simulated build of the same kernel sources
+
+    # ------------------------------------------------------------------------------------------------
+    def create_frustum(self):
+        """(D, fH, fW, 3) grid of (u, v, depth) in the image plane (reference: fiery.py:109-128)."""
+        h, w = self.cfg.IMAGE.FINAL_DIM
+        fh, fw = h // self.encoder_downsample, w // self.encoder_downsample
+        depth = torch.arange(*self.cfg.LIFT.D_BOUND, dtype=torch.float)
+        n_depth = depth.shape[0]
+        us = torch.linspace(0, w - 1, fw, dtype=torch.float).view(1, 1, fw).expand(n_depth, fh, fw)
+        vs = torch.linspace(0, h - 1, fh, dtype=torch.float).view(1, fh, 1).expand(n_depth, fh, fw)
+        ds = depth.view(-1, 1, 1).expand(n_depth, fh, fw)
+        return nn.Parameter(torch.stack((us, vs, ds), -1), requires_grad=False)
+
+    # -- engine management ----------------------------------------------------------------------------
+    def _params_version(self):
+        """Identity + in-place version of every tensor the kernel plan was built from (not the image trunk)."""
+        mods = [m for name, m in self.named_children() if name != 'encoder']
+        sig = [(p.data_ptr(), p._version) for p in self.parameters(recurse=False)]
+        for m in mods:
+            sig.extend((p.data_ptr(), p._version) for p in m.parameters())
+            sig.extend((b.data_ptr(), b._version) for b in m.buffers())
+        return tuple(sig)
+
+    def engine(self):
+        """The kernel plan for the current weights/device; rebuilt when either changes."""
+        device = self.frustum.device
+        lib = self._lib
+        if lib is None:
+            if device.type != 'cuda':
+                raise RuntimeError('fiery_amd.Fiery runs its BEV path on MI355X kernels only: move the model to a '
+                                   'HIP device (model.cuda()); there is no CPU fallback')
+            lib = native.get()
+        key = (str(device), id(lib), self._params_version())
+        if self._engine is None or self._engine_key != key:
+            from .engine import BevEngine
+            self._engine = BevEngine(self, lib, device)
+            self._engine_key = key
+        return self._engine
+
+    def refresh_engine(self):
+        self._engine = None
+
+    def _require_eval(self):
+        if self.training:
+            raise RuntimeError('fiery_amd.Fiery: the HIP path implements inference; call model.eval(). Training needs '
+                               'the backward kernels (SURVEY.md section 8f, rank 2), which are not built yet')
+
+    # -- reference method seams -------------------------------------------------------------------------
+    def get_geometry(self, intrinsics, extrinsics):
+        """(B, N, 3, 3), (B, N, 4, 4) -> (B, N, D, fH, fW, 3) ego-frame positions (reference: fiery.py:193-208)."""
+        return self.engine().geometry(intrinsics, extrinsics)
+
+    def encoder_forward(self, x):
+        """(b, n, c, h, w) images -> (b, n, D, fH, fW, C) lifted features as a permuted view
+        (reference: fiery.py:210-219)."""
+        b, n, c, h, w = x.shape
+        x = self.encoder(x.view(b * n, c, h, w))
+        x = x.view(b, n, *x.shape[1:])
+        return x.permute(0, 1, 3, 4, 5, 2)
+
+    def projection_to_birds_eye_view(self, x, geometry):
+        """`voxel_pooling` (reference: fiery.py:221-273): x (b, n, D, fH, fW, C), any strides, geometry
+        (b, n, D, fH, fW, 3) -> (b, C, X, Y)."""
+        if self.bev_dimension[2].item() != 1:
+            raise ValueError('projection_to_birds_eye_view needs a single z cell (reference: fiery.py:268-271)')
+        return self.engine().pool(x.float(), geometry.float())
+
+    def calculate_birds_eye_view_features(self, x, intrinsics, extrinsics):
+        """(B, S, n, c, h, w) images -> (B, S, C, X, Y) (reference: fiery.py:275-286).  The lift head's
+        depth distribution and features go straight into the fused lift-splat kernel."""
+        b, s, n, c, h, w = x.shape
+        geometry = self.get_geometry(pack_sequence_dim(intrinsics), pack_sequence_dim(extrinsics))
+        depth_logits, features = self.encoder.lift_head(x.view(b * s * n, c, h, w))
+        bev = self._pool_head_outputs(depth_logits, features, geometry, b * s, n)
+        return unpack_sequence_dim(bev, b, s)
+
+    def _pool_head_outputs(self, depth_logits, features, geometry, frames, n):
+        eng = self.engine()
+        fh, fw = features.shape[-2:]
+        feats = features.float().reshape(frames, n, -1, fh, fw)
+        if depth_logits is None:
+            # no depth distribution: the feature vector is repeated along the ray (encoder.py:101-102)
+            d = self.depth_channels
+            x = feats.unsqueeze(3).expand(frames, n, feats.shape[2], d, fh, fw).permute(0, 1, 3, 4, 5, 2)
+            return eng.pool(x, geometry)
+        return eng.pool_fused(depth_logits.float().reshape(frames, n, -1, fh, fw), feats, geometry)
+
+    def distribution_forward(self, present_features, future_distribution_inputs=None, noise=None):
+        """(b, 1, c, h, w) present state -> (sample broadcast to (b, 1, latent, h, w), distribution dict)
+        (reference: fiery.py:288-339, inference branch)."""
+        self._require_eval()
+        eng = self.engine()
+        b, s, c, h, w = present_features.shape
+        assert s == 1
+        from .ops import Buf
+        present = eng.buf('api_present', b, h, w, c)
+        eng.lib.nchw_to_nhwc(present_features.float().contiguous().view(b, c, h * w), b, c, h * w, present.tensor,
+                             present.ld, present.img_stride)
+        mu, log_sigma = eng._run_distribution(eng.present, [present], 'pd')
+        fmu = flog = None
+        if future_distribution_inputs is not None:
+            lab = future_distribution_inputs[:, 1:].float().contiguous()
+            lc = lab.shape[1] * lab.shape[2]
+            labels = eng.buf('labels', b, h, w, lc)
+            eng.lib.nchw_to_nhwc(lab.view(b, lc, h * w), b, lc, h * w, labels.tensor, labels.ld, labels.img_stride)
+            fmu, flog = eng._run_distribution(eng.future_dist, [present, labels], 'fd')
+        sample = torch.empty(b, self.latent_dim, dtype=torch.float32, device=mu.device)
+        nz = noise.float().contiguous().view(b, self.latent_dim) if noise is not None else None
+        eng.lib.latent_sample(mu, log_sigma, nz, self.latent_dim, b, self.latent_dim, sample, self.latent_dim)
+        sample = sample.view(b, s, self.latent_dim, 1, 1).expand(b, s, self.latent_dim, h, w)
+        return sample, {'present_mu': mu, 'present_log_sigma': log_sigma, 'future_mu': fmu, 'future_log_sigma': flog}
+
+    # -- hot path ------------------------------------------------------------------------------------------
+    def bev_forward(self, lifted, intrinsics, extrinsics, future_egomotion, future_distribution_inputs=None,
+                    noise=None, depth_logits=None, features=None):
+        """The hot path from the image encoder's outputs to the output dict.
+
+        Either `lifted` (B, S, n, C, D, fH, fW) - what `Encoder.forward` returns per frame and camera, the
+        operand of the reference's `projection_to_birds_eye_view` - or the lift head's two factors
+        `depth_logits` (B, S, n, D, fH, fW) and `features` (B, S, n, C, fH, fW) for the fused kernel.
+        """
+        self._require_eval()
+        eng = self.engine()
+        rf = self.receptive_field
+        intrinsics = intrinsics[:, :rf].contiguous()
+        extrinsics = extrinsics[:, :rf].contiguous()
+        ego = future_egomotion[:, :rf].contiguous()
+        b = intrinsics.shape[0]
+        n = intrinsics.shape[2]
+        geometry = eng.geometry(pack_sequence_dim(intrinsics), pack_sequence_dim(extrinsics))
+        if lifted is not None:
+            lifted = lifted[:, :rf]
+            x = lifted.reshape(b * rf, *lifted.shape[2:]).permute(0, 1, 3, 4, 5, 2)      # view: (F, n, D, h, w, C)
+            bev = eng.pool(x, geometry)
+        else:
+            dl = depth_logits[:, :rf].reshape(b * rf, n, *depth_logits.shape[3:])
+            ft = features[:, :rf].reshape(b * rf, n, *features.shape[3:])
+            bev = eng.pool_fused(dl, ft, geometry)
+        return eng.bev_stack(bev, ego, future_distribution_inputs, noise)
+
+    def forward(self, image, intrinsics, extrinsics, future_egomotion, future_distribution_inputs=None, noise=None):
+        """reference: fiery.py:130-191.  image (B, S_total, n, 3, H, W); intrinsics (B, S_total, n, 3, 3);
+        extrinsics (B, S_total, n, 4, 4); future_egomotion (B, S_total, 6); labels (B, 1+n_future, 6, X, Y);
+        noise (B, 1, latent)."""
+        self._require_eval()
+        rf = self.receptive_field
+        image = image[:, :rf].contiguous()
+        b, s, n, c, h, w = image.shape
+        depth_logits, features = self.encoder.lift_head(image.view(b * s * n, c, h, w))
+        fh, fw = features.shape[-2:]
+        feats = features.view(b, s, n, -1, fh, fw)
+        if depth_logits is None:
+            lifted = feats.unsqueeze(4).expand(b, s, n, feats.shape[3], self.depth_channels, fh, fw)
+            return self.bev_forward(lifted, intrinsics, extrinsics, future_egomotion, future_distribution_inputs, noise)
+        return self.bev_forward(None, intrinsics, extrinsics, future_egomotion, future_distribution_inputs, noise,
+                                depth_logits=depth_logits.view(b, s, n, -1, fh, fw), features=feats)

@@ -58,12 +58,20 @@ class NativeError(RuntimeError):
 
 
 def _ptr(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    """Device address of a tensor, of a pixel-major view object exposing `.ptr` (ops.Buf), or a raw int."""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return C.c_void_p(t)
+    if isinstance(t, torch.Tensor):
+        return C.c_void_p(t.data_ptr())
+    return C.c_void_p(t.ptr)
 
 
 def _stream_of(*tensors):
     for t in tensors:
-        if t is not None and t.is_cuda:
+        t = getattr(t, 'tensor', t)
+        if isinstance(t, torch.Tensor) and t.is_cuda:
             return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
     return C.c_void_p(0)
 
@@ -88,9 +96,13 @@ _SIGNATURES = {
     'fiery_conv_fwd': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     'fiery_heads_1x1_nchw': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        c_int32_p, c_uint8_p, C.c_void_p, C.c_void_p]),
-    'fiery_spatial_mean': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    'fiery_rowwise_dense': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                      C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'fiery_spatial_mean': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fiery_rowwise_dense': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                      C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int,
+                                      C.c_void_p]),
+    'fiery_latent_sample': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                      C.c_void_p]),
     'fiery_maxpool2x2_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'fiery_upsample2x_add_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                             C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
@@ -214,13 +226,18 @@ class Lib:
                                                  _ptr(out), _stream_of(out)))
 
     # -- helpers ----------------------------------------------------------------------------------
-    def spatial_mean(self, x, in_ld, in_img_stride, n_img, hw, c, out, workspace):
-        self.check(self.dll.fiery_spatial_mean(_ptr(x), in_ld, in_img_stride, n_img, hw, c, _ptr(out), _ptr(workspace),
-                                               _stream_of(out)))
+    def spatial_mean(self, x_ptr, in_ld, outer_stride, n_outer, inner_stride, n_inner, n_pixels, c, out, workspace):
+        self.check(self.dll.fiery_spatial_mean(_ptr(x_ptr), in_ld, outer_stride, n_outer, inner_stride, n_inner, n_pixels, c,
+                                               _ptr(out), _ptr(workspace), _stream_of(out)))
 
-    def rowwise_dense(self, v, v_ld, rows, n_in, w, w_ld, w_col0, n_out, scale, shift, act, accumulate, y, y_ld):
-        self.check(self.dll.fiery_rowwise_dense(_ptr(v), v_ld, rows, n_in, _ptr(w), w_ld, w_col0, n_out, _ptr(scale),
-                                                _ptr(shift), act, int(accumulate), _ptr(y), y_ld, _stream_of(y)))
+    def rowwise_dense(self, v, v_ld, rows, n_in, w, w_ld, w_col0, n_out, scale, shift, act, accumulate, y, y_ld,
+                      w_mul=1.0, lo=float('-inf'), hi=float('inf')):
+        self.check(self.dll.fiery_rowwise_dense(_ptr(v), v_ld, rows, n_in, _ptr(w), w_ld, w_col0, n_out, w_mul, _ptr(scale),
+                                                _ptr(shift), act, int(accumulate), lo, hi, _ptr(y), y_ld, _stream_of(y)))
+
+    def latent_sample(self, mu, log_sigma, noise, ld, rows, n, sample, sample_ld):
+        self.check(self.dll.fiery_latent_sample(_ptr(mu), _ptr(log_sigma), _ptr(noise), ld, rows, n, _ptr(sample), sample_ld,
+                                                _stream_of(sample)))
 
     def maxpool2x2(self, x, in_ld, n_img, h, w, c, out, out_ld):
         self.check(self.dll.fiery_maxpool2x2_nhwc(_ptr(x), in_ld, n_img, h, w, c, _ptr(out), out_ld, _stream_of(out)))

@@ -1,0 +1,157 @@
+"""Host-side operator objects over the C ABI: pixel-major (NHWC) buffers and convolution ops.
+
+This is the layer `fiery_amd.engine` composes the BEV stack from.  It only prepares arguments
+(weight packing, BatchNorm folding, descriptors); all arithmetic runs in libfiery_hip.so.
+"""
+import ctypes as C
+
+import torch
+
+from . import native
+
+UNIT = 8          # input channels are consumed in units of 8 floats
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+class Buf:
+    """A pixel-major activation view: `n_img` images of H x W pixels, `C` channels wide inside rows of
+    `ld` floats.  Element (img, y, x, c) lives at base + img*img_stride + (y*W + x)*ld + c.  Views can
+    select a channel slice (writers of a concatenation target its slices) or a strided image subset
+    (one time step of a (batch, time) sequence)."""
+
+    def __init__(self, tensor, n_img, H, W, C, ld=None, img_stride=None, base_off=0):
+        self.tensor = tensor                 # keeps the storage alive
+        self.n_img, self.H, self.W, self.C = n_img, H, W, C
+        self.ld = ld if ld is not None else tensor.shape[-1]
+        self.img_stride = img_stride if img_stride is not None else H * W * self.ld
+        self.base_off = base_off             # floats from the start of `tensor`
+
+    @staticmethod
+    def alloc(n_img, H, W, C, device, zero=True):
+        width = round_up(C, UNIT)
+        make = torch.zeros if zero else torch.empty
+        return Buf(make(n_img, H, W, width, dtype=torch.float32, device=device), n_img, H, W, width)
+
+    @property
+    def ptr(self):
+        return self.tensor.data_ptr() + 4 * self.base_off
+
+    def slice(self, c_off, C):
+        assert c_off % 4 == 0 and c_off + C <= self.C
+        return Buf(self.tensor, self.n_img, self.H, self.W, C, self.ld, self.img_stride, self.base_off + c_off)
+
+    def images(self, first, count, step=1):
+        """Images first, first+step, ... (count of them)."""
+        assert first + (count - 1) * step < self.n_img
+        return Buf(self.tensor, count, self.H, self.W, self.C, self.ld, self.img_stride * step,
+                   self.base_off + first * self.img_stride)
+
+    def nhwc(self):
+        """(n_img, H, W, C) torch view of the data."""
+        return torch.as_strided(self.tensor, (self.n_img, self.H, self.W, self.C),
+                                (self.img_stride, self.W * self.ld, self.ld, 1),
+                                self.tensor.storage_offset() + self.base_off)
+
+    def to_nchw(self):
+        return self.nhwc().permute(0, 3, 1, 2).contiguous()
+
+    def as_nhwc_struct(self):
+        s = native.Nhwc()
+        s.ptr, s.ld, s.img_stride = self.ptr, self.ld, self.img_stride
+        return s
+
+
+def _null_nhwc():
+    s = native.Nhwc()
+    s.ptr, s.ld, s.img_stride = None, 0, 0
+    return s
+
+
+def fold_bn(bn, cout, conv_bias=None, eps=None):
+    """(scale, shift) of `BN(conv + bias)` in inference mode; identity scale when bn is None."""
+    if bn is None:
+        scale = torch.ones(cout, dtype=torch.float32)
+        shift = torch.zeros(cout, dtype=torch.float32) if conv_bias is None else conv_bias.detach().float().cpu().clone()
+        return scale, shift
+    w, b = bn.weight.detach().float().cpu(), bn.bias.detach().float().cpu()
+    mean, var = bn.running_mean.detach().float().cpu(), bn.running_var.detach().float().cpu()
+    scale = w / torch.sqrt(var + (bn.eps if eps is None else eps))
+    shift = b - mean * scale
+    if conv_bias is not None:
+        shift = shift + conv_bias.detach().float().cpu() * scale
+    return scale, shift
+
+
+class ConvOp:
+    """One convolution (+ folded BN / bias, activation, residual, GRU epilogues) ready to launch.
+
+    weight   : (Cout, Cin_total, kH, kW) or (Cout, Cin_total, kT, kH, kW) dense tensor (any device)
+    chan_map : for every logical input channel its position in the padded, unit-aligned channel
+               space formed by source 0 followed by source 1
+    units    : (units0, units1) 8-channel units read from each source
+    """
+
+    def __init__(self, lib, weight, chan_map, units, scale, shift, device, stride=1, pad=None,
+                 act=native.ACT_NONE, epi=native.EPI_PLAIN, res_before_act=False):
+        self.lib = lib
+        w = weight.detach().to(device=device, dtype=torch.float32).contiguous()
+        self.cout, self.cin_total = w.shape[0], w.shape[1]
+        kernel = tuple(w.shape[2:])
+        self.kT, self.kH, self.kW = (1,) * (3 - len(kernel)) + kernel
+        self.stride = stride
+        self.padH, self.padW = ((self.kH - 1) // 2, (self.kW - 1) // 2) if pad is None else pad
+        self.units = tuple(units)
+        cin_units = sum(self.units)
+        taps = self.kT * self.kH * self.kW
+        assert len(chan_map) == self.cin_total
+        self.packed = lib.conv_pack_weights(w.view(self.cout, self.cin_total, taps), self.cout, self.cin_total, taps,
+                                            list(chan_map), cin_units)
+        self.cout_pad = round_up(self.cout, 32)
+        sc = torch.zeros(self.cout_pad, dtype=torch.float32)
+        sh = torch.zeros(self.cout_pad, dtype=torch.float32)
+        sc[:self.cout] = scale
+        sh[:self.cout] = shift
+        self.scale, self.shift = sc.to(device), sh.to(device)
+        self.act, self.epi, self.res_before_act = act, epi, res_before_act
+
+    def out_hw(self, H, W):
+        return ((H + 2 * self.padH - self.kH) // self.stride + 1, (W + 2 * self.padW - self.kW) // self.stride + 1)
+
+    def __call__(self, srcs, out, res=None, img_bias=None, out2=None, aux0=None, aux1=None,
+                 T_out=1, t_out0=0, t_in_add=0, cout_store=None):
+        """srcs: list of (Buf, batch_stride, time_stride) or Buf (plain image batch)."""
+        d = native.ConvDesc()
+        first = None
+        for i in range(2):
+            s = d.src[i]
+            if i < len(srcs) and self.units[i] > 0:
+                item = srcs[i]
+                buf, bstride, tstride = item if isinstance(item, tuple) else (item, item.img_stride, 0)
+                first = first or buf
+                s.ptr = buf.ptr
+                s.ld, s.units, s.batch_stride, s.time_stride = buf.ld, self.units[i], bstride, tstride
+            else:
+                s.ptr, s.ld, s.units, s.batch_stride, s.time_stride = None, 0, 0, 0, 0
+        d.Hin, d.Win = first.H, first.W
+        d.Hout, d.Wout = out.H, out.W
+        d.n_img_out, d.T_out, d.t_out0, d.t_in_add = out.n_img, T_out, t_out0, t_in_add
+        d.kT, d.kH, d.kW, d.stride, d.padH, d.padW = self.kT, self.kH, self.kW, self.stride, self.padH, self.padW
+        d.weights, d.cout_pad = self.packed.data_ptr(), self.cout_pad
+        d.scale, d.shift = self.scale.data_ptr(), self.shift.data_ptr()
+        d.img_bias = img_bias.data_ptr() if img_bias is not None else None
+        d.act, d.epi, d.res_before_act = self.act, self.epi, int(self.res_before_act)
+        d.res = res.as_nhwc_struct() if res is not None else _null_nhwc()
+        d.out = out.as_nhwc_struct()
+        d.cout_store = cout_store if cout_store is not None else min(self.cout_pad, round_up(self.cout, UNIT), out.C)
+        d.out2 = out2.as_nhwc_struct() if out2 is not None else _null_nhwc()
+        d.aux0 = aux0.as_nhwc_struct() if aux0 is not None else _null_nhwc()
+        d.aux1 = aux1.as_nhwc_struct() if aux1 is not None else _null_nhwc()
+        self._keep = (srcs, out, res, img_bias, out2, aux0, aux1)
+        self.lib.conv_fwd(d, out.tensor)
+
+
+def identity_chan_map(channels, offset=0):
+    return [offset + i for i in range(channels)]

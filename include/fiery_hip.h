@@ -199,18 +199,26 @@ int fiery_heads_1x1_nchw(const float* in, int in_ld, int n_img, int HW, int C, i
  * Small dense / pooling / resampling helpers of the stack
  * ---------------------------------------------------------------------------------------------- */
 
-/* mean over the H*W pixels of each image: in NHWC -> out[n_img][C] (AdaptiveAvgPool2d(1),
- * models/distributions.py:24; also the spatial part of the (2,H,W) pyramid average pool,
- * layers/temporal.py:186-191).  workspace >= n_img*C*64 floats. */
-int fiery_spatial_mean(const float* in, int in_ld, int64_t in_img_stride, int n_img, int HW, int C,
-                       float* out, float* workspace, fiery_stream_t stream);
+/* mean over `n_pixels` consecutive pixels starting at in + o*outer_stride + i*inner_stride, for
+ * o < n_outer, i < n_inner: out[o*n_inner + i][C].  AdaptiveAvgPool2d(1) (models/distributions.py:24)
+ * is n_pixels = H*W; the (2,H,W) pyramid average pool (layers/temporal.py:186-191) is
+ * n_pixels = 2*H*W over two adjacent frames of a (batch, time) buffer with inner_stride = one frame.
+ * workspace >= n_outer*n_inner*C*64 floats. */
+int fiery_spatial_mean(const float* in, int in_ld, int64_t outer_stride, int n_outer, int64_t inner_stride,
+                       int n_inner, int n_pixels, int C, float* out, float* workspace, fiery_stream_t stream);
 
-/* y[r][o] = act(scale[o] * (sum_j W[o][w_col0 + j] * v[r][j]) + shift[o]) for small matrices
- * (1x1 convs on per-image vectors: pyramid-pool branch, ego-pose channels, distribution head).
- * W is [n_out][w_ld]; scale/shift may be NULL (1 / 0). */
+/* y[r][o] = clamp(act(scale[o] * (w_mul * sum_j W[o][w_col0 + j] * v[r][j] + (accumulate ? y[r][o] : 0))
+ *                     + shift[o]), lo, hi)   for small matrices (1x1 convs on per-image vectors: pyramid-pool
+ * branch, ego-pose channels, distribution head and its log-sigma clamp, models/distributions.py:37).
+ * W is [n_out][w_ld]; scale/shift may be NULL (1 / 0); lo/hi = -inf/+inf for no clamp. */
 int fiery_rowwise_dense(const float* v, int v_ld, int rows, int n_in, const float* W, int w_ld, int w_col0,
-                        int n_out, const float* scale, const float* shift, int act, int accumulate,
-                        float* y, int y_ld, fiery_stream_t stream);
+                        int n_out, float w_mul, const float* scale, const float* shift, int act, int accumulate,
+                        float lo, float hi, float* y, int y_ld, fiery_stream_t stream);
+
+/* sample[r][j] = mu[r][j] + exp(log_sigma[r][j]) * noise[r][j]   (noise NULL = zeros)
+ * (fiery/models/fiery.py:316-327, inference branch). */
+int fiery_latent_sample(const float* mu, const float* log_sigma, const float* noise, int ld, int rows, int n,
+                        float* sample, int sample_ld, fiery_stream_t stream);
 
 /* 2x2 stride-2 max pooling, NHWC, odd sizes padded with one zero row/column first
  * (layers/convolutions.py:150,166). */

@@ -1,0 +1,41 @@
+"""Shared test helpers: small configurations and deterministic, non-trivial weights."""
+import torch
+
+from fiery_amd.config import get_preset_cfg
+
+
+def tiny_cfg(preset='baseline.yml', bev=16, **overrides):
+    """A configuration with the reference's structure but a small image/BEV so the CPU tiers are fast."""
+    half = bev / 2.0
+    opts = ['IMAGE.FINAL_DIM', '(64, 96)', 'LIFT.X_BOUND', f'[-{half}, {half}, 1.0]', 'LIFT.Y_BOUND', f'[-{half}, {half}, 1.0]',
+            'LIFT.D_BOUND', '[2.0, 10.0, 2.0]']
+    for k, v in overrides.items():
+        opts += [k, str(v)]
+    return get_preset_cfg(preset, opts)
+
+
+def randomise_weights(model, seed=2):
+    """Non-trivial values everywhere, BatchNorm statistics included (fresh BN is the identity: a weak test).
+    Deterministic per key name, so any module tree with the same state_dict keys gets the same values."""
+    sd = model.state_dict()
+    new = {}
+    for i, key in enumerate(sorted(sd)):
+        t = sd[key]
+        if key in ('frustum', 'bev_resolution', 'bev_start_position', 'bev_dimension') or key.endswith('num_batches_tracked'):
+            new[key] = t
+            continue
+        g = torch.Generator().manual_seed(seed * 1000003 + i)
+        if key.endswith('running_var'):
+            v = 0.5 + torch.rand(t.shape, generator=g)
+        elif key.endswith('running_mean'):
+            v = 0.2 * torch.randn(t.shape, generator=g)
+        elif t.dim() == 1 and key.endswith('weight'):          # BN / affine scale
+            v = 0.75 + 0.5 * torch.rand(t.shape, generator=g)
+        elif t.dim() == 1:
+            v = 0.1 * torch.randn(t.shape, generator=g)
+        else:
+            fan_in = t[0].numel()
+            v = torch.randn(t.shape, generator=g) * (1.3 / fan_in ** 0.5)
+        new[key] = v.to(t.dtype)
+    model.load_state_dict(new)
+    return new

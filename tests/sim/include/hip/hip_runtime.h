@@ -3,20 +3,21 @@
 // The product kernels under fiery_amd/csrc are written for gfx950 only and contain no host/device
 // dual paths.  To exercise their index arithmetic, LDS tiling and MFMA fragment mapping in the
 // GPU-less test tier, tests/sim/build_sim.py compiles those same .hip sources with g++ against THIS
-// header (it shadows the real one through the include path).  One std::thread plays one work-item;
-// __syncthreads() is a std::barrier; the f32 MFMA builtin is emulated with the lane->element
+// header (it shadows the real one through the include path).  One cooperative fiber plays one work-item;
+// __syncthreads() parks fibers until the workgroup has arrived; the f32 MFMA builtin is emulated with the lane->element
 // mapping documented for gfx950 (A[i=l&31][k=l>>5], B[k=l>>5][j=l&31], D row=(r&3)+8*(r>>2)+4*(l>>5),
 // col=l&31).  It is slow, only meant for tiny problems, and never part of a shipped path.
 #pragma once
-#include <atomic>
-#include <barrier>
+#include <ucontext.h>
+
+#include <algorithm>
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
-#include <thread>
 #include <vector>
 
 #define __global__
@@ -43,23 +44,83 @@ constexpr hipError_t hipSuccess = 0;
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "sim"; }
 
+// One work-item = one cooperative fiber (ucontext) on the calling OS thread; a workgroup's fibers are
+// scheduled round-robin and only switch at barriers (__syncthreads, the wave-level exchange inside the
+// emulated MFMA) or when they finish.  Workgroups run one after another.
 namespace hipsim {
-struct WaveShared {
-    float a[64], b[64];
-    std::barrier<> bar{64};
-    explicit WaveShared(int lanes) : bar(lanes) {}
+constexpr size_t kStack = 256 * 1024;
+
+struct Barrier {
+    int arrived = 0, generation = 0, alive = 0;
 };
 struct Tls {
     uint3_sim tid, bid;
     dim3 bdim, gdim;
     void* dyn_smem = nullptr;
-    std::barrier<>* block_bar = nullptr;
-    WaveShared* wave = nullptr;
-    int lane = 0;
+    int lane = 0, wave = 0;
 };
-inline Tls& tls() {
-    static thread_local Tls t;
-    return t;
+struct Fiber {
+    ucontext_t ctx;
+    Tls tls;
+    bool done = false;
+    const int* wait_gen = nullptr;   // parked until *wait_gen != wait_val
+    int wait_val = 0;
+};
+struct Run {
+    std::vector<Fiber> fibers;
+    std::vector<Barrier> waves;
+    std::vector<std::vector<float>> wave_a, wave_b;
+    Barrier block;
+    ucontext_t scheduler;
+    int current = 0;
+    std::function<void()> body;
+};
+inline Run*& run_ptr() {
+    static Run* r = nullptr;
+    return r;
+}
+inline Tls& tls() { return run_ptr()->fibers[run_ptr()->current].tls; }
+
+inline void park(const int* gen, int val) {
+    Run& r = *run_ptr();
+    Fiber& f = r.fibers[r.current];
+    f.wait_gen = gen;
+    f.wait_val = val;
+    swapcontext(&f.ctx, &r.scheduler);
+}
+inline void barrier_wait(Barrier& b) {
+    const int gen = b.generation;
+    if (++b.arrived == b.alive) {
+        b.arrived = 0;
+        ++b.generation;
+    } else {
+        park(&b.generation, gen);
+    }
+}
+inline void barrier_leave(Barrier& b) {
+    if (--b.alive > 0 && b.arrived == b.alive) {   // the others were only waiting for this one
+        b.arrived = 0;
+        ++b.generation;
+    }
+}
+inline void trampoline() {
+    Run& r = *run_ptr();
+    r.body();
+    Fiber& f = r.fibers[r.current];
+    f.done = true;
+    barrier_leave(r.waves[f.tls.wave]);
+    barrier_leave(r.block);
+    swapcontext(&f.ctx, &r.scheduler);
+}
+inline char* stack_pool(size_t n_fibers) {
+    static char* pool = nullptr;
+    static size_t cap = 0;
+    if (n_fibers > cap) {
+        free(pool);
+        if (posix_memalign(reinterpret_cast<void**>(&pool), 4096, n_fibers * kStack)) abort();
+        cap = n_fibers;
+    }
+    return pool;
 }
 
 template <typename Kernel, typename... Args>
@@ -68,35 +129,50 @@ void launch(Kernel kernel, dim3 grid, dim3 block, size_t shmem, Args... args) {
     const unsigned n_waves = (n_threads + 63) / 64;
     void* smem = nullptr;
     if (posix_memalign(&smem, 64, shmem ? shmem : 64)) abort();
+    char* stacks = stack_pool(n_threads);
+    Run run;
+    run.body = [&]() { kernel(args...); };
+    Run* previous = run_ptr();
+    run_ptr() = &run;
     for (unsigned bz = 0; bz < grid.z; ++bz)
         for (unsigned by = 0; by < grid.y; ++by)
             for (unsigned bx = 0; bx < grid.x; ++bx) {
-                std::barrier<> block_bar(n_threads);
-                std::vector<std::unique_ptr<WaveShared>> waves;
-                for (unsigned w = 0; w < n_waves; ++w) {
-                    unsigned lanes = std::min(64u, n_threads - w * 64);
-                    waves.emplace_back(new WaveShared(static_cast<int>(lanes)));
-                }
-                std::vector<std::thread> pool;
-                pool.reserve(n_threads);
+                run.fibers.assign(n_threads, Fiber());
+                run.waves.assign(n_waves, Barrier());
+                run.wave_a.assign(n_waves, std::vector<float>(64));
+                run.wave_b.assign(n_waves, std::vector<float>(64));
+                run.block = Barrier();
+                run.block.alive = static_cast<int>(n_threads);
                 for (unsigned t = 0; t < n_threads; ++t) {
-                    pool.emplace_back([&, t, bx, by, bz]() {
-                        Tls& c = tls();
-                        c.tid = {t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};
-                        c.bid = {bx, by, bz};
-                        c.bdim = block;
-                        c.gdim = grid;
-                        c.dyn_smem = smem;
-                        c.block_bar = &block_bar;
-                        c.wave = waves[t / 64].get();
-                        c.lane = static_cast<int>(t % 64);
-                        kernel(args...);
-                        c.wave->bar.arrive_and_drop();
-                        block_bar.arrive_and_drop();
-                    });
+                    Fiber& f = run.fibers[t];
+                    f.tls.tid = {t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};
+                    f.tls.bid = {bx, by, bz};
+                    f.tls.bdim = block;
+                    f.tls.gdim = grid;
+                    f.tls.dyn_smem = smem;
+                    f.tls.lane = static_cast<int>(t % 64);
+                    f.tls.wave = static_cast<int>(t / 64);
+                    run.waves[t / 64].alive++;
+                    getcontext(&f.ctx);
+                    f.ctx.uc_stack.ss_sp = stacks + static_cast<size_t>(t) * kStack;
+                    f.ctx.uc_stack.ss_size = kStack;
+                    f.ctx.uc_link = nullptr;
+                    makecontext(&f.ctx, reinterpret_cast<void (*)()>(&trampoline), 0);
                 }
-                for (auto& th : pool) th.join();
+                unsigned remaining = n_threads;
+                while (remaining) {
+                    for (unsigned t = 0; t < n_threads; ++t) {
+                        Fiber& f = run.fibers[t];
+                        if (f.done) continue;
+                        if (f.wait_gen && *f.wait_gen == f.wait_val) continue;   // still parked
+                        f.wait_gen = nullptr;
+                        run.current = static_cast<int>(t);
+                        swapcontext(&run.scheduler, &f.ctx);
+                        if (f.done) --remaining;
+                    }
+                }
             }
+    run_ptr() = previous;
     free(smem);
 }
 }  // namespace hipsim
@@ -108,45 +184,46 @@ void launch(Kernel kernel, dim3 grid, dim3 block, size_t shmem, Args... args) {
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     ::hipsim::launch(kernel, grid, block, shmem, __VA_ARGS__)
 
-inline void __syncthreads() { ::hipsim::tls().block_bar->arrive_and_wait(); }
+inline void __syncthreads() { ::hipsim::barrier_wait(::hipsim::run_ptr()->block); }
 
 using std::max;
 using std::min;
 
 inline float atomicAdd(float* addr, float v) {
-    uint32_t* p = reinterpret_cast<uint32_t*>(addr);
-    uint32_t old = __atomic_load_n(p, __ATOMIC_RELAXED);
-    for (;;) {
-        float f;
-        std::memcpy(&f, &old, 4);
-        float nf = f + v;
-        uint32_t desired;
-        std::memcpy(&desired, &nf, 4);
-        if (__atomic_compare_exchange_n(p, &old, desired, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) return f;
-    }
+    const float old = *addr;
+    *addr = old + v;
+    return old;
 }
-inline int atomicAdd(int* addr, int v) { return __atomic_fetch_add(addr, v, __ATOMIC_RELAXED); }
+inline int atomicAdd(int* addr, int v) {
+    const int old = *addr;
+    *addr = old + v;
+    return old;
+}
 inline unsigned long long atomicAdd(unsigned long long* addr, unsigned long long v) {
-    return __atomic_fetch_add(addr, v, __ATOMIC_RELAXED);
+    const unsigned long long old = *addr;
+    *addr = old + v;
+    return old;
 }
 
 // f32 MFMA 32x32x2: D = A(32x2) . B(2x32) + C, one wave.
 typedef float hipsim_v16f __attribute__((vector_size(64)));
 inline hipsim_v16f __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, hipsim_v16f c, int, int, int) {
-    ::hipsim::Tls& t = ::hipsim::tls();
-    ::hipsim::WaveShared& w = *t.wave;
-    const int l = t.lane;
-    w.a[l] = a;
-    w.b[l] = b;
-    w.bar.arrive_and_wait();
+    ::hipsim::Run& run = *::hipsim::run_ptr();
+    const ::hipsim::Tls& t = ::hipsim::tls();
+    const int l = t.lane, w = t.wave;
+    float* wa = run.wave_a[w].data();
+    float* wb = run.wave_b[w].data();
+    wa[l] = a;
+    wb[l] = b;
+    ::hipsim::barrier_wait(run.waves[w]);
     const int j = l & 31, hi = l >> 5;
     for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
         float acc = c[r];
-        acc = std::fmaf(w.a[i], w.b[j], acc);             // k = 0 : lanes 0..31
-        acc = std::fmaf(w.a[i + 32], w.b[j + 32], acc);   // k = 1 : lanes 32..63
+        acc = std::fmaf(wa[i], wb[j], acc);             // k = 0 : lanes 0..31
+        acc = std::fmaf(wa[i + 32], wb[j + 32], acc);   // k = 1 : lanes 32..63
         c[r] = acc;
     }
-    w.bar.arrive_and_wait();
+    ::hipsim::barrier_wait(run.waves[w]);
     return c;
 }

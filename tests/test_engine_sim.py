@@ -1,0 +1,108 @@
+"""The whole BEV engine (every kernel source + the host plan) on the CPU simulator at a tiny
+configuration, against the oracle's restatement of `Fiery.forward` from the lifted features onward."""
+import pytest
+import torch
+
+from fiery_amd.model import Fiery
+from fiery_amd.synthetic import make_inputs, make_lifted_features
+from oracle import bev_stack
+from tests.helpers import randomise_weights, tiny_cfg
+
+KEYS = ('segmentation', 'instance_center', 'instance_offset', 'instance_flow', 'present_mu', 'present_log_sigma')
+
+
+def _run(cfg, sim, B=1, with_labels=False, noise=None, fused=False, seed=0):
+    torch.manual_seed(0)
+    model = Fiery(cfg).eval()
+    sd = randomise_weights(model)
+    model._lib = sim
+    rf = model.receptive_field
+    n = 2
+    _, K, E, ego = make_inputs(B, rf + model.n_future, n, with_image=False, seed=seed)
+    fh, fw = cfg.IMAGE.FINAL_DIM[0] // 8, cfg.IMAGE.FINAL_DIM[1] // 8
+    dl, ft, lifted = make_lifted_features(B * rf * n, 64, model.depth_channels, (fh, fw), seed=seed + 1)
+    lifted = lifted.view(B, rf, n, 64, model.depth_channels, fh, fw)
+    labels = None
+    if with_labels:
+        g = torch.Generator().manual_seed(5)
+        labels = torch.randn(B, 1 + model.n_future, 6, *model.bev_size, generator=g)
+    with torch.no_grad():
+        if fused:
+            got = model.bev_forward(None, K, E, ego, labels, noise,
+                                    depth_logits=dl.view(B, rf, n, -1, fh, fw), features=ft.view(B, rf, n, 64, fh, fw))
+        else:
+            got = model.bev_forward(lifted, K, E, ego, labels, noise)
+        want = bev_stack.bev_hot_path(sd, cfg, lifted, K, E, ego, noise)
+    return model, got, want, sd, (lifted, K, E, ego, labels)
+
+
+def _compare(got, want, keys, tol=2e-4):
+    for k in keys:
+        if want.get(k) is None:
+            assert got.get(k) is None
+            continue
+        assert got[k].shape == want[k].shape, k
+        err = (got[k] - want[k]).abs().max().item()
+        scale = max(1.0, want[k].abs().max().item())
+        assert err <= tol * scale, (k, err, scale)
+
+
+def test_baseline_structure_end_to_end(sim):
+    """3 past frames, ego-pose channels, pyramid pooling, probabilistic latent, 3 GRU blocks, decoder."""
+    cfg = tiny_cfg('baseline.yml')
+    noise = torch.randn(1, 1, 32, generator=torch.Generator().manual_seed(3))
+    model, got, want, sd, _ = _run(cfg, sim, noise=noise)
+    _compare(got, want, KEYS)
+    assert got['segmentation'].shape == (1, 5, 2, 16, 16)
+    assert got['future_mu'] is None
+
+
+def test_fused_lift_splat_path_and_batch_of_two(sim):
+    cfg = tiny_cfg('baseline.yml', **{'MODEL.FUTURE_PRED.N_GRU_BLOCKS': 1, 'MODEL.FUTURE_PRED.N_RES_LAYERS': 1,
+                                      'N_FUTURE_FRAMES': 2})
+    model, got, want, sd, _ = _run(cfg, sim, B=2, fused=True)
+    _compare(got, want, KEYS)
+
+
+def test_static_single_frame_setting(sim):
+    """literature/static_lss_setting.yml: identity temporal model, no future, no distribution."""
+    cfg = tiny_cfg('literature/static_lss_setting.yml')
+    model, got, want, sd, _ = _run(cfg, sim)
+    _compare(got, want, ('segmentation', 'instance_center', 'instance_offset', 'instance_flow'))
+    assert 'present_mu' not in got and got['instance_flow'] is None
+
+
+def test_future_distribution_with_labels(sim):
+    """evaluate.py passes the future labels in eval mode: the future distribution must be evaluated too
+    (reference: evaluate.py:55-59, fiery.py:310-314)."""
+    from oracle.bev_stack import Weights, distribution
+    cfg = tiny_cfg('baseline.yml', **{'MODEL.FUTURE_PRED.N_GRU_BLOCKS': 1, 'MODEL.FUTURE_PRED.N_RES_LAYERS': 1})
+    model, got, want, sd, (lifted, K, E, ego, labels) = _run(cfg, sim, with_labels=True)
+    _compare(got, want, KEYS)
+    assert got['future_mu'] is not None and got['future_mu'].shape == (1, 1, 32)
+    # oracle for the future distribution: needs the present state, recomputed through the oracle stack
+    import oracle.lift_splat as ls
+    from oracle.bev_stack import pool_lifted, cumulative_warp_features, temporal_model
+    res, start, dim = ls.bev_parameters(cfg.LIFT.X_BOUND, cfg.LIFT.Y_BOUND, cfg.LIFT.Z_BOUND)
+    rf = 3
+    geo = ls.get_geometry(sd['frustum'].numpy(), K[:, :rf].reshape(rf, -1, 3, 3).numpy(), E[:, :rf].reshape(rf, -1, 4, 4).numpy())
+    x = pool_lifted(lifted.reshape(rf, *lifted.shape[2:]), geo, res, start, dim).view(1, rf, 64, 16, 16)
+    x = cumulative_warp_features(x.clone(), ego[:, :rf], 'bilinear', (8.0, 8.0))
+    e = ego[:, :rf].view(1, rf, 6, 1, 1).expand(1, rf, 6, 16, 16)
+    e = torch.cat([torch.zeros_like(e[:, :1]), e[:, :rf - 1]], 1)
+    present = temporal_model(torch.cat([x, e], 2), Weights(sd, 'temporal_model.'), rf)[:, :1]
+    fut = torch.cat([present, labels[:, 1:].contiguous().view(1, 1, -1, 16, 16)], dim=2)
+    fmu, flog = distribution(fut, Weights(sd, 'future_distribution.'), 32, -5.0, 5.0)
+    assert torch.allclose(got['future_mu'], fmu, atol=2e-4)
+    assert torch.allclose(got['future_log_sigma'], flog, atol=2e-4)
+
+
+def test_training_mode_and_cpu_without_library_raise():
+    cfg = tiny_cfg('baseline.yml')
+    model = Fiery(cfg)
+    _, K, E, ego = make_inputs(1, 7, 2, with_image=False)
+    with pytest.raises(RuntimeError, match='eval'):
+        model.bev_forward(torch.zeros(1, 3, 2, 64, 4, 8, 12), K, E, ego)
+    model.eval()
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        model.bev_forward(torch.zeros(1, 3, 2, 64, 4, 8, 12), K, E, ego)

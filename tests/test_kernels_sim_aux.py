@@ -1,0 +1,137 @@
+"""Warp and helper kernel *sources* on the CPU simulator versus the oracle / torch fp32 ops."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from fiery_amd import native
+from oracle import bev_stack
+
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+def test_warp_params_match_reference_pose_algebra(sim):
+    g = torch.Generator().manual_seed(0)
+    B, S = 3, 4
+    ego = torch.zeros(B, S, 6)
+    ego[..., 0] = 2.5 + torch.rand(B, S, generator=g)
+    ego[..., 1] = 0.2 * torch.randn(B, S, generator=g)
+    ego[..., 5] = 0.05 * torch.randn(B, S, generator=g)
+    ego[..., 3:5] = 0.01 * torch.randn(B, S, 2, generator=g)      # small roll/pitch must be ignored consistently
+    theta = sim.warp_params(ego, (50.0, 25.0))
+    want = bev_stack.cumulative_warp_thetas(ego, (50.0, 25.0))
+    for t in range(S - 1):
+        assert torch.allclose(theta[:, t].view(B, 2, 3), want[t], **TOL)
+    assert torch.equal(theta[:, S - 1], torch.tensor([1.0, 0, 0, 0, 1, 0]).expand(B, 6))
+
+
+def test_warp_single_frame_is_identity(sim):
+    theta = sim.warp_params(torch.randn(2, 1, 6), (50.0, 50.0))
+    assert torch.equal(theta[:, 0], torch.tensor([1.0, 0, 0, 0, 1, 0]).expand(2, 6))
+
+
+def test_bev_warp_matches_grid_sample_and_changes_layout(sim):
+    g = torch.Generator().manual_seed(1)
+    B, S, C, H, W = 2, 3, 5, 12, 70        # W > 64 exercises two x-tiles
+    x = torch.randn(B, S, C, H, W, generator=g)
+    ego = torch.zeros(B, S, 6)
+    ego[..., 0] = 3.0 + torch.rand(B, S, generator=g)
+    ego[..., 1] = 0.5 * torch.randn(B, S, generator=g)
+    ego[..., 5] = 0.1 * torch.randn(B, S, generator=g)
+    extent = (6.0, 35.0)
+    want = bev_stack.cumulative_warp_features(x.clone(), ego, 'bilinear', extent)
+    theta = sim.warp_params(ego, extent)
+    out = torch.zeros(B * S, H, W, 8)
+    identity = [(i % S) == S - 1 for i in range(B * S)]
+    sim.bev_warp_nchw_to_nhwc(x.view(B * S, C, H, W), theta.view(B * S, 6), identity, out, 8, H * W * 8)
+    got = out[..., :C].permute(0, 3, 1, 2).reshape(B, S, C, H, W)
+    assert torch.allclose(got, want, rtol=1e-4, atol=2e-5), (got - want).abs().max()
+    assert torch.equal(got[:, -1], x[:, -1])          # the present frame is copied, not resampled
+    assert out[..., C:].abs().max() == 0
+
+
+def test_spatial_mean(sim):
+    g = torch.Generator().manual_seed(2)
+    n, H, W, C = 3, 9, 11, 70
+    x = torch.randn(n, H, W, 72, generator=g)
+    out = torch.empty(n, C)
+    ws = torch.empty(n * C * 64)
+    sim.spatial_mean(x, 72, H * W * 72, n, 0, 1, H * W, C, out, ws)
+    assert torch.allclose(out, x[..., :C].mean(dim=(1, 2)), **TOL)
+    # two-frame windows of a (batch=1, time=3) buffer: frames (0,1) and (1,2)
+    out2 = torch.empty(2, C)
+    sim.spatial_mean(x, 72, 0, 1, H * W * 72, 2, 2 * H * W, C, out2, ws)
+    want = torch.stack([x[0:2, ..., :C].mean(dim=(0, 1, 2)), x[1:3, ..., :C].mean(dim=(0, 1, 2))])
+    assert torch.allclose(out2, want, **TOL)
+
+
+@pytest.mark.parametrize('act', [native.ACT_NONE, native.ACT_RELU])
+def test_rowwise_dense(sim, act):
+    g = torch.Generator().manual_seed(3)
+    rows, n_in, n_out = 5, 6, 23
+    v = torch.randn(rows, 8, generator=g)
+    w = torch.randn(n_out, 70, generator=g)
+    sc, sh = torch.rand(n_out, generator=g) + 0.5, torch.randn(n_out, generator=g)
+    y = torch.zeros(rows, 24)
+    sim.rowwise_dense(v, 8, rows, n_in, w, 70, 64, n_out, sc, sh, act, False, y, 24)
+    want = (v[:, :n_in] @ w[:, 64:70].t()) * sc + sh
+    if act == native.ACT_RELU:
+        want = F.relu(want)
+    assert torch.allclose(y[:, :n_out], want, **TOL)
+    before = y.clone()
+    sim.rowwise_dense(v, 8, rows, n_in, w, 70, 0, n_out, None, None, native.ACT_NONE, True, y, 24, w_mul=0.5)
+    assert torch.allclose(y[:, :n_out], before[:, :n_out] + 0.5 * (v[:, :n_in] @ w[:, :n_in].t()), **TOL)
+    sim.rowwise_dense(v, 8, rows, n_in, w, 70, 0, n_out, None, None, native.ACT_NONE, False, y, 24, lo=-0.25, hi=0.5)
+    assert torch.allclose(y[:, :n_out], (v[:, :n_in] @ w[:, :n_in].t()).clamp(-0.25, 0.5), **TOL)
+
+
+def test_latent_sample(sim):
+    g = torch.Generator().manual_seed(9)
+    mu, ls_, eps = torch.randn(3, 32, generator=g), torch.randn(3, 32, generator=g), torch.randn(3, 32, generator=g)
+    out = torch.empty(3, 32)
+    sim.latent_sample(mu, ls_, eps, 32, 3, 32, out, 32)
+    assert torch.allclose(out, mu + torch.exp(ls_) * eps, **TOL)
+    sim.latent_sample(mu, ls_, None, 32, 3, 32, out, 32)
+    assert torch.equal(out, mu)
+
+
+@pytest.mark.parametrize('hw', [(8, 10), (7, 13)])
+def test_maxpool2x2_with_zero_padding_of_odd_sizes(sim, hw):
+    g = torch.Generator().manual_seed(4)
+    H, W = hw
+    x = torch.randn(2, 16, H, W, generator=g) - 0.5
+    xin = x.permute(0, 2, 3, 1).contiguous()
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    out = torch.empty(2, Ho, Wo, 16)
+    sim.maxpool2x2(xin, 16, 2, H, W, 16, out, 16)
+    want = F.max_pool2d(F.pad(x, (0, W % 2, 0, H % 2), value=0), 2, 2)
+    assert torch.equal(out.permute(0, 3, 1, 2), want)
+
+
+def test_upsample2x_add(sim):
+    g = torch.Generator().manual_seed(5)
+    n, C, H, W = 2, 16, 5, 7
+    x = torch.randn(n, C, H, W, generator=g)
+    skip = torch.randn(n, C, 2 * H, 2 * W, generator=g)
+    shift = torch.randn(C, generator=g)
+    out = torch.empty(n, 2 * H, 2 * W, C)
+    sim.upsample2x_add(x.permute(0, 2, 3, 1).contiguous(), C, n, H, W, C, shift,
+                       skip.permute(0, 2, 3, 1).contiguous(), C, out, C)
+    want = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False) + shift.view(1, -1, 1, 1) + skip
+    assert torch.allclose(out.permute(0, 3, 1, 2), want, **TOL)
+
+
+def test_broadcast_and_layout_changes(sim):
+    g = torch.Generator().manual_seed(6)
+    n, C, HW = 2, 32, 75
+    v = torch.randn(n, C, generator=g)
+    out = torch.zeros(n, HW, 40)
+    sim.broadcast(v, C, n, HW, C, out, 40, HW * 40)
+    assert torch.equal(out[..., :C], v.view(n, 1, C).expand(n, HW, C))
+    assert out[..., C:].abs().max() == 0
+    x = torch.randn(n, 7, HW, generator=g)
+    nhwc = torch.zeros(n, HW, 8)
+    sim.nchw_to_nhwc(x, n, 7, HW, nhwc, 8, HW * 8)
+    assert torch.equal(nhwc[..., :7], x.permute(0, 2, 1))
+    back = torch.empty(n, 7, HW)
+    sim.nhwc_to_nchw(nhwc, 8, HW * 8, n, 7, HW, back)
+    assert torch.equal(back, x)

@@ -1,0 +1,179 @@
+"""The implicit-GEMM convolution *source* (fiery_amd/csrc/conv_igemm.hip) on the CPU simulator versus
+torch's fp32 convolutions: MFMA fragment mapping, LDS swizzle, im2col gather (strides, padding, causal
+time taps, two-source concat), weight packing and every epilogue, without a GPU."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from fiery_amd import native
+from fiery_amd.ops import Buf, ConvOp, identity_chan_map, round_up
+
+TOL = dict(rtol=2e-5, atol=2e-5)
+
+
+def _to_buf(x_nchw, width=None):
+    n, c, h, w = x_nchw.shape
+    width = width or round_up(c, 8)
+    t = torch.zeros(n, h, w, width)
+    t[..., :c] = x_nchw.permute(0, 2, 3, 1)
+    return Buf(t, n, h, w, width)
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,hw', [
+    (16, 64, 3, 1, (9, 14)),      # BN=64 tile, 3x3
+    (13, 32, 3, 2, (11, 9)),      # ragged channels, BN=32, stride 2, odd size
+    (24, 70, 1, 1, (7, 20)),      # 1x1, cout padded to 96 (three BN=32 tiles)
+    (8, 40, 7, 2, (12, 12)),      # 7x7 stride 2 like the decoder stem, cout padded to 64
+])
+def test_conv2d_bn_relu(sim, cin, cout, k, stride, hw):
+    g = torch.Generator().manual_seed(cin * 100 + cout)
+    x = torch.randn(2, cin, *hw, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * 0.2
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g)
+    src = _to_buf(x)
+    op = ConvOp(sim, w, identity_chan_map(cin), (src.C // 8, 0), scale, shift, 'cpu', stride=stride, act=native.ACT_RELU)
+    ho, wo = op.out_hw(*hw)
+    out = Buf.alloc(2, ho, wo, cout, 'cpu')
+    op([src], out)
+    want = F.relu(F.conv2d(x, w, stride=stride, padding=(k - 1) // 2) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    got = out.to_nchw()[:, :cout]
+    assert torch.allclose(got, want, **TOL), (got - want).abs().max()
+    # padded output channels are written as exact zeros (they feed later convs as inputs)
+    assert out.to_nchw()[:, cout:].abs().max() == 0 if out.C > cout else True
+
+
+def test_asymmetric_weights_catch_transposes(sim):
+    """A = identity-like input with an asymmetric weight matrix: a row/column swap in the MFMA output
+    mapping or the packing cannot pass."""
+    cin, cout = 32, 64
+    x = torch.zeros(1, cin, 4, 8)
+    for c in range(cin):
+        x[0, c, c % 4, c % 8] = 1.0 + c
+    w = torch.arange(cout * cin, dtype=torch.float32).view(cout, cin, 1, 1) / 100.0
+    src = _to_buf(x)
+    op = ConvOp(sim, w, identity_chan_map(cin), (4, 0), torch.ones(cout), torch.zeros(cout), 'cpu')
+    out = Buf.alloc(1, 4, 8, cout, 'cpu')
+    op([src], out)
+    assert torch.allclose(out.to_nchw(), F.conv2d(x, w), **TOL)
+
+
+def test_two_source_concat_with_residual_and_bias(sim):
+    g = torch.Generator().manual_seed(5)
+    xa = torch.randn(2, 12, 6, 10, generator=g)      # source 0: 12 real channels in 16
+    xb = torch.randn(2, 20, 6, 10, generator=g)      # source 1: 20 real channels in 24
+    w = torch.randn(64, 32, 3, 3, generator=g) * 0.1
+    res = torch.randn(2, 64, 6, 10, generator=g)
+    img_bias = torch.randn(2, 64, generator=g)
+    a, b, r = _to_buf(xa), _to_buf(xb), _to_buf(res)
+    cmap = identity_chan_map(12) + identity_chan_map(20, offset=16)
+    for res_pre in (False, True):
+        op = ConvOp(sim, w, cmap, (2, 3), torch.ones(64), torch.zeros(64), 'cpu', act=native.ACT_RELU,
+                    res_before_act=res_pre)
+        out = Buf.alloc(2, 6, 10, 64, 'cpu')
+        op([a, b], out, res=r, img_bias=img_bias)
+        y = F.conv2d(torch.cat([xa, xb], 1), w, padding=1) + img_bias.view(2, 64, 1, 1)
+        want = F.relu(y + res) if res_pre else F.relu(y) + res
+        assert torch.allclose(out.to_nchw(), want, **TOL)
+
+
+def test_channel_slices_of_wider_buffers(sim):
+    """Reads a channel slice of a wide buffer and writes into a slice of another (concat by placement)."""
+    g = torch.Generator().manual_seed(6)
+    wide = torch.randn(1, 5, 7, 48, generator=g)
+    src = Buf(wide, 1, 5, 7, 48).slice(16, 16)
+    w = torch.randn(32, 16, 1, 1, generator=g)
+    dst_t = torch.full((1, 5, 7, 96), 7.0)
+    dst = Buf(dst_t, 1, 5, 7, 96).slice(32, 32)
+    op = ConvOp(sim, w, identity_chan_map(16), (2, 0), torch.ones(32), torch.zeros(32), 'cpu')
+    op([src], dst)
+    want = F.conv2d(wide[..., 16:32].permute(0, 3, 1, 2), w)
+    assert torch.allclose(dst_t[..., 32:64].permute(0, 3, 1, 2), want, **TOL)
+    assert (dst_t[..., :32] == 7.0).all() and (dst_t[..., 64:] == 7.0).all()
+
+
+@pytest.mark.parametrize('kt', [2, 1])
+def test_causal_conv3d_with_time_window(sim, kt):
+    """(kT,3,3) causal convolution computing only output frames t >= t_out0 (dead-frame pruning)."""
+    g = torch.Generator().manual_seed(8 + kt)
+    B, T, cin, cout, H, W = 2, 3, 16, 32, 5, 6
+    x = torch.randn(B, cin, T, H, W, generator=g)
+    w = torch.randn(cout, cin, kt, 3, 3, generator=g) * 0.2
+    want = F.conv3d(F.pad(x, (1, 1, 1, 1, kt - 1, 0)), w)                  # (B, cout, T, H, W)
+    x_img = x.permute(0, 2, 1, 3, 4).reshape(B * T, cin, H, W)               # images ordered (b, t)
+    src = _to_buf(x_img)
+    op = ConvOp(sim, w, identity_chan_map(cin), (2, 0), torch.ones(cout), torch.zeros(cout), 'cpu')
+    for t_out0 in (0, 1):
+        T_out = T - t_out0
+        out = Buf.alloc(B * T_out, H, W, cout, 'cpu')
+        op([(src, T * src.img_stride, src.img_stride)], out, T_out=T_out, t_out0=t_out0, t_in_add=t_out0)
+        got = out.to_nchw().view(B, T_out, cout, H, W).permute(0, 2, 1, 3, 4)
+        assert torch.allclose(got, want[:, :, t_out0:], **TOL)
+
+
+def test_gru_epilogues(sim):
+    """conv_update|conv_reset fused into one N=128 GEMM, then the state_tilde conv with the gate
+    arithmetic in its epilogue: one full SpatialGRU cell (fiery/layers/temporal.py:49-62)."""
+    g = torch.Generator().manual_seed(11)
+    B, cx, ch, H, W = 2, 32, 64, 6, 9
+    x = torch.randn(B, cx, H, W, generator=g)
+    h = torch.randn(B, ch, H, W, generator=g)
+    wu = torch.randn(ch, cx + ch, 3, 3, generator=g) * 0.05
+    wr = torch.randn(ch, cx + ch, 3, 3, generator=g) * 0.05
+    bu, br = torch.randn(ch, generator=g), torch.randn(ch, generator=g)
+    wt = torch.randn(ch, cx + ch, 3, 3, generator=g) * 0.05
+    sc, sh = torch.rand(ch, generator=g) + 0.5, torch.randn(ch, generator=g)
+    xs = torch.cat([x, h], 1)
+    u = torch.sigmoid(F.conv2d(xs, wu, bu, padding=1))
+    r = torch.sigmoid(F.conv2d(xs, wr, br, padding=1))
+    tilde = F.relu(F.conv2d(torch.cat([x, (1 - r) * h], 1), wt, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    want = (1 - u) * h + u * tilde
+
+    xb, hb = _to_buf(x), _to_buf(h)
+    cmap = identity_chan_map(cx) + identity_chan_map(ch, offset=cx)
+    gates = ConvOp(sim, torch.cat([wu, wr], 0), cmap, (cx // 8, ch // 8), torch.ones(2 * ch), torch.cat([bu, br]),
+                   'cpu', epi=native.EPI_GRU_GATES)
+    ubuf, rh = Buf.alloc(B, H, W, ch, 'cpu'), Buf.alloc(B, H, W, ch, 'cpu')
+    gates([xb, hb], ubuf, out2=rh, aux0=hb)
+    assert torch.allclose(ubuf.to_nchw(), u, **TOL)
+    assert torch.allclose(rh.to_nchw(), (1 - r) * h, **TOL)
+    tilde_op = ConvOp(sim, wt, cmap, (cx // 8, ch // 8), sc, sh, 'cpu', act=native.ACT_RELU, epi=native.EPI_GRU_OUT)
+    out, out2 = Buf.alloc(B, H, W, ch, 'cpu'), Buf.alloc(B, H, W, ch, 'cpu')
+    tilde_op([xb, rh], out, out2=out2, aux0=ubuf, aux1=hb)
+    assert torch.allclose(out.to_nchw(), want, **TOL)
+    assert torch.equal(out.to_nchw(), out2.to_nchw())
+
+
+def test_strided_image_views_for_time_steps(sim):
+    """Reading time step t of a (batch, time) sequence buffer and writing step t of another."""
+    g = torch.Generator().manual_seed(12)
+    B, T, c, H, W = 2, 3, 16, 4, 5
+    seq = torch.randn(B * T, H, W, c, generator=g)
+    sbuf = Buf(seq, B * T, H, W, c)
+    w = torch.randn(32, c, 3, 3, generator=g) * 0.2
+    op = ConvOp(sim, w, identity_chan_map(c), (2, 0), torch.ones(32), torch.zeros(32), 'cpu')
+    dst = Buf.alloc(B * T, H, W, 32, 'cpu')
+    t = 1
+    op([sbuf.images(t, B, step=T)], dst.images(t, B, step=T))
+    x_t = seq.view(B, T, H, W, c)[:, t].permute(0, 3, 1, 2)
+    got = dst.nhwc().view(B, T, H, W, 32)[:, t].permute(0, 3, 1, 2)
+    assert torch.allclose(got, F.conv2d(x_t, w, padding=1), **TOL)
+    assert dst.nhwc().view(B, T, H, W, 32)[:, 0].abs().max() == 0
+
+
+def test_heads_1x1_nchw(sim):
+    g = torch.Generator().manual_seed(13)
+    n, hw, C, head_c = 2, 70, 64, 16
+    x = torch.randn(n, hw, C, generator=g)
+    c_off = [0, 0, 16, 32, 32, 48, 48]
+    sig = [0, 0, 1, 0, 0, 0, 0]
+    w = torch.randn(7, head_c, generator=g)
+    b = torch.randn(7, generator=g)
+    out = torch.empty(n, 7, hw)
+    sim.heads_1x1_nchw(x, C, n, hw, C, head_c, w, b, c_off, sig, out)
+    for o in range(7):
+        want = (x[:, :, c_off[o]:c_off[o] + head_c] * w[o]).sum(-1) + b[o]
+        if sig[o]:
+            want = torch.sigmoid(want)
+        assert torch.allclose(out[:, o], want, **TOL)
