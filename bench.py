@@ -1,0 +1,169 @@
+#!/usr/bin/env python
+"""Headline benchmark: BEV samples/s of the FIERY camera-to-BEV hot path on MI355X.
+
+  python bench.py --gpus 1 --steps 10 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path (geometry -> voxel pooling -> ego-warp -> temporal model -> present
+distribution -> SpatialGRU future prediction -> decoder) over one batch of synthetic input that is already
+resident in HBM: BASELINE.json configs[1], `baseline.yml`, 6 cameras x 3 past frames -> 200x200 BEV, batch 3
+per GPU, fp32.  The inputs are the image encoder's outputs (the trunk is upstream of the path).
+With N > 1 every rank runs its own batch of 3 (the path is independent per sample: no data-path collective),
+so the job processes 3*N samples per step: weak scaling.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0             # MI355X HBM3E spec bandwidth
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=3, help='samples per GPU (baseline.yml BATCHSIZE)')
+    ap.add_argument('--config', default='baseline.yml')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--fused', action='store_true', help='feed depth logits + features to the fused lift-splat kernel '
+                                                         'instead of the materialised outer product')
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, sd, lifted, K, E, ego, runs=2):
+    """The oracle (a port of the reference's CPU path on the same ATen CPU kernels) on the host cores, on a
+    bounded sample: one batch element of the same workload."""
+    from oracle import bev_stack
+    one = [t[:1].cpu() for t in (lifted, K, E, ego)]
+    sd_cpu = {k: v.cpu() for k, v in sd.items()}
+    with torch.no_grad():
+        bev_stack.bev_hot_path(sd_cpu, cfg, *one)          # warm-up (first-call allocator / oneDNN primitive caches)
+        t0 = time.perf_counter()
+        for _ in range(runs):
+            bev_stack.bev_hot_path(sd_cpu, cfg, *one)
+        dt = (time.perf_counter() - t0) / runs
+    return {'value': 1.0 / dt, 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'1 sample (batch 1 of the same workload), mean of {runs} runs after 1 warm-up, {dt:.2f} s each'}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)     # RCCL over xGMI
+
+    from fiery_amd import ops
+    from fiery_amd.config import get_preset_cfg
+    from fiery_amd.model import Fiery
+    from fiery_amd.synthetic import make_inputs, make_lifted_features
+
+    cfg = get_preset_cfg(args.config)
+    torch.manual_seed(0)
+    model = Fiery(cfg).eval()
+    from tests.helpers import randomise_weights
+    sd = randomise_weights(model)                          # random-init weights, non-trivial BN statistics
+    model = model.to(dev)
+
+    B, rf, nf = args.batch, model.receptive_field, model.n_future
+    n_cam = len(cfg.IMAGE.NAMES)
+    D = model.depth_channels
+    fh, fw = cfg.IMAGE.FINAL_DIM[0] // 8, cfg.IMAGE.FINAL_DIM[1] // 8
+    C = cfg.MODEL.ENCODER.OUT_CHANNELS
+    _, K, E, ego = make_inputs(B, rf + nf, n_cam, with_image=False, seed=rank)
+    dl, ft, lifted = make_lifted_features(B * rf * n_cam, C, D, (fh, fw), seed=100 + rank)
+    lifted = lifted.view(B, rf, n_cam, C, D, fh, fw)
+    K_d, E_d, ego_d = K.to(dev), E.to(dev), ego.to(dev)
+    if args.fused:
+        dl_d = dl.view(B, rf, n_cam, D, fh, fw).to(dev)
+        ft_d = ft.view(B, rf, n_cam, C, fh, fw).to(dev)
+        step = lambda: model.bev_forward(None, K_d, E_d, ego_d, depth_logits=dl_d, features=ft_d)
+    else:
+        lifted_d = lifted.to(dev)
+        step = lambda: model.bev_forward(lifted_d, K_d, E_d, ego_d)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    assert all(torch.isfinite(v).all() for v in out.values() if v is not None)
+
+    # one instrumented replica of the step, after the timed region, so the event records do not perturb `value`:
+    # HIP events around every launch of the dominant kernel on the stream it is launched on
+    roofline = pooling = None
+    if rank == 0:
+        ops.PROFILE_SINK = []
+        with torch.no_grad():
+            step()
+        torch.cuda.synchronize()
+        recs, ops.PROFILE_SINK = ops.PROFILE_SINK, None
+        conv = [(s.elapsed_time(e) * 1e-3, w) for k, s, e, w in recs if k == 'conv_igemm']
+        pool = [(s.elapsed_time(e) * 1e-3, w) for k, s, e, w in recs if k == 'voxel_pool']
+        t_conv, f_conv = sum(t for t, _ in conv), sum(w for _, w in conv)
+        achieved = f_conv / t_conv / 1e12
+        roofline = {'kernel': 'k_conv_igemm (fp32 MFMA implicit GEMM)', 'bound': 'mfma', 'achieved': round(achieved, 2),
+                    'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                    'traffic': None, 'launches': len(conv), 'avg_launch_us': round(t_conv / len(conv) * 1e6, 2),
+                    'algorithmic_gflop_per_step': round(f_conv / 1e9, 1), 'kernel_ms_per_step': round(t_conv * 1e3, 3),
+                    'measured': 'HIP events around every launch, one instrumented step after the timed region'}
+        if pool:
+            t_pool, b_pool = sum(t for t, _ in pool), sum(w for _, w in pool)
+            gbs = b_pool / t_pool / 1e9
+            pooling = {'kernel': 'k_rank_columns + k_voxel_pool (op boundary projection_to_birds_eye_view)', 'bound': 'hbm',
+                       'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
+                       'traffic': None, 'algorithmic_mb_per_step': round(b_pool / 1e6, 1), 'op_us_per_step': round(t_pool * 1e6, 1)}
+
+    if rank == 0:
+        line = {
+            'metric': 'BEV samples/s (6 cams x 3 frames -> 200x200 BEV, hot path from encoder outputs to output dict)',
+            'value': round(B * world * args.steps / elapsed, 3), 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{args.config}: {n_cam} cams x {rf} past frames -> {model.bev_size[0]}x{model.bev_size[1]} BEV, '
+                                   f'{nf} future frames, batch {B} per GPU, fp32, '
+                                   f'{"fused lift-splat from depth+features" if args.fused else "lifted features (n,C,D,h,w) resident in HBM"}',
+                       'global_batch': B * world, 'parallelism': f'batch-sharded x{world}, no data-path collective'},
+            'roofline': roofline, 'roofline_pooling': pooling,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(cfg, sd, lifted, K, E, ego)
+            line['speedup_vs_cpu_baseline'] = round(line['value'] / line['cpu_baseline']['value'], 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import native
+from . import ops
 from .ops import Buf, ConvOp, fold_bn, identity_chan_map, round_up
 
 RELU, NONE, SIGMOID = native.ACT_RELU, native.ACT_NONE, native.ACT_SIGMOID
@@ -380,8 +381,12 @@ class BevEngine:
         ws = self._bufs.get(('poolws', f, n, d, h, w))
         if ws is None:
             ws = self._bufs[('poolws', f, n, d, h, w)] = self.lib.pool_workspace(f, n, d, h, w, x.device)
-        return self.lib.voxel_pool(x, x.stride(), geometry.contiguous(), f, n, d, h, w, c, self.grid, workspace=ws,
-                                   tile_voxels=self.pool_tile, flags=self.pool_flags)
+        # algorithmic bytes of the op: every point's C features + its geometry + the dense output;
+        # out-of-grid points are charged too here (an upper bound that needs no device read-back)
+        work = 4.0 * c * f * n * d * h * w + 12.0 * f * n * d * h * w + 4.0 * c * f * self.X * self.Y
+        return ops.profiled('voxel_pool', work, x, lambda: self.lib.voxel_pool(
+            x, x.stride(), geometry.contiguous(), f, n, d, h, w, c, self.grid, workspace=ws,
+            tile_voxels=self.pool_tile, flags=self.pool_flags))
 
     def pool_fused(self, depth_logits, features, geometry):
         """depth logits (F, n, D, h, w) + features (F, n, C, h, w) -> (F, C, X, Y) without the outer product."""

@@ -11,6 +11,21 @@ from . import native
 
 UNIT = 8          # input channels are consumed in units of 8 floats
 
+# When a list is installed here (bench.py does, for its instrumented step), every launch appends
+# (kind, start_event, end_event, algorithmic_work) - flops for convolutions, bytes for pooling.
+PROFILE_SINK = None
+
+
+def profiled(kind, work, stream_tensor, fn):
+    if PROFILE_SINK is None or not stream_tensor.is_cuda:
+        return fn()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    out = fn()
+    end.record()
+    PROFILE_SINK.append((kind, start, end, work))
+    return out
+
 
 def round_up(v, m):
     return (v + m - 1) // m * m
@@ -150,7 +165,8 @@ class ConvOp:
         d.aux0 = aux0.as_nhwc_struct() if aux0 is not None else _null_nhwc()
         d.aux1 = aux1.as_nhwc_struct() if aux1 is not None else _null_nhwc()
         self._keep = (srcs, out, res, img_bias, out2, aux0, aux1)
-        self.lib.conv_fwd(d, out.tensor)
+        flops = 2.0 * out.n_img * out.H * out.W * self.cin_total * self.kT * self.kH * self.kW * self.cout
+        profiled('conv_igemm', flops, out.tensor, lambda: self.lib.conv_fwd(d, out.tensor))
 
 
 def identity_chan_map(channels, offset=0):

@@ -1,0 +1,117 @@
+"""Generates the committed golden fixtures by running the REFERENCE's own code on the CPU.
+
+Only runs in the build container (needs /root/reference; see oracle/ref_shims.py).  Inputs come from the
+seeded generators in fiery_amd/synthetic.py and tests/helpers.py, so the fixtures only need to store
+outputs (sub-sampled where the full tensors are large).  Usage:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from fiery_amd.config import get_preset_cfg                      # noqa: E402
+from fiery_amd.synthetic import make_inputs, make_lifted_features  # noqa: E402
+from oracle.ref_shims import load_reference                       # noqa: E402
+from tests.helpers import randomise_weights, tiny_cfg, forward_case  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+SUB = 8     # spatial sub-sampling of the full-size maps
+
+
+def reference_model(cfg):
+    ref = load_reference()
+    torch.manual_seed(0)
+    model = ref.Fiery(cfg).eval()
+    randomise_weights(model)
+    return model
+
+
+def run_reference_from_lifted(model, lifted, K, E, ego, labels=None, noise=None):
+    """Reference `forward` with the encoder's output supplied (the trunk is upstream of the hot path)."""
+    B, S, n = lifted.shape[:3]
+    flat = lifted.reshape(B * S, n, *lifted.shape[3:]).permute(0, 1, 3, 4, 5, 2)
+    model.encoder_forward = lambda x: flat                    # instance attribute; reference files untouched
+    h, w = model.cfg.IMAGE.FINAL_DIM
+    image = torch.zeros(B, K.shape[1], n, 3, 2, 2)
+    with torch.no_grad():
+        return model(image, K, E, ego, labels, noise)
+
+
+def golden_index_path():
+    """Integer path at full size for both rigs: counts, checksums and a strided sample of the indices."""
+    ref = load_reference()
+    out = {}
+    for name, preset, n_cam in (('baseline', 'baseline.yml', 6), ('pon', 'literature/pon_setting.yml', 6),
+                                ('fishing', 'literature/fishing_setting.yml', 6), ('lyft7', 'lyft/baseline.yml', 7)):
+        cfg = get_preset_cfg(preset)
+        torch.manual_seed(0)
+        model = ref.Fiery(cfg).eval()
+        for jitter in (True, False):
+            _, K, E, _ = make_inputs(1, 1, n_cam, with_image=False, jitter=jitter)
+            with torch.no_grad():
+                geo = model.get_geometry(K[:, 0], E[:, 0])
+                g = ((geo[0] - (model.bev_start_position - model.bev_resolution / 2.0)) / model.bev_resolution)
+                idx = g.view(-1, 3).long()
+            dim = model.bev_dimension
+            keep = ((idx[:, 0] >= 0) & (idx[:, 0] < dim[0]) & (idx[:, 1] >= 0) & (idx[:, 1] < dim[1]) &
+                    (idx[:, 2] >= 0) & (idx[:, 2] < dim[2]))
+            rank = idx[:, 0] * (dim[1] * dim[2]) + idx[:, 1] * dim[2] + idx[:, 2]
+            rank = torch.where(keep, rank, torch.full_like(rank, -1))
+            key = f'{name}_{"jit" if jitter else "axis"}'
+            out[key + '_n_kept'] = np.int64(keep.sum().item())
+            out[key + '_n_voxels'] = np.int64(torch.unique(rank[keep]).numel())
+            out[key + '_rank_sum'] = np.int64(rank.sum().item())
+            out[key + '_rank_wsum'] = np.int64((rank * (torch.arange(rank.numel()) % 1009)).sum().item())
+            out[key + '_rank_sample'] = rank[::97].numpy().astype(np.int32)
+            out[key + '_geo_sample'] = geo.reshape(-1, 3)[::9973].numpy()
+    np.savez_compressed(os.path.join(OUT, 'index_path.npz'), **out)
+
+
+def golden_pooling_small():
+    """`projection_to_birds_eye_view` of the reference on a small problem, inputs included."""
+    cfg = tiny_cfg('baseline.yml', bev=16)
+    model = reference_model(cfg)
+    _, K, E, _ = make_inputs(1, 2, 3, with_image=False)
+    _, _, lifted = make_lifted_features(2 * 3, 8, model.depth_channels, (8, 12), seed=4)
+    lifted = lifted.view(2, 3, 8, model.depth_channels, 8, 12)
+    with torch.no_grad():
+        geo = model.get_geometry(K[0], E[0])
+        bev = model.projection_to_birds_eye_view(lifted.permute(0, 1, 3, 4, 5, 2), geo)
+    np.savez_compressed(os.path.join(OUT, 'pooling_small.npz'), lifted=lifted.numpy(), geometry=geo.numpy(),
+                        intrinsics=K[0].numpy(), extrinsics=E[0].numpy(), bev=bev.numpy())
+
+
+def golden_forward(name, cfg, B, n_cam, sub, with_labels=False, with_noise=False):
+    model = reference_model(cfg)
+    lifted, K, E, ego, labels, noise = forward_case(cfg, model.receptive_field, model.n_future, model.depth_channels,
+                                                    model.bev_size, B, n_cam, with_labels, with_noise)
+    got = run_reference_from_lifted(model, lifted, K, E, ego, labels, noise)
+    out = {}
+    for k, v in got.items():
+        if v is None:
+            continue
+        a = v.numpy()
+        if a.ndim == 5:
+            out[k + '_sub'] = a[..., ::sub, ::sub]
+            out[k + '_mean'] = a.mean(axis=(-1, -2))
+            out[k + '_absmax'] = np.float32(np.abs(a).max())
+        else:
+            out[k] = a
+    np.savez_compressed(os.path.join(OUT, f'forward_{name}.npz'), **out)
+    return {k: (None if v is None else tuple(v.shape)) for k, v in got.items()}
+
+
+if __name__ == '__main__':
+    golden_index_path()
+    golden_pooling_small()
+    print(golden_forward('tiny_baseline', tiny_cfg('baseline.yml'), 2, 2, 1, with_labels=True, with_noise=True))
+    print(golden_forward('tiny_static', tiny_cfg('literature/static_lss_setting.yml'), 1, 2, 1))
+    print(golden_forward('baseline_b1', get_preset_cfg('baseline.yml'), 1, 6, SUB))
+    print(golden_forward('static_lss_1cam', get_preset_cfg('literature/static_lss_setting.yml'), 1, 1, SUB))
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith('.npz'):
+            print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -1,0 +1,258 @@
+"""Parity tests proper: the HIP path on a real MI355X, called through the C ABI (libfiery_hip.so), against
+the oracle on the same seeded inputs, against the committed reference fixtures, and - at BASELINE.json's
+full sizes - through size-independent properties.  Integer/index work is compared bit-for-bit; floating
+point within the 1e-4 fp32 tolerance BASELINE.json's north_star states."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fiery_amd import native
+from fiery_amd.config import get_preset_cfg
+from fiery_amd.model import Fiery
+from fiery_amd.ops import Buf, ConvOp, identity_chan_map
+from fiery_amd.synthetic import make_inputs, make_lifted_features
+from oracle import bev_stack
+from oracle import lift_splat as ls
+from tests.helpers import forward_case, randomise_weights, tiny_cfg
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+DEV = 'cuda:0'
+TOL = 1e-4          # BASELINE.json: "within 1e-4 fp32"
+
+
+def _grid_of(cfg):
+    res, start, dim = ls.bev_parameters(cfg.LIFT.X_BOUND, cfg.LIFT.Y_BOUND, cfg.LIFT.Z_BOUND)
+    origin = (start - res / np.float32(2.0)).astype(np.float32)
+    return native.make_grid(origin, res, dim), (res, start, dim)
+
+
+def _frustum(cfg):
+    return ls.create_frustum(cfg.IMAGE.FINAL_DIM, cfg.MODEL.ENCODER.DOWNSAMPLE, cfg.LIFT.D_BOUND)
+
+
+# ------------------------------------------------------------------------------------------------------
+# integer / index path: bit-exact
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name,preset,n_cam', [('baseline', 'baseline.yml', 6), ('pon', 'literature/pon_setting.yml', 6),
+                                               ('fishing', 'literature/fishing_setting.yml', 6), ('lyft7', 'lyft/baseline.yml', 7)])
+@pytest.mark.parametrize('jitter', [True, False])
+def test_geometry_and_indices_bit_exact_full_size(hip, name, preset, n_cam, jitter):
+    cfg = get_preset_cfg(preset)
+    grid, (res, start, dim) = _grid_of(cfg)
+    frustum = _frustum(cfg)
+    _, K, E, _ = make_inputs(1, 1, n_cam, with_image=False, jitter=jitter)
+    cam = hip.camera_matrices(K[0, 0].to(DEV), E[0, 0].to(DEV))
+    comb, trans = ls.camera_matrices(K[0, 0].numpy(), E[0, 0].numpy())
+    assert np.array_equal(cam[:, :9].cpu().numpy().reshape(-1, 3, 3), comb)
+    geo = hip.lift_geometry(torch.from_numpy(frustum).to(DEV), cam)
+    want_geo = ls.get_geometry(frustum, K[:, 0].numpy(), E[:, 0].numpy())[0]
+    assert np.array_equal(geo.cpu().numpy(), want_geo)
+    rank, idx = hip.voxel_index(geo, grid)
+    idx_o, keep_o, rank_o = ls.voxel_indices(want_geo.reshape(-1, 3), res, start, dim)
+    rank = rank.cpu().numpy().astype(np.int64)
+    assert np.array_equal(rank >= 0, keep_o)
+    assert np.array_equal(rank[keep_o], rank_o[keep_o])
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64)[keep_o], idx_o[keep_o])
+    # and against what the reference itself produced in the build container
+    gold = np.load(os.path.join(GOLD, 'index_path.npz'))
+    key = f'{name}_{"jit" if jitter else "axis"}'
+    assert (rank >= 0).sum() == gold[key + '_n_kept']
+    assert rank.sum() == gold[key + '_rank_sum']
+    assert (rank * (np.arange(rank.size) % 1009)).sum() == gold[key + '_rank_wsum']
+    assert np.array_equal(rank[::97].astype(np.int32), gold[key + '_rank_sample'])
+
+
+# ------------------------------------------------------------------------------------------------------
+# voxel pooling
+# ------------------------------------------------------------------------------------------------------
+def _pool_case(cfg, n_cam, frames, C=64, seed=1, jitter=True):
+    frustum = _frustum(cfg)
+    D, fh, fw = frustum.shape[:3]
+    _, K, E, _ = make_inputs(1, frames, n_cam, with_image=False, jitter=jitter)
+    geo = ls.get_geometry(frustum, K[0].numpy(), E[0].numpy())
+    _, _, lifted = make_lifted_features(frames * n_cam, C, D, (fh, fw), seed=seed)
+    return lifted.view(frames, n_cam, C, D, fh, fw), geo
+
+
+def _native_strides(x):
+    st = x.stride()
+    return (st[0], st[1], st[3], st[4], st[5], st[2])
+
+
+@pytest.mark.parametrize('preset,n_cam', [('literature/static_lss_setting.yml', 1), ('baseline.yml', 6),
+                                          ('literature/pon_setting.yml', 6)])
+@pytest.mark.parametrize('flags', [0, native.POOL_DETERMINISTIC])
+def test_voxel_pool_vs_oracle(hip, preset, n_cam, flags):
+    cfg = get_preset_cfg(preset)
+    grid, (res, start, dim) = _grid_of(cfg)
+    lifted, geo = _pool_case(cfg, n_cam, 1)
+    x = lifted.to(DEV)
+    f, n, C, D, h, w = x.shape
+    out = hip.voxel_pool(x, _native_strides(x), torch.from_numpy(geo).to(DEV), f, n, D, h, w, C, grid, flags=flags)
+    pts = ls.lifted_to_points(lifted[0].numpy())
+    exact = ls.voxel_pool_exact(pts, geo[0].reshape(-1, 3), res, start, dim)
+    ref = ls.voxel_pool_reference(pts, geo[0].reshape(-1, 3), res, start, dim)
+    got = out[0].cpu().numpy()
+    assert np.abs(got - exact).max() < 2e-5          # a plain fp32 segmented sum sits ~1e-6 from the truth
+    assert np.abs(got - ref).max() < TOL             # the reference's prefix-sum trick is the noisy one
+    if flags:
+        again = hip.voxel_pool(x, _native_strides(x), torch.from_numpy(geo).to(DEV), f, n, D, h, w, C, grid, flags=flags)
+        assert torch.equal(again, out)               # bit-reproducible mode
+
+
+def test_voxel_pool_full_baseline_size_properties(hip):
+    """baseline.yml at batch 3 (9 frames x 6 cameras, 1.1 GB of lifted features): mass conservation
+    (a checksum of checksums) and linearity, which need no oracle pass over the full tensor."""
+    cfg = get_preset_cfg('baseline.yml')
+    grid, (res, start, dim) = _grid_of(cfg)
+    frames, n_cam = 9, 6
+    frustum = _frustum(cfg)
+    D, fh, fw = frustum.shape[:3]
+    _, K, E, _ = make_inputs(3, 3, n_cam, with_image=False)
+    geo = hip.lift_geometry(torch.from_numpy(frustum).to(DEV),
+                            hip.camera_matrices(K.view(-1, 3, 3).to(DEV), E.view(-1, 4, 4).to(DEV))).view(frames, n_cam, D, fh, fw, 3)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(frames, n_cam, 64, D, fh, fw, device=DEV, generator=g)
+    y = torch.randn(frames, n_cam, 64, D, fh, fw, device=DEV, generator=g)
+    px = hip.voxel_pool(x, _native_strides(x), geo, frames, n_cam, D, fh, fw, 64, grid)
+    rank, _ = hip.voxel_index(geo, grid, want_idx=False)
+    keep = (rank >= 0).view(frames, n_cam, 1, D, fh, fw)
+    want_mass = (x.double() * keep).sum(dim=(1, 3, 4, 5))                 # (frames, C)
+    got_mass = px.double().sum(dim=(2, 3))
+    assert torch.allclose(got_mass, want_mass, rtol=0, atol=2e-2 * 1e-2 + 1e-3)
+    py = hip.voxel_pool(y, _native_strides(y), geo, frames, n_cam, D, fh, fw, 64, grid)
+    z = 0.5 * x + 2.0 * y
+    pz = hip.voxel_pool(z, _native_strides(z), geo, frames, n_cam, D, fh, fw, 64, grid)
+    assert (pz - (0.5 * px + 2.0 * py)).abs().max() < 1e-4
+    assert ((px != 0).sum(dim=1) > 0).float().mean() > 0.2              # occupancy is in the expected range
+
+
+def test_fused_lift_splat_equals_pooling_of_the_outer_product(hip):
+    cfg = get_preset_cfg('baseline.yml')
+    grid, (res, start, dim) = _grid_of(cfg)
+    frustum = _frustum(cfg)
+    D, fh, fw = frustum.shape[:3]
+    _, K, E, _ = make_inputs(1, 2, 6, with_image=False)
+    geo = torch.from_numpy(ls.get_geometry(frustum, K[0].numpy(), E[0].numpy())).to(DEV)
+    dl, ft, lifted = make_lifted_features(12, 64, D, (fh, fw), seed=2)
+    prob = hip.depth_softmax(dl.to(DEV))
+    assert torch.allclose(prob.cpu(), dl.softmax(dim=1), atol=1e-6)
+    fused = hip.lift_splat(prob, ft.to(DEV), geo, 2, 6, D, fh, fw, 64, grid)
+    x = lifted.view(2, 6, 64, D, fh, fw).to(DEV)
+    unfused = hip.voxel_pool(x, _native_strides(x), geo, 2, 6, D, fh, fw, 64, grid)
+    assert (fused - unfused).abs().max() < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------------
+# convolution kernel at the real shapes vs torch fp32 (CPU)
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('cin,cout,k,stride', [(64, 64, 3, 1), (64, 32, 1, 1), (64, 64, 7, 2), (32, 32, 3, 1),
+                                               (128, 256, 3, 2)])
+def test_conv_igemm_real_shapes(hip, cin, cout, k, stride):
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(cin + cout + k)
+    x = torch.randn(2, cin, 200, 200, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    src = Buf(x.permute(0, 2, 3, 1).contiguous().to(DEV), 2, 200, 200, cin)
+    op = ConvOp(hip, w, identity_chan_map(cin), (cin // 8, 0), sc, sh, DEV, stride=stride, act=native.ACT_RELU)
+    ho, wo = op.out_hw(200, 200)
+    out = Buf.alloc(2, ho, wo, cout, DEV)
+    op([src], out)
+    want = F.relu(F.conv2d(x, w, stride=stride, padding=(k - 1) // 2) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    assert (out.to_nchw().cpu() - want).abs().max() < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------------
+# whole hot path
+# ------------------------------------------------------------------------------------------------------
+def _model(cfg):
+    torch.manual_seed(0)
+    model = Fiery(cfg).eval()
+    sd = randomise_weights(model)
+    return model.to(DEV), sd
+
+
+def _check_against_fixture(out, gold, sub):
+    for k, v in out.items():
+        if v is None:
+            continue
+        a = v.cpu().numpy()
+        if a.ndim == 5:
+            scale = max(1.0, float(gold[k + '_absmax']))
+            assert np.abs(a[..., ::sub, ::sub] - gold[k + '_sub']).max() <= TOL * scale, k
+            assert np.abs(a.mean(axis=(-1, -2)) - gold[k + '_mean']).max() <= TOL * scale, k
+        elif k in gold:
+            assert np.abs(a - gold[k]).max() <= TOL, k
+
+
+@pytest.mark.parametrize('fixture,preset,tiny,B,n_cam,sub,labels', [
+    ('forward_tiny_baseline.npz', 'baseline.yml', True, 2, 2, 1, True),
+    ('forward_tiny_static.npz', 'literature/static_lss_setting.yml', True, 1, 2, 1, False),
+    ('forward_static_lss_1cam.npz', 'literature/static_lss_setting.yml', False, 1, 1, 8, False),   # BASELINE.json configs[0]
+    ('forward_baseline_b1.npz', 'baseline.yml', False, 1, 6, 8, False),                              # configs[1] at batch 1
+])
+def test_hot_path_against_reference_fixture(hip, fixture, preset, tiny, B, n_cam, sub, labels):
+    cfg = tiny_cfg(preset) if tiny else get_preset_cfg(preset)
+    model, sd = _model(cfg)
+    lifted, K, E, ego, lab, noise = forward_case(cfg, model.receptive_field, model.n_future, model.depth_channels,
+                                                 model.bev_size, B, n_cam, labels, labels)
+    dev = lambda t: None if t is None else t.to(DEV)
+    with torch.no_grad():
+        out = model.bev_forward(dev(lifted), dev(K), dev(E), dev(ego), dev(lab), dev(noise))
+    _check_against_fixture(out, np.load(os.path.join(GOLD, fixture)), sub)
+
+
+def test_hot_path_baseline_batch3_against_live_oracle_and_fused_variant(hip):
+    """BASELINE.json configs[1]: baseline.yml, 6 cams x 3 frames, batch 3, fp32 - every output element."""
+    cfg = get_preset_cfg('baseline.yml')
+    model, sd = _model(cfg)
+    B, n = 3, 6
+    rf, D = model.receptive_field, model.depth_channels
+    _, K, E, ego = make_inputs(B, rf + model.n_future, n, with_image=False)
+    dl, ft, lifted = make_lifted_features(B * rf * n, 64, D, (28, 60), seed=1)
+    lifted = lifted.view(B, rf, n, 64, D, 28, 60)
+    with torch.no_grad():
+        want = bev_stack.bev_hot_path(sd, cfg, lifted, K, E, ego)
+        got = model.bev_forward(lifted.to(DEV), K.to(DEV), E.to(DEV), ego.to(DEV))
+        fused = model.bev_forward(None, K.to(DEV), E.to(DEV), ego.to(DEV),
+                                  depth_logits=dl.view(B, rf, n, D, 28, 60).to(DEV), features=ft.view(B, rf, n, 64, 28, 60).to(DEV))
+    for k, v in want.items():
+        if v is None:
+            assert got[k] is None
+            continue
+        scale = max(1.0, v.abs().max().item())
+        assert (got[k].cpu() - v).abs().max().item() <= TOL * scale, k
+        assert (fused[k].cpu() - v).abs().max().item() <= TOL * scale, k
+
+
+def test_method_seams_keep_the_reference_signatures(hip):
+    cfg = tiny_cfg('baseline.yml')
+    model, sd = _model(cfg)
+    image, K, E, ego = make_inputs(1, 7, 2, image_hw=(64, 96))
+    image, K, E, ego = image.to(DEV), K.to(DEV), E.to(DEV), ego.to(DEV)
+    with torch.no_grad():
+        geo = model.get_geometry(K[:, 0], E[:, 0])
+        assert geo.shape == (1, 2, model.depth_channels, 8, 12, 3)
+        x = model.encoder_forward(image[:, 0])
+        assert x.shape == (1, 2, model.depth_channels, 8, 12, 64) and not x.is_contiguous()
+        bev = model.projection_to_birds_eye_view(x, geo)
+        assert bev.shape == (1, 64, 16, 16)
+        pts = ls.lifted_to_points(x[0].permute(0, 4, 1, 2, 3).cpu().numpy())
+        res, start, dim = ls.bev_parameters(cfg.LIFT.X_BOUND, cfg.LIFT.Y_BOUND, cfg.LIFT.Z_BOUND)
+        exact = ls.voxel_pool_exact(pts, geo[0].cpu().numpy().reshape(-1, 3), res, start, dim)
+        assert np.abs(bev[0].cpu().numpy() - exact).max() < 1e-4 * max(1.0, np.abs(exact).max())
+        feats = model.calculate_birds_eye_view_features(image[:, :3], K[:, :3], E[:, :3])
+        assert feats.shape == (1, 3, 64, 16, 16)
+        assert torch.allclose(feats[0, 0], bev[0], atol=1e-4 * max(1.0, bev.abs().max().item()))
+        out = model(image, K, E, ego)
+        assert out['segmentation'].shape == (1, 5, 2, 16, 16) and out['present_mu'].shape == (1, 1, 32)
+        assert all(torch.isfinite(v).all() for v in out.values() if v is not None)
+        sample, dist = model.distribution_forward(torch.randn(1, 1, 64, 16, 16, device=DEV))
+        assert sample.shape == (1, 1, 32, 16, 16) and dist['future_mu'] is None
+    model.train()
+    with pytest.raises(RuntimeError, match='eval'):
+        model(image, K, E, ego)

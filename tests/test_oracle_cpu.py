@@ -1,0 +1,109 @@
+"""Pins the oracle (oracle/) against the committed golden fixtures the REFERENCE produced
+(tests/golden/make_golden.py).  Runs anywhere, no GPU, no reference tree."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fiery_amd.config import get_preset_cfg
+from fiery_amd.synthetic import camera_rig, make_inputs
+from oracle import bev_stack
+from oracle import lift_splat as ls
+from tests.helpers import forward_case, randomise_weights, tiny_cfg
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _load(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+@pytest.mark.parametrize('name,preset,n_cam', [('baseline', 'baseline.yml', 6), ('pon', 'literature/pon_setting.yml', 6),
+                                               ('fishing', 'literature/fishing_setting.yml', 6),
+                                               ('lyft7', 'lyft/baseline.yml', 7)])
+@pytest.mark.parametrize('jitter', [True, False])
+def test_index_path_matches_reference_fixture(name, preset, n_cam, jitter):
+    gold = _load('index_path.npz')
+    cfg = get_preset_cfg(preset)
+    res, start, dim = ls.bev_parameters(cfg.LIFT.X_BOUND, cfg.LIFT.Y_BOUND, cfg.LIFT.Z_BOUND)
+    frustum = ls.create_frustum(cfg.IMAGE.FINAL_DIM, cfg.MODEL.ENCODER.DOWNSAMPLE, cfg.LIFT.D_BOUND)
+    _, K, E, _ = make_inputs(1, 1, n_cam, with_image=False, jitter=jitter)
+    geo = ls.get_geometry(frustum, K[:, 0].numpy(), E[:, 0].numpy())
+    idx, keep, rank = ls.voxel_indices(geo.reshape(-1, 3), res, start, dim)
+    rank = np.where(keep, rank, -1)
+    key = f'{name}_{"jit" if jitter else "axis"}'
+    assert np.array_equal(geo.reshape(-1, 3)[::9973], gold[key + '_geo_sample'])       # geometry bit-exact
+    assert keep.sum() == gold[key + '_n_kept']
+    assert np.unique(rank[keep]).size == gold[key + '_n_voxels']
+    assert rank.sum() == gold[key + '_rank_sum']
+    assert (rank * (np.arange(rank.size) % 1009)).sum() == gold[key + '_rank_wsum']
+    assert np.array_equal(rank[::97].astype(np.int32), gold[key + '_rank_sample'])
+
+
+def test_bev_dimension_truncation_quirk():
+    """fishing_setting.yml: Y = [-9.6, 9.7, 0.1] gives 192 cells, not 193 (reference: geometry.py:55-56)."""
+    cfg = get_preset_cfg('literature/fishing_setting.yml')
+    _, _, dim = ls.bev_parameters(cfg.LIFT.X_BOUND, cfg.LIFT.Y_BOUND, cfg.LIFT.Z_BOUND)
+    assert dim.tolist() == [320, 192, 1]
+
+
+@pytest.mark.parametrize('n,jitter', [(1, True), (6, True), (6, False), (7, True), (8, True)])
+def test_closed_form_intrinsics_inverse_equals_lapack_on_the_test_rigs(n, jitter):
+    K, _ = camera_rig(n, jitter=jitter)
+    assert np.array_equal(torch.inverse(K).numpy(), ls.canonical_intrinsics_inverse(K.numpy()))
+
+
+def test_pooling_small_fixture():
+    gold = _load('pooling_small.npz')
+    cfg = tiny_cfg('baseline.yml', bev=16)
+    res, start, dim = ls.bev_parameters(cfg.LIFT.X_BOUND, cfg.LIFT.Y_BOUND, cfg.LIFT.Z_BOUND)
+    frustum = ls.create_frustum(cfg.IMAGE.FINAL_DIM, 8, cfg.LIFT.D_BOUND)
+    geo = ls.get_geometry(frustum, gold['intrinsics'], gold['extrinsics'])
+    assert np.array_equal(geo, gold['geometry'])
+    for f in range(2):
+        pts = ls.lifted_to_points(gold['lifted'][f])
+        got = ls.voxel_pool_reference(pts, geo[f].reshape(-1, 3), res, start, dim)
+        exact = ls.voxel_pool_exact(pts, geo[f].reshape(-1, 3), res, start, dim)
+        assert np.abs(got - gold['bev'][f]).max() < 1e-5
+        assert np.abs(exact - gold['bev'][f]).max() < 1e-4       # the reference's own prefix-sum noise
+
+
+def _oracle_forward(cfg, B, n_cam, with_labels=False, with_noise=False):
+    from fiery_amd.model import Fiery
+    torch.manual_seed(0)
+    model = Fiery(cfg).eval()
+    sd = randomise_weights(model)
+    lifted, K, E, ego, labels, noise = forward_case(cfg, model.receptive_field, model.n_future, model.depth_channels,
+                                                    model.bev_size, B, n_cam, with_labels, with_noise)
+    with torch.no_grad():
+        return bev_stack.bev_hot_path(sd, cfg, lifted, K, E, ego, noise)
+
+
+def _check_forward(out, gold, sub, tol=1e-4):
+    for k, v in out.items():
+        if v is None:
+            assert k + '_sub' not in gold and k not in gold
+            continue
+        a = v.numpy()
+        if a.ndim == 5:
+            scale = max(1.0, float(gold[k + '_absmax']))
+            assert np.abs(a[..., ::sub, ::sub] - gold[k + '_sub']).max() <= tol * scale, k
+            assert np.abs(a.mean(axis=(-1, -2)) - gold[k + '_mean']).max() <= tol * scale, k
+        else:
+            assert np.abs(a - gold[k]).max() <= tol, k
+
+
+def test_forward_tiny_fixtures():
+    out = _oracle_forward(tiny_cfg('baseline.yml'), 2, 2, with_labels=True, with_noise=True)
+    gold = _load('forward_tiny_baseline.npz')
+    out.pop('future_mu'), out.pop('future_log_sigma')       # the oracle's hot path does not take labels
+    _check_forward(out, gold, 1)
+    out = _oracle_forward(tiny_cfg('literature/static_lss_setting.yml'), 1, 2)
+    _check_forward(out, _load('forward_tiny_static.npz'), 1)
+
+
+def test_forward_static_lss_one_camera_full_size():
+    """BASELINE.json configs[0]: literature/static_lss_setting.yml, 1 camera, 200x200 BEV, batch 1."""
+    out = _oracle_forward(get_preset_cfg('literature/static_lss_setting.yml'), 1, 1)
+    _check_forward(out, _load('forward_static_lss_1cam.npz'), 8)

@@ -1,0 +1,77 @@
+"""Pins the oracle against the reference's own code, executed here on the CPU (build container only)."""
+import numpy as np
+import pytest
+import torch
+
+from fiery_amd.synthetic import make_inputs, make_lifted_features
+from oracle import bev_stack
+from oracle import lift_splat as ls
+from tests.helpers import forward_case, randomise_weights, tiny_cfg
+
+pytestmark = pytest.mark.needs_reference
+
+
+@pytest.fixture(scope='module')
+def ref():
+    from oracle.ref_shims import load_reference
+    return load_reference()
+
+
+def test_state_dict_keys_and_shapes_match_reference(ref):
+    from fiery_amd.config import get_preset_cfg
+    from fiery_amd.model import Fiery
+    for preset in ('baseline.yml', 'literature/static_lss_setting.yml', 'literature/pon_setting.yml', 'lyft/baseline.yml'):
+        cfg = get_preset_cfg(preset)
+        theirs = ref.Fiery(cfg).state_dict()
+        ours = Fiery(cfg).state_dict()
+        assert list(theirs) == list(ours), preset
+        for k in theirs:
+            assert theirs[k].shape == ours[k].shape and theirs[k].dtype == ours[k].dtype, (preset, k)
+        ref.Fiery(cfg).load_state_dict(ours, strict=True)
+
+
+def test_geometry_and_pooling_equal_reference_bitwise(ref):
+    cfg = tiny_cfg('baseline.yml', bev=16)
+    torch.manual_seed(0)
+    m = ref.Fiery(cfg).eval()
+    _, K, E, _ = make_inputs(1, 2, 3, with_image=False)
+    _, _, lifted = make_lifted_features(6, 8, m.depth_channels, (8, 12), seed=9)
+    lifted = lifted.view(2, 3, 8, m.depth_channels, 8, 12)
+    with torch.no_grad():
+        geo_ref = m.get_geometry(K[0], E[0]).numpy()
+        bev_ref = m.projection_to_birds_eye_view(lifted.permute(0, 1, 3, 4, 5, 2), torch.from_numpy(geo_ref)).numpy()
+    res, start, dim = ls.bev_parameters(cfg.LIFT.X_BOUND, cfg.LIFT.Y_BOUND, cfg.LIFT.Z_BOUND)
+    geo = ls.get_geometry(m.frustum.numpy(), K[0].numpy(), E[0].numpy())
+    assert np.array_equal(geo, geo_ref)
+    for f in range(2):
+        got = ls.voxel_pool_reference(ls.lifted_to_points(lifted[f].numpy()), geo[f].reshape(-1, 3), res, start, dim)
+        assert np.array_equal(got, bev_ref[f])
+
+
+def test_warp_matches_reference(ref):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 3, 4, 10, 12, generator=g)
+    _, _, _, ego = make_inputs(2, 3, 1, with_image=False)
+    ego[..., 1] = 0.3
+    want = ref.geometry.cumulative_warp_features(x.clone(), ego, mode='bilinear', spatial_extent=(5.0, 6.0))
+    got = bev_stack.cumulative_warp_features(x.clone(), ego, 'bilinear', (5.0, 6.0))
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize('preset,B,labels', [('baseline.yml', 2, True), ('literature/static_lss_setting.yml', 1, False),
+                                             ('literature/pon_setting.yml', 1, False)])
+def test_hot_path_equals_reference_forward(ref, preset, B, labels):
+    from tests.golden.make_golden import run_reference_from_lifted
+    cfg = tiny_cfg(preset)
+    torch.manual_seed(0)
+    m = ref.Fiery(cfg).eval()
+    sd = randomise_weights(m)
+    lifted, K, E, ego, lab, noise = forward_case(cfg, m.receptive_field, m.n_future, m.depth_channels, m.bev_size, B, 2,
+                                                 with_labels=labels, with_noise=labels)
+    want = run_reference_from_lifted(m, lifted, K, E, ego, lab, noise)
+    with torch.no_grad():
+        got = bev_stack.bev_hot_path(sd, cfg, lifted, K, E, ego, noise)
+    for k, v in got.items():
+        if v is None:
+            continue
+        assert torch.allclose(v, want[k], rtol=1e-5, atol=1e-5), k
