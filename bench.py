@@ -44,6 +44,14 @@ def cpu_baseline(cfg, sd, lifted, K, E, ego, runs=2):
     """The oracle (a port of the reference's CPU path on the same ATen CPU kernels) on the host cores, on a
     bounded sample: one batch element of the same workload."""
     from oracle import bev_stack
+    cores = len(os.sched_getaffinity(0))
+    try:                                               # a cgroup CPU quota caps the usable cores below the affinity mask
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    torch.set_num_threads(cores)
     one = [t[:1].cpu() for t in (lifted, K, E, ego)]
     sd_cpu = {k: v.cpu() for k, v in sd.items()}
     with torch.no_grad():
@@ -128,8 +136,12 @@ def main():
             step()
         torch.cuda.synchronize()
         recs, ops.PROFILE_SINK = ops.PROFILE_SINK, None
-        conv = [(s.elapsed_time(e) * 1e-3, w) for k, s, e, w in recs if k == 'conv_igemm']
-        pool = [(s.elapsed_time(e) * 1e-3, w) for k, s, e, w in recs if k == 'voxel_pool']
+        conv = [(s.elapsed_time(e) * 1e-3, w) for k, s, e, w, _ in recs if k == 'conv_igemm']
+        pool = [(s.elapsed_time(e) * 1e-3, w) for k, s, e, w, _ in recs if k == 'voxel_pool']
+        dump = os.environ.get('FIERY_BENCH_DUMP')
+        if dump:                                           # per-launch table for kernel tuning
+            rows = [dict(kind=k, us=round(s.elapsed_time(e) * 1e3, 2), work=w, detail=d) for k, s, e, w, d in recs]
+            json.dump(rows, open(dump, 'w'))
         t_conv, f_conv = sum(t for t, _ in conv), sum(w for _, w in conv)
         achieved = f_conv / t_conv / 1e12
         roofline = {'kernel': 'k_conv_igemm (fp32 MFMA implicit GEMM)', 'bound': 'mfma', 'achieved': round(achieved, 2),

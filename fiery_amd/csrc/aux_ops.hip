@@ -65,6 +65,24 @@ __global__ void k_rowwise_dense(const float* __restrict__ v, int v_ld, int rows,
     *dst = fminf(fmaxf(apply_act(fmaf(acc, sc, sh), act), lo), hi);
 }
 
+// one thread per (row, channel): a dependent chain of fp32 additions, on purpose (see fiery_hip.h)
+__global__ void k_sequential_window_mean(const float* __restrict__ prev, const float* __restrict__ cur, int rows, int n,
+                                         int count_each, float* __restrict__ out, int out_ld) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * n) return;
+    const int r = i / n, j = i - r * n;
+    float s = 0.f;
+    int total = count_each;
+    if (prev) {
+        const float v = prev[static_cast<long long>(r) * n + j];
+        for (int k = 0; k < count_each; ++k) s += v;
+        total += count_each;
+    }
+    const float v = cur[static_cast<long long>(r) * n + j];
+    for (int k = 0; k < count_each; ++k) s += v;
+    out[static_cast<long long>(r) * out_ld + j] = s / static_cast<float>(total);
+}
+
 __global__ void k_latent_sample(const float* __restrict__ mu, const float* __restrict__ log_sigma,
                                 const float* __restrict__ noise, int ld, int rows, int n, float* __restrict__ sample,
                                 int sample_ld) {
@@ -199,6 +217,14 @@ extern "C" int fiery_rowwise_dense(const float* v, int v_ld, int rows, int n_in,
     hipLaunchKernelGGL(k_rowwise_dense, dim3(ceil_div(rows * n_out, 128)), dim3(128), 0, as_stream(stream), v, v_ld, rows,
                        n_in, W, w_ld, w_col0, n_out, w_mul, scale, shift, act, accumulate, lo, hi, y, y_ld);
     return check_launch("rowwise_dense");
+}
+
+extern "C" int fiery_sequential_window_mean(const float* prev, const float* cur, int rows, int n, int count_each, float* out,
+                                            int out_ld, fiery_stream_t stream) {
+    FIERY_REQUIRE(cur && out && rows > 0 && n > 0 && count_each > 0 && out_ld >= n, "sequential_window_mean: bad argument");
+    hipLaunchKernelGGL(k_sequential_window_mean, dim3(ceil_div(rows * n, 64)), dim3(64), 0, as_stream(stream), prev, cur,
+                       rows, n, count_each, out, out_ld);
+    return check_launch("sequential_window_mean");
 }
 
 extern "C" int fiery_latent_sample(const float* mu, const float* log_sigma, const float* noise, int ld, int rows, int n,

@@ -73,8 +73,9 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     const int wm = wv % WM, wn = wv / WM;
     const int m = lane & 31, hi = lane >> 5;
     const int tile_n = blockIdx.y;
-    const long long pix0 = static_cast<long long>(blockIdx.x) * BM;
+    const int pix0 = blockIdx.x * BM;          // M < 2^31 is checked on the host: 32-bit pixel arithmetic throughout
     const int HWout = p.Hout * p.Wout;
+    const int M = static_cast<int>(p.M);
 
     // ---- this thread's share of the A gather: one 16-byte slot of 4 pixels per stage ----------------
     const int f4 = tid & 7;                // logical 16-byte slot inside the 32-k row
@@ -83,11 +84,11 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     bool pvalid[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const long long gp = pix0 + prow + 32 * j;
-        pvalid[j] = gp < p.M;
-        const long long g = pvalid[j] ? gp : 0;
-        const int o = static_cast<int>(g / HWout);
-        const int rem = static_cast<int>(g - static_cast<long long>(o) * HWout);
+        const int gp = pix0 + prow + 32 * j;
+        pvalid[j] = gp < M;
+        const int g = pvalid[j] ? gp : 0;
+        const int o = g / HWout;
+        const int rem = g - o * HWout;
         const int y = rem / p.Wout, x = rem - y * p.Wout;
         pb[j] = o / p.Tout;
         pt[j] = o - pb[j] * p.Tout;
@@ -191,13 +192,21 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     const int half = p.cout_pad >> 1;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
+        // image / in-image pixel of this lane's first row; the other 15 rows are small constant offsets away,
+        // so one division per tile instead of one per element
+        const int gp_base = pix0 + wm * (32 * MT) + t * 32 + 4 * hi;
+        const int o_base = gp_base / HWout;
+        const int pp_base = gp_base - o_base * HWout;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const long long gp = pix0 + wm * (32 * MT) + t * 32 + row;
-            if (gp >= p.M) continue;
-            const int o = static_cast<int>(gp / HWout);
-            const long long pp = gp - static_cast<long long>(o) * HWout;
+            const int off = (r & 3) + 8 * (r >> 2);
+            if (gp_base + off >= M) continue;
+            int o = o_base, ppi = pp_base + off;
+            while (ppi >= HWout) {
+                ppi -= HWout;
+                ++o;
+            }
+            const long long pp = ppi;
             float v = acc[t][r];
             if (p.img_bias) v += p.img_bias[static_cast<long long>(o) * p.cout_pad + co];
             v = fmaf(v, sc, sh);
@@ -349,6 +358,7 @@ extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) {
     FIERY_REQUIRE(d->Hin > 0 && d->Win > 0 && d->Hout > 0 && d->Wout > 0, "conv_fwd: bad spatial shape");
     FIERY_REQUIRE(d->cout_pad > 0 && d->cout_pad % 32 == 0, "conv_fwd: cout_pad must be a multiple of 32");
     FIERY_REQUIRE(d->cout_store > 0 && d->cout_store <= d->cout_pad, "conv_fwd: bad cout_store");
+    FIERY_REQUIRE(static_cast<long long>(d->n_img_out) * d->Hout * d->Wout < (1ll << 31) - 256, "conv_fwd: more than 2^31 output pixels");
     for (int s = 0; s < 2; ++s) {
         if (d->src[s].units == 0) continue;
         FIERY_REQUIRE(aligned16(d->src[s].ptr) && d->src[s].ld % 4 == 0 && d->src[s].batch_stride % 4 == 0 &&

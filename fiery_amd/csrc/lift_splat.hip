@@ -149,9 +149,14 @@ __global__ void k_voxel_index(const float* __restrict__ geometry, long long n, G
     }
 }
 
-// One thread per image column (frame*camera, d, w): ranks of its H points + the column class.
+constexpr int kMaxTiles = 30;          // tile membership is a bit mask in an int
+constexpr int kPackW = 10, kPackD = 10;   // list entries pack (camera, d, w) into one int
+
+// One thread per image column (frame*camera, d, w): ranks of its H points, the column class and the set of
+// output tiles the column touches.
 __global__ void k_rank_columns(const float* __restrict__ geometry, int n_fc, int D, int H, int W, GridParams p,
-                               int* __restrict__ rank, int* __restrict__ coldesc) {
+                               int tile_vox, int* __restrict__ rank, int* __restrict__ coldesc,
+                               int* __restrict__ colmask) {
     const long long col = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     const long long n_cols = static_cast<long long>(n_fc) * D * W;
     if (col >= n_cols) return;
@@ -160,7 +165,7 @@ __global__ void k_rank_columns(const float* __restrict__ geometry, int n_fc, int
     const long long base = fd * H * W + w;                 // point index of (.., h = 0, w)
     int first = -3;
     bool uniform = true;
-    bool any = false;
+    int mask = 0;
     for (int h = 0; h < H; ++h) {
         const long long pt = base + static_cast<long long>(h) * W;
         const float* g = geometry + 3 * pt;
@@ -168,9 +173,50 @@ __global__ void k_rank_columns(const float* __restrict__ geometry, int n_fc, int
         rank[pt] = r;
         if (h == 0) first = r;
         uniform = uniform && (r == first);
-        any = any || (r >= 0);
+        if (r >= 0) mask |= 1 << (r / tile_vox);
     }
-    coldesc[col] = !any ? kColEmpty : ((uniform && first >= 0) ? first : kColMixed);
+    coldesc[col] = mask == 0 ? kColEmpty : ((uniform && first >= 0) ? first : kColMixed);
+    colmask[col] = mask;
+}
+
+// Ordered (ascending column id) list of the columns that touch one tile of one frame: adjacent list
+// entries are adjacent columns, so the pooling kernel's wavefront loads stay unit-stride.
+// grid (n_tiles, frames), 1024 threads; entry = {camera<<20 | d<<10 | w, column class}.
+__global__ __launch_bounds__(1024) void k_build_tile_lists(const int* __restrict__ coldesc,
+                                                           const int* __restrict__ colmask, int n_cam, int D, int W,
+                                                           int n_tiles, int2* __restrict__ lists, int* __restrict__ counts) {
+    __shared__ int wave_count[16];
+    __shared__ int running;
+    const int tile = blockIdx.x, f = blockIdx.y;
+    const int n_cols = n_cam * D * W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int* cd = coldesc + static_cast<long long>(f) * n_cols;
+    const int* cm = colmask + static_cast<long long>(f) * n_cols;
+    int2* out = lists + (static_cast<long long>(f) * n_tiles + tile) * n_cols;
+    if (threadIdx.x == 0) running = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n_cols; c0 += 1024) {
+        const int col = c0 + threadIdx.x;
+        const bool hit = col < n_cols && ((cm[col] >> tile) & 1);
+        const unsigned long long ballot = __ballot(hit);
+        const int before = __popcll(ballot & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_count[wave] = __popcll(ballot);
+        __syncthreads();
+        int offset = running;
+        for (int k = 0; k < wave; ++k) offset += wave_count[k];
+        if (hit) {
+            const int w = col % W, nd = col / W;
+            out[offset + before] = make_int2(((nd / D) << (kPackW + kPackD)) | ((nd % D) << kPackW) | w, cd[col]);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int total = 0;
+            for (int k = 0; k < 16; ++k) total += wave_count[k];
+            running += total;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) counts[f * n_tiles + tile] = running;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -200,12 +246,14 @@ template <> struct Cell<true> {
     }
 };
 
+constexpr int kRowsInRegs = 32;   // columns of up to this many rows are held in registers
+
 template <bool kFused, bool kFixed>
 __global__ __launch_bounds__(256) void k_voxel_pool(
     const float* __restrict__ x, PoolStrides xs,            // unfused: the lifted tensor
     const float* __restrict__ depth, const float* __restrict__ feat,   // fused: depth prob + features
-    const int* __restrict__ rank, const int* __restrict__ coldesc, float* __restrict__ out,
-    int n_cam, int D, int H, int W, int C, int n_vox, int tile_vox) {
+    const int* __restrict__ rank, const int2* __restrict__ lists, const int* __restrict__ counts,
+    float* __restrict__ out, int n_cam, int D, int H, int W, int C, int n_vox, int tile_vox, int n_tiles) {
     using cell_t = typename Cell<kFixed>::type;
     HIP_DYNAMIC_SHARED(unsigned char, pool_lds)
     cell_t* plane = reinterpret_cast<cell_t*>(pool_lds);
@@ -217,17 +265,16 @@ __global__ __launch_bounds__(256) void k_voxel_pool(
     __syncthreads();
 
     const int n_cols = n_cam * D * W;
-    const int* cd = coldesc + static_cast<long long>(f) * n_cols;
+    const int2* lst = lists + (static_cast<long long>(f) * n_tiles + tile) * n_cols;
+    const int count = counts[f * n_tiles + tile];
     const int HW = H * W;
-    for (int col = threadIdx.x; col < n_cols; col += blockDim.x) {
-        const int desc = cd[col];
-        if (desc == kColEmpty) continue;
-        if (desc >= 0 && (desc < v0 || desc >= v1)) continue;
-        const int w = col % W;
-        const int nd = col / W;
-        const int d = nd % D;
-        const int cam = nd / D;
-        // element (h) of this column lives at p[h * step]; fused: value = depth[h] * feature[h]
+    for (int i = threadIdx.x; i < count; i += blockDim.x) {
+        const int2 e = lst[i];
+        const int w = e.x & ((1 << kPackW) - 1);
+        const int d = (e.x >> kPackW) & ((1 << kPackD) - 1);
+        const int cam = e.x >> (kPackW + kPackD);
+        const int desc = e.y;
+        // row h of this column lives at p[h * step]; fused: value = depth[h] * feature[h]
         const float* p;
         const float* q = nullptr;
         long long step, qstep = 0;
@@ -240,34 +287,49 @@ __global__ __launch_bounds__(256) void k_voxel_pool(
             p = x + f * xs.f + cam * xs.n + d * xs.d + w * xs.w + c * xs.c;
             step = xs.h;
         }
-        if (desc >= 0) {
-            float s = 0.f;
-            int h = 0;
-            for (; h + 4 <= H; h += 4) {
-                float a0 = p[(h + 0) * step], a1 = p[(h + 1) * step], a2 = p[(h + 2) * step], a3 = p[(h + 3) * step];
-                if (kFused) {
-                    a0 *= q[(h + 0) * qstep];
-                    a1 *= q[(h + 1) * qstep];
-                    a2 *= q[(h + 2) * qstep];
-                    a3 *= q[(h + 3) * qstep];
-                }
-                s += a0;
-                s += a1;
-                s += a2;
-                s += a3;
+        const int* rk = rank + ((static_cast<long long>(f) * n_cam + cam) * D + d) * HW + w;
+        if (H <= kRowsInRegs) {
+            // every load of the column is issued before the first use: one memory round trip per column
+            float v[kRowsInRegs];
+#pragma unroll
+            for (int h = 0; h < kRowsInRegs; ++h) v[h] = h < H ? p[h * step] : 0.f;
+            if (kFused) {
+#pragma unroll
+                for (int h = 0; h < kRowsInRegs; ++h) v[h] *= h < H ? q[h * qstep] : 0.f;
             }
-            for (; h < H; ++h) s += kFused ? p[h * step] * q[h * qstep] : p[h * step];
-            Cell<kFixed>::add(&plane[desc - v0], s);
+            if (desc >= 0) {
+                float s = 0.f;
+#pragma unroll
+                for (int h = 0; h < kRowsInRegs; ++h) s += v[h];        // rows >= H add an exact zero
+                Cell<kFixed>::add(&plane[desc - v0], s);
+            } else {
+                int r[kRowsInRegs];
+#pragma unroll
+                for (int h = 0; h < kRowsInRegs; ++h) r[h] = h < H ? rk[h * W] : -1;
+                int cur = -1;
+                float s = 0.f;
+#pragma unroll
+                for (int h = 0; h < kRowsInRegs; ++h) {
+                    const int rr = (r[h] >= v0 && r[h] < v1) ? r[h] : -1;
+                    if (rr != cur) {
+                        if (cur >= 0) Cell<kFixed>::add(&plane[cur - v0], s);
+                        cur = rr;
+                        s = 0.f;
+                    }
+                    if (cur >= 0) s += v[h];
+                }
+                if (cur >= 0) Cell<kFixed>::add(&plane[cur - v0], s);
+            }
         } else {
-            const int* rk = rank + ((static_cast<long long>(f) * n_cam + cam) * D + d) * HW + w;
+            // tall columns: same arithmetic, row by row
             int cur = -1;
             float s = 0.f;
             for (int h = 0; h < H; ++h) {
-                int r = rk[h * W];
-                if (r < v0 || r >= v1) r = -1;
-                if (r != cur) {
+                int rr = desc >= 0 ? desc : rk[h * W];
+                if (rr < v0 || rr >= v1) rr = -1;
+                if (rr != cur) {
                     if (cur >= 0) Cell<kFixed>::add(&plane[cur - v0], s);
-                    cur = r;
+                    cur = rr;
                     s = 0.f;
                 }
                 if (cur >= 0) s += kFused ? p[h * step] * q[h * qstep] : p[h * step];
@@ -314,22 +376,52 @@ extern "C" int fiery_voxel_index(const float* geometry, int64_t n_points, const 
     return check_launch("voxel_index");
 }
 
-extern "C" size_t fiery_voxel_pool_workspace_bytes(int frames, int n_cameras, int D, int H, int W) {
-    const size_t points = static_cast<size_t>(frames) * n_cameras * D * H * W;
-    const size_t cols = static_cast<size_t>(frames) * n_cameras * D * W;
-    return (points + cols) * sizeof(int32_t) + 256;
+namespace {
+
+struct PoolPlan {
+    int n_vox, tile, n_tiles;
+    size_t lds, off_coldesc, off_colmask, off_counts, off_lists, total;
+};
+
+// LDS tile of the output plane.  40 KiB tiles keep four workgroups per CU resident (160 KiB LDS); the tile
+// grows when the grid would otherwise need more than kMaxTiles tiles.
+int plan_pool(int frames, int n_cam, int D, int H, int W, long long n_vox_ll, int requested, bool fixed, PoolPlan* pl) {
+    FIERY_REQUIRE(n_vox_ll > 0 && n_vox_ll < (1ll << 30), "voxel_pool: bad grid size");
+    FIERY_REQUIRE(W < (1 << kPackW) && D < (1 << kPackD) && n_cam < (1 << (31 - kPackW - kPackD)),
+                  "voxel_pool: feature map too large for the column encoding (W, D < 1024, cameras < 2048)");
+    const int cell_bytes = fixed ? 8 : 4;
+    const int cap = 160000 / cell_bytes;
+    pl->n_vox = static_cast<int>(n_vox_ll);
+    int tile = requested > 0 ? requested : 40960 / cell_bytes;
+    if (tile > cap) tile = cap;
+    if (tile > pl->n_vox) tile = pl->n_vox;
+    if (ceil_div(pl->n_vox, tile) > kMaxTiles) tile = ceil_div(pl->n_vox, kMaxTiles);
+    FIERY_REQUIRE(tile <= cap, "voxel_pool: a %d-voxel grid needs more than %d LDS tiles", pl->n_vox, kMaxTiles);
+    pl->tile = tile;
+    pl->n_tiles = ceil_div(pl->n_vox, tile);
+    pl->lds = static_cast<size_t>(tile) * cell_bytes;
+    const size_t points = static_cast<size_t>(frames) * n_cam * D * H * W;
+    const size_t cols = static_cast<size_t>(frames) * n_cam * D * W;
+    auto align = [](size_t v) { return (v + 255) / 256 * 256; };
+    pl->off_coldesc = align(points * 4);
+    pl->off_colmask = align(pl->off_coldesc + cols * 4);
+    pl->off_counts = align(pl->off_colmask + cols * 4);
+    pl->off_lists = align(pl->off_counts + static_cast<size_t>(frames) * pl->n_tiles * 4);
+    pl->total = pl->off_lists + cols * pl->n_tiles * sizeof(int2);
+    return FIERY_OK;
+}
+
+}  // namespace
+
+extern "C" size_t fiery_voxel_pool_workspace_bytes(int frames, int n_cameras, int D, int H, int W, int n_voxels,
+                                                   int tile_voxels, uint32_t flags) {
+    PoolPlan pl;
+    if (frames <= 0 || n_cameras <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    if (plan_pool(frames, n_cameras, D, H, W, n_voxels, tile_voxels, (flags & FIERY_POOL_DETERMINISTIC) != 0, &pl)) return 0;
+    return pl.total;
 }
 
 namespace {
-
-int choose_tile(int n_vox, int requested, int cell_bytes) {
-    // LDS tile of the output plane.  40 KiB tiles keep four workgroups per CU resident (160 KiB LDS).
-    const int cap = 160000 / cell_bytes;            // 160,000 B: a whole 200x200 fp32 plane, one workgroup per CU
-    int tile = requested > 0 ? requested : 40960 / cell_bytes;
-    if (tile > cap) tile = cap;
-    if (tile > n_vox) tile = n_vox;
-    return tile;
-}
 
 int pool_common(bool fused, const float* x, const int64_t* xs, const float* depth, const float* feat,
                 const float* geometry, int frames, int n_cam, int D, int H, int W, int C,
@@ -342,36 +434,38 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
                   "(fiery/models/fiery.py:268-271)", grid->dim[2]);
     FIERY_REQUIRE(grid->dim[0] > 0 && grid->dim[1] > 0, "voxel_pool: empty grid");
     FIERY_REQUIRE((flags & ~FIERY_POOL_DETERMINISTIC) == 0, "voxel_pool: unknown flags 0x%x", flags);
-    const size_t need = fiery_voxel_pool_workspace_bytes(frames, n_cam, D, H, W);
-    if (ws_bytes < need) return fail(FIERY_ENOMEM, "voxel_pool: workspace %zu B < required %zu B", ws_bytes, need);
-    const long long n_vox_ll = static_cast<long long>(grid->dim[0]) * grid->dim[1];
-    FIERY_REQUIRE(n_vox_ll < (1ll << 30), "voxel_pool: grid too large");
-    const int n_vox = static_cast<int>(n_vox_ll);
-    const long long points = static_cast<long long>(frames) * n_cam * D * H * W;
-    int* rank = static_cast<int*>(workspace);
-    int* coldesc = rank + points;
-    const long long n_cols_all = static_cast<long long>(frames) * n_cam * D * W;
-    hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(k_rank_columns, dim3(ceil_div(n_cols_all, 256)), dim3(256), 0, s, geometry, frames * n_cam, D, H,
-                       W, to_params(*grid), rank, coldesc);
-    int rc = check_launch("rank_columns");
-    if (rc) return rc;
     const bool fixed = (flags & FIERY_POOL_DETERMINISTIC) != 0;
-    const int cell_bytes = fixed ? 8 : 4;
-    const int tile = choose_tile(n_vox, tile_voxels, cell_bytes);
-    const int n_tiles = ceil_div(n_vox, tile);
-    const size_t lds = static_cast<size_t>(tile) * cell_bytes;
-    dim3 gridDim3(n_tiles, C, frames);
-    PoolStrides st{0, 0, 0, 0, 0, 0};
+    PoolPlan pl;
+    int rc = plan_pool(frames, n_cam, D, H, W, static_cast<long long>(grid->dim[0]) * grid->dim[1], tile_voxels, fixed, &pl);
+    if (rc) return rc;
+    if (ws_bytes < pl.total) return fail(FIERY_ENOMEM, "voxel_pool: workspace %zu B < required %zu B", ws_bytes, pl.total);
     if (fused) {
         FIERY_REQUIRE(depth && feat, "lift_splat: null pointer");
     } else {
         FIERY_REQUIRE(x && xs, "voxel_pool: null pointer");
-        st = PoolStrides{xs[0], xs[1], xs[2], xs[3], xs[4], xs[5]};
     }
-#define FIERY_POOL_LAUNCH(FUSED, FIXED)                                                                          \
-    hipLaunchKernelGGL((k_voxel_pool<FUSED, FIXED>), gridDim3, dim3(256), lds, s, x, st, depth, feat, rank, coldesc, \
-                       out, n_cam, D, H, W, C, n_vox, tile)
+    char* ws = static_cast<char*>(workspace);
+    int* rank = reinterpret_cast<int*>(ws);
+    int* coldesc = reinterpret_cast<int*>(ws + pl.off_coldesc);
+    int* colmask = reinterpret_cast<int*>(ws + pl.off_colmask);
+    int* counts = reinterpret_cast<int*>(ws + pl.off_counts);
+    int2* lists = reinterpret_cast<int2*>(ws + pl.off_lists);
+    const long long n_cols_all = static_cast<long long>(frames) * n_cam * D * W;
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(k_rank_columns, dim3(ceil_div(n_cols_all, 256)), dim3(256), 0, s, geometry, frames * n_cam, D, H,
+                       W, to_params(*grid), pl.tile, rank, coldesc, colmask);
+    rc = check_launch("rank_columns");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_build_tile_lists, dim3(pl.n_tiles, frames), dim3(1024), 0, s, coldesc, colmask, n_cam, D, W,
+                       pl.n_tiles, lists, counts);
+    rc = check_launch("build_tile_lists");
+    if (rc) return rc;
+    dim3 gridDim3(pl.n_tiles, C, frames);
+    PoolStrides st{0, 0, 0, 0, 0, 0};
+    if (!fused) st = PoolStrides{xs[0], xs[1], xs[2], xs[3], xs[4], xs[5]};
+#define FIERY_POOL_LAUNCH(FUSED, FIXED)                                                                             \
+    hipLaunchKernelGGL((k_voxel_pool<FUSED, FIXED>), gridDim3, dim3(256), pl.lds, s, x, st, depth, feat, rank, lists, \
+                       counts, out, n_cam, D, H, W, C, pl.n_vox, pl.tile, pl.n_tiles)
     if (fused && fixed) FIERY_POOL_LAUNCH(true, true);
     else if (fused) FIERY_POOL_LAUNCH(true, false);
     else if (fixed) FIERY_POOL_LAUNCH(false, true);

@@ -14,6 +14,8 @@ Every intermediate lives in pixel-major (NHWC) buffers owned by this object; the
 no device memory.  Inference (`model.eval()`) only - the backward kernels are a later row of the scope
 table.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -180,13 +182,14 @@ class _TemporalBlock:
                               self.pool['scale'] if last else None, self.pool['shift'] if last else None,
                               RELU if last else NONE, False, z, z.shape[1])
             if self.ego:
-                # the ego-pose channels are constant over a frame: their window mean is the mean of two rows
+                # the ego-pose channels are constant over a frame; ATen's avg_pool3d adds the 2*H*W copies one by
+                # one in fp32, which is reproduced bit for bit (fiery_sequential_window_mean, see fiery_hip.h)
                 prev = ego_in[:, t_out0 - 1:S - 1].reshape(B * T_out, self.ego).contiguous()
                 cur = ego_in[:, t_out0:].reshape(B * T_out, self.ego).contiguous()
-                lib.rowwise_dense(prev, self.ego, B * T_out, self.ego, self.pool['w'], self.cin, self.cf, red, None, None,
-                                  NONE, True, z, z.shape[1], w_mul=0.5)
-                lib.rowwise_dense(cur, self.ego, B * T_out, self.ego, self.pool['w'], self.cin, self.cf, red,
-                                  self.pool['scale'], self.pool['shift'], RELU, True, z, z.shape[1], w_mul=0.5)
+                emean = eng.vec(tag + 'egomean', B * T_out, self.ego)
+                lib.sequential_window_mean(prev, cur, B * T_out, self.ego, H * W, emean, self.ego)
+                lib.rowwise_dense(emean, self.ego, B * T_out, self.ego, self.pool['w'], self.cin, self.cf, red,
+                                  self.pool['scale'], self.pool['shift'], RELU, True, z, z.shape[1])
             agg_bias = eng.vec(tag + 'abias', B * T_out, self.agg.cout_pad)
             lib.rowwise_dense(z, z.shape[1], B * T_out, red, self.pool['wagg'], red, 0, self.cout, None, None, NONE, False,
                               agg_bias, self.agg.cout_pad)
@@ -257,7 +260,7 @@ class BevEngine:
         self.X, self.Y = int(dim[0]), int(dim[1])
         self.extent = model.spatial_extent
         self.frustum = model.frustum.detach().float().contiguous().to(self.device)
-        self.pool_tile = 0
+        self.pool_tile = int(os.environ.get('FIERY_POOL_TILE', '0'))      # voxels per LDS tile, 0 = library default
         self.pool_flags = 0
         self._build()
 
@@ -375,12 +378,17 @@ class BevEngine:
         geo = self.lib.lift_geometry(self.frustum, cam)
         return geo.view(f, n, *geo.shape[1:])
 
+    def _pool_workspace(self, f, n, d, h, w, device):
+        key = ('poolws', f, n, d, h, w, self.pool_tile, self.pool_flags)
+        ws = self._bufs.get(key)
+        if ws is None:
+            ws = self._bufs[key] = self.lib.pool_workspace(f, n, d, h, w, device, self.grid, self.pool_tile, self.pool_flags)
+        return ws
+
     def pool(self, x, geometry):
         """`projection_to_birds_eye_view`: x logical (F, n, D, h, w, C) of any strides -> (F, C, X, Y)."""
         f, n, d, h, w, c = x.shape
-        ws = self._bufs.get(('poolws', f, n, d, h, w))
-        if ws is None:
-            ws = self._bufs[('poolws', f, n, d, h, w)] = self.lib.pool_workspace(f, n, d, h, w, x.device)
+        ws = self._pool_workspace(f, n, d, h, w, x.device)
         # algorithmic bytes of the op: every point's C features + its geometry + the dense output (SURVEY 8d);
         # out-of-grid points are charged too here (an upper bound that needs no device read-back)
         work = 4.0 * c * f * n * d * h * w + 12.0 * f * n * d * h * w + 4.0 * c * f * self.X * self.Y
@@ -393,9 +401,7 @@ class BevEngine:
         f, n, d, h, w = depth_logits.shape
         c = features.shape[2]
         prob = self.lib.depth_softmax(depth_logits.reshape(f * n, d, h, w).contiguous())
-        ws = self._bufs.get(('poolws', f, n, d, h, w))
-        if ws is None:
-            ws = self._bufs[('poolws', f, n, d, h, w)] = self.lib.pool_workspace(f, n, d, h, w, features.device)
+        ws = self._pool_workspace(f, n, d, h, w, features.device)
         return self.lib.lift_splat(prob, features.contiguous(), geometry.contiguous(), f, n, d, h, w, c, self.grid,
                                    workspace=ws, tile_voxels=self.pool_tile, flags=self.pool_flags)
 

@@ -82,7 +82,7 @@ _SIGNATURES = {
     'fiery_camera_matrices': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'fiery_lift_geometry': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'fiery_voxel_index': (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(BevGrid), C.c_void_p, C.c_void_p, C.c_void_p]),
-    'fiery_voxel_pool_workspace_bytes': (C.c_size_t, [C.c_int] * 5),
+    'fiery_voxel_pool_workspace_bytes': (C.c_size_t, [C.c_int] * 7 + [C.c_uint32]),
     'fiery_voxel_pool_fwd': (C.c_int, [C.c_void_p, c_int64_p, C.c_void_p] + [C.c_int] * 6 +
                              [C.POINTER(BevGrid), C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_void_p]),
     'fiery_lift_splat_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6 +
@@ -101,6 +101,7 @@ _SIGNATURES = {
     'fiery_rowwise_dense': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
                                       C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int,
                                       C.c_void_p]),
+    'fiery_sequential_window_mean': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'fiery_latent_sample': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                       C.c_void_p]),
     'fiery_maxpool2x2_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
@@ -158,14 +159,17 @@ class Lib:
         self.check(self.dll.fiery_voxel_index(_ptr(geometry), n, C.byref(grid), _ptr(rank), _ptr(idx), _stream_of(rank)))
         return rank, idx
 
-    def pool_workspace(self, frames, n_cam, d, h, w, device):
-        nbytes = self.dll.fiery_voxel_pool_workspace_bytes(frames, n_cam, d, h, w)
+    def pool_workspace(self, frames, n_cam, d, h, w, device, grid, tile_voxels=0, flags=0):
+        nbytes = self.dll.fiery_voxel_pool_workspace_bytes(frames, n_cam, d, h, w, grid.dim[0] * grid.dim[1],
+                                                           tile_voxels, flags)
+        if nbytes == 0:
+            raise NativeError('libfiery_hip: unusable pooling problem size (see fiery_voxel_pool_workspace_bytes)')
         return torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=device)
 
     def voxel_pool(self, x, strides, geometry, frames, n_cam, d, h, w, c, grid, out=None, workspace=None,
                    tile_voxels=0, flags=0):
         if workspace is None:
-            workspace = self.pool_workspace(frames, n_cam, d, h, w, x.device)
+            workspace = self.pool_workspace(frames, n_cam, d, h, w, x.device, grid, tile_voxels, flags)
         if out is None:
             out = torch.empty(frames, c, grid.dim[0], grid.dim[1], dtype=torch.float32, device=x.device)
         xs = (C.c_int64 * 6)(*strides)
@@ -177,7 +181,7 @@ class Lib:
     def lift_splat(self, depth_prob, features, geometry, frames, n_cam, d, h, w, c, grid, out=None, workspace=None,
                    tile_voxels=0, flags=0):
         if workspace is None:
-            workspace = self.pool_workspace(frames, n_cam, d, h, w, features.device)
+            workspace = self.pool_workspace(frames, n_cam, d, h, w, features.device, grid, tile_voxels, flags)
         if out is None:
             out = torch.empty(frames, c, grid.dim[0], grid.dim[1], dtype=torch.float32, device=features.device)
         self.check(self.dll.fiery_lift_splat_fwd(
@@ -234,6 +238,10 @@ class Lib:
                       w_mul=1.0, lo=float('-inf'), hi=float('inf')):
         self.check(self.dll.fiery_rowwise_dense(_ptr(v), v_ld, rows, n_in, _ptr(w), w_ld, w_col0, n_out, w_mul, _ptr(scale),
                                                 _ptr(shift), act, int(accumulate), lo, hi, _ptr(y), y_ld, _stream_of(y)))
+
+    def sequential_window_mean(self, prev, cur, rows, n, count_each, out, out_ld):
+        self.check(self.dll.fiery_sequential_window_mean(_ptr(prev), _ptr(cur), rows, n, count_each, _ptr(out), out_ld,
+                                                         _stream_of(out)))
 
     def latent_sample(self, mu, log_sigma, noise, ld, rows, n, sample, sample_ld):
         self.check(self.dll.fiery_latent_sample(_ptr(mu), _ptr(log_sigma), _ptr(noise), ld, rows, n, _ptr(sample), sample_ld,

@@ -16,14 +16,14 @@ UNIT = 8          # input channels are consumed in units of 8 floats
 PROFILE_SINK = None
 
 
-def profiled(kind, work, stream_tensor, fn):
+def profiled(kind, work, stream_tensor, fn, detail=None):
     if PROFILE_SINK is None or not stream_tensor.is_cuda:
         return fn()
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     start.record()
     out = fn()
     end.record()
-    PROFILE_SINK.append((kind, start, end, work))
+    PROFILE_SINK.append((kind, start, end, work, detail))
     return out
 
 
@@ -166,7 +166,8 @@ class ConvOp:
         d.aux1 = aux1.as_nhwc_struct() if aux1 is not None else _null_nhwc()
         self._keep = (srcs, out, res, img_bias, out2, aux0, aux1)
         flops = 2.0 * out.n_img * out.H * out.W * self.cin_total * self.kT * self.kH * self.kW * self.cout
-        profiled('conv_igemm', flops, out.tensor, lambda: self.lib.conv_fwd(d, out.tensor))
+        profiled('conv_igemm', flops, out.tensor, lambda: self.lib.conv_fwd(d, out.tensor),
+                 detail=(self.kT, self.kH, self.kW, self.stride, self.cin_total, self.cout, out.n_img, out.H, out.W))
 
 
 def identity_chan_map(channels, offset=0):

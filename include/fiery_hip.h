@@ -70,10 +70,12 @@ typedef struct {
 int fiery_voxel_index(const float* geometry, int64_t n_points, const fiery_bev_grid* grid /* host */,
                       int32_t* rank, int32_t* idx /* [n_points][3] or NULL */, fiery_stream_t stream);
 
-/* Scratch needed by fiery_voxel_pool_fwd for this problem size. */
-size_t fiery_voxel_pool_workspace_bytes(int frames, int n_cameras, int D, int H, int W);
+#define FIERY_POOL_DETERMINISTIC 1u  /* flags: bit-reproducible sums (order-independent fixed point), slower */
 
-#define FIERY_POOL_DETERMINISTIC 1u  /* flags: bit-reproducible sums (fixed order), slower */
+/* Scratch needed by fiery_voxel_pool_fwd / fiery_lift_splat_fwd for this problem (n_voxels = X*Y;
+ * tile_voxels and flags as passed to the pooling call); 0 if the arguments are unusable. */
+size_t fiery_voxel_pool_workspace_bytes(int frames, int n_cameras, int D, int H, int W, int n_voxels,
+                                        int tile_voxels, uint32_t flags);
 
 /* out[f][c][ix][iy] = sum of x over the points of frame f that fall in voxel (ix, iy, 0); voxels no
  * point reaches are 0.
@@ -214,6 +216,15 @@ int fiery_spatial_mean(const float* in, int in_ld, int64_t outer_stride, int n_o
 int fiery_rowwise_dense(const float* v, int v_ld, int rows, int n_in, const float* W, int w_ld, int w_col0,
                         int n_out, float w_mul, const float* scale, const float* shift, int act, int accumulate,
                         float lo, float hi, float* y, int y_ld, fiery_stream_t stream);
+
+/* Average pooling of spatially CONSTANT channels exactly as ATen computes it: avg_pool3d adds the window's
+ * elements one by one in fp32 (t, then y, then x), so 2*H*W additions of a constant round in the same
+ * direction every time and the reference's pooled ego-pose channels (layers/temporal.py:186-191 applied to
+ * the channels fiery.py:148-155 appends) are ~5e-4 off their true mean.  This reproduces that sum bit for bit:
+ * out[r][j] = (count_each additions of prev[r][j], then count_each additions of cur[r][j]) / total count;
+ * prev may be NULL (window clipped at t = 0). */
+int fiery_sequential_window_mean(const float* prev, const float* cur, int rows, int n, int count_each,
+                                 float* out, int out_ld, fiery_stream_t stream);
 
 /* sample[r][j] = mu[r][j] + exp(log_sigma[r][j]) * noise[r][j]   (noise NULL = zeros)
  * (fiery/models/fiery.py:316-327, inference branch). */

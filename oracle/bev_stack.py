@@ -86,10 +86,11 @@ def warp_affine_params(flow, spatial_extent):
 
 
 def warp_features(x, flow, mode, spatial_extent):
-    """fiery/utils/geometry.py:181-222."""
+    """fiery/utils/geometry.py:181-222 (the reference samples with `grid.float()`; `.to(x.dtype)` is the same
+    thing for its fp32 tensors and lets the float64 evaluation below go through)."""
     theta = warp_affine_params(flow, spatial_extent)
     grid = F.affine_grid(theta, size=x.shape, align_corners=False)
-    return F.grid_sample(x, grid.float(), mode=mode, padding_mode='zeros', align_corners=False)
+    return F.grid_sample(x, grid.to(x.dtype), mode=mode, padding_mode='zeros', align_corners=False)
 
 
 def cumulative_warp_thetas(flow, spatial_extent):
@@ -296,18 +297,27 @@ def decoder(x, w):
 # ---------------------------------------------------------------------------------------------
 # whole hot path
 # ---------------------------------------------------------------------------------------------
-def pool_lifted(lifted, geometry, resolution, start, dimension):
+def pool_lifted(lifted, geometry, resolution, start, dimension, exact=False):
     """`projection_to_birds_eye_view` on the encoder's native (F, n, C, D, h, w) layout -> (F, C, X, Y).
-    fiery/models/fiery.py:221-273."""
+    fiery/models/fiery.py:221-273.  exact=True: float64 sums instead of the reference's fp32 prefix-sum trick."""
     frames = []
+    pool = lift_splat.voxel_pool_exact if exact else lift_splat.voxel_pool_reference
     for f in range(lifted.shape[0]):
         pts = lift_splat.lifted_to_points(lifted[f].numpy())
-        frames.append(torch.from_numpy(lift_splat.voxel_pool_reference(
-            pts, geometry[f].reshape(-1, 3), resolution, start, dimension)))
+        frames.append(torch.from_numpy(pool(pts, geometry[f].reshape(-1, 3), resolution, start, dimension)))
     return torch.stack(frames)
 
 
-def bev_hot_path(sd, cfg, lifted, intrinsics, extrinsics, future_egomotion, noise=None):
+def bev_hot_path_exact(sd, cfg, lifted, intrinsics, extrinsics, future_egomotion, noise=None):
+    """The same network evaluated in float64 (weights and activations cast up, exact pooling sums; the voxel
+    indices still come from the fp32 geometry, as they must).  This is the value the reference's fp32 arithmetic
+    approximates; tests use it to measure the reference's own rounding noise and to bound ours."""
+    sd64 = {k: (v.double() if v.is_floating_point() and k != 'frustum' else v) for k, v in sd.items()}
+    return bev_hot_path(sd64, cfg, lifted, intrinsics, extrinsics, future_egomotion.double(),
+                        None if noise is None else noise.double(), exact=True)
+
+
+def bev_hot_path(sd, cfg, lifted, intrinsics, extrinsics, future_egomotion, noise=None, exact=False):
     """`Fiery.forward` from the lifted features onward (eval mode, no future labels).
     fiery/models/fiery.py:130-191, 275-286, 288-339.
 
@@ -330,7 +340,7 @@ def bev_hot_path(sd, cfg, lifted, intrinsics, extrinsics, future_egomotion, nois
     frustum = sd['frustum'].numpy()
     geometry = lift_splat.get_geometry(frustum, intrinsics.reshape(b * s, -1, 3, 3).numpy(),
                                        extrinsics.reshape(b * s, -1, 4, 4).numpy())
-    x = pool_lifted(lifted.reshape(b * s, *lifted.shape[2:]), geometry, resolution, start, dimension)
+    x = pool_lifted(lifted.reshape(b * s, *lifted.shape[2:]), geometry, resolution, start, dimension, exact)
     x = x.view(b, s, *x.shape[1:])
     x = cumulative_warp_features(x.clone(), ego, 'bilinear', extent)
     if cfg.MODEL.TEMPORAL_MODEL.INPUT_EGOPOSE:

@@ -90,17 +90,26 @@ def golden_forward(name, cfg, B, n_cam, sub, with_labels=False, with_noise=False
     lifted, K, E, ego, labels, noise = forward_case(cfg, model.receptive_field, model.n_future, model.depth_channels,
                                                     model.bev_size, B, n_cam, with_labels, with_noise)
     got = run_reference_from_lifted(model, lifted, K, E, ego, labels, noise)
+    # float64 evaluation of the same network (oracle, pinned to the reference in tests/test_oracle_vs_reference.py):
+    # how far the reference's own fp32 result is from the value it approximates
+    from oracle import bev_stack
+    with torch.no_grad():
+        exact = bev_stack.bev_hot_path_exact(model.state_dict(), cfg, lifted, K, E, ego, noise)
     out = {}
     for k, v in got.items():
         if v is None:
             continue
         a = v.numpy()
+        e = exact[k].numpy() if exact.get(k) is not None else None
         if a.ndim == 5:
             out[k + '_sub'] = a[..., ::sub, ::sub]
             out[k + '_mean'] = a.mean(axis=(-1, -2))
             out[k + '_absmax'] = np.float32(np.abs(a).max())
         else:
             out[k] = a
+        if e is not None:
+            out[k + '_exact'] = e[..., ::sub, ::sub] if a.ndim == 5 else e
+            out[k + '_refnoise'] = np.float64(np.abs(a.astype(np.float64) - e).max())
     np.savez_compressed(os.path.join(OUT, f'forward_{name}.npz'), **out)
     return {k: (None if v is None else tuple(v.shape)) for k, v in got.items()}
 

@@ -35,7 +35,7 @@ def randomise_weights(model, seed=2):
             v = 0.1 * torch.randn(t.shape, generator=g)
         else:
             fan_in = t[0].numel()
-            v = torch.randn(t.shape, generator=g) * (1.3 / fan_in ** 0.5)
+            v = torch.randn(t.shape, generator=g) * (1.0 / fan_in ** 0.5)     # keeps activations O(1..10) through the stack
         new[key] = v.to(t.dtype)
     model.load_state_dict(new)
     return new

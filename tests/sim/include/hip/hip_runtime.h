@@ -36,6 +36,8 @@ struct dim3 {
 struct uint3_sim { unsigned x, y, z; };
 struct float4 { float x, y, z, w; };
 struct float2 { float x, y; };
+struct int2 { int x, y; };
+inline int2 make_int2(int x, int y) { return {x, y}; }
 inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
 
 typedef void* hipStream_t;
@@ -203,6 +205,21 @@ inline unsigned long long atomicAdd(unsigned long long* addr, unsigned long long
     const unsigned long long old = *addr;
     *addr = old + v;
     return old;
+}
+
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+// wave-wide vote: bit l of the result is lane l's predicate
+inline unsigned long long __ballot(int predicate) {
+    ::hipsim::Run& run = *::hipsim::run_ptr();
+    const ::hipsim::Tls& t = ::hipsim::tls();
+    float* flags = run.wave_a[t.wave].data();
+    flags[t.lane] = predicate ? 1.f : 0.f;
+    ::hipsim::barrier_wait(run.waves[t.wave]);
+    unsigned long long mask = 0;
+    for (int l = 0; l < 64; ++l)
+        if (flags[l] != 0.f) mask |= 1ull << l;
+    ::hipsim::barrier_wait(run.waves[t.wave]);
+    return mask;
 }
 
 // f32 MFMA 32x32x2: D = A(32x2) . B(2x32) + C, one wave.

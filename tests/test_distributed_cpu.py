@@ -1,0 +1,85 @@
+"""world_size-2 (and 3) gloo runs of the sharding bookkeeping in fiery_amd/parallel.py on the CPU."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from fiery_amd.parallel import ShardedBevPath, block_range, gather_blocks, owner_of
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _frame_value(f):
+    """A recognisable fake 'pooled BEV map' for global frame f."""
+    return torch.full((2, 3, 3), float(f)) + torch.arange(18, dtype=torch.float32).view(2, 3, 3) / 100.0
+
+
+def _worker(rank, world, port, batch, S, results):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        calls = []
+
+        def pool_frames(lo, hi):
+            calls.append((lo, hi))
+            return torch.stack([_frame_value(f) for f in range(lo, hi)]) if hi > lo else torch.zeros(0, 2, 3, 3)
+
+        def stack(bev, blo, bhi):
+            return {'sum': bev.view(bhi - blo, S, -1).sum(dim=(1, 2)), 'range': (blo, bhi), 'bev': bev.clone()}
+
+        sharder = ShardedBevPath()
+        out = sharder.run(batch, S, pool_frames, stack)
+        # gather_blocks round trip with an uneven split
+        n = 5
+        lo, hi = block_range(n, world, rank)
+        full = gather_blocks(torch.arange(lo, hi, dtype=torch.float32).view(-1, 1), n)
+        results[rank] = dict(layout=sharder.layout(batch), calls=calls, out=out, full=full)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, batch, S):
+    port = _free_port()
+    with mp.Manager() as manager:
+        results = manager.dict()
+        mp.spawn(_worker, args=(world, port, batch, S, results), nprocs=world, join=True)
+        return dict(results)
+
+
+def test_block_partition_covers_everything_once():
+    for n in (1, 3, 9, 24, 72):
+        for world in (1, 2, 4, 8):
+            owned = [i for r in range(world) for i in range(*block_range(n, world, r))]
+            assert owned == list(range(n))
+            assert all(lo <= i < hi for i in range(n) for lo, hi in [block_range(n, world, owner_of(i, n, world))])
+
+
+def test_batch_sharding_needs_no_collective():
+    res = _run(world=2, batch=4, S=3)
+    assert res[0]['layout'] == res[1]['layout'] == 'batch'
+    assert res[0]['calls'] == [(0, 6)] and res[1]['calls'] == [(6, 12)]          # frames of the owned samples only
+    assert res[0]['out']['range'] == (0, 2) and res[1]['out']['range'] == (2, 4)
+    want = torch.stack([sum(_frame_value(b * 3 + t).sum() for t in range(3)) for b in range(4)])
+    got = torch.cat([res[0]['out']['sum'], res[1]['out']['sum']])
+    assert torch.allclose(got, want)
+    assert torch.equal(res[0]['full'].view(-1), torch.arange(5.0)) and torch.equal(res[1]['full'], res[0]['full'])
+
+
+def test_frame_sharding_all_gathers_the_bev_maps():
+    """batch 1 on 2 ranks (and on 3): frames split for lift-splat, one all-gather, full stack per rank."""
+    for world in (2, 3):
+        res = _run(world=world, batch=1, S=3)
+        pooled = sorted(f for r in range(world) for lo, hi in res[r]['calls'] for f in range(lo, hi))
+        assert pooled == [0, 1, 2]                                               # every frame pooled exactly once
+        want = torch.stack([_frame_value(f) for f in range(3)])
+        for r in range(world):
+            assert res[r]['layout'] == 'frames'
+            assert torch.equal(res[r]['out']['bev'], want)                       # every rank sees all frames, in order
+            assert res[r]['out']['range'] == (0, 1)

@@ -135,3 +135,21 @@ def test_broadcast_and_layout_changes(sim):
     back = torch.empty(n, 7, HW)
     sim.nhwc_to_nchw(nhwc, 8, HW * 8, n, 7, HW, back)
     assert torch.equal(back, x)
+
+
+def test_sequential_window_mean_reproduces_aten_avg_pool3d_on_constant_channels(sim):
+    """ATen's avg_pool3d adds the window's elements one by one in fp32; for the spatially constant ego-pose
+    channels that is a systematic rounding drift the reference's numbers contain.  Must match bit for bit."""
+    H, W = 40, 50
+    g = torch.Generator().manual_seed(4)
+    prev = torch.randn(3, 6, generator=g) * 2.5
+    cur = torch.randn(3, 6, generator=g) * 2.5
+    prev[0] = 0.0                                                   # fiery.py:152-154: zeros at t = 0
+    out = torch.empty(3, 6)
+    sim.sequential_window_mean(prev, cur, 3, 6, H * W, out, 6)
+    x = torch.stack([prev, cur], dim=2).view(3, 6, 2, 1, 1).expand(3, 6, 2, H, W).contiguous()
+    want = F.avg_pool3d(x, kernel_size=(2, H, W), stride=(1, H, W), padding=(1, 0, 0), count_include_pad=False)[:, :, 1, 0, 0]
+    assert torch.equal(out, want)
+    sim.sequential_window_mean(None, prev, 3, 6, H * W, out, 6)     # window clipped at t = 0: first frame only
+    want0 = F.avg_pool3d(x, kernel_size=(2, H, W), stride=(1, H, W), padding=(1, 0, 0), count_include_pad=False)[:, :, 0, 0, 0]
+    assert torch.equal(out, want0)
