@@ -1,0 +1,95 @@
+#!/usr/bin/env python
+"""Kernel microbenchmarks for tuning (GPU box): the voxel-pooling op at baseline.yml size and the convolution
+shapes that dominate the step.  Prints one line per case; run under rocprofv3 (--kernel-trace / --pmc) for counters.
+  python tools/microbench.py [pool] [conv] [--reps N]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from fiery_amd import native                                   # noqa: E402
+from fiery_amd.config import get_preset_cfg                    # noqa: E402
+from fiery_amd.ops import Buf, ConvOp, identity_chan_map       # noqa: E402
+from fiery_amd.synthetic import make_inputs                    # noqa: E402
+from oracle import lift_splat as ls                            # noqa: E402
+
+DEV = 'cuda:0'
+
+
+def timed(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) * 1e3 / reps      # us
+
+
+def bench_pool(lib, reps, frames=9, tiles=(0,)):
+    cfg = get_preset_cfg('baseline.yml')
+    res, start, dim = ls.bev_parameters(cfg.LIFT.X_BOUND, cfg.LIFT.Y_BOUND, cfg.LIFT.Z_BOUND)
+    grid = native.make_grid((start - res / np.float32(2)).astype(np.float32), res, dim)
+    frustum = torch.from_numpy(ls.create_frustum(cfg.IMAGE.FINAL_DIM, 8, cfg.LIFT.D_BOUND)).to(DEV)
+    D, fh, fw = frustum.shape[:3]
+    _, K, E, _ = make_inputs(frames // 3, 3, 6, with_image=False)
+    cam = lib.camera_matrices(K.view(-1, 3, 3).to(DEV), E.view(-1, 4, 4).to(DEV))
+    geo = lib.lift_geometry(frustum, cam).view(frames, 6, D, fh, fw, 3)
+    x = torch.randn(frames, 6, 64, D, fh, fw, device=DEV)
+    st = x.stride()
+    strides = (st[0], st[1], st[3], st[4], st[5], st[2])
+    rank, _ = lib.voxel_index(geo, grid, want_idx=False)
+    n_kept = int((rank >= 0).sum())
+    n_pts = rank.numel()
+    algo = 4.0 * 64 * n_kept + 12.0 * n_pts + 4.0 * 64 * frames * 200 * 200
+    for tile in tiles:
+        ws = lib.pool_workspace(frames, 6, D, fh, fw, DEV, grid, tile, 0)
+        out = torch.empty(frames, 64, 200, 200, device=DEV)
+        us = timed(lambda: lib.voxel_pool(x, strides, geo, frames, 6, D, fh, fw, 64, grid, out=out, workspace=ws,
+                                          tile_voxels=tile), reps)
+        print(f'pool frames={frames} tile={tile or "default"}: {us:8.1f} us/op  {us / frames:6.1f} us/frame  '
+              f'algorithmic {algo / 1e6:.1f} MB -> {algo / us / 1e3:7.1f} GB/s ({algo / us / 1e3 / 8000:.1%} of 8 TB/s); kept {n_kept / n_pts:.3f}',
+              flush=True)
+
+
+CONV_CASES = [  # (k, stride, cin, cout, n_img, H, W, residual)
+    (3, 1, 128, 128, 3, 200, 200, False),
+    (3, 1, 128, 64, 3, 200, 200, False),
+    (3, 1, 64, 256, 15, 200, 200, False),
+    (3, 1, 32, 32, 12, 200, 200, False),
+    (1, 1, 32, 64, 12, 200, 200, True),
+    (1, 1, 64, 32, 12, 200, 200, False),
+    (7, 2, 64, 64, 15, 200, 200, False),
+]
+
+
+def bench_conv(lib, reps):
+    for k, stride, cin, cout, n, H, W, residual in CONV_CASES:
+        x = Buf(torch.randn(n, H, W, cin, device=DEV), n, H, W, cin)
+        w = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
+        op = ConvOp(lib, w, identity_chan_map(cin), (cin // 8, 0), torch.ones(cout), torch.zeros(cout), DEV, stride=stride,
+                    act=native.ACT_RELU)
+        ho, wo = op.out_hw(H, W)
+        out = Buf.alloc(n, ho, wo, cout, DEV)
+        res = Buf(torch.randn(n, ho, wo, cout, device=DEV), n, ho, wo, cout) if residual else None
+        us = timed(lambda: op([x], out, res=res), reps)
+        flops = 2.0 * n * ho * wo * cin * k * k * cout
+        print(f'conv k{k} s{stride} {cin:3d}->{cout:3d} n={n:2d} {H}x{W}: {us:8.1f} us  {flops / us / 1e6:6.1f} TFLOP/s '
+              f'({flops / us / 1e6 / 157.3:.1%} of fp32 MFMA peak)', flush=True)
+
+
+if __name__ == '__main__':
+    reps = int(sys.argv[sys.argv.index('--reps') + 1]) if '--reps' in sys.argv else 5
+    lib = native.get()
+    what = [a for a in sys.argv[1:] if a in ('pool', 'conv')] or ['pool', 'conv']
+    if 'pool' in what:
+        bench_pool(lib, reps)
+    if 'conv' in what:
+        bench_conv(lib, reps)
