@@ -65,7 +65,42 @@ __global__ void k_rowwise_dense(const float* __restrict__ v, int v_ld, int rows,
     *dst = fminf(fmaxf(apply_act(fmaf(acc, sc, sh), act), lo), hi);
 }
 
-// one thread per (row, channel): a dependent chain of fp32 additions, on purpose (see fiery_hip.h)
+// n sequential fp32 additions of the constant v onto s, bit for bit, in O(number of binades crossed):
+// while the running sum stays inside one binade (and keeps its sign) every step advances it by the same
+// rounded increment, so after two real additions agree on that increment the rest of the binade is one
+// multiply-add in double (exact: everything is a multiple of the binade's ulp).  Ties-to-even settle after one
+// step, binade crossings and sign changes are walked with real additions.  Validated against the plain loop
+// (tests/test_kernels_sim_aux.py) and against ATen's avg_pool3d.
+__device__ float repeated_add(float s, float v, int n) {
+    while (n > 0) {
+        const float s1 = s + v;
+        --n;
+        if (n == 0 || s1 == s) return s1;            // done, or stagnated (|v| below half an ulp, or v == 0)
+        const float s2 = s1 + v;
+        --n;
+        if (n == 0) return s2;
+        const double d1 = static_cast<double>(s1) - static_cast<double>(s);
+        const double d2 = static_cast<double>(s2) - static_cast<double>(s1);
+        s = s2;
+        if (d1 != d2 || fabsf(s1) < 1e-30f || fabsf(s2) < 1e-30f) continue;
+        int e1, e2;
+        frexpf(fabsf(s1), &e1);
+        frexpf(fabsf(s2), &e2);
+        if (e1 != e2 || (s1 > 0.f) != (s2 > 0.f)) continue;
+        const double hi = ldexp(1.0, e2), lo = ldexp(0.5, e2), ulp = ldexp(1.0, e2 - 24);
+        const double mag = fabs(static_cast<double>(s2));
+        const double dm = s2 > 0.f ? d2 : -d2;        // change of magnitude per step
+        const double room = dm > 0.0 ? (hi - ulp - mag) / dm : (mag - lo) / (-dm);
+        long long k = static_cast<long long>(floor(room)) - 2;     // stay two steps clear of the binade edge
+        if (k > 0) {
+            if (k > n) k = n;
+            s = static_cast<float>(static_cast<double>(s2) + static_cast<double>(k) * d2);
+            n -= static_cast<int>(k);
+        }
+    }
+    return s;
+}
+
 __global__ void k_sequential_window_mean(const float* __restrict__ prev, const float* __restrict__ cur, int rows, int n,
                                          int count_each, float* __restrict__ out, int out_ld) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -74,12 +109,10 @@ __global__ void k_sequential_window_mean(const float* __restrict__ prev, const f
     float s = 0.f;
     int total = count_each;
     if (prev) {
-        const float v = prev[static_cast<long long>(r) * n + j];
-        for (int k = 0; k < count_each; ++k) s += v;
+        s = repeated_add(s, prev[static_cast<long long>(r) * n + j], count_each);
         total += count_each;
     }
-    const float v = cur[static_cast<long long>(r) * n + j];
-    for (int k = 0; k < count_each; ++k) s += v;
+    s = repeated_add(s, cur[static_cast<long long>(r) * n + j], count_each);
     out[static_cast<long long>(r) * out_ld + j] = s / static_cast<float>(total);
 }
 

@@ -60,9 +60,10 @@ __device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(
 
 template <int BN>
 __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
-    constexpr int WN = BN / 32;            // wavefronts along couts
+    constexpr int WN = BN >= 64 ? 2 : 1;   // wavefronts along couts
     constexpr int WM = 4 / WN;             // wavefronts along pixels
-    constexpr int MT = BM / (32 * WM);     // 32-pixel MFMA tiles per wavefront
+    constexpr int MT = BM / (32 * WM);     // 32-pixel MFMA tiles per wavefront   (BN=32: 1, else 2)
+    constexpr int NT = BN / (32 * WN);     // 32-cout MFMA tiles per wavefront    (BN=128: 2, else 1)
     constexpr int BLOADS = (BK * BN / 4) / 256;
 
     __shared__ float As[2][BM * BK];
@@ -73,14 +74,25 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     const int wm = wv % WM, wn = wv / WM;
     const int m = lane & 31, hi = lane >> 5;
     const int tile_n = blockIdx.y;
-    const int pix0 = blockIdx.x * BM;          // M < 2^31 is checked on the host: 32-bit pixel arithmetic throughout
+    // XCD-aware tile order: workgroup b runs on XCD b % 8, so give every XCD a contiguous run of pixel
+    // tiles - neighbouring tiles share their 3x3 halo rows through that XCD's L2 instead of re-fetching them
+    int tile_m;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        tile_m = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int pix0 = tile_m * BM;             // M < 2^31 is checked on the host: 32-bit pixel arithmetic throughout
     const int HWout = p.Hout * p.Wout;
     const int M = static_cast<int>(p.M);
 
     // ---- this thread's share of the A gather: one 16-byte slot of 4 pixels per stage ----------------
+    // Everything that does not change from stage to stage is computed once here, as 32-bit element offsets
+    // (the host checks that every source spans < 2^31 floats); a stage then costs one add and a bounds
+    // predicate per load, and the (tap, channel-unit) of the thread's slot advances incrementally.
     const int f4 = tid & 7;                // logical 16-byte slot inside the 32-k row
     const int prow = tid >> 3;             // 0..31
-    int pb[4], pt[4], pys[4], pxs[4];
+    int py0[4], px0[4], ptmin[4], poff0[4], poff1[4];
     bool pvalid[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -90,49 +102,69 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
         const int o = g / HWout;
         const int rem = g - o * HWout;
         const int y = rem / p.Wout, x = rem - y * p.Wout;
-        pb[j] = o / p.Tout;
-        pt[j] = o - pb[j] * p.Tout;
-        pys[j] = y * p.stride - p.padH;
-        pxs[j] = x * p.stride - p.padW;
+        const int b = o / p.Tout, tl = o - b * p.Tout;
+        py0[j] = y * p.stride - p.padH;
+        px0[j] = x * p.stride - p.padW;
+        ptmin[j] = tl + p.tout0 - (p.kT - 1);                       // absolute time of the dt = 0 tap
+        const int pos = py0[j] * p.Win + px0[j];
+        poff0[j] = static_cast<int>(b * p.src[0].bstride + (tl + p.tinadd - (p.kT - 1)) * p.src[0].tstride) + pos * p.src[0].ld;
+        poff1[j] = static_cast<int>(b * p.src[1].bstride + (tl + p.tinadd - (p.kT - 1)) * p.src[1].tstride) + pos * p.src[1].ld;
     }
-    const float* wtile = p.w + static_cast<long long>(tile_n) * p.k_chunks * (BK * BN);
-    const int khw = p.kH * p.kW;
+    const int taps = p.kT * p.kH * p.kW;
+    // running decode of this thread's unit: u = stage*4 + (f4 >> 1) = tap * cin_units + cc
+    int u_cc, u_tap, u_dt, u_dy, u_dx;
+    {
+        const int u = f4 >> 1;
+        u_tap = u / p.cin_units;
+        u_cc = u - u_tap * p.cin_units;
+        const int khw = p.kH * p.kW;
+        u_dt = u_tap / khw;
+        const int r = u_tap - u_dt * khw;
+        u_dy = r / p.kW;
+        u_dx = r - u_dy * p.kW;
+    }
+    const float* wnext = p.w + static_cast<long long>(tile_n) * p.k_chunks * (BK * BN) + tid * 4;
 
     float4 areg[4];
-    float4 breg0 = make_float4(0.f, 0.f, 0.f, 0.f), breg1 = breg0;   // named: an indexed array ends up in scratch
+    float4 breg0 = make_float4(0.f, 0.f, 0.f, 0.f), breg1 = breg0, breg2 = breg0, breg3 = breg0;   // named: an indexed array ends up in scratch
 
-    auto load_stage = [&](int chunk) {
-        const int u = chunk * 4 + (f4 >> 1);
-        const bool uvalid = u < p.n_units;
-        const int tap = uvalid ? u / p.cin_units : 0;
-        const int cc = uvalid ? u - tap * p.cin_units : 0;
-        const int dt = tap / khw;
-        const int r = tap - dt * khw;
-        const int dy = r / p.kW, dx = r - dy * p.kW;
-        const bool second = cc >= p.src[0].units;
-        SrcP sp;                                   // selects, not a runtime-indexed copy (that would go to scratch)
-        sp.ptr = second ? p.src[1].ptr : p.src[0].ptr;
-        sp.ld = second ? p.src[1].ld : p.src[0].ld;
-        sp.bstride = second ? p.src[1].bstride : p.src[0].bstride;
-        sp.tstride = second ? p.src[1].tstride : p.src[0].tstride;
-        const int choff = (cc - (second ? p.src[0].units : 0)) * 8 + (f4 & 1) * 4;
-        const int tshift = dt - (p.kT - 1);
+    // loads stage `next` (stages are requested in order 0, 1, 2, ...)
+    auto load_stage = [&]() {
+        const bool uvalid = u_tap < taps;
+        const bool second = u_cc >= p.src[0].units;
+        const float* base = second ? p.src[1].ptr : p.src[0].ptr;
+        const int ld = second ? p.src[1].ld : p.src[0].ld;
+        const int tstride = static_cast<int>(second ? p.src[1].tstride : p.src[0].tstride);
+        const int tap_off = u_dt * tstride + (u_dy * p.Win + u_dx) * ld + (u_cc - (second ? p.src[0].units : 0)) * 8 + (f4 & 1) * 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int iy = pys[j] + dy, ix = pxs[j] + dx;
-            const bool ok = uvalid && pvalid[j] && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win &&
-                            (pt[j] + p.tout0 + tshift) >= 0;
+            const int iy = py0[j] + u_dy, ix = px0[j] + u_dx;
+            const bool ok = uvalid && pvalid[j] && static_cast<unsigned>(iy) < static_cast<unsigned>(p.Hin) &&
+                            static_cast<unsigned>(ix) < static_cast<unsigned>(p.Win) && (ptmin[j] + u_dt) >= 0;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
-                const float* a = sp.ptr + pb[j] * sp.bstride + (pt[j] + p.tinadd + tshift) * sp.tstride +
-                                 (static_cast<long long>(iy) * p.Win + ix) * sp.ld + choff;
-                v = *reinterpret_cast<const float4*>(a);
-            }
+            if (ok) v = *reinterpret_cast<const float4*>(base + ((second ? poff1[j] : poff0[j]) + tap_off));
             areg[j] = v;
         }
-        const float4* wsrc = reinterpret_cast<const float4*>(wtile + static_cast<long long>(chunk) * (BK * BN));
-        breg0 = wsrc[tid];
-        if (BLOADS > 1) breg1 = wsrc[tid + 256];
+        breg0 = *reinterpret_cast<const float4*>(wnext);
+        if (BLOADS > 1) breg1 = *reinterpret_cast<const float4*>(wnext + 256 * 4);
+        if (BLOADS > 2) {
+            breg2 = *reinterpret_cast<const float4*>(wnext + 512 * 4);
+            breg3 = *reinterpret_cast<const float4*>(wnext + 768 * 4);
+        }
+        wnext += BK * BN;
+        // advance the unit by one stage (4 units), carrying into the tap and its (dt, dy, dx)
+        u_cc += 4;
+        while (u_cc >= p.cin_units) {
+            u_cc -= p.cin_units;
+            ++u_tap;
+            if (++u_dx == p.kW) {
+                u_dx = 0;
+                if (++u_dy == p.kH) {
+                    u_dy = 0;
+                    ++u_dt;
+                }
+            }
+        }
     };
     auto store_stage = [&](int buf) {
 #pragma unroll
@@ -143,22 +175,26 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
         }
         *reinterpret_cast<float4*>(&Bs[buf][tid * 4]) = breg0;
         if (BLOADS > 1) *reinterpret_cast<float4*>(&Bs[buf][(tid + 256) * 4]) = breg1;
+        if (BLOADS > 2) {
+            *reinterpret_cast<float4*>(&Bs[buf][(tid + 512) * 4]) = breg2;
+            *reinterpret_cast<float4*>(&Bs[buf][(tid + 768) * 4]) = breg3;
+        }
     };
 
-    v16f acc[MT];
+    v16f acc[MT * NT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
+    for (int t = 0; t < MT * NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    load_stage(0);
+    load_stage();
     store_stage(0);
     __syncthreads();
 
     for (int chunk = 0; chunk < p.k_chunks; ++chunk) {
         const int buf = chunk & 1;
         const bool more = chunk + 1 < p.k_chunks;
-        if (more) load_stage(chunk + 1);          // global loads fly while the MFMAs below run
+        if (more) load_stage();                   // global loads fly while the MFMAs below run
 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -176,9 +212,13 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 // this lane's k for the step: 8q + 4hi + j, for its A element and its W element alike
-                const float bv = Bs[buf][(8 * q + 4 * hi + j) * BN + wn * 32 + m];
 #pragma unroll
-                for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t][j], bv, acc[t], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float bv = Bs[buf][(8 * q + 4 * hi + j) * BN + wn * (32 * NT) + nt * 32 + m];
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+                        acc[t * NT + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t][j], bv, acc[t * NT + nt], 0, 0, 0);
+                }
             }
         }
 
@@ -186,12 +226,11 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds cout = co for 16 pixel rows of each tile ------------------------------
-    const int co = tile_n * BN + wn * 32 + m;
-    const float sc = p.scale[co], sh = p.shift[co];
+    // ---- epilogue: for each of its 32x32 tiles a lane holds one cout for 16 pixel rows ---------------------
     const int half = p.cout_pad >> 1;
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
+    auto emit = [&](const v16f& a, int t, int nt) {
+        const int co = tile_n * BN + wn * (32 * NT) + nt * 32 + m;
+        const float sc = p.scale[co], sh = p.shift[co];
         // image / in-image pixel of this lane's first row; the other 15 rows are small constant offsets away,
         // so one division per tile instead of one per element
         const int gp_base = pix0 + wm * (32 * MT) + t * 32 + 4 * hi;
@@ -207,7 +246,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
                 ++o;
             }
             const long long pp = ppi;
-            float v = acc[t][r];
+            float v = a[r];
             if (p.img_bias) v += p.img_bias[static_cast<long long>(o) * p.cout_pad + co];
             v = fmaf(v, sc, sh);
             if (p.epi == FIERY_EPI_PLAIN) {
@@ -231,13 +270,20 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
                 const float ht = fmaxf(v, 0.f);
                 const float u = p.aux0.ptr[o * p.aux0.istride + pp * p.aux0.ld + co];
                 const float h = p.aux1.ptr[o * p.aux1.istride + pp * p.aux1.ld + co];
-                const float a = (1.0f - u) * h;
-                const float b = u * ht;
-                const float hn = a + b;
+                const float x1 = (1.0f - u) * h;
+                const float x2 = u * ht;
+                const float hn = x1 + x2;
                 p.out.ptr[o * p.out.istride + pp * p.out.ld + co] = hn;
                 if (p.out2.ptr) p.out2.ptr[o * p.out2.istride + pp * p.out2.ld + co] = hn;
             }
         }
+    };
+    // compile-time tile indices keep the accumulators in registers
+    emit(acc[0], 0, 0);
+    if constexpr (NT == 2) emit(acc[1], 0, 1);
+    if constexpr (MT == 2) {
+        emit(acc[NT], 1, 0);
+        if constexpr (NT == 2) emit(acc[NT + 1], 1, 1);
     }
 }
 
@@ -275,7 +321,7 @@ struct Geometry {
 Geometry conv_geometry(int cout, int cin_units, int taps) {
     Geometry g;
     g.cout_pad = (cout + 31) / 32 * 32;
-    g.bn = (g.cout_pad % 64 == 0) ? 64 : 32;
+    g.bn = (g.cout_pad % 128 == 0) ? 128 : (g.cout_pad % 64 == 0) ? 64 : 32;
     g.n_tiles = g.cout_pad / g.bn;
     g.n_units = cin_units * taps;
     g.k_chunks = (g.n_units + 3) / 4;
@@ -368,6 +414,15 @@ extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) {
     }
     const int cin_units = d->src[0].units + d->src[1].units;
     FIERY_REQUIRE(cin_units <= kMaxCinUnits, "conv_fwd: too many input channels");
+    for (int s = 0; s < 2; ++s) {
+        if (d->src[s].units == 0) continue;
+        // the kernel addresses each source with 32-bit element offsets
+        const long long n_batch = d->n_img_out / d->T_out;
+        const long long span = (n_batch - 1) * llabs(d->src[s].batch_stride) +
+                               (static_cast<long long>(d->T_out) + d->kT + llabs(static_cast<long long>(d->t_in_add))) * llabs(d->src[s].time_stride) +
+                               (static_cast<long long>(d->Hin) + d->kH) * (d->Win + d->kW) * d->src[s].ld;
+        FIERY_REQUIRE(span < (1ll << 31), "conv_fwd: source %d spans more than 2^31 floats", s);
+    }
     if (d->epi == FIERY_EPI_GRU_GATES) {
         FIERY_REQUIRE(d->out2.ptr && d->aux0.ptr, "conv_fwd: GRU gate epilogue needs out2 and aux0");
     } else if (d->epi == FIERY_EPI_GRU_OUT) {
@@ -396,9 +451,10 @@ extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) {
     p.aux1 = TensP{d->aux1.ptr, d->aux1.ld, d->aux1.img_stride};
     p.cout_store = d->cout_store;
     p.M = static_cast<long long>(d->n_img_out) * d->Hout * d->Wout;
-    const int bn = (d->cout_pad % 64 == 0) ? 64 : 32;
+    const int bn = (d->cout_pad % 128 == 0) ? 128 : (d->cout_pad % 64 == 0) ? 64 : 32;
     dim3 grid(ceil_div(p.M, BM), d->cout_pad / bn);
-    if (bn == 64) hipLaunchKernelGGL(k_conv_igemm<64>, grid, dim3(256), 0, as_stream(stream), p);
+    if (bn == 128) hipLaunchKernelGGL(k_conv_igemm<128>, grid, dim3(256), 0, as_stream(stream), p);
+    else if (bn == 64) hipLaunchKernelGGL(k_conv_igemm<64>, grid, dim3(256), 0, as_stream(stream), p);
     else hipLaunchKernelGGL(k_conv_igemm<32>, grid, dim3(256), 0, as_stream(stream), p);
     return check_launch("conv_fwd");
 }

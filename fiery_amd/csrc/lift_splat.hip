@@ -342,6 +342,183 @@ __global__ __launch_bounds__(256) void k_voxel_pool(
     for (int i = threadIdx.x; i < span; i += blockDim.x) o[i] = Cell<kFixed>::value(plane[i]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// vectorised pooling: four adjacent columns (a "quad", 16 bytes of every row) per work-item
+// ------------------------------------------------------------------------------------------------
+// Same tile lists, but of quads: entry = camera<<20 | d<<10 | (w/4); a quad is listed for a tile when any of
+// its columns touches it.  grid (n_tiles, frames), 1024 threads.
+__global__ __launch_bounds__(1024) void k_build_quad_lists(const int* __restrict__ colmask, int n_cam, int D, int W,
+                                                           int n_tiles, int* __restrict__ lists, int* __restrict__ counts) {
+    __shared__ int wave_count[16];
+    __shared__ int running;
+    const int tile = blockIdx.x, f = blockIdx.y;
+    const int W4 = W >> 2;
+    const int n_quads = n_cam * D * W4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int4* cm = reinterpret_cast<const int4*>(colmask + static_cast<long long>(f) * n_quads * 4);
+    int* out = lists + (static_cast<long long>(f) * n_tiles + tile) * n_quads;
+    if (threadIdx.x == 0) running = 0;
+    __syncthreads();
+    for (int q0 = 0; q0 < n_quads; q0 += 1024) {
+        const int q = q0 + threadIdx.x;
+        bool hit = false;
+        if (q < n_quads) {
+            const int4 mk = cm[q];
+            hit = ((mk.x | mk.y | mk.z | mk.w) >> tile) & 1;
+        }
+        const unsigned long long ballot = __ballot(hit);
+        const int before = __popcll(ballot & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_count[wave] = __popcll(ballot);
+        __syncthreads();
+        int offset = running;
+        for (int k = 0; k < wave; ++k) offset += wave_count[k];
+        if (hit) {
+            const int w4 = q % W4, nd = q / W4;
+            out[offset + before] = ((nd / D) << (kPackW + kPackD)) | ((nd % D) << kPackW) | w4;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int total = 0;
+            for (int k = 0; k < 16; ++k) total += wave_count[k];
+            running += total;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) counts[f * n_tiles + tile] = running;
+}
+
+constexpr int kQuadBatch = 7;    // rows in flight per work-item: 7 x 16 B (+ 7 x 16 B of ranks on the general path)
+
+// One run-length accumulator per column: add `val` for voxel `r` (r < 0 = not in this tile); when the voxel
+// changes the finished run is retired with one LDS atomic.
+template <bool kFixed>
+struct Run {
+    int cur = -1;
+    float sum = 0.f;
+    __device__ __forceinline__ void step(typename Cell<kFixed>::type* plane, int v0, int r, float val) {
+        if (r != cur) {
+            if (cur >= 0) Cell<kFixed>::add(&plane[cur - v0], sum);
+            cur = r;
+            sum = 0.f;
+        }
+        if (cur >= 0) sum += val;
+    }
+    __device__ __forceinline__ void flush(typename Cell<kFixed>::type* plane, int v0) {
+        if (cur >= 0) Cell<kFixed>::add(&plane[cur - v0], sum);
+        cur = -1;
+        sum = 0.f;
+    }
+};
+
+template <bool kFused, bool kFixed>
+__global__ __launch_bounds__(256) void k_voxel_pool_quad(
+    const float* __restrict__ x, PoolStrides xs, const float* __restrict__ depth, const float* __restrict__ feat,
+    const int* __restrict__ rank, const int* __restrict__ coldesc, const int* __restrict__ lists,
+    const int* __restrict__ counts, float* __restrict__ out, int n_cam, int D, int H, int W, int C, int n_vox,
+    int tile_vox, int n_tiles) {
+    using cell_t = typename Cell<kFixed>::type;
+    HIP_DYNAMIC_SHARED(unsigned char, pool_lds)
+    cell_t* plane = reinterpret_cast<cell_t*>(pool_lds);
+    const int tile = blockIdx.x, c = blockIdx.y, f = blockIdx.z;
+    const int v0 = tile * tile_vox;
+    const int v1 = min(v0 + tile_vox, n_vox);
+    const int span = v1 - v0;
+    for (int i = threadIdx.x; i < span; i += blockDim.x) plane[i] = cell_t(0);
+    __syncthreads();
+
+    const int W4 = W >> 2;
+    const int n_quads = n_cam * D * W4;
+    const int* lst = lists + (static_cast<long long>(f) * n_tiles + tile) * n_quads;
+    const int count = counts[f * n_tiles + tile];
+    const int HW = H * W;
+    const int4* cdesc = reinterpret_cast<const int4*>(coldesc + static_cast<long long>(f) * n_quads * 4);
+    for (int i = threadIdx.x; i < count; i += blockDim.x) {
+        const int e = lst[i];
+        const int w = (e & ((1 << kPackW) - 1)) << 2;
+        const int d = (e >> kPackW) & ((1 << kPackD) - 1);
+        const int cam = e >> (kPackW + kPackD);
+        const int4 dsc = cdesc[(cam * D + d) * W4 + (w >> 2)];
+        // row h of this quad: 16 bytes at p + h*step; fused: depth row times feature row
+        const float* p;
+        const float* q = nullptr;
+        long long step, qstep = 0;
+        if (kFused) {
+            p = depth + ((static_cast<long long>(f) * n_cam + cam) * D + d) * HW + w;
+            step = W;
+            q = feat + ((static_cast<long long>(f) * n_cam + cam) * C + c) * HW + w;
+            qstep = W;
+        } else {
+            p = x + f * xs.f + cam * xs.n + d * xs.d + w + c * xs.c;
+            step = xs.h;
+        }
+        const bool general = dsc.x == kColMixed || dsc.y == kColMixed || dsc.z == kColMixed || dsc.w == kColMixed;
+        if (!general) {
+            // every column of the quad falls into one voxel (or outside the grid): sum the rows, then retire
+            // the four column sums, merging neighbours that share a voxel
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            for (int h0 = 0; h0 < H; h0 += kQuadBatch) {
+                float4 v[kQuadBatch];
+#pragma unroll
+                for (int k = 0; k < kQuadBatch; ++k)
+                    v[k] = (h0 + k < H) ? *reinterpret_cast<const float4*>(p + (h0 + k) * step) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (kFused) {
+#pragma unroll
+                    for (int k = 0; k < kQuadBatch; ++k) {
+                        const float4 g = (h0 + k < H) ? *reinterpret_cast<const float4*>(q + (h0 + k) * qstep) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        v[k].x *= g.x;  v[k].y *= g.y;  v[k].z *= g.z;  v[k].w *= g.w;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < kQuadBatch; ++k) {
+                    s0 += v[k].x;  s1 += v[k].y;  s2 += v[k].z;  s3 += v[k].w;
+                }
+            }
+            Run<kFixed> run;
+            run.step(plane, v0, (dsc.x >= v0 && dsc.x < v1) ? dsc.x : -1, s0);
+            run.step(plane, v0, (dsc.y >= v0 && dsc.y < v1) ? dsc.y : -1, s1);
+            run.step(plane, v0, (dsc.z >= v0 && dsc.z < v1) ? dsc.z : -1, s2);
+            run.step(plane, v0, (dsc.w >= v0 && dsc.w < v1) ? dsc.w : -1, s3);
+            run.flush(plane, v0);
+        } else {
+            // some column crosses voxels: four run-length accumulators driven by the per-point ranks
+            const int* rk = rank + ((static_cast<long long>(f) * n_cam + cam) * D + d) * HW + w;
+            Run<kFixed> r0, r1, r2, r3;
+            for (int h0 = 0; h0 < H; h0 += kQuadBatch) {
+                float4 v[kQuadBatch];
+                int4 r[kQuadBatch];
+#pragma unroll
+                for (int k = 0; k < kQuadBatch; ++k) {
+                    const bool in = h0 + k < H;
+                    v[k] = in ? *reinterpret_cast<const float4*>(p + (h0 + k) * step) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    r[k] = in ? *reinterpret_cast<const int4*>(rk + (h0 + k) * W) : make_int4(-1, -1, -1, -1);
+                }
+                if (kFused) {
+#pragma unroll
+                    for (int k = 0; k < kQuadBatch; ++k) {
+                        const float4 g = (h0 + k < H) ? *reinterpret_cast<const float4*>(q + (h0 + k) * qstep) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        v[k].x *= g.x;  v[k].y *= g.y;  v[k].z *= g.z;  v[k].w *= g.w;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < kQuadBatch; ++k) {
+                    if (h0 + k >= H) break;
+                    r0.step(plane, v0, (r[k].x >= v0 && r[k].x < v1) ? r[k].x : -1, v[k].x);
+                    r1.step(plane, v0, (r[k].y >= v0 && r[k].y < v1) ? r[k].y : -1, v[k].y);
+                    r2.step(plane, v0, (r[k].z >= v0 && r[k].z < v1) ? r[k].z : -1, v[k].z);
+                    r3.step(plane, v0, (r[k].w >= v0 && r[k].w < v1) ? r[k].w : -1, v[k].w);
+                }
+            }
+            r0.flush(plane, v0);
+            r1.flush(plane, v0);
+            r2.flush(plane, v0);
+            r3.flush(plane, v0);
+        }
+    }
+    __syncthreads();
+    float* o = out + (static_cast<long long>(f) * C + c) * n_vox + v0;
+    for (int i = threadIdx.x; i < span; i += blockDim.x) o[i] = Cell<kFixed>::value(plane[i]);
+}
+
 }  // namespace
 }  // namespace fiery
 
@@ -456,13 +633,37 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
                        W, to_params(*grid), pl.tile, rank, coldesc, colmask);
     rc = check_launch("rank_columns");
     if (rc) return rc;
+    dim3 gridDim3(pl.n_tiles, C, frames);
+    PoolStrides st{0, 0, 0, 0, 0, 0};
+    if (!fused) st = PoolStrides{xs[0], xs[1], xs[2], xs[3], xs[4], xs[5]};
+    // 16-byte path: rows of four columns must be contiguous and 16-byte aligned
+    bool quads = (W % 4 == 0);
+    if (fused) {
+        quads = quads && aligned16(depth) && aligned16(feat);
+    } else {
+        quads = quads && aligned16(x) && st.w == 1 && st.f % 4 == 0 && st.n % 4 == 0 && st.d % 4 == 0 && st.h % 4 == 0 &&
+                st.c % 4 == 0;
+    }
+    if (quads) {
+        int* qlists = reinterpret_cast<int*>(lists);
+        hipLaunchKernelGGL(k_build_quad_lists, dim3(pl.n_tiles, frames), dim3(1024), 0, s, colmask, n_cam, D, W, pl.n_tiles,
+                           qlists, counts);
+        rc = check_launch("build_quad_lists");
+        if (rc) return rc;
+#define FIERY_POOL_LAUNCH_Q(FUSED, FIXED)                                                                               \
+    hipLaunchKernelGGL((k_voxel_pool_quad<FUSED, FIXED>), gridDim3, dim3(256), pl.lds, s, x, st, depth, feat, rank, coldesc, \
+                       qlists, counts, out, n_cam, D, H, W, C, pl.n_vox, pl.tile, pl.n_tiles)
+        if (fused && fixed) FIERY_POOL_LAUNCH_Q(true, true);
+        else if (fused) FIERY_POOL_LAUNCH_Q(true, false);
+        else if (fixed) FIERY_POOL_LAUNCH_Q(false, true);
+        else FIERY_POOL_LAUNCH_Q(false, false);
+#undef FIERY_POOL_LAUNCH_Q
+        return check_launch("voxel_pool_quad");
+    }
     hipLaunchKernelGGL(k_build_tile_lists, dim3(pl.n_tiles, frames), dim3(1024), 0, s, coldesc, colmask, n_cam, D, W,
                        pl.n_tiles, lists, counts);
     rc = check_launch("build_tile_lists");
     if (rc) return rc;
-    dim3 gridDim3(pl.n_tiles, C, frames);
-    PoolStrides st{0, 0, 0, 0, 0, 0};
-    if (!fused) st = PoolStrides{xs[0], xs[1], xs[2], xs[3], xs[4], xs[5]};
 #define FIERY_POOL_LAUNCH(FUSED, FIXED)                                                                             \
     hipLaunchKernelGGL((k_voxel_pool<FUSED, FIXED>), gridDim3, dim3(256), pl.lds, s, x, st, depth, feat, rank, lists, \
                        counts, out, n_cam, D, H, W, C, pl.n_vox, pl.tile, pl.n_tiles)

@@ -140,16 +140,18 @@ def test_broadcast_and_layout_changes(sim):
 def test_sequential_window_mean_reproduces_aten_avg_pool3d_on_constant_channels(sim):
     """ATen's avg_pool3d adds the window's elements one by one in fp32; for the spatially constant ego-pose
     channels that is a systematic rounding drift the reference's numbers contain.  Must match bit for bit."""
-    H, W = 40, 50
+    H, W = 200, 200                                                 # the real baseline.yml window: 2 x 40,000 additions
     g = torch.Generator().manual_seed(4)
-    prev = torch.randn(3, 6, generator=g) * 2.5
-    cur = torch.randn(3, 6, generator=g) * 2.5
+    prev = torch.randn(8, 6, generator=g) * 2.5
+    cur = torch.randn(8, 6, generator=g) * 2.5
     prev[0] = 0.0                                                   # fiery.py:152-154: zeros at t = 0
-    out = torch.empty(3, 6)
-    sim.sequential_window_mean(prev, cur, 3, 6, H * W, out, 6)
-    x = torch.stack([prev, cur], dim=2).view(3, 6, 2, 1, 1).expand(3, 6, 2, H, W).contiguous()
+    cur[1] = torch.tensor([0.5, -0.25, 3.0, 1e-9, 0.0, 2.5])        # exact ties, stagnation, zero
+    prev[2], cur[2] = torch.full((6,), 0.02), torch.full((6,), -0.021)    # sign change half way
+    out = torch.empty(8, 6)
+    sim.sequential_window_mean(prev, cur, 8, 6, H * W, out, 6)
+    x = torch.stack([prev, cur], dim=2).view(8, 6, 2, 1, 1).expand(8, 6, 2, H, W).contiguous()
     want = F.avg_pool3d(x, kernel_size=(2, H, W), stride=(1, H, W), padding=(1, 0, 0), count_include_pad=False)[:, :, 1, 0, 0]
     assert torch.equal(out, want)
-    sim.sequential_window_mean(None, prev, 3, 6, H * W, out, 6)     # window clipped at t = 0: first frame only
+    sim.sequential_window_mean(None, prev, 8, 6, H * W, out, 6)     # window clipped at t = 0: first frame only
     want0 = F.avg_pool3d(x, kernel_size=(2, H, W), stride=(1, H, W), padding=(1, 0, 0), count_include_pad=False)[:, :, 0, 0, 0]
     assert torch.equal(out, want0)

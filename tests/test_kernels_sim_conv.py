@@ -25,6 +25,8 @@ def _to_buf(x_nchw, width=None):
     (13, 32, 3, 2, (11, 9)),      # ragged channels, BN=32, stride 2, odd size
     (24, 70, 1, 1, (7, 20)),      # 1x1, cout padded to 96 (three BN=32 tiles)
     (8, 40, 7, 2, (12, 12)),      # 7x7 stride 2 like the decoder stem, cout padded to 64
+    (24, 128, 3, 1, (10, 13)),    # BN=128 tile: 64x64 per wavefront
+    (16, 250, 1, 1, (6, 22)),     # cout padded to 256: two BN=128 tiles
 ])
 def test_conv2d_bn_relu(sim, cin, cout, k, stride, hw):
     g = torch.Generator().manual_seed(cin * 100 + cout)

@@ -164,3 +164,40 @@ def test_fused_lift_splat_matches_unfused(sim):
         pts = ls.lifted_to_points(lifted[f].numpy())
         exact = ls.voxel_pool_exact(pts, geo[f].reshape(-1, 3), res, start, dim)
         assert np.abs(out[f].numpy() - exact).max() < 5e-6
+
+
+@pytest.mark.parametrize('flags', [0, native.POOL_DETERMINISTIC])
+@pytest.mark.parametrize('rolled', [False, True])
+def test_quad_path_16_byte_rows(sim, flags, rolled):
+    """W divisible by 4 with the encoder's native layout takes the vectorised kernel (four columns per
+    work-item); `rolled` makes camera 0's columns cross voxels, which drives its run-length branch."""
+    frustum, intr, extr, lifted = _small_problem(8, n_cam=2, W=12, C=3, frames=2)
+    if rolled:
+        roll = torch.tensor([[0.0, -1.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0], [0.0, 0.0, 1.0, 0.0], [0.0, 0.0, 0.0, 1.0]])
+        extr = extr.clone()
+        extr[:, 0] = extr[:, 0] @ roll
+    frames, n_cam, C, D, H, W = lifted.shape
+    assert W % 4 == 0
+    geo = ls.get_geometry(frustum, intr.numpy(), extr.numpy())
+    grid, (res, start, dim) = _grid([-20.0, 20.0, 0.5], [-16.0, 16.0, 0.5], [-10.0, 10.0, 20.0])
+    st = lifted.stride()
+    out = sim.voxel_pool(lifted, (st[0], st[1], st[3], st[4], st[5], st[2]), torch.from_numpy(geo), frames, n_cam, D, H, W, C,
+                         grid, tile_voxels=301, flags=flags)
+    for f in range(frames):
+        exact = ls.voxel_pool_exact(ls.lifted_to_points(lifted[f].numpy()), geo[f].reshape(-1, 3), res, start, dim)
+        assert np.abs(out[f].numpy() - exact).max() < 5e-6
+
+
+def test_quad_path_fused(sim):
+    frustum, intr, extr, _ = _small_problem(9, W=12)
+    frames, n_cam, D, H, W, C = 2, 2, 5, 6, 12, 4
+    gen = torch.Generator().manual_seed(10)
+    prob = torch.randn(frames * n_cam, D, H, W, generator=gen).softmax(dim=1)
+    feats = torch.randn(frames * n_cam, C, H, W, generator=gen)
+    geo = ls.get_geometry(frustum, intr.numpy(), extr.numpy())
+    grid, (res, start, dim) = _grid([-20.0, 20.0, 1.0], [-16.0, 16.0, 1.0], [-10.0, 10.0, 20.0])
+    out = sim.lift_splat(prob, feats, torch.from_numpy(geo), frames, n_cam, D, H, W, C, grid)
+    lifted = (prob.unsqueeze(1) * feats.unsqueeze(2)).view(frames, n_cam, C, D, H, W)
+    for f in range(frames):
+        exact = ls.voxel_pool_exact(ls.lifted_to_points(lifted[f].numpy()), geo[f].reshape(-1, 3), res, start, dim)
+        assert np.abs(out[f].numpy() - exact).max() < 5e-6
