@@ -54,6 +54,10 @@ struct ConvP {
     TensP res, out, out2, aux0, aux1;
     int cout_store;
     long long M;
+    const float* w2;      // chained 1x1 (BN = 32 only)
+    const float* scale2;
+    const float* shift2;
+    int act2;
 };
 
 __device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -224,6 +228,82 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
 
         if (more) store_stage(buf ^ 1);
         __syncthreads();
+    }
+
+    // ---- optional chained 1x1 convolution on the tile (Bottleneck up-projection) -----------------------------
+    if constexpr (BN == 32) {
+        if (p.w2) {
+            // (1) h = act(acc*scale + shift) back into LDS as the A operand of a second GEMM: [pixel][32 k], same
+            //     slot swizzle as the main loop.  Every wave passed the loop's last barrier, so stage 0 is free.
+            {
+                const int co = m;                                   // tile_n == 0, wn == 0 for BN = 32
+                const float sc = p.scale[co], sh = p.shift[co];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    float v = fmaf(acc[0][r], sc, sh);
+                    if (p.act == FIERY_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (p.act == FIERY_ACT_SIGMOID) v = sigmoidf(v);
+                    As[0][pl * BK + (((co >> 2) ^ ((pl >> 1) & 7)) << 2) + (co & 3)] = v;
+                }
+            }
+            // (2) the 32 x 64 weight tile, already in its LDS image, into the (now idle) W stages
+            {
+                float* bdst = &Bs[0][0];                            // 2 stages x 32 x 32 floats = 32 x 64
+                const float4* wsrc = reinterpret_cast<const float4*>(p.w2);
+                *reinterpret_cast<float4*>(bdst + tid * 4) = wsrc[tid];
+                *reinterpret_cast<float4*>(bdst + (tid + 256) * 4) = wsrc[tid + 256];
+            }
+            __syncthreads();
+            // (3) 128 x 64 = (128 x 32) . (32 x 64): each wavefront 32 pixels x 64 couts
+            v16f acc2[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
+            const float* b2 = &Bs[0][0];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int pl = wm * 32 + m;
+                const int slot = (2 * q + hi) ^ ((pl >> 1) & 7);
+                const float4 a4 = *reinterpret_cast<const float4*>(&As[0][pl * BK + slot * 4]);
+                const float av2[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const float bv = b2[(8 * q + 4 * hi + j) * 64 + nt * 32 + m];
+                        acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av2[j], bv, acc2[nt], 0, 0, 0);
+                    }
+                }
+            }
+            // (4) second epilogue: folded BN, activation, residual, store
+            const int gp_base = pix0 + wm * 32 + 4 * hi;
+            const int o_base = gp_base / HWout;
+            const int pp_base = gp_base - o_base * HWout;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int co = nt * 32 + m;
+                const float sc = p.scale2[co], sh = p.shift2[co];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int off = (r & 3) + 8 * (r >> 2);
+                    if (gp_base + off >= M || co >= p.cout_store) continue;
+                    int o = o_base, ppi = pp_base + off;
+                    while (ppi >= HWout) {
+                        ppi -= HWout;
+                        ++o;
+                    }
+                    const long long pp = ppi;
+                    float v = fmaf(acc2[nt][r], sc, sh);
+                    if (p.act2 == FIERY_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (p.act2 == FIERY_ACT_SIGMOID) v = sigmoidf(v);
+                    if (p.res.ptr) v += p.res.ptr[o * p.res.istride + pp * p.res.ld + co];
+                    p.out.ptr[o * p.out.istride + pp * p.out.ld + co] = v;
+                }
+            }
+            return;
+        }
     }
 
     // ---- epilogue: for each of its 32x32 tiles a lane holds one cout for 16 pixel rows ---------------------
@@ -403,7 +483,7 @@ extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) {
     FIERY_REQUIRE(d->n_img_out > 0 && d->T_out > 0 && d->n_img_out % d->T_out == 0, "conv_fwd: bad image counts");
     FIERY_REQUIRE(d->Hin > 0 && d->Win > 0 && d->Hout > 0 && d->Wout > 0, "conv_fwd: bad spatial shape");
     FIERY_REQUIRE(d->cout_pad > 0 && d->cout_pad % 32 == 0, "conv_fwd: cout_pad must be a multiple of 32");
-    FIERY_REQUIRE(d->cout_store > 0 && d->cout_store <= d->cout_pad, "conv_fwd: bad cout_store");
+    FIERY_REQUIRE(d->cout_store > 0 && (d->weights2 || d->cout_store <= d->cout_pad), "conv_fwd: bad cout_store");
     FIERY_REQUIRE(static_cast<long long>(d->n_img_out) * d->Hout * d->Wout < (1ll << 31) - 256, "conv_fwd: more than 2^31 output pixels");
     for (int s = 0; s < 2; ++s) {
         if (d->src[s].units == 0) continue;
@@ -451,6 +531,16 @@ extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) {
     p.aux1 = TensP{d->aux1.ptr, d->aux1.ld, d->aux1.img_stride};
     p.cout_store = d->cout_store;
     p.M = static_cast<long long>(d->n_img_out) * d->Hout * d->Wout;
+    p.w2 = d->weights2;
+    p.scale2 = d->scale2;
+    p.shift2 = d->shift2;
+    p.act2 = d->act2;
+    if (d->weights2) {
+        FIERY_REQUIRE(d->cout_pad == 32 && d->epi == FIERY_EPI_PLAIN, "conv_fwd: a chained 1x1 needs cout_pad == 32 and the plain epilogue");
+        FIERY_REQUIRE(d->scale2 && d->shift2 && aligned16(d->weights2), "conv_fwd: chained 1x1 operands missing or misaligned");
+        FIERY_REQUIRE(d->cout_store <= 64, "conv_fwd: a chained 1x1 produces at most 64 channels");
+        FIERY_REQUIRE(!d->res.ptr || !d->res_before_act, "conv_fwd: chained 1x1 adds the residual after the activation");
+    }
     const int bn = (d->cout_pad % 128 == 0) ? 128 : (d->cout_pad % 64 == 0) ? 64 : 32;
     dim3 grid(ceil_div(p.M, BM), d->cout_pad / bn);
     if (bn == 128) hipLaunchKernelGGL(k_conv_igemm<128>, grid, dim3(256), 0, as_stream(stream), p);

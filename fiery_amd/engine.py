@@ -54,6 +54,13 @@ class _Bottleneck:
         sc, sh = fold_bn(L.abn_up_project[0], cout)
         self.conv3 = ConvOp(lib, L.conv_up_project.weight, identity_chan_map(mid), (round_up(mid, 8) // 8, 0), sc, sh,
                             dev, act=RELU)
+        # 3x3 -> 1x1 up-projection (+ residual) as one kernel when the shapes allow: the mid tensor stays on chip
+        self.fused_tail = None
+        if mid <= 32 and cout <= 64:
+            s2, b2 = fold_bn(L.abn[0], mid)
+            self.fused_tail = ConvOp(lib, L.conv.weight, identity_chan_map(mid), (round_up(mid, 8) // 8, 0), s2, b2, dev,
+                                     stride=2 if self.down else 1, act=RELU).chain_pointwise(
+                                         L.conv_up_project.weight, sc, sh, RELU)
         self.skip = None
         if mod.projection is not None:
             sc, sh = fold_bn(mod.projection.bn_skip_proj, cout)
@@ -70,11 +77,15 @@ class _Bottleneck:
         Ho, Wo = self.out_hw(H, W)
         t1 = scratch('bn_t1', n, H, W, self.mid)
         self.conv1(list(srcs), t1)
-        t2 = scratch('bn_t2', n, Ho, Wo, self.mid)
-        self.conv2([t1], t2)
+        if self.fused_tail is None:
+            t2 = scratch('bn_t2', n, Ho, Wo, self.mid)
+            self.conv2([t1], t2)
+            tail = lambda res: self.conv3([t2], out, res=res)
+        else:
+            tail = lambda res: self.fused_tail([t1], out, res=res)
         if self.skip is None:
             assert len(srcs) == 1
-            self.conv3([t2], out, res=x)
+            tail(x)
             return
         if self.down:
             pooled = scratch('bn_pool', n, Ho, Wo, self.cin)
@@ -89,7 +100,7 @@ class _Bottleneck:
             skip_in = x
         s2 = scratch('bn_skip', n, Ho, Wo, self.cout)
         self.skip([skip_in], s2)
-        self.conv3([t2], out, res=s2)
+        tail(s2)
 
 
 class _TemporalBlock:
@@ -508,10 +519,15 @@ class BevEngine:
                     # the last convolution writes straight into frames 1.. of the decoder input, per batch element
                     t1 = self.buf('fpbn_t1', B * nf, H, W, blk.mid)
                     blk.conv1([x], t1)
-                    t2 = self.buf('fpbn_t2', B * nf, H, W, blk.mid)
-                    blk.conv2([t1], t2)
+                    if blk.fused_tail is None:
+                        t2 = self.buf('fpbn_t2', B * nf, H, W, blk.mid)
+                        blk.conv2([t1], t2)
                     for b in range(B):
-                        blk.conv3([t2.images(b * nf, nf)], dec_in.images(b * (nf + 1) + 1, nf), res=x.images(b * nf, nf))
+                        dst, res = dec_in.images(b * (nf + 1) + 1, nf), x.images(b * nf, nf)
+                        if blk.fused_tail is None:
+                            blk.conv3([t2.images(b * nf, nf)], dst, res=res)
+                        else:
+                            blk.fused_tail([t1.images(b * nf, nf)], dst, res=res)
             seq_in = x
         if not self.res_blocks[-1]:
             dec_in.nhwc().view(B, nf + 1, H, W, -1)[:, 1:].copy_(seq_in.nhwc().view(B, nf, H, W, -1))

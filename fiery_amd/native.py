@@ -50,6 +50,7 @@ class ConvDesc(C.Structure):
         ('act', C.c_int32), ('epi', C.c_int32), ('res_before_act', C.c_int32),
         ('res', Nhwc), ('out', Nhwc), ('cout_store', C.c_int32), ('out2', Nhwc),
         ('aux0', Nhwc), ('aux1', Nhwc),
+        ('weights2', C.c_void_p), ('scale2', C.c_void_p), ('shift2', C.c_void_p), ('act2', C.c_int32),
     ]
 
 

@@ -131,6 +131,24 @@ class ConvOp:
         sh[:self.cout] = shift
         self.scale, self.shift = sc.to(device), sh.to(device)
         self.act, self.epi, self.res_before_act = act, epi, res_before_act
+        self.chain = None
+
+    def chain_pointwise(self, weight, scale, shift, act):
+        """Fuse a following 1x1 convolution (Cin <= 32 = this op's padded outputs, Cout <= 64) into this kernel:
+        its input tile never leaves the chip.  `weight` (Cout2, Cin2[, 1, 1])."""
+        assert self.cout_pad == 32 and self.epi == native.EPI_PLAIN, 'chaining needs a 32-channel plain convolution'
+        w = weight.detach().float().reshape(weight.shape[0], weight.shape[1])
+        cout2, cin2 = w.shape
+        assert cin2 == self.cout and cout2 <= 64
+        device = self.packed.device
+        w64 = torch.zeros(64, cin2, dtype=torch.float32, device=device)     # pack as a 64-wide tile (BN = 64 image)
+        w64[:cout2] = w.to(device)
+        packed = self.lib.conv_pack_weights(w64.contiguous(), 64, cin2, 1, list(range(cin2)), 4)
+        sc = torch.zeros(64, dtype=torch.float32)
+        sh = torch.zeros(64, dtype=torch.float32)
+        sc[:cout2], sh[:cout2] = scale, shift
+        self.chain = dict(w=packed, scale=sc.to(device), shift=sh.to(device), act=act, cout=cout2)
+        return self
 
     def out_hw(self, H, W):
         return ((H + 2 * self.padH - self.kH) // self.stride + 1, (W + 2 * self.padW - self.kW) // self.stride + 1)
@@ -160,12 +178,21 @@ class ConvOp:
         d.act, d.epi, d.res_before_act = self.act, self.epi, int(self.res_before_act)
         d.res = res.as_nhwc_struct() if res is not None else _null_nhwc()
         d.out = out.as_nhwc_struct()
-        d.cout_store = cout_store if cout_store is not None else min(self.cout_pad, round_up(self.cout, UNIT), out.C)
+        if self.chain is not None:
+            d.weights2, d.scale2, d.shift2 = self.chain['w'].data_ptr(), self.chain['scale'].data_ptr(), self.chain['shift'].data_ptr()
+            d.act2 = self.chain['act']
+            d.cout_store = cout_store if cout_store is not None else min(64, round_up(self.chain['cout'], UNIT), out.C)
+        else:
+            d.weights2 = d.scale2 = d.shift2 = None
+            d.act2 = 0
+            d.cout_store = cout_store if cout_store is not None else min(self.cout_pad, round_up(self.cout, UNIT), out.C)
         d.out2 = out2.as_nhwc_struct() if out2 is not None else _null_nhwc()
         d.aux0 = aux0.as_nhwc_struct() if aux0 is not None else _null_nhwc()
         d.aux1 = aux1.as_nhwc_struct() if aux1 is not None else _null_nhwc()
         self._keep = (srcs, out, res, img_bias, out2, aux0, aux1)
         flops = 2.0 * out.n_img * out.H * out.W * self.cin_total * self.kT * self.kH * self.kW * self.cout
+        if self.chain is not None:
+            flops += 2.0 * out.n_img * out.H * out.W * self.cout * self.chain['cout']
         profiled('conv_igemm', flops, out.tensor, lambda: self.lib.conv_fwd(d, out.tensor),
                  detail=(self.kT, self.kH, self.kW, self.stride, self.cin_total, self.cout, out.n_img, out.H, out.W))
 

@@ -177,6 +177,15 @@ typedef struct {
     int32_t cout_store;                /* channels written to out (<= cout_pad)                         */
     fiery_nhwc out2;                   /* second destination (GRU modes), ptr NULL = none               */
     fiery_nhwc aux0, aux1;             /* GRU operands                                                   */
+    /* Optional chained 1x1 convolution on the result tile (the Bottleneck's up-projection,
+     * layers/convolutions.py:128-133): when weights2 != NULL (requires cout_pad == 32 and FIERY_EPI_PLAIN) the
+     * activation act(acc*scale+shift) is not stored but multiplied, still on chip, by weights2
+     * (packed with fiery_conv_pack_weights for 4 input units and cout2 <= 64 outputs), then
+     * out = act2(.*scale2 + shift2) [+ res after the activation]; cout_store counts channels of that result. */
+    const float* weights2;
+    const float* scale2;               /* [64] */
+    const float* shift2;               /* [64] */
+    int32_t act2;
 } fiery_conv_desc;
 
 /* Packs a dense weight W[cout][cin_total][taps] (taps = kT*kH*kW, row-major as PyTorch stores conv

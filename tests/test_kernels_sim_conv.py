@@ -179,3 +179,25 @@ def test_heads_1x1_nchw(sim):
         if sig[o]:
             want = torch.sigmoid(want)
         assert torch.allclose(out[:, o], want, **TOL)
+
+
+@pytest.mark.parametrize('mid,cout,stride', [(32, 64, 1), (20, 40, 2)])
+def test_chained_pointwise_conv_with_residual(sim, mid, cout, stride):
+    """3x3 conv + BN + ReLU -> 1x1 conv + BN + ReLU + residual as ONE kernel (the Bottleneck's tail,
+    fiery/layers/convolutions.py:123-168): the intermediate tile stays on chip."""
+    g = torch.Generator().manual_seed(mid + cout)
+    x = torch.randn(2, mid, 9, 14, generator=g)
+    w2 = torch.randn(mid, mid, 3, 3, generator=g) * 0.15
+    w3 = torch.randn(cout, mid, 1, 1, generator=g) * 0.3
+    s2, b2 = torch.rand(mid, generator=g) + 0.5, torch.randn(mid, generator=g)
+    s3, b3 = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    src = _to_buf(x)
+    op = ConvOp(sim, w2, identity_chan_map(mid), (src.C // 8, 0), s2, b2, 'cpu', stride=stride, act=native.ACT_RELU)
+    op.chain_pointwise(w3, s3, b3, native.ACT_RELU)
+    ho, wo = op.out_hw(9, 14)
+    res = torch.randn(2, cout, ho, wo, generator=g)
+    out = Buf.alloc(2, ho, wo, cout, 'cpu')
+    op([src], out, res=_to_buf(res))
+    h = F.relu(F.conv2d(x, w2, stride=stride, padding=1) * s2.view(1, -1, 1, 1) + b2.view(1, -1, 1, 1))
+    want = F.relu(F.conv2d(h, w3) * s3.view(1, -1, 1, 1) + b3.view(1, -1, 1, 1)) + res
+    assert torch.allclose(out.to_nchw()[:, :cout], want, **TOL), (out.to_nchw()[:, :cout] - want).abs().max()
