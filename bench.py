@@ -130,7 +130,14 @@ def main():
     # one instrumented replica of the step, after the timed region, so the event records do not perturb `value`:
     # HIP events around every launch of the dominant kernel on the stream it is launched on
     roofline = pooling = None
+    host_ms = None
     if rank == 0:
+        torch.cuda.synchronize()
+        t_host = time.perf_counter()
+        with torch.no_grad():
+            step()                                         # enqueue only: how long the host needs to issue one step
+        host_ms = (time.perf_counter() - t_host) * 1e3
+        torch.cuda.synchronize()
         ops.PROFILE_SINK = []
         with torch.no_grad():
             step()
@@ -166,7 +173,7 @@ def main():
                                    f'{nf} future frames, batch {B} per GPU, fp32, '
                                    f'{"fused lift-splat from depth+features" if args.fused else "lifted features (n,C,D,h,w) resident in HBM"}',
                        'global_batch': B * world, 'parallelism': f'batch-sharded x{world}, no data-path collective'},
-            'roofline': roofline, 'roofline_pooling': pooling,
+            'roofline': roofline, 'roofline_pooling': pooling, 'host_enqueue_ms_per_step': round(host_ms, 3),
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(cfg, sd, lifted, K, E, ego)

@@ -22,12 +22,14 @@
 //     the epilogue applies bias / folded BatchNorm / activation / residual / GRU gate math in registers.
 #include "common.h"
 
+#include <cmath>
+#include <cstdlib>
+
 namespace fiery {
 namespace {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128;   // output pixels per workgroup
 constexpr int BK = 32;    // k per LDS stage (4 units of 8 input channels)
 constexpr int kMaxCinUnits = 64;
 
@@ -62,8 +64,11 @@ struct ConvP {
 
 __device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(-v)); }
 
-template <int BN>
+// BM output pixels x BN couts per workgroup: (128, 32|64|128) and (64, 64|128).  The 64-pixel tiles exist for
+// launches whose 128-pixel tile count would leave a badly filled last wave of workgroups.
+template <int BM, int BN>
 __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
+    constexpr int NA = BM / 32;            // A-gather loads (16 B each) per thread and stage
     constexpr int WN = BN >= 64 ? 2 : 1;   // wavefronts along couts
     constexpr int WM = 4 / WN;             // wavefronts along pixels
     constexpr int MT = BM / (32 * WM);     // 32-pixel MFMA tiles per wavefront   (BN=32: 1, else 2)
@@ -96,10 +101,10 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     // predicate per load, and the (tap, channel-unit) of the thread's slot advances incrementally.
     const int f4 = tid & 7;                // logical 16-byte slot inside the 32-k row
     const int prow = tid >> 3;             // 0..31
-    int py0[4], px0[4], ptmin[4], poff0[4], poff1[4];
-    bool pvalid[4];
+    int py0[NA], px0[NA], ptmin[NA], poff0[NA], poff1[NA];
+    bool pvalid[NA];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NA; ++j) {
         const int gp = pix0 + prow + 32 * j;
         pvalid[j] = gp < M;
         const int g = pvalid[j] ? gp : 0;
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     }
     const float* wnext = p.w + static_cast<long long>(tile_n) * p.k_chunks * (BK * BN) + tid * 4;
 
-    float4 areg[4];
+    float4 areg[NA];
     float4 breg0 = make_float4(0.f, 0.f, 0.f, 0.f), breg1 = breg0, breg2 = breg0, breg3 = breg0;   // named: an indexed array ends up in scratch
 
     // loads stage `next` (stages are requested in order 0, 1, 2, ...)
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
         const int tstride = static_cast<int>(second ? p.src[1].tstride : p.src[0].tstride);
         const int tap_off = u_dt * tstride + (u_dy * p.Win + u_dx) * ld + (u_cc - (second ? p.src[0].units : 0)) * 8 + (f4 & 1) * 4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NA; ++j) {
             const int iy = py0[j] + u_dy, ix = px0[j] + u_dx;
             const bool ok = uvalid && pvalid[j] && static_cast<unsigned>(iy) < static_cast<unsigned>(p.Hin) &&
                             static_cast<unsigned>(ix) < static_cast<unsigned>(p.Win) && (ptmin[j] + u_dt) >= 0;
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     };
     auto store_stage = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NA; ++j) {
             const int pl = prow + 32 * j;
             const int slot = f4 ^ ((pl >> 1) & 7);
             *reinterpret_cast<float4*>(&As[buf][pl * BK + slot * 4]) = areg[j];
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     }
 
     // ---- optional chained 1x1 convolution on the tile (Bottleneck up-projection) -----------------------------
-    if constexpr (BN == 32) {
+    if constexpr (BN == 32 && BM == 128) {
         if (p.w2) {
             // (1) h = act(acc*scale + shift) back into LDS as the A operand of a second GEMM: [pixel][32 k], same
             //     slot swizzle as the main loop.  Every wave passed the loop's last barrier, so stage 0 is free.
@@ -542,10 +547,33 @@ extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) {
         FIERY_REQUIRE(!d->res.ptr || !d->res_before_act, "conv_fwd: chained 1x1 adds the residual after the activation");
     }
     const int bn = (d->cout_pad % 128 == 0) ? 128 : (d->cout_pad % 64 == 0) ? 64 : 32;
-    dim3 grid(ceil_div(p.M, BM), d->cout_pad / bn);
-    if (bn == 128) hipLaunchKernelGGL(k_conv_igemm<128>, grid, dim3(256), 0, as_stream(stream), p);
-    else if (bn == 64) hipLaunchKernelGGL(k_conv_igemm<64>, grid, dim3(256), 0, as_stream(stream), p);
-    else hipLaunchKernelGGL(k_conv_igemm<32>, grid, dim3(256), 0, as_stream(stream), p);
+    const int n_tiles = d->cout_pad / bn;
+    // Tile height: workgroups run in waves of (256 CUs x resident workgroups per CU); pick the height whose last
+    // wave is better filled, charging the 64-pixel tile 10 % for its higher load/MFMA ratio.
+    bool half_tiles = false;
+    if (bn >= 64 && !d->weights2) {
+        auto fill = [&](int bm, int per_cu) {
+            const double tiles = static_cast<double>(ceil_div(p.M, bm)) * n_tiles;
+            const double slots = 256.0 * per_cu;
+            return tiles / (ceil(tiles / slots) * slots);
+        };
+        const double e128 = fill(128, bn == 128 ? 2 : 3);
+        const double e64 = 0.9 * fill(64, bn == 128 ? 3 : 5);
+        half_tiles = e64 > e128;
+        if (const char* forced = getenv("FIERY_CONV_TILE_M")) half_tiles = atoi(forced) == 64;   // tuning / tests
+    }
+    dim3 grid(ceil_div(p.M, half_tiles ? 64 : 128), n_tiles);
+    hipStream_t hs = as_stream(stream);
+    if (half_tiles) {
+        if (bn == 128) hipLaunchKernelGGL((k_conv_igemm<64, 128>), grid, dim3(256), 0, hs, p);
+        else hipLaunchKernelGGL((k_conv_igemm<64, 64>), grid, dim3(256), 0, hs, p);
+    } else if (bn == 128) {
+        hipLaunchKernelGGL((k_conv_igemm<128, 128>), grid, dim3(256), 0, hs, p);
+    } else if (bn == 64) {
+        hipLaunchKernelGGL((k_conv_igemm<128, 64>), grid, dim3(256), 0, hs, p);
+    } else {
+        hipLaunchKernelGGL((k_conv_igemm<128, 32>), grid, dim3(256), 0, hs, p);
+    }
     return check_launch("conv_fwd");
 }
 

@@ -16,13 +16,12 @@
 // rounding (separate multiply and add, k ascending) bit for bit.
 #include "common.h"
 
+#include <cstdlib>
+
 #pragma clang fp contract(off)
 
 namespace fiery {
 namespace {
-
-constexpr int kColEmpty = -1;   // no point of the column falls inside the grid
-constexpr int kColMixed = -2;   // the column touches more than one voxel (or is partly outside)
 
 struct GridParams {
     float ox, oy, oz;
@@ -152,10 +151,15 @@ __global__ void k_voxel_index(const float* __restrict__ geometry, long long n, G
 constexpr int kMaxTiles = 30;          // tile membership is a bit mask in an int
 constexpr int kPackW = 10, kPackD = 10;   // list entries pack (camera, d, w) into one int
 
-// One thread per image column (frame*camera, d, w): ranks of its H points, the column class and the set of
-// output tiles the column touches.
+// Column descriptor, one int4 per image column (frame*camera, d, w): the column's rows as up to three runs
+//   .x / .y / .z = voxel rank of rows [0, s1) / [s1, s2) / [s2, H)   (-1: those rows fall outside the grid)
+//   .w = s1 | s2 << 12 | general << 24        (s1 = s2 = H: one run; s2 = H: two runs)
+//   general = the column has more than three runs: its rows are then walked one by one with `rank`
+// An upright camera gives single-run columns; a fraction of a degree of pitch or roll makes columns straddle
+// two or three voxels (35 % / 7 % of the columns of the synthetic baseline rig).
+constexpr int kSplitBits = 12;
 __global__ void k_rank_columns(const float* __restrict__ geometry, int n_fc, int D, int H, int W, GridParams p,
-                               int tile_vox, int* __restrict__ rank, int* __restrict__ coldesc,
+                               int tile_vox, int* __restrict__ rank, int4* __restrict__ coldesc,
                                int* __restrict__ colmask) {
     const long long col = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     const long long n_cols = static_cast<long long>(n_fc) * D * W;
@@ -163,41 +167,51 @@ __global__ void k_rank_columns(const float* __restrict__ geometry, int n_fc, int
     const int w = static_cast<int>(col % W);
     const long long fd = col / W;                          // (frame*camera)*D + d
     const long long base = fd * H * W + w;                 // point index of (.., h = 0, w)
-    int first = -3;
-    bool uniform = true;
-    int mask = 0;
+    int ra = -1, rb = -1, rc = -1, s1 = H, s2 = H, runs = 0, prev = 0, mask = 0;
     for (int h = 0; h < H; ++h) {
         const long long pt = base + static_cast<long long>(h) * W;
         const float* g = geometry + 3 * pt;
         const int r = voxel_rank(g[0], g[1], g[2], p, nullptr);
         rank[pt] = r;
-        if (h == 0) first = r;
-        uniform = uniform && (r == first);
+        if (h == 0 || r != prev) {
+            if (runs == 0) ra = r;
+            else if (runs == 1) { rb = r; s1 = h; }
+            else if (runs == 2) { rc = r; s2 = h; }
+            ++runs;
+        }
+        prev = r;
         if (r >= 0) mask |= 1 << (r / tile_vox);
     }
-    coldesc[col] = mask == 0 ? kColEmpty : ((uniform && first >= 0) ? first : kColMixed);
+    const int general = (runs > 3 || H >= (1 << kSplitBits)) ? 1 : 0;
+    coldesc[col] = make_int4(ra, rb, rc, s1 | (s2 << kSplitBits) | (general << (2 * kSplitBits)));
     colmask[col] = mask;
 }
 
-// Ordered (ascending column id) list of the columns that touch one tile of one frame: adjacent list
-// entries are adjacent columns, so the pooling kernel's wavefront loads stay unit-stride.
-// grid (n_tiles, frames), 1024 threads; entry = {camera<<20 | d<<10 | w, column class}.
-__global__ __launch_bounds__(1024) void k_build_tile_lists(const int* __restrict__ coldesc,
-                                                           const int* __restrict__ colmask, int n_cam, int D, int W,
-                                                           int n_tiles, int2* __restrict__ lists, int* __restrict__ counts) {
+// Ordered (ascending id) list of the work-items that touch one tile of one frame; adjacent entries are adjacent
+// in memory, so the pooling kernel's wavefront loads stay unit-stride.  A work-item is a column (group = 1) or
+// four adjacent columns (group = 4, W % 4 == 0): entry = camera<<20 | d<<10 | (w / group).
+// grid (n_tiles, frames), 1024 threads.
+__global__ __launch_bounds__(1024) void k_build_tile_lists(const int* __restrict__ colmask, int n_cam, int D, int W,
+                                                           int group, int n_tiles, int* __restrict__ lists,
+                                                           int* __restrict__ counts) {
     __shared__ int wave_count[16];
     __shared__ int running;
     const int tile = blockIdx.x, f = blockIdx.y;
-    const int n_cols = n_cam * D * W;
+    const int Wg = W / group;
+    const int n_items = n_cam * D * Wg;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int* cd = coldesc + static_cast<long long>(f) * n_cols;
-    const int* cm = colmask + static_cast<long long>(f) * n_cols;
-    int2* out = lists + (static_cast<long long>(f) * n_tiles + tile) * n_cols;
+    const int* cm = colmask + static_cast<long long>(f) * n_items * group;
+    int* out = lists + (static_cast<long long>(f) * n_tiles + tile) * n_items;
     if (threadIdx.x == 0) running = 0;
     __syncthreads();
-    for (int c0 = 0; c0 < n_cols; c0 += 1024) {
-        const int col = c0 + threadIdx.x;
-        const bool hit = col < n_cols && ((cm[col] >> tile) & 1);
+    for (int i0 = 0; i0 < n_items; i0 += 1024) {
+        const int i = i0 + threadIdx.x;
+        bool hit = false;
+        if (i < n_items) {
+            int mk = 0;
+            for (int k = 0; k < group; ++k) mk |= cm[i * group + k];
+            hit = (mk >> tile) & 1;
+        }
         const unsigned long long ballot = __ballot(hit);
         const int before = __popcll(ballot & ((1ull << lane) - 1ull));
         if (lane == 0) wave_count[wave] = __popcll(ballot);
@@ -205,8 +219,8 @@ __global__ __launch_bounds__(1024) void k_build_tile_lists(const int* __restrict
         int offset = running;
         for (int k = 0; k < wave; ++k) offset += wave_count[k];
         if (hit) {
-            const int w = col % W, nd = col / W;
-            out[offset + before] = make_int2(((nd / D) << (kPackW + kPackD)) | ((nd % D) << kPackW) | w, cd[col]);
+            const int wg = i % Wg, nd = i / Wg;
+            out[offset + before] = ((nd / D) << (kPackW + kPackD)) | ((nd % D) << kPackW) | wg;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -246,174 +260,34 @@ template <> struct Cell<true> {
     }
 };
 
-constexpr int kRowsInRegs = 32;   // columns of up to this many rows are held in registers
-
-template <bool kFused, bool kFixed>
-__global__ __launch_bounds__(256) void k_voxel_pool(
-    const float* __restrict__ x, PoolStrides xs,            // unfused: the lifted tensor
-    const float* __restrict__ depth, const float* __restrict__ feat,   // fused: depth prob + features
-    const int* __restrict__ rank, const int2* __restrict__ lists, const int* __restrict__ counts,
-    float* __restrict__ out, int n_cam, int D, int H, int W, int C, int n_vox, int tile_vox, int n_tiles) {
-    using cell_t = typename Cell<kFixed>::type;
-    HIP_DYNAMIC_SHARED(unsigned char, pool_lds)
-    cell_t* plane = reinterpret_cast<cell_t*>(pool_lds);
-    const int tile = blockIdx.x, c = blockIdx.y, f = blockIdx.z;
-    const int v0 = tile * tile_vox;
-    const int v1 = min(v0 + tile_vox, n_vox);
-    const int span = v1 - v0;
-    for (int i = threadIdx.x; i < span; i += blockDim.x) plane[i] = cell_t(0);
-    __syncthreads();
-
-    const int n_cols = n_cam * D * W;
-    const int2* lst = lists + (static_cast<long long>(f) * n_tiles + tile) * n_cols;
-    const int count = counts[f * n_tiles + tile];
-    const int HW = H * W;
-    for (int i = threadIdx.x; i < count; i += blockDim.x) {
-        const int2 e = lst[i];
-        const int w = e.x & ((1 << kPackW) - 1);
-        const int d = (e.x >> kPackW) & ((1 << kPackD) - 1);
-        const int cam = e.x >> (kPackW + kPackD);
-        const int desc = e.y;
-        // row h of this column lives at p[h * step]; fused: value = depth[h] * feature[h]
-        const float* p;
-        const float* q = nullptr;
-        long long step, qstep = 0;
-        if (kFused) {
-            p = depth + ((static_cast<long long>(f) * n_cam + cam) * D + d) * HW + w;
-            step = W;
-            q = feat + ((static_cast<long long>(f) * n_cam + cam) * C + c) * HW + w;
-            qstep = W;
-        } else {
-            p = x + f * xs.f + cam * xs.n + d * xs.d + w * xs.w + c * xs.c;
-            step = xs.h;
-        }
-        const int* rk = rank + ((static_cast<long long>(f) * n_cam + cam) * D + d) * HW + w;
-        if (H <= kRowsInRegs) {
-            // every load of the column is issued before the first use: one memory round trip per column
-            float v[kRowsInRegs];
-#pragma unroll
-            for (int h = 0; h < kRowsInRegs; ++h) v[h] = h < H ? p[h * step] : 0.f;
-            if (kFused) {
-#pragma unroll
-                for (int h = 0; h < kRowsInRegs; ++h) v[h] *= h < H ? q[h * qstep] : 0.f;
-            }
-            if (desc >= 0) {
-                float s = 0.f;
-#pragma unroll
-                for (int h = 0; h < kRowsInRegs; ++h) s += v[h];        // rows >= H add an exact zero
-                Cell<kFixed>::add(&plane[desc - v0], s);
-            } else {
-                int r[kRowsInRegs];
-#pragma unroll
-                for (int h = 0; h < kRowsInRegs; ++h) r[h] = h < H ? rk[h * W] : -1;
-                int cur = -1;
-                float s = 0.f;
-#pragma unroll
-                for (int h = 0; h < kRowsInRegs; ++h) {
-                    const int rr = (r[h] >= v0 && r[h] < v1) ? r[h] : -1;
-                    if (rr != cur) {
-                        if (cur >= 0) Cell<kFixed>::add(&plane[cur - v0], s);
-                        cur = rr;
-                        s = 0.f;
-                    }
-                    if (cur >= 0) s += v[h];
-                }
-                if (cur >= 0) Cell<kFixed>::add(&plane[cur - v0], s);
-            }
-        } else {
-            // tall columns: same arithmetic, row by row
-            int cur = -1;
-            float s = 0.f;
-            for (int h = 0; h < H; ++h) {
-                int rr = desc >= 0 ? desc : rk[h * W];
-                if (rr < v0 || rr >= v1) rr = -1;
-                if (rr != cur) {
-                    if (cur >= 0) Cell<kFixed>::add(&plane[cur - v0], s);
-                    cur = rr;
-                    s = 0.f;
-                }
-                if (cur >= 0) s += kFused ? p[h * step] * q[h * qstep] : p[h * step];
-            }
-            if (cur >= 0) Cell<kFixed>::add(&plane[cur - v0], s);
-        }
-    }
-    __syncthreads();
-    float* o = out + (static_cast<long long>(f) * C + c) * n_vox + v0;
-    for (int i = threadIdx.x; i < span; i += blockDim.x) o[i] = Cell<kFixed>::value(plane[i]);
-}
-
-// ------------------------------------------------------------------------------------------------
-// vectorised pooling: four adjacent columns (a "quad", 16 bytes of every row) per work-item
-// ------------------------------------------------------------------------------------------------
-// Same tile lists, but of quads: entry = camera<<20 | d<<10 | (w/4); a quad is listed for a tile when any of
-// its columns touches it.  grid (n_tiles, frames), 1024 threads.
-__global__ __launch_bounds__(1024) void k_build_quad_lists(const int* __restrict__ colmask, int n_cam, int D, int W,
-                                                           int n_tiles, int* __restrict__ lists, int* __restrict__ counts) {
-    __shared__ int wave_count[16];
-    __shared__ int running;
-    const int tile = blockIdx.x, f = blockIdx.y;
-    const int W4 = W >> 2;
-    const int n_quads = n_cam * D * W4;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int4* cm = reinterpret_cast<const int4*>(colmask + static_cast<long long>(f) * n_quads * 4);
-    int* out = lists + (static_cast<long long>(f) * n_tiles + tile) * n_quads;
-    if (threadIdx.x == 0) running = 0;
-    __syncthreads();
-    for (int q0 = 0; q0 < n_quads; q0 += 1024) {
-        const int q = q0 + threadIdx.x;
-        bool hit = false;
-        if (q < n_quads) {
-            const int4 mk = cm[q];
-            hit = ((mk.x | mk.y | mk.z | mk.w) >> tile) & 1;
-        }
-        const unsigned long long ballot = __ballot(hit);
-        const int before = __popcll(ballot & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_count[wave] = __popcll(ballot);
-        __syncthreads();
-        int offset = running;
-        for (int k = 0; k < wave; ++k) offset += wave_count[k];
-        if (hit) {
-            const int w4 = q % W4, nd = q / W4;
-            out[offset + before] = ((nd / D) << (kPackW + kPackD)) | ((nd % D) << kPackW) | w4;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int total = 0;
-            for (int k = 0; k < 16; ++k) total += wave_count[k];
-            running += total;
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) counts[f * n_tiles + tile] = running;
-}
-
-constexpr int kQuadBatch = 7;    // rows in flight per work-item: 7 x 16 B (+ 7 x 16 B of ranks on the general path)
-
-// One run-length accumulator per column: add `val` for voxel `r` (r < 0 = not in this tile); when the voxel
-// changes the finished run is retired with one LDS atomic.
+// Merges consecutive contributions to the same voxel before they reach LDS: add(r, val) with r < 0 ignored.
 template <bool kFixed>
-struct Run {
+struct Merge {
     int cur = -1;
     float sum = 0.f;
-    __device__ __forceinline__ void step(typename Cell<kFixed>::type* plane, int v0, int r, float val) {
+    __device__ __forceinline__ void add(typename Cell<kFixed>::type* plane, int v0, int v1, int r, float val) {
+        if (r < v0 || r >= v1) return;                     // other tile, or outside the grid
         if (r != cur) {
             if (cur >= 0) Cell<kFixed>::add(&plane[cur - v0], sum);
             cur = r;
             sum = 0.f;
         }
-        if (cur >= 0) sum += val;
+        sum += val;
     }
     __device__ __forceinline__ void flush(typename Cell<kFixed>::type* plane, int v0) {
         if (cur >= 0) Cell<kFixed>::add(&plane[cur - v0], sum);
         cur = -1;
-        sum = 0.f;
     }
 };
 
-template <bool kFused, bool kFixed>
-__global__ __launch_bounds__(256) void k_voxel_pool_quad(
-    const float* __restrict__ x, PoolStrides xs, const float* __restrict__ depth, const float* __restrict__ feat,
-    const int* __restrict__ rank, const int* __restrict__ coldesc, const int* __restrict__ lists,
+constexpr int kBatch = 16;     // rows of a work-item in flight at once
+
+// kVec = 4: a work-item is four adjacent columns, every row one 16-byte load; kVec = 1: one column, any strides.
+template <int kVec, bool kFused, bool kFixed>
+__global__ __launch_bounds__(256) void k_voxel_pool(
+    const float* __restrict__ x, PoolStrides xs,            // unfused: the lifted tensor
+    const float* __restrict__ depth, const float* __restrict__ feat,   // fused: depth prob + features
+    const int* __restrict__ rank, const int4* __restrict__ coldesc, const int* __restrict__ lists,
     const int* __restrict__ counts, float* __restrict__ out, int n_cam, int D, int H, int W, int C, int n_vox,
     int tile_vox, int n_tiles) {
     using cell_t = typename Cell<kFixed>::type;
@@ -426,19 +300,38 @@ __global__ __launch_bounds__(256) void k_voxel_pool_quad(
     for (int i = threadIdx.x; i < span; i += blockDim.x) plane[i] = cell_t(0);
     __syncthreads();
 
-    const int W4 = W >> 2;
-    const int n_quads = n_cam * D * W4;
-    const int* lst = lists + (static_cast<long long>(f) * n_tiles + tile) * n_quads;
+    const int Wg = W / kVec;
+    const int n_items = n_cam * D * Wg;
+    const int* lst = lists + (static_cast<long long>(f) * n_tiles + tile) * n_items;
     const int count = counts[f * n_tiles + tile];
     const int HW = H * W;
-    const int4* cdesc = reinterpret_cast<const int4*>(coldesc + static_cast<long long>(f) * n_quads * 4);
+    const int4* cdesc = coldesc + static_cast<long long>(f) * n_items * kVec;
+
+    // the next work-item's list entry and descriptors are fetched while the current one is summed
+    int e_next = 0;
+    int4 d_next[kVec];
+    auto fetch = [&](int i) {
+        if (i < count) {
+            e_next = lst[i];
+            const int wg = e_next & ((1 << kPackW) - 1);
+            const int d = (e_next >> kPackW) & ((1 << kPackD) - 1);
+            const int cam = e_next >> (kPackW + kPackD);
+            const int4* dp = cdesc + (static_cast<long long>(cam) * D + d) * W + wg * kVec;
+#pragma unroll
+            for (int k = 0; k < kVec; ++k) d_next[k] = dp[k];
+        }
+    };
+    fetch(threadIdx.x);
     for (int i = threadIdx.x; i < count; i += blockDim.x) {
-        const int e = lst[i];
-        const int w = (e & ((1 << kPackW) - 1)) << 2;
+        const int e = e_next;
+        int4 dsc[kVec];
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) dsc[k] = d_next[k];
+        fetch(i + blockDim.x);
+        const int w = (e & ((1 << kPackW) - 1)) * kVec;
         const int d = (e >> kPackW) & ((1 << kPackD) - 1);
         const int cam = e >> (kPackW + kPackD);
-        const int4 dsc = cdesc[(cam * D + d) * W4 + (w >> 2)];
-        // row h of this quad: 16 bytes at p + h*step; fused: depth row times feature row
+        // row h of this work-item lives at p + h*step (kVec floats); fused: depth row times feature row
         const float* p;
         const float* q = nullptr;
         long long step, qstep = 0;
@@ -448,71 +341,74 @@ __global__ __launch_bounds__(256) void k_voxel_pool_quad(
             q = feat + ((static_cast<long long>(f) * n_cam + cam) * C + c) * HW + w;
             qstep = W;
         } else {
-            p = x + f * xs.f + cam * xs.n + d * xs.d + w + c * xs.c;
+            p = x + f * xs.f + cam * xs.n + d * xs.d + w * xs.w + c * xs.c;
             step = xs.h;
         }
-        const bool general = dsc.x == kColMixed || dsc.y == kColMixed || dsc.z == kColMixed || dsc.w == kColMixed;
-        if (!general) {
-            // every column of the quad falls into one voxel (or outside the grid): sum the rows, then retire
-            // the four column sums, merging neighbours that share a voxel
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            for (int h0 = 0; h0 < H; h0 += kQuadBatch) {
-                float4 v[kQuadBatch];
+        bool general = false;
 #pragma unroll
-                for (int k = 0; k < kQuadBatch; ++k)
-                    v[k] = (h0 + k < H) ? *reinterpret_cast<const float4*>(p + (h0 + k) * step) : make_float4(0.f, 0.f, 0.f, 0.f);
-                if (kFused) {
+        for (int k = 0; k < kVec; ++k) general = general || (dsc[k].w >> (2 * kSplitBits)) != 0;
+
+        float sa[kVec], sb[kVec], sc[kVec];
+        int s1[kVec], s2[kVec];
 #pragma unroll
-                    for (int k = 0; k < kQuadBatch; ++k) {
-                        const float4 g = (h0 + k < H) ? *reinterpret_cast<const float4*>(q + (h0 + k) * qstep) : make_float4(0.f, 0.f, 0.f, 0.f);
-                        v[k].x *= g.x;  v[k].y *= g.y;  v[k].z *= g.z;  v[k].w *= g.w;
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < kQuadBatch; ++k) {
-                    s0 += v[k].x;  s1 += v[k].y;  s2 += v[k].z;  s3 += v[k].w;
-                }
-            }
-            Run<kFixed> run;
-            run.step(plane, v0, (dsc.x >= v0 && dsc.x < v1) ? dsc.x : -1, s0);
-            run.step(plane, v0, (dsc.y >= v0 && dsc.y < v1) ? dsc.y : -1, s1);
-            run.step(plane, v0, (dsc.z >= v0 && dsc.z < v1) ? dsc.z : -1, s2);
-            run.step(plane, v0, (dsc.w >= v0 && dsc.w < v1) ? dsc.w : -1, s3);
-            run.flush(plane, v0);
-        } else {
-            // some column crosses voxels: four run-length accumulators driven by the per-point ranks
-            const int* rk = rank + ((static_cast<long long>(f) * n_cam + cam) * D + d) * HW + w;
-            Run<kFixed> r0, r1, r2, r3;
-            for (int h0 = 0; h0 < H; h0 += kQuadBatch) {
-                float4 v[kQuadBatch];
-                int4 r[kQuadBatch];
-#pragma unroll
-                for (int k = 0; k < kQuadBatch; ++k) {
-                    const bool in = h0 + k < H;
-                    v[k] = in ? *reinterpret_cast<const float4*>(p + (h0 + k) * step) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    r[k] = in ? *reinterpret_cast<const int4*>(rk + (h0 + k) * W) : make_int4(-1, -1, -1, -1);
-                }
-                if (kFused) {
-#pragma unroll
-                    for (int k = 0; k < kQuadBatch; ++k) {
-                        const float4 g = (h0 + k < H) ? *reinterpret_cast<const float4*>(q + (h0 + k) * qstep) : make_float4(0.f, 0.f, 0.f, 0.f);
-                        v[k].x *= g.x;  v[k].y *= g.y;  v[k].z *= g.z;  v[k].w *= g.w;
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < kQuadBatch; ++k) {
-                    if (h0 + k >= H) break;
-                    r0.step(plane, v0, (r[k].x >= v0 && r[k].x < v1) ? r[k].x : -1, v[k].x);
-                    r1.step(plane, v0, (r[k].y >= v0 && r[k].y < v1) ? r[k].y : -1, v[k].y);
-                    r2.step(plane, v0, (r[k].z >= v0 && r[k].z < v1) ? r[k].z : -1, v[k].z);
-                    r3.step(plane, v0, (r[k].w >= v0 && r[k].w < v1) ? r[k].w : -1, v[k].w);
-                }
-            }
-            r0.flush(plane, v0);
-            r1.flush(plane, v0);
-            r2.flush(plane, v0);
-            r3.flush(plane, v0);
+        for (int k = 0; k < kVec; ++k) {
+            sa[k] = sb[k] = sc[k] = 0.f;
+            s1[k] = dsc[k].w & ((1 << kSplitBits) - 1);
+            s2[k] = (dsc[k].w >> kSplitBits) & ((1 << kSplitBits) - 1);
         }
+        Merge<kFixed> merge;
+        const int* rk = rank + ((static_cast<long long>(f) * n_cam + cam) * D + d) * HW + w;
+        for (int h0 = 0; h0 < H; h0 += kBatch) {
+            float v[kBatch][kVec];
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                const bool in = h0 + j < H;
+                if (kVec == 4) {
+                    const float4 t = in ? *reinterpret_cast<const float4*>(p + (h0 + j) * step) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    v[j][0] = t.x;  v[j][1 % kVec] = t.y;  v[j][2 % kVec] = t.z;  v[j][3 % kVec] = t.w;
+                } else {
+                    v[j][0] = in ? p[(h0 + j) * step] : 0.f;
+                }
+            }
+            if (kFused) {
+#pragma unroll
+                for (int j = 0; j < kBatch; ++j) {
+                    const bool in = h0 + j < H;
+                    if (kVec == 4) {
+                        const float4 t = in ? *reinterpret_cast<const float4*>(q + (h0 + j) * qstep) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        v[j][0] *= t.x;  v[j][1 % kVec] *= t.y;  v[j][2 % kVec] *= t.z;  v[j][3 % kVec] *= t.w;
+                    } else {
+                        v[j][0] *= in ? q[(h0 + j) * qstep] : 0.f;
+                    }
+                }
+            }
+            if (!general) {
+                // each row adds to the run it belongs to (adding 0.f to the others is exact)
+#pragma unroll
+                for (int j = 0; j < kBatch; ++j)
+#pragma unroll
+                    for (int k = 0; k < kVec; ++k) {
+                        const bool first = h0 + j < s1[k], third = h0 + j >= s2[k];
+                        sa[k] += first ? v[j][k] : 0.f;
+                        sc[k] += third ? v[j][k] : 0.f;
+                        sb[k] += (first || third) ? 0.f : v[j][k];
+                    }
+            } else {
+                // a column with four or more runs somewhere in this work-item: walk the rows with their ranks
+                for (int j = 0; j < kBatch && h0 + j < H; ++j)
+                    for (int k = 0; k < kVec; ++k) merge.add(plane, v0, v1, rk[(h0 + j) * W + k], v[j][k]);
+                // (columns are interleaved here, so `merge` only fuses vertical runs of a single-column item)
+            }
+        }
+        if (!general) {
+#pragma unroll
+            for (int k = 0; k < kVec; ++k) {
+                merge.add(plane, v0, v1, dsc[k].x, sa[k]);
+                if (s1[k] < H) merge.add(plane, v0, v1, dsc[k].y, sb[k]);
+                if (s2[k] < H) merge.add(plane, v0, v1, dsc[k].z, sc[k]);
+            }
+        }
+        merge.flush(plane, v0);
     }
     __syncthreads();
     float* o = out + (static_cast<long long>(f) * C + c) * n_vox + v0;
@@ -581,10 +477,10 @@ int plan_pool(int frames, int n_cam, int D, int H, int W, long long n_vox_ll, in
     const size_t cols = static_cast<size_t>(frames) * n_cam * D * W;
     auto align = [](size_t v) { return (v + 255) / 256 * 256; };
     pl->off_coldesc = align(points * 4);
-    pl->off_colmask = align(pl->off_coldesc + cols * 4);
+    pl->off_colmask = align(pl->off_coldesc + cols * sizeof(int4));
     pl->off_counts = align(pl->off_colmask + cols * 4);
     pl->off_lists = align(pl->off_counts + static_cast<size_t>(frames) * pl->n_tiles * 4);
-    pl->total = pl->off_lists + cols * pl->n_tiles * sizeof(int2);
+    pl->total = pl->off_lists + cols * pl->n_tiles * sizeof(int);
     return FIERY_OK;
 }
 
@@ -623,17 +519,16 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
     }
     char* ws = static_cast<char*>(workspace);
     int* rank = reinterpret_cast<int*>(ws);
-    int* coldesc = reinterpret_cast<int*>(ws + pl.off_coldesc);
+    int4* coldesc = reinterpret_cast<int4*>(ws + pl.off_coldesc);
     int* colmask = reinterpret_cast<int*>(ws + pl.off_colmask);
     int* counts = reinterpret_cast<int*>(ws + pl.off_counts);
-    int2* lists = reinterpret_cast<int2*>(ws + pl.off_lists);
+    int* lists = reinterpret_cast<int*>(ws + pl.off_lists);
     const long long n_cols_all = static_cast<long long>(frames) * n_cam * D * W;
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(k_rank_columns, dim3(ceil_div(n_cols_all, 256)), dim3(256), 0, s, geometry, frames * n_cam, D, H,
                        W, to_params(*grid), pl.tile, rank, coldesc, colmask);
     rc = check_launch("rank_columns");
     if (rc) return rc;
-    dim3 gridDim3(pl.n_tiles, C, frames);
     PoolStrides st{0, 0, 0, 0, 0, 0};
     if (!fused) st = PoolStrides{xs[0], xs[1], xs[2], xs[3], xs[4], xs[5]};
     // 16-byte path: rows of four columns must be contiguous and 16-byte aligned
@@ -644,33 +539,26 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
         quads = quads && aligned16(x) && st.w == 1 && st.f % 4 == 0 && st.n % 4 == 0 && st.d % 4 == 0 && st.h % 4 == 0 &&
                 st.c % 4 == 0;
     }
-    if (quads) {
-        int* qlists = reinterpret_cast<int*>(lists);
-        hipLaunchKernelGGL(k_build_quad_lists, dim3(pl.n_tiles, frames), dim3(1024), 0, s, colmask, n_cam, D, W, pl.n_tiles,
-                           qlists, counts);
-        rc = check_launch("build_quad_lists");
-        if (rc) return rc;
-#define FIERY_POOL_LAUNCH_Q(FUSED, FIXED)                                                                               \
-    hipLaunchKernelGGL((k_voxel_pool_quad<FUSED, FIXED>), gridDim3, dim3(256), pl.lds, s, x, st, depth, feat, rank, coldesc, \
-                       qlists, counts, out, n_cam, D, H, W, C, pl.n_vox, pl.tile, pl.n_tiles)
-        if (fused && fixed) FIERY_POOL_LAUNCH_Q(true, true);
-        else if (fused) FIERY_POOL_LAUNCH_Q(true, false);
-        else if (fixed) FIERY_POOL_LAUNCH_Q(false, true);
-        else FIERY_POOL_LAUNCH_Q(false, false);
-#undef FIERY_POOL_LAUNCH_Q
-        return check_launch("voxel_pool_quad");
-    }
-    hipLaunchKernelGGL(k_build_tile_lists, dim3(pl.n_tiles, frames), dim3(1024), 0, s, coldesc, colmask, n_cam, D, W,
+    if (const char* forced = getenv("FIERY_POOL_VEC")) quads = quads && atoi(forced) == 4;      // tuning / tests
+    hipLaunchKernelGGL(k_build_tile_lists, dim3(pl.n_tiles, frames), dim3(1024), 0, s, colmask, n_cam, D, W, quads ? 4 : 1,
                        pl.n_tiles, lists, counts);
     rc = check_launch("build_tile_lists");
     if (rc) return rc;
-#define FIERY_POOL_LAUNCH(FUSED, FIXED)                                                                             \
-    hipLaunchKernelGGL((k_voxel_pool<FUSED, FIXED>), gridDim3, dim3(256), pl.lds, s, x, st, depth, feat, rank, lists, \
-                       counts, out, n_cam, D, H, W, C, pl.n_vox, pl.tile, pl.n_tiles)
-    if (fused && fixed) FIERY_POOL_LAUNCH(true, true);
-    else if (fused) FIERY_POOL_LAUNCH(true, false);
-    else if (fixed) FIERY_POOL_LAUNCH(false, true);
-    else FIERY_POOL_LAUNCH(false, false);
+    dim3 gridDim3(pl.n_tiles, C, frames);
+#define FIERY_POOL_LAUNCH(VEC, FUSED, FIXED)                                                                           \
+    hipLaunchKernelGGL((k_voxel_pool<VEC, FUSED, FIXED>), gridDim3, dim3(256), pl.lds, s, x, st, depth, feat, rank, coldesc, \
+                       lists, counts, out, n_cam, D, H, W, C, pl.n_vox, pl.tile, pl.n_tiles)
+    if (quads) {
+        if (fused && fixed) FIERY_POOL_LAUNCH(4, true, true);
+        else if (fused) FIERY_POOL_LAUNCH(4, true, false);
+        else if (fixed) FIERY_POOL_LAUNCH(4, false, true);
+        else FIERY_POOL_LAUNCH(4, false, false);
+    } else {
+        if (fused && fixed) FIERY_POOL_LAUNCH(1, true, true);
+        else if (fused) FIERY_POOL_LAUNCH(1, true, false);
+        else if (fixed) FIERY_POOL_LAUNCH(1, false, true);
+        else FIERY_POOL_LAUNCH(1, false, false);
+    }
 #undef FIERY_POOL_LAUNCH
     return check_launch("voxel_pool");
 }

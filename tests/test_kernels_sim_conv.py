@@ -46,6 +46,21 @@ def test_conv2d_bn_relu(sim, cin, cout, k, stride, hw):
     assert out.to_nchw()[:, cout:].abs().max() == 0 if out.C > cout else True
 
 
+@pytest.mark.parametrize('tile_m', ['64', '128'])
+@pytest.mark.parametrize('cout', [64, 128])
+def test_both_tile_heights(sim, monkeypatch, tile_m, cout):
+    """The 64- and 128-pixel tile variants are chosen by a fill heuristic; force each and compare."""
+    monkeypatch.setenv('FIERY_CONV_TILE_M', tile_m)
+    g = torch.Generator().manual_seed(int(tile_m) + cout)
+    x = torch.randn(1, 16, 11, 19, generator=g)               # 209 pixels: ragged last tile either way
+    w = torch.randn(cout, 16, 3, 3, generator=g) * 0.2
+    src = _to_buf(x)
+    op = ConvOp(sim, w, identity_chan_map(16), (2, 0), torch.ones(cout), torch.zeros(cout), 'cpu', act=native.ACT_RELU)
+    out = Buf.alloc(1, 11, 19, cout, 'cpu')
+    op([src], out)
+    assert torch.allclose(out.to_nchw(), F.relu(F.conv2d(x, w, padding=1)), **TOL)
+
+
 def test_asymmetric_weights_catch_transposes(sim):
     """A = identity-like input with an asymmetric weight matrix: a row/column swap in the MFMA output
     mapping or the packing cannot pass."""
