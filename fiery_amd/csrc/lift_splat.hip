@@ -280,10 +280,10 @@ struct Merge {
     }
 };
 
-constexpr int kBatch = 16;     // rows of a work-item in flight at once
 
 // kVec = 4: a work-item is four adjacent columns, every row one 16-byte load; kVec = 1: one column, any strides.
-template <int kVec, bool kFused, bool kFixed>
+// kBatch: rows of a work-item in flight at once.
+template <int kVec, int kBatch, bool kFused, bool kFixed>
 __global__ __launch_bounds__(256) void k_voxel_pool(
     const float* __restrict__ x, PoolStrides xs,            // unfused: the lifted tensor
     const float* __restrict__ depth, const float* __restrict__ feat,   // fused: depth prob + features
@@ -545,20 +545,26 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
     rc = check_launch("build_tile_lists");
     if (rc) return rc;
     dim3 gridDim3(pl.n_tiles, C, frames);
-#define FIERY_POOL_LAUNCH(VEC, FUSED, FIXED)                                                                           \
-    hipLaunchKernelGGL((k_voxel_pool<VEC, FUSED, FIXED>), gridDim3, dim3(256), pl.lds, s, x, st, depth, feat, rank, coldesc, \
-                       lists, counts, out, n_cam, D, H, W, C, pl.n_vox, pl.tile, pl.n_tiles)
+    int batch = fused ? 8 : 16;                 // the fused form holds two operands per row
+    if (const char* forced = getenv("FIERY_POOL_BATCH")) batch = atoi(forced) == 8 ? 8 : 16;
+#define FIERY_POOL_LAUNCH(VEC, BATCH, FUSED, FIXED)                                                                      \
+    hipLaunchKernelGGL((k_voxel_pool<VEC, BATCH, FUSED, FIXED>), gridDim3, dim3(256), pl.lds, s, x, st, depth, feat, rank, \
+                       coldesc, lists, counts, out, n_cam, D, H, W, C, pl.n_vox, pl.tile, pl.n_tiles)
+#define FIERY_POOL_DISPATCH(VEC, BATCH)                          \
+    do {                                                         \
+        if (fused && fixed) FIERY_POOL_LAUNCH(VEC, BATCH, true, true);        \
+        else if (fused) FIERY_POOL_LAUNCH(VEC, BATCH, true, false);           \
+        else if (fixed) FIERY_POOL_LAUNCH(VEC, BATCH, false, true);           \
+        else FIERY_POOL_LAUNCH(VEC, BATCH, false, false);                     \
+    } while (0)
     if (quads) {
-        if (fused && fixed) FIERY_POOL_LAUNCH(4, true, true);
-        else if (fused) FIERY_POOL_LAUNCH(4, true, false);
-        else if (fixed) FIERY_POOL_LAUNCH(4, false, true);
-        else FIERY_POOL_LAUNCH(4, false, false);
+        if (batch == 8) FIERY_POOL_DISPATCH(4, 8);
+        else FIERY_POOL_DISPATCH(4, 16);
     } else {
-        if (fused && fixed) FIERY_POOL_LAUNCH(1, true, true);
-        else if (fused) FIERY_POOL_LAUNCH(1, true, false);
-        else if (fixed) FIERY_POOL_LAUNCH(1, false, true);
-        else FIERY_POOL_LAUNCH(1, false, false);
+        if (batch == 8) FIERY_POOL_DISPATCH(1, 8);
+        else FIERY_POOL_DISPATCH(1, 16);
     }
+#undef FIERY_POOL_DISPATCH
 #undef FIERY_POOL_LAUNCH
     return check_launch("voxel_pool");
 }

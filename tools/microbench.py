@@ -90,6 +90,7 @@ if __name__ == '__main__':
     lib = native.get()
     what = [a for a in sys.argv[1:] if a in ('pool', 'conv')] or ['pool', 'conv']
     if 'pool' in what:
-        bench_pool(lib, reps)
+        tiles = tuple(int(t) for t in os.environ.get('POOL_TILES', '0').split(','))
+        bench_pool(lib, reps, tiles=tiles)
     if 'conv' in what:
         bench_conv(lib, reps)
