@@ -284,7 +284,7 @@ struct Merge {
 // kVec = 4: a work-item is four adjacent columns, every row one 16-byte load; kVec = 1: one column, any strides.
 // kBatch: rows of a work-item in flight at once.
 template <int kVec, int kBatch, bool kFused, bool kFixed>
-__global__ __launch_bounds__(256) void k_voxel_pool(
+__global__ __launch_bounds__(kFused ? 512 : 1024) void k_voxel_pool(
     const float* __restrict__ x, PoolStrides xs,            // unfused: the lifted tensor
     const float* __restrict__ depth, const float* __restrict__ feat,   // fused: depth prob + features
     const int* __restrict__ rank, const int4* __restrict__ coldesc, const int* __restrict__ lists,
@@ -458,12 +458,13 @@ struct PoolPlan {
 
 // LDS tile of the output plane.  40 KiB tiles keep four workgroups per CU resident (160 KiB LDS); the tile
 // grows when the grid would otherwise need more than kMaxTiles tiles.
-int plan_pool(int frames, int n_cam, int D, int H, int W, long long n_vox_ll, int requested, bool fixed, PoolPlan* pl) {
+int plan_pool(int frames, int n_cam, int D, int H, int W, long long n_vox_ll, int requested, bool fixed, bool fused,
+              PoolPlan* pl) {
     FIERY_REQUIRE(n_vox_ll > 0 && n_vox_ll < (1ll << 30), "voxel_pool: bad grid size");
     FIERY_REQUIRE(W < (1 << kPackW) && D < (1 << kPackD) && n_cam < (1 << (31 - kPackW - kPackD)),
                   "voxel_pool: feature map too large for the column encoding (W, D < 1024, cameras < 2048)");
     const int cell_bytes = fixed ? 8 : 4;
-    const int cap = 160000 / cell_bytes;
+    const int cap = (fused ? 81920 : 160000) / cell_bytes;     // the fused form runs 512-thread workgroups at most
     pl->n_vox = static_cast<int>(n_vox_ll);
     int tile = requested > 0 ? requested : 40960 / cell_bytes;
     if (tile > cap) tile = cap;
@@ -490,7 +491,8 @@ extern "C" size_t fiery_voxel_pool_workspace_bytes(int frames, int n_cameras, in
                                                    int tile_voxels, uint32_t flags) {
     PoolPlan pl;
     if (frames <= 0 || n_cameras <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
-    if (plan_pool(frames, n_cameras, D, H, W, n_voxels, tile_voxels, (flags & FIERY_POOL_DETERMINISTIC) != 0, &pl)) return 0;
+    // sized for the fused form too (its tile cap is the smaller one, so it never needs fewer list slots)
+    if (plan_pool(frames, n_cameras, D, H, W, n_voxels, tile_voxels, (flags & FIERY_POOL_DETERMINISTIC) != 0, true, &pl)) return 0;
     return pl.total;
 }
 
@@ -509,7 +511,7 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
     FIERY_REQUIRE((flags & ~FIERY_POOL_DETERMINISTIC) == 0, "voxel_pool: unknown flags 0x%x", flags);
     const bool fixed = (flags & FIERY_POOL_DETERMINISTIC) != 0;
     PoolPlan pl;
-    int rc = plan_pool(frames, n_cam, D, H, W, static_cast<long long>(grid->dim[0]) * grid->dim[1], tile_voxels, fixed, &pl);
+    int rc = plan_pool(frames, n_cam, D, H, W, static_cast<long long>(grid->dim[0]) * grid->dim[1], tile_voxels, fixed, fused, &pl);
     if (rc) return rc;
     if (ws_bytes < pl.total) return fail(FIERY_ENOMEM, "voxel_pool: workspace %zu B < required %zu B", ws_bytes, pl.total);
     if (fused) {
@@ -547,9 +549,16 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
     dim3 gridDim3(pl.n_tiles, C, frames);
     int batch = fused ? 8 : 16;                 // the fused form holds two operands per row
     if (const char* forced = getenv("FIERY_POOL_BATCH")) batch = atoi(forced) == 8 ? 8 : 16;
+    // workgroup size follows the tile: 256 threads per 40 KiB of LDS keeps 16 wavefronts per CU whatever the tile
+    const int threads = pl.lds <= 40960 ? 256 : (pl.lds <= 81920 ? 512 : 1024);
 #define FIERY_POOL_LAUNCH(VEC, BATCH, FUSED, FIXED)                                                                      \
-    hipLaunchKernelGGL((k_voxel_pool<VEC, BATCH, FUSED, FIXED>), gridDim3, dim3(256), pl.lds, s, x, st, depth, feat, rank, \
-                       coldesc, lists, counts, out, n_cam, D, H, W, C, pl.n_vox, pl.tile, pl.n_tiles)
+    do {                                                                                                                 \
+        if (pl.lds > 65536)                                                                                              \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_voxel_pool<VEC, BATCH, FUSED, FIXED>),                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pl.lds));                   \
+        hipLaunchKernelGGL((k_voxel_pool<VEC, BATCH, FUSED, FIXED>), gridDim3, dim3(threads), pl.lds, s, x, st, depth, feat, \
+                           rank, coldesc, lists, counts, out, n_cam, D, H, W, C, pl.n_vox, pl.tile, pl.n_tiles);          \
+    } while (0)
 #define FIERY_POOL_DISPATCH(VEC, BATCH)                          \
     do {                                                         \
         if (fused && fixed) FIERY_POOL_LAUNCH(VEC, BATCH, true, true);        \

@@ -47,6 +47,8 @@ typedef int hipError_t;
 constexpr hipError_t hipSuccess = 0;
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "sim"; }
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 
 // One work-item = one cooperative fiber (ucontext) on the calling OS thread; a workgroup's fibers are
 // scheduled round-robin and only switch at barriers (__syncthreads, the wave-level exchange inside the
