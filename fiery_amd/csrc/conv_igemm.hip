@@ -60,6 +60,7 @@ struct ConvP {
     const float* scale2;
     const float* shift2;
     int act2;
+    int vec_epilogue;     // destinations / residual / bias rows are 16-byte addressable
 };
 
 __device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -75,8 +76,11 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     constexpr int NT = BN / (32 * WN);     // 32-cout MFMA tiles per wavefront    (BN=128: 2, else 1)
     constexpr int BLOADS = (BK * BN / 4) / 256;
 
-    __shared__ float As[2][BM * BK];
-    __shared__ float Bs[2][BK * BN];
+    // one LDS block: two A stages, two W stages; the epilogue reuses it as a BM x BN staging tile
+    __shared__ __attribute__((aligned(16))) float smem[2 * BM * BK + 2 * BK * BN];
+    float (*As)[BM * BK] = reinterpret_cast<float (*)[BM * BK]>(smem);
+    float (*Bs)[BK * BN] = reinterpret_cast<float (*)[BK * BN]>(smem + 2 * BM * BK);
+    static_assert(BM * BN <= 2 * BM * BK + 2 * BK * BN, "staging tile must fit");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
@@ -235,6 +239,56 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
         __syncthreads();
     }
 
+    // ---- staged epilogue (plain mode): accumulators -> LDS tile [pixel][cout] -> 16-byte rows -----------------
+    // A lane holds one cout for 16 scattered pixel rows, so storing from registers means 4-byte accesses 128 B
+    // at a time; going through LDS turns the tile into full rows: every residual load and output store is a
+    // 16-byte, unit-stride access.  `store_rows(width, ...)` finishes a staged tile of `width` couts.
+    auto store_rows = [&](int width, int cout0, const float* scale, const float* shift, int act, bool with_bias) {
+        const int c4n = width >> 2;                                 // 16-byte chunks per pixel row
+        const int rows_per_pass = 256 / c4n;
+        const int c4 = tid % c4n, prow0 = tid / c4n;
+        const int co = cout0 + c4 * 4;
+        if (co >= p.cout_store) return;                             // padding couts are never stored
+        const float4 sc = *reinterpret_cast<const float4*>(scale + co);
+        const float4 sh = *reinterpret_cast<const float4*>(shift + co);
+        int gp = pix0 + prow0;
+        int o = gp / HWout, ppi = gp - o * HWout;
+        for (int pl = prow0; pl < BM; pl += rows_per_pass) {
+            if (gp >= M) break;
+            float4 v = *reinterpret_cast<const float4*>(&smem[pl * width + c4 * 4]);
+            if (with_bias && p.img_bias) {
+                const float4 b = *reinterpret_cast<const float4*>(p.img_bias + static_cast<long long>(o) * p.cout_pad + co);
+                v.x += b.x;  v.y += b.y;  v.z += b.z;  v.w += b.w;
+            }
+            v.x = fmaf(v.x, sc.x, sh.x);  v.y = fmaf(v.y, sc.y, sh.y);  v.z = fmaf(v.z, sc.z, sh.z);  v.w = fmaf(v.w, sc.w, sh.w);
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.res.ptr) r = *reinterpret_cast<const float4*>(p.res.ptr + o * p.res.istride + static_cast<long long>(ppi) * p.res.ld + co);
+            if (p.res_pre) { v.x += r.x;  v.y += r.y;  v.z += r.z;  v.w += r.w; }
+            if (act == FIERY_ACT_RELU) {
+                v.x = fmaxf(v.x, 0.f);  v.y = fmaxf(v.y, 0.f);  v.z = fmaxf(v.z, 0.f);  v.w = fmaxf(v.w, 0.f);
+            } else if (act == FIERY_ACT_SIGMOID) {
+                v.x = sigmoidf(v.x);  v.y = sigmoidf(v.y);  v.z = sigmoidf(v.z);  v.w = sigmoidf(v.w);
+            }
+            if (!p.res_pre) { v.x += r.x;  v.y += r.y;  v.z += r.z;  v.w += r.w; }
+            *reinterpret_cast<float4*>(p.out.ptr + o * p.out.istride + static_cast<long long>(ppi) * p.out.ld + co) = v;
+            gp += rows_per_pass;
+            ppi += rows_per_pass;
+            while (ppi >= HWout) {
+                ppi -= HWout;
+                ++o;
+            }
+        }
+    };
+    auto stage_tile = [&](const v16f& a, int t, int nt, int width) {
+        const int col = wn * (32 * NT) + nt * 32 + m;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pl = wm * (32 * MT) + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            smem[pl * width + col] = a[r];
+        }
+    };
+    const bool rows16 = p.vec_epilogue != 0;
+
     // ---- optional chained 1x1 convolution on the tile (Bottleneck up-projection) -----------------------------
     if constexpr (BN == 32 && BM == 128) {
         if (p.w2) {
@@ -283,6 +337,22 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
                 }
             }
             // (4) second epilogue: folded BN, activation, residual, store
+            if (rows16) {
+                __syncthreads();                                   // everyone is done reading the h and W tiles
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int pl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        smem[pl * 64 + nt * 32 + m] = acc2[nt][r];
+                    }
+                __syncthreads();
+                const int keep_res_pre = p.res_pre;
+                p.res_pre = 0;                                     // the chained form adds the residual after the activation
+                store_rows(64, 0, p.scale2, p.shift2, p.act2, false);
+                p.res_pre = keep_res_pre;
+                return;
+            }
             const int gp_base = pix0 + wm * 32 + 4 * hi;
             const int o_base = gp_base / HWout;
             const int pp_base = gp_base - o_base * HWout;
@@ -311,7 +381,20 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
         }
     }
 
-    // ---- epilogue: for each of its 32x32 tiles a lane holds one cout for 16 pixel rows ---------------------
+    if (rows16 && p.epi == FIERY_EPI_PLAIN) {
+        // (the loop's last barrier has passed: the stages are free)
+        stage_tile(acc[0], 0, 0, BN);
+        if constexpr (NT == 2) stage_tile(acc[1], 0, 1, BN);
+        if constexpr (MT == 2) {
+            stage_tile(acc[NT], 1, 0, BN);
+            if constexpr (NT == 2) stage_tile(acc[NT + 1], 1, 1, BN);
+        }
+        __syncthreads();
+        store_rows(BN, tile_n * BN, p.scale, p.shift, p.act, true);
+        return;
+    }
+
+    // ---- register epilogue (GRU modes, or unaligned destinations): a lane holds one cout for 16 pixel rows -----
     const int half = p.cout_pad >> 1;
     auto emit = [&](const v16f& a, int t, int nt) {
         const int co = tile_n * BN + wn * (32 * NT) + nt * 32 + m;
@@ -536,6 +619,15 @@ extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) {
     p.aux1 = TensP{d->aux1.ptr, d->aux1.ld, d->aux1.img_stride};
     p.cout_store = d->cout_store;
     p.M = static_cast<long long>(d->n_img_out) * d->Hout * d->Wout;
+    // 16-byte rows need 16-byte aligned bases and strides in multiples of 4 floats everywhere the epilogue touches
+    auto rows_ok = [](const fiery_nhwc& t) {
+        return !t.ptr || (aligned16(t.ptr) && t.ld % 4 == 0 && t.img_stride % 4 == 0);
+    };
+    p.vec_epilogue = (d->epi == FIERY_EPI_PLAIN && rows_ok(d->out) && rows_ok(d->res) && d->cout_store % 4 == 0 &&
+                      (!d->img_bias || aligned16(d->img_bias)) && aligned16(d->scale) && aligned16(d->shift) &&
+                      (!d->weights2 || (aligned16(d->scale2) && aligned16(d->shift2))))
+                         ? 1 : 0;
+    if (const char* forced = getenv("FIERY_CONV_VEC_EPILOGUE")) p.vec_epilogue = p.vec_epilogue && atoi(forced) != 0;
     p.w2 = d->weights2;
     p.scale2 = d->scale2;
     p.shift2 = d->shift2;

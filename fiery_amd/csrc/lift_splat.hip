@@ -139,13 +139,7 @@ __global__ void k_voxel_index(const float* __restrict__ geometry, long long n, G
     const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* g = geometry + 3 * i;
-    int triple[3];
-    rank[i] = voxel_rank(g[0], g[1], g[2], p, idx ? triple : nullptr);
-    if (idx) {
-        idx[3 * i + 0] = triple[0];
-        idx[3 * i + 1] = triple[1];
-        idx[3 * i + 2] = triple[2];
-    }
+    rank[i] = voxel_rank(g[0], g[1], g[2], p, idx ? idx + 3 * i : nullptr);
 }
 
 constexpr int kMaxTiles = 30;          // tile membership is a bit mask in an int
@@ -553,9 +547,10 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
     const int threads = pl.lds <= 40960 ? 256 : (pl.lds <= 81920 ? 512 : 1024);
 #define FIERY_POOL_LAUNCH(VEC, BATCH, FUSED, FIXED)                                                                      \
     do {                                                                                                                 \
-        if (pl.lds > 65536)                                                                                              \
+        if (pl.lds > 65536 &&                                                                                            \
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_voxel_pool<VEC, BATCH, FUSED, FIXED>),                  \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pl.lds));                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pl.lds)) != hipSuccess)      \
+            return fail(FIERY_ELAUNCH, "voxel_pool: cannot reserve %zu B of LDS", pl.lds);                              \
         hipLaunchKernelGGL((k_voxel_pool<VEC, BATCH, FUSED, FIXED>), gridDim3, dim3(threads), pl.lds, s, x, st, depth, feat, \
                            rank, coldesc, lists, counts, out, n_cam, D, H, W, C, pl.n_vox, pl.tile, pl.n_tiles);          \
     } while (0)

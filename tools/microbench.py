@@ -45,6 +45,13 @@ def bench_pool(lib, reps, frames=9, tiles=(0,)):
     x = torch.randn(frames, 6, 64, D, fh, fw, device=DEV)
     st = x.stride()
     strides = (st[0], st[1], st[3], st[4], st[5], st[2])
+    # platform calibration on the same tensor: what plain streaming kernels reach here
+    us = timed(lambda: x.sum(), reps)
+    print(f'calib torch.sum over x ({x.numel() * 4 / 1e6:.0f} MB): {us:8.1f} us -> {x.numel() * 4 / us / 1e3:7.1f} GB/s read', flush=True)
+    y = torch.empty_like(x)
+    us = timed(lambda: y.copy_(x), reps)
+    print(f'calib copy x -> y: {us:8.1f} us -> {2 * x.numel() * 4 / us / 1e3:7.1f} GB/s read+write', flush=True)
+    del y
     rank, _ = lib.voxel_index(geo, grid, want_idx=False)
     n_kept = int((rank >= 0).sum())
     n_pts = rank.numel()
