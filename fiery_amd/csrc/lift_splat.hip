@@ -450,8 +450,9 @@ struct PoolPlan {
     size_t lds, off_coldesc, off_colmask, off_counts, off_lists, total;
 };
 
-// LDS tile of the output plane.  40 KiB tiles keep four workgroups per CU resident (160 KiB LDS); the tile
-// grows when the grid would otherwise need more than kMaxTiles tiles.
+// LDS tile of the output plane.  Default 80 KiB (two 512-thread workgroups per CU): measured best and least
+// erratic on MI355X (profiles/r1_pool_tile_sweep.txt); the tile grows when the grid would otherwise need more than
+// kMaxTiles tiles.
 int plan_pool(int frames, int n_cam, int D, int H, int W, long long n_vox_ll, int requested, bool fixed, bool fused,
               PoolPlan* pl) {
     FIERY_REQUIRE(n_vox_ll > 0 && n_vox_ll < (1ll << 30), "voxel_pool: bad grid size");
@@ -460,7 +461,7 @@ int plan_pool(int frames, int n_cam, int D, int H, int W, long long n_vox_ll, in
     const int cell_bytes = fixed ? 8 : 4;
     const int cap = (fused ? 81920 : 160000) / cell_bytes;     // the fused form runs 512-thread workgroups at most
     pl->n_vox = static_cast<int>(n_vox_ll);
-    int tile = requested > 0 ? requested : 40960 / cell_bytes;
+    int tile = requested > 0 ? requested : 81920 / cell_bytes;
     if (tile > cap) tile = cap;
     if (tile > pl->n_vox) tile = pl->n_vox;
     if (ceil_div(pl->n_vox, tile) > kMaxTiles) tile = ceil_div(pl->n_vox, kMaxTiles);
