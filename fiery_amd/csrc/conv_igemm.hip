@@ -16,8 +16,8 @@
 //   * A tile is stored [pixel][32 k] with the 16-byte slot index XOR-ed by (pixel>>1)&7, so the
 //     ds_read_b128 of 32 consecutive pixels at one k-slot is bank-conflict free; each b128 feeds four
 //     MFMA k-steps (the K order inside a step is permuted identically for A and W).
-//   * the weight tile is pre-packed on the host side in exactly its LDS image: one contiguous 4/8 KiB
-//     copy per step.
+//   * the weight tile is pre-packed on the host side in exactly its LDS image ([k/4][cout][k%4], so a
+//     lane's four k of an MFMA group are one ds_read_b128): one contiguous 4/8/16 KiB copy per step.
 //   * input channels are a virtual concat of two tensors (GRU [x, h], temporal-block path concat), and
 //     the epilogue applies bias / folded BatchNorm / activation / residual / GRU gate math in registers.
 #include "common.h"
@@ -194,6 +194,15 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
         }
     };
 
+    auto lds_a = [&](int buf, int q, int t) {
+        const int pl = wm * (32 * MT) + t * 32 + m;
+        const int slot = (2 * q + hi) ^ ((pl >> 1) & 7);
+        return *reinterpret_cast<const float4*>(&As[buf][pl * BK + slot * 4]);
+    };
+    auto lds_b = [&](int buf, int q, int nt) {
+        return *reinterpret_cast<const float4*>(&Bs[buf][((2 * q + hi) * BN + wn * (32 * NT) + nt * 32 + m) * 4]);
+    };
+
     v16f acc[MT * NT];
 #pragma unroll
     for (int t = 0; t < MT * NT; ++t)
@@ -209,29 +218,41 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
         const bool more = chunk + 1 < p.k_chunks;
         if (more) load_stage();                   // global loads fly while the MFMAs below run
 
+        // operands of k-group q+1 are read from LDS while the MFMAs of group q run (one b128 per 32x4 operand
+        // block: A rows are [pixel][k], the W image is [k/4][cout][k%4])
+        float4 a_cur[MT], b_cur[NT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) a_cur[t] = lds_a(buf, 0, t);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b_cur[nt] = lds_b(buf, 0, nt);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float av[MT][4];
+            float4 a_nxt[MT], b_nxt[NT];
+            if (q < 3) {
 #pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                const int pl = wm * (32 * MT) + t * 32 + m;
-                const int slot = (2 * q + hi) ^ ((pl >> 1) & 7);
-                const float4 a4 = *reinterpret_cast<const float4*>(&As[buf][pl * BK + slot * 4]);
-                av[t][0] = a4.x;
-                av[t][1] = a4.y;
-                av[t][2] = a4.z;
-                av[t][3] = a4.w;
+                for (int t = 0; t < MT; ++t) a_nxt[t] = lds_a(buf, q + 1, t);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b_nxt[nt] = lds_b(buf, q + 1, nt);
             }
+            __builtin_amdgcn_sched_barrier(0);     // keep the reads of group q+1 ahead of this group's MFMAs
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 // this lane's k for the step: 8q + 4hi + j, for its A element and its W element alike
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const float bv = Bs[buf][(8 * q + 4 * hi + j) * BN + wn * (32 * NT) + nt * 32 + m];
+                    const float bv = j == 0 ? b_cur[nt].x : j == 1 ? b_cur[nt].y : j == 2 ? b_cur[nt].z : b_cur[nt].w;
 #pragma unroll
-                    for (int t = 0; t < MT; ++t)
-                        acc[t * NT + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t][j], bv, acc[t * NT + nt], 0, 0, 0);
+                    for (int t = 0; t < MT; ++t) {
+                        const float av = j == 0 ? a_cur[t].x : j == 1 ? a_cur[t].y : j == 2 ? a_cur[t].z : a_cur[t].w;
+                        acc[t * NT + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t * NT + nt], 0, 0, 0);
+                    }
                 }
+            }
+            if (q < 3) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t) a_cur[t] = a_nxt[t];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b_cur[nt] = b_nxt[nt];
             }
         }
 
@@ -248,7 +269,8 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
         const int rows_per_pass = 256 / c4n;
         const int c4 = tid % c4n, prow0 = tid / c4n;
         const int co = cout0 + c4 * 4;
-        if (co >= p.cout_store) return;                             // padding couts are never stored
+        const int half = p.cout_pad >> 1;
+        if (p.epi != FIERY_EPI_GRU_GATES && co >= p.cout_store) return;    // padding couts are never stored
         const float4 sc = *reinterpret_cast<const float4*>(scale + co);
         const float4 sh = *reinterpret_cast<const float4*>(shift + co);
         int gp = pix0 + prow0;
@@ -261,16 +283,39 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
                 v.x += b.x;  v.y += b.y;  v.z += b.z;  v.w += b.w;
             }
             v.x = fmaf(v.x, sc.x, sh.x);  v.y = fmaf(v.y, sc.y, sh.y);  v.z = fmaf(v.z, sc.z, sh.z);  v.w = fmaf(v.w, sc.w, sh.w);
-            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.res.ptr) r = *reinterpret_cast<const float4*>(p.res.ptr + o * p.res.istride + static_cast<long long>(ppi) * p.res.ld + co);
-            if (p.res_pre) { v.x += r.x;  v.y += r.y;  v.z += r.z;  v.w += r.w; }
-            if (act == FIERY_ACT_RELU) {
-                v.x = fmaxf(v.x, 0.f);  v.y = fmaxf(v.y, 0.f);  v.z = fmaxf(v.z, 0.f);  v.w = fmaxf(v.w, 0.f);
-            } else if (act == FIERY_ACT_SIGMOID) {
-                v.x = sigmoidf(v.x);  v.y = sigmoidf(v.y);  v.z = sigmoidf(v.z);  v.w = sigmoidf(v.w);
+            const long long pp = ppi;
+            if (p.epi == FIERY_EPI_PLAIN) {
+                float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.res.ptr) r = *reinterpret_cast<const float4*>(p.res.ptr + o * p.res.istride + pp * p.res.ld + co);
+                if (p.res_pre) { v.x += r.x;  v.y += r.y;  v.z += r.z;  v.w += r.w; }
+                if (act == FIERY_ACT_RELU) {
+                    v.x = fmaxf(v.x, 0.f);  v.y = fmaxf(v.y, 0.f);  v.z = fmaxf(v.z, 0.f);  v.w = fmaxf(v.w, 0.f);
+                } else if (act == FIERY_ACT_SIGMOID) {
+                    v.x = sigmoidf(v.x);  v.y = sigmoidf(v.y);  v.z = sigmoidf(v.z);  v.w = sigmoidf(v.w);
+                }
+                if (!p.res_pre) { v.x += r.x;  v.y += r.y;  v.z += r.z;  v.w += r.w; }
+                *reinterpret_cast<float4*>(p.out.ptr + o * p.out.istride + pp * p.out.ld + co) = v;
+            } else if (p.epi == FIERY_EPI_GRU_GATES) {
+                float4 g = make_float4(sigmoidf(v.x), sigmoidf(v.y), sigmoidf(v.z), sigmoidf(v.w));
+                if (co < half) {                                                            // update gate
+                    *reinterpret_cast<float4*>(p.out.ptr + o * p.out.istride + pp * p.out.ld + co) = g;
+                } else {                                                                    // (1 - reset) * state
+                    const int c2 = co - half;
+                    const float4 h = *reinterpret_cast<const float4*>(p.aux0.ptr + o * p.aux0.istride + pp * p.aux0.ld + c2);
+                    g.x = (1.0f - g.x) * h.x;  g.y = (1.0f - g.y) * h.y;  g.z = (1.0f - g.z) * h.z;  g.w = (1.0f - g.w) * h.w;
+                    *reinterpret_cast<float4*>(p.out2.ptr + o * p.out2.istride + pp * p.out2.ld + c2) = g;
+                }
+            } else {                                                                        // FIERY_EPI_GRU_OUT
+                const float4 u = *reinterpret_cast<const float4*>(p.aux0.ptr + o * p.aux0.istride + pp * p.aux0.ld + co);
+                const float4 h = *reinterpret_cast<const float4*>(p.aux1.ptr + o * p.aux1.istride + pp * p.aux1.ld + co);
+                float4 hn;
+                { const float a = (1.0f - u.x) * h.x, b = u.x * fmaxf(v.x, 0.f); hn.x = a + b; }
+                { const float a = (1.0f - u.y) * h.y, b = u.y * fmaxf(v.y, 0.f); hn.y = a + b; }
+                { const float a = (1.0f - u.z) * h.z, b = u.z * fmaxf(v.z, 0.f); hn.z = a + b; }
+                { const float a = (1.0f - u.w) * h.w, b = u.w * fmaxf(v.w, 0.f); hn.w = a + b; }
+                *reinterpret_cast<float4*>(p.out.ptr + o * p.out.istride + pp * p.out.ld + co) = hn;
+                if (p.out2.ptr) *reinterpret_cast<float4*>(p.out2.ptr + o * p.out2.istride + pp * p.out2.ld + co) = hn;
             }
-            if (!p.res_pre) { v.x += r.x;  v.y += r.y;  v.z += r.z;  v.w += r.w; }
-            *reinterpret_cast<float4*>(p.out.ptr + o * p.out.istride + static_cast<long long>(ppi) * p.out.ld + co) = v;
             gp += rows_per_pass;
             ppi += rows_per_pass;
             while (ppi >= HWout) {
@@ -328,12 +373,12 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
                 const float4 a4 = *reinterpret_cast<const float4*>(&As[0][pl * BK + slot * 4]);
                 const float av2[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int nt = 0; nt < 2; ++nt) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(&b2[((2 * q + hi) * 64 + nt * 32 + m) * 4]);
+                    const float bv2[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        const float bv = b2[(8 * q + 4 * hi + j) * 64 + nt * 32 + m];
-                        acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av2[j], bv, acc2[nt], 0, 0, 0);
-                    }
+                    for (int j = 0; j < 4; ++j)
+                        acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av2[j], bv2[j], acc2[nt], 0, 0, 0);
                 }
             }
             // (4) second epilogue: folded BN, activation, residual, store
@@ -381,7 +426,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
         }
     }
 
-    if (rows16 && p.epi == FIERY_EPI_PLAIN) {
+    if (rows16) {
         // (the loop's last barrier has passed: the stages are free)
         stage_tile(acc[0], 0, 0, BN);
         if constexpr (NT == 2) stage_tile(acc[1], 0, 1, BN);
@@ -394,7 +439,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
         return;
     }
 
-    // ---- register epilogue (GRU modes, or unaligned destinations): a lane holds one cout for 16 pixel rows -----
+    // ---- register epilogue (unaligned destinations): a lane holds one cout for 16 pixel rows ---------------------
     const int half = p.cout_pad >> 1;
     auto emit = [&](const v16f& a, int t, int nt) {
         const int co = tile_n * BN + wn * (32 * NT) + nt * 32 + m;
@@ -464,10 +509,13 @@ __global__ void k_pack_weights(const float* __restrict__ w, int cout, int cin_to
                                int cin_units, int bn, int k_chunks, long long total, float* __restrict__ packed) {
     const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const int nn = static_cast<int>(i % bn);
-    long long r = i / bn;
-    const int kk = static_cast<int>(r % BK);
-    r /= BK;
+    // inside a (chunk, cout tile) block the image is [k / 4][cout][k % 4]: a lane's four k of one MFMA
+    // group are one 16-byte LDS read
+    const int kj = static_cast<int>(i & 3);
+    const int nn = static_cast<int>((i >> 2) % bn);
+    long long r = (i >> 2) / bn;
+    const int kk = static_cast<int>(r % (BK / 4)) * 4 + kj;
+    r /= BK / 4;
     const int chunk = static_cast<int>(r % k_chunks);
     const int tile = static_cast<int>(r / k_chunks);
     const int n = tile * bn + nn;
@@ -623,7 +671,8 @@ extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) {
     auto rows_ok = [](const fiery_nhwc& t) {
         return !t.ptr || (aligned16(t.ptr) && t.ld % 4 == 0 && t.img_stride % 4 == 0);
     };
-    p.vec_epilogue = (d->epi == FIERY_EPI_PLAIN && rows_ok(d->out) && rows_ok(d->res) && d->cout_store % 4 == 0 &&
+    p.vec_epilogue = (rows_ok(d->out) && rows_ok(d->res) && rows_ok(d->out2) && rows_ok(d->aux0) && rows_ok(d->aux1) &&
+                      d->cout_store % 4 == 0 &&
                       (!d->img_bias || aligned16(d->img_bias)) && aligned16(d->scale) && aligned16(d->shift) &&
                       (!d->weights2 || (aligned16(d->scale2) && aligned16(d->shift2))))
                          ? 1 : 0;

@@ -228,6 +228,10 @@ inline unsigned long long __ballot(int predicate) {
 
 // f32 MFMA 32x32x2: D = A(32x2) . B(2x32) + C, one wave.
 typedef float hipsim_v16f __attribute__((vector_size(64)));
+// instruction-scheduling hints have no effect on results
+inline void __builtin_amdgcn_sched_barrier(int) {}
+inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
+
 inline hipsim_v16f __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, hipsim_v16f c, int, int, int) {
     ::hipsim::Run& run = *::hipsim::run_ptr();
     const ::hipsim::Tls& t = ::hipsim::tls();

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Kernel microbenchmarks for tuning (GPU box): the voxel-pooling op at baseline.yml size and the convolution
 shapes that dominate the step.  Prints one line per case; run under rocprofv3 (--kernel-trace / --pmc) for counters.
-  python tools/microbench.py [pool] [conv] [--reps N]"""
+  python tools/microbench.py [probe] [pool] [conv] [--reps N]      (env: POOL_TILES=a,b  POOL_FRAMES=9,12)"""
 import os
 import sys
 import time
@@ -31,6 +31,28 @@ def timed(fn, reps):
     e.record()
     torch.cuda.synchronize()
     return s.elapsed_time(e) * 1e3 / reps      # us
+
+
+def bench_probe(reps):
+    """Plain streaming reads of a 1.1 GB tensor: the practical HBM read ceiling of this box."""
+    import ctypes as C
+    so = os.path.join(ROOT, 'tools', 'probe', 'libhbm_probe.so')
+    if not os.path.exists(so):
+        import subprocess
+        subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
+                               os.path.join(ROOT, 'tools', 'probe', 'hbm_probe.hip'), '-o', so])
+    probe = C.CDLL(so)
+    probe.probe_read.argtypes = [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    x = torch.randn(9 * 6 * 64 * 48 * 28 * 60 // 4, 4, device=DEV)
+    sink = torch.zeros(4, device=DEV)
+    nbytes = x.numel() * 4
+    stream = torch.cuda.current_stream().cuda_stream
+    for mode, name in ((0, 'grid-stride'), (1, 'grid-stride nontemporal'), (2, 'slab per workgroup')):
+        for blocks, threads, unroll in ((2048, 256, 4), (4096, 256, 8), (1024, 512, 8), (512, 1024, 8), (2048, 512, 16),
+                                        (8192, 256, 4), (1152, 512, 16), (1024, 512, 16)):
+            us = timed(lambda: probe.probe_read(x.data_ptr(), nbytes, blocks, threads, unroll, mode, sink.data_ptr(), stream), reps)
+            print(f'probe {name:24s} blocks={blocks:5d} threads={threads:4d} unroll={unroll:2d}: {us:7.1f} us -> '
+                  f'{nbytes / us / 1e3:7.1f} GB/s', flush=True)
 
 
 def bench_pool(lib, reps, frames=9, tiles=(0,)):
@@ -74,6 +96,10 @@ CONV_CASES = [  # (k, stride, cin, cout, n_img, H, W, residual)
     (1, 1, 32, 64, 12, 200, 200, True),
     (1, 1, 64, 32, 12, 200, 200, False),
     (7, 2, 64, 64, 15, 200, 200, False),
+    # tile-count quantisation probes: 147456 = 768 * 192 pixel rows (whole rounds of 64-row tiles at 3 per CU)
+    (3, 1, 128, 128, 3, 192, 256, False),
+    (3, 1, 128, 128, 6, 192, 256, False),
+    (3, 1, 128, 64, 3, 192, 256, False),
 ]
 
 
@@ -95,9 +121,12 @@ def bench_conv(lib, reps):
 if __name__ == '__main__':
     reps = int(sys.argv[sys.argv.index('--reps') + 1]) if '--reps' in sys.argv else 5
     lib = native.get()
-    what = [a for a in sys.argv[1:] if a in ('pool', 'conv')] or ['pool', 'conv']
+    what = [a for a in sys.argv[1:] if a in ('pool', 'conv', 'probe')] or ['pool', 'conv']
+    if 'probe' in what:
+        bench_probe(reps)
     if 'pool' in what:
         tiles = tuple(int(t) for t in os.environ.get('POOL_TILES', '0').split(','))
-        bench_pool(lib, reps, tiles=tiles)
+        for frames in (int(f) for f in os.environ.get('POOL_FRAMES', '9').split(',')):
+            bench_pool(lib, reps, frames=frames, tiles=tiles)
     if 'conv' in what:
         bench_conv(lib, reps)
