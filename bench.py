@@ -35,6 +35,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=3, help='samples per GPU (baseline.yml BATCHSIZE)')
     ap.add_argument('--config', default='baseline.yml')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='enqueue every launch from the host each step instead of '
+                                                            'replaying the captured hipGraph')
     ap.add_argument('--fused', action='store_true', help='feed depth logits + features to the fused lift-splat kernel '
                                                          'instead of the materialised outer product')
     return ap.parse_args()
@@ -100,10 +102,26 @@ def main():
     if args.fused:
         dl_d = dl.view(B, rf, n_cam, D, fh, fw).to(dev)
         ft_d = ft.view(B, rf, n_cam, C, fh, fw).to(dev)
-        step = lambda: model.bev_forward(None, K_d, E_d, ego_d, depth_logits=dl_d, features=ft_d)
+        eager_step = lambda: model.bev_forward(None, K_d, E_d, ego_d, depth_logits=dl_d, features=ft_d)
+        graph_step = lambda: model.bev_forward_graph(None, K_d, E_d, ego_d, depth_logits=dl_d, features=ft_d)
     else:
         lifted_d = lifted.to(dev)
-        step = lambda: model.bev_forward(lifted_d, K_d, E_d, ego_d)
+        eager_step = lambda: model.bev_forward(lifted_d, K_d, E_d, ego_d)
+        graph_step = lambda: model.bev_forward_graph(lifted_d, K_d, E_d, ego_d)
+    # The timed step replays the whole path (every kernel, same work) from one captured hipGraph; the first call
+    # captures it and is checked against the eager path.
+    step, launch_mode = eager_step, 'host enqueue per launch'
+    if not args.no_graph:
+        try:
+            with torch.no_grad():
+                ref = {k: v.clone() for k, v in eager_step().items() if v is not None}
+                got = graph_step()
+                torch.cuda.synchronize()
+                for k, v in ref.items():
+                    assert (got[k] - v).abs().max().item() <= 1e-5 * max(1.0, v.abs().max().item()), k
+            step, launch_mode = graph_step, 'hipGraph replay (one graph launch per step)'
+        except Exception as e:                                       # noqa: BLE001  (report, then measure the eager path)
+            launch_mode = f'host enqueue per launch (graph capture failed: {repr(e)[:160]})'
 
     def barrier():
         if world > 1:
@@ -140,7 +158,7 @@ def main():
         torch.cuda.synchronize()
         ops.PROFILE_SINK = []
         with torch.no_grad():
-            step()
+            eager_step()                                   # same kernels, launched one by one so each can be bracketed
         torch.cuda.synchronize()
         recs, ops.PROFILE_SINK = ops.PROFILE_SINK, None
         conv = [(s.elapsed_time(e) * 1e-3, w) for k, s, e, w, _ in recs if k == 'conv_igemm']
@@ -172,7 +190,8 @@ def main():
             'config': {'workload': f'{args.config}: {n_cam} cams x {rf} past frames -> {model.bev_size[0]}x{model.bev_size[1]} BEV, '
                                    f'{nf} future frames, batch {B} per GPU, fp32, '
                                    f'{"fused lift-splat from depth+features" if args.fused else "lifted features (n,C,D,h,w) resident in HBM"}',
-                       'global_batch': B * world, 'parallelism': f'batch-sharded x{world}, no data-path collective'},
+                       'global_batch': B * world, 'parallelism': f'batch-sharded x{world}, no data-path collective',
+                       'launch': launch_mode},
             'roofline': roofline, 'roofline_pooling': pooling, 'host_enqueue_ms_per_step': round(host_ms, 3),
         }
         if world == 1 and not args.no_cpu_baseline:

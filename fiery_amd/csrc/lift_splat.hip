@@ -16,6 +16,9 @@
 // rounding (separate multiply and add, k ascending) bit for bit.
 #include "common.h"
 
+#include <cstdio>
+#include <type_traits>
+
 #include <cstdlib>
 
 #pragma clang fp contract(off)
@@ -178,53 +181,86 @@ __global__ void k_rank_columns(const float* __restrict__ geometry, int n_fc, int
     }
     const int general = (runs > 3 || H >= (1 << kSplitBits)) ? 1 : 0;
     coldesc[col] = make_int4(ra, rb, rc, s1 | (s2 << kSplitBits) | (general << (2 * kSplitBits)));
-    colmask[col] = mask;
+    colmask[col] = mask | (general ? static_cast<int>(0x80000000u) : 0);      // bit 31: walk this column row by row
 }
 
 // Ordered (ascending id) list of the work-items that touch one tile of one frame; adjacent entries are adjacent
-// in memory, so the pooling kernel's wavefront loads stay unit-stride.  A work-item is a column (group = 1) or
+// in memory, so the pooling kernel's wavefront loads stay unit-stride.  Items with a "general" column (more than
+// three runs) go to a second list that grows down from the end of the same array; counts = {front, back}.  A work-item is a column (group = 1) or
 // four adjacent columns (group = 4, W % 4 == 0): entry = camera<<20 | d<<10 | (w / group).
 // grid (n_tiles, frames), 1024 threads.
 __global__ __launch_bounds__(1024) void k_build_tile_lists(const int* __restrict__ colmask, int n_cam, int D, int W,
                                                            int group, int n_tiles, int* __restrict__ lists,
                                                            int* __restrict__ counts) {
-    __shared__ int wave_count[16];
-    __shared__ int running;
+    __shared__ int wave_count[16], wave_gcount[16];
+    __shared__ int running, running_general;
     const int tile = blockIdx.x, f = blockIdx.y;
     const int Wg = W / group;
     const int n_items = n_cam * D * Wg;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int* cm = colmask + static_cast<long long>(f) * n_items * group;
     int* out = lists + (static_cast<long long>(f) * n_tiles + tile) * n_items;
-    if (threadIdx.x == 0) running = 0;
+    if (threadIdx.x == 0) running = running_general = 0;
     __syncthreads();
-    for (int i0 = 0; i0 < n_items; i0 += 1024) {
-        const int i = i0 + threadIdx.x;
-        bool hit = false;
-        if (i < n_items) {
-            int mk = 0;
-            for (int k = 0; k < group; ++k) mk |= cm[i * group + k];
-            hit = (mk >> tile) & 1;
+    // four consecutive items per thread and pass: 4096 items between barriers
+    constexpr int kPer = 4;
+    for (int i0 = 0; i0 < n_items; i0 += 1024 * kPer) {
+        const int ibase = i0 + threadIdx.x * kPer;
+        bool hit[kPer], gen[kPer];
+        int before = 0, wave_total = 0, gbefore = 0, gwave_total = 0;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int i = ibase + k;
+            hit[k] = gen[k] = false;
+            if (i < n_items) {
+                int mk = 0;
+                for (int g = 0; g < group; ++g) mk |= cm[i * group + g];
+                const bool touches = (mk >> tile) & 1;
+                gen[k] = touches && mk < 0;                              // bit 31: some column needs the row walk
+                hit[k] = touches && mk >= 0;
+            }
+            const unsigned long long lower = (1ull << lane) - 1ull;
+            const unsigned long long ballot = __ballot(hit[k]);
+            before += __popcll(ballot & lower);                          // hits of lower lanes come first (their items are lower)
+            wave_total += __popcll(ballot);
+            const unsigned long long gballot = __ballot(gen[k]);
+            gbefore += __popcll(gballot & lower);
+            gwave_total += __popcll(gballot);
         }
-        const unsigned long long ballot = __ballot(hit);
-        const int before = __popcll(ballot & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_count[wave] = __popcll(ballot);
+        if (lane == 0) {
+            wave_count[wave] = wave_total;
+            wave_gcount[wave] = gwave_total;
+        }
         __syncthreads();
-        int offset = running;
-        for (int k = 0; k < wave; ++k) offset += wave_count[k];
-        if (hit) {
+        int offset = running + before, goffset = running_general + gbefore;
+        for (int k = 0; k < wave; ++k) {
+            offset += wave_count[k];
+            goffset += wave_gcount[k];
+        }
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int i = ibase + k;
             const int wg = i % Wg, nd = i / Wg;
-            out[offset + before] = ((nd / D) << (kPackW + kPackD)) | ((nd % D) << kPackW) | wg;
+            const int entry = ((nd / D) << (kPackW + kPackD)) | ((nd % D) << kPackW) | wg;
+            if (hit[k]) out[offset++] = entry;
+            if (gen[k]) out[n_items - 1 - goffset++] = entry;             // general items: from the back, downwards
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            int total = 0;
-            for (int k = 0; k < 16; ++k) total += wave_count[k];
+            int total = 0, gtotal = 0;
+            for (int k = 0; k < 16; ++k) {
+                total += wave_count[k];
+                gtotal += wave_gcount[k];
+            }
             running += total;
+            running_general += gtotal;
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) counts[f * n_tiles + tile] = running;
+    if (threadIdx.x == 0) {
+        counts[2 * (f * n_tiles + tile)] = running;
+        counts[2 * (f * n_tiles + tile) + 1] = running_general;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -233,6 +269,7 @@ __global__ __launch_bounds__(1024) void k_build_tile_lists(const int* __restrict
 struct PoolStrides {
     long long f, n, d, h, w, c;
 };
+typedef float vf4 __attribute__((vector_size(16)));
 
 // Accumulator cell of the LDS plane.  The default is an fp32 LDS atomic (ds_add_f32): sums of a voxel's
 // columns may be added in any order, so the last bit can differ between runs.  The reproducible mode
@@ -287,7 +324,10 @@ __global__ __launch_bounds__(kFused ? 512 : 1024) void k_voxel_pool(
     using cell_t = typename Cell<kFixed>::type;
     HIP_DYNAMIC_SHARED(unsigned char, pool_lds)
     cell_t* plane = reinterpret_cast<cell_t*>(pool_lds);
-    const int tile = blockIdx.x, c = blockIdx.y, f = blockIdx.z;
+    // unit = (tile, channel, frame), tile fastest
+    const int tile = blockIdx.x % n_tiles;
+    const int c = (blockIdx.x / n_tiles) % C;
+    const int f = blockIdx.x / (n_tiles * C);
     const int v0 = tile * tile_vox;
     const int v1 = min(v0 + tile_vox, n_vox);
     const int span = v1 - v0;
@@ -297,113 +337,141 @@ __global__ __launch_bounds__(kFused ? 512 : 1024) void k_voxel_pool(
     const int Wg = W / kVec;
     const int n_items = n_cam * D * Wg;
     const int* lst = lists + (static_cast<long long>(f) * n_tiles + tile) * n_items;
-    const int count = counts[f * n_tiles + tile];
     const int HW = H * W;
     const int4* cdesc = coldesc + static_cast<long long>(f) * n_items * kVec;
 
-    // the next work-item's list entry and descriptors are fetched while the current one is summed
-    int e_next = 0;
-    int4 d_next[kVec];
-    auto fetch = [&](int i) {
-        if (i < count) {
-            e_next = lst[i];
-            const int wg = e_next & ((1 << kPackW) - 1);
-            const int d = (e_next >> kPackW) & ((1 << kPackD) - 1);
-            const int cam = e_next >> (kPackW + kPackD);
+    // One pass over an ordered list of work-items; `dir` = +1 walks up from `first`, -1 walks down.  The items whose
+    // columns all have at most three runs (the front list) take the register path; the rare ones with a column of
+    // four or more runs sit in their own list (the back of the same array), so that their slow row-by-row walk is
+    // executed by a few full wavefronts instead of diverging inside nearly every wavefront of the tile.
+    auto run_list = [&](auto general_tag, const int* first, int dir, int count) {
+        constexpr bool kGeneral = decltype(general_tag)::value;
+        // Two-deep prefetch: the list entry of the item after next and the descriptors of the next item are
+        // requested together with this item's rows, so no dependent (entry -> descriptor -> rows) latency is exposed.
+        int e_next = 0, e_next2 = 0;
+        int4 d_next[kVec];
+        auto fetch_desc = [&](int e) {
+            const int wg = e & ((1 << kPackW) - 1);
+            const int d = (e >> kPackW) & ((1 << kPackD) - 1);
+            const int cam = e >> (kPackW + kPackD);
             const int4* dp = cdesc + (static_cast<long long>(cam) * D + d) * W + wg * kVec;
 #pragma unroll
             for (int k = 0; k < kVec; ++k) d_next[k] = dp[k];
-        }
-    };
-    fetch(threadIdx.x);
-    for (int i = threadIdx.x; i < count; i += blockDim.x) {
-        const int e = e_next;
-        int4 dsc[kVec];
+        };
+        const int tid = threadIdx.x, nthr = blockDim.x;
+        if (tid < count) e_next = first[dir * tid];
+        if (tid + nthr < count) e_next2 = first[dir * (tid + nthr)];
+        if (tid < count) fetch_desc(e_next);
+        for (int i = tid; i < count; i += nthr) {
+            const int e = e_next;
+            int4 dsc[kVec];
 #pragma unroll
-        for (int k = 0; k < kVec; ++k) dsc[k] = d_next[k];
-        fetch(i + blockDim.x);
-        const int w = (e & ((1 << kPackW) - 1)) * kVec;
-        const int d = (e >> kPackW) & ((1 << kPackD) - 1);
-        const int cam = e >> (kPackW + kPackD);
-        // row h of this work-item lives at p + h*step (kVec floats); fused: depth row times feature row
-        const float* p;
-        const float* q = nullptr;
-        long long step, qstep = 0;
-        if (kFused) {
-            p = depth + ((static_cast<long long>(f) * n_cam + cam) * D + d) * HW + w;
-            step = W;
-            q = feat + ((static_cast<long long>(f) * n_cam + cam) * C + c) * HW + w;
-            qstep = W;
-        } else {
-            p = x + f * xs.f + cam * xs.n + d * xs.d + w * xs.w + c * xs.c;
-            step = xs.h;
-        }
-        bool general = false;
-#pragma unroll
-        for (int k = 0; k < kVec; ++k) general = general || (dsc[k].w >> (2 * kSplitBits)) != 0;
-
-        float sa[kVec], sb[kVec], sc[kVec];
-        int s1[kVec], s2[kVec];
-#pragma unroll
-        for (int k = 0; k < kVec; ++k) {
-            sa[k] = sb[k] = sc[k] = 0.f;
-            s1[k] = dsc[k].w & ((1 << kSplitBits) - 1);
-            s2[k] = (dsc[k].w >> kSplitBits) & ((1 << kSplitBits) - 1);
-        }
-        Merge<kFixed> merge;
-        const int* rk = rank + ((static_cast<long long>(f) * n_cam + cam) * D + d) * HW + w;
-        for (int h0 = 0; h0 < H; h0 += kBatch) {
-            float v[kBatch][kVec];
-#pragma unroll
-            for (int j = 0; j < kBatch; ++j) {
-                const bool in = h0 + j < H;
-                if (kVec == 4) {
-                    const float4 t = in ? *reinterpret_cast<const float4*>(p + (h0 + j) * step) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    v[j][0] = t.x;  v[j][1 % kVec] = t.y;  v[j][2 % kVec] = t.z;  v[j][3 % kVec] = t.w;
-                } else {
-                    v[j][0] = in ? p[(h0 + j) * step] : 0.f;
-                }
-            }
+            for (int k = 0; k < kVec; ++k) dsc[k] = d_next[k];
+            e_next = e_next2;
+            if (i + nthr < count) fetch_desc(e_next);
+            if (i + 2 * nthr < count) e_next2 = first[dir * (i + 2 * nthr)];
+            const int w = (e & ((1 << kPackW) - 1)) * kVec;
+            const int d = (e >> kPackW) & ((1 << kPackD) - 1);
+            const int cam = e >> (kPackW + kPackD);
+            // row h of this work-item lives at p + h*step (kVec floats); fused: depth row times feature row
+            const float* p;
+            const float* q = nullptr;
+            long long step, qstep = 0;
             if (kFused) {
+                p = depth + ((static_cast<long long>(f) * n_cam + cam) * D + d) * HW + w;
+                step = W;
+                q = feat + ((static_cast<long long>(f) * n_cam + cam) * C + c) * HW + w;
+                qstep = W;
+            } else {
+                p = x + f * xs.f + cam * xs.n + d * xs.d + w * xs.w + c * xs.c;
+                step = xs.h;
+            }
+            float sa[kVec], sb[kVec], sc[kVec];
+            int s1[kVec], s2[kVec];
+#pragma unroll
+            for (int k = 0; k < kVec; ++k) {
+                sa[k] = sb[k] = sc[k] = 0.f;
+                s1[k] = dsc[k].w & ((1 << kSplitBits) - 1);
+                s2[k] = (dsc[k].w >> kSplitBits) & ((1 << kSplitBits) - 1);
+            }
+            Merge<kFixed> merge;
+            const int* rk = rank + ((static_cast<long long>(f) * n_cam + cam) * D + d) * HW + w;
+            for (int h0 = 0; h0 < H; h0 += kBatch) {
+                float v[kBatch][kVec];
 #pragma unroll
                 for (int j = 0; j < kBatch; ++j) {
                     const bool in = h0 + j < H;
                     if (kVec == 4) {
-                        const float4 t = in ? *reinterpret_cast<const float4*>(q + (h0 + j) * qstep) : make_float4(0.f, 0.f, 0.f, 0.f);
-                        v[j][0] *= t.x;  v[j][1 % kVec] *= t.y;  v[j][2 % kVec] *= t.z;  v[j][3 % kVec] *= t.w;
+                        vf4 t = {0.f, 0.f, 0.f, 0.f};
+                        if (in) {
+                            const vf4* src = reinterpret_cast<const vf4*>(p + (h0 + j) * step);
+                            // the lifted tensor is read exactly once: stream it past the caches
+                            t = kFused ? *src : __builtin_nontemporal_load(src);
+                        }
+                        v[j][0] = t[0];  v[j][1 % kVec] = t[1];  v[j][2 % kVec] = t[2];  v[j][3 % kVec] = t[3];
                     } else {
-                        v[j][0] *= in ? q[(h0 + j) * qstep] : 0.f;
+                        v[j][0] = in ? p[(h0 + j) * step] : 0.f;
                     }
                 }
-            }
-            if (!general) {
-                // each row adds to the run it belongs to (adding 0.f to the others is exact)
+                if (kFused) {
 #pragma unroll
-                for (int j = 0; j < kBatch; ++j)
-#pragma unroll
-                    for (int k = 0; k < kVec; ++k) {
-                        const bool first = h0 + j < s1[k], third = h0 + j >= s2[k];
-                        sa[k] += first ? v[j][k] : 0.f;
-                        sc[k] += third ? v[j][k] : 0.f;
-                        sb[k] += (first || third) ? 0.f : v[j][k];
+                    for (int j = 0; j < kBatch; ++j) {
+                        const bool in = h0 + j < H;
+                        if (kVec == 4) {
+                            const float4 t = in ? *reinterpret_cast<const float4*>(q + (h0 + j) * qstep) : make_float4(0.f, 0.f, 0.f, 0.f);
+                            v[j][0] *= t.x;  v[j][1 % kVec] *= t.y;  v[j][2 % kVec] *= t.z;  v[j][3 % kVec] *= t.w;
+                        } else {
+                            v[j][0] *= in ? q[(h0 + j) * qstep] : 0.f;
+                        }
                     }
-            } else {
-                // a column with four or more runs somewhere in this work-item: walk the rows with their ranks
-                for (int j = 0; j < kBatch && h0 + j < H; ++j)
-                    for (int k = 0; k < kVec; ++k) merge.add(plane, v0, v1, rk[(h0 + j) * W + k], v[j][k]);
-                // (columns are interleaved here, so `merge` only fuses vertical runs of a single-column item)
-            }
-        }
-        if (!general) {
+                }
+                if (!kGeneral) {
+                    // each row adds to the run it belongs to (adding 0.f to the others is exact)
 #pragma unroll
-            for (int k = 0; k < kVec; ++k) {
-                merge.add(plane, v0, v1, dsc[k].x, sa[k]);
-                if (s1[k] < H) merge.add(plane, v0, v1, dsc[k].y, sb[k]);
-                if (s2[k] < H) merge.add(plane, v0, v1, dsc[k].z, sc[k]);
+                    for (int j = 0; j < kBatch; ++j)
+#pragma unroll
+                        for (int k = 0; k < kVec; ++k) {
+                            const bool first_run = h0 + j < s1[k], third = h0 + j >= s2[k];
+                            sa[k] += first_run ? v[j][k] : 0.f;
+                            sc[k] += third ? v[j][k] : 0.f;
+                            sb[k] += (first_run || third) ? 0.f : v[j][k];
+                        }
+                } else {
+                    // a column with four or more runs somewhere in this work-item: every element goes to the voxel its
+                    // own rank names.  The ranks of a row are fetched like the row itself (one 16-byte load for four
+                    // columns), all rows of the batch in flight together.
+                    int r[kBatch][kVec];
+#pragma unroll
+                    for (int j = 0; j < kBatch; ++j) {
+                        const bool in = h0 + j < H;
+                        if (kVec == 4) {
+                            const int4 t = in ? *reinterpret_cast<const int4*>(rk + (h0 + j) * W) : make_int4(-1, -1, -1, -1);
+                            r[j][0] = t.x;  r[j][1 % kVec] = t.y;  r[j][2 % kVec] = t.z;  r[j][3 % kVec] = t.w;
+                        } else {
+                            r[j][0] = in ? rk[(h0 + j) * W] : -1;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < kBatch; ++j)
+#pragma unroll
+                        for (int k = 0; k < kVec; ++k)
+                            if (r[j][k] >= v0 && r[j][k] < v1) Cell<kFixed>::add(&plane[r[j][k] - v0], v[j][k]);
+                }
             }
+            if (!kGeneral) {
+#pragma unroll
+                for (int k = 0; k < kVec; ++k) {
+                    merge.add(plane, v0, v1, dsc[k].x, sa[k]);
+                    if (s1[k] < H) merge.add(plane, v0, v1, dsc[k].y, sb[k]);
+                    if (s2[k] < H) merge.add(plane, v0, v1, dsc[k].z, sc[k]);
+                }
+            }
+            merge.flush(plane, v0);
         }
-        merge.flush(plane, v0);
-    }
+    };
+    const int* cnt = counts + 2 * (f * n_tiles + tile);
+    run_list(std::false_type{}, lst, 1, cnt[0]);
+    if (cnt[1] > 0) run_list(std::true_type{}, lst + n_items - 1, -1, cnt[1]);
     __syncthreads();
     float* o = out + (static_cast<long long>(f) * C + c) * n_vox + v0;
     for (int i = threadIdx.x; i < span; i += blockDim.x) o[i] = Cell<kFixed>::value(plane[i]);
@@ -475,7 +543,7 @@ int plan_pool(int frames, int n_cam, int D, int H, int W, long long n_vox_ll, in
     pl->off_coldesc = align(points * 4);
     pl->off_colmask = align(pl->off_coldesc + cols * sizeof(int4));
     pl->off_counts = align(pl->off_colmask + cols * 4);
-    pl->off_lists = align(pl->off_counts + static_cast<size_t>(frames) * pl->n_tiles * 4);
+    pl->off_lists = align(pl->off_counts + static_cast<size_t>(frames) * pl->n_tiles * 2 * 4);
     pl->total = pl->off_lists + cols * pl->n_tiles * sizeof(int);
     return FIERY_OK;
 }
@@ -522,6 +590,11 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
     int* lists = reinterpret_cast<int*>(ws + pl.off_lists);
     const long long n_cols_all = static_cast<long long>(frames) * n_cam * D * W;
     hipStream_t s = as_stream(stream);
+    // workgroup size follows the tile: 256 threads per 40 KiB of LDS keeps 16 wavefronts per CU whatever the tile
+    const int threads = pl.lds <= 40960 ? 256 : (pl.lds <= 81920 ? 512 : 1024);
+    if (getenv("FIERY_POOL_VERBOSE"))
+        fprintf(stderr, "voxel_pool plan: frames=%d C=%d tile=%d x%d, %d threads, %zu B LDS\n", frames, C, pl.tile, pl.n_tiles,
+                threads, pl.lds);
     hipLaunchKernelGGL(k_rank_columns, dim3(ceil_div(n_cols_all, 256)), dim3(256), 0, s, geometry, frames * n_cam, D, H,
                        W, to_params(*grid), pl.tile, rank, coldesc, colmask);
     rc = check_launch("rank_columns");
@@ -537,15 +610,15 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
                 st.c % 4 == 0;
     }
     if (const char* forced = getenv("FIERY_POOL_VEC")) quads = quads && atoi(forced) == 4;      // tuning / tests
-    hipLaunchKernelGGL(k_build_tile_lists, dim3(pl.n_tiles, frames), dim3(1024), 0, s, colmask, n_cam, D, W, quads ? 4 : 1,
-                       pl.n_tiles, lists, counts);
+    hipLaunchKernelGGL(k_build_tile_lists, dim3(pl.n_tiles, frames), dim3(1024), 0, s, colmask, n_cam, D, W,
+                       quads ? 4 : 1, pl.n_tiles, lists, counts);
     rc = check_launch("build_tile_lists");
     if (rc) return rc;
-    dim3 gridDim3(pl.n_tiles, C, frames);
+    const long long n_units = static_cast<long long>(C) * frames * pl.n_tiles;
+    FIERY_REQUIRE(n_units < (1ll << 31), "voxel_pool: too many (tile, channel, frame) units");
+    dim3 gridDim3(static_cast<unsigned>(n_units));
     int batch = fused ? 8 : 16;                 // the fused form holds two operands per row
     if (const char* forced = getenv("FIERY_POOL_BATCH")) batch = atoi(forced) == 8 ? 8 : 16;
-    // workgroup size follows the tile: 256 threads per 40 KiB of LDS keeps 16 wavefronts per CU whatever the tile
-    const int threads = pl.lds <= 40960 ? 256 : (pl.lds <= 81920 ? 512 : 1024);
 #define FIERY_POOL_LAUNCH(VEC, BATCH, FUSED, FIXED)                                                                      \
     do {                                                                                                                 \
         if (pl.lds > 65536 &&                                                                                            \
@@ -553,7 +626,7 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pl.lds)) != hipSuccess)      \
             return fail(FIERY_ELAUNCH, "voxel_pool: cannot reserve %zu B of LDS", pl.lds);                              \
         hipLaunchKernelGGL((k_voxel_pool<VEC, BATCH, FUSED, FIXED>), gridDim3, dim3(threads), pl.lds, s, x, st, depth, feat, \
-                           rank, coldesc, lists, counts, out, n_cam, D, H, W, C, pl.n_vox, pl.tile, pl.n_tiles);          \
+                           rank, coldesc, lists, counts, out, n_cam, D, H, W, C, pl.n_vox, pl.tile, pl.n_tiles); \
     } while (0)
 #define FIERY_POOL_DISPATCH(VEC, BATCH)                          \
     do {                                                         \

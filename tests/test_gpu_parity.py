@@ -234,6 +234,37 @@ def test_hot_path_baseline_batch3_against_live_oracle_and_fused_variant(hip):
         assert (fused[k].cpu() - v).abs().max().item() <= TOL * scale, k
 
 
+def test_graph_replay_equals_eager_and_follows_in_place_input_updates(hip):
+    """`bev_forward_graph`: one hipGraphLaunch instead of ~130 launches.  The replay must give what the eager path
+    gives (up to the pooling atomics' summation order), also after the resident input buffers were refreshed."""
+    cfg = tiny_cfg('baseline.yml')
+    model, sd = _model(cfg)
+    lifted, K, E, ego, lab, noise = forward_case(cfg, model.receptive_field, model.n_future, model.depth_channels,
+                                                 model.bev_size, 2, 2, True, True)
+    lifted, K, E, ego, lab, noise = (t.to(DEV) for t in (lifted, K, E, ego, lab, noise))
+
+    def close(a, b):
+        for k, v in a.items():
+            if v is None:
+                assert b[k] is None
+                continue
+            assert (v - b[k]).abs().max().item() <= 1e-5 * max(1.0, v.abs().max().item()), k
+
+    with torch.no_grad():
+        eager = {k: None if v is None else v.clone() for k, v in model.bev_forward(lifted, K, E, ego, lab, noise).items()}
+        close(eager, model.bev_forward_graph(lifted, K, E, ego, lab, noise))
+        assert len(model._graphs) == 1
+        lifted.mul_(0.5)                                  # refresh the resident buffers in place
+        noise.neg_()
+        ego[:, :, 0] += 0.3
+        replay = model.bev_forward_graph(lifted, K, E, ego, lab, noise)
+        assert len(model._graphs) == 1                    # same buffers: no second capture
+        replay = {k: None if v is None else v.clone() for k, v in replay.items()}
+        changed = model.bev_forward(lifted, K, E, ego, lab, noise)
+        close(changed, replay)
+        assert (changed['segmentation'] - eager['segmentation']).abs().max().item() > 1e-3
+
+
 def test_method_seams_keep_the_reference_signatures(hip):
     cfg = tiny_cfg('baseline.yml')
     model, sd = _model(cfg)

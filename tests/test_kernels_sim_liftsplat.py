@@ -188,6 +188,28 @@ def test_quad_path_16_byte_rows(sim, flags, rolled):
         assert np.abs(out[f].numpy() - exact).max() < 5e-6
 
 
+def test_many_units_and_general_items(sim):
+    """3 frames x 6 channels x 2 tiles on the 1-D unit grid, with camera 0 rolled so that some quads hold a
+    column of four or more runs (their own list, row-by-row path)."""
+    frustum, intr, extr, lifted = _small_problem(21, n_cam=2, W=12, C=6, frames=3)
+    roll = torch.tensor([[0.0, -1.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0], [0.0, 0.0, 1.0, 0.0], [0.0, 0.0, 0.0, 1.0]])
+    extr = extr.clone()
+    extr[:, 0] = extr[:, 0] @ roll
+    frames, n_cam, C, D, H, W = lifted.shape
+    geo = ls.get_geometry(frustum, intr.numpy(), extr.numpy())
+    grid, (res, start, dim) = _grid([-20.0, 20.0, 0.5], [-16.0, 16.0, 0.5], [-10.0, 10.0, 20.0])
+    q = np.floor((geo[0, 0] - (start - res / np.float32(2))) / res).astype(np.int64)       # camera 0, frame 0
+    r = q[..., 0] * int(dim[1]) + q[..., 1]
+    runs = (r[:, 1:, :] != r[:, :-1, :]).sum(axis=1) + 1
+    assert runs.max() >= 4                                   # the general path is exercised
+    st = lifted.stride()
+    out = sim.voxel_pool(lifted, (st[0], st[1], st[3], st[4], st[5], st[2]), torch.from_numpy(geo), frames, n_cam, D, H, W, C,
+                         grid, tile_voxels=2560)
+    for f in range(frames):
+        exact = ls.voxel_pool_exact(ls.lifted_to_points(lifted[f].numpy()), geo[f].reshape(-1, 3), res, start, dim)
+        assert np.abs(out[f].numpy() - exact).max() < 5e-6
+
+
 def test_quad_path_fused(sim):
     frustum, intr, extr, _ = _small_problem(9, W=12)
     frames, n_cam, D, H, W, C = 2, 2, 5, 6, 12, 4

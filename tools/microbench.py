@@ -47,6 +47,11 @@ def bench_probe(reps):
     sink = torch.zeros(4, device=DEV)
     nbytes = x.numel() * 4
     stream = torch.cuda.current_stream().cuda_stream
+    for blocks, threads, unroll in ((1152, 512, 16), (1152, 512, 28), (1152, 512, 8), (2304, 256, 16), (576, 1024, 16),
+                                    (4608, 512, 16), (512, 512, 16), (1024, 512, 28)):
+        us = timed(lambda: probe.probe_read(x.data_ptr(), nbytes, blocks, threads, unroll, 3, sink.data_ptr(), stream), reps)
+        print(f'probe pooling pattern (28 rows x 16 B per lane) blocks={blocks:5d} threads={threads:4d} rows in flight={unroll:2d}: '
+              f'{us:7.1f} us -> {nbytes / us / 1e3:7.1f} GB/s', flush=True)
     for mode, name in ((0, 'grid-stride'), (1, 'grid-stride nontemporal'), (2, 'slab per workgroup')):
         for blocks, threads, unroll in ((2048, 256, 4), (4096, 256, 8), (1024, 512, 8), (512, 1024, 8), (2048, 512, 16),
                                         (8192, 256, 4), (1152, 512, 16), (1024, 512, 16)):
@@ -100,6 +105,11 @@ CONV_CASES = [  # (k, stride, cin, cout, n_img, H, W, residual)
     (3, 1, 128, 128, 3, 192, 256, False),
     (3, 1, 128, 128, 6, 192, 256, False),
     (3, 1, 128, 64, 3, 192, 256, False),
+    # partial rounds: 768 / 384 / 339 / 1536 tiles of 64 rows
+    (3, 1, 128, 128, 1, 192, 256, False),
+    (3, 1, 128, 128, 1, 192, 128, False),
+    (3, 1, 128, 128, 1, 96, 226, False),
+    (3, 1, 128, 128, 2, 192, 256, False),
 ]
 
 
@@ -118,10 +128,69 @@ def bench_conv(lib, reps):
               f'({flops / us / 1e6 / 157.3:.1%} of fp32 MFMA peak)', flush=True)
 
 
+def bench_chains(lib, reps):
+    """Does per-sample stream parallelism hide the partly filled last round of workgroups?  A GRU-like dependent
+    chain (gates 128->128 then tilde 128->64, 4 steps) for 3 samples: batched on one stream vs one stream per sample."""
+    H = W = 200
+    cases = [(128, 128), (128, 64)]
+    ops = []
+    for cin, cout in cases:
+        w = torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5
+        ops.append(ConvOp(lib, w, identity_chan_map(cin), (cin // 8, 0), torch.ones(cout), torch.zeros(cout), DEV,
+                          act=native.ACT_RELU))
+
+    def make(n):
+        x = Buf(torch.randn(n, H, W, 128, device=DEV), n, H, W, 128)
+        return x, Buf.alloc(n, H, W, 128, DEV), Buf.alloc(n, H, W, 64, DEV)
+
+    def chain(bufs, steps=4):
+        x, a, b = bufs
+        for _ in range(steps):
+            ops[0]([x], a)
+            ops[1]([a], b)
+
+    batched = make(3)
+    us = timed(lambda: chain(batched), reps)
+    flops = 4 * 3 * 2.0 * H * W * 128 * 9 * (128 + 64)
+    print(f'chain batched n=3, 1 stream : {us:8.1f} us  {flops / us / 1e6:6.1f} TFLOP/s', flush=True)
+    singles = [make(1) for _ in range(3)]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+
+    def fan():
+        cur = torch.cuda.current_stream()
+        for s_, bufs in zip(streams, singles):
+            s_.wait_stream(cur)
+            with torch.cuda.stream(s_):
+                chain(bufs)
+        for s_ in streams:
+            cur.wait_stream(s_)
+
+    us = timed(fan, reps)
+    print(f'chain 3 x n=1, 3 streams   : {us:8.1f} us  {flops / us / 1e6:6.1f} TFLOP/s', flush=True)
+    g = torch.cuda.CUDAGraph()
+    fan()
+    torch.cuda.synchronize()
+    try:
+        with torch.cuda.graph(g):
+            fan()
+        us = timed(g.replay, reps)
+        print(f'chain 3 x n=1, hipGraph    : {us:8.1f} us  {flops / us / 1e6:6.1f} TFLOP/s', flush=True)
+    except Exception as e:                                       # noqa: BLE001
+        print('graph capture failed:', repr(e)[:300], flush=True)
+    g2 = torch.cuda.CUDAGraph()
+    try:
+        with torch.cuda.graph(g2):
+            chain(batched)
+        us = timed(g2.replay, reps)
+        print(f'chain batched n=3, hipGraph : {us:8.1f} us  {flops / us / 1e6:6.1f} TFLOP/s', flush=True)
+    except Exception as e:                                       # noqa: BLE001
+        print('graph capture failed:', repr(e)[:300], flush=True)
+
+
 if __name__ == '__main__':
     reps = int(sys.argv[sys.argv.index('--reps') + 1]) if '--reps' in sys.argv else 5
     lib = native.get()
-    what = [a for a in sys.argv[1:] if a in ('pool', 'conv', 'probe')] or ['pool', 'conv']
+    what = [a for a in sys.argv[1:] if a in ('pool', 'conv', 'probe', 'chains')] or ['pool', 'conv']
     if 'probe' in what:
         bench_probe(reps)
     if 'pool' in what:
@@ -130,3 +199,5 @@ if __name__ == '__main__':
             bench_pool(lib, reps, frames=frames, tiles=tiles)
     if 'conv' in what:
         bench_conv(lib, reps)
+    if 'chains' in what:
+        bench_chains(lib, reps)

@@ -43,6 +43,27 @@ __global__ void k_read_slabs(const float4* __restrict__ x, long long n4, float* 
     if (acc == 1.2345e-30f) sink[0] = acc;
 }
 
+// the pooling kernel's pattern: the tensor is a sequence of (28 rows x 15 quads) slices; a lane owns one quad column
+// of a slice and reads its 28 rows (240 B apart), kBatch rows in flight; neighbouring lanes own neighbouring columns
+template <int kBatch>
+__global__ void k_read_columns(const float4* __restrict__ x, long long n4, float* __restrict__ sink) {
+    const long long n_items = n4 / 28;
+    const long long per = (n_items + gridDim.x - 1) / gridDim.x;
+    const long long lo = per * blockIdx.x, hi = lo + per < n_items ? lo + per : n_items;
+    float acc = 0.f;
+    for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const float4* p = x + (i / 15) * 420 + (i % 15);
+        for (int h0 = 0; h0 < 28; h0 += kBatch) {
+            float4 v[kBatch];
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) v[j] = h0 + j < 28 ? p[(h0 + j) * 15] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) acc += v[j].x + v[j].y + v[j].z + v[j].w;
+        }
+    }
+    if (acc == 1.2345e-30f) sink[0] = acc;
+}
+
 extern "C" int probe_read(const void* x, long long n_bytes, int blocks, int threads, int unroll, int mode, void* sink,
                           void* stream) {
     const float4* p = static_cast<const float4*>(x);
@@ -56,6 +77,9 @@ extern "C" int probe_read(const void* x, long long n_bytes, int blocks, int thre
     } else if (mode == 1) {
         if (unroll == 1) GO((k_read<1, true>), 1); else if (unroll == 4) GO((k_read<4, true>), 4);
         else if (unroll == 8) GO((k_read<8, true>), 8); else GO((k_read<16, true>), 16);
+    } else if (mode == 3) {
+        if (unroll <= 8) GO((k_read_columns<8>), 8); else if (unroll <= 16) GO((k_read_columns<16>), 16);
+        else GO((k_read_columns<28>), 28);
     } else {
         if (unroll == 1) GO((k_read_slabs<1>), 1); else if (unroll == 4) GO((k_read_slabs<4>), 4);
         else if (unroll == 8) GO((k_read_slabs<8>), 8); else GO((k_read_slabs<16>), 16);
