@@ -689,9 +689,10 @@ extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) {
     }
     const int bn = (d->cout_pad % 128 == 0) ? 128 : (d->cout_pad % 64 == 0) ? 64 : 32;
     const int n_tiles = d->cout_pad / bn;
-    // Tile height: workgroups run in waves of (256 CUs x resident workgroups per CU); pick the height whose last
-    // wave is better filled.  Measured (profiles/): with 128 couts per tile the 64-pixel tile is never slower (three
-    // workgroups per CU instead of two); with 64 couts it pays ~20 % for its higher load/MFMA ratio.
+    // Tile height: workgroups run in rounds of (256 CUs x resident workgroups per CU); the default picks the height
+    // whose last round is better filled.  How a partly filled round really behaves depends on the launch (a lone
+    // workgroup is latency-bound, not three times faster), so callers that repeat a launch can time both heights
+    // and pass the winner in desc->tile_m (fiery_amd/ops.py does, once per shape).
     bool half_tiles = false;
     if (bn >= 64 && !d->weights2) {
         auto fill = [&](int bm, int per_cu) {
@@ -702,6 +703,7 @@ extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) {
         const double e128 = fill(128, bn == 128 ? 2 : 3);
         const double e64 = (bn == 128 ? 1.0 : 0.8) * fill(64, bn == 128 ? 3 : 5);
         half_tiles = bn == 128 || e64 > e128;
+        if (d->tile_m == 64 || d->tile_m == 128) half_tiles = d->tile_m == 64;                   // the caller measured
         if (const char* forced = getenv("FIERY_CONV_TILE_M")) half_tiles = atoi(forced) == 64;   // tuning / tests
     }
     dim3 grid(ceil_div(p.M, half_tiles ? 64 : 128), n_tiles);

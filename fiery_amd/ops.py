@@ -4,6 +4,7 @@ This is the layer `fiery_amd.engine` composes the BEV stack from.  It only prepa
 (weight packing, BatchNorm folding, descriptors); all arithmetic runs in libfiery_hip.so.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -14,6 +15,7 @@ UNIT = 8          # input channels are consumed in units of 8 floats
 # When a list is installed here (bench.py does, for its instrumented step), every launch appends
 # (kind, start_event, end_event, algorithmic_work) - flops for convolutions, bytes for pooling.
 PROFILE_SINK = None
+AUTOTUNE = os.environ.get('FIERY_CONV_AUTOTUNE', '1') != '0'     # time both tile heights once per conv shape (GPU only)
 
 
 def profiled(kind, work, stream_tensor, fn, detail=None):
@@ -132,6 +134,7 @@ class ConvOp:
         self.scale, self.shift = sc.to(device), sh.to(device)
         self.act, self.epi, self.res_before_act = act, epi, res_before_act
         self.chain = None
+        self._tile_m = {}            # (n_img, H, W) of the output -> measured best tile height
 
     def chain_pointwise(self, weight, scale, shift, act):
         """Fuse a following 1x1 convolution (Cin <= 32 = this op's padded outputs, Cout <= 64) into this kernel:
@@ -152,6 +155,32 @@ class ConvOp:
 
     def out_hw(self, H, W):
         return ((H + 2 * self.padH - self.kH) // self.stride + 1, (W + 2 * self.padW - self.kW) // self.stride + 1)
+
+    def _pick_tile(self, d, out):
+        """Tile height for this launch.  The same launches repeat every step, so the first time a shape is seen on
+        the GPU both heights are timed (HIP events, on the launch stream) and the faster one is kept - the partly
+        filled last round of workgroups makes the better choice shape-dependent.  The
+        convolution is a pure function of its inputs, so the extra launches leave the same result behind."""
+        if self.cout_pad % 64 != 0 or self.chain is not None:
+            return 0                                   # one tile shape only
+        key = (out.n_img, out.H, out.W)
+        choice = self._tile_m.get(key)
+        if choice is None:
+            if not _autotune_enabled(out.tensor):
+                return 0                               # library heuristic (and nothing cached: tune when possible)
+            times = {}
+            for tile in (64, 128):
+                d.tile_m = tile
+                self.lib.conv_fwd(d, out.tensor)       # warm
+                start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                start.record()
+                for _ in range(3):
+                    self.lib.conv_fwd(d, out.tensor)
+                end.record()
+                end.synchronize()
+                times[tile] = start.elapsed_time(end)
+            choice = self._tile_m[key] = min(times, key=times.get)
+        return choice
 
     def __call__(self, srcs, out, res=None, img_bias=None, out2=None, aux0=None, aux1=None,
                  T_out=1, t_out0=0, t_in_add=0, cout_store=None):
@@ -190,11 +219,16 @@ class ConvOp:
         d.aux0 = aux0.as_nhwc_struct() if aux0 is not None else _null_nhwc()
         d.aux1 = aux1.as_nhwc_struct() if aux1 is not None else _null_nhwc()
         self._keep = (srcs, out, res, img_bias, out2, aux0, aux1)
+        d.tile_m = self._pick_tile(d, out)
         flops = 2.0 * out.n_img * out.H * out.W * self.cin_total * self.kT * self.kH * self.kW * self.cout
         if self.chain is not None:
             flops += 2.0 * out.n_img * out.H * out.W * self.cout * self.chain['cout']
         profiled('conv_igemm', flops, out.tensor, lambda: self.lib.conv_fwd(d, out.tensor),
                  detail=(self.kT, self.kH, self.kW, self.stride, self.cin_total, self.cout, out.n_img, out.H, out.W))
+
+
+def _autotune_enabled(t):
+    return AUTOTUNE and t.is_cuda and PROFILE_SINK is None and not torch.cuda.is_current_stream_capturing()
 
 
 def identity_chan_map(channels, offset=0):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FIERY_ABI_VERSION 1
+#define FIERY_ABI_VERSION 2
 
 #define FIERY_OK 0
 #define FIERY_EINVAL (-22)      /* bad argument (shape, alignment, null pointer) */
@@ -186,6 +186,10 @@ typedef struct {
     const float* scale2;               /* [64] */
     const float* shift2;               /* [64] */
     int32_t act2;
+    /* Output pixels per workgroup tile: 0 = let the library choose, 64 or 128 = the caller's choice (a caller that
+     * issues the same launch every step can time both once and keep the faster; 64 needs cout_pad % 64 == 0 and
+     * no chained 1x1, otherwise the value is ignored).  Results do not depend on it. */
+    int32_t tile_m;
 } fiery_conv_desc;
 
 /* Packs a dense weight W[cout][cin_total][taps] (taps = kT*kH*kW, row-major as PyTorch stores conv
