@@ -27,6 +27,17 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X dense fp32 matrix peak (MI355X_MICROA
 PEAK_HBM_GBS = 8000.0             # MI355X HBM3E spec bandwidth
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over
+    this bench command, folded by tools/pmc_traffic.py with the gfx950 correction); None when the summary is absent.
+    Counters cannot be collected from inside the timed process, so this is the one roofline field not measured live."""
+    path = os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')
+    try:
+        return json.load(open(path))[kernel]['traffic_bytes']
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -171,7 +182,8 @@ def main():
         achieved = f_conv / t_conv / 1e12
         roofline = {'kernel': 'k_conv_igemm (fp32 MFMA implicit GEMM)', 'bound': 'mfma', 'achieved': round(achieved, 2),
                     'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                    'traffic': None, 'launches': len(conv), 'avg_launch_us': round(t_conv / len(conv) * 1e6, 2),
+                    'traffic': pmc_traffic('k_conv_igemm (all tile shapes)'), 'launches': len(conv),
+                    'avg_launch_us': round(t_conv / len(conv) * 1e6, 2),
                     'algorithmic_gflop_per_step': round(f_conv / 1e9, 1), 'kernel_ms_per_step': round(t_conv * 1e3, 3),
                     'measured': 'HIP events around every launch, one instrumented step after the timed region'}
         if pool:
@@ -179,7 +191,8 @@ def main():
             gbs = b_pool / t_pool / 1e9
             pooling = {'kernel': 'k_rank_columns + k_voxel_pool (op boundary projection_to_birds_eye_view)', 'bound': 'hbm',
                        'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
-                       'traffic': None, 'algorithmic_mb_per_step': round(b_pool / 1e6, 1), 'op_us_per_step': round(t_pool * 1e6, 1)}
+                       'traffic': pmc_traffic('k_voxel_pool'), 'algorithmic_mb_per_step': round(b_pool / 1e6, 1),
+                       'op_us_per_step': round(t_pool * 1e6, 1)}
 
     if rank == 0:
         line = {

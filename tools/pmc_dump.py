@@ -2,8 +2,16 @@
 """Prints per-kernel averages of the PMC counters in a rocprofv3 result database (rocpd SQLite)."""
 import collections
 import glob
+import re
 import sqlite3
 import sys
+
+
+def short(name):
+    name = re.sub(r'\(anonymous namespace\)::', '', name)
+    name = re.sub(r'^void ', '', name)
+    m = re.match(r'([A-Za-z0-9_:<>, ]+?)\(', name)
+    return (m.group(1) if m else name)[:70]
 
 
 def main():
@@ -18,11 +26,11 @@ def main():
             cname = 'counter_name' if 'counter_name' in cols else 'counter'
             agg = collections.defaultdict(lambda: [0, 0.0])
             for name, counter, value in con.execute(f'select {kname}, {cname}, value from counters_collection'):
-                a = agg[(name.split('(')[0][-60:], counter)]
+                a = agg[(short(name), counter)]
                 a[0] += 1
                 a[1] += value
             for (name, counter), (n, total) in sorted(agg.items()):
-                print(f'{name:62s} {counter:28s} n={n:4d} avg={total / n:16.1f}')
+                print(f'{name:72s} {counter:20s} n={n:4d} avg={total / n:16.1f} total={total:18.1f}')
         else:
             for t in views[:6]:
                 print(t, [r[1] for r in con.execute(f'pragma table_info({t})')])
