@@ -61,6 +61,7 @@ struct ConvP {
     const float* shift2;
     int act2;
     int vec_epilogue;     // destinations / residual / bias rows are 16-byte addressable
+    int bias_border;      // img_bias holds nine rows per image, chosen by the output pixel's border class
 };
 
 __device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -279,7 +280,12 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
             if (gp >= M) break;
             float4 v = *reinterpret_cast<const float4*>(&smem[pl * width + c4 * 4]);
             if (with_bias && p.img_bias) {
-                const float4 b = *reinterpret_cast<const float4*>(p.img_bias + static_cast<long long>(o) * p.cout_pad + co);
+                long long brow = o;
+                if (p.bias_border) {                        // 3x3 class of (y, x): which taps fall inside the image
+                    const int y = ppi / p.Wout, x = ppi - y * p.Wout;
+                    brow = brow * 9 + (y == 0 ? 0 : y == p.Hout - 1 ? 2 : 1) * 3 + (x == 0 ? 0 : x == p.Wout - 1 ? 2 : 1);
+                }
+                const float4 b = *reinterpret_cast<const float4*>(p.img_bias + brow * p.cout_pad + co);
                 v.x += b.x;  v.y += b.y;  v.z += b.z;  v.w += b.w;
             }
             v.x = fmaf(v.x, sc.x, sh.x);  v.y = fmaf(v.y, sc.y, sh.y);  v.z = fmaf(v.z, sc.z, sh.z);  v.w = fmaf(v.w, sc.w, sh.w);
@@ -460,7 +466,14 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
             }
             const long long pp = ppi;
             float v = a[r];
-            if (p.img_bias) v += p.img_bias[static_cast<long long>(o) * p.cout_pad + co];
+            if (p.img_bias) {
+                long long brow = o;
+                if (p.bias_border) {
+                    const int y = ppi / p.Wout, x = ppi - y * p.Wout;
+                    brow = brow * 9 + (y == 0 ? 0 : y == p.Hout - 1 ? 2 : 1) * 3 + (x == 0 ? 0 : x == p.Wout - 1 ? 2 : 1);
+                }
+                v += p.img_bias[brow * p.cout_pad + co];
+            }
             v = fmaf(v, sc, sh);
             if (p.epi == FIERY_EPI_PLAIN) {
                 if (co >= p.cout_store) continue;
@@ -659,6 +672,9 @@ extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) {
     p.n_units = cin_units * taps;
     p.k_chunks = (p.n_units + 3) / 4;
     p.scale = d->scale; p.shift = d->shift; p.img_bias = d->img_bias;
+    p.bias_border = d->img_bias_border != 0;
+    FIERY_REQUIRE(!p.bias_border || (d->img_bias && d->Hout >= 2 && d->Wout >= 2),
+                  "conv_fwd: img_bias_border needs img_bias and an output of at least 2x2 pixels");
     p.act = d->act; p.epi = d->epi; p.res_pre = d->res_before_act;
     p.res = TensP{d->res.ptr, d->res.ld, d->res.img_stride};
     p.out = TensP{d->out.ptr, d->out.ld, d->out.img_stride};

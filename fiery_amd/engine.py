@@ -235,23 +235,48 @@ class _TemporalBlock:
         return out
 
 
-class _Gru:
-    """fiery/layers/temporal.py:10-62: update|reset as one N=2h GEMM, gate arithmetic in the epilogues."""
+def _border_tables(w_x):
+    """(cout, cx, 3, 3) weights of spatially constant input channels -> (9 * cout, cx): for each border class
+    (cy, cx) of a zero-padded 3x3 convolution the sum of the taps that fall inside the image
+    (include/fiery_hip.h, img_bias_border)."""
+    w64 = w_x.detach().double().cpu()
+    rows = []
+    for cy in range(3):
+        kys = [1, 2] if cy == 0 else [0, 1] if cy == 2 else [0, 1, 2]
+        for cx in range(3):
+            kxs = [1, 2] if cx == 0 else [0, 1] if cx == 2 else [0, 1, 2]
+            rows.append(w64[:, :, kys][:, :, :, kxs].sum(dim=(2, 3)))
+    return torch.cat(rows, 0).float().contiguous()
 
-    def __init__(self, eng, g):
+
+class _Gru:
+    """fiery/layers/temporal.py:10-62: update|reset as one N=2h GEMM, gate arithmetic in the epilogues.
+
+    `const_x`: the input is the same vector at every pixel (the first SpatialGRU is fed the broadcast latent sample
+    at every future step, fiery.py:316-330).  Its third of the K dimension then collapses into nine per-image bias
+    rows - one per border class of the zero padding - and only the hidden-state channels go through the GEMM."""
+
+    def __init__(self, eng, g, const_x=False):
         lib, dev = eng.lib, eng.device
         cx, ch = g.input_size, g.hidden_size
         assert ch % 16 == 0, 'hidden size must be a multiple of 16 for the fused gate GEMM'
         self.cx, self.ch = cx, ch
-        cxp = round_up(cx, 8)
-        cmap = identity_chan_map(cx) + identity_chan_map(ch, offset=cxp)
-        units = (cxp // 8, ch // 8)
         wg = torch.cat([g.conv_update.weight.detach(), g.conv_reset.weight.detach()], 0)
         bg = torch.cat([g.conv_update.bias.detach(), g.conv_reset.bias.detach()], 0).float().cpu() + g.gru_bias_init
-        self.gates = ConvOp(lib, wg, cmap, units, torch.ones(2 * ch), bg, dev, epi=native.EPI_GRU_GATES)
+        wt = g.conv_state_tilde.conv.weight.detach()
         sc, sh = fold_bn(g.conv_state_tilde.norm, ch)
-        self.tilde = ConvOp(lib, g.conv_state_tilde.conv.weight, cmap, units, sc, sh, dev, act=RELU,
-                            epi=native.EPI_GRU_OUT)
+        self.const_x = bool(const_x) and tuple(wg.shape[2:]) == (3, 3) and (2 * ch) % 32 == 0 and ch % 32 == 0
+        if self.const_x:
+            cmap, units = identity_chan_map(ch), (ch // 8, 0)
+            self.gates_xw = _border_tables(wg[:, :cx]).to(dev)        # (9 * 2ch, cx)
+            self.tilde_xw = _border_tables(wt[:, :cx]).to(dev)        # (9 * ch, cx)
+            wg, wt = wg[:, cx:], wt[:, cx:]
+        else:
+            cxp = round_up(cx, 8)
+            cmap = identity_chan_map(cx) + identity_chan_map(ch, offset=cxp)
+            units = (cxp // 8, ch // 8)
+        self.gates = ConvOp(lib, wg, cmap, units, torch.ones(2 * ch), bg, dev, epi=native.EPI_GRU_GATES)
+        self.tilde = ConvOp(lib, wt, cmap, units, sc, sh, dev, act=RELU, epi=native.EPI_GRU_OUT)
 
 
 class BevEngine:
@@ -299,7 +324,7 @@ class BevEngine:
         # future prediction
         if self.nf > 0:
             fp = m.future_prediction
-            self.grus = [_Gru(self, g) for g in fp.spatial_grus]
+            self.grus = [_Gru(self, g, const_x=(i == 0)) for i, g in enumerate(fp.spatial_grus)]
             self.res_blocks = [[_Bottleneck(self, b) for b in seq] for seq in fp.res_blocks]
         # decoder
         d = m.decoder
@@ -477,12 +502,14 @@ class BevEngine:
                 sample = self.vec('sample', B, self.latent)
                 nz = noise.float().contiguous().view(B, self.latent) if noise is not None else None
                 lib.latent_sample(mu, log_sigma, nz, self.latent, B, self.latent, sample, self.latent)
+            else:
+                sample = self.vec('zero_sample', B, self.latent)     # zeros (fiery.py:175-176)
+            gx = None
+            if not self.grus[0].const_x:                            # the broadcast input is only materialised if needed
                 gx = self.buf('gru_x0', B, H, W, self.latent)
                 lib.broadcast(sample, self.latent, B, H * W, self.latent, gx.tensor, gx.ld, gx.img_stride)
-            else:
-                gx = self.buf('gru_x0', B, H, W, self.latent)       # zeros (fiery.py:175-176)
             dec_in = self.buf('dec_in', B * (self.nf + 1), H, W, self.state_c)
-            self._future_prediction(gx, present, dec_in, B)
+            self._future_prediction(gx, sample, present, dec_in, B)
             n_dec_t = self.nf + 1
         else:
             dec_in = present
@@ -490,9 +517,19 @@ class BevEngine:
         out.update(self._decoder(dec_in, B, n_dec_t))
         return out
 
-    def _future_prediction(self, gx, present, dec_in, B):
+    def _future_prediction(self, gx, sample, present, dec_in, B):
         lib = self.lib
         nf, H, W, ch = self.nf, present.H, present.W, self.state_c
+        g0 = self.grus[0]
+        gates_bias = tilde_bias = None
+        if g0.const_x:
+            # nine bias rows per sample: what the constant latent channels contribute for each border class
+            gates_bias = self.vec('gru0_gates_bias', B, 9 * 2 * ch)
+            tilde_bias = self.vec('gru0_tilde_bias', B, 9 * ch)
+            lib.rowwise_dense(sample, self.latent, B, self.latent, g0.gates_xw, self.latent, 0, 9 * 2 * ch, None, None, NONE,
+                              False, gates_bias, 9 * 2 * ch)
+            lib.rowwise_dense(sample, self.latent, B, self.latent, g0.tilde_xw, self.latent, 0, 9 * ch, None, None, NONE,
+                              False, tilde_bias, 9 * ch)
         # present state -> slot 0 of every batch element of the decoder input (plain copy)
         dec_in.nhwc().view(B, nf + 1, H, W, -1)[:, 0].copy_(present.nhwc())
         seq_in = None
@@ -502,9 +539,13 @@ class BevEngine:
             U = self.buf('gru_U', B, H, W, ch)
             RH = self.buf('gru_RH', B, H, W, ch)
             for t in range(nf):
-                x_t = gx if i == 0 else seq_in.images(t, B, step=nf)
                 h_t = present if t == 0 else O.images(t - 1, B, step=nf)
                 o_t = O.images(t, B, step=nf)
+                if i == 0 and gru.const_x:
+                    gru.gates([h_t], U, out2=RH, aux0=h_t, img_bias=gates_bias, img_bias_border=True)
+                    gru.tilde([RH], o_t, aux0=U, aux1=h_t, img_bias=tilde_bias, img_bias_border=True)
+                    continue
+                x_t = gx if i == 0 else seq_in.images(t, B, step=nf)
                 gru.gates([x_t, h_t], U, out2=RH, aux0=h_t)
                 gru.tilde([x_t, RH], o_t, aux0=U, aux1=h_t)
             x = O

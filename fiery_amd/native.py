@@ -51,7 +51,7 @@ class ConvDesc(C.Structure):
         ('res', Nhwc), ('out', Nhwc), ('cout_store', C.c_int32), ('out2', Nhwc),
         ('aux0', Nhwc), ('aux1', Nhwc),
         ('weights2', C.c_void_p), ('scale2', C.c_void_p), ('shift2', C.c_void_p), ('act2', C.c_int32),
-        ('tile_m', C.c_int32),
+        ('tile_m', C.c_int32), ('img_bias_border', C.c_int32),
     ]
 
 

@@ -183,7 +183,7 @@ class ConvOp:
         return choice
 
     def __call__(self, srcs, out, res=None, img_bias=None, out2=None, aux0=None, aux1=None,
-                 T_out=1, t_out0=0, t_in_add=0, cout_store=None):
+                 T_out=1, t_out0=0, t_in_add=0, cout_store=None, img_bias_border=False):
         """srcs: list of (Buf, batch_stride, time_stride) or Buf (plain image batch)."""
         d = native.ConvDesc()
         first = None
@@ -204,6 +204,7 @@ class ConvOp:
         d.weights, d.cout_pad = self.packed.data_ptr(), self.cout_pad
         d.scale, d.shift = self.scale.data_ptr(), self.shift.data_ptr()
         d.img_bias = img_bias.data_ptr() if img_bias is not None else None
+        d.img_bias_border = int(bool(img_bias_border))
         d.act, d.epi, d.res_before_act = self.act, self.epi, int(self.res_before_act)
         d.res = res.as_nhwc_struct() if res is not None else _null_nhwc()
         d.out = out.as_nhwc_struct()

@@ -168,7 +168,7 @@ typedef struct {
     int32_t cout_pad;                  /* multiple of 32                                                */
     const float* scale;                /* [cout_pad]                                                    */
     const float* shift;                /* [cout_pad]                                                    */
-    const float* img_bias;             /* [n_img_out][cout_pad] added before scale, or NULL            */
+    const float* img_bias;             /* [n_img_out][cout_pad] added before scale, or NULL (see img_bias_border) */
     int32_t act;
     int32_t epi;
     int32_t res_before_act;
@@ -190,6 +190,12 @@ typedef struct {
      * issues the same launch every step can time both once and keep the faster; 64 needs cout_pad % 64 == 0 and
      * no chained 1x1, otherwise the value is ignored).  Results do not depend on it. */
     int32_t tile_m;
+    /* != 0: img_bias is [n_img_out][9][cout_pad]; output pixel (y, x) takes row 3*cy + cx with
+     * cy = 0 / 1 / 2 for y == 0 / interior / y == Hout-1 and cx likewise.  This is how a spatially constant group
+     * of input channels (the broadcast latent sample of the first SpatialGRU, fiery.py:316-330 + temporal.py:36-62)
+     * is folded out of a zero-padded 3x3 convolution: its contribution is one of nine per-image vectors,
+     * depending on which taps fall inside the image. */
+    int32_t img_bias_border;
 } fiery_conv_desc;
 
 /* Packs a dense weight W[cout][cin_total][taps] (taps = kT*kH*kW, row-major as PyTorch stores conv

@@ -95,6 +95,39 @@ def test_two_source_concat_with_residual_and_bias(sim):
         assert torch.allclose(out.to_nchw(), want, **TOL)
 
 
+def border_class_bias(w_const, vec):
+    """[9][cout] table: contribution of spatially constant input channels `vec` (cin_c,) through the 3x3 weights
+    `w_const` (cout, cin_c, 3, 3) for the nine border classes of a zero-padded, stride-1 convolution."""
+    rows = []
+    for cy in range(3):
+        kys = [1, 2] if cy == 0 else [0, 1] if cy == 2 else [0, 1, 2]
+        for cx in range(3):
+            kxs = [1, 2] if cx == 0 else [0, 1] if cx == 2 else [0, 1, 2]
+            wsum = w_const[:, :, kys][:, :, :, kxs].sum(dim=(2, 3))           # (cout, cin_c)
+            rows.append(wsum @ vec)
+    return torch.stack(rows)
+
+
+@pytest.mark.parametrize('unaligned', [False, True])
+def test_constant_channels_folded_into_border_class_bias(sim, monkeypatch, unaligned):
+    """cat[const, h] through a 3x3 convolution == h-part convolution + one of nine per-image bias rows."""
+    if unaligned:
+        monkeypatch.setenv('FIERY_CONV_VEC_EPILOGUE', '0')         # register epilogue path
+    g = torch.Generator().manual_seed(77)
+    n, cc, ch, cout, hw = 2, 8, 16, 64, (7, 9)
+    vec = torch.randn(n, cc, generator=g)
+    h = torch.randn(n, ch, *hw, generator=g)
+    w = torch.randn(cout, cc + ch, 3, 3, generator=g) * 0.2
+    shift = torch.randn(cout, generator=g)
+    full = torch.cat([vec.view(n, cc, 1, 1).expand(n, cc, *hw), h], 1)
+    want = torch.sigmoid(F.conv2d(full, w, padding=1) + shift.view(1, -1, 1, 1))
+    op = ConvOp(sim, w[:, cc:], identity_chan_map(ch), (ch // 8, 0), torch.ones(cout), shift, 'cpu', act=native.ACT_SIGMOID)
+    table = torch.stack([border_class_bias(w[:, :cc], vec[i]) for i in range(n)]).contiguous()      # (n, 9, cout)
+    out = Buf.alloc(n, *hw, cout, 'cpu')
+    op([_to_buf(h)], out, img_bias=table, img_bias_border=True)
+    assert torch.allclose(out.to_nchw(), want, **TOL), (out.to_nchw() - want).abs().max()
+
+
 def test_channel_slices_of_wider_buffers(sim):
     """Reads a channel slice of a wide buffer and writes into a slice of another (concat by placement)."""
     g = torch.Generator().manual_seed(6)
