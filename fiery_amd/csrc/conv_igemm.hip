@@ -43,6 +43,14 @@ struct TensP {
     int ld;
     long long istride;
 };
+struct HeadsP {
+    const float* w;
+    const float* bias;
+    int n_out;
+    int group[FIERY_MAX_HEAD_OUTPUTS], sigmoid[FIERY_MAX_HEAD_OUTPUTS];
+    float* out[FIERY_MAX_HEAD_OUTPUTS];
+    long long istride[FIERY_MAX_HEAD_OUTPUTS];
+};
 struct ConvP {
     SrcP src[2];
     int Hin, Win, Hout, Wout, n_img, Tout, tout0, tinadd;
@@ -62,6 +70,7 @@ struct ConvP {
     int act2;
     int vec_epilogue;     // destinations / residual / bias rows are 16-byte addressable
     int bias_border;      // img_bias holds nine rows per image, chosen by the output pixel's border class
+    HeadsP heads;         // FIERY_EPI_HEADS
 };
 
 __device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -432,6 +441,66 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
         }
     }
 
+    // ---- decoder heads: the hidden tile stays in LDS, only the heads' final 1x1 outputs are stored -------------
+    if constexpr (BM == 64 && BN == 128) {
+        if (p.epi == FIERY_EPI_HEADS) {
+            float* w2 = smem + BM * BN;                              // [<= 4 outputs of this cout tile][64], behind the tile
+            stage_tile(acc[0], 0, 0, BN);
+            stage_tile(acc[1], 0, 1, BN);
+            // the final 1x1 rows whose 64-channel group lies in this 128-cout tile (at most 4: one per wavefront)
+            int my_out = -1;
+            {
+                int slot = 0;
+                for (int o = 0; o < p.heads.n_out; ++o) {
+                    if ((p.heads.group[o] >> 1) != tile_n) continue;
+                    if (slot < 4 && tid < 64) w2[slot * 64 + tid] = p.heads.w[o * 64 + tid];
+                    if (slot == wv) my_out = o;
+                    ++slot;
+                }
+            }
+            __syncthreads();
+            // hidden = act(acc * scale + shift), in place, 16 bytes per thread and pass
+            {
+                const int c4 = tid & 31, prow0 = tid >> 5;            // 32 chunks of four couts, 8 rows per pass
+                const float4 sc = *reinterpret_cast<const float4*>(p.scale + tile_n * BN + c4 * 4);
+                const float4 sh = *reinterpret_cast<const float4*>(p.shift + tile_n * BN + c4 * 4);
+                for (int pl = prow0; pl < BM; pl += 8) {
+                    float4 v = *reinterpret_cast<float4*>(&smem[pl * BN + c4 * 4]);
+                    v.x = fmaf(v.x, sc.x, sh.x);  v.y = fmaf(v.y, sc.y, sh.y);  v.z = fmaf(v.z, sc.z, sh.z);  v.w = fmaf(v.w, sc.w, sh.w);
+                    if (p.act == FIERY_ACT_RELU) {
+                        v.x = fmaxf(v.x, 0.f);  v.y = fmaxf(v.y, 0.f);  v.z = fmaxf(v.z, 0.f);  v.w = fmaxf(v.w, 0.f);
+                    } else if (p.act == FIERY_ACT_SIGMOID) {
+                        v.x = sigmoidf(v.x);  v.y = sigmoidf(v.y);  v.z = sigmoidf(v.z);  v.w = sigmoidf(v.w);
+                    }
+                    *reinterpret_cast<float4*>(&smem[pl * BN + c4 * 4]) = v;
+                }
+            }
+            __syncthreads();
+            // wavefront wv owns one output row; a lane owns a pixel.  Lane l starts at channel l and walks round, so the
+            // 64 lanes touch 32 different banks at every step although their rows are 512 bytes apart.
+            if (my_out >= 0) {
+                const int slot = wv;                                   // == position of my_out among this tile's rows
+                const int cb = (p.heads.group[my_out] & 1) * 64;
+                const float* row = &smem[lane * BN + cb];
+                const float* wrow = &w2[slot * 64];
+                float a = 0.f;
+#pragma unroll 8
+                for (int c0 = 0; c0 < 64; ++c0) {
+                    const int cc = (c0 + lane) & 63;
+                    a = fmaf(row[cc], wrow[cc], a);
+                }
+                a += p.heads.bias[my_out];
+                if (p.heads.sigmoid[my_out]) a = sigmoidf(a);
+                const int gp = pix0 + lane;
+                if (gp < M) {
+                    const int o = gp / HWout, ppi = gp - o * HWout;
+                    p.heads.out[my_out][o * p.heads.istride[my_out] + ppi] = a;
+                }
+            }
+            return;
+        }
+    }
+
     if (rows16) {
         // (the loop's last barrier has passed: the stages are free)
         stage_tile(acc[0], 0, 0, BN);
@@ -627,7 +696,7 @@ extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) {
     FIERY_REQUIRE(d, "conv_fwd: null descriptor");
     FIERY_REQUIRE(d->src[0].ptr && d->src[0].units > 0, "conv_fwd: source 0 missing");
     FIERY_REQUIRE(d->src[1].units == 0 || d->src[1].ptr, "conv_fwd: source 1 missing");
-    FIERY_REQUIRE(d->weights && d->scale && d->shift && d->out.ptr, "conv_fwd: null pointer");
+    FIERY_REQUIRE(d->weights && d->scale && d->shift && (d->out.ptr || d->epi == FIERY_EPI_HEADS), "conv_fwd: null pointer");
     FIERY_REQUIRE(d->kT >= 1 && d->kH >= 1 && d->kW >= 1 && d->stride >= 1, "conv_fwd: bad kernel shape");
     FIERY_REQUIRE(d->n_img_out > 0 && d->T_out > 0 && d->n_img_out % d->T_out == 0, "conv_fwd: bad image counts");
     FIERY_REQUIRE(d->Hin > 0 && d->Win > 0 && d->Hout > 0 && d->Wout > 0, "conv_fwd: bad spatial shape");
@@ -657,7 +726,7 @@ extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) {
     } else if (d->epi == FIERY_EPI_GRU_OUT) {
         FIERY_REQUIRE(d->aux0.ptr && d->aux1.ptr, "conv_fwd: GRU output epilogue needs aux0 and aux1");
     } else {
-        FIERY_REQUIRE(d->epi == FIERY_EPI_PLAIN, "conv_fwd: unknown epilogue %d", d->epi);
+        FIERY_REQUIRE(d->epi == FIERY_EPI_PLAIN || d->epi == FIERY_EPI_HEADS, "conv_fwd: unknown epilogue %d", d->epi);
     }
     const int taps = d->kT * d->kH * d->kW;
     ConvP p;
@@ -673,6 +742,27 @@ extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) {
     p.k_chunks = (p.n_units + 3) / 4;
     p.scale = d->scale; p.shift = d->shift; p.img_bias = d->img_bias;
     p.bias_border = d->img_bias_border != 0;
+    p.heads.w = nullptr;
+    p.heads.bias = nullptr;
+    p.heads.n_out = 0;
+    if (d->epi == FIERY_EPI_HEADS) {
+        FIERY_REQUIRE(d->cout_pad % 128 == 0 && !d->weights2 && !d->res.ptr, "conv_fwd: heads epilogue needs cout_pad % 128 == 0, no chain, no residual");
+        FIERY_REQUIRE(d->heads.w && d->heads.bias && d->heads.n_out > 0 && d->heads.n_out <= FIERY_MAX_HEAD_OUTPUTS,
+                      "conv_fwd: heads epilogue needs 1..%d output rows", FIERY_MAX_HEAD_OUTPUTS);
+        p.heads.w = d->heads.w;
+        p.heads.bias = d->heads.bias;
+        p.heads.n_out = d->heads.n_out;
+        int per_tile[64] = {0};
+        for (int o = 0; o < d->heads.n_out; ++o) {
+            const int g = d->heads.group[o];
+            FIERY_REQUIRE(g >= 0 && g * 64 < d->cout_pad && d->heads.out[o], "conv_fwd: heads output %d: bad group or null plane", o);
+            FIERY_REQUIRE(++per_tile[(g >> 1) & 63] <= 4, "conv_fwd: more than four head outputs read one 128-channel tile");
+            p.heads.group[o] = g;
+            p.heads.sigmoid[o] = d->heads.sigmoid[o];
+            p.heads.out[o] = d->heads.out[o];
+            p.heads.istride[o] = d->heads.img_stride[o];
+        }
+    }
     FIERY_REQUIRE(!p.bias_border || (d->img_bias && d->Hout >= 2 && d->Wout >= 2),
                   "conv_fwd: img_bias_border needs img_bias and an output of at least 2x2 pixels");
     p.act = d->act; p.epi = d->epi; p.res_pre = d->res_before_act;
@@ -720,7 +810,9 @@ extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) {
         const double e64 = (bn == 128 ? 1.0 : 0.8) * fill(64, bn == 128 ? 3 : 5);
         half_tiles = bn == 128 || e64 > e128;
         if (d->tile_m == 64 || d->tile_m == 128) half_tiles = d->tile_m == 64;                   // the caller measured
-        if (const char* forced = getenv("FIERY_CONV_TILE_M")) half_tiles = atoi(forced) == 64;   // tuning / tests
+        if (d->epi == FIERY_EPI_HEADS) half_tiles = true;          // its LDS plan (tile + 1x1 rows) is the 64-pixel one
+        if (const char* forced = getenv("FIERY_CONV_TILE_M"))                                    // tuning / tests
+            if (d->epi != FIERY_EPI_HEADS) half_tiles = atoi(forced) == 64;
     }
     dim3 grid(ceil_div(p.M, half_tiles ? 64 : 128), n_tiles);
     hipStream_t hs = as_stream(stream);

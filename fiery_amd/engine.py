@@ -21,7 +21,7 @@ import torch.nn as nn
 
 from . import native
 from . import ops
-from .ops import Buf, ConvOp, fold_bn, identity_chan_map, round_up
+from .ops import HeadsOut, Buf, ConvOp, fold_bn, identity_chan_map, round_up
 
 RELU, NONE, SIGMOID = native.ACT_RELU, native.ACT_NONE, native.ACT_SIGMOID
 
@@ -374,6 +374,15 @@ class BevEngine:
             self.heads_final.append(dict(name=name, w=_w2d(h[3]).contiguous().to(dev),
                                          b=h[3].bias.detach().float().contiguous().to(dev), n_out=n_out,
                                          sigmoid=len(h) > 4, c_off=i * cin))
+        # With 64 hidden channels per head (the reference's shared_out_channels) the final 1x1s ride in the 3x3 GEMM's
+        # epilogue: the (images, 200, 200, 256) hidden tensor is never written.
+        n_rows = sum(hd['n_out'] for hd in self.heads_final)
+        self.heads_fused = cin == 64 and (len(heads) * cin) % 128 == 0 and n_rows <= native.MAX_HEAD_OUTPUTS
+        if self.heads_fused:
+            groups = [i for i, hd in enumerate(self.heads_final) for _ in range(hd['n_out'])]
+            self.heads_conv.attach_heads(torch.cat([hd['w'] for hd in self.heads_final]),
+                                         torch.cat([hd['b'] for hd in self.heads_final]), groups,
+                                         [self.heads_final[g]['sigmoid'] for g in groups])
         self.head_c = cin
 
     def _distribution_ops(self, dm, in_split):
@@ -601,14 +610,22 @@ class BevEngine:
             o = self.buf(f'dec_up{ui}', n, skip.H, skip.W, up['cout'])
             lib.upsample2x_add(low, low.ld, n, low.H, low.W, up['cout'], up['shift'], skip, skip.ld, o, o.ld)
             y = o
-        hb = self.buf('dec_heads', n, H, W, self.heads_conv.cout)
-        self.heads_conv([y], hb)
         out = {}
-        for hd in self.heads_final:
-            res = torch.empty(n, hd['n_out'], H, W, dtype=torch.float32, device=self.device)
-            lib.heads_1x1_nchw(hb.slice(hd['c_off'], self.head_c), hb.ld, n, H * W, self.head_c, self.head_c,
-                               hd['w'], hd['b'], [0] * hd['n_out'], [hd['sigmoid']] * hd['n_out'], res)
-            out[hd['name']] = res.view(B, T, hd['n_out'], H, W)
+        if self.heads_fused:
+            results = [torch.empty(n, hd['n_out'], H, W, dtype=torch.float32, device=self.device) for hd in self.heads_final]
+            planes = [(res.data_ptr() + 4 * j * H * W, hd['n_out'] * H * W)
+                      for res, hd in zip(results, self.heads_final) for j in range(hd['n_out'])]
+            self.heads_conv([y], HeadsOut(n, H, W, results[0]), head_planes=planes)
+            for res, hd in zip(results, self.heads_final):
+                out[hd['name']] = res.view(B, T, hd['n_out'], H, W)
+        else:
+            hb = self.buf('dec_heads', n, H, W, self.heads_conv.cout)
+            self.heads_conv([y], hb)
+            for hd in self.heads_final:
+                res = torch.empty(n, hd['n_out'], H, W, dtype=torch.float32, device=self.device)
+                lib.heads_1x1_nchw(hb.slice(hd['c_off'], self.head_c), hb.ld, n, H * W, self.head_c, self.head_c,
+                                   hd['w'], hd['b'], [0] * hd['n_out'], [hd['sigmoid']] * hd['n_out'], res)
+                out[hd['name']] = res.view(B, T, hd['n_out'], H, W)
         if 'instance_flow' not in out:
             out['instance_flow'] = None
         return out

@@ -21,7 +21,7 @@ c_int64_p = C.POINTER(C.c_int64)
 c_uint8_p = C.POINTER(C.c_uint8)
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
-EPI_PLAIN, EPI_GRU_GATES, EPI_GRU_OUT = 0, 1, 2
+EPI_PLAIN, EPI_GRU_GATES, EPI_GRU_OUT, EPI_HEADS = 0, 1, 2, 3
 POOL_DETERMINISTIC = 1
 
 
@@ -38,6 +38,15 @@ class Nhwc(C.Structure):
     _fields_ = [('ptr', C.c_void_p), ('ld', C.c_int32), ('img_stride', C.c_int64)]
 
 
+MAX_HEAD_OUTPUTS = 8
+
+
+class ConvHeads(C.Structure):
+    _fields_ = [('w', C.c_void_p), ('bias', C.c_void_p), ('n_out', C.c_int32),
+                ('group', C.c_int32 * MAX_HEAD_OUTPUTS), ('sigmoid', C.c_int32 * MAX_HEAD_OUTPUTS),
+                ('out', C.c_void_p * MAX_HEAD_OUTPUTS), ('img_stride', C.c_int64 * MAX_HEAD_OUTPUTS)]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [
         ('src', ConvSrc * 2),
@@ -51,7 +60,7 @@ class ConvDesc(C.Structure):
         ('res', Nhwc), ('out', Nhwc), ('cout_store', C.c_int32), ('out2', Nhwc),
         ('aux0', Nhwc), ('aux1', Nhwc),
         ('weights2', C.c_void_p), ('scale2', C.c_void_p), ('shift2', C.c_void_p), ('act2', C.c_int32),
-        ('tile_m', C.c_int32), ('img_bias_border', C.c_int32),
+        ('tile_m', C.c_int32), ('img_bias_border', C.c_int32), ('heads', ConvHeads),
     ]
 
 

@@ -134,6 +134,7 @@ class ConvOp:
         self.scale, self.shift = sc.to(device), sh.to(device)
         self.act, self.epi, self.res_before_act = act, epi, res_before_act
         self.chain = None
+        self.heads = None
         self._tile_m = {}            # (n_img, H, W) of the output -> measured best tile height
 
     def chain_pointwise(self, weight, scale, shift, act):
@@ -153,6 +154,19 @@ class ConvOp:
         self.chain = dict(w=packed, scale=sc.to(device), shift=sh.to(device), act=act, cout=cout2)
         return self
 
+    def attach_heads(self, weight, bias, groups, sigmoids):
+        """Turn this convolution into the decoder-heads form (FIERY_EPI_HEADS): its activated output - 64 hidden
+        channels per head - stays on chip and only the final 1x1 rows are stored.  weight (n_out, 64), bias (n_out,),
+        groups[o] = which 64-channel group row o reads, sigmoids[o] = apply a sigmoid to row o."""
+        assert self.cout_pad % 128 == 0 and self.chain is None and self.epi == native.EPI_PLAIN
+        n_out = weight.shape[0]
+        assert weight.shape == (n_out, 64) and n_out <= native.MAX_HEAD_OUTPUTS and len(groups) == len(sigmoids) == n_out
+        device = self.packed.device
+        self.heads = dict(w=weight.detach().float().contiguous().to(device), b=bias.detach().float().contiguous().to(device),
+                          groups=[int(g) for g in groups], sigmoids=[int(bool(v)) for v in sigmoids], n_out=n_out)
+        self.epi = native.EPI_HEADS
+        return self
+
     def out_hw(self, H, W):
         return ((H + 2 * self.padH - self.kH) // self.stride + 1, (W + 2 * self.padW - self.kW) // self.stride + 1)
 
@@ -161,30 +175,32 @@ class ConvOp:
         the GPU both heights are timed (HIP events, on the launch stream) and the faster one is kept - the partly
         filled last round of workgroups makes the better choice shape-dependent.  The
         convolution is a pure function of its inputs, so the extra launches leave the same result behind."""
-        if self.cout_pad % 64 != 0 or self.chain is not None:
+        if self.cout_pad % 64 != 0 or self.chain is not None or self.heads is not None:
             return 0                                   # one tile shape only
         key = (out.n_img, out.H, out.W)
         choice = self._tile_m.get(key)
         if choice is None:
             if not _autotune_enabled(out.tensor):
                 return 0                               # library heuristic (and nothing cached: tune when possible)
-            times = {}
-            for tile in (64, 128):
-                d.tile_m = tile
-                self.lib.conv_fwd(d, out.tensor)       # warm
-                start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                start.record()
-                for _ in range(3):
-                    self.lib.conv_fwd(d, out.tensor)
-                end.record()
-                end.synchronize()
-                times[tile] = start.elapsed_time(end)
+            times = {64: float('inf'), 128: float('inf')}
+            for _trial in range(3):                    # alternate the candidates, keep each one's best trial
+                for tile in (64, 128):
+                    d.tile_m = tile
+                    self.lib.conv_fwd(d, out.tensor)   # warm
+                    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    start.record()
+                    for _ in range(3):
+                        self.lib.conv_fwd(d, out.tensor)
+                    end.record()
+                    end.synchronize()
+                    times[tile] = min(times[tile], start.elapsed_time(end))
             choice = self._tile_m[key] = min(times, key=times.get)
         return choice
 
     def __call__(self, srcs, out, res=None, img_bias=None, out2=None, aux0=None, aux1=None,
-                 T_out=1, t_out0=0, t_in_add=0, cout_store=None, img_bias_border=False):
-        """srcs: list of (Buf, batch_stride, time_stride) or Buf (plain image batch)."""
+                 T_out=1, t_out0=0, t_in_add=0, cout_store=None, img_bias_border=False, head_planes=None):
+        """srcs: list of (Buf, batch_stride, time_stride) or Buf (plain image batch).  With attached heads `out` is a
+        `HeadsOut(n_img, H, W, tensor)` and head_planes[o] = (address of row o's plane of image 0, floats between images)."""
         d = native.ConvDesc()
         first = None
         for i in range(2):
@@ -207,7 +223,15 @@ class ConvOp:
         d.img_bias_border = int(bool(img_bias_border))
         d.act, d.epi, d.res_before_act = self.act, self.epi, int(self.res_before_act)
         d.res = res.as_nhwc_struct() if res is not None else _null_nhwc()
-        d.out = out.as_nhwc_struct()
+        if self.heads is not None:
+            d.out = _null_nhwc()
+            hd = d.heads
+            hd.w, hd.bias, hd.n_out = self.heads['w'].data_ptr(), self.heads['b'].data_ptr(), self.heads['n_out']
+            for o in range(self.heads['n_out']):
+                hd.group[o], hd.sigmoid[o] = self.heads['groups'][o], self.heads['sigmoids'][o]
+                hd.out[o], hd.img_stride[o] = head_planes[o]
+        else:
+            d.out = out.as_nhwc_struct()
         if self.chain is not None:
             d.weights2, d.scale2, d.shift2 = self.chain['w'].data_ptr(), self.chain['scale'].data_ptr(), self.chain['shift'].data_ptr()
             d.act2 = self.chain['act']
@@ -215,7 +239,8 @@ class ConvOp:
         else:
             d.weights2 = d.scale2 = d.shift2 = None
             d.act2 = 0
-            d.cout_store = cout_store if cout_store is not None else min(self.cout_pad, round_up(self.cout, UNIT), out.C)
+            d.cout_store = cout_store if cout_store is not None else min(self.cout_pad, round_up(self.cout, UNIT),
+                                                                         getattr(out, 'C', self.cout_pad))
         d.out2 = out2.as_nhwc_struct() if out2 is not None else _null_nhwc()
         d.aux0 = aux0.as_nhwc_struct() if aux0 is not None else _null_nhwc()
         d.aux1 = aux1.as_nhwc_struct() if aux1 is not None else _null_nhwc()
@@ -224,8 +249,17 @@ class ConvOp:
         flops = 2.0 * out.n_img * out.H * out.W * self.cin_total * self.kT * self.kH * self.kW * self.cout
         if self.chain is not None:
             flops += 2.0 * out.n_img * out.H * out.W * self.cout * self.chain['cout']
+        if self.heads is not None:
+            flops += 2.0 * out.n_img * out.H * out.W * 64 * self.heads['n_out']
         profiled('conv_igemm', flops, out.tensor, lambda: self.lib.conv_fwd(d, out.tensor),
                  detail=(self.kT, self.kH, self.kW, self.stride, self.cin_total, self.cout, out.n_img, out.H, out.W))
+
+
+class HeadsOut:
+    """Stands in for the output Buf of a heads convolution: its shape, and a tensor that names the device/stream."""
+
+    def __init__(self, n_img, H, W, tensor):
+        self.n_img, self.H, self.W, self.tensor = n_img, H, W, tensor
 
 
 def _autotune_enabled(t):

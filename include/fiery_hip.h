@@ -151,6 +151,8 @@ typedef struct {
 #define FIERY_EPI_PLAIN 0      /* out = act(acc*scale+shift [+res before act]) [+res after act]          */
 #define FIERY_EPI_GRU_GATES 1  /* channels [0,C/2): out=sigmoid -> update gate; [C/2,C): out2=(1-sigmoid)*aux0 */
 #define FIERY_EPI_GRU_OUT 2    /* h~=relu(..); out(=out2) = (1-aux0)*aux1 + aux0*h~   (layers/temporal.py:49-62) */
+#define FIERY_EPI_HEADS 3      /* hidden = act(acc*scale+shift) stays on chip; heads_out = final 1x1s of it (see heads) */
+#define FIERY_MAX_HEAD_OUTPUTS 8
 
 /* One implicit-GEMM convolution with a fused epilogue, NHWC fp32, fp32 MFMA accumulate.
  * Input channels are the virtual concatenation of src[0] and src[1] (8-channel units); the kernel
@@ -196,6 +198,20 @@ typedef struct {
      * is folded out of a zero-padded 3x3 convolution: its contribution is one of nine per-image vectors,
      * depending on which taps fall inside the image. */
     int32_t img_bias_border;
+    /* FIERY_EPI_HEADS: the decoder heads (models/decoder.py:30-51) are Conv3x3 -> BN -> ReLU -> Conv1x1(+bias)
+     * [-> Sigmoid].  All heads' 3x3 convolutions run as this one GEMM (cout_pad = 64 hidden channels per head,
+     * a multiple of 128); the hidden tile never leaves the chip: output o is
+     *   heads_out[o][image*heads_img_stride[o] + pixel] = [sigmoid](bias[o] + sum_c w[o][c] * hidden[64*group[o] + c])
+     * i.e. pixel-contiguous planes (NCHW).  `out` is not written and may be null. */
+    struct {
+        const float* w;                              /* [n_out][64]                                     */
+        const float* bias;                           /* [n_out]                                         */
+        int32_t n_out;                               /* <= FIERY_MAX_HEAD_OUTPUTS                       */
+        int32_t group[FIERY_MAX_HEAD_OUTPUTS];       /* 64-channel group of the hidden tensor it reads  */
+        int32_t sigmoid[FIERY_MAX_HEAD_OUTPUTS];
+        float* out[FIERY_MAX_HEAD_OUTPUTS];          /* plane of image 0                                */
+        int64_t img_stride[FIERY_MAX_HEAD_OUTPUTS];  /* floats between the planes of consecutive images */
+    } heads;
 } fiery_conv_desc;
 
 /* Packs a dense weight W[cout][cin_total][taps] (taps = kT*kH*kW, row-major as PyTorch stores conv

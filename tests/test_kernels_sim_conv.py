@@ -7,7 +7,7 @@ import torch
 import torch.nn.functional as F
 
 from fiery_amd import native
-from fiery_amd.ops import Buf, ConvOp, identity_chan_map, round_up
+from fiery_amd.ops import Buf, ConvOp, HeadsOut, identity_chan_map, round_up
 
 TOL = dict(rtol=2e-5, atol=2e-5)
 
@@ -126,6 +126,33 @@ def test_constant_channels_folded_into_border_class_bias(sim, monkeypatch, unali
     out = Buf.alloc(n, *hw, cout, 'cpu')
     op([_to_buf(h)], out, img_bias=table, img_bias_border=True)
     assert torch.allclose(out.to_nchw(), want, **TOL), (out.to_nchw() - want).abs().max()
+
+
+def test_decoder_heads_epilogue_keeps_the_hidden_tensor_on_chip(sim):
+    """Four heads (Conv3x3 -> BN -> ReLU -> Conv1x1 + bias [-> Sigmoid], models/decoder.py:30-51) as one 256-cout GEMM
+    whose epilogue stores only the seven final rows, as NCHW planes of four separate tensors."""
+    g = torch.Generator().manual_seed(5)
+    n, cin, hw = 2, 16, (9, 11)                       # 99 pixels per image: tiles straddle the image boundary
+    n_outs, sig = [2, 1, 2, 2], [False, True, False, False]
+    x = torch.randn(n, cin, *hw, generator=g)
+    w3 = torch.randn(4 * 64, cin, 3, 3, generator=g) * 0.15
+    scale = torch.rand(4 * 64, generator=g) + 0.5
+    shift = torch.randn(4 * 64, generator=g) * 0.3
+    w1 = [torch.randn(k, 64, generator=g) * 0.2 for k in n_outs]
+    b1 = [torch.randn(k, generator=g) for k in n_outs]
+    op = ConvOp(sim, w3, identity_chan_map(cin), (cin // 8, 0), scale, shift, 'cpu', act=native.ACT_RELU)
+    groups = [h for h, k in enumerate(n_outs) for _ in range(k)]
+    op.attach_heads(torch.cat(w1), torch.cat(b1), groups, [sig[h] for h in groups])
+    outs = [torch.full((n, k, *hw), float('nan')) for k in n_outs]
+    hwp = hw[0] * hw[1]
+    planes = [(outs[h].data_ptr() + 4 * j * hwp, n_outs[h] * hwp) for h in range(4) for j in range(n_outs[h])]
+    op([_to_buf(x)], HeadsOut(n, *hw, outs[0]), head_planes=planes)
+    hidden = F.relu(F.conv2d(x, w3, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    for h in range(4):
+        want = F.conv2d(hidden[:, 64 * h:64 * h + 64], w1[h].view(-1, 64, 1, 1), b1[h])
+        if sig[h]:
+            want = torch.sigmoid(want)
+        assert torch.allclose(outs[h], want, **TOL), (h, (outs[h] - want).abs().max())
 
 
 def test_channel_slices_of_wider_buffers(sim):
