@@ -3,6 +3,8 @@
 // the entry points in include/fiery_hip.h); all are unit-stride on the pixel-major (NHWC) layout.
 #include "common.h"
 
+#include <cstdint>
+
 namespace fiery {
 namespace {
 
@@ -32,13 +34,59 @@ __global__ __launch_bounds__(256) void k_mean_partial(const float* __restrict__ 
     }
 }
 
-__global__ void k_mean_final(const float* __restrict__ partial, int n_img, int C, float inv_count, float* __restrict__ out) {
+__global__ void k_mean_final(const float* __restrict__ partial, int n_img, int C, int chunks, float inv_count,
+                             float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_img * C) return;
     const int img = i / C, c = i - img * C;
     float s = 0.f;
-    for (int k = 0; k < kMeanChunks; ++k) s += partial[(static_cast<long long>(img) * kMeanChunks + k) * C + c];
+    for (int k = 0; k < chunks; ++k) s += partial[(static_cast<long long>(img) * chunks + k) * C + c];
     out[i] = s * inv_count;
+}
+
+// 16-byte variant of stage 1 for C % 4 == 0 and aligned rows: a thread owns four channels and every
+// (256 / (C/4))-th pixel of its chunk, four independent accumulator quads per thread keep several loads in flight.
+// grid (chunks, n_img), 256 threads; requires C/4 <= 256.
+__global__ __launch_bounds__(256) void k_mean_partial4(const float* __restrict__ in, int ld, long long outer_stride,
+                                                       long long inner_stride, int n_inner, int HW, int C, int chunks,
+                                                       float* __restrict__ partial) {
+    __shared__ float4 red[256];
+    const int chunk = blockIdx.x, img = blockIdx.y;
+    const int per = (HW + chunks - 1) / chunks;
+    const int p0 = chunk * per, p1 = min(HW, p0 + per);
+    const int c4n = C >> 2;                        // channel quads
+    const int lanes = 256 / c4n;                   // pixel lanes
+    const int cq = threadIdx.x % c4n, pl = threadIdx.x / c4n;
+    const float* base = in + (img / n_inner) * outer_stride + (img % n_inner) * inner_stride + cq * 4;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    if (pl < lanes) {
+        int p = p0 + pl;
+        for (; p + 3 * lanes < p1; p += 4 * lanes) {
+            const float4 a = *reinterpret_cast<const float4*>(base + static_cast<long long>(p) * ld);
+            const float4 b = *reinterpret_cast<const float4*>(base + static_cast<long long>(p + lanes) * ld);
+            const float4 c = *reinterpret_cast<const float4*>(base + static_cast<long long>(p + 2 * lanes) * ld);
+            const float4 d = *reinterpret_cast<const float4*>(base + static_cast<long long>(p + 3 * lanes) * ld);
+            s0.x += a.x;  s0.y += a.y;  s0.z += a.z;  s0.w += a.w;
+            s1.x += b.x;  s1.y += b.y;  s1.z += b.z;  s1.w += b.w;
+            s2.x += c.x;  s2.y += c.y;  s2.z += c.z;  s2.w += c.w;
+            s3.x += d.x;  s3.y += d.y;  s3.z += d.z;  s3.w += d.w;
+        }
+        for (; p < p1; p += lanes) {
+            const float4 a = *reinterpret_cast<const float4*>(base + static_cast<long long>(p) * ld);
+            s0.x += a.x;  s0.y += a.y;  s0.z += a.z;  s0.w += a.w;
+        }
+    }
+    red[threadIdx.x] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y),
+                                   (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w));
+    __syncthreads();
+    if (pl == 0) {
+        float4 t = red[cq];
+        for (int k = 1; k < lanes; ++k) {
+            const float4 u = red[k * c4n + cq];
+            t.x += u.x;  t.y += u.y;  t.z += u.z;  t.w += u.w;
+        }
+        *reinterpret_cast<float4*>(&partial[(static_cast<long long>(img) * chunks + chunk) * C + cq * 4]) = t;
+    }
 }
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -174,6 +222,39 @@ __global__ void k_upsample2x_add(const float* __restrict__ in, int in_ld, int H,
     out[po * out_ld + c] = up + (shift ? shift[c] : 0.f) + skip[po * skip_ld + c];
 }
 
+// the same, four channels (16 bytes) per thread: C, the leading dimensions and the base addresses are multiples of 4
+__global__ void k_upsample2x_add4(const float* __restrict__ in, int in_ld, int H, int W, int C4,
+                                  const float* __restrict__ shift, const float* __restrict__ skip, int skip_ld,
+                                  float* __restrict__ out, int out_ld, long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = static_cast<int>(i % C4) * 4;
+    long long r = i / C4;
+    const int Wo = 2 * W, Ho = 2 * H;
+    const int x = static_cast<int>(r % Wo);
+    r /= Wo;
+    const int y = static_cast<int>(r % Ho);
+    const int img = static_cast<int>(r / Ho);
+    const float sy = fmaxf(0.5f * (y + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * (x + 0.5f) - 0.5f, 0.f);
+    const int y0 = static_cast<int>(sy), x0 = static_cast<int>(sx);
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float ly = sy - y0, lx = sx - x0;
+    const float* base = in + static_cast<long long>(img) * H * W * in_ld + c;
+    const float4 v00 = *reinterpret_cast<const float4*>(base + (static_cast<long long>(y0) * W + x0) * in_ld);
+    const float4 v01 = *reinterpret_cast<const float4*>(base + (static_cast<long long>(y0) * W + x1) * in_ld);
+    const float4 v10 = *reinterpret_cast<const float4*>(base + (static_cast<long long>(y1) * W + x0) * in_ld);
+    const float4 v11 = *reinterpret_cast<const float4*>(base + (static_cast<long long>(y1) * W + x1) * in_ld);
+    const long long po = (static_cast<long long>(img) * Ho + y) * Wo + x;
+    const float4 sk = *reinterpret_cast<const float4*>(skip + po * skip_ld + c);
+    const float4 sh = shift ? *reinterpret_cast<const float4*>(shift + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 o;
+    o.x = (1.f - ly) * ((1.f - lx) * v00.x + lx * v01.x) + ly * ((1.f - lx) * v10.x + lx * v11.x) + sh.x + sk.x;
+    o.y = (1.f - ly) * ((1.f - lx) * v00.y + lx * v01.y) + ly * ((1.f - lx) * v10.y + lx * v11.y) + sh.y + sk.y;
+    o.z = (1.f - ly) * ((1.f - lx) * v00.z + lx * v01.z) + ly * ((1.f - lx) * v10.z + lx * v11.z) + sh.z + sk.z;
+    o.w = (1.f - ly) * ((1.f - lx) * v00.w + lx * v01.w) + ly * ((1.f - lx) * v10.w + lx * v11.w) + sh.w + sk.w;
+    *reinterpret_cast<float4*>(out + po * out_ld + c) = o;
+}
+
 __global__ void k_broadcast(const float* __restrict__ v, int v_ld, int HW, int C, float* __restrict__ out, int out_ld,
                             long long out_img_stride, long long total) {
     const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -232,13 +313,21 @@ extern "C" int fiery_spatial_mean(const float* in, int in_ld, int64_t outer_stri
     FIERY_REQUIRE(in && out && workspace, "spatial_mean: null pointer");
     FIERY_REQUIRE(n_outer > 0 && n_inner > 0 && n_pixels > 0 && C > 0 && in_ld >= C, "spatial_mean: bad shape");
     const int n_img = n_outer * n_inner;
-    hipLaunchKernelGGL(k_mean_partial, dim3(kMeanChunks, n_img), dim3(256), 0, as_stream(stream), in, in_ld,
-                       static_cast<long long>(outer_stride), static_cast<long long>(inner_stride), n_inner, n_pixels, C,
-                       workspace);
+    // 16-byte rows when the layout allows; the chunk count stays kMeanChunks (the workspace contract)
+    const bool vec4 = C % 4 == 0 && C / 4 <= 256 && in_ld % 4 == 0 && outer_stride % 4 == 0 && inner_stride % 4 == 0 &&
+                      (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0;
+    if (vec4)
+        hipLaunchKernelGGL(k_mean_partial4, dim3(kMeanChunks, n_img), dim3(256), 0, as_stream(stream), in, in_ld,
+                           static_cast<long long>(outer_stride), static_cast<long long>(inner_stride), n_inner, n_pixels, C,
+                           kMeanChunks, workspace);
+    else
+        hipLaunchKernelGGL(k_mean_partial, dim3(kMeanChunks, n_img), dim3(256), 0, as_stream(stream), in, in_ld,
+                           static_cast<long long>(outer_stride), static_cast<long long>(inner_stride), n_inner, n_pixels, C,
+                           workspace);
     int rc = check_launch("spatial_mean(partial)");
     if (rc) return rc;
     hipLaunchKernelGGL(k_mean_final, dim3(ceil_div(n_img * C, 256)), dim3(256), 0, as_stream(stream), workspace, n_img, C,
-                       1.0f / static_cast<float>(n_pixels), out);
+                       kMeanChunks, 1.0f / static_cast<float>(n_pixels), out);
     return check_launch("spatial_mean(final)");
 }
 
@@ -281,6 +370,14 @@ extern "C" int fiery_maxpool2x2_nhwc(const float* in, int in_ld, int n_img, int 
 extern "C" int fiery_upsample2x_add_nhwc(const float* in, int in_ld, int n_img, int H, int W, int C, const float* shift,
                                          const float* skip, int skip_ld, float* out, int out_ld, fiery_stream_t stream) {
     FIERY_REQUIRE(in && skip && out && n_img > 0 && H > 0 && W > 0 && C > 0, "upsample2x_add: bad argument");
+    auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (C % 4 == 0 && in_ld % 4 == 0 && skip_ld % 4 == 0 && out_ld % 4 == 0 && a16(in) && a16(skip) && a16(out) &&
+        (!shift || a16(shift))) {
+        const long long total4 = static_cast<long long>(n_img) * 4 * H * W * (C / 4);
+        hipLaunchKernelGGL(k_upsample2x_add4, dim3(ceil_div(total4, 256)), dim3(256), 0, as_stream(stream), in, in_ld, H, W,
+                           C / 4, shift, skip, skip_ld, out, out_ld, total4);
+        return check_launch("upsample2x_add");
+    }
     const long long total = static_cast<long long>(n_img) * 4 * H * W * C;
     hipLaunchKernelGGL(k_upsample2x_add, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), in, in_ld, H, W, C,
                        shift, skip, skip_ld, out, out_ld, total);

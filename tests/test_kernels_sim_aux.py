@@ -49,9 +49,10 @@ def test_bev_warp_matches_grid_sample_and_changes_layout(sim):
     assert out[..., C:].abs().max() == 0
 
 
-def test_spatial_mean(sim):
+@pytest.mark.parametrize('C', [70, 64])          # 70: scalar rows; 64 of 72: the 16-byte kernel
+def test_spatial_mean(sim, C):
     g = torch.Generator().manual_seed(2)
-    n, H, W, C = 3, 9, 11, 70
+    n, H, W = 3, 9, 11
     x = torch.randn(n, H, W, 72, generator=g)
     out = torch.empty(n, C)
     ws = torch.empty(n * C * 64)
@@ -107,9 +108,10 @@ def test_maxpool2x2_with_zero_padding_of_odd_sizes(sim, hw):
     assert torch.equal(out.permute(0, 3, 1, 2), want)
 
 
-def test_upsample2x_add(sim):
+@pytest.mark.parametrize('C', [16, 10])          # 16: the 16-byte kernel; 10: scalar
+def test_upsample2x_add(sim, C):
     g = torch.Generator().manual_seed(5)
-    n, C, H, W = 2, 16, 5, 7
+    n, H, W = 2, 5, 7
     x = torch.randn(n, C, H, W, generator=g)
     skip = torch.randn(n, C, 2 * H, 2 * W, generator=g)
     shift = torch.randn(C, generator=g)
