@@ -165,19 +165,34 @@ __global__ void k_rank_columns(const float* __restrict__ geometry, int n_fc, int
     const long long fd = col / W;                          // (frame*camera)*D + d
     const long long base = fd * H * W + w;                 // point index of (.., h = 0, w)
     int ra = -1, rb = -1, rc = -1, s1 = H, s2 = H, runs = 0, prev = 0, mask = 0;
-    for (int h = 0; h < H; ++h) {
-        const long long pt = base + static_cast<long long>(h) * W;
-        const float* g = geometry + 3 * pt;
-        const int r = voxel_rank(g[0], g[1], g[2], p, nullptr);
-        rank[pt] = r;
-        if (h == 0 || r != prev) {
-            if (runs == 0) ra = r;
-            else if (runs == 1) { rb = r; s1 = h; }
-            else if (runs == 2) { rc = r; s2 = h; }
-            ++runs;
+    // eight rows at a time: their 24 coordinate loads are independent and all in flight before the run bookkeeping,
+    // which is the only sequential part
+    constexpr int kRows = 8;
+    for (int h0 = 0; h0 < H; h0 += kRows) {
+        float gx[kRows], gy[kRows], gz[kRows];
+#pragma unroll
+        for (int j = 0; j < kRows; ++j) {
+            const int h = h0 + j < H ? h0 + j : H - 1;                 // clamp: rows past the end re-read the last one
+            const float* g = geometry + 3 * (base + static_cast<long long>(h) * W);
+            gx[j] = g[0];
+            gy[j] = g[1];
+            gz[j] = g[2];
         }
-        prev = r;
-        if (r >= 0) mask |= 1 << (r / tile_vox);
+#pragma unroll
+        for (int j = 0; j < kRows; ++j) {
+            const int h = h0 + j;
+            if (h >= H) break;
+            const int r = voxel_rank(gx[j], gy[j], gz[j], p, nullptr);
+            rank[base + static_cast<long long>(h) * W] = r;
+            if (h == 0 || r != prev) {
+                if (runs == 0) ra = r;
+                else if (runs == 1) { rb = r; s1 = h; }
+                else if (runs == 2) { rc = r; s2 = h; }
+                ++runs;
+            }
+            prev = r;
+            if (r >= 0) mask |= 1 << (r / tile_vox);
+        }
     }
     const int general = (runs > 3 || H >= (1 << kSplitBits)) ? 1 : 0;
     coldesc[col] = make_int4(ra, rb, rc, s1 | (s2 << kSplitBits) | (general << (2 * kSplitBits)));

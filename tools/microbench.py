@@ -88,6 +88,21 @@ def bench_pool(lib, reps, frames=9, tiles=(0,)):
         out = torch.empty(frames, 64, 200, 200, device=DEV)
         us = timed(lambda: lib.voxel_pool(x, strides, geo, frames, 6, D, fh, fw, 64, grid, out=out, workspace=ws,
                                           tile_voxels=tile), reps)
+        # the same op with the caches (L2, 256 MB Infinity Cache) flushed by an unrelated 2 GB copy before every call -
+        # what the op sees inside a step
+        junk_a = torch.empty(512 * 1024 * 1024 // 4, device=DEV)
+        junk_b = torch.empty_like(junk_a)
+        cold = []
+        for _ in range(reps):
+            junk_b.copy_(junk_a)
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record()
+            lib.voxel_pool(x, strides, geo, frames, 6, D, fh, fw, 64, grid, out=out, workspace=ws, tile_voxels=tile)
+            e_.record()
+            torch.cuda.synchronize()
+            cold.append(s_.elapsed_time(e_) * 1e3)
+        del junk_a, junk_b
+        print(f'pool frames={frames} cold caches: {sum(cold) / len(cold):8.1f} us/op (min {min(cold):.1f})', flush=True)
         print(f'pool frames={frames} tile={tile or "default"}: {us:8.1f} us/op  {us / frames:6.1f} us/frame  '
               f'algorithmic {algo / 1e6:.1f} MB -> {algo / us / 1e3:7.1f} GB/s ({algo / us / 1e3 / 8000:.1%} of 8 TB/s); kept {n_kept / n_pts:.3f}',
               flush=True)
