@@ -234,6 +234,32 @@ def test_hot_path_baseline_batch3_against_live_oracle_and_fused_variant(hip):
         assert (fused[k].cpu() - v).abs().max().item() <= TOL * scale, k
 
 
+@pytest.mark.parametrize('preset', ['literature/fishing_setting.yml', 'lyft/baseline.yml', 'temporal_single_timeframe.yml',
+                                    'literature/pon_setting.yml', 'single_timeframe.yml'])
+def test_other_reference_configs_against_the_live_oracle(hip, preset):
+    """The reference's other YAML files (different grids, receptive fields, horizons, camera counts, with and without
+    the probabilistic / future branches), one sample each, every output element against the oracle on the CPU."""
+    cfg = get_preset_cfg(preset)
+    model, sd = _model(cfg)
+    n = len(cfg.IMAGE.NAMES)
+    rf, D = model.receptive_field, model.depth_channels
+    fh, fw = cfg.IMAGE.FINAL_DIM[0] // 8, cfg.IMAGE.FINAL_DIM[1] // 8
+    C = cfg.MODEL.ENCODER.OUT_CHANNELS
+    _, K, E, ego = make_inputs(1, rf + model.n_future, n, with_image=False, seed=3)
+    _, _, lifted = make_lifted_features(rf * n, C, D, (fh, fw), seed=4)
+    lifted = lifted.view(1, rf, n, C, D, fh, fw)
+    with torch.no_grad():
+        want = bev_stack.bev_hot_path(sd, cfg, lifted, K, E, ego)
+        got = model.bev_forward(lifted.to(DEV), K.to(DEV), E.to(DEV), ego.to(DEV))
+    assert set(k for k, v in want.items() if v is not None) == set(k for k, v in got.items() if v is not None)
+    for k, v in want.items():
+        if v is None:
+            continue
+        assert got[k].shape == v.shape, k
+        scale = max(1.0, v.abs().max().item())
+        assert (got[k].cpu() - v).abs().max().item() <= TOL * scale, k
+
+
 def test_graph_replay_equals_eager_and_follows_in_place_input_updates(hip):
     """`bev_forward_graph`: one hipGraphLaunch instead of ~130 launches.  The replay must give what the eager path
     gives (up to the pooling atomics' summation order), also after the resident input buffers were refreshed."""
