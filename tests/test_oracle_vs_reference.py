@@ -59,7 +59,9 @@ def test_warp_matches_reference(ref):
 
 
 @pytest.mark.parametrize('preset,B,labels', [('baseline.yml', 2, True), ('literature/static_lss_setting.yml', 1, False),
-                                             ('literature/pon_setting.yml', 1, False)])
+                                             ('literature/pon_setting.yml', 1, False), ('lyft/baseline.yml', 1, True),
+                                             ('literature/fishing_setting.yml', 1, False),
+                                             ('temporal_single_timeframe.yml', 1, False), ('single_timeframe.yml', 1, False)])
 def test_hot_path_equals_reference_forward(ref, preset, B, labels):
     from tests.golden.make_golden import run_reference_from_lifted
     cfg = tiny_cfg(preset)

@@ -27,6 +27,11 @@ def main():
         w.writerow(['kernel', 'calls', 'total_us', 'avg_us', 'percent'])
         for name, calls, total, avg, pct in rows:
             w.writerow([short(name), calls, round(total, 1), round(avg, 2), round(pct, 2)])
+        conv = [(c, t, p) for n, c, t, a, p in rows if 'k_conv_igemm' in n]
+        if conv:                                      # the five tile shapes of the one convolution kernel, together
+            calls, total = sum(c for c, _, _ in conv), sum(t for _, t, _ in conv)
+            w.writerow(['fiery::k_conv_igemm (all tile shapes)', calls, round(total, 1), round(total / calls, 2),
+                        round(sum(p for _, _, p in conv), 2)])
     print(f'wrote {out} ({len(rows)} kernels)')
 
 
