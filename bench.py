@@ -48,6 +48,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='enqueue every launch from the host each step instead of '
                                                             'replaying the captured hipGraph')
+    ap.add_argument('--no-sample-streams', action='store_true', help='one stream for the whole batch instead of one '
+                                                                      'independent chain (HIP stream) per sample')
     ap.add_argument('--fused', action='store_true', help='feed depth logits + features to the fused lift-splat kernel '
                                                          'instead of the materialised outer product')
     return ap.parse_args()
@@ -100,6 +102,7 @@ def main():
     from tests.helpers import randomise_weights
     sd = randomise_weights(model)                          # random-init weights, non-trivial BN statistics
     model = model.to(dev)
+    model.sample_streams = not args.no_sample_streams
 
     B, rf, nf = args.batch, model.receptive_field, model.n_future
     n_cam = len(cfg.IMAGE.NAMES)
@@ -167,11 +170,17 @@ def main():
             step()                                         # enqueue only: how long the host needs to issue one step
         host_ms = (time.perf_counter() - t_host) * 1e3
         torch.cuda.synchronize()
+        # The kernel rooflines are per-kernel figures: they are taken with the whole batch on ONE stream, where a launch
+        # has the GPU to itself (with a chain per sample three kernels share the CUs and every bracket stretches).
+        streams_on, model.sample_streams = model.sample_streams, False
         with torch.no_grad():
+            eager_step()                                   # also tunes this mode's launches, outside the brackets
+            torch.cuda.synchronize()
             eager_step()                                   # backlog: the GPU must not wait for the host during the next one
             ops.PROFILE_SINK = []
             eager_step()                                   # same kernels, launched one by one so each can be bracketed
         torch.cuda.synchronize()
+        model.sample_streams = streams_on
         recs, ops.PROFILE_SINK = ops.PROFILE_SINK, None
         conv = [(s.elapsed_time(e) * 1e-3, w) for k, s, e, w, _ in recs if k == 'conv_igemm']
         pool = [(s.elapsed_time(e) * 1e-3, w) for k, s, e, w, _ in recs if k == 'voxel_pool']
@@ -186,7 +195,9 @@ def main():
                     'traffic': pmc_traffic('k_conv_igemm (all tile shapes)'), 'launches': len(conv),
                     'avg_launch_us': round(t_conv / len(conv) * 1e6, 2),
                     'algorithmic_gflop_per_step': round(f_conv / 1e9, 1), 'kernel_ms_per_step': round(t_conv * 1e3, 3),
-                    'measured': 'HIP events around every launch, one instrumented step after the timed region'}
+                    'measured': 'HIP events around every launch of one instrumented step after the timed region, whole '
+                                'batch on one stream (`--no-sample-streams` mode)',
+                    'step_tflops': round(f_conv / (elapsed / args.steps) / 1e12, 2)}
         if pool:
             t_pool, b_pool = sum(t for t, _ in pool), sum(w for _, w in pool)
             gbs = b_pool / t_pool / 1e9
@@ -205,7 +216,7 @@ def main():
                                    f'{nf} future frames, batch {B} per GPU, fp32, '
                                    f'{"fused lift-splat from depth+features" if args.fused else "lifted features (n,C,D,h,w) resident in HBM"}',
                        'global_batch': B * world, 'parallelism': f'batch-sharded x{world}, no data-path collective',
-                       'launch': launch_mode},
+                       'launch': launch_mode + (', one stream per sample' if model.sample_streams else '')},
             'roofline': roofline, 'roofline_pooling': pooling, 'host_enqueue_ms_per_step': round(host_ms, 3),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -450,7 +450,7 @@ class BevEngine:
         return self.lib.lift_splat(prob, features.contiguous(), geometry.contiguous(), f, n, d, h, w, c, self.grid,
                                    workspace=ws, tile_voxels=self.pool_tile, flags=self.pool_flags)
 
-    def _run_distribution(self, ops, srcs, tag):
+    def _run_distribution(self, ops, srcs, tag, mu=None, log_sigma=None):
         lib = self.lib
         x = list(srcs)
         n = x[0].n_img
@@ -465,15 +465,19 @@ class BevEngine:
         ws = self.vec(tag + 'gapws', n, cd * 64)
         lib.spatial_mean(enc, enc.ld, enc.img_stride, n, 0, 1, enc.H * enc.W, cd, gap, ws)
         L = self.latent
-        mu = torch.empty(n, 1, L, dtype=torch.float32, device=self.device)
-        log_sigma = torch.empty(n, 1, L, dtype=torch.float32, device=self.device)
+        if mu is None:
+            mu = torch.empty(n, 1, L, dtype=torch.float32, device=self.device)
+        if log_sigma is None:
+            log_sigma = torch.empty(n, 1, L, dtype=torch.float32, device=self.device)
         lib.rowwise_dense(gap, gap.shape[1], n, cd, ops['w'], cd, 0, L, None, ops['b'], NONE, False, mu, L)
         lib.rowwise_dense(gap, gap.shape[1], n, cd, ops['w'][L:], cd, 0, L, None, ops['b'][L:], NONE, False, log_sigma, L,
                           lo=ops['lo'], hi=ops['hi'])
         return mu, log_sigma
 
-    def bev_stack(self, bev, future_egomotion, future_distribution_inputs=None, noise=None):
-        """Everything after pooling.  bev: (B*S, C, X, Y) NCHW; future_egomotion (B, S, 6)."""
+    def bev_stack(self, bev, future_egomotion, future_distribution_inputs=None, noise=None, into=None):
+        """Everything after pooling.  bev: (B*S, C, X, Y) NCHW; future_egomotion (B, S, 6).  `into`: optional dict of
+        preallocated output tensors (by output name) to write instead of allocating."""
+        into = into or {}
         lib, dev = self.lib, self.device
         S = self.rf
         B = bev.shape[0] // S
@@ -499,14 +503,16 @@ class BevEngine:
         # -- distributions ---------------------------------------------------------------------------
         if self.nf > 0:
             if self.probabilistic:
-                mu, log_sigma = self._run_distribution(self.present, [present], 'pd')
+                mu, log_sigma = self._run_distribution(self.present, [present], 'pd', into.get('present_mu'),
+                                                       into.get('present_log_sigma'))
                 fmu = flog = None
                 if future_distribution_inputs is not None:
                     lab = future_distribution_inputs[:, 1:].float().contiguous()
                     lc = lab.shape[1] * lab.shape[2]
                     labels = self.buf('labels', B, H, W, lc)
                     lib.nchw_to_nhwc(lab.view(B, lc, H * W), B, lc, H * W, labels.tensor, labels.ld, labels.img_stride)
-                    fmu, flog = self._run_distribution(self.future_dist, [present, labels], 'fd')
+                    fmu, flog = self._run_distribution(self.future_dist, [present, labels], 'fd', into.get('future_mu'),
+                                                       into.get('future_log_sigma'))
                 out.update(present_mu=mu, present_log_sigma=log_sigma, future_mu=fmu, future_log_sigma=flog)
                 sample = self.vec('sample', B, self.latent)
                 nz = noise.float().contiguous().view(B, self.latent) if noise is not None else None
@@ -523,7 +529,7 @@ class BevEngine:
         else:
             dec_in = present
             n_dec_t = 1
-        out.update(self._decoder(dec_in, B, n_dec_t))
+        out.update(self._decoder(dec_in, B, n_dec_t, into))
         return out
 
     def _future_prediction(self, gx, sample, present, dec_in, B):
@@ -582,7 +588,8 @@ class BevEngine:
         if not self.res_blocks[-1]:
             dec_in.nhwc().view(B, nf + 1, H, W, -1)[:, 1:].copy_(seq_in.nhwc().view(B, nf, H, W, -1))
 
-    def _decoder(self, x, B, T):
+    def _decoder(self, x, B, T, into=None):
+        into = into or {}
         lib = self.lib
         n, H, W = x.n_img, x.H, x.W
         skips = [x]
@@ -612,7 +619,8 @@ class BevEngine:
             y = o
         out = {}
         if self.heads_fused:
-            results = [torch.empty(n, hd['n_out'], H, W, dtype=torch.float32, device=self.device) for hd in self.heads_final]
+            results = [into[hd['name']].view(n, hd['n_out'], H, W) if hd['name'] in into else
+                       torch.empty(n, hd['n_out'], H, W, dtype=torch.float32, device=self.device) for hd in self.heads_final]
             planes = [(res.data_ptr() + 4 * j * H * W, hd['n_out'] * H * W)
                       for res, hd in zip(results, self.heads_final) for j in range(hd['n_out'])]
             self.heads_conv([y], HeadsOut(n, H, W, results[0]), head_planes=planes)
@@ -622,7 +630,8 @@ class BevEngine:
             hb = self.buf('dec_heads', n, H, W, self.heads_conv.cout)
             self.heads_conv([y], hb)
             for hd in self.heads_final:
-                res = torch.empty(n, hd['n_out'], H, W, dtype=torch.float32, device=self.device)
+                res = (into[hd['name']].view(n, hd['n_out'], H, W) if hd['name'] in into else
+                       torch.empty(n, hd['n_out'], H, W, dtype=torch.float32, device=self.device))
                 lib.heads_1x1_nchw(hb.slice(hd['c_off'], self.head_c), hb.ld, n, H * W, self.head_c, self.head_c,
                                    hd['w'], hd['b'], [0] * hd['n_out'], [hd['sigmoid']] * hd['n_out'], res)
                 out[hd['name']] = res.view(B, T, hd['n_out'], H, W)

@@ -103,6 +103,9 @@ class Fiery(nn.Module):
         self._engine_key = None
         self._lib = None          # tests substitute the CPU-simulated build of the same kernel sources
         self._graphs = {}         # captured hipGraphs of bev_forward, keyed on the argument buffers
+        self.sample_streams = True    # run the samples of a batch as independent chains on their own HIP streams
+        self._lanes = []          # their engines (lane 0 is the main engine) ...
+        self._lane_streams = []   # ... and streams
 
     # ------------------------------------------------------------------------------------------------
     def create_frustum(self):
@@ -145,6 +148,49 @@ class Fiery(nn.Module):
     def refresh_engine(self):
         self._engine = None
         self._graphs.clear()
+        self._lanes = []
+
+    def _lane_engines(self, n):
+        """One kernel plan (own activation buffers, own packed weights) and one stream per sample of the batch."""
+        eng = self.engine()
+        if not self._lanes or self._lanes[0] is not eng:
+            self._lanes = [eng]
+        from .engine import BevEngine
+        while len(self._lanes) < n:
+            self._lanes.append(BevEngine(self, eng.lib, eng.device))
+        while len(self._lane_streams) < n:
+            self._lane_streams.append(torch.cuda.Stream(device=eng.device))
+        return self._lanes[:n], self._lane_streams[:n]
+
+    def _bev_stack_per_sample(self, bev, ego, labels, noise):
+        """`BevEngine.bev_stack` for every sample on its own stream.  After pooling the samples of a batch never meet
+        again, and a convolution over one sample does not fill the GPU for a whole number of rounds of workgroups:
+        independent chains let the tail of one launch overlap the head of another sample's.  Results are written
+        into batch tensors allocated here, on the calling stream, which also joins the chains."""
+        eng = self.engine()
+        b, rf = ego.shape[0], self.receptive_field
+        engines, streams = self._lane_engines(b)
+        dev, T = bev.device, (eng.nf + 1 if eng.nf > 0 else 1)
+        f32 = dict(dtype=torch.float32, device=dev)
+        merged = {}
+        if eng.nf > 0 and eng.probabilistic:
+            merged['present_mu'] = torch.empty(b, 1, eng.latent, **f32)
+            merged['present_log_sigma'] = torch.empty(b, 1, eng.latent, **f32)
+            merged['future_mu'] = torch.empty(b, 1, eng.latent, **f32) if labels is not None else None
+            merged['future_log_sigma'] = torch.empty(b, 1, eng.latent, **f32) if labels is not None else None
+        for hd in eng.heads_final:
+            merged[hd['name']] = torch.empty(b, T, hd['n_out'], eng.X, eng.Y, **f32)
+        merged.setdefault('instance_flow', None)
+        cur = torch.cuda.current_stream(dev)
+        for i, (lane, stream) in enumerate(zip(engines, streams)):
+            stream.wait_stream(cur)
+            with torch.cuda.stream(stream):
+                lane.bev_stack(bev[i * rf:(i + 1) * rf], ego[i:i + 1], None if labels is None else labels[i:i + 1],
+                               None if noise is None else noise[i:i + 1],
+                               into={k: v[i:i + 1] for k, v in merged.items() if v is not None})
+        for stream in streams:
+            cur.wait_stream(stream)
+        return merged
 
     def _require_eval(self):
         if self.training:
@@ -242,6 +288,8 @@ class Fiery(nn.Module):
             dl = depth_logits[:, :rf].reshape(b * rf, n, *depth_logits.shape[3:])
             ft = features[:, :rf].reshape(b * rf, n, *features.shape[3:])
             bev = eng.pool_fused(dl, ft, geometry)
+        if self.sample_streams and b > 1 and bev.is_cuda:
+            return self._bev_stack_per_sample(bev, ego, future_distribution_inputs, noise)
         return eng.bev_stack(bev, ego, future_distribution_inputs, noise)
 
     def bev_forward_graph(self, lifted, intrinsics, extrinsics, future_egomotion, future_distribution_inputs=None,
@@ -258,7 +306,7 @@ class Fiery(nn.Module):
                     future_distribution_inputs=future_distribution_inputs, noise=noise, depth_logits=depth_logits,
                     features=features)
         eng = self.engine()
-        key = (id(eng),) + tuple(
+        key = (id(eng), self.sample_streams) + tuple(
             (k,) if v is None else (k, v.data_ptr(), tuple(v.shape), tuple(v.stride()), v.dtype) for k, v in args.items())
         entry = self._graphs.get(key)
         if entry is None:

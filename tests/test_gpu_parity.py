@@ -291,6 +291,34 @@ def test_graph_replay_equals_eager_and_follows_in_place_input_updates(hip):
         assert (changed['segmentation'] - eager['segmentation']).abs().max().item() > 1e-3
 
 
+def test_per_sample_streams_give_the_batched_result(hip):
+    """`model.sample_streams`: the samples of a batch as independent chains on their own HIP streams (eager and
+    captured) - same numbers as the one-stream batched pass."""
+    cfg = tiny_cfg('baseline.yml')
+    model, sd = _model(cfg)
+    lifted, K, E, ego, lab, noise = forward_case(cfg, model.receptive_field, model.n_future, model.depth_channels,
+                                                 model.bev_size, 3, 2, True, True)
+    args = [t.to(DEV) for t in (lifted, K, E, ego, lab, noise)]
+    with torch.no_grad():
+        model.sample_streams = False
+        batched = {k: None if v is None else v.clone() for k, v in model.bev_forward(*args).items()}
+        model.sample_streams = True
+        lanes = model.bev_forward(*args)
+        torch.cuda.synchronize()
+        assert list(lanes) == list(batched)
+        for k, v in batched.items():
+            if v is None:
+                assert lanes[k] is None
+                continue
+            assert lanes[k].shape == v.shape, k
+            assert (lanes[k] - v).abs().max().item() <= 1e-5 * max(1.0, v.abs().max().item()), k
+        replay = model.bev_forward_graph(*args)
+        torch.cuda.synchronize()
+        for k, v in batched.items():
+            if v is not None:
+                assert (replay[k] - v).abs().max().item() <= 1e-5 * max(1.0, v.abs().max().item()), k
+
+
 def test_method_seams_keep_the_reference_signatures(hip):
     cfg = tiny_cfg('baseline.yml')
     model, sd = _model(cfg)
