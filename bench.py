@@ -82,12 +82,13 @@ def cpu_baseline(cfg, sd, lifted, K, E, ego, runs=2):
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    use_dist = world > 1 or os.environ.get('FIERY_BENCH_FORCE_DIST') == '1'     # (the env var: 1-rank RCCL dry run)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=dev)     # RCCL over xGMI
 
@@ -138,7 +139,7 @@ def main():
             launch_mode = f'host enqueue per launch (graph capture failed: {repr(e)[:160]})'
 
     def barrier():
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -152,7 +153,7 @@ def main():
             out = step()
         barrier()
         elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -223,7 +224,7 @@ def main():
             line['cpu_baseline'] = cpu_baseline(cfg, sd, lifted, K, E, ego)
             line['speedup_vs_cpu_baseline'] = round(line['value'] / line['cpu_baseline']['value'], 1)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.destroy_process_group()
 
