@@ -71,6 +71,7 @@ struct ConvP {
     int vec_epilogue;     // destinations / residual / bias rows are 16-byte addressable
     int bias_border;      // img_bias holds nine rows per image, chosen by the output pixel's border class
     HeadsP heads;         // FIERY_EPI_HEADS
+    unsigned long long* clk;   // tuning aid (FIERY_CONV_CLKPROBE): {sum of shader cycles, sum of 100 MHz ticks} of sampled workgroups
 };
 
 __device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -78,7 +79,7 @@ __device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(
 // BM output pixels x BN couts per workgroup: (128, 32|64|128) and (64, 64|128).  The 64-pixel tiles exist for
 // launches whose 128-pixel tile count would leave a badly filled last wave of workgroups.
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
+__device__ __forceinline__ void conv_tile(ConvP& p) {
     constexpr int NA = BM / 32;            // A-gather loads (16 B each) per thread and stage
     constexpr int WN = BN >= 64 ? 2 : 1;   // wavefronts along couts
     constexpr int WM = 4 / WN;             // wavefronts along pixels
@@ -582,6 +583,28 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     }
 }
 
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
+    conv_tile<BM, BN>(p);
+}
+
+// tuning aid (FIERY_CONV_CLKPROBE): the same tile body, bracketed by the shader-cycle and the 100 MHz counters in every
+// 16th workgroup - effective shader clock under this kernel's load = cycles / ticks * 100 MHz
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void k_conv_igemm_clk(ConvP p) {
+    const bool sampled = threadIdx.x == 0 && (blockIdx.x & 15) == 0;
+    unsigned long long c0 = 0, w0 = 0;
+    if (sampled) {
+        c0 = clock64();
+        w0 = wall_clock64();
+    }
+    conv_tile<BM, BN>(p);
+    if (sampled) {
+        atomicAdd(p.clk, static_cast<unsigned long long>(clock64() - c0));
+        atomicAdd(p.clk + 1, static_cast<unsigned long long>(wall_clock64() - w0));
+    }
+}
+
 // ---- weight packing ------------------------------------------------------------------------------
 struct ChanInverse {
     short ci[kMaxCinUnits * 8];   // padded channel position -> logical input channel, -1 = padding
@@ -783,6 +806,8 @@ extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) {
                       (!d->weights2 || (aligned16(d->scale2) && aligned16(d->shift2))))
                          ? 1 : 0;
     if (const char* forced = getenv("FIERY_CONV_VEC_EPILOGUE")) p.vec_epilogue = p.vec_epilogue && atoi(forced) != 0;
+    p.clk = nullptr;
+    if (const char* probe = getenv("FIERY_CONV_CLKPROBE")) p.clk = reinterpret_cast<unsigned long long*>(strtoull(probe, nullptr, 0));
     p.w2 = d->weights2;
     p.scale2 = d->scale2;
     p.shift2 = d->shift2;
@@ -816,16 +841,22 @@ extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) {
     }
     dim3 grid(ceil_div(p.M, half_tiles ? 64 : 128), n_tiles);
     hipStream_t hs = as_stream(stream);
+#define FIERY_CONV_LAUNCH(BM_, BN_)                                                                    \
+    do {                                                                                               \
+        if (p.clk) hipLaunchKernelGGL((k_conv_igemm_clk<BM_, BN_>), grid, dim3(256), 0, hs, p);        \
+        else hipLaunchKernelGGL((k_conv_igemm<BM_, BN_>), grid, dim3(256), 0, hs, p);                  \
+    } while (0)
     if (half_tiles) {
-        if (bn == 128) hipLaunchKernelGGL((k_conv_igemm<64, 128>), grid, dim3(256), 0, hs, p);
-        else hipLaunchKernelGGL((k_conv_igemm<64, 64>), grid, dim3(256), 0, hs, p);
+        if (bn == 128) FIERY_CONV_LAUNCH(64, 128);
+        else FIERY_CONV_LAUNCH(64, 64);
     } else if (bn == 128) {
-        hipLaunchKernelGGL((k_conv_igemm<128, 128>), grid, dim3(256), 0, hs, p);
+        FIERY_CONV_LAUNCH(128, 128);
     } else if (bn == 64) {
-        hipLaunchKernelGGL((k_conv_igemm<128, 64>), grid, dim3(256), 0, hs, p);
+        FIERY_CONV_LAUNCH(128, 64);
     } else {
-        hipLaunchKernelGGL((k_conv_igemm<128, 32>), grid, dim3(256), 0, hs, p);
+        FIERY_CONV_LAUNCH(128, 32);
     }
+#undef FIERY_CONV_LAUNCH
     return check_launch("conv_fwd");
 }
 

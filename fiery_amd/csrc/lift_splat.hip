@@ -335,14 +335,41 @@ __global__ __launch_bounds__(kFused ? 512 : 1024) void k_voxel_pool(
     const float* __restrict__ depth, const float* __restrict__ feat,   // fused: depth prob + features
     const int* __restrict__ rank, const int4* __restrict__ coldesc, const int* __restrict__ lists,
     const int* __restrict__ counts, float* __restrict__ out, int n_cam, int D, int H, int W, int C, int n_vox,
-    int tile_vox, int n_tiles) {
+    int tile_vox, int n_tiles, int n_frames, int balanced) {
     using cell_t = typename Cell<kFixed>::type;
     HIP_DYNAMIC_SHARED(unsigned char, pool_lds)
     cell_t* plane = reinterpret_cast<cell_t*>(pool_lds);
-    // unit = (tile, channel, frame), tile fastest
-    const int tile = blockIdx.x % n_tiles;
-    const int c = (blockIdx.x / n_tiles) % C;
-    const int f = blockIdx.x / (n_tiles * C);
+    // unit = (tile, channel, frame).  Workgroup b is dispatched to XCD b % 8, in index order, and the length of a
+    // tile's list depends on where the tile lies (the strips next to the ego vehicle hold three times the points of
+    // the far ones), so the order decides the balance: the channel runs fastest - every XCD then sees the same mix of
+    // tiles - and the tiles of all frames follow from the longest list to the shortest, so that the short units fill
+    // the tail of the launch (longest-processing-time-first on the hardware's own greedy dispatcher).
+    int tile, c, f;
+    if (balanced) {
+        c = blockIdx.x % C;
+        const int rest = blockIdx.x / C;
+        f = rest % n_frames;
+        const int place = rest / n_frames;               // 0 = the frame's longest list
+        int* sel = reinterpret_cast<int*>(pool_lds);
+        if (static_cast<int>(threadIdx.x) < n_tiles) {
+            const int* cf = counts + 2 * f * n_tiles;
+            const int t = threadIdx.x;
+            const int wt = cf[2 * t] + 4 * cf[2 * t + 1];      // a row-by-row item costs a few register-path items
+            int before = 0;
+            for (int u = 0; u < n_tiles; ++u) {
+                const int wu = cf[2 * u] + 4 * cf[2 * u + 1];
+                before += (wu > wt || (wu == wt && u < t)) ? 1 : 0;
+            }
+            if (before == place) sel[0] = t;
+        }
+        __syncthreads();
+        tile = sel[0];
+        __syncthreads();                                 // everyone has read it before the plane is cleared
+    } else {
+        tile = blockIdx.x % n_tiles;
+        c = (blockIdx.x / n_tiles) % C;
+        f = blockIdx.x / (n_tiles * C);
+    }
     const int v0 = tile * tile_vox;
     const int v1 = min(v0 + tile_vox, n_vox);
     const int span = v1 - v0;
@@ -634,6 +661,8 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
     dim3 gridDim3(static_cast<unsigned>(n_units));
     int batch = fused ? 8 : 16;                 // the fused form holds two operands per row
     if (const char* forced = getenv("FIERY_POOL_BATCH")) batch = atoi(forced) == 8 ? 8 : 16;
+    int balanced = 1;                           // unit order, see k_voxel_pool
+    if (const char* forced = getenv("FIERY_POOL_ORDER")) balanced = atoi(forced) != 0;         // tuning / A-B runs
 #define FIERY_POOL_LAUNCH(VEC, BATCH, FUSED, FIXED)                                                                      \
     do {                                                                                                                 \
         if (pl.lds > 65536 &&                                                                                            \
@@ -641,7 +670,8 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pl.lds)) != hipSuccess)      \
             return fail(FIERY_ELAUNCH, "voxel_pool: cannot reserve %zu B of LDS", pl.lds);                              \
         hipLaunchKernelGGL((k_voxel_pool<VEC, BATCH, FUSED, FIXED>), gridDim3, dim3(threads), pl.lds, s, x, st, depth, feat, \
-                           rank, coldesc, lists, counts, out, n_cam, D, H, W, C, pl.n_vox, pl.tile, pl.n_tiles); \
+                           rank, coldesc, lists, counts, out, n_cam, D, H, W, C, pl.n_vox, pl.tile, pl.n_tiles, frames, \
+                           balanced);                                                                                    \
     } while (0)
 #define FIERY_POOL_DISPATCH(VEC, BATCH)                          \
     do {                                                         \

@@ -233,6 +233,8 @@ inline unsigned long long __ballot(int predicate) {
 
 // f32 MFMA 32x32x2: D = A(32x2) . B(2x32) + C, one wave.
 typedef float hipsim_v16f __attribute__((vector_size(64)));
+inline unsigned long long clock64() { return 0; }
+inline unsigned long long wall_clock64() { return 0; }
 // instruction-scheduling hints have no effect on results
 inline void __builtin_amdgcn_sched_barrier(int) {}
 inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
