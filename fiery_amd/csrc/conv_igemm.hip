@@ -24,6 +24,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <utility>
 
 namespace fiery {
 namespace {
@@ -71,15 +72,38 @@ struct ConvP {
     int vec_epilogue;     // destinations / residual / bias rows are 16-byte addressable
     int bias_border;      // img_bias holds nine rows per image, chosen by the output pixel's border class
     HeadsP heads;         // FIERY_EPI_HEADS
-    unsigned long long* clk;   // tuning aid (FIERY_CONV_CLKPROBE): {sum of shader cycles, sum of 100 MHz ticks} of sampled workgroups
 };
+// tuning aid (FIERY_CONV_CLKPROBE): {sum of shader cycles, sum of 100 MHz ticks} over the K loops of sampled workgroups;
+// a __device__ global rather than a ConvP member so that the production kernel's argument block (and with it its
+// register allocation, which is touchy) is exactly what it is without the probe
+__device__ unsigned long long* g_clk_probe = nullptr;
+// what a tap outside the image (zero padding) or past the end of K reads
+__device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};   // (not const: it must live in the global address space like the sources, or the select makes the loads flat)
 
 __device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(-v)); }
 
 // BM output pixels x BN couts per workgroup: (128, 32|64|128) and (64, 64|128).  The 64-pixel tiles exist for
 // launches whose 128-pixel tile count would leave a badly filled last wave of workgroups.
-template <int BM, int BN>
-__device__ __forceinline__ void conv_tile(ConvP& p) {
+// Workgroups of one tile shape that fit a CU, as its LDS (two A stages + two W stages) allows, capped where the tile's
+// registers would not follow: one wavefront per workgroup and SIMD, so this is also the waves-per-SIMD target that the
+// register allocation is held to (without it the compiler aims one notch too high for the 64 x 128 tile and spills).
+constexpr int conv_waves_per_simd(int bm, int bn) {
+    const int by_lds = 163840 / ((2 * bm * BK + 2 * BK * bn) * 4);
+    const int cap = (bm == 64 && bn == 64) ? 4 : 3;
+    return by_lds < cap ? by_lds : cap;
+}
+
+template <int BM, int BN, bool CLK = false, int PRIO = 0, bool SMALLCIN = false>
+__global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm(ConvP p) {
+    if constexpr (PRIO == 1) {
+        // experiment: workgroups that share a CU (dispatch order puts b and b + 256 on one CU first) get different wave
+        // priorities, so that they do not march through their MFMA and load/store phases in lockstep
+        switch ((blockIdx.x >> 8) % 3) {
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: break;
+        }
+    }
     constexpr int NA = BM / 32;            // A-gather loads (16 B each) per thread and stage
     constexpr int WN = BN >= 64 ? 2 : 1;   // wavefronts along couts
     constexpr int WM = 4 / WN;             // wavefronts along pixels
@@ -148,61 +172,105 @@ __device__ __forceinline__ void conv_tile(ConvP& p) {
         u_dx = r - u_dy * p.kW;
     }
     const float* wnext = p.w + static_cast<long long>(tile_n) * p.k_chunks * (BK * BN) + tid * 4;
+    const float* const wfirst = wnext;
 
-    float4 areg[NA];
+    float4 areg0, areg1, areg2, areg3;          // named, like breg*: an indexed array that lives across iterations ends up in scratch
+    areg0 = areg1 = areg2 = areg3 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 breg0 = make_float4(0.f, 0.f, 0.f, 0.f), breg1 = breg0, breg2 = breg0, breg3 = breg0;   // named: an indexed array ends up in scratch
 
-    // loads stage `next` (stages are requested in order 0, 1, 2, ...)
-    auto load_stage = [&]() {
-        const bool uvalid = u_tap < taps;
-        const bool second = u_cc >= p.src[0].units;
-        const float* base = second ? p.src[1].ptr : p.src[0].ptr;
-        const int ld = second ? p.src[1].ld : p.src[0].ld;
-        const int tstride = static_cast<int>(second ? p.src[1].tstride : p.src[0].tstride);
-        const int tap_off = u_dt * tstride + (u_dy * p.Win + u_dx) * ld + (u_cc - (second ? p.src[0].units : 0)) * 8 + (f4 & 1) * 4;
-#pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const int iy = py0[j] + u_dy, ix = px0[j] + u_dx;
-            const bool ok = uvalid && pvalid[j] && static_cast<unsigned>(iy) < static_cast<unsigned>(p.Hin) &&
-                            static_cast<unsigned>(ix) < static_cast<unsigned>(p.Win) && (ptmin[j] + u_dt) >= 0;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) v = *reinterpret_cast<const float4*>(base + ((second ? poff1[j] : poff0[j]) + tap_off));
-            areg[j] = v;
-        }
-        breg0 = *reinterpret_cast<const float4*>(wnext);
-        if (BLOADS > 1) breg1 = *reinterpret_cast<const float4*>(wnext + 256 * 4);
-        if (BLOADS > 2) {
-            breg2 = *reinterpret_cast<const float4*>(wnext + 512 * 4);
-            breg3 = *reinterpret_cast<const float4*>(wnext + 768 * 4);
-        }
+    // ---- the side work of a stage, cut into pieces that fit between two MFMAs ---------------------------------------
+    // (a) writing stage s+1 from the registers to LDS: one 16-byte store per piece;
+    // (b) requesting stage s+2: one piece per 16-byte global load (bounds, address, load).  Straight-line code: a tap that
+    //     falls outside the image (or a stage past the last one) reads the 16-byte zero page instead of being branched
+    //     around, so the whole K-loop body is one basic block;
+    // (c) advancing this thread's (tap, channel-unit) by one stage.
+    int ld_stage = 0;
+    const float* const zero_page = g_zero_page;
+    bool ld_valid = false, ld_second = false;
+    const float* ld_base = nullptr;
+    int ld_tap_off = 0;
+    // the two sources' fields as scalars (selecting between p.src[0].x and p.src[1].x directly turns into a dynamic
+    // index into the argument block, which then has to live in scratch)
+    const int c_Win = p.Win, c_Hin = p.Hin, c_cin_units = p.cin_units, c_kW = p.kW, c_kH = p.kH, c_k_chunks = p.k_chunks;
+    const float* const src0_ptr = p.src[0].ptr;
+    const float* const src1_ptr = p.src[1].ptr;
+    const int src0_ld = p.src[0].ld, src1_ld = p.src[1].ld, src0_units = p.src[0].units;
+    const int src0_ts = static_cast<int>(p.src[0].tstride), src1_ts = static_cast<int>(p.src[1].tstride);
+    auto load_setup = [&]() {
+        ld_valid = u_tap < taps;
+        ld_second = u_cc >= src0_units;
+        ld_base = ld_second ? src1_ptr : src0_ptr;
+        const int ld = ld_second ? src1_ld : src0_ld;
+        const int tstride = ld_second ? src1_ts : src0_ts;
+        ld_tap_off = u_dt * tstride + (u_dy * c_Win + u_dx) * ld + (u_cc - (ld_second ? src0_units : 0)) * 8 + (f4 & 1) * 4;
+    };
+    auto gather = [&](int j) {
+        const int iy = py0[j] + u_dy, ix = px0[j] + u_dx;
+        // (bitwise &: a short-circuit && would come back as a branch around the rest)
+        const bool ok = ld_valid & pvalid[j] & (static_cast<unsigned>(iy) < static_cast<unsigned>(c_Hin)) &
+                        (static_cast<unsigned>(ix) < static_cast<unsigned>(c_Win)) & ((ptmin[j] + u_dt) >= 0);
+        const float* src = ok ? ld_base + ((ld_second ? poff1[j] : poff0[j]) + ld_tap_off) : zero_page;
+        return *reinterpret_cast<const float4*>(src);
+    };
+    auto load_a = [&](int j) {
+        if (j == 0) areg0 = gather(0);
+        else if (j == 1) areg1 = gather(1);
+        else if (j == 2) areg2 = gather(2);
+        else areg3 = gather(3);
+    };
+    auto load_b = [&](int k) {
+        const float* wsrc = ld_stage < c_k_chunks ? wnext : wfirst;      // past the end: any valid address
+        if (k == 0) breg0 = *reinterpret_cast<const float4*>(wsrc);
+        else if (k == 1) breg1 = *reinterpret_cast<const float4*>(wsrc + 256 * 4);
+        else if (k == 2) breg2 = *reinterpret_cast<const float4*>(wsrc + 512 * 4);
+        else breg3 = *reinterpret_cast<const float4*>(wsrc + 768 * 4);
+    };
+    auto advance = [&]() {
         wnext += BK * BN;
-        // advance the unit by one stage (4 units), carrying into the tap and its (dt, dy, dx)
-        u_cc += 4;
-        while (u_cc >= p.cin_units) {
-            u_cc -= p.cin_units;
-            ++u_tap;
-            if (++u_dx == p.kW) {
-                u_dx = 0;
-                if (++u_dy == p.kH) {
-                    u_dy = 0;
-                    ++u_dt;
+        ++ld_stage;
+        u_cc += 4;                                        // one stage = 4 units, carrying into the tap and its (dt, dy, dx)
+        if constexpr (SMALLCIN) {
+            while (u_cc >= c_cin_units) {                 // fewer than four units per tap: several carries per stage
+                u_cc -= c_cin_units;
+                ++u_tap;
+                if (++u_dx == c_kW) {
+                    u_dx = 0;
+                    if (++u_dy == c_kH) {
+                        u_dy = 0;
+                        ++u_dt;
+                    }
                 }
             }
+        } else {                                          // cin_units >= 4: at most one carry, as selects
+            const bool carry = u_cc >= c_cin_units;
+            u_cc -= carry ? c_cin_units : 0;
+            u_tap += carry ? 1 : 0;
+            u_dx += carry ? 1 : 0;
+            const bool cx = u_dx == c_kW;
+            u_dx = cx ? 0 : u_dx;
+            u_dy += cx ? 1 : 0;
+            const bool cy = u_dy == c_kH;
+            u_dy = cy ? 0 : u_dy;
+            u_dt += cy ? 1 : 0;
         }
     };
-    auto store_stage = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const int pl = prow + 32 * j;
-            const int slot = f4 ^ ((pl >> 1) & 7);
-            *reinterpret_cast<float4*>(&As[buf][pl * BK + slot * 4]) = areg[j];
-        }
-        *reinterpret_cast<float4*>(&Bs[buf][tid * 4]) = breg0;
-        if (BLOADS > 1) *reinterpret_cast<float4*>(&Bs[buf][(tid + 256) * 4]) = breg1;
-        if (BLOADS > 2) {
-            *reinterpret_cast<float4*>(&Bs[buf][(tid + 512) * 4]) = breg2;
-            *reinterpret_cast<float4*>(&Bs[buf][(tid + 768) * 4]) = breg3;
-        }
+    auto store_a = [&](int buf, int j) {
+        const int pl = prow + 32 * j;
+        const int slot = f4 ^ ((pl >> 1) & 7);
+        *reinterpret_cast<float4*>(&As[buf][pl * BK + slot * 4]) = j == 0 ? areg0 : j == 1 ? areg1 : j == 2 ? areg2 : areg3;
+    };
+    auto store_b = [&](int buf, int k) {
+        *reinterpret_cast<float4*>(&Bs[buf][(tid + 256 * k) * 4]) = k == 0 ? breg0 : k == 1 ? breg1 : k == 2 ? breg2 : breg3;
+    };
+    // piece i of a stage's side work, i = 0 .. N_PIECES-1
+    constexpr int N_PIECES = 2 * (NA + BLOADS) + 2;
+    auto side_piece = [&](int buf, int i) {
+        if (i < NA) store_a(buf ^ 1, i);
+        else if (i < NA + BLOADS) store_b(buf ^ 1, i - NA);
+        else if (i == NA + BLOADS) load_setup();
+        else if (i < 2 * NA + BLOADS + 1) load_a(i - (NA + BLOADS + 1));
+        else if (i < 2 * NA + 2 * BLOADS + 1) load_b(i - (2 * NA + BLOADS + 1));
+        else advance();
     };
 
     auto lds_a = [&](int buf, int q, int t) {
@@ -220,15 +288,30 @@ __device__ __forceinline__ void conv_tile(ConvP& p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    load_stage();
-    store_stage(0);
+    unsigned long long clk_c0 = 0, clk_w0 = 0;
+    if constexpr (CLK) {
+        if (tid == 0 && (blockIdx.x & 15) == 0) {
+            clk_c0 = clock64();
+            clk_w0 = wall_clock64();
+        }
+    }
+    // ---- software pipeline ------------------------------------------------------------------------------------
+    // While stage s is multiplied out of LDS buffer s&1, stage s+1 sits in registers (requested one iteration
+    // earlier, so its latency is long gone) and is written to the other buffer, and stage s+2 is requested into
+    // the registers that frees.  None of that work has its own phase: the LDS stores, the address arithmetic, the
+    // global loads and the LDS operand reads are dealt out between the MFMAs of the running stage (one MFMA keeps
+    // the matrix pipe for 64 cycles, during which the wavefront can issue a dozen other instructions), so a
+    // wavefront's instruction stream is MFMA-bound even when it has its SIMD to itself.
+    // prologue: stage 0 -> LDS, stage 1 -> registers (it stays in flight across the barrier)
+#pragma unroll
+    for (int i = NA + BLOADS; i < N_PIECES; ++i) side_piece(1, i);
+#pragma unroll
+    for (int i = 0; i < N_PIECES; ++i) side_piece(1, i);
     __syncthreads();
 
+    constexpr int N_MFMA = 16 * MT * NT;
     for (int chunk = 0; chunk < p.k_chunks; ++chunk) {
         const int buf = chunk & 1;
-        const bool more = chunk + 1 < p.k_chunks;
-        if (more) load_stage();                   // global loads fly while the MFMAs below run
-
         // operands of k-group q+1 are read from LDS while the MFMAs of group q run (one b128 per 32x4 operand
         // block: A rows are [pixel][k], the W image is [k/4][cout][k%4])
         float4 a_cur[MT], b_cur[NT];
@@ -245,7 +328,7 @@ __device__ __forceinline__ void conv_tile(ConvP& p) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) b_nxt[nt] = lds_b(buf, q + 1, nt);
             }
-            __builtin_amdgcn_sched_barrier(0);     // keep the reads of group q+1 ahead of this group's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 // this lane's k for the step: 8q + 4hi + j, for its A element and its W element alike
@@ -256,6 +339,12 @@ __device__ __forceinline__ void conv_tile(ConvP& p) {
                     for (int t = 0; t < MT; ++t) {
                         const float av = j == 0 ? a_cur[t].x : j == 1 ? a_cur[t].y : j == 2 ? a_cur[t].z : a_cur[t].w;
                         acc[t * NT + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t * NT + nt], 0, 0, 0);
+                        // MFMA slot s of the stage is followed by the side-work pieces dealt to it (spread evenly)
+                        const int s = ((q * 4 + j) * NT + nt) * MT + t;
+#pragma unroll
+                        for (int i = 0; i < N_PIECES; ++i)
+                            if ((i * N_MFMA) / N_PIECES == s) side_piece(buf, i);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
@@ -266,9 +355,15 @@ __device__ __forceinline__ void conv_tile(ConvP& p) {
                 for (int nt = 0; nt < NT; ++nt) b_cur[nt] = b_nxt[nt];
             }
         }
-
-        if (more) store_stage(buf ^ 1);
         __syncthreads();
+    }
+    if constexpr (CLK) {
+        // effective shader clock under this kernel's load = cycles / ticks * 100 MHz
+        if (tid == 0 && (blockIdx.x & 15) == 0 && g_clk_probe) {
+            atomicAdd(g_clk_probe, static_cast<unsigned long long>(clock64() - clk_c0));
+            atomicAdd(g_clk_probe + 1, static_cast<unsigned long long>(wall_clock64() - clk_w0));
+            atomicAdd(g_clk_probe + 6, 1ull);
+        }
     }
 
     // ---- staged epilogue (plain mode): accumulators -> LDS tile [pixel][cout] -> 16-byte rows -----------------
@@ -583,28 +678,6 @@ __device__ __forceinline__ void conv_tile(ConvP& p) {
     }
 }
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
-    conv_tile<BM, BN>(p);
-}
-
-// tuning aid (FIERY_CONV_CLKPROBE): the same tile body, bracketed by the shader-cycle and the 100 MHz counters in every
-// 16th workgroup - effective shader clock under this kernel's load = cycles / ticks * 100 MHz
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void k_conv_igemm_clk(ConvP p) {
-    const bool sampled = threadIdx.x == 0 && (blockIdx.x & 15) == 0;
-    unsigned long long c0 = 0, w0 = 0;
-    if (sampled) {
-        c0 = clock64();
-        w0 = wall_clock64();
-    }
-    conv_tile<BM, BN>(p);
-    if (sampled) {
-        atomicAdd(p.clk, static_cast<unsigned long long>(clock64() - c0));
-        atomicAdd(p.clk + 1, static_cast<unsigned long long>(wall_clock64() - w0));
-    }
-}
-
 // ---- weight packing ------------------------------------------------------------------------------
 struct ChanInverse {
     short ci[kMaxCinUnits * 8];   // padded channel position -> logical input channel, -1 = padding
@@ -806,8 +879,6 @@ extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) {
                       (!d->weights2 || (aligned16(d->scale2) && aligned16(d->shift2))))
                          ? 1 : 0;
     if (const char* forced = getenv("FIERY_CONV_VEC_EPILOGUE")) p.vec_epilogue = p.vec_epilogue && atoi(forced) != 0;
-    p.clk = nullptr;
-    if (const char* probe = getenv("FIERY_CONV_CLKPROBE")) p.clk = reinterpret_cast<unsigned long long*>(strtoull(probe, nullptr, 0));
     p.w2 = d->weights2;
     p.scale2 = d->scale2;
     p.shift2 = d->shift2;
@@ -839,14 +910,29 @@ extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) {
         if (const char* forced = getenv("FIERY_CONV_TILE_M"))                                    // tuning / tests
             if (d->epi != FIERY_EPI_HEADS) half_tiles = atoi(forced) == 64;
     }
+    if (cin_units < 4 && d->epi != FIERY_EPI_HEADS) half_tiles = false;      // that variant exists for 128-pixel tiles only
     dim3 grid(ceil_div(p.M, half_tiles ? 64 : 128), n_tiles);
     hipStream_t hs = as_stream(stream);
+    unsigned long long* clk = nullptr;
+    if (const char* probe = getenv("FIERY_CONV_CLKPROBE")) {
+        clk = reinterpret_cast<unsigned long long*>(strtoull(probe, nullptr, 0));
+        if (hipMemcpyToSymbolAsync(HIP_SYMBOL(g_clk_probe), &clk, sizeof(clk), 0, hipMemcpyHostToDevice, hs) != hipSuccess)
+            return fail(FIERY_ELAUNCH, "conv_fwd: cannot set the clock probe");
+    }
+    const bool prio = getenv("FIERY_CONV_PRIO") != nullptr;                                    // tuning experiment
 #define FIERY_CONV_LAUNCH(BM_, BN_)                                                                    \
     do {                                                                                               \
-        if (p.clk) hipLaunchKernelGGL((k_conv_igemm_clk<BM_, BN_>), grid, dim3(256), 0, hs, p);        \
+        if (clk) hipLaunchKernelGGL((k_conv_igemm<BM_, BN_, true>), grid, dim3(256), 0, hs, p);        \
+        else if (prio) hipLaunchKernelGGL((k_conv_igemm<BM_, BN_, false, 1>), grid, dim3(256), 0, hs, p); \
         else hipLaunchKernelGGL((k_conv_igemm<BM_, BN_>), grid, dim3(256), 0, hs, p);                  \
     } while (0)
-    if (half_tiles) {
+    if (cin_units < 4) {
+        // fewer than four 8-channel units per tap: the variant whose unit advance may carry several times per stage
+        if (half_tiles) hipLaunchKernelGGL((k_conv_igemm<64, 128, false, 0, true>), grid, dim3(256), 0, hs, p);      // heads epilogue
+        else if (bn == 128) hipLaunchKernelGGL((k_conv_igemm<128, 128, false, 0, true>), grid, dim3(256), 0, hs, p);
+        else if (bn == 64) hipLaunchKernelGGL((k_conv_igemm<128, 64, false, 0, true>), grid, dim3(256), 0, hs, p);
+        else hipLaunchKernelGGL((k_conv_igemm<128, 32, false, 0, true>), grid, dim3(256), 0, hs, p);
+    } else if (half_tiles) {
         if (bn == 128) FIERY_CONV_LAUNCH(64, 128);
         else FIERY_CONV_LAUNCH(64, 64);
     } else if (bn == 128) {

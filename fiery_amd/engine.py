@@ -378,6 +378,8 @@ class BevEngine:
         # epilogue: the (images, 200, 200, 256) hidden tensor is never written.
         n_rows = sum(hd['n_out'] for hd in self.heads_final)
         self.heads_fused = cin == 64 and (len(heads) * cin) % 128 == 0 and n_rows <= native.MAX_HEAD_OUTPUTS
+        if os.environ.get('FIERY_HEADS_FUSED') == '0':                 # tuning / A-B runs
+            self.heads_fused = False
         if self.heads_fused:
             groups = [i for i, hd in enumerate(self.heads_final) for _ in range(hd['n_out'])]
             self.heads_conv.attach_heads(torch.cat([hd['w'] for hd in self.heads_final]),

@@ -292,7 +292,8 @@ def get():
     """The product library; raises NativeError when it has not been built."""
     global _LIB
     if _LIB is None:
-        _LIB = Lib(LIB_PATH)
+        # FIERY_HIP_LIB: another build of the same library (A/B runs of two kernel versions on one GPU box)
+        _LIB = Lib(os.environ.get('FIERY_HIP_LIB') or LIB_PATH)
     return _LIB
 
 

@@ -233,10 +233,17 @@ inline unsigned long long __ballot(int predicate) {
 
 // f32 MFMA 32x32x2: D = A(32x2) . B(2x32) + C, one wave.
 typedef float hipsim_v16f __attribute__((vector_size(64)));
+#define HIP_SYMBOL(x) (&(x))
+enum hipMemcpyKind { hipMemcpyHostToDevice = 1 };
+inline hipError_t hipMemcpyToSymbolAsync(void* symbol, const void* src, size_t n, size_t offset, hipMemcpyKind, hipStream_t) {
+    __builtin_memcpy(static_cast<char*>(symbol) + offset, src, n);
+    return hipSuccess;
+}
 inline unsigned long long clock64() { return 0; }
 inline unsigned long long wall_clock64() { return 0; }
 // instruction-scheduling hints have no effect on results
 inline void __builtin_amdgcn_sched_barrier(int) {}
+inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 
 inline hipsim_v16f __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, hipsim_v16f c, int, int, int) {

@@ -141,14 +141,15 @@ def bench_conv(lib, reps):
         flops = 2.0 * n * ho * wo * cin * k * k * cout
         clk = ''
         if '--clk' in sys.argv:                  # effective shader clock under this launch (instrumented kernel variant)
-            probe = torch.zeros(2, dtype=torch.int64, device=DEV)
+            probe = torch.zeros(8, dtype=torch.int64, device=DEV)
             os.environ['FIERY_CONV_CLKPROBE'] = hex(probe.data_ptr())
             us_p = timed(lambda: op([x], out, res=res), reps)
             del os.environ['FIERY_CONV_CLKPROBE']
-            cyc, ticks = (int(v) for v in probe.cpu())
+            cyc, ticks, pa, pb, pc, pd, nwg = (int(v) for v in probe.cpu()[:7])
             mhz = 100.0 * cyc / max(ticks, 1)
-            clk = (f'  | shader clock {mhz:6.0f} MHz -> peak at that clock {157.3 * mhz / 2400:6.1f} TFLOP/s, '
-                   f'{flops / us / 1e6 / (157.3 * mhz / 2400):.1%} of it (probe run {us_p:.1f} us)')
+            nwg = max(nwg, 1)
+            clk = (f'\n      shader clock {mhz:6.0f} MHz; probe run {us_p:.1f} us; per sampled workgroup (wave 0): K loop {cyc / nwg:9.0f} cycles = '
+                   f'load issue {pa / nwg:8.0f} + LDS reads/MFMA {pb / nwg:8.0f} + load wait/LDS store {pc / nwg:8.0f} + barrier {pd / nwg:8.0f}')
         print(f'conv k{k} s{stride} {cin:3d}->{cout:3d} n={n:2d} {H}x{W}: {us:8.1f} us  {flops / us / 1e6:6.1f} TFLOP/s '
               f'({flops / us / 1e6 / 157.3:.1%} of fp32 MFMA peak){clk}', flush=True)
 
