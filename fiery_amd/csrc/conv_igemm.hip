@@ -24,6 +24,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <utility>
 
 namespace fiery {
@@ -93,7 +94,7 @@ constexpr int conv_waves_per_simd(int bm, int bn) {
     return by_lds < cap ? by_lds : cap;
 }
 
-template <int BM, int BN, bool CLK = false, int PRIO = 0, bool SMALLCIN = false>
+template <int BM, int BN, bool CLK = false, int PRIO = 0, bool SMALLCIN = false, bool ALIGNED = false>
 __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm(ConvP p) {
     if constexpr (PRIO == 1) {
         // experiment: workgroups that share a CU (dispatch order puts b and b + 256 on one CU first) get different wave
@@ -159,9 +160,83 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
         poff1[j] = static_cast<int>(b * p.src[1].bstride + (tl + p.tinadd - (p.kT - 1)) * p.src[1].tstride) + pos * p.src[1].ld;
     }
     const int taps = p.kT * p.kH * p.kW;
-    // running decode of this thread's unit: u = stage*4 + (f4 >> 1) = tap * cin_units + cc
-    int u_cc, u_tap, u_dt, u_dy, u_dx;
-    {
+    const int c_Win = p.Win, c_Hin = p.Hin, c_cin_units = p.cin_units, c_kW = p.kW, c_kH = p.kH, c_k_chunks = p.k_chunks;
+    // the two sources' fields as scalars (selecting between p.src[0].x and p.src[1].x directly turns into a dynamic
+    // index into the argument block, which then has to live in scratch)
+    const float* const src0_ptr = p.src[0].ptr;
+    const float* const src1_ptr = p.src[1].ptr;
+    const int src0_ld = p.src[0].ld, src1_ld = p.src[1].ld, src0_units = p.src[0].units;
+    const int src0_ts = static_cast<int>(p.src[0].tstride), src1_ts = static_cast<int>(p.src[1].tstride);
+
+    float4 areg0, areg1, areg2, areg3;          // named, like breg*: an indexed array that lives across iterations ends up in scratch
+    areg0 = areg1 = areg2 = areg3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 breg0 = make_float4(0.f, 0.f, 0.f, 0.f), breg1 = breg0, breg2 = breg0, breg3 = breg0;
+
+    // ---- the side work of a stage, cut into pieces that go between two MFMAs ------------------------------------------
+    // Measured on gfx950 (tools/probe/mfma_valu_probe.hip): a VALU instruction issued between two fp32 MFMAs does NOT run
+    // in their shadow - it takes ~3-6 cycles of the same pipe - so the K loop is built to need as few vector ALU
+    // instructions as possible, not merely to hide them:
+    //   * ALIGNED (every tap holds a whole number of stages from one source - all the big layers): the (tap, channel
+    //     group) of a stage is the same for the whole workgroup, so it lives in SGPRs and is advanced by the scalar unit;
+    //     a thread's pixel offsets never change; the tap's offset goes into the buffer load's scalar offset; zero padding
+    //     is the buffer's out-of-range rule (an invalid tap gets an offset beyond the descriptor's size and reads 0).
+    //     Per 16-byte load that leaves one mask test and one select on the vector ALU.
+    //   * otherwise the thread's own (tap, unit) advances on the vector ALU, and an invalid tap reads the zero page.
+    // Both ways the stage body is straight-line code, and the LDS addresses of a stage are thread constants plus
+    // immediates because the two buffers are two copies of the body.
+    constexpr int N_PIECES = 2 * (NA + BLOADS) + 2;
+    //   generic path state
+    int u_cc = 0, u_tap = 0, u_dt = 0, u_dy = 0, u_dx = 0;
+    const float* wnext = p.w + static_cast<long long>(tile_n) * p.k_chunks * (BK * BN) + tid * 4;
+    const float* const wfirst = wnext;
+    int ld_stage = 0;
+    const float* const zero_page = g_zero_page;
+    bool ld_valid = false, ld_second = false;
+    const float* ld_base = nullptr;
+    int ld_tap_off = 0;
+    //   aligned path state
+    int voff0[NA], voff1[NA];                   // this thread's pixels in the two sources, bytes, >= 0
+    unsigned long long vmask[NA];               // bit t: tap t of pixel j lies inside the image (and the pixel exists)
+    int s_tap = 0, s_g = 0, s_dt = 0, s_dy = 0, s_dx = 0;      // wave-uniform
+    int s_off = 0;
+    bool s_second = false;
+    __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src0_ptr), 0, 0, 0x00020000);
+    const int s_groups = c_cin_units >> 2, s_groups0 = src0_units >> 2;
+    if constexpr (ALIGNED) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int gp = pix0 + prow + 32 * j;
+            const bool pv = gp < M;
+            const int g = pv ? gp : 0;
+            const int o = g / HWout;
+            const int rem = g - o * HWout;
+            const int y = rem / p.Wout, x = rem - y * p.Wout;
+            const int b = o / p.Tout, tl = o - b * p.Tout;
+            const int sp = (y * p.stride) * c_Win + x * p.stride;
+            const int kofs = (f4 >> 1) * 8 + (f4 & 1) * 4;
+            voff0[j] = 4 * (static_cast<int>(b * p.src[0].bstride + (tl + p.tinadd) * p.src[0].tstride) + sp * src0_ld + kofs);
+            voff1[j] = 4 * (static_cast<int>(b * p.src[1].bstride + (tl + p.tinadd) * p.src[1].tstride) + sp * src1_ld + kofs);
+            unsigned rowm = 0, colm = 0, tm = 0;
+            for (int dy = 0; dy < c_kH; ++dy)
+                rowm |= (static_cast<unsigned>(y * p.stride - p.padH + dy) < static_cast<unsigned>(c_Hin) ? 1u : 0u) << dy;
+            for (int dx = 0; dx < c_kW; ++dx)
+                colm |= (static_cast<unsigned>(x * p.stride - p.padW + dx) < static_cast<unsigned>(c_Win) ? 1u : 0u) << dx;
+            for (int dt = 0; dt < p.kT; ++dt) tm |= ((tl + p.tout0 - (p.kT - 1) + dt) >= 0 ? 1u : 0u) << dt;
+            unsigned long long mk = 0;
+            int tap = 0;
+            for (int dt = 0; dt < p.kT; ++dt)
+                for (int dy = 0; dy < c_kH; ++dy)
+                    for (int dx = 0; dx < c_kW; ++dx, ++tap)
+                        mk |= static_cast<unsigned long long>((tm >> dt) & (rowm >> dy) & (colm >> dx) & 1u) << tap;
+            vmask[j] = pv ? mk : 0ull;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            voff0[j] = voff1[j] = 0;
+            vmask[j] = 0;
+        }
+        // running decode of this thread's unit: u = stage*4 + (f4 >> 1) = tap * cin_units + cc
         const int u = f4 >> 1;
         u_tap = u / p.cin_units;
         u_cc = u - u_tap * p.cin_units;
@@ -171,99 +246,136 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
         u_dy = r / p.kW;
         u_dx = r - u_dy * p.kW;
     }
-    const float* wnext = p.w + static_cast<long long>(tile_n) * p.k_chunks * (BK * BN) + tid * 4;
-    const float* const wfirst = wnext;
+    // weights: one descriptor for this cout tile's packed image; thread t reads bytes [16 t, 16 t + 16) of every 4 KiB
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.w + static_cast<long long>(tile_n) * p.k_chunks * (BK * BN)), 0, 0x7fffffff, 0x00020000);
+    const int w_voff = tid * 16;
+    int w_soff = 0;
+    auto to_float4 = [](auto raw) {
+        float4 f;
+        __builtin_memcpy(&f, &raw, 16);
+        return f;
+    };
 
-    float4 areg0, areg1, areg2, areg3;          // named, like breg*: an indexed array that lives across iterations ends up in scratch
-    areg0 = areg1 = areg2 = areg3 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 breg0 = make_float4(0.f, 0.f, 0.f, 0.f), breg1 = breg0, breg2 = breg0, breg3 = breg0;   // named: an indexed array ends up in scratch
-
-    // ---- the side work of a stage, cut into pieces that fit between two MFMAs ---------------------------------------
-    // (a) writing stage s+1 from the registers to LDS: one 16-byte store per piece;
-    // (b) requesting stage s+2: one piece per 16-byte global load (bounds, address, load).  Straight-line code: a tap that
-    //     falls outside the image (or a stage past the last one) reads the 16-byte zero page instead of being branched
-    //     around, so the whole K-loop body is one basic block;
-    // (c) advancing this thread's (tap, channel-unit) by one stage.
-    int ld_stage = 0;
-    const float* const zero_page = g_zero_page;
-    bool ld_valid = false, ld_second = false;
-    const float* ld_base = nullptr;
-    int ld_tap_off = 0;
-    // the two sources' fields as scalars (selecting between p.src[0].x and p.src[1].x directly turns into a dynamic
-    // index into the argument block, which then has to live in scratch)
-    const int c_Win = p.Win, c_Hin = p.Hin, c_cin_units = p.cin_units, c_kW = p.kW, c_kH = p.kH, c_k_chunks = p.k_chunks;
-    const float* const src0_ptr = p.src[0].ptr;
-    const float* const src1_ptr = p.src[1].ptr;
-    const int src0_ld = p.src[0].ld, src1_ld = p.src[1].ld, src0_units = p.src[0].units;
-    const int src0_ts = static_cast<int>(p.src[0].tstride), src1_ts = static_cast<int>(p.src[1].tstride);
     auto load_setup = [&]() {
-        ld_valid = u_tap < taps;
-        ld_second = u_cc >= src0_units;
-        ld_base = ld_second ? src1_ptr : src0_ptr;
-        const int ld = ld_second ? src1_ld : src0_ld;
-        const int tstride = ld_second ? src1_ts : src0_ts;
-        ld_tap_off = u_dt * tstride + (u_dy * c_Win + u_dx) * ld + (u_cc - (ld_second ? src0_units : 0)) * 8 + (f4 & 1) * 4;
+        if constexpr (ALIGNED) {
+            s_second = s_g >= s_groups0;
+            const float* base = s_second ? src1_ptr : src0_ptr;
+            const int ld = s_second ? src1_ld : src0_ld;
+            const int ts = s_second ? src1_ts : src0_ts;
+            // the descriptor's base sits (kT-1) frames and (padH, padW) pixels before the source, so that the
+            // tap's offset below is never negative; its size only has to exceed every real offset
+            base -= (p.kT - 1) * ts + (p.padH * c_Win + p.padW) * ld;
+            s_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+            s_off = 4 * (s_dt * ts + (s_dy * c_Win + s_dx) * ld + (s_g - (s_second ? s_groups0 : 0)) * 32);
+            w_soff = (ld_stage < c_k_chunks ? ld_stage : c_k_chunks - 1) * (BK * BN * 4);      // past the end: repeat
+        } else {
+            ld_valid = u_tap < taps;
+            ld_second = u_cc >= src0_units;
+            ld_base = ld_second ? src1_ptr : src0_ptr;
+            const int ld = ld_second ? src1_ld : src0_ld;
+            const int tstride = ld_second ? src1_ts : src0_ts;
+            ld_tap_off = u_dt * tstride + (u_dy * c_Win + u_dx) * ld + (u_cc - (ld_second ? src0_units : 0)) * 8 + (f4 & 1) * 4;
+        }
     };
     auto gather = [&](int j) {
-        const int iy = py0[j] + u_dy, ix = px0[j] + u_dx;
-        // (bitwise &: a short-circuit && would come back as a branch around the rest)
-        const bool ok = ld_valid & pvalid[j] & (static_cast<unsigned>(iy) < static_cast<unsigned>(c_Hin)) &
-                        (static_cast<unsigned>(ix) < static_cast<unsigned>(c_Win)) & ((ptmin[j] + u_dt) >= 0);
-        const float* src = ok ? ld_base + ((ld_second ? poff1[j] : poff0[j]) + ld_tap_off) : zero_page;
-        return *reinterpret_cast<const float4*>(src);
+        if constexpr (ALIGNED) {
+            const bool ok = ((vmask[j] >> (s_tap < 63 ? s_tap : 63)) & 1ull) != 0;
+            int voff = s_second ? voff1[j] : voff0[j];
+            voff = ok ? voff : static_cast<int>(0x80000000u);               // beyond the descriptor: reads as zero
+            return to_float4(__builtin_amdgcn_raw_buffer_load_b128(s_rsrc, voff, s_off, 0));
+        } else {
+            const int iy = py0[j] + u_dy, ix = px0[j] + u_dx;
+            // (bitwise &: a short-circuit && would come back as a branch around the rest)
+            const bool ok = ld_valid & pvalid[j] & (static_cast<unsigned>(iy) < static_cast<unsigned>(c_Hin)) &
+                            (static_cast<unsigned>(ix) < static_cast<unsigned>(c_Win)) & ((ptmin[j] + u_dt) >= 0);
+            const float* src = ok ? ld_base + ((ld_second ? poff1[j] : poff0[j]) + ld_tap_off) : zero_page;
+            return *reinterpret_cast<const float4*>(src);
+        }
     };
     auto load_a = [&](int j) {
         if (j == 0) areg0 = gather(0);
         else if (j == 1) areg1 = gather(1);
-        else if (j == 2) areg2 = gather(2);
-        else areg3 = gather(3);
+        else if (j == 2) areg2 = gather(NA > 2 ? 2 : 0);
+        else areg3 = gather(NA > 2 ? 3 : 0);
     };
     auto load_b = [&](int k) {
-        const float* wsrc = ld_stage < c_k_chunks ? wnext : wfirst;      // past the end: any valid address
-        if (k == 0) breg0 = *reinterpret_cast<const float4*>(wsrc);
-        else if (k == 1) breg1 = *reinterpret_cast<const float4*>(wsrc + 256 * 4);
-        else if (k == 2) breg2 = *reinterpret_cast<const float4*>(wsrc + 512 * 4);
-        else breg3 = *reinterpret_cast<const float4*>(wsrc + 768 * 4);
+        float4 v;
+        if constexpr (ALIGNED) {
+            v = to_float4(__builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff, w_soff + k * 4096, 0));
+        } else {
+            const float* wsrc = ld_stage < c_k_chunks ? wnext : wfirst;  // past the end: any valid address
+            v = *reinterpret_cast<const float4*>(wsrc + k * 1024);
+        }
+        if (k == 0) breg0 = v;
+        else if (k == 1) breg1 = v;
+        else if (k == 2) breg2 = v;
+        else breg3 = v;
     };
     auto advance = [&]() {
-        wnext += BK * BN;
         ++ld_stage;
-        u_cc += 4;                                        // one stage = 4 units, carrying into the tap and its (dt, dy, dx)
-        if constexpr (SMALLCIN) {
-            while (u_cc >= c_cin_units) {                 // fewer than four units per tap: several carries per stage
-                u_cc -= c_cin_units;
-                ++u_tap;
-                if (++u_dx == c_kW) {
-                    u_dx = 0;
-                    if (++u_dy == c_kH) {
-                        u_dy = 0;
-                        ++u_dt;
+        if constexpr (ALIGNED) {                          // all on the scalar unit
+            ++s_g;
+            const bool cg = s_g == s_groups;
+            s_g = cg ? 0 : s_g;
+            s_tap += cg ? 1 : 0;
+            s_dx += cg ? 1 : 0;
+            const bool cx = s_dx == c_kW;
+            s_dx = cx ? 0 : s_dx;
+            s_dy += cx ? 1 : 0;
+            const bool cy = s_dy == c_kH;
+            s_dy = cy ? 0 : s_dy;
+            s_dt += cy ? 1 : 0;
+        } else {
+            wnext += BK * BN;
+            u_cc += 4;                                    // one stage = 4 units, carrying into the tap and its (dt, dy, dx)
+            if constexpr (SMALLCIN) {
+                while (u_cc >= c_cin_units) {             // fewer than four units per tap: several carries per stage
+                    u_cc -= c_cin_units;
+                    ++u_tap;
+                    if (++u_dx == c_kW) {
+                        u_dx = 0;
+                        if (++u_dy == c_kH) {
+                            u_dy = 0;
+                            ++u_dt;
+                        }
                     }
                 }
+            } else {                                      // cin_units >= 4: at most one carry, as selects
+                const bool carry = u_cc >= c_cin_units;
+                u_cc -= carry ? c_cin_units : 0;
+                u_tap += carry ? 1 : 0;
+                u_dx += carry ? 1 : 0;
+                const bool cx = u_dx == c_kW;
+                u_dx = cx ? 0 : u_dx;
+                u_dy += cx ? 1 : 0;
+                const bool cy = u_dy == c_kH;
+                u_dy = cy ? 0 : u_dy;
+                u_dt += cy ? 1 : 0;
             }
-        } else {                                          // cin_units >= 4: at most one carry, as selects
-            const bool carry = u_cc >= c_cin_units;
-            u_cc -= carry ? c_cin_units : 0;
-            u_tap += carry ? 1 : 0;
-            u_dx += carry ? 1 : 0;
-            const bool cx = u_dx == c_kW;
-            u_dx = cx ? 0 : u_dx;
-            u_dy += cx ? 1 : 0;
-            const bool cy = u_dy == c_kH;
-            u_dy = cy ? 0 : u_dy;
-            u_dt += cy ? 1 : 0;
         }
     };
+    // LDS addresses: thread constants (floats from smem) + compile-time offsets
+    const int a_st = prow * BK + ((f4 ^ ((prow >> 1) & 7)) << 2);                     // + 32 j BK + buf BM BK
+    const int b_st = 2 * BM * BK + tid * 4;                                            // + 1024 k + buf BK BN
+    const int a_row = wm * (32 * MT) + m;
+    int a_rd[4];                                                                       // + 32 t BK + buf BM BK
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a_rd[q] = a_row * BK + (((2 * q + hi) ^ ((a_row >> 1) & 7)) << 2);
+    const int b_rd = 2 * BM * BK + (hi * BN + wn * (32 * NT) + m) * 4;                 // + (2 q BN + 32 nt) 4 + buf BK BN
     auto store_a = [&](int buf, int j) {
-        const int pl = prow + 32 * j;
-        const int slot = f4 ^ ((pl >> 1) & 7);
-        *reinterpret_cast<float4*>(&As[buf][pl * BK + slot * 4]) = j == 0 ? areg0 : j == 1 ? areg1 : j == 2 ? areg2 : areg3;
+        *reinterpret_cast<float4*>(&smem[a_st + 32 * j * BK + buf * BM * BK]) = j == 0 ? areg0 : j == 1 ? areg1 : j == 2 ? areg2 : areg3;
     };
     auto store_b = [&](int buf, int k) {
-        *reinterpret_cast<float4*>(&Bs[buf][(tid + 256 * k) * 4]) = k == 0 ? breg0 : k == 1 ? breg1 : k == 2 ? breg2 : breg3;
+        *reinterpret_cast<float4*>(&smem[b_st + 1024 * k + buf * BK * BN]) = k == 0 ? breg0 : k == 1 ? breg1 : k == 2 ? breg2 : breg3;
     };
-    // piece i of a stage's side work, i = 0 .. N_PIECES-1
-    constexpr int N_PIECES = 2 * (NA + BLOADS) + 2;
+    auto lds_a = [&](int buf, int q, int t) {
+        return *reinterpret_cast<const float4*>(&smem[a_rd[q] + 32 * t * BK + buf * BM * BK]);
+    };
+    auto lds_b = [&](int buf, int q, int nt) {
+        return *reinterpret_cast<const float4*>(&smem[b_rd + (2 * q * BN + 32 * nt) * 4 + buf * BK * BN]);
+    };
+    // piece i of a stage's side work, i = 0 .. N_PIECES-1; the stage running out of `buf` fills the other buffer
     auto side_piece = [&](int buf, int i) {
         if (i < NA) store_a(buf ^ 1, i);
         else if (i < NA + BLOADS) store_b(buf ^ 1, i - NA);
@@ -271,15 +383,6 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
         else if (i < 2 * NA + BLOADS + 1) load_a(i - (NA + BLOADS + 1));
         else if (i < 2 * NA + 2 * BLOADS + 1) load_b(i - (2 * NA + BLOADS + 1));
         else advance();
-    };
-
-    auto lds_a = [&](int buf, int q, int t) {
-        const int pl = wm * (32 * MT) + t * 32 + m;
-        const int slot = (2 * q + hi) ^ ((pl >> 1) & 7);
-        return *reinterpret_cast<const float4*>(&As[buf][pl * BK + slot * 4]);
-    };
-    auto lds_b = [&](int buf, int q, int nt) {
-        return *reinterpret_cast<const float4*>(&Bs[buf][((2 * q + hi) * BN + wn * (32 * NT) + nt * 32 + m) * 4]);
     };
 
     v16f acc[MT * NT];
@@ -298,11 +401,8 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
     // ---- software pipeline ------------------------------------------------------------------------------------
     // While stage s is multiplied out of LDS buffer s&1, stage s+1 sits in registers (requested one iteration
     // earlier, so its latency is long gone) and is written to the other buffer, and stage s+2 is requested into
-    // the registers that frees.  None of that work has its own phase: the LDS stores, the address arithmetic, the
-    // global loads and the LDS operand reads are dealt out between the MFMAs of the running stage (one MFMA keeps
-    // the matrix pipe for 64 cycles, during which the wavefront can issue a dozen other instructions), so a
-    // wavefront's instruction stream is MFMA-bound even when it has its SIMD to itself.
-    // prologue: stage 0 -> LDS, stage 1 -> registers (it stays in flight across the barrier)
+    // the registers that frees.  The pieces are dealt out evenly between the MFMAs of the running stage.
+    // prologue: stage 0 -> LDS buffer 0, stage 1 -> registers (it stays in flight across the barrier)
 #pragma unroll
     for (int i = NA + BLOADS; i < N_PIECES; ++i) side_piece(1, i);
 #pragma unroll
@@ -310,8 +410,8 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
     __syncthreads();
 
     constexpr int N_MFMA = 16 * MT * NT;
-    for (int chunk = 0; chunk < p.k_chunks; ++chunk) {
-        const int buf = chunk & 1;
+    auto stage_body = [&](auto buf_c) {
+        constexpr int buf = decltype(buf_c)::value;
         // operands of k-group q+1 are read from LDS while the MFMAs of group q run (one b128 per 32x4 operand
         // block: A rows are [pixel][k], the W image is [k/4][cout][k%4])
         float4 a_cur[MT], b_cur[NT];
@@ -356,6 +456,14 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
             }
         }
         __syncthreads();
+    };
+    {
+        int chunk = 0;
+        for (; chunk + 1 < c_k_chunks; chunk += 2) {
+            stage_body(std::integral_constant<int, 0>{});
+            stage_body(std::integral_constant<int, 1>{});
+        }
+        if (chunk < c_k_chunks) stage_body(std::integral_constant<int, 0>{});
     }
     if constexpr (CLK) {
         // effective shader clock under this kernel's load = cycles / ticks * 100 MHz
@@ -920,10 +1028,24 @@ extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) {
             return fail(FIERY_ELAUNCH, "conv_fwd: cannot set the clock probe");
     }
     const bool prio = getenv("FIERY_CONV_PRIO") != nullptr;                                    // tuning experiment
+    // The scalar-addressed K loop (ALIGNED): every tap must hold a whole number of 32-channel stages from one source,
+    // and each source must be addressable with non-negative 31-bit byte offsets from (a little before) its base.
+    bool aligned = cin_units % 4 == 0 && d->src[0].units % 4 == 0 && taps <= 63 && d->t_in_add >= 0;
+    for (int s = 0; s < 2 && aligned; ++s) {
+        if (d->src[s].units == 0) continue;
+        const long long n_batch = d->n_img_out / d->T_out;
+        const long long span = (n_batch - 1) * d->src[s].batch_stride +
+                               (static_cast<long long>(d->T_out) + d->kT + d->t_in_add) * d->src[s].time_stride +
+                               (static_cast<long long>(d->Hin) + d->kH) * (d->Win + d->kW) * d->src[s].ld;
+        aligned = d->src[s].batch_stride >= 0 && d->src[s].time_stride >= 0 && span < (1ll << 29);
+    }
+    if (const char* forced = getenv("FIERY_CONV_ALIGNED")) aligned = aligned && atoi(forced) != 0;       // tuning / tests
 #define FIERY_CONV_LAUNCH(BM_, BN_)                                                                    \
     do {                                                                                               \
-        if (clk) hipLaunchKernelGGL((k_conv_igemm<BM_, BN_, true>), grid, dim3(256), 0, hs, p);        \
+        if (clk && aligned) hipLaunchKernelGGL((k_conv_igemm<BM_, BN_, true, 0, false, true>), grid, dim3(256), 0, hs, p); \
+        else if (clk) hipLaunchKernelGGL((k_conv_igemm<BM_, BN_, true>), grid, dim3(256), 0, hs, p);   \
         else if (prio) hipLaunchKernelGGL((k_conv_igemm<BM_, BN_, false, 1>), grid, dim3(256), 0, hs, p); \
+        else if (aligned) hipLaunchKernelGGL((k_conv_igemm<BM_, BN_, false, 0, false, true>), grid, dim3(256), 0, hs, p); \
         else hipLaunchKernelGGL((k_conv_igemm<BM_, BN_>), grid, dim3(256), 0, hs, p);                  \
     } while (0)
     if (cin_units < 4) {

@@ -239,6 +239,19 @@ inline hipError_t hipMemcpyToSymbolAsync(void* symbol, const void* src, size_t n
     __builtin_memcpy(static_cast<char*>(symbol) + offset, src, n);
     return hipSuccess;
 }
+// raw buffer loads: a descriptor is (base, size in bytes); an offset past the size reads zeros; the scalar offset is
+// not range-checked (as on the hardware)
+struct __amdgpu_buffer_rsrc_t { const char* base; unsigned num; };
+inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, int num, int) {
+    return {static_cast<const char*>(p), static_cast<unsigned>(num)};
+}
+typedef unsigned hipsim_v4u __attribute__((vector_size(16)));
+inline hipsim_v4u __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
+    hipsim_v4u v = {0, 0, 0, 0};
+    if (static_cast<unsigned long long>(static_cast<unsigned>(voff)) + 16ull <= r.num)
+        __builtin_memcpy(&v, r.base + static_cast<unsigned>(voff) + static_cast<long long>(soff), 16);
+    return v;
+}
 inline unsigned long long clock64() { return 0; }
 inline unsigned long long wall_clock64() { return 0; }
 // instruction-scheduling hints have no effect on results
