@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
     //   * otherwise the thread's own (tap, unit) advances on the vector ALU, and an invalid tap reads the zero page.
     // Both ways the stage body is straight-line code, and the LDS addresses of a stage are thread constants plus
     // immediates because the two buffers are two copies of the body.
-    constexpr int N_PIECES = 2 * (NA + BLOADS) + 2;
+    constexpr int N_PIECES = 2 * (NA + BLOADS) + 4;
     //   generic path state
     int u_cc = 0, u_tap = 0, u_dt = 0, u_dy = 0, u_dx = 0;
     const float* wnext = p.w + static_cast<long long>(tile_n) * p.k_chunks * (BK * BN) + tid * 4;
@@ -257,19 +257,27 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
         return f;
     };
 
-    auto load_setup = [&]() {
+    // (the scalar unit issues in order with the MFMAs: the stage's scalar bookkeeping is cut in three so that no single
+    // gap between two MFMAs has to take all of it)
+    int s_ld = 0, s_ts = 0;
+    const float* s_base = nullptr;
+    auto load_setup = [&](int part) {
         if constexpr (ALIGNED) {
-            s_second = s_g >= s_groups0;
-            const float* base = s_second ? src1_ptr : src0_ptr;
-            const int ld = s_second ? src1_ld : src0_ld;
-            const int ts = s_second ? src1_ts : src0_ts;
-            // the descriptor's base sits (kT-1) frames and (padH, padW) pixels before the source, so that the
-            // tap's offset below is never negative; its size only has to exceed every real offset
-            base -= (p.kT - 1) * ts + (p.padH * c_Win + p.padW) * ld;
-            s_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
-            s_off = 4 * (s_dt * ts + (s_dy * c_Win + s_dx) * ld + (s_g - (s_second ? s_groups0 : 0)) * 32);
-            w_soff = (ld_stage < c_k_chunks ? ld_stage : c_k_chunks - 1) * (BK * BN * 4);      // past the end: repeat
-        } else {
+            if (part == 0) {
+                s_second = s_g >= s_groups0;
+                s_base = s_second ? src1_ptr : src0_ptr;
+                s_ld = s_second ? src1_ld : src0_ld;
+                s_ts = s_second ? src1_ts : src0_ts;
+                w_soff = (ld_stage < c_k_chunks ? ld_stage : c_k_chunks - 1) * (BK * BN * 4);      // past the end: repeat
+            } else if (part == 1) {
+                // the descriptor's base sits (kT-1) frames and (padH, padW) pixels before the source, so that the
+                // tap's offset below is never negative; its size only has to exceed every real offset
+                const float* base = s_base - ((p.kT - 1) * s_ts + (p.padH * c_Win + p.padW) * s_ld);
+                s_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+            } else {
+                s_off = 4 * (s_dt * s_ts + (s_dy * c_Win + s_dx) * s_ld + (s_g - (s_second ? s_groups0 : 0)) * 32);
+            }
+        } else if (part == 0) {
             ld_valid = u_tap < taps;
             ld_second = u_cc >= src0_units;
             ld_base = ld_second ? src1_ptr : src0_ptr;
@@ -377,11 +385,12 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
     };
     // piece i of a stage's side work, i = 0 .. N_PIECES-1; the stage running out of `buf` fills the other buffer
     auto side_piece = [&](int buf, int i) {
+        constexpr int S0 = NA + BLOADS;            // first setup piece
         if (i < NA) store_a(buf ^ 1, i);
-        else if (i < NA + BLOADS) store_b(buf ^ 1, i - NA);
-        else if (i == NA + BLOADS) load_setup();
-        else if (i < 2 * NA + BLOADS + 1) load_a(i - (NA + BLOADS + 1));
-        else if (i < 2 * NA + 2 * BLOADS + 1) load_b(i - (2 * NA + BLOADS + 1));
+        else if (i < S0) store_b(buf ^ 1, i - NA);
+        else if (i < S0 + 3) load_setup(i - S0);
+        else if (i < S0 + 3 + NA) load_a(i - (S0 + 3));
+        else if (i < S0 + 3 + NA + BLOADS) load_b(i - (S0 + 3 + NA));
         else advance();
     };
 

@@ -329,7 +329,12 @@ struct Merge {
 
 // kVec = 4: a work-item is four adjacent columns, every row one 16-byte load; kVec = 1: one column, any strides.
 // kBatch: rows of a work-item in flight at once.
-template <int kVec, int kBatch, bool kFused, bool kFixed>
+// tuning aid (FIERY_POOL_PROBE): shader cycles of wave 0 of every 8th workgroup, by phase:
+// {total, clear plane, load issue + wait, everything else in the item loop, merge + LDS adds, final barrier + write-out,
+//  workgroups, items}
+__device__ unsigned long long* g_pool_probe = nullptr;
+
+template <int kVec, int kBatch, bool kFused, bool kFixed, bool kProbe = false>
 __global__ __launch_bounds__(kFused ? 512 : 1024) void k_voxel_pool(
     const float* __restrict__ x, PoolStrides xs,            // unfused: the lifted tensor
     const float* __restrict__ depth, const float* __restrict__ feat,   // fused: depth prob + features
@@ -370,11 +375,14 @@ __global__ __launch_bounds__(kFused ? 512 : 1024) void k_voxel_pool(
         c = (blockIdx.x / n_tiles) % C;
         f = blockIdx.x / (n_tiles * C);
     }
+    unsigned long long pr_t0 = 0, pr_clear = 0, pr_load = 0, pr_merge = 0, pr_items = 0;
+    if constexpr (kProbe) pr_t0 = clock64();
     const int v0 = tile * tile_vox;
     const int v1 = min(v0 + tile_vox, n_vox);
     const int span = v1 - v0;
     for (int i = threadIdx.x; i < span; i += blockDim.x) plane[i] = cell_t(0);
     __syncthreads();
+    if constexpr (kProbe) pr_clear = clock64() - pr_t0;
 
     const int Wg = W / kVec;
     const int n_items = n_cam * D * Wg;
@@ -440,6 +448,8 @@ __global__ __launch_bounds__(kFused ? 512 : 1024) void k_voxel_pool(
             const int* rk = rank + ((static_cast<long long>(f) * n_cam + cam) * D + d) * HW + w;
             for (int h0 = 0; h0 < H; h0 += kBatch) {
                 float v[kBatch][kVec];
+                unsigned long long pr_a = 0;
+                if constexpr (kProbe) pr_a = clock64();
 #pragma unroll
                 for (int j = 0; j < kBatch; ++j) {
                     const bool in = h0 + j < H;
@@ -467,8 +477,14 @@ __global__ __launch_bounds__(kFused ? 512 : 1024) void k_voxel_pool(
                         }
                     }
                 }
+                if constexpr (kProbe) {
+                    __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0)
+                    pr_load += clock64() - pr_a;
+                }
                 if (!kGeneral) {
-                    // each row adds to the run it belongs to (adding 0.f to the others is exact)
+                    // each row adds to the run it belongs to (adding 0.f to the others is exact).  This block - two compares,
+                    // three selects and three adds per element - is what the kernel runs out of first: the probe
+                    // (FIERY_POOL_PROBE) shows a wavefront spending as many cycles here as waiting for its rows.
 #pragma unroll
                     for (int j = 0; j < kBatch; ++j)
 #pragma unroll
@@ -500,6 +516,11 @@ __global__ __launch_bounds__(kFused ? 512 : 1024) void k_voxel_pool(
                             if (r[j][k] >= v0 && r[j][k] < v1) Cell<kFixed>::add(&plane[r[j][k] - v0], v[j][k]);
                 }
             }
+            unsigned long long pr_c = 0;
+            if constexpr (kProbe) {
+                pr_c = clock64();
+                ++pr_items;
+            }
             if (!kGeneral) {
 #pragma unroll
                 for (int k = 0; k < kVec; ++k) {
@@ -509,14 +530,31 @@ __global__ __launch_bounds__(kFused ? 512 : 1024) void k_voxel_pool(
                 }
             }
             merge.flush(plane, v0);
+            if constexpr (kProbe) pr_merge += clock64() - pr_c;
         }
     };
     const int* cnt = counts + 2 * (f * n_tiles + tile);
+    unsigned long long pr_l0 = 0, pr_l1 = 0;
+    if constexpr (kProbe) pr_l0 = clock64();
     run_list(std::false_type{}, lst, 1, cnt[0]);
     if (cnt[1] > 0) run_list(std::true_type{}, lst + n_items - 1, -1, cnt[1]);
+    if constexpr (kProbe) pr_l1 = clock64();
     __syncthreads();
     float* o = out + (static_cast<long long>(f) * C + c) * n_vox + v0;
     for (int i = threadIdx.x; i < span; i += blockDim.x) o[i] = Cell<kFixed>::value(plane[i]);
+    if constexpr (kProbe) {
+        if (threadIdx.x == 0 && (blockIdx.x & 7) == 0 && g_pool_probe) {
+            const unsigned long long t1 = clock64();
+            atomicAdd(g_pool_probe + 0, t1 - pr_t0);
+            atomicAdd(g_pool_probe + 1, pr_clear);
+            atomicAdd(g_pool_probe + 2, pr_load);
+            atomicAdd(g_pool_probe + 3, (pr_l1 - pr_l0) - pr_load - pr_merge);
+            atomicAdd(g_pool_probe + 4, pr_merge);
+            atomicAdd(g_pool_probe + 5, t1 - pr_l1);
+            atomicAdd(g_pool_probe + 6, 1ull);
+            atomicAdd(g_pool_probe + 7, pr_items);
+        }
+    }
 }
 
 }  // namespace
@@ -680,7 +718,16 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
         else if (fixed) FIERY_POOL_LAUNCH(VEC, BATCH, false, true);           \
         else FIERY_POOL_LAUNCH(VEC, BATCH, false, false);                     \
     } while (0)
-    if (quads) {
+    if (const char* probe = getenv("FIERY_POOL_PROBE")) {
+        unsigned long long* ptr = reinterpret_cast<unsigned long long*>(strtoull(probe, nullptr, 0));
+        FIERY_REQUIRE(quads && !fused && !fixed, "voxel_pool: the probe variant exists for the 16-byte fp32 path only");
+        if (hipMemcpyToSymbolAsync(HIP_SYMBOL(g_pool_probe), &ptr, sizeof(ptr), 0, hipMemcpyHostToDevice, s) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_voxel_pool<4, 16, false, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pl.lds)) != hipSuccess)
+            return fail(FIERY_ELAUNCH, "voxel_pool: cannot set up the probe");
+        hipLaunchKernelGGL((k_voxel_pool<4, 16, false, false, true>), gridDim3, dim3(threads), pl.lds, s, x, st, depth, feat,
+                           rank, coldesc, lists, counts, out, n_cam, D, H, W, C, pl.n_vox, pl.tile, pl.n_tiles, frames, balanced);
+    } else if (quads) {
         if (batch == 8) FIERY_POOL_DISPATCH(4, 8);
         else FIERY_POOL_DISPATCH(4, 16);
     } else {

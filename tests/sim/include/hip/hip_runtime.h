@@ -257,6 +257,7 @@ inline unsigned long long wall_clock64() { return 0; }
 // instruction-scheduling hints have no effect on results
 inline void __builtin_amdgcn_sched_barrier(int) {}
 inline void __builtin_amdgcn_s_setprio(int) {}
+inline void __builtin_amdgcn_s_waitcnt(int) {}
 inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 
 inline hipsim_v16f __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, hipsim_v16f c, int, int, int) {

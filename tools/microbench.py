@@ -103,6 +103,17 @@ def bench_pool(lib, reps, frames=9, tiles=(0,)):
             cold.append(s_.elapsed_time(e_) * 1e3)
         del junk_a, junk_b
         print(f'pool frames={frames} cold caches: {sum(cold) / len(cold):8.1f} us/op (min {min(cold):.1f})', flush=True)
+        if '--probe' in sys.argv:
+            probe = torch.zeros(8, dtype=torch.int64, device=DEV)
+            os.environ['FIERY_POOL_PROBE'] = hex(probe.data_ptr())
+            us_p = timed(lambda: lib.voxel_pool(x, strides, geo, frames, 6, D, fh, fw, 64, grid, out=out, workspace=ws,
+                                                tile_voxels=tile), reps)
+            del os.environ['FIERY_POOL_PROBE']
+            tot, clr, ld, acc, mrg, fin, nwg, nit = (int(v) for v in probe.cpu())
+            nwg = max(nwg, 1)
+            print(f'  probe ({us_p:.1f} us/op): per sampled workgroup (wave 0) {tot / nwg:9.0f} cycles = clear {clr / nwg:7.0f} + '
+                  f'row loads issue/wait {ld / nwg:8.0f} + rest of the item loop {acc / nwg:8.0f} + merge/LDS adds {mrg / nwg:8.0f} + '
+                  f'barrier/write-out {fin / nwg:7.0f}; {nit / nwg:.1f} items per thread', flush=True)
         print(f'pool frames={frames} tile={tile or "default"}: {us:8.1f} us/op  {us / frames:6.1f} us/frame  '
               f'algorithmic {algo / 1e6:.1f} MB -> {algo / us / 1e3:7.1f} GB/s ({algo / us / 1e3 / 8000:.1%} of 8 TB/s); kept {n_kept / n_pts:.3f}',
               flush=True)
