@@ -31,7 +31,7 @@ def build(force=False, verbose=True):
     objdir = os.path.join(HERE, 'build')
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, 'common.h'), os.path.join(INCLUDE, 'fiery_hip.h')]
-    objs = []
+    objs, jobs = [], []
     for name, extra in SOURCES:
         src = os.path.join(CSRC, name)
         obj = os.path.join(objdir, name + '.o')
@@ -40,7 +40,10 @@ def build(force=False, verbose=True):
             cmd = [HIPCC] + COMMON + extra + ['-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            jobs.append((name, subprocess.Popen(cmd)))       # translation units compile side by side
+    failed = [name for name, proc in jobs if proc.wait() != 0]
+    if failed:
+        raise RuntimeError('hipcc failed for ' + ', '.join(failed))
     if force or _stale(OUT, objs):
         cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
         if verbose:

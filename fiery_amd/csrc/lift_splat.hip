@@ -15,6 +15,7 @@
 // This translation unit is compiled with -ffp-contract=off: the index path must reproduce ATen's CPU
 // rounding (separate multiply and add, k ascending) bit for bit.
 #include "common.h"
+#include <fiery_gfx950.h>
 
 #include <cstdio>
 #include <type_traits>
@@ -22,6 +23,11 @@
 #include <cstdlib>
 
 #pragma clang fp contract(off)
+
+// A/B switch for the streaming (non-temporal) row loads of the pooling kernel
+#ifndef FIERY_POOL_NT_LOADS
+#define FIERY_POOL_NT_LOADS 1
+#endif
 
 namespace fiery {
 namespace {
@@ -334,7 +340,7 @@ struct Merge {
 //  workgroups, items}
 __device__ unsigned long long* g_pool_probe = nullptr;
 
-template <int kVec, int kBatch, bool kFused, bool kFixed, bool kProbe = false>
+template <int kVec, int kBatch, bool kFused, bool kFixed, bool kProbe = false, bool kPipe = false>
 __global__ __launch_bounds__(kFused ? 512 : 1024) void k_voxel_pool(
     const float* __restrict__ x, PoolStrides xs,            // unfused: the lifted tensor
     const float* __restrict__ depth, const float* __restrict__ feat,   // fused: depth prob + features
@@ -444,55 +450,98 @@ __global__ __launch_bounds__(kFused ? 512 : 1024) void k_voxel_pool(
                 s1[k] = dsc[k].w & ((1 << kSplitBits) - 1);
                 s2[k] = (dsc[k].w >> kSplitBits) & ((1 << kSplitBits) - 1);
             }
+            // packed form of the run sums (kVec = 4, register path), two columns per register pair.  A row's membership
+            // of a run is a 0/1 weight that costs one packed add with the clamp bit: sat(s1 - h) is 1 below the first
+            // split and 0 from it on, sat(h + 1 - s2) the other way round for the second, and the middle run's weight is
+            // what is left of 1.  A product with 0 or 1 is exact and fma(v, 1, acc) rounds like acc + v, so every run sum
+            // has the bits of the plain row-by-row sum.
+            constexpr bool kPacked = kVec == 4;
+            constexpr int kPairs = kPacked ? 2 : 1;
+            v2f first[kPairs], mid[kPairs], third[kPairs], below[kPairs], above[kPairs];
+            if constexpr (kPacked) {
+#pragma unroll
+                for (int q = 0; q < kPairs; ++q) {
+                    first[q] = mid[q] = third[q] = pk_splat(0.f);
+                    below[q] = pk_make(static_cast<float>(s1[2 * q]), static_cast<float>(s1[(2 * q + 1) % kVec]));
+                    above[q] = pk_make(static_cast<float>(1 - s2[2 * q]), static_cast<float>(1 - s2[(2 * q + 1) % kVec]));
+                }
+            }
             Merge<kFixed> merge;
             const int* rk = rank + ((static_cast<long long>(f) * n_cam + cam) * D + d) * HW + w;
             for (int h0 = 0; h0 < H; h0 += kBatch) {
                 float v[kBatch][kVec];
                 unsigned long long pr_a = 0;
                 if constexpr (kProbe) pr_a = clock64();
-#pragma unroll
-                for (int j = 0; j < kBatch; ++j) {
-                    const bool in = h0 + j < H;
-                    if (kVec == 4) {
-                        vf4 t = {0.f, 0.f, 0.f, 0.f};
-                        if (in) {
-                            const vf4* src = reinterpret_cast<const vf4*>(p + (h0 + j) * step);
-                            // the lifted tensor is read exactly once: stream it past the caches
-                            t = kFused ? *src : __builtin_nontemporal_load(src);
-                        }
-                        v[j][0] = t[0];  v[j][1 % kVec] = t[1];  v[j][2 % kVec] = t[2];  v[j][3 % kVec] = t[3];
-                    } else {
-                        v[j][0] = in ? p[(h0 + j) * step] : 0.f;
-                    }
-                }
-                if (kFused) {
+                // a whole batch inside the column (the common case: the host picks a batch that divides H) needs no
+                // per-row predicate and no zero fill
+                auto load_rows = [&](auto full_tag) {
+                    constexpr bool kFull = decltype(full_tag)::value;
 #pragma unroll
                     for (int j = 0; j < kBatch; ++j) {
-                        const bool in = h0 + j < H;
+                        const bool in = kFull || h0 + j < H;
                         if (kVec == 4) {
-                            const float4 t = in ? *reinterpret_cast<const float4*>(q + (h0 + j) * qstep) : make_float4(0.f, 0.f, 0.f, 0.f);
-                            v[j][0] *= t.x;  v[j][1 % kVec] *= t.y;  v[j][2 % kVec] *= t.z;  v[j][3 % kVec] *= t.w;
+                            vf4 t = {0.f, 0.f, 0.f, 0.f};
+                            if (in) {
+                                const vf4* src = reinterpret_cast<const vf4*>(p + (h0 + j) * step);
+                                // the lifted tensor is read exactly once: stream it past the caches
+                                t = (kFused || !FIERY_POOL_NT_LOADS) ? *src : __builtin_nontemporal_load(src);
+                            }
+                            v[j][0] = t[0];  v[j][1 % kVec] = t[1];  v[j][2 % kVec] = t[2];  v[j][3 % kVec] = t[3];
                         } else {
-                            v[j][0] *= in ? q[(h0 + j) * qstep] : 0.f;
+                            v[j][0] = in ? p[(h0 + j) * step] : 0.f;
                         }
                     }
-                }
+                    if (kFused) {
+#pragma unroll
+                        for (int j = 0; j < kBatch; ++j) {
+                            const bool in = kFull || h0 + j < H;
+                            if (kVec == 4) {
+                                const float4 t = in ? *reinterpret_cast<const float4*>(q + (h0 + j) * qstep) : make_float4(0.f, 0.f, 0.f, 0.f);
+                                v[j][0] *= t.x;  v[j][1 % kVec] *= t.y;  v[j][2 % kVec] *= t.z;  v[j][3 % kVec] *= t.w;
+                            } else {
+                                v[j][0] *= in ? q[(h0 + j) * qstep] : 0.f;
+                            }
+                        }
+                    }
+                };
+                if (h0 + kBatch <= H) load_rows(std::true_type{});
+                else load_rows(std::false_type{});
                 if constexpr (kProbe) {
                     __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0)
                     pr_load += clock64() - pr_a;
                 }
-                if (!kGeneral) {
-                    // each row adds to the run it belongs to (adding 0.f to the others is exact).  This block - two compares,
-                    // three selects and three adds per element - is what the kernel runs out of first: the probe
-                    // (FIERY_POOL_PROBE) shows a wavefront spending as many cycles here as waiting for its rows.
+                if (!kGeneral && kPacked) {
+                    // 3.5 vector instructions per element (the compare / select / add form below needs 9, and its
+                    // compares feed scalar ORs that stall the vector pipe); rows past the end are zeros
+                    const float h0f = static_cast<float>(h0);
+                    v2f b0[kPairs], a0[kPairs];
+#pragma unroll
+                    for (int q = 0; q < kPairs; ++q) {
+                        b0[q] = below[q] - pk_splat(h0f);
+                        a0[q] = above[q] + pk_splat(h0f);
+                    }
+#pragma unroll
+                    for (int j = 0; j < kBatch; ++j)
+#pragma unroll
+                        for (int q = 0; q < kPairs; ++q) {
+                            const v2f val = pk_make(v[j][(2 * q) % kVec], v[j][(2 * q + 1) % kVec]);
+                            const v2f w_first = pk_add_sat_uniform(b0[q], pk_splat(-static_cast<float>(j)));
+                            const v2f w_third = pk_add_sat_uniform(a0[q], pk_splat(static_cast<float>(j)));
+                            const v2f w_mid = (pk_splat(1.f) - w_first) - w_third;
+                            first[q] = pk_fma(val, w_first, first[q]);
+                            mid[q] = pk_fma(val, w_mid, mid[q]);
+                            third[q] = pk_fma(val, w_third, third[q]);
+                        }
+                } else if (!kGeneral) {
+                    // each row adds to the run it belongs to (adding 0.f to the others is exact)
 #pragma unroll
                     for (int j = 0; j < kBatch; ++j)
 #pragma unroll
                         for (int k = 0; k < kVec; ++k) {
-                            const bool first_run = h0 + j < s1[k], third = h0 + j >= s2[k];
+                            const bool first_run = h0 + j < s1[k], third_run = h0 + j >= s2[k];
                             sa[k] += first_run ? v[j][k] : 0.f;
-                            sc[k] += third ? v[j][k] : 0.f;
-                            sb[k] += (first_run || third) ? 0.f : v[j][k];
+                            sc[k] += third_run ? v[j][k] : 0.f;
+                            sb[k] += (first_run || third_run) ? 0.f : v[j][k];
                         }
                 } else {
                     // a column with four or more runs somewhere in this work-item: every element goes to the voxel its
@@ -516,6 +565,16 @@ __global__ __launch_bounds__(kFused ? 512 : 1024) void k_voxel_pool(
                             if (r[j][k] >= v0 && r[j][k] < v1) Cell<kFixed>::add(&plane[r[j][k] - v0], v[j][k]);
                 }
             }
+            if constexpr (kPacked) {
+                if (!kGeneral) {
+#pragma unroll
+                    for (int q = 0; q < kPairs; ++q) {
+                        sa[2 * q] = pk_lo(first[q]);            sa[(2 * q + 1) % kVec] = pk_hi(first[q]);
+                        sb[2 * q] = pk_lo(mid[q]);              sb[(2 * q + 1) % kVec] = pk_hi(mid[q]);
+                        sc[2 * q] = pk_lo(third[q]);            sc[(2 * q + 1) % kVec] = pk_hi(third[q]);
+                    }
+                }
+            }
             unsigned long long pr_c = 0;
             if constexpr (kProbe) {
                 pr_c = clock64();
@@ -533,10 +592,154 @@ __global__ __launch_bounds__(kFused ? 512 : 1024) void k_voxel_pool(
             if constexpr (kProbe) pr_merge += clock64() - pr_c;
         }
     };
+    // Software-pipelined walk of the front list (kPipe: 16-byte path, unfused, H a multiple of 2 * kBatch).  In the
+    // loop above a wavefront asks for a batch of rows, waits for all of them, reduces them and only then asks for
+    // more, so it has nothing in flight half of the time and the row loads see ~6 us of queueing.  Here two register
+    // buffers alternate: the rows of batch k + 1 - across item boundaries, the first batch of the thread's next item -
+    // are requested before batch k is reduced, so every wavefront keeps kBatch 16-byte rows per lane in flight at all
+    // times.  Arithmetic and merge order are those of the plain loop: same bits.
+    auto run_list_pipelined = [&](const int* first, int count) {
+        static_assert(!kPipe || (kVec == 4 && !kFused), "the pipelined walk is the unfused 16-byte path");
+        // Register diet (two row buffers take 56 of the 128 registers a wavefront has at four per SIMD): of the next
+        // item's descriptors only the four split words are fetched ahead; the ranks of an item are requested just
+        // before its last batch is reduced - ahead of the next item's rows, because loads complete in order and the
+        // merge must not wait for those.
+        int e_next = 0, e_next2 = 0;
+        int split_next[kVec];
+        auto desc_of = [&](int e) {
+            const int wg = e & ((1 << kPackW) - 1);
+            const int d = (e >> kPackW) & ((1 << kPackD) - 1);
+            const int cam = e >> (kPackW + kPackD);
+            return cdesc + (static_cast<long long>(cam) * D + d) * W + wg * kVec;
+        };
+        auto fetch_splits = [&](const int4* dp) {
+#pragma unroll
+            for (int k = 0; k < kVec; ++k) split_next[k] = reinterpret_cast<const int*>(dp + k)[3];
+        };
+        // A row address is (wave-uniform plane base + row * stride) + a 32-bit lane offset.  As a buffer load that is
+        // descriptor + scalar offset + one vector register per item: no vector instruction is spent on addresses and
+        // no 64-bit pointer is held per lane.  (The host checks that the byte offsets fit 31 bits.)
+        const __amdgpu_buffer_rsrc_t rows = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + f * xs.f + c * xs.c), 0,
+                                                                              0x7fffffff, 0x00020000);
+        auto rows_of = [&](int e) {
+            const int w = (e & ((1 << kPackW) - 1)) * kVec;
+            const int d = (e >> kPackW) & ((1 << kPackD) - 1);
+            const int cam = e >> (kPackW + kPackD);
+            return 4 * static_cast<int>(cam * xs.n + d * xs.d + w * xs.w);          // bytes
+        };
+        const int step_bytes = 4 * static_cast<int>(xs.h);
+        float buf_a[kBatch][kVec], buf_b[kBatch][kVec];
+        auto load_rows = [&](float (&buf)[kBatch][kVec], int p, int h0) {
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                // aux 2: non-temporal - the lifted tensor is read exactly once
+                const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rows, p, (h0 + j) * step_bytes, FIERY_POOL_NT_LOADS ? 2 : 0);
+                float t[4];
+                __builtin_memcpy(t, &raw, 16);
+                buf[j][0] = t[0];  buf[j][1 % kVec] = t[1];  buf[j][2 % kVec] = t[2];  buf[j][3 % kVec] = t[3];
+            }
+        };
+        const int tid = threadIdx.x, nthr = blockDim.x;
+        int p_next = 0;
+        const int4* dp_next = nullptr;
+        if (tid < count) e_next = first[tid];
+        if (tid + nthr < count) e_next2 = first[tid + nthr];
+        if (tid < count) {
+            dp_next = desc_of(e_next);
+            fetch_splits(dp_next);
+            p_next = rows_of(e_next);
+            load_rows(buf_a, p_next, 0);
+        }
+        for (int i = tid; i < count; i += nthr) {
+            const int p = p_next;
+            const int4* dp = dp_next;
+            constexpr int kPairs = 2;
+            int s1[kVec], s2[kVec];
+#pragma unroll
+            for (int k = 0; k < kVec; ++k) {
+                s1[k] = split_next[k] & ((1 << kSplitBits) - 1);
+                s2[k] = (split_next[k] >> kSplitBits) & ((1 << kSplitBits) - 1);
+            }
+            e_next = e_next2;
+            const bool more = i + nthr < count;
+            if (more) {
+                dp_next = desc_of(e_next);
+                fetch_splits(dp_next);
+                p_next = rows_of(e_next);
+            }
+            if (i + 2 * nthr < count) e_next2 = first[i + 2 * nthr];
+            v2f first_run[kPairs], mid_run[kPairs], third_run[kPairs], below[kPairs], above[kPairs];
+#pragma unroll
+            for (int q = 0; q < kPairs; ++q) {
+                first_run[q] = mid_run[q] = third_run[q] = pk_splat(0.f);
+                below[q] = pk_make(static_cast<float>(s1[2 * q]), static_cast<float>(s1[(2 * q + 1) % kVec]));
+                above[q] = pk_make(static_cast<float>(1 - s2[2 * q]), static_cast<float>(1 - s2[(2 * q + 1) % kVec]));
+            }
+            auto accumulate = [&](float (&buf)[kBatch][kVec], int h0) {
+                const float h0f = static_cast<float>(h0);
+                v2f b0[kPairs], a0[kPairs];
+#pragma unroll
+                for (int q = 0; q < kPairs; ++q) {
+                    b0[q] = below[q] - pk_splat(h0f);
+                    a0[q] = above[q] + pk_splat(h0f);
+                }
+#pragma unroll
+                for (int j = 0; j < kBatch; ++j)
+#pragma unroll
+                    for (int q = 0; q < kPairs; ++q) {
+                        const v2f val = pk_make(buf[j][(2 * q) % kVec], buf[j][(2 * q + 1) % kVec]);
+                        const v2f w_first = pk_add_sat_uniform(b0[q], pk_splat(-static_cast<float>(j)));
+                        const v2f w_third = pk_add_sat_uniform(a0[q], pk_splat(static_cast<float>(j)));
+                        const v2f w_mid = (pk_splat(1.f) - w_first) - w_third;
+                        first_run[q] = pk_fma(val, w_first, first_run[q]);
+                        mid_run[q] = pk_fma(val, w_mid, mid_run[q]);
+                        third_run[q] = pk_fma(val, w_third, third_run[q]);
+                        // a row's weights are made and spent here: without the fence the scheduler computes the
+                        // weights of a whole batch first and spills the row buffers to make room for them
+                        if (q == kPairs - 1) __builtin_amdgcn_sched_barrier(0);
+                    }
+            };
+            auto pin = [&]() {
+#pragma unroll
+                for (int q = 0; q < kPairs; ++q) pk_pin(first_run[q], mid_run[q], third_run[q]);
+            };
+            int rk_a[kVec], rk_b[kVec], rk_c[kVec];
+            for (int h0 = 0; h0 < H; h0 += 2 * kBatch) {
+                load_rows(buf_b, p, h0 + kBatch);
+                accumulate(buf_a, h0);
+                pin();
+                if (h0 + 2 * kBatch < H) {
+                    load_rows(buf_a, p, h0 + 2 * kBatch);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < kVec; ++k) {
+                        const int4 t = dp[k];
+                        rk_a[k] = t.x;
+                        rk_b[k] = t.y;
+                        rk_c[k] = t.z;
+                    }
+                    if (more) load_rows(buf_a, p_next, 0);
+                }
+                accumulate(buf_b, h0 + kBatch);
+                pin();
+            }
+            Merge<kFixed> merge;
+#pragma unroll
+            for (int k = 0; k < kVec; ++k) {
+                const int q = k / 2;
+                const bool hi = (k & 1) != 0;
+                merge.add(plane, v0, v1, rk_a[k], hi ? pk_hi(first_run[q]) : pk_lo(first_run[q]));
+                if (s1[k] < H) merge.add(plane, v0, v1, rk_b[k], hi ? pk_hi(mid_run[q]) : pk_lo(mid_run[q]));
+                if (s2[k] < H) merge.add(plane, v0, v1, rk_c[k], hi ? pk_hi(third_run[q]) : pk_lo(third_run[q]));
+            }
+            merge.flush(plane, v0);
+        }
+    };
     const int* cnt = counts + 2 * (f * n_tiles + tile);
     unsigned long long pr_l0 = 0, pr_l1 = 0;
     if constexpr (kProbe) pr_l0 = clock64();
-    run_list(std::false_type{}, lst, 1, cnt[0]);
+    if constexpr (kPipe) run_list_pipelined(lst, cnt[0]);
+    else run_list(std::false_type{}, lst, 1, cnt[0]);
     if (cnt[1] > 0) run_list(std::true_type{}, lst + n_items - 1, -1, cnt[1]);
     if constexpr (kProbe) pr_l1 = clock64();
     __syncthreads();
@@ -697,8 +900,16 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
     const long long n_units = static_cast<long long>(C) * frames * pl.n_tiles;
     FIERY_REQUIRE(n_units < (1ll << 31), "voxel_pool: too many (tile, channel, frame) units");
     dim3 gridDim3(static_cast<unsigned>(n_units));
-    int batch = fused ? 8 : 16;                 // the fused form holds two operands per row
-    if (const char* forced = getenv("FIERY_POOL_BATCH")) batch = atoi(forced) == 8 ? 8 : 16;
+    // rows of a work-item in flight at once: a count that divides H spares the row predicates and zero fills of a
+    // ragged last batch (H = 28: 14); the fused form holds two operands per row, hence its shorter batches
+    int batch = fused ? 8 : 16;
+    if (H % batch != 0) {
+        if (H % 14 == 0 || (fused && H % 7 == 0)) batch = 7;       // H = 28: four batches of 7 (measured best)
+    }
+    if (const char* forced = getenv("FIERY_POOL_BATCH")) {                                      // tuning / tests
+        const int b = atoi(forced);
+        if (b == 4 || b == 7 || b == 8 || (!fused && (b == 14 || b == 16))) batch = b;
+    }
     int balanced = 1;                           // unit order, see k_voxel_pool
     if (const char* forced = getenv("FIERY_POOL_ORDER")) balanced = atoi(forced) != 0;         // tuning / A-B runs
 #define FIERY_POOL_LAUNCH(VEC, BATCH, FUSED, FIXED)                                                                      \
@@ -718,23 +929,64 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
         else if (fixed) FIERY_POOL_LAUNCH(VEC, BATCH, false, true);           \
         else FIERY_POOL_LAUNCH(VEC, BATCH, false, false);                     \
     } while (0)
-    if (const char* probe = getenv("FIERY_POOL_PROBE")) {
+#define FIERY_POOL_LAUNCH_PIPE(BATCH, FIXED)                                                                             \
+    do {                                                                                                                 \
+        if (pl.lds > 65536 &&                                                                                            \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_voxel_pool<4, BATCH, false, FIXED, false, true>),       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pl.lds)) != hipSuccess)      \
+            return fail(FIERY_ELAUNCH, "voxel_pool: cannot reserve %zu B of LDS", pl.lds);                              \
+        hipLaunchKernelGGL((k_voxel_pool<4, BATCH, false, FIXED, false, true>), gridDim3, dim3(threads), pl.lds, s, x, st, \
+                           depth, feat, rank, coldesc, lists, counts, out, n_cam, D, H, W, C, pl.n_vox, pl.tile,         \
+                           pl.n_tiles, frames, balanced);                                                                \
+    } while (0)
+    // The software-pipelined walk (two alternating row buffers) needs an even number of whole batches per column.
+    // Opt-in (FIERY_POOL_PIPE=1): on MI355X keeping twice the rows in flight made the kernel slower, not faster (350 vs
+    // 330 us at batch 7, 505 vs 362 us at batch 14: the loads already queue behind the memory system).
+    const char* pipe_env = getenv("FIERY_POOL_PIPE");
+    bool pipe = pipe_env && atoi(pipe_env) != 0 && quads && !fused && (batch == 7 || batch == 14) && H % (2 * batch) == 0;
+    if (pipe) {
+        // its buffer loads address a (frame, channel) plane with 31-bit byte offsets
+        const long long reach = (n_cam - 1) * st.n + (D - 1) * st.d + (H - 1) * st.h + (W - 1) * st.w + 4;
+        pipe = st.n >= 0 && st.d >= 0 && st.h >= 0 && reach < (1ll << 29);
+    }
+    if (getenv("FIERY_POOL_PROBE")) pipe = false;
+    if (pipe) {
+        if (batch == 7) {
+            if (fixed) FIERY_POOL_LAUNCH_PIPE(7, true);
+            else FIERY_POOL_LAUNCH_PIPE(7, false);
+        } else {
+            if (fixed) FIERY_POOL_LAUNCH_PIPE(14, true);
+            else FIERY_POOL_LAUNCH_PIPE(14, false);
+        }
+    } else if (const char* probe = getenv("FIERY_POOL_PROBE")) {
         unsigned long long* ptr = reinterpret_cast<unsigned long long*>(strtoull(probe, nullptr, 0));
         FIERY_REQUIRE(quads && !fused && !fixed, "voxel_pool: the probe variant exists for the 16-byte fp32 path only");
-        if (hipMemcpyToSymbolAsync(HIP_SYMBOL(g_pool_probe), &ptr, sizeof(ptr), 0, hipMemcpyHostToDevice, s) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_voxel_pool<4, 16, false, false, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pl.lds)) != hipSuccess)
+        if (hipMemcpyToSymbolAsync(HIP_SYMBOL(g_pool_probe), &ptr, sizeof(ptr), 0, hipMemcpyHostToDevice, s) != hipSuccess)
             return fail(FIERY_ELAUNCH, "voxel_pool: cannot set up the probe");
-        hipLaunchKernelGGL((k_voxel_pool<4, 16, false, false, true>), gridDim3, dim3(threads), pl.lds, s, x, st, depth, feat,
-                           rank, coldesc, lists, counts, out, n_cam, D, H, W, C, pl.n_vox, pl.tile, pl.n_tiles, frames, balanced);
+#define FIERY_POOL_PROBE_LAUNCH(BATCH)                                                                                   \
+    do {                                                                                                                 \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_voxel_pool<4, BATCH, false, false, true>),              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pl.lds)) != hipSuccess)      \
+            return fail(FIERY_ELAUNCH, "voxel_pool: cannot set up the probe");                                           \
+        hipLaunchKernelGGL((k_voxel_pool<4, BATCH, false, false, true>), gridDim3, dim3(threads), pl.lds, s, x, st, depth, \
+                           feat, rank, coldesc, lists, counts, out, n_cam, D, H, W, C, pl.n_vox, pl.tile, pl.n_tiles,    \
+                           frames, balanced);                                                                            \
+    } while (0)
+        if (batch == 14) FIERY_POOL_PROBE_LAUNCH(14);
+        else FIERY_POOL_PROBE_LAUNCH(16);
+#undef FIERY_POOL_PROBE_LAUNCH
     } else if (quads) {
-        if (batch == 8) FIERY_POOL_DISPATCH(4, 8);
+        if (batch == 4) FIERY_POOL_DISPATCH(4, 4);
+        else if (batch == 7) FIERY_POOL_DISPATCH(4, 7);
+        else if (batch == 8) FIERY_POOL_DISPATCH(4, 8);
+        else if (batch == 14) FIERY_POOL_DISPATCH(4, 14);
         else FIERY_POOL_DISPATCH(4, 16);
     } else {
-        if (batch == 8) FIERY_POOL_DISPATCH(1, 8);
+        if (batch <= 8) FIERY_POOL_DISPATCH(1, 8);
         else FIERY_POOL_DISPATCH(1, 16);
     }
 #undef FIERY_POOL_DISPATCH
+#undef FIERY_POOL_LAUNCH_PIPE
 #undef FIERY_POOL_LAUNCH
     return check_launch("voxel_pool");
 }
@@ -757,6 +1009,182 @@ extern "C" int fiery_lift_splat_fwd(const float* depth_prob, const float* featur
                        workspace, workspace_bytes, tile_voxels, flags, stream);
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward of the pooling (training)
+// ------------------------------------------------------------------------------------------------
+namespace fiery {
+namespace {
+
+// d(out)/d(x): every in-grid point receives the gradient of the voxel it was added to, every other point 0 -
+// what `VoxelsSumming.backward` (fiery/utils/geometry.py:304-314: grad_out[cumsum(keep) - keep]) amounts to once
+// autograd has undone the sort, the mask and the reshape around it (fiery.py:233-261).  A pure copy, so bit-exact.
+// HBM-bound on the write of grad_x: a thread owns kVec adjacent points (one 16-byte rank load), keeps their ranks in
+// registers and walks kChan channels - eight channels' gathers (L2-resident: a channel plane is n_vox floats, and
+// the 28 rows of a column name the same voxel) are in flight before their eight 16-byte streaming stores.
+// grid (ceil(D*H*W / kVec / 256), ceil(C / kChan), frames * n_cam)
+template <int kVec, int kChan>
+__global__ __launch_bounds__(256) void k_voxel_pool_bwd(const float* __restrict__ g, const int* __restrict__ rank,
+                                                         float* __restrict__ gx, PoolStrides gs, int n_cam, int D, int H,
+                                                         int W, int C, int n_vox) {
+    const int Wg = W / kVec;
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= D * H * Wg) return;
+    const int w = (item % Wg) * kVec;
+    const int h = (item / Wg) % H;
+    const int d = item / (Wg * H);
+    const int fc = blockIdx.z;
+    const int f = fc / n_cam, cam = fc - f * n_cam;
+    const int* rp = rank + (static_cast<long long>(fc) * D + d) * H * W + h * W + w;
+    int r[kVec];
+    if (kVec == 4) {
+        const int4 t = *reinterpret_cast<const int4*>(rp);
+        r[0] = t.x;  r[1 % kVec] = t.y;  r[2 % kVec] = t.z;  r[3 % kVec] = t.w;
+    } else {
+        r[0] = rp[0];
+    }
+    const int c0 = blockIdx.y * kChan;
+    const int c1 = min(c0 + kChan, C);
+    const float* gp = g + (static_cast<long long>(f) * C + c0) * n_vox;
+    float* op = gx + f * gs.f + cam * gs.n + d * gs.d + h * gs.h + w * gs.w + c0 * gs.c;
+    constexpr int kUnroll = 8;
+    for (int c = c0; c < c1; c += kUnroll) {
+        float v[kUnroll][kVec];
+#pragma unroll
+        for (int j = 0; j < kUnroll; ++j)
+#pragma unroll
+            for (int k = 0; k < kVec; ++k)
+                v[j][k] = (c + j < c1 && r[k] >= 0) ? gp[static_cast<long long>(j) * n_vox + r[k]] : 0.f;
+#pragma unroll
+        for (int j = 0; j < kUnroll; ++j) {
+            if (c + j >= c1) break;
+            if (kVec == 4) {
+                vf4 t = {v[j][0], v[j][1 % kVec], v[j][2 % kVec], v[j][3 % kVec]};
+                __builtin_nontemporal_store(t, reinterpret_cast<vf4*>(op + j * gs.c));     // written once, read by another kernel
+            } else {
+                op[j * gs.c] = v[j][0];
+            }
+        }
+        gp += static_cast<long long>(kUnroll) * n_vox;
+        op += kUnroll * gs.c;
+    }
+}
+
+// Backward of the fused lift (x) splat, out = sum_points depth * feat:
+//   grad_depth[f][n][d][h][w] = sum_c feat[f][n][c][h][w] * g[f][c][rank(f,n,d,h,w)]
+//   grad_feat [f][n][c][h][w] = sum_d depth[f][n][d][h][w] * g[f][c][rank(f,n,d,h,w)]
+// (autograd through fiery/models/encoder.py:99-100 and the pooling).  The (n, C, D, H, W) gradient of the outer
+// product - 372 MB per sample - never exists.  Sums run in a fixed order (c, respectively d, ascending): reproducible.
+// grid (ceil(D*H*W / 256), 1, frames * n_cam): one thread per point
+__global__ __launch_bounds__(256) void k_lift_splat_bwd_depth(const float* __restrict__ g, const int* __restrict__ rank,
+                                                               const float* __restrict__ feat, float* __restrict__ gdepth,
+                                                               int D, int HW, int C, int n_cam, int n_vox) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= D * HW) return;
+    const int fc = blockIdx.z;
+    const int f = fc / n_cam;
+    const int hw = p % HW;
+    const int r = rank[static_cast<long long>(fc) * D * HW + p];
+    float acc = 0.f;
+    if (r >= 0) {
+        const float* gp = g + static_cast<long long>(f) * C * n_vox + r;
+        const float* fp = feat + static_cast<long long>(fc) * C * HW + hw;
+        constexpr int kUnroll = 8;
+        for (int c = 0; c < C; c += kUnroll) {
+            float a[kUnroll], b[kUnroll];
+#pragma unroll
+            for (int j = 0; j < kUnroll; ++j) {
+                const bool in = c + j < C;
+                a[j] = in ? gp[static_cast<long long>(c + j) * n_vox] : 0.f;
+                b[j] = in ? fp[static_cast<long long>(c + j) * HW] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < kUnroll; ++j) acc += a[j] * b[j];
+        }
+    }
+    gdepth[static_cast<long long>(fc) * D * HW + p] = acc;
+}
+
+// grid (ceil(H*W / 64), ceil(C / kChan), frames * n_cam), 64 threads: one thread per pixel and kChan channels
+template <int kChan>
+__global__ __launch_bounds__(64) void k_lift_splat_bwd_feat(const float* __restrict__ g, const int* __restrict__ rank,
+                                                             const float* __restrict__ depth, float* __restrict__ gfeat,
+                                                             int D, int HW, int C, int n_cam, int n_vox) {
+    const int hw = blockIdx.x * blockDim.x + threadIdx.x;
+    if (hw >= HW) return;
+    const int fc = blockIdx.z;
+    const int f = fc / n_cam;
+    const int c0 = blockIdx.y * kChan;
+    const int* rp = rank + static_cast<long long>(fc) * D * HW + hw;
+    const float* dp = depth + static_cast<long long>(fc) * D * HW + hw;
+    const float* gp = g + (static_cast<long long>(f) * C + c0) * n_vox;
+    float acc[kChan];
+#pragma unroll
+    for (int j = 0; j < kChan; ++j) acc[j] = 0.f;
+    for (int d = 0; d < D; ++d) {
+        const int r = rp[static_cast<long long>(d) * HW];
+        const float pd = dp[static_cast<long long>(d) * HW];
+        if (r < 0) continue;
+        float a[kChan];
+#pragma unroll
+        for (int j = 0; j < kChan; ++j) a[j] = (c0 + j < C) ? gp[static_cast<long long>(j) * n_vox + r] : 0.f;
+#pragma unroll
+        for (int j = 0; j < kChan; ++j) acc[j] += pd * a[j];
+    }
+#pragma unroll
+    for (int j = 0; j < kChan; ++j)
+        if (c0 + j < C) gfeat[(static_cast<long long>(fc) * C + c0 + j) * HW + hw] = acc[j];
+}
+
+}  // namespace
+}  // namespace fiery
+
+extern "C" int fiery_voxel_pool_bwd(const float* grad_out, const int32_t* rank, int frames, int n_cameras, int D, int H,
+                                    int W, int C, int n_voxels, float* grad_x, const int64_t* gx_strides,
+                                    fiery_stream_t stream) {
+    FIERY_REQUIRE(grad_out && rank && grad_x && gx_strides, "voxel_pool_bwd: null pointer");
+    FIERY_REQUIRE(frames > 0 && n_cameras > 0 && D > 0 && H > 0 && W > 0 && C > 0 && n_voxels > 0, "voxel_pool_bwd: bad shape");
+    FIERY_REQUIRE(static_cast<long long>(frames) * n_cameras < 65536, "voxel_pool_bwd: frames * cameras >= 65536");
+    const PoolStrides st{gx_strides[0], gx_strides[1], gx_strides[2], gx_strides[3], gx_strides[4], gx_strides[5]};
+    // 16-byte path: four adjacent points of a row are contiguous and aligned in both the rank array and grad_x
+    bool quads = W % 4 == 0 && aligned16(rank) && aligned16(grad_x) && st.w == 1 && st.f % 4 == 0 && st.n % 4 == 0 &&
+                 st.d % 4 == 0 && st.h % 4 == 0 && st.c % 4 == 0;
+    if (const char* forced = getenv("FIERY_POOL_VEC")) quads = quads && atoi(forced) == 4;      // tuning / tests
+    constexpr int kChan = 16;
+    const int vec = quads ? 4 : 1;
+    dim3 grid3(ceil_div(static_cast<long long>(D) * H * (W / vec), 256), ceil_div(C, kChan), frames * n_cameras);
+    if (quads)
+        hipLaunchKernelGGL((fiery::k_voxel_pool_bwd<4, kChan>), grid3, dim3(256), 0, as_stream(stream), grad_out, rank, grad_x,
+                           st, n_cameras, D, H, W, C, n_voxels);
+    else
+        hipLaunchKernelGGL((fiery::k_voxel_pool_bwd<1, kChan>), grid3, dim3(256), 0, as_stream(stream), grad_out, rank, grad_x,
+                           st, n_cameras, D, H, W, C, n_voxels);
+    return check_launch("voxel_pool_bwd");
+}
+
+extern "C" int fiery_lift_splat_bwd(const float* grad_out, const int32_t* rank, const float* depth_prob,
+                                    const float* features, int frames, int n_cameras, int D, int H, int W, int C,
+                                    int n_voxels, float* grad_depth, float* grad_features, fiery_stream_t stream) {
+    FIERY_REQUIRE(grad_out && rank && depth_prob && features, "lift_splat_bwd: null pointer");
+    FIERY_REQUIRE(grad_depth || grad_features, "lift_splat_bwd: nothing to compute");
+    FIERY_REQUIRE(frames > 0 && n_cameras > 0 && D > 0 && H > 0 && W > 0 && C > 0 && n_voxels > 0, "lift_splat_bwd: bad shape");
+    FIERY_REQUIRE(static_cast<long long>(frames) * n_cameras < 65536, "lift_splat_bwd: frames * cameras >= 65536");
+    const int HW = H * W;
+    hipStream_t s = as_stream(stream);
+    if (grad_depth) {
+        hipLaunchKernelGGL(fiery::k_lift_splat_bwd_depth, dim3(ceil_div(static_cast<long long>(D) * HW, 256), 1, frames * n_cameras),
+                           dim3(256), 0, s, grad_out, rank, features, grad_depth, D, HW, C, n_cameras, n_voxels);
+        const int rc = check_launch("lift_splat_bwd (depth)");
+        if (rc) return rc;
+    }
+    if (grad_features) {
+        constexpr int kChan = 8;
+        hipLaunchKernelGGL((fiery::k_lift_splat_bwd_feat<kChan>), dim3(ceil_div(HW, 64), ceil_div(C, kChan), frames * n_cameras),
+                           dim3(64), 0, s, grad_out, rank, depth_prob, grad_features, D, HW, C, n_cameras, n_voxels);
+        return check_launch("lift_splat_bwd (features)");
+    }
+    return FIERY_OK;
+}
+
 namespace fiery {
 namespace {
 __global__ void k_depth_softmax(const float* __restrict__ logits, int n, int D, int HW, float* __restrict__ prob) {
@@ -772,8 +1200,30 @@ __global__ void k_depth_softmax(const float* __restrict__ logits, int n, int D, 
     for (int d = 0; d < D; ++d) s += expf(in[static_cast<long long>(d) * HW] - m);
     for (int d = 0; d < D; ++d) o[static_cast<long long>(d) * HW] = expf(in[static_cast<long long>(d) * HW] - m) / s;
 }
+// softmax backward over the depth axis: grad_logits = p * (grad_p - sum_d p * grad_p)
+__global__ void k_depth_softmax_bwd(const float* __restrict__ prob, const float* __restrict__ gprob, int n, int D, int HW,
+                                    float* __restrict__ glogits) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= static_cast<long long>(n) * HW) return;
+    const int img = static_cast<int>(i / HW);
+    const long long base = static_cast<long long>(img) * D * HW + (i - static_cast<long long>(img) * HW);
+    float dot = 0.f;
+    for (int d = 0; d < D; ++d) dot += prob[base + static_cast<long long>(d) * HW] * gprob[base + static_cast<long long>(d) * HW];
+    for (int d = 0; d < D; ++d) {
+        const long long j = base + static_cast<long long>(d) * HW;
+        glogits[j] = prob[j] * (gprob[j] - dot);
+    }
+}
 }  // namespace
 }  // namespace fiery
+
+extern "C" int fiery_depth_softmax_bwd(const float* prob, const float* grad_prob, int n, int D, int HW, float* grad_logits,
+                                       fiery_stream_t stream) {
+    FIERY_REQUIRE(prob && grad_prob && grad_logits && n > 0 && D > 0 && HW > 0, "depth_softmax_bwd: bad argument");
+    hipLaunchKernelGGL(fiery::k_depth_softmax_bwd, dim3(ceil_div(static_cast<long long>(n) * HW, 256)), dim3(256), 0,
+                       as_stream(stream), prob, grad_prob, n, D, HW, grad_logits);
+    return check_launch("depth_softmax_bwd");
+}
 
 extern "C" int fiery_depth_softmax(const float* logits, int n, int D, int HW, float* prob, fiery_stream_t stream) {
     FIERY_REQUIRE(logits && prob && n > 0 && D > 0 && HW > 0, "depth_softmax: bad argument");

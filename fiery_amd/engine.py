@@ -433,8 +433,11 @@ class BevEngine:
         return ws
 
     def pool(self, x, geometry):
-        """`projection_to_birds_eye_view`: x logical (F, n, D, h, w, C) of any strides -> (F, C, X, Y)."""
+        """`projection_to_birds_eye_view`: x logical (F, n, D, h, w, C) of any strides -> (F, C, X, Y).
+        Differentiable with respect to x (ops.VoxelPool) when autograd is recording."""
         f, n, d, h, w, c = x.shape
+        if torch.is_grad_enabled() and x.requires_grad:
+            return ops.VoxelPool.apply(x, geometry, self)
         ws = self._pool_workspace(f, n, d, h, w, x.device)
         # algorithmic bytes of the op: every point's C features + its geometry + the dense output (SURVEY 8d);
         # out-of-grid points are charged too here (an upper bound that needs no device read-back)
@@ -447,6 +450,8 @@ class BevEngine:
         """depth logits (F, n, D, h, w) + features (F, n, C, h, w) -> (F, C, X, Y) without the outer product."""
         f, n, d, h, w = depth_logits.shape
         c = features.shape[2]
+        if torch.is_grad_enabled() and (depth_logits.requires_grad or features.requires_grad):
+            return ops.LiftSplat.apply(depth_logits, features, geometry, self)
         prob = self.lib.depth_softmax(depth_logits.reshape(f * n, d, h, w).contiguous())
         ws = self._pool_workspace(f, n, d, h, w, features.device)
         return self.lib.lift_splat(prob, features.contiguous(), geometry.contiguous(), f, n, d, h, w, c, self.grid,

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libfiery_hip.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -98,7 +98,10 @@ _SIGNATURES = {
                              [C.POINTER(BevGrid), C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_void_p]),
     'fiery_lift_splat_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6 +
                              [C.POINTER(BevGrid), C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_void_p]),
+    'fiery_voxel_pool_bwd': (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, c_int64_p, C.c_void_p]),
+    'fiery_lift_splat_bwd': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_void_p]),
     'fiery_depth_softmax': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'fiery_depth_softmax_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'fiery_warp_params': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     'fiery_bev_warp_nchw_to_nhwc': (C.c_int, [C.c_void_p, C.c_void_p, c_uint8_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                               C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
@@ -200,11 +203,35 @@ class Lib:
             _ptr(workspace), workspace.numel() * 4, tile_voxels, flags, _stream_of(out)))
         return out
 
+    def voxel_pool_bwd(self, grad_out, rank, frames, n_cam, d, h, w, c, grad_x):
+        """grad_x: a (frames, n_cam, d, h, w, c) tensor of any strides, fully overwritten."""
+        n_vox = grad_out[0, 0].numel()
+        gs = (C.c_int64 * 6)(*grad_x.stride())
+        self.check(self.dll.fiery_voxel_pool_bwd(_ptr(grad_out), _ptr(rank), frames, n_cam, d, h, w, c, n_vox,
+                                                 _ptr(grad_x), gs, _stream_of(grad_x)))
+        return grad_x
+
+    def lift_splat_bwd(self, grad_out, rank, depth_prob, features, frames, n_cam, d, h, w, c, want_depth=True,
+                       want_features=True):
+        n_vox = grad_out[0, 0].numel()
+        gd = torch.empty_like(depth_prob) if want_depth else None
+        gf = torch.empty_like(features) if want_features else None
+        self.check(self.dll.fiery_lift_splat_bwd(_ptr(grad_out), _ptr(rank), _ptr(depth_prob), _ptr(features), frames,
+                                                 n_cam, d, h, w, c, n_vox, _ptr(gd), _ptr(gf), _stream_of(grad_out)))
+        return gd, gf
+
     def depth_softmax(self, logits):
         n, d = logits.shape[:2]
         hw = logits[0, 0].numel()
         out = torch.empty_like(logits)
         self.check(self.dll.fiery_depth_softmax(_ptr(logits), n, d, hw, _ptr(out), _stream_of(out)))
+        return out
+
+    def depth_softmax_bwd(self, prob, grad_prob):
+        n, d = prob.shape[:2]
+        hw = prob[0, 0].numel()
+        out = torch.empty_like(prob)
+        self.check(self.dll.fiery_depth_softmax_bwd(_ptr(prob), _ptr(grad_prob), n, d, hw, _ptr(out), _stream_of(out)))
         return out
 
     # -- warp -------------------------------------------------------------------------------------

@@ -268,3 +268,62 @@ def _autotune_enabled(t):
 
 def identity_chan_map(channels, offset=0):
     return [offset + i for i in range(channels)]
+
+
+class VoxelPool(torch.autograd.Function):
+    """`projection_to_birds_eye_view` as one differentiable operator - the seam the reference fills with
+    `VoxelsSumming.apply` (fiery/utils/geometry.py:283-314, called at fiery/models/fiery.py:261).  Forward is
+    `fiery_voxel_pool_fwd`; backward hands every in-grid point the gradient of its voxel (`fiery_voxel_pool_bwd`) using
+    the voxel ranks the forward call left in its workspace.  Geometry gets no gradient, as in the reference
+    (`ctx.mark_non_differentiable(geometry)`, geometry.py:300)."""
+
+    @staticmethod
+    def forward(ctx, x, geometry, engine):
+        f, n, d, h, w, c = x.shape
+        lib = engine.lib
+        # a workspace of its own: the ranks must outlive later pooling calls until backward runs
+        ws = lib.pool_workspace(f, n, d, h, w, x.device, engine.grid, engine.pool_tile, engine.pool_flags)
+        out = lib.voxel_pool(x.detach(), x.stride(), geometry.detach().contiguous(), f, n, d, h, w, c, engine.grid,
+                             workspace=ws, tile_voxels=engine.pool_tile, flags=engine.pool_flags)
+        ctx.lib, ctx.dims = lib, (f, n, d, h, w, c)
+        ctx.save_for_backward(ws[:f * n * d * h * w])
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (rank,) = ctx.saved_tensors
+        f, n, d, h, w, c = ctx.dims
+        # the gradient is laid out like the encoder's output, (F, n, C, D, h, w): the 16-byte streaming-store path
+        gx = torch.empty(f, n, c, d, h, w, dtype=torch.float32, device=grad_out.device).permute(0, 1, 3, 4, 5, 2)
+        ctx.lib.voxel_pool_bwd(grad_out.float().contiguous(), rank, f, n, d, h, w, c, gx)
+        return gx, None, None
+
+
+class LiftSplat(torch.autograd.Function):
+    """Depth softmax + fused lift (x) splat, differentiable in the depth logits and the features (the autograd path of
+    fiery/models/encoder.py:99-100 followed by fiery/models/fiery.py:221-273) without the (n, C, D, h, w) outer
+    product or its gradient ever existing."""
+
+    @staticmethod
+    def forward(ctx, depth_logits, features, geometry, engine):
+        f, n, d, h, w = depth_logits.shape
+        c = features.shape[2]
+        lib = engine.lib
+        prob = lib.depth_softmax(depth_logits.detach().reshape(f * n, d, h, w).contiguous())
+        feats = features.detach().contiguous()
+        ws = lib.pool_workspace(f, n, d, h, w, feats.device, engine.grid, engine.pool_tile, engine.pool_flags)
+        out = lib.lift_splat(prob, feats, geometry.detach().contiguous(), f, n, d, h, w, c, engine.grid, workspace=ws,
+                             tile_voxels=engine.pool_tile, flags=engine.pool_flags)
+        ctx.lib, ctx.dims = lib, (f, n, d, h, w, c)
+        ctx.save_for_backward(ws[:f * n * d * h * w], prob, feats)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        rank, prob, feats = ctx.saved_tensors
+        f, n, d, h, w, c = ctx.dims
+        want_depth, want_feat = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gd, gf = ctx.lib.lift_splat_bwd(grad_out.float().contiguous(), rank, prob, feats, f, n, d, h, w, c,
+                                        want_depth=want_depth, want_features=want_feat)
+        glogits = ctx.lib.depth_softmax_bwd(prob, gd).view(f, n, d, h, w) if want_depth else None
+        return glogits, gf, None, None

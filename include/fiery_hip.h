@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FIERY_ABI_VERSION 2
+#define FIERY_ABI_VERSION 3
 
 #define FIERY_OK 0
 #define FIERY_EINVAL (-22)      /* bad argument (shape, alignment, null pointer) */
@@ -102,8 +102,35 @@ int fiery_lift_splat_fwd(const float* depth_prob, const float* features, const f
                          void* workspace, size_t workspace_bytes, int tile_voxels, uint32_t flags,
                          fiery_stream_t stream);
 
+/* Backward of fiery_voxel_pool_fwd with respect to x (training).  Replaces `VoxelsSumming.backward`
+ * (fiery/utils/geometry.py:304-314, `grad_out[cumsum(keep) - keep]`) together with what autograd does around it to
+ * undo the argsort, the bounds mask and the reshape (fiery.py:233-261): every in-grid point receives the gradient
+ * of the voxel it was added to, every other point zero.  A copy: bit-exact.  Geometry gets no gradient
+ * (`ctx.mark_non_differentiable`, geometry.py:300).
+ *   grad_out : [frames][C][n_voxels]            (n_voxels = X*Y)
+ *   rank     : int32 [frames][n_cameras][D][H][W], voxel rank or -1 - the first frames*n_cameras*D*H*W ints of the
+ *              workspace the forward call filled, or the output of fiery_voxel_index
+ *   grad_x   : logical [frames][n_cameras][D][H][W][C] addressed through gx_strides (host [6]) like x in the forward
+ *              call; every element is written. */
+int fiery_voxel_pool_bwd(const float* grad_out, const int32_t* rank, int frames, int n_cameras, int D, int H, int W,
+                         int C, int n_voxels, float* grad_x, const int64_t* gx_strides /* host [6] */,
+                         fiery_stream_t stream);
+
+/* Backward of fiery_lift_splat_fwd (autograd through fiery/models/encoder.py:99-100 and the pooling) without the
+ * (n, C, D, H, W) gradient of the outer product:
+ *   grad_depth[f][n][d][h][w]    = sum_c features[f][n][c][h][w]   * grad_out[f][c][rank[f][n][d][h][w]]
+ *   grad_features[f][n][c][h][w] = sum_d depth_prob[f][n][d][h][w] * grad_out[f][c][rank[f][n][d][h][w]]
+ * (points with rank -1 contribute nothing).  Either output may be NULL. */
+int fiery_lift_splat_bwd(const float* grad_out, const int32_t* rank, const float* depth_prob, const float* features,
+                         int frames, int n_cameras, int D, int H, int W, int C, int n_voxels,
+                         float* grad_depth, float* grad_features, fiery_stream_t stream);
+
 /* softmax over the depth axis: logits [n][D][HW] -> prob (reference: fiery/models/encoder.py:99). */
 int fiery_depth_softmax(const float* logits, int n, int D, int HW, float* prob, fiery_stream_t stream);
+
+/* its backward: grad_logits = prob * (grad_prob - sum_D prob * grad_prob)   (autograd of encoder.py:99) */
+int fiery_depth_softmax_bwd(const float* prob, const float* grad_prob, int n, int D, int HW, float* grad_logits,
+                            fiery_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Ego-motion warp                  (reference: fiery/utils/geometry.py:181-253

@@ -172,3 +172,37 @@ def lifted_to_points(lifted):
     lifted = np.asarray(lifted)
     n, c = lifted.shape[:2]
     return np.ascontiguousarray(np.moveaxis(lifted, 1, -1)).reshape(-1, c)
+
+
+def voxel_pool_backward(grad_bev, geometry, resolution, start, dimension):
+    """Gradient of `voxel_pooling` with respect to its point features, one batch element.
+    reference: fiery/utils/geometry.py:304-314 (`VoxelsSumming.backward`: `grad_out[cumsum(keep) - keep]` hands every
+    sorted point the gradient of its voxel), seen through what autograd does around it to undo the argsort, the bounds
+    mask and the reshape of fiery/models/fiery.py:233-261, and the dense scatter + permute of :263-271.
+
+    grad_bev (C, X, Y) f32, geometry (N, 3) f32 -> (N, C) f32: row p = grad_bev[:, ix_p, iy_p] for in-grid points, 0
+    for the others.  A pure copy, so the result is bit-exact.
+    """
+    nx = [int(v) for v in dimension]
+    if nx[2] != 1:
+        raise ValueError('the reference only supports a single z cell (fiery/models/fiery.py:268-271)')
+    idx, keep, _ = voxel_indices(geometry, resolution, start, dimension)
+    g = np.asarray(grad_bev, dtype=F32)
+    out = np.zeros((idx.shape[0], g.shape[0]), dtype=F32)
+    out[keep] = g[:, idx[keep, 0], idx[keep, 1]].T
+    return out
+
+
+def lift_splat_backward(grad_bev, depth_prob, features, geometry, resolution, start, dimension):
+    """Gradients of `voxel_pooling(depth_prob (x) features)` (fiery/models/encoder.py:99-100 followed by
+    fiery/models/fiery.py:221-273) with respect to both factors, one batch element, accumulated in float64.
+
+    depth_prob (n, D, h, w), features (n, C, h, w), geometry (n*D*h*w, 3) -> (n, D, h, w), (n, C, h, w).
+    """
+    n, D, h, w = depth_prob.shape
+    C = features.shape[1]
+    gx = voxel_pool_backward(grad_bev, geometry, resolution, start, dimension).astype(np.float64)
+    gx = gx.reshape(n, D, h, w, C)
+    g_depth = np.einsum('ndhwc,nchw->ndhw', gx, np.asarray(features, dtype=np.float64))
+    g_feat = np.einsum('ndhwc,ndhw->nchw', gx, np.asarray(depth_prob, dtype=np.float64))
+    return g_depth, g_feat

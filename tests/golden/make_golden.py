@@ -85,6 +85,32 @@ def golden_pooling_small():
                         intrinsics=K[0].numpy(), extrinsics=E[0].numpy(), bev=bev.numpy())
 
 
+def golden_pooling_backward_small():
+    """Autograd of the reference through `projection_to_birds_eye_view` (VoxelsSumming.backward and the graph around
+    it) and through the lift head's softmax (x) features product (fiery/models/encoder.py:99-100), same small problem
+    as `pooling_small.npz`; inputs included."""
+    cfg = tiny_cfg('baseline.yml', bev=16)
+    model = reference_model(cfg)
+    _, K, E, _ = make_inputs(1, 2, 3, with_image=False)
+    D = model.depth_channels
+    logits, feats, _ = make_lifted_features(2 * 3, 8, D, (8, 12), seed=4, materialise=False)
+    logits.requires_grad_(True)
+    feats.requires_grad_(True)
+    lifted = logits.softmax(dim=1).unsqueeze(1) * feats.unsqueeze(2)            # encoder.py:99-100
+    lifted.retain_grad()
+    x = lifted.view(2, 3, 8, D, 8, 12).permute(0, 1, 3, 4, 5, 2)                 # fiery.py:214-219
+    with torch.no_grad():
+        geo = model.get_geometry(K[0], E[0])
+    bev = model.projection_to_birds_eye_view(x, geo)
+    grad_bev = torch.randn(bev.shape, generator=torch.Generator().manual_seed(6))
+    bev.backward(grad_bev)
+    np.savez_compressed(os.path.join(OUT, 'pooling_bwd_small.npz'), depth_logits=logits.detach().numpy(),
+                        features=feats.detach().numpy(), geometry=geo.numpy(), intrinsics=K[0].numpy(),
+                        extrinsics=E[0].numpy(), bev=bev.detach().numpy(), grad_bev=grad_bev.numpy(),
+                        grad_lifted=lifted.grad.numpy(), grad_depth_logits=logits.grad.numpy(),
+                        grad_features=feats.grad.numpy())
+
+
 def golden_forward(name, cfg, B, n_cam, sub, with_labels=False, with_noise=False):
     model = reference_model(cfg)
     lifted, K, E, ego, labels, noise = forward_case(cfg, model.receptive_field, model.n_future, model.depth_channels,
@@ -117,6 +143,7 @@ def golden_forward(name, cfg, B, n_cam, sub, with_labels=False, with_noise=False
 if __name__ == '__main__':
     golden_index_path()
     golden_pooling_small()
+    golden_pooling_backward_small()
     print(golden_forward('tiny_baseline', tiny_cfg('baseline.yml'), 2, 2, 1, with_labels=True, with_noise=True))
     print(golden_forward('tiny_static', tiny_cfg('literature/static_lss_setting.yml'), 1, 2, 1))
     print(golden_forward('baseline_b1', get_preset_cfg('baseline.yml'), 1, 6, SUB))

@@ -54,6 +54,7 @@ inline hipError_t hipGetDevice(int* dev) { *dev = 0; return hipSuccess; }
 // a 4-CU device: small test problems then span several rounds of workgroups, like the real sizes do on 256 CUs
 inline hipError_t hipDeviceGetAttribute(int* value, hipDeviceAttribute_t, int) { *value = 4; return hipSuccess; }
 #define __builtin_nontemporal_load(p) (*(p))
+#define __builtin_nontemporal_store(v, p) (*(p) = (v))
 
 // One work-item = one cooperative fiber (ucontext) on the calling OS thread; a workgroup's fibers are
 // scheduled round-robin and only switch at barriers (__syncthreads, the wave-level exchange inside the

@@ -106,3 +106,51 @@ def test_training_mode_and_cpu_without_library_raise():
     model.eval()
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         model.bev_forward(torch.zeros(1, 3, 2, 64, 4, 8, 12), K, E, ego)
+
+
+def test_method_seams_are_differentiable_through_the_pooling(sim):
+    """`projection_to_birds_eye_view` (ops.VoxelPool: the `VoxelsSumming.apply` seam, geometry.py:283-314) and the fused
+    lift head -> splat (ops.LiftSplat) under autograd, against the oracle's gradients; two forward calls before the
+    backward passes check that each keeps its own ranks."""
+    import numpy as np
+    from oracle import lift_splat as ls
+    cfg = tiny_cfg('baseline.yml', bev=8)
+    torch.manual_seed(0)
+    model = Fiery(cfg).eval()
+    model._lib = sim
+    n = 2
+    _, K, E, _ = make_inputs(1, 2, n, with_image=False, seed=3)
+    fh, fw = cfg.IMAGE.FINAL_DIM[0] // 8, cfg.IMAGE.FINAL_DIM[1] // 8
+    D = model.depth_channels
+    dl, ft, lifted = make_lifted_features(2 * n, 64, D, (fh, fw), seed=4)
+    res, start, dim = ls.bev_parameters(cfg.LIFT.X_BOUND, cfg.LIFT.Y_BOUND, cfg.LIFT.Z_BOUND)
+    geo = model.get_geometry(K[0], E[0])
+    assert not geo.requires_grad
+    x = lifted.view(2, n, 64, D, fh, fw).permute(0, 1, 3, 4, 5, 2).clone().requires_grad_(True)
+    bev = model.projection_to_birds_eye_view(x, geo)
+    assert bev.requires_grad
+    geo_flipped = geo.flip(0)
+    bev2 = model.projection_to_birds_eye_view(x, geo_flipped)                  # a second call before backward
+    g = torch.randn(bev.shape, generator=torch.Generator().manual_seed(7))
+    bev.backward(g)
+    for f in range(2):
+        want = ls.voxel_pool_backward(g[f].numpy(), geo[f].numpy().reshape(-1, 3), res, start, dim)
+        assert np.array_equal(x.grad[f].reshape(-1, 64).numpy(), want)
+    x.grad = None
+    bev2.backward(g)
+    for f in range(2):
+        want = ls.voxel_pool_backward(g[f].numpy(), geo_flipped[f].numpy().reshape(-1, 3), res, start, dim)
+        assert np.array_equal(x.grad[f].reshape(-1, 64).numpy(), want)
+    # fused: gradients reach the depth logits and the features
+    logits = dl.view(2, n, D, fh, fw).clone().requires_grad_(True)
+    feats = ft.view(2, n, 64, fh, fw).clone().requires_grad_(True)
+    out = model.engine().pool_fused(logits, feats, geo)
+    assert torch.allclose(out, bev.detach(), atol=2e-5)
+    out.backward(g)
+    prob = logits.detach().double().softmax(dim=2).numpy()
+    for f in range(2):
+        wd, wf = ls.lift_splat_backward(g[f].numpy(), prob[f], feats[f].detach().numpy(), geo[f].numpy().reshape(-1, 3),
+                                        res, start, dim)
+        wl = prob[f] * (wd - (prob[f] * wd).sum(axis=1, keepdims=True))
+        assert np.abs(logits.grad[f].numpy() - wl).max() < 1e-5
+        assert np.abs(feats.grad[f].numpy() - wf).max() < 1e-5

@@ -147,6 +147,117 @@ def test_fused_lift_splat_equals_pooling_of_the_outer_product(hip):
 
 
 # ------------------------------------------------------------------------------------------------------
+# pooling backward (training): VoxelsSumming.backward and the autograd graph around it
+# ------------------------------------------------------------------------------------------------------
+def test_pooling_backward_against_the_reference_fixture(hip):
+    gold = np.load(os.path.join(GOLD, 'pooling_bwd_small.npz'))
+    cfg = tiny_cfg('baseline.yml', bev=16)
+    grid, _ = _grid_of(cfg)
+    geo = torch.from_numpy(gold['geometry']).to(DEV)
+    frames, n_cam, D, H, W = geo.shape[:5]
+    C = gold['features'].shape[1]
+    g = torch.from_numpy(gold['grad_bev']).to(DEV)
+    rank, _ = hip.voxel_index(geo, grid, want_idx=False)
+    gx = torch.empty(frames, n_cam, C, D, H, W, device=DEV).permute(0, 1, 3, 4, 5, 2)
+    hip.voxel_pool_bwd(g, rank, frames, n_cam, D, H, W, C, gx)
+    want = torch.from_numpy(gold['grad_lifted']).view(frames, n_cam, C, D, H, W).permute(0, 1, 3, 4, 5, 2)
+    assert torch.equal(gx.cpu(), want)                                   # a copy: bit-exact
+    prob = hip.depth_softmax(torch.from_numpy(gold['depth_logits']).to(DEV))
+    feats = torch.from_numpy(gold['features']).to(DEV).view(frames, n_cam, C, H, W)
+    gd, gf = hip.lift_splat_bwd(g, rank, prob, feats, frames, n_cam, D, H, W, C)
+    gl = hip.depth_softmax_bwd(prob, gd)
+    assert np.abs(gl.cpu().numpy() - gold['grad_depth_logits']).max() < 1e-5
+    assert np.abs(gf.reshape(-1, C, H, W).cpu().numpy() - gold['grad_features']).max() < 1e-5
+
+
+@pytest.mark.parametrize('preset,n_cam', [('baseline.yml', 6), ('literature/pon_setting.yml', 6)])
+def test_voxel_pool_bwd_vs_oracle_full_size(hip, preset, n_cam):
+    cfg = get_preset_cfg(preset)
+    grid, (res, start, dim) = _grid_of(cfg)
+    lifted, geo = _pool_case(cfg, n_cam, 1)
+    x = lifted.to(DEV)
+    f, n, C, D, h, w = x.shape
+    ws = hip.pool_workspace(f, n, D, h, w, DEV, grid)
+    hip.voxel_pool(x, _native_strides(x), torch.from_numpy(geo).to(DEV), f, n, D, h, w, C, grid, workspace=ws)
+    g = torch.randn(f, C, int(dim[0]), int(dim[1]), generator=torch.Generator().manual_seed(11))
+    want = ls.voxel_pool_backward(g[0].numpy(), geo[0].reshape(-1, 3), res, start, dim)
+    for layout in ('native', 'point_major'):
+        if layout == 'native':
+            gx = torch.full((f, n, C, D, h, w), float('nan'), device=DEV).permute(0, 1, 3, 4, 5, 2)
+        else:
+            gx = torch.full((f, n, D, h, w, C), float('nan'), device=DEV)
+        hip.voxel_pool_bwd(g.to(DEV), ws[:f * n * D * h * w], f, n, D, h, w, C, gx)
+        assert np.array_equal(gx[0].reshape(-1, C).cpu().numpy(), want), layout
+
+
+def test_pooling_backward_is_the_adjoint_at_batch_size(hip):
+    """baseline.yml at batch 3 (9 frames): <pool(x), g> == <x, pool_bwd(g)> and the fused form's two gradients
+    against the same identity - size-independent properties that need no oracle pass over 1.1 GB."""
+    cfg = get_preset_cfg('baseline.yml')
+    grid, _ = _grid_of(cfg)
+    frames, n_cam = 9, 6
+    frustum = _frustum(cfg)
+    D, fh, fw = frustum.shape[:3]
+    _, K, E, _ = make_inputs(3, 3, n_cam, with_image=False)
+    geo = hip.lift_geometry(torch.from_numpy(frustum).to(DEV),
+                            hip.camera_matrices(K.view(-1, 3, 3).to(DEV), E.view(-1, 4, 4).to(DEV))).view(frames, n_cam, D, fh, fw, 3)
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(frames, n_cam, 64, D, fh, fw, device=DEV, generator=gen)
+    g = torch.randn(frames, 64, 200, 200, device=DEV, generator=gen)
+    ws = hip.pool_workspace(frames, n_cam, D, fh, fw, DEV, grid)
+    px = hip.voxel_pool(x, _native_strides(x), geo, frames, n_cam, D, fh, fw, 64, grid, workspace=ws)
+    rank = ws[:frames * n_cam * D * fh * fw]
+    assert torch.equal(rank, hip.voxel_index(geo, grid, want_idx=False)[0])
+    gx = torch.empty_like(x).permute(0, 1, 3, 4, 5, 2)
+    hip.voxel_pool_bwd(g, rank, frames, n_cam, D, fh, fw, 64, gx)
+    lhs = (px.double() * g.double()).sum().item()
+    rhs = (x.permute(0, 1, 3, 4, 5, 2).double() * gx.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-6 * max(1.0, abs(lhs)) + 1e-2
+    keep = (rank >= 0).view(frames, n_cam, D, fh, fw, 1)
+    assert (gx[~keep.expand_as(gx)] == 0).all()              # out-of-grid points get exact zeros
+    # fused: d<out, g>/d(depth) . depth' + d<out, g>/d(feat) . feat' = <lift_splat(depth', feat) + lift_splat(depth, feat'), g>
+    prob = torch.rand(frames, n_cam, D, fh, fw, device=DEV, generator=gen)
+    feat = torch.randn(frames, n_cam, 64, fh, fw, device=DEV, generator=gen)
+    gd, gf = hip.lift_splat_bwd(g, rank, prob, feat, frames, n_cam, D, fh, fw, 64)
+    out = hip.lift_splat(prob, feat, geo, frames, n_cam, D, fh, fw, 64, grid, workspace=ws)
+    total = (out.double() * g.double()).sum().item()
+    # the form is bilinear: <grad_depth, depth> = <grad_feat, feat> = <out, g>
+    assert abs((gd.double() * prob.double()).sum().item() - total) <= 1e-5 * max(1.0, abs(total)) + 1e-1
+    assert abs((gf.double() * feat.double()).sum().item() - total) <= 1e-5 * max(1.0, abs(total)) + 1e-1
+
+
+def test_lift_splat_bwd_vs_oracle_full_size(hip):
+    cfg = get_preset_cfg('baseline.yml')
+    grid, (res, start, dim) = _grid_of(cfg)
+    frustum = _frustum(cfg)
+    D, fh, fw = frustum.shape[:3]
+    _, K, E, _ = make_inputs(1, 1, 6, with_image=False)
+    geo = ls.get_geometry(frustum, K[0].numpy(), E[0].numpy())
+    dl, ft, _ = make_lifted_features(6, 64, D, (fh, fw), seed=2, materialise=False)
+    prob = hip.depth_softmax(dl.to(DEV))
+    g = torch.randn(1, 64, 200, 200, generator=torch.Generator().manual_seed(12))
+    rank, _ = hip.voxel_index(torch.from_numpy(geo).to(DEV), grid, want_idx=False)
+    gd, gf = hip.lift_splat_bwd(g.to(DEV), rank, prob, ft.to(DEV).view(1, 6, 64, fh, fw), 1, 6, D, fh, fw, 64)
+    wd, wf = ls.lift_splat_backward(g[0].numpy(), prob.double().cpu().numpy(), ft.numpy(), geo[0].reshape(-1, 3), res, start, dim)
+    assert np.abs(gd.view(6, D, fh, fw).cpu().numpy() - wd).max() < 1e-4 * max(1.0, np.abs(wd).max())
+    assert np.abs(gf.view(6, 64, fh, fw).cpu().numpy() - wf).max() < 1e-4 * max(1.0, np.abs(wf).max())
+
+
+def test_projection_seam_under_autograd(hip):
+    """`model.projection_to_birds_eye_view(x, geometry)` with x.requires_grad: the VoxelsSumming.apply seam."""
+    cfg = get_preset_cfg('baseline.yml')
+    _, (res, start, dim) = _grid_of(cfg)
+    model, _ = _model(cfg)
+    lifted, geo = _pool_case(cfg, 6, 1, seed=6)
+    x = lifted.to(DEV).permute(0, 1, 3, 4, 5, 2).requires_grad_(True)
+    bev = model.projection_to_birds_eye_view(x, torch.from_numpy(geo).to(DEV))
+    g = torch.randn(bev.shape, generator=torch.Generator().manual_seed(13))
+    bev.backward(g.to(DEV))
+    want = ls.voxel_pool_backward(g[0].numpy(), geo[0].reshape(-1, 3), res, start, dim)
+    assert np.array_equal(x.grad[0].reshape(-1, 64).cpu().numpy(), want)
+
+
+# ------------------------------------------------------------------------------------------------------
 # convolution kernel at the real shapes vs torch fp32 (CPU)
 # ------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('cin,cout,k,stride', [(64, 64, 3, 1), (64, 32, 1, 1), (64, 64, 7, 2), (32, 32, 3, 1),

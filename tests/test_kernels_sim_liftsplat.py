@@ -223,3 +223,141 @@ def test_quad_path_fused(sim):
     for f in range(frames):
         exact = ls.voxel_pool_exact(ls.lifted_to_points(lifted[f].numpy()), geo[f].reshape(-1, 3), res, start, dim)
         assert np.abs(out[f].numpy() - exact).max() < 5e-6
+
+
+# ------------------------------------------------------------------------------------------------------
+# backward (training): fiery_voxel_pool_bwd / fiery_lift_splat_bwd / fiery_depth_softmax_bwd
+# ------------------------------------------------------------------------------------------------------
+def _bwd_case(seed, W, rolled=False, **kw):
+    frustum, intr, extr, lifted = _small_problem(seed, W=W, **kw)
+    if rolled:
+        roll = torch.tensor([[0.0, -1.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0], [0.0, 0.0, 1.0, 0.0], [0.0, 0.0, 0.0, 1.0]])
+        extr = extr.clone()
+        extr[:, 0] = extr[:, 0] @ roll
+    geo = ls.get_geometry(frustum, intr.numpy(), extr.numpy())
+    grid, (res, start, dim) = _grid([-20.0, 20.0, 1.0], [-16.0, 16.0, 1.0], [-10.0, 10.0, 20.0])
+    frames, n_cam, C, D, H, W = lifted.shape
+    g = torch.randn(frames, C, int(dim[0]), int(dim[1]), generator=torch.Generator().manual_seed(seed + 100))
+    return lifted, geo, grid, (res, start, dim), g
+
+
+@pytest.mark.parametrize('W,layout', [(10, 'native'), (12, 'native'), (12, 'point_major')])
+def test_voxel_pool_bwd_is_a_bit_exact_gather(sim, W, layout):
+    """Both the scalar (W = 10) and the 16-byte (W = 12) form, into the encoder's layout and into a point-major one,
+    with the ranks the forward call left in its workspace."""
+    lifted, geo, grid, (res, start, dim), g = _bwd_case(31, W, rolled=True)
+    frames, n_cam, C, D, H, W = lifted.shape
+    st = lifted.stride()
+    ws = sim.pool_workspace(frames, n_cam, D, H, W, lifted.device, grid)
+    sim.voxel_pool(lifted, (st[0], st[1], st[3], st[4], st[5], st[2]), torch.from_numpy(geo), frames, n_cam, D, H, W, C,
+                   grid, workspace=ws)
+    rank = ws[:frames * n_cam * D * H * W]
+    if layout == 'native':
+        gx = torch.full((frames, n_cam, C, D, H, W), float('nan')).permute(0, 1, 3, 4, 5, 2)
+    else:
+        gx = torch.full((frames, n_cam, D, H, W, C), float('nan'))
+    sim.voxel_pool_bwd(g, rank, frames, n_cam, D, H, W, C, gx)
+    for f in range(frames):
+        want = ls.voxel_pool_backward(g[f].numpy(), geo[f].reshape(-1, 3), res, start, dim)
+        assert np.array_equal(gx[f].reshape(-1, C).numpy(), want)
+    assert (gx != 0).any() and (gx == 0).any()
+
+
+def test_voxel_pool_bwd_with_ranks_from_voxel_index(sim):
+    lifted, geo, grid, (res, start, dim), g = _bwd_case(32, 12, frames=1)
+    frames, n_cam, C, D, H, W = lifted.shape
+    rank, _ = sim.voxel_index(torch.from_numpy(geo), grid, want_idx=False)
+    gx = torch.empty(frames, n_cam, C, D, H, W).permute(0, 1, 3, 4, 5, 2)
+    sim.voxel_pool_bwd(g, rank, frames, n_cam, D, H, W, C, gx)
+    want = ls.voxel_pool_backward(g[0].numpy(), geo[0].reshape(-1, 3), res, start, dim)
+    assert np.array_equal(gx[0].reshape(-1, C).numpy(), want)
+
+
+def test_lift_splat_bwd_matches_oracle(sim):
+    frustum, intr, extr, _ = _small_problem(33, W=12, C=5)
+    frames, n_cam, D, H, W, C = 2, 2, 5, 6, 12, 5
+    geo = ls.get_geometry(frustum, intr.numpy(), extr.numpy())
+    grid, (res, start, dim) = _grid([-20.0, 20.0, 1.0], [-16.0, 16.0, 1.0], [-10.0, 10.0, 20.0])
+    gen = torch.Generator().manual_seed(34)
+    logits = torch.randn(frames * n_cam, D, H, W, generator=gen)
+    feats = torch.randn(frames, n_cam, C, H, W, generator=gen)
+    g = torch.randn(frames, C, int(dim[0]), int(dim[1]), generator=gen)
+    prob = sim.depth_softmax(logits)
+    rank, _ = sim.voxel_index(torch.from_numpy(geo), grid, want_idx=False)
+    gd, gf = sim.lift_splat_bwd(g, rank, prob, feats, frames, n_cam, D, H, W, C)
+    gl = sim.depth_softmax_bwd(prob, gd)
+    p64 = prob.double().view(frames, n_cam, D, H, W).numpy()
+    for f in range(frames):
+        wd, wf = ls.lift_splat_backward(g[f].numpy(), p64[f], feats[f].numpy(), geo[f].reshape(-1, 3), res, start, dim)
+        assert np.abs(gd.view(frames, n_cam, D, H, W)[f].numpy() - wd).max() < 1e-5
+        assert np.abs(gf[f].numpy() - wf).max() < 1e-5
+        wl = p64[f] * (wd - (p64[f] * wd).sum(axis=1, keepdims=True))
+        assert np.abs(gl.view(frames, n_cam, D, H, W)[f].numpy() - wl).max() < 1e-5
+    only_feat = sim.lift_splat_bwd(g, rank, prob, feats, frames, n_cam, D, H, W, C, want_depth=False)
+    assert only_feat[0] is None and torch.equal(only_feat[1], gf)
+
+
+def test_backward_against_the_reference_fixture(sim):
+    """tests/golden/pooling_bwd_small.npz: the reference's own autograd (generator: tests/golden/make_golden.py)."""
+    import os
+    gold = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'pooling_bwd_small.npz'))
+    from tests.helpers import tiny_cfg
+    cfg = tiny_cfg('baseline.yml', bev=16)
+    grid, _ = _grid(cfg.LIFT.X_BOUND, cfg.LIFT.Y_BOUND, cfg.LIFT.Z_BOUND)
+    geo = torch.from_numpy(gold['geometry'])
+    frames, n_cam, D, H, W = geo.shape[:5]
+    C = gold['features'].shape[1]
+    g = torch.from_numpy(gold['grad_bev'])
+    rank, _ = sim.voxel_index(geo, grid, want_idx=False)
+    gx = torch.empty(frames, n_cam, C, D, H, W).permute(0, 1, 3, 4, 5, 2)
+    sim.voxel_pool_bwd(g, rank, frames, n_cam, D, H, W, C, gx)
+    want = torch.from_numpy(gold['grad_lifted']).view(frames, n_cam, C, D, H, W).permute(0, 1, 3, 4, 5, 2)
+    assert torch.equal(gx, want)
+    prob = sim.depth_softmax(torch.from_numpy(gold['depth_logits']))
+    feats = torch.from_numpy(gold['features']).view(frames, n_cam, C, H, W)
+    gd, gf = sim.lift_splat_bwd(g, rank, prob, feats, frames, n_cam, D, H, W, C)
+    gl = sim.depth_softmax_bwd(prob, gd)
+    assert np.abs(gl.numpy() - gold['grad_depth_logits']).max() < 1e-5
+    assert np.abs(gf.reshape(-1, C, H, W).numpy() - gold['grad_features']).max() < 1e-5
+
+
+def test_backward_rejects_bad_arguments(sim):
+    g = torch.zeros(1, 2, 4, 4)
+    rank = torch.zeros(8, dtype=torch.int32)
+    with pytest.raises(native.NativeError):
+        sim.voxel_pool_bwd(g, rank, 1, 1, 1, 2, 4, 0, torch.empty(1, 1, 1, 2, 4, 1))
+
+
+@pytest.mark.parametrize('H,batch', [(14, 7), (28, 7), (28, 14)])
+@pytest.mark.parametrize('flags', [0, native.POOL_DETERMINISTIC])
+def test_pipelined_walk_has_the_bits_of_the_plain_loop(sim, monkeypatch, H, batch, flags):
+    """Columns whose height is an even number of batches take the software-pipelined walk (two alternating row
+    buffers, packed run sums).  A slightly pitched and a rolled camera give two-, three- and many-run columns; enough
+    items per thread that the cross-item prefetch runs.  Against the oracle, and bit for bit against the plain loop
+    (in the order-independent fixed-point mode; the fp32 mode adds the same run sums in a thread order of its own)."""
+    frustum, intr, extr, lifted = _small_problem(40, n_cam=3, D=16, H=H, W=40, C=2, frames=2)      # 480 items, 256 threads
+    roll = torch.tensor([[0.0, -1.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0], [0.0, 0.0, 1.0, 0.0], [0.0, 0.0, 0.0, 1.0]])
+    a = 0.06
+    pitch = torch.tensor([[1.0, 0.0, 0.0, 0.0], [0.0, float(np.cos(a)), -float(np.sin(a)), 0.0],
+                          [0.0, float(np.sin(a)), float(np.cos(a)), 0.0], [0.0, 0.0, 0.0, 1.0]])
+    extr = extr.clone()
+    extr[:, 0] = extr[:, 0] @ roll
+    extr[:, 1] = extr[:, 1] @ pitch
+    frames, n_cam, C, D, H, W = lifted.shape
+    geo = ls.get_geometry(frustum, intr.numpy(), extr.numpy())
+    grid, (res, start, dim) = _grid([-30.0, 30.0, 0.5], [-24.0, 24.0, 0.5], [-10.0, 10.0, 20.0])
+    st = lifted.stride()
+    strides = (st[0], st[1], st[3], st[4], st[5], st[2])
+    monkeypatch.setenv('FIERY_POOL_BATCH', str(batch))
+    monkeypatch.setenv('FIERY_POOL_PIPE', '1')
+    out = sim.voxel_pool(lifted, strides, torch.from_numpy(geo), frames, n_cam, D, H, W, C, grid, flags=flags)
+    monkeypatch.setenv('FIERY_POOL_PIPE', '0')
+    plain = sim.voxel_pool(lifted, strides, torch.from_numpy(geo), frames, n_cam, D, H, W, C, grid, flags=flags)
+    if flags:
+        assert torch.equal(out, plain)
+    else:
+        assert (out - plain).abs().max() < 2e-6
+    for f in range(frames):
+        exact = ls.voxel_pool_exact(ls.lifted_to_points(lifted[f].numpy()), geo[f].reshape(-1, 3), res, start, dim)
+        assert np.abs(out[f].numpy() - exact).max() < 5e-6
+    assert (out != 0).any()

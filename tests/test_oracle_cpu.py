@@ -69,6 +69,32 @@ def test_pooling_small_fixture():
         assert np.abs(exact - gold['bev'][f]).max() < 1e-4       # the reference's own prefix-sum noise
 
 
+def _softmax_backward(prob, grad_prob):
+    return prob * (grad_prob - (prob * grad_prob).sum(axis=1, keepdims=True))
+
+
+def test_pooling_backward_fixture():
+    """The reference's autograd through `projection_to_birds_eye_view` and the lift head's outer product
+    (tests/golden/make_golden.py:golden_pooling_backward_small)."""
+    gold = _load('pooling_bwd_small.npz')
+    cfg = tiny_cfg('baseline.yml', bev=16)
+    res, start, dim = ls.bev_parameters(cfg.LIFT.X_BOUND, cfg.LIFT.Y_BOUND, cfg.LIFT.Z_BOUND)
+    geo = gold['geometry']
+    logits, feats = gold['depth_logits'], gold['features']
+    D = logits.shape[1]
+    prob = torch.from_numpy(logits).softmax(dim=1).numpy()
+    g_lifted = gold['grad_lifted'].reshape(2, 3, 8, D, 8, 12)
+    for f in range(2):
+        gx = ls.voxel_pool_backward(gold['grad_bev'][f], geo[f].reshape(-1, 3), res, start, dim)
+        assert np.array_equal(gx, ls.lifted_to_points(g_lifted[f]))              # a copy: bit-exact
+        gd, gf = ls.lift_splat_backward(gold['grad_bev'][f], prob[3 * f:3 * f + 3], feats[3 * f:3 * f + 3],
+                                        geo[f].reshape(-1, 3), res, start, dim)
+        gl = _softmax_backward(prob[3 * f:3 * f + 3].astype(np.float64), gd)
+        assert np.abs(gl - gold['grad_depth_logits'][3 * f:3 * f + 3]).max() < 1e-5
+        assert np.abs(gf - gold['grad_features'][3 * f:3 * f + 3]).max() < 1e-5
+    assert np.abs(gold['grad_lifted']).max() > 0
+
+
 def _oracle_forward(cfg, B, n_cam, with_labels=False, with_noise=False):
     from fiery_amd.model import Fiery
     torch.manual_seed(0)

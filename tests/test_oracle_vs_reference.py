@@ -48,6 +48,26 @@ def test_geometry_and_pooling_equal_reference_bitwise(ref):
         assert np.array_equal(got, bev_ref[f])
 
 
+def test_pooling_backward_equals_reference_autograd_bitwise(ref):
+    """`VoxelsSumming.backward` + the autograd graph around it (fiery.py:233-271), run by the reference itself."""
+    cfg = tiny_cfg('baseline.yml', bev=16)
+    torch.manual_seed(0)
+    m = ref.Fiery(cfg)
+    _, K, E, _ = make_inputs(1, 2, 3, with_image=False)
+    _, _, lifted = make_lifted_features(6, 8, m.depth_channels, (8, 12), seed=9)
+    x = lifted.view(2, 3, 8, m.depth_channels, 8, 12).permute(0, 1, 3, 4, 5, 2).clone().requires_grad_(True)
+    with torch.no_grad():
+        geo = m.get_geometry(K[0], E[0])
+    bev = m.projection_to_birds_eye_view(x, geo)
+    grad_bev = torch.randn(bev.shape, generator=torch.Generator().manual_seed(5))
+    bev.backward(grad_bev)
+    res, start, dim = ls.bev_parameters(cfg.LIFT.X_BOUND, cfg.LIFT.Y_BOUND, cfg.LIFT.Z_BOUND)
+    for f in range(2):
+        got = ls.voxel_pool_backward(grad_bev[f].numpy(), geo[f].numpy().reshape(-1, 3), res, start, dim)
+        assert np.array_equal(got, x.grad[f].numpy().reshape(-1, 8))
+    assert (x.grad != 0).any()
+
+
 def test_warp_matches_reference(ref):
     g = torch.Generator().manual_seed(1)
     x = torch.randn(2, 3, 4, 10, 12, generator=g)

@@ -119,6 +119,21 @@ def bench_pool(lib, reps, frames=9, tiles=(0,)):
               flush=True)
 
 
+    # backward (training): grad_x = gather of grad_out through the ranks the forward call left in the workspace.
+    # algorithmic bytes: every grad_x element written once + the ranks + the dense gradient read once
+    gx = torch.empty_like(x).permute(0, 1, 3, 4, 5, 2)
+    gout = torch.randn(frames, 64, 200, 200, device=DEV)
+    rk = ws[:n_pts]
+    us = timed(lambda: lib.voxel_pool_bwd(gout, rk, frames, 6, D, fh, fw, 64, gx), reps)
+    algo_b = 4.0 * 64 * n_pts + 4.0 * n_pts + 4.0 * 64 * frames * 200 * 200
+    print(f'pool bwd frames={frames}: {us:8.1f} us/op  {us / frames:6.1f} us/frame  algorithmic {algo_b / 1e6:.1f} MB -> '
+          f'{algo_b / us / 1e3:7.1f} GB/s ({algo_b / us / 1e3 / 8000:.1%} of 8 TB/s)', flush=True)
+    prob = torch.rand(frames, 6, D, fh, fw, device=DEV)
+    feat = torch.randn(frames, 6, 64, fh, fw, device=DEV)
+    us = timed(lambda: lib.lift_splat_bwd(gout, rk, prob, feat, frames, 6, D, fh, fw, 64), reps)
+    print(f'lift-splat bwd frames={frames}: {us:8.1f} us/op  {us / frames:6.1f} us/frame', flush=True)
+
+
 CONV_CASES = [  # (k, stride, cin, cout, n_img, H, W, residual)
     (3, 1, 128, 128, 3, 200, 200, False),
     (3, 1, 128, 64, 3, 200, 200, False),
