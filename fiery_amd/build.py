@@ -15,8 +15,17 @@ SOURCES = [
     ('lift_splat.hip', ['-ffp-contract=off']),
     ('warp.hip', []),
     ('conv_igemm.hip', []),
+    # one translation unit per tile shape of the convolution kernel: they compile side by side
+    ('conv_tile_128x32.hip', []),
+    ('conv_tile_128x64.hip', []),
+    ('conv_tile_128x128.hip', []),
+    ('conv_tile_128x128_rest.hip', []),
+    ('conv_tile_64x64.hip', []),
+    ('conv_tile_64x128.hip', []),
     ('aux_ops.hip', []),
 ]
+# FIERY_CONV_TUNING=1: also build the convolution's clock-probe / priority variants (tools/microbench.py conv --clk)
+TUNING = ['-DFIERY_CONV_TUNING=1'] if os.environ.get('FIERY_CONV_TUNING') == '1' else ['-DFIERY_CONV_TUNING=0']
 COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + INCLUDE, '-I' + CSRC, '-x', 'hip']
 
 
@@ -30,14 +39,15 @@ def _stale(target, deps):
 def build(force=False, verbose=True):
     objdir = os.path.join(HERE, 'build')
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, 'common.h'), os.path.join(INCLUDE, 'fiery_hip.h')]
+    headers = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_igemm_kernel.h'),
+               os.path.join(CSRC, 'fiery_gfx950.h'), os.path.join(INCLUDE, 'fiery_hip.h')]
     objs, jobs = [], []
     for name, extra in SOURCES:
         src = os.path.join(CSRC, name)
         obj = os.path.join(objdir, name + '.o')
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            cmd = [HIPCC] + COMMON + extra + ['-c', src, '-o', obj]
+            cmd = [HIPCC] + COMMON + TUNING + extra + ['-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)
             jobs.append((name, subprocess.Popen(cmd)))       # translation units compile side by side

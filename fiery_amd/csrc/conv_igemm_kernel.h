@@ -1,0 +1,869 @@
+// Implicit-GEMM convolution on the gfx950 matrix cores, fp32 in / fp32 accumulate.
+//
+// Replaces the cuDNN conv2d/conv3d + batch_norm + activation (+ residual, + GRU gate arithmetic) call
+// chains of the reference's BEV stack (fiery/layers/convolutions.py:9-168, fiery/layers/temporal.py:10-281,
+// fiery/models/decoder.py:53-91).  One kernel covers 1x1, 3x3 (stride 1/2), 7x7 stride 2 and the causal
+// (kT,3,3) temporal convolutions: the GEMM is  out[pixel][cout] = sum_k A[pixel][k] * W[k][cout]  with
+// k = (tap, input channel), A gathered on the fly from pixel-major (NHWC) activations.
+//
+// Mapping to CDNA4:
+//   * v_mfma_f32_32x32x2_f32 - exact fp32 products, fp32 accumulate (the 1e-4 parity budget rules out
+//     bf16 for this configuration); 64 cycles per instruction per SIMD, so the matrix pipe is the
+//     bound and everything else is sized to stay out of its way.
+//   * workgroup = 4 wavefronts, tile = 128 pixels x BN couts (BN = 64: 2x2 wavefronts of 64x32;
+//     BN = 32: 4x1 wavefronts of 32x32), K advanced 32 at a time through double-buffered LDS, one
+//     barrier per step; global loads for step k+1 are in flight while step k runs on the MFMAs.
+//   * A tile is stored [pixel][32 k] with the 16-byte slot index XOR-ed by (pixel>>1)&7, so the
+//     ds_read_b128 of 32 consecutive pixels at one k-slot is bank-conflict free; each b128 feeds four
+//     MFMA k-steps (the K order inside a step is permuted identically for A and W).
+//   * the weight tile is pre-packed on the host side in exactly its LDS image ([k/4][cout][k%4], so a
+//     lane's four k of an MFMA group are one ds_read_b128): one contiguous 4/8/16 KiB copy per step.
+//   * input channels are a virtual concat of two tensors (GRU [x, h], temporal-block path concat), and
+//     the epilogue applies bias / folded BatchNorm / activation / residual / GRU gate math in registers.
+//
+// This header holds the kernel template; every tile shape is instantiated in a translation unit of its own
+// (conv_tile_<BM>x<BN>.hip) so that the five shapes compile side by side, and conv_igemm.hip holds the C ABI.
+#pragma once
+#include "common.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
+
+namespace fiery {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;    // k per LDS stage (4 units of 8 input channels)
+constexpr int kMaxCinUnits = 64;
+struct SrcP {
+    const float* ptr;
+    int ld, units;
+    long long bstride, tstride;
+};
+struct TensP {
+    float* ptr;
+    int ld;
+    long long istride;
+};
+struct HeadsP {
+    const float* w;
+    const float* bias;
+    int n_out;
+    int group[FIERY_MAX_HEAD_OUTPUTS], sigmoid[FIERY_MAX_HEAD_OUTPUTS];
+    float* out[FIERY_MAX_HEAD_OUTPUTS];
+    long long istride[FIERY_MAX_HEAD_OUTPUTS];
+};
+struct ConvP {
+    SrcP src[2];
+    int Hin, Win, Hout, Wout, n_img, Tout, tout0, tinadd;
+    int kT, kH, kW, stride, padH, padW;
+    const float* w;
+    int cout_pad, k_chunks, n_units, cin_units;
+    const float* scale;
+    const float* shift;
+    const float* img_bias;
+    int act, epi, res_pre;
+    TensP res, out, out2, aux0, aux1;
+    int cout_store;
+    long long M;
+    const float* w2;      // chained 1x1 (BN = 32 only)
+    const float* scale2;
+    const float* shift2;
+    int act2;
+    int vec_epilogue;     // destinations / residual / bias rows are 16-byte addressable
+    int bias_border;      // img_bias holds nine rows per image, chosen by the output pixel's border class
+    HeadsP heads;         // FIERY_EPI_HEADS
+};
+
+// kernel variants of one tile shape
+enum ConvVariant {
+    kConvGeneric = 0,      // per-lane addressed K loop: any channel layout
+    kConvAligned = 1,      // scalar-addressed K loop (every tap holds whole 32-channel stages of one source)
+    kConvSmallCin = 2,     // fewer than four 8-channel units per tap
+    kConvClock = 3,        // tuning builds (FIERY_CONV_TUNING): clock/phase probe, generic loop
+    kConvClockAligned = 4, //                                      clock/phase probe, scalar-addressed loop
+    kConvPrio = 5,         //                                      wave-priority experiment
+};
+// one launcher per tile shape, each in its own translation unit; returns false when the variant is not built
+bool conv_launch_128x32(const ConvP& p, dim3 grid, hipStream_t stream, int variant, unsigned long long* clk);
+bool conv_launch_128x64(const ConvP& p, dim3 grid, hipStream_t stream, int variant, unsigned long long* clk);
+bool conv_launch_128x128(const ConvP& p, dim3 grid, hipStream_t stream, int variant, unsigned long long* clk);
+bool conv_launch_128x128_rest(const ConvP& p, dim3 grid, hipStream_t stream, int variant, unsigned long long* clk);
+bool conv_launch_64x64(const ConvP& p, dim3 grid, hipStream_t stream, int variant, unsigned long long* clk);
+bool conv_launch_64x128(const ConvP& p, dim3 grid, hipStream_t stream, int variant, unsigned long long* clk);
+
+#ifdef FIERY_CONV_KERNEL_TU
+namespace {
+
+// tuning aid (FIERY_CONV_CLKPROBE): {sum of shader cycles, sum of 100 MHz ticks} over the K loops of sampled workgroups;
+// a __device__ global rather than a ConvP member so that the production kernel's argument block (and with it its
+// register allocation, which is touchy) is exactly what it is without the probe
+__device__ unsigned long long* g_clk_probe = nullptr;
+// what a tap outside the image (zero padding) or past the end of K reads
+__device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};   // (not const: it must live in the global address space like the sources, or the select makes the loads flat)
+
+__device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// BM output pixels x BN couts per workgroup: (128, 32|64|128) and (64, 64|128).  The 64-pixel tiles exist for
+// launches whose 128-pixel tile count would leave a badly filled last wave of workgroups.
+// Workgroups of one tile shape that fit a CU, as its LDS (two A stages + two W stages) allows, capped where the tile's
+// registers would not follow: one wavefront per workgroup and SIMD, so this is also the waves-per-SIMD target that the
+// register allocation is held to (without it the compiler aims one notch too high for the 64 x 128 tile and spills).
+constexpr int conv_waves_per_simd(int bm, int bn) {
+    const int by_lds = 163840 / ((2 * bm * BK + 2 * BK * bn) * 4);
+    const int cap = (bm == 64 && bn == 64) ? 4 : 3;
+    return by_lds < cap ? by_lds : cap;
+}
+
+template <int BM, int BN, bool CLK = false, int PRIO = 0, bool SMALLCIN = false, bool ALIGNED = false>
+__global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm(ConvP p) {
+    if constexpr (PRIO == 1) {
+        // experiment: workgroups that share a CU (dispatch order puts b and b + 256 on one CU first) get different wave
+        // priorities, so that they do not march through their MFMA and load/store phases in lockstep
+        switch ((blockIdx.x >> 8) % 3) {
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: break;
+        }
+    }
+    constexpr int NA = BM / 32;            // A-gather loads (16 B each) per thread and stage
+    constexpr int WN = BN >= 64 ? 2 : 1;   // wavefronts along couts
+    constexpr int WM = 4 / WN;             // wavefronts along pixels
+    constexpr int MT = BM / (32 * WM);     // 32-pixel MFMA tiles per wavefront   (BN=32: 1, else 2)
+    constexpr int NT = BN / (32 * WN);     // 32-cout MFMA tiles per wavefront    (BN=128: 2, else 1)
+    constexpr int BLOADS = (BK * BN / 4) / 256;
+
+    // one LDS block: two A stages, two W stages; the epilogue reuses it as a BM x BN staging tile
+    __shared__ __attribute__((aligned(16))) float smem[2 * BM * BK + 2 * BK * BN];
+    float (*As)[BM * BK] = reinterpret_cast<float (*)[BM * BK]>(smem);
+    float (*Bs)[BK * BN] = reinterpret_cast<float (*)[BK * BN]>(smem + 2 * BM * BK);
+    static_assert(BM * BN <= 2 * BM * BK + 2 * BK * BN, "staging tile must fit");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int wm = wv % WM, wn = wv / WM;
+    const int m = lane & 31, hi = lane >> 5;
+    const int tile_n = blockIdx.y;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8, so give every XCD a contiguous run of pixel
+    // tiles - neighbouring tiles share their 3x3 halo rows through that XCD's L2 instead of re-fetching them
+    int tile_m;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        tile_m = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int pix0 = tile_m * BM;             // M < 2^31 is checked on the host: 32-bit pixel arithmetic throughout
+    const int HWout = p.Hout * p.Wout;
+    const int M = static_cast<int>(p.M);
+
+    // ---- this thread's share of the A gather: one 16-byte slot of 4 pixels per stage ----------------
+    // Everything that does not change from stage to stage is computed once here, as 32-bit element offsets
+    // (the host checks that every source spans < 2^31 floats); a stage then costs one add and a bounds
+    // predicate per load, and the (tap, channel-unit) of the thread's slot advances incrementally.
+    const int f4 = tid & 7;                // logical 16-byte slot inside the 32-k row
+    const int prow = tid >> 3;             // 0..31
+    int py0[NA], px0[NA], ptmin[NA], poff0[NA], poff1[NA];
+    bool pvalid[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int gp = pix0 + prow + 32 * j;
+        pvalid[j] = gp < M;
+        const int g = pvalid[j] ? gp : 0;
+        const int o = g / HWout;
+        const int rem = g - o * HWout;
+        const int y = rem / p.Wout, x = rem - y * p.Wout;
+        const int b = o / p.Tout, tl = o - b * p.Tout;
+        py0[j] = y * p.stride - p.padH;
+        px0[j] = x * p.stride - p.padW;
+        ptmin[j] = tl + p.tout0 - (p.kT - 1);                       // absolute time of the dt = 0 tap
+        const int pos = py0[j] * p.Win + px0[j];
+        poff0[j] = static_cast<int>(b * p.src[0].bstride + (tl + p.tinadd - (p.kT - 1)) * p.src[0].tstride) + pos * p.src[0].ld;
+        poff1[j] = static_cast<int>(b * p.src[1].bstride + (tl + p.tinadd - (p.kT - 1)) * p.src[1].tstride) + pos * p.src[1].ld;
+    }
+    const int taps = p.kT * p.kH * p.kW;
+    const int c_Win = p.Win, c_Hin = p.Hin, c_cin_units = p.cin_units, c_kW = p.kW, c_kH = p.kH, c_k_chunks = p.k_chunks;
+    // the two sources' fields as scalars (selecting between p.src[0].x and p.src[1].x directly turns into a dynamic
+    // index into the argument block, which then has to live in scratch)
+    const float* const src0_ptr = p.src[0].ptr;
+    const float* const src1_ptr = p.src[1].ptr;
+    const int src0_ld = p.src[0].ld, src1_ld = p.src[1].ld, src0_units = p.src[0].units;
+    const int src0_ts = static_cast<int>(p.src[0].tstride), src1_ts = static_cast<int>(p.src[1].tstride);
+
+    float4 areg0, areg1, areg2, areg3;          // named, like breg*: an indexed array that lives across iterations ends up in scratch
+    areg0 = areg1 = areg2 = areg3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 breg0 = make_float4(0.f, 0.f, 0.f, 0.f), breg1 = breg0, breg2 = breg0, breg3 = breg0;
+
+    // ---- the side work of a stage, cut into pieces that go between two MFMAs ------------------------------------------
+    // Measured on gfx950 (tools/probe/mfma_valu_probe.hip): a VALU instruction issued between two fp32 MFMAs does NOT run
+    // in their shadow - it takes ~3-6 cycles of the same pipe - so the K loop is built to need as few vector ALU
+    // instructions as possible, not merely to hide them:
+    //   * ALIGNED (every tap holds a whole number of stages from one source - all the big layers): the (tap, channel
+    //     group) of a stage is the same for the whole workgroup, so it lives in SGPRs and is advanced by the scalar unit;
+    //     a thread's pixel offsets never change; the tap's offset goes into the buffer load's scalar offset; zero padding
+    //     is the buffer's out-of-range rule (an invalid tap gets an offset beyond the descriptor's size and reads 0).
+    //     Per 16-byte load that leaves one mask test and one select on the vector ALU.
+    //   * otherwise the thread's own (tap, unit) advances on the vector ALU, and an invalid tap reads the zero page.
+    // Both ways the stage body is straight-line code, and the LDS addresses of a stage are thread constants plus
+    // immediates because the two buffers are two copies of the body.
+    constexpr int N_PIECES = 2 * (NA + BLOADS) + 4;
+    //   generic path state
+    int u_cc = 0, u_tap = 0, u_dt = 0, u_dy = 0, u_dx = 0;
+    const float* wnext = p.w + static_cast<long long>(tile_n) * p.k_chunks * (BK * BN) + tid * 4;
+    const float* const wfirst = wnext;
+    int ld_stage = 0;
+    const float* const zero_page = g_zero_page;
+    bool ld_valid = false, ld_second = false;
+    const float* ld_base = nullptr;
+    int ld_tap_off = 0;
+    //   aligned path state
+    int voff0[NA], voff1[NA];                   // this thread's pixels in the two sources, bytes, >= 0
+    unsigned long long vmask[NA];               // bit t: tap t of pixel j lies inside the image (and the pixel exists)
+    int s_tap = 0, s_g = 0, s_dt = 0, s_dy = 0, s_dx = 0;      // wave-uniform
+    int s_off = 0;
+    bool s_second = false;
+    __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src0_ptr), 0, 0, 0x00020000);
+    const int s_groups = c_cin_units >> 2, s_groups0 = src0_units >> 2;
+    if constexpr (ALIGNED) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int gp = pix0 + prow + 32 * j;
+            const bool pv = gp < M;
+            const int g = pv ? gp : 0;
+            const int o = g / HWout;
+            const int rem = g - o * HWout;
+            const int y = rem / p.Wout, x = rem - y * p.Wout;
+            const int b = o / p.Tout, tl = o - b * p.Tout;
+            const int sp = (y * p.stride) * c_Win + x * p.stride;
+            const int kofs = (f4 >> 1) * 8 + (f4 & 1) * 4;
+            voff0[j] = 4 * (static_cast<int>(b * p.src[0].bstride + (tl + p.tinadd) * p.src[0].tstride) + sp * src0_ld + kofs);
+            voff1[j] = 4 * (static_cast<int>(b * p.src[1].bstride + (tl + p.tinadd) * p.src[1].tstride) + sp * src1_ld + kofs);
+            unsigned rowm = 0, colm = 0, tm = 0;
+            for (int dy = 0; dy < c_kH; ++dy)
+                rowm |= (static_cast<unsigned>(y * p.stride - p.padH + dy) < static_cast<unsigned>(c_Hin) ? 1u : 0u) << dy;
+            for (int dx = 0; dx < c_kW; ++dx)
+                colm |= (static_cast<unsigned>(x * p.stride - p.padW + dx) < static_cast<unsigned>(c_Win) ? 1u : 0u) << dx;
+            for (int dt = 0; dt < p.kT; ++dt) tm |= ((tl + p.tout0 - (p.kT - 1) + dt) >= 0 ? 1u : 0u) << dt;
+            unsigned long long mk = 0;
+            int tap = 0;
+            for (int dt = 0; dt < p.kT; ++dt)
+                for (int dy = 0; dy < c_kH; ++dy)
+                    for (int dx = 0; dx < c_kW; ++dx, ++tap)
+                        mk |= static_cast<unsigned long long>((tm >> dt) & (rowm >> dy) & (colm >> dx) & 1u) << tap;
+            vmask[j] = pv ? mk : 0ull;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            voff0[j] = voff1[j] = 0;
+            vmask[j] = 0;
+        }
+        // running decode of this thread's unit: u = stage*4 + (f4 >> 1) = tap * cin_units + cc
+        const int u = f4 >> 1;
+        u_tap = u / p.cin_units;
+        u_cc = u - u_tap * p.cin_units;
+        const int khw = p.kH * p.kW;
+        u_dt = u_tap / khw;
+        const int r = u_tap - u_dt * khw;
+        u_dy = r / p.kW;
+        u_dx = r - u_dy * p.kW;
+    }
+    // weights: one descriptor for this cout tile's packed image; thread t reads bytes [16 t, 16 t + 16) of every 4 KiB
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.w + static_cast<long long>(tile_n) * p.k_chunks * (BK * BN)), 0, 0x7fffffff, 0x00020000);
+    const int w_voff = tid * 16;
+    int w_soff = 0;
+    auto to_float4 = [](auto raw) {
+        float4 f;
+        __builtin_memcpy(&f, &raw, 16);
+        return f;
+    };
+
+    // (the scalar unit issues in order with the MFMAs: the stage's scalar bookkeeping is cut in three so that no single
+    // gap between two MFMAs has to take all of it)
+    int s_ld = 0, s_ts = 0;
+    const float* s_base = nullptr;
+    auto load_setup = [&](int part) {
+        if constexpr (ALIGNED) {
+            if (part == 0) {
+                s_second = s_g >= s_groups0;
+                s_base = s_second ? src1_ptr : src0_ptr;
+                s_ld = s_second ? src1_ld : src0_ld;
+                s_ts = s_second ? src1_ts : src0_ts;
+                w_soff = (ld_stage < c_k_chunks ? ld_stage : c_k_chunks - 1) * (BK * BN * 4);      // past the end: repeat
+            } else if (part == 1) {
+                // the descriptor's base sits (kT-1) frames and (padH, padW) pixels before the source, so that the
+                // tap's offset below is never negative; its size only has to exceed every real offset
+                const float* base = s_base - ((p.kT - 1) * s_ts + (p.padH * c_Win + p.padW) * s_ld);
+                s_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+            } else {
+                s_off = 4 * (s_dt * s_ts + (s_dy * c_Win + s_dx) * s_ld + (s_g - (s_second ? s_groups0 : 0)) * 32);
+            }
+        } else if (part == 0) {
+            ld_valid = u_tap < taps;
+            ld_second = u_cc >= src0_units;
+            ld_base = ld_second ? src1_ptr : src0_ptr;
+            const int ld = ld_second ? src1_ld : src0_ld;
+            const int tstride = ld_second ? src1_ts : src0_ts;
+            ld_tap_off = u_dt * tstride + (u_dy * c_Win + u_dx) * ld + (u_cc - (ld_second ? src0_units : 0)) * 8 + (f4 & 1) * 4;
+        }
+    };
+    auto gather = [&](int j) {
+        if constexpr (ALIGNED) {
+            const bool ok = ((vmask[j] >> (s_tap < 63 ? s_tap : 63)) & 1ull) != 0;
+            int voff = s_second ? voff1[j] : voff0[j];
+            voff = ok ? voff : static_cast<int>(0x80000000u);               // beyond the descriptor: reads as zero
+            return to_float4(__builtin_amdgcn_raw_buffer_load_b128(s_rsrc, voff, s_off, 0));
+        } else {
+            const int iy = py0[j] + u_dy, ix = px0[j] + u_dx;
+            // (bitwise &: a short-circuit && would come back as a branch around the rest)
+            const bool ok = ld_valid & pvalid[j] & (static_cast<unsigned>(iy) < static_cast<unsigned>(c_Hin)) &
+                            (static_cast<unsigned>(ix) < static_cast<unsigned>(c_Win)) & ((ptmin[j] + u_dt) >= 0);
+            const float* src = ok ? ld_base + ((ld_second ? poff1[j] : poff0[j]) + ld_tap_off) : zero_page;
+            return *reinterpret_cast<const float4*>(src);
+        }
+    };
+    auto load_a = [&](int j) {
+        if (j == 0) areg0 = gather(0);
+        else if (j == 1) areg1 = gather(1);
+        else if (j == 2) areg2 = gather(NA > 2 ? 2 : 0);
+        else areg3 = gather(NA > 2 ? 3 : 0);
+    };
+    auto load_b = [&](int k) {
+        float4 v;
+        if constexpr (ALIGNED) {
+            v = to_float4(__builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff, w_soff + k * 4096, 0));
+        } else {
+            const float* wsrc = ld_stage < c_k_chunks ? wnext : wfirst;  // past the end: any valid address
+            v = *reinterpret_cast<const float4*>(wsrc + k * 1024);
+        }
+        if (k == 0) breg0 = v;
+        else if (k == 1) breg1 = v;
+        else if (k == 2) breg2 = v;
+        else breg3 = v;
+    };
+    auto advance = [&]() {
+        ++ld_stage;
+        if constexpr (ALIGNED) {                          // all on the scalar unit
+            ++s_g;
+            const bool cg = s_g == s_groups;
+            s_g = cg ? 0 : s_g;
+            s_tap += cg ? 1 : 0;
+            s_dx += cg ? 1 : 0;
+            const bool cx = s_dx == c_kW;
+            s_dx = cx ? 0 : s_dx;
+            s_dy += cx ? 1 : 0;
+            const bool cy = s_dy == c_kH;
+            s_dy = cy ? 0 : s_dy;
+            s_dt += cy ? 1 : 0;
+        } else {
+            wnext += BK * BN;
+            u_cc += 4;                                    // one stage = 4 units, carrying into the tap and its (dt, dy, dx)
+            if constexpr (SMALLCIN) {
+                while (u_cc >= c_cin_units) {             // fewer than four units per tap: several carries per stage
+                    u_cc -= c_cin_units;
+                    ++u_tap;
+                    if (++u_dx == c_kW) {
+                        u_dx = 0;
+                        if (++u_dy == c_kH) {
+                            u_dy = 0;
+                            ++u_dt;
+                        }
+                    }
+                }
+            } else {                                      // cin_units >= 4: at most one carry, as selects
+                const bool carry = u_cc >= c_cin_units;
+                u_cc -= carry ? c_cin_units : 0;
+                u_tap += carry ? 1 : 0;
+                u_dx += carry ? 1 : 0;
+                const bool cx = u_dx == c_kW;
+                u_dx = cx ? 0 : u_dx;
+                u_dy += cx ? 1 : 0;
+                const bool cy = u_dy == c_kH;
+                u_dy = cy ? 0 : u_dy;
+                u_dt += cy ? 1 : 0;
+            }
+        }
+    };
+    // LDS addresses: thread constants (floats from smem) + compile-time offsets
+    const int a_st = prow * BK + ((f4 ^ ((prow >> 1) & 7)) << 2);                     // + 32 j BK + buf BM BK
+    const int b_st = 2 * BM * BK + tid * 4;                                            // + 1024 k + buf BK BN
+    const int a_row = wm * (32 * MT) + m;
+    int a_rd[4];                                                                       // + 32 t BK + buf BM BK
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a_rd[q] = a_row * BK + (((2 * q + hi) ^ ((a_row >> 1) & 7)) << 2);
+    const int b_rd = 2 * BM * BK + (hi * BN + wn * (32 * NT) + m) * 4;                 // + (2 q BN + 32 nt) 4 + buf BK BN
+    auto store_a = [&](int buf, int j) {
+        *reinterpret_cast<float4*>(&smem[a_st + 32 * j * BK + buf * BM * BK]) = j == 0 ? areg0 : j == 1 ? areg1 : j == 2 ? areg2 : areg3;
+    };
+    auto store_b = [&](int buf, int k) {
+        *reinterpret_cast<float4*>(&smem[b_st + 1024 * k + buf * BK * BN]) = k == 0 ? breg0 : k == 1 ? breg1 : k == 2 ? breg2 : breg3;
+    };
+    auto lds_a = [&](int buf, int q, int t) {
+        return *reinterpret_cast<const float4*>(&smem[a_rd[q] + 32 * t * BK + buf * BM * BK]);
+    };
+    auto lds_b = [&](int buf, int q, int nt) {
+        return *reinterpret_cast<const float4*>(&smem[b_rd + (2 * q * BN + 32 * nt) * 4 + buf * BK * BN]);
+    };
+    // piece i of a stage's side work, i = 0 .. N_PIECES-1; the stage running out of `buf` fills the other buffer
+    auto side_piece = [&](int buf, int i) {
+        constexpr int S0 = NA + BLOADS;            // first setup piece
+        if (i < NA) store_a(buf ^ 1, i);
+        else if (i < S0) store_b(buf ^ 1, i - NA);
+        else if (i < S0 + 3) load_setup(i - S0);
+        else if (i < S0 + 3 + NA) load_a(i - (S0 + 3));
+        else if (i < S0 + 3 + NA + BLOADS) load_b(i - (S0 + 3 + NA));
+        else advance();
+    };
+
+    v16f acc[MT * NT];
+#pragma unroll
+    for (int t = 0; t < MT * NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    unsigned long long clk_c0 = 0, clk_w0 = 0;
+    if constexpr (CLK) {
+        if (tid == 0 && (blockIdx.x & 15) == 0) {
+            clk_c0 = clock64();
+            clk_w0 = wall_clock64();
+        }
+    }
+    // ---- software pipeline ------------------------------------------------------------------------------------
+    // While stage s is multiplied out of LDS buffer s&1, stage s+1 sits in registers (requested one iteration
+    // earlier, so its latency is long gone) and is written to the other buffer, and stage s+2 is requested into
+    // the registers that frees.  The pieces are dealt out evenly between the MFMAs of the running stage.
+    // prologue: stage 0 -> LDS buffer 0, stage 1 -> registers (it stays in flight across the barrier)
+#pragma unroll
+    for (int i = NA + BLOADS; i < N_PIECES; ++i) side_piece(1, i);
+#pragma unroll
+    for (int i = 0; i < N_PIECES; ++i) side_piece(1, i);
+    __syncthreads();
+
+    constexpr int N_MFMA = 16 * MT * NT;
+    auto stage_body = [&](auto buf_c) {
+        constexpr int buf = decltype(buf_c)::value;
+        // operands of k-group q+1 are read from LDS while the MFMAs of group q run (one b128 per 32x4 operand
+        // block: A rows are [pixel][k], the W image is [k/4][cout][k%4])
+        float4 a_cur[MT], b_cur[NT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) a_cur[t] = lds_a(buf, 0, t);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b_cur[nt] = lds_b(buf, 0, nt);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 a_nxt[MT], b_nxt[NT];
+            if (q < 3) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t) a_nxt[t] = lds_a(buf, q + 1, t);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b_nxt[nt] = lds_b(buf, q + 1, nt);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // this lane's k for the step: 8q + 4hi + j, for its A element and its W element alike
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float bv = j == 0 ? b_cur[nt].x : j == 1 ? b_cur[nt].y : j == 2 ? b_cur[nt].z : b_cur[nt].w;
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) {
+                        const float av = j == 0 ? a_cur[t].x : j == 1 ? a_cur[t].y : j == 2 ? a_cur[t].z : a_cur[t].w;
+                        acc[t * NT + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t * NT + nt], 0, 0, 0);
+                        // MFMA slot s of the stage is followed by the side-work pieces dealt to it (spread evenly)
+                        const int s = ((q * 4 + j) * NT + nt) * MT + t;
+#pragma unroll
+                        for (int i = 0; i < N_PIECES; ++i)
+                            if ((i * N_MFMA) / N_PIECES == s) side_piece(buf, i);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            if (q < 3) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t) a_cur[t] = a_nxt[t];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b_cur[nt] = b_nxt[nt];
+            }
+        }
+        __syncthreads();
+    };
+    {
+        int chunk = 0;
+        for (; chunk + 1 < c_k_chunks; chunk += 2) {
+            stage_body(std::integral_constant<int, 0>{});
+            stage_body(std::integral_constant<int, 1>{});
+        }
+        if (chunk < c_k_chunks) stage_body(std::integral_constant<int, 0>{});
+    }
+    if constexpr (CLK) {
+        // effective shader clock under this kernel's load = cycles / ticks * 100 MHz
+        if (tid == 0 && (blockIdx.x & 15) == 0 && g_clk_probe) {
+            atomicAdd(g_clk_probe, static_cast<unsigned long long>(clock64() - clk_c0));
+            atomicAdd(g_clk_probe + 1, static_cast<unsigned long long>(wall_clock64() - clk_w0));
+            atomicAdd(g_clk_probe + 6, 1ull);
+        }
+    }
+
+    // ---- staged epilogue (plain mode): accumulators -> LDS tile [pixel][cout] -> 16-byte rows -----------------
+    // A lane holds one cout for 16 scattered pixel rows, so storing from registers means 4-byte accesses 128 B
+    // at a time; going through LDS turns the tile into full rows: every residual load and output store is a
+    // 16-byte, unit-stride access.  `store_rows(width, ...)` finishes a staged tile of `width` couts.
+    auto store_rows = [&](int width, int cout0, const float* scale, const float* shift, int act, bool with_bias) {
+        const int c4n = width >> 2;                                 // 16-byte chunks per pixel row
+        const int rows_per_pass = 256 / c4n;
+        const int c4 = tid % c4n, prow0 = tid / c4n;
+        const int co = cout0 + c4 * 4;
+        const int half = p.cout_pad >> 1;
+        if (p.epi != FIERY_EPI_GRU_GATES && co >= p.cout_store) return;    // padding couts are never stored
+        const float4 sc = *reinterpret_cast<const float4*>(scale + co);
+        const float4 sh = *reinterpret_cast<const float4*>(shift + co);
+        int gp = pix0 + prow0;
+        int o = gp / HWout, ppi = gp - o * HWout;
+        for (int pl = prow0; pl < BM; pl += rows_per_pass) {
+            if (gp >= M) break;
+            float4 v = *reinterpret_cast<const float4*>(&smem[pl * width + c4 * 4]);
+            if (with_bias && p.img_bias) {
+                long long brow = o;
+                if (p.bias_border) {                        // 3x3 class of (y, x): which taps fall inside the image
+                    const int y = ppi / p.Wout, x = ppi - y * p.Wout;
+                    brow = brow * 9 + (y == 0 ? 0 : y == p.Hout - 1 ? 2 : 1) * 3 + (x == 0 ? 0 : x == p.Wout - 1 ? 2 : 1);
+                }
+                const float4 b = *reinterpret_cast<const float4*>(p.img_bias + brow * p.cout_pad + co);
+                v.x += b.x;  v.y += b.y;  v.z += b.z;  v.w += b.w;
+            }
+            v.x = fmaf(v.x, sc.x, sh.x);  v.y = fmaf(v.y, sc.y, sh.y);  v.z = fmaf(v.z, sc.z, sh.z);  v.w = fmaf(v.w, sc.w, sh.w);
+            const long long pp = ppi;
+            if (p.epi == FIERY_EPI_PLAIN) {
+                float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.res.ptr) r = *reinterpret_cast<const float4*>(p.res.ptr + o * p.res.istride + pp * p.res.ld + co);
+                if (p.res_pre) { v.x += r.x;  v.y += r.y;  v.z += r.z;  v.w += r.w; }
+                if (act == FIERY_ACT_RELU) {
+                    v.x = fmaxf(v.x, 0.f);  v.y = fmaxf(v.y, 0.f);  v.z = fmaxf(v.z, 0.f);  v.w = fmaxf(v.w, 0.f);
+                } else if (act == FIERY_ACT_SIGMOID) {
+                    v.x = sigmoidf(v.x);  v.y = sigmoidf(v.y);  v.z = sigmoidf(v.z);  v.w = sigmoidf(v.w);
+                }
+                if (!p.res_pre) { v.x += r.x;  v.y += r.y;  v.z += r.z;  v.w += r.w; }
+                *reinterpret_cast<float4*>(p.out.ptr + o * p.out.istride + pp * p.out.ld + co) = v;
+            } else if (p.epi == FIERY_EPI_GRU_GATES) {
+                float4 g = make_float4(sigmoidf(v.x), sigmoidf(v.y), sigmoidf(v.z), sigmoidf(v.w));
+                if (co < half) {                                                            // update gate
+                    *reinterpret_cast<float4*>(p.out.ptr + o * p.out.istride + pp * p.out.ld + co) = g;
+                } else {                                                                    // (1 - reset) * state
+                    const int c2 = co - half;
+                    const float4 h = *reinterpret_cast<const float4*>(p.aux0.ptr + o * p.aux0.istride + pp * p.aux0.ld + c2);
+                    g.x = (1.0f - g.x) * h.x;  g.y = (1.0f - g.y) * h.y;  g.z = (1.0f - g.z) * h.z;  g.w = (1.0f - g.w) * h.w;
+                    *reinterpret_cast<float4*>(p.out2.ptr + o * p.out2.istride + pp * p.out2.ld + c2) = g;
+                }
+            } else {                                                                        // FIERY_EPI_GRU_OUT
+                const float4 u = *reinterpret_cast<const float4*>(p.aux0.ptr + o * p.aux0.istride + pp * p.aux0.ld + co);
+                const float4 h = *reinterpret_cast<const float4*>(p.aux1.ptr + o * p.aux1.istride + pp * p.aux1.ld + co);
+                float4 hn;
+                { const float a = (1.0f - u.x) * h.x, b = u.x * fmaxf(v.x, 0.f); hn.x = a + b; }
+                { const float a = (1.0f - u.y) * h.y, b = u.y * fmaxf(v.y, 0.f); hn.y = a + b; }
+                { const float a = (1.0f - u.z) * h.z, b = u.z * fmaxf(v.z, 0.f); hn.z = a + b; }
+                { const float a = (1.0f - u.w) * h.w, b = u.w * fmaxf(v.w, 0.f); hn.w = a + b; }
+                *reinterpret_cast<float4*>(p.out.ptr + o * p.out.istride + pp * p.out.ld + co) = hn;
+                if (p.out2.ptr) *reinterpret_cast<float4*>(p.out2.ptr + o * p.out2.istride + pp * p.out2.ld + co) = hn;
+            }
+            gp += rows_per_pass;
+            ppi += rows_per_pass;
+            while (ppi >= HWout) {
+                ppi -= HWout;
+                ++o;
+            }
+        }
+    };
+    auto stage_tile = [&](const v16f& a, int t, int nt, int width) {
+        const int col = wn * (32 * NT) + nt * 32 + m;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pl = wm * (32 * MT) + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            smem[pl * width + col] = a[r];
+        }
+    };
+    const bool rows16 = p.vec_epilogue != 0;
+
+    // ---- optional chained 1x1 convolution on the tile (Bottleneck up-projection) -----------------------------
+    if constexpr (BN == 32 && BM == 128) {
+        if (p.w2) {
+            // (1) h = act(acc*scale + shift) back into LDS as the A operand of a second GEMM: [pixel][32 k], same
+            //     slot swizzle as the main loop.  Every wave passed the loop's last barrier, so stage 0 is free.
+            {
+                const int co = m;                                   // tile_n == 0, wn == 0 for BN = 32
+                const float sc = p.scale[co], sh = p.shift[co];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    float v = fmaf(acc[0][r], sc, sh);
+                    if (p.act == FIERY_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (p.act == FIERY_ACT_SIGMOID) v = sigmoidf(v);
+                    As[0][pl * BK + (((co >> 2) ^ ((pl >> 1) & 7)) << 2) + (co & 3)] = v;
+                }
+            }
+            // (2) the 32 x 64 weight tile, already in its LDS image, into the (now idle) W stages
+            {
+                float* bdst = &Bs[0][0];                            // 2 stages x 32 x 32 floats = 32 x 64
+                const float4* wsrc = reinterpret_cast<const float4*>(p.w2);
+                *reinterpret_cast<float4*>(bdst + tid * 4) = wsrc[tid];
+                *reinterpret_cast<float4*>(bdst + (tid + 256) * 4) = wsrc[tid + 256];
+            }
+            __syncthreads();
+            // (3) 128 x 64 = (128 x 32) . (32 x 64): each wavefront 32 pixels x 64 couts
+            v16f acc2[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
+            const float* b2 = &Bs[0][0];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int pl = wm * 32 + m;
+                const int slot = (2 * q + hi) ^ ((pl >> 1) & 7);
+                const float4 a4 = *reinterpret_cast<const float4*>(&As[0][pl * BK + slot * 4]);
+                const float av2[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(&b2[((2 * q + hi) * 64 + nt * 32 + m) * 4]);
+                    const float bv2[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av2[j], bv2[j], acc2[nt], 0, 0, 0);
+                }
+            }
+            // (4) second epilogue: folded BN, activation, residual, store
+            if (rows16) {
+                __syncthreads();                                   // everyone is done reading the h and W tiles
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int pl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        smem[pl * 64 + nt * 32 + m] = acc2[nt][r];
+                    }
+                __syncthreads();
+                const int keep_res_pre = p.res_pre;
+                p.res_pre = 0;                                     // the chained form adds the residual after the activation
+                store_rows(64, 0, p.scale2, p.shift2, p.act2, false);
+                p.res_pre = keep_res_pre;
+                return;
+            }
+            const int gp_base = pix0 + wm * 32 + 4 * hi;
+            const int o_base = gp_base / HWout;
+            const int pp_base = gp_base - o_base * HWout;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int co = nt * 32 + m;
+                const float sc = p.scale2[co], sh = p.shift2[co];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int off = (r & 3) + 8 * (r >> 2);
+                    if (gp_base + off >= M || co >= p.cout_store) continue;
+                    int o = o_base, ppi = pp_base + off;
+                    while (ppi >= HWout) {
+                        ppi -= HWout;
+                        ++o;
+                    }
+                    const long long pp = ppi;
+                    float v = fmaf(acc2[nt][r], sc, sh);
+                    if (p.act2 == FIERY_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (p.act2 == FIERY_ACT_SIGMOID) v = sigmoidf(v);
+                    if (p.res.ptr) v += p.res.ptr[o * p.res.istride + pp * p.res.ld + co];
+                    p.out.ptr[o * p.out.istride + pp * p.out.ld + co] = v;
+                }
+            }
+            return;
+        }
+    }
+
+    // ---- decoder heads: the hidden tile stays in LDS, only the heads' final 1x1 outputs are stored -------------
+    if constexpr (BM == 64 && BN == 128) {
+        if (p.epi == FIERY_EPI_HEADS) {
+            float* w2 = smem + BM * BN;                              // [<= 4 outputs of this cout tile][64], behind the tile
+            stage_tile(acc[0], 0, 0, BN);
+            stage_tile(acc[1], 0, 1, BN);
+            // the final 1x1 rows whose 64-channel group lies in this 128-cout tile (at most 4: one per wavefront)
+            int my_out = -1;
+            {
+                int slot = 0;
+                for (int o = 0; o < p.heads.n_out; ++o) {
+                    if ((p.heads.group[o] >> 1) != tile_n) continue;
+                    if (slot < 4 && tid < 64) w2[slot * 64 + tid] = p.heads.w[o * 64 + tid];
+                    if (slot == wv) my_out = o;
+                    ++slot;
+                }
+            }
+            __syncthreads();
+            // hidden = act(acc * scale + shift), in place, 16 bytes per thread and pass
+            {
+                const int c4 = tid & 31, prow0 = tid >> 5;            // 32 chunks of four couts, 8 rows per pass
+                const float4 sc = *reinterpret_cast<const float4*>(p.scale + tile_n * BN + c4 * 4);
+                const float4 sh = *reinterpret_cast<const float4*>(p.shift + tile_n * BN + c4 * 4);
+                for (int pl = prow0; pl < BM; pl += 8) {
+                    float4 v = *reinterpret_cast<float4*>(&smem[pl * BN + c4 * 4]);
+                    v.x = fmaf(v.x, sc.x, sh.x);  v.y = fmaf(v.y, sc.y, sh.y);  v.z = fmaf(v.z, sc.z, sh.z);  v.w = fmaf(v.w, sc.w, sh.w);
+                    if (p.act == FIERY_ACT_RELU) {
+                        v.x = fmaxf(v.x, 0.f);  v.y = fmaxf(v.y, 0.f);  v.z = fmaxf(v.z, 0.f);  v.w = fmaxf(v.w, 0.f);
+                    } else if (p.act == FIERY_ACT_SIGMOID) {
+                        v.x = sigmoidf(v.x);  v.y = sigmoidf(v.y);  v.z = sigmoidf(v.z);  v.w = sigmoidf(v.w);
+                    }
+                    *reinterpret_cast<float4*>(&smem[pl * BN + c4 * 4]) = v;
+                }
+            }
+            __syncthreads();
+            // wavefront wv owns one output row; a lane owns a pixel.  Lane l starts at channel l and walks round, so the
+            // 64 lanes touch 32 different banks at every step although their rows are 512 bytes apart.
+            if (my_out >= 0) {
+                const int slot = wv;                                   // == position of my_out among this tile's rows
+                const int cb = (p.heads.group[my_out] & 1) * 64;
+                const float* row = &smem[lane * BN + cb];
+                const float* wrow = &w2[slot * 64];
+                float a = 0.f;
+#pragma unroll 8
+                for (int c0 = 0; c0 < 64; ++c0) {
+                    const int cc = (c0 + lane) & 63;
+                    a = fmaf(row[cc], wrow[cc], a);
+                }
+                a += p.heads.bias[my_out];
+                if (p.heads.sigmoid[my_out]) a = sigmoidf(a);
+                const int gp = pix0 + lane;
+                if (gp < M) {
+                    const int o = gp / HWout, ppi = gp - o * HWout;
+                    p.heads.out[my_out][o * p.heads.istride[my_out] + ppi] = a;
+                }
+            }
+            return;
+        }
+    }
+
+    if (rows16) {
+        // (the loop's last barrier has passed: the stages are free)
+        stage_tile(acc[0], 0, 0, BN);
+        if constexpr (NT == 2) stage_tile(acc[1], 0, 1, BN);
+        if constexpr (MT == 2) {
+            stage_tile(acc[NT], 1, 0, BN);
+            if constexpr (NT == 2) stage_tile(acc[NT + 1], 1, 1, BN);
+        }
+        __syncthreads();
+        store_rows(BN, tile_n * BN, p.scale, p.shift, p.act, true);
+        return;
+    }
+
+    // ---- register epilogue (unaligned destinations): a lane holds one cout for 16 pixel rows ---------------------
+    const int half = p.cout_pad >> 1;
+    auto emit = [&](const v16f& a, int t, int nt) {
+        const int co = tile_n * BN + wn * (32 * NT) + nt * 32 + m;
+        const float sc = p.scale[co], sh = p.shift[co];
+        // image / in-image pixel of this lane's first row; the other 15 rows are small constant offsets away,
+        // so one division per tile instead of one per element
+        const int gp_base = pix0 + wm * (32 * MT) + t * 32 + 4 * hi;
+        const int o_base = gp_base / HWout;
+        const int pp_base = gp_base - o_base * HWout;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int off = (r & 3) + 8 * (r >> 2);
+            if (gp_base + off >= M) continue;
+            int o = o_base, ppi = pp_base + off;
+            while (ppi >= HWout) {
+                ppi -= HWout;
+                ++o;
+            }
+            const long long pp = ppi;
+            float v = a[r];
+            if (p.img_bias) {
+                long long brow = o;
+                if (p.bias_border) {
+                    const int y = ppi / p.Wout, x = ppi - y * p.Wout;
+                    brow = brow * 9 + (y == 0 ? 0 : y == p.Hout - 1 ? 2 : 1) * 3 + (x == 0 ? 0 : x == p.Wout - 1 ? 2 : 1);
+                }
+                v += p.img_bias[brow * p.cout_pad + co];
+            }
+            v = fmaf(v, sc, sh);
+            if (p.epi == FIERY_EPI_PLAIN) {
+                if (co >= p.cout_store) continue;
+                if (p.res.ptr && p.res_pre) v += p.res.ptr[o * p.res.istride + pp * p.res.ld + co];
+                if (p.act == FIERY_ACT_RELU) v = fmaxf(v, 0.f);
+                else if (p.act == FIERY_ACT_SIGMOID) v = sigmoidf(v);
+                if (p.res.ptr && !p.res_pre) v += p.res.ptr[o * p.res.istride + pp * p.res.ld + co];
+                p.out.ptr[o * p.out.istride + pp * p.out.ld + co] = v;
+            } else if (p.epi == FIERY_EPI_GRU_GATES) {
+                const float g = sigmoidf(v);
+                if (co < half) {
+                    p.out.ptr[o * p.out.istride + pp * p.out.ld + co] = g;                       // update gate
+                } else {
+                    const int c2 = co - half;
+                    const float h = p.aux0.ptr[o * p.aux0.istride + pp * p.aux0.ld + c2];
+                    p.out2.ptr[o * p.out2.istride + pp * p.out2.ld + c2] = (1.0f - g) * h;       // (1 - reset) * state
+                }
+            } else {   // FIERY_EPI_GRU_OUT
+                if (co >= p.cout_store) continue;
+                const float ht = fmaxf(v, 0.f);
+                const float u = p.aux0.ptr[o * p.aux0.istride + pp * p.aux0.ld + co];
+                const float h = p.aux1.ptr[o * p.aux1.istride + pp * p.aux1.ld + co];
+                const float x1 = (1.0f - u) * h;
+                const float x2 = u * ht;
+                const float hn = x1 + x2;
+                p.out.ptr[o * p.out.istride + pp * p.out.ld + co] = hn;
+                if (p.out2.ptr) p.out2.ptr[o * p.out2.istride + pp * p.out2.ld + co] = hn;
+            }
+        }
+    };
+    // compile-time tile indices keep the accumulators in registers
+    emit(acc[0], 0, 0);
+    if constexpr (NT == 2) emit(acc[1], 0, 1);
+    if constexpr (MT == 2) {
+        emit(acc[NT], 1, 0);
+        if constexpr (NT == 2) emit(acc[NT + 1], 1, 1);
+    }
+}
+
+// ---- weight packing ------------------------------------------------------------------------------
+// The variants of tile shape (BM, BN) that exist: generic and scalar-addressed for all five shapes, the small-cin
+// loop for the four shapes that use it, the probes only in tuning builds (FIERY_CONV_TUNING=1: they double the
+// compile time and nothing in the product path launches them).
+// kMask: which variants this translation unit instantiates (bit = ConvVariant); the 128 x 128 tile, whose kernels take
+// minutes each to compile, is spread over two units.
+template <int BM, int BN, unsigned kMask>
+bool conv_launch_tile(const ConvP& p, dim3 grid, hipStream_t hs, int variant, unsigned long long* clk) {
+    (void)clk;
+    if constexpr ((kMask >> kConvGeneric) & 1u) {
+        if (variant == kConvGeneric) {
+            hipLaunchKernelGGL((k_conv_igemm<BM, BN>), grid, dim3(256), 0, hs, p);
+            return true;
+        }
+    }
+    if constexpr ((kMask >> kConvAligned) & 1u) {
+        if (variant == kConvAligned) {
+            hipLaunchKernelGGL((k_conv_igemm<BM, BN, false, 0, false, true>), grid, dim3(256), 0, hs, p);
+            return true;
+        }
+    }
+    if constexpr ((kMask >> kConvSmallCin) & 1u) {
+        if (variant == kConvSmallCin) {
+            hipLaunchKernelGGL((k_conv_igemm<BM, BN, false, 0, true>), grid, dim3(256), 0, hs, p);
+            return true;
+        }
+    }
+#if FIERY_CONV_TUNING
+    if constexpr ((kMask >> kConvAligned) & 1u) {            // the probes travel with the scalar-addressed kernel's unit
+        if (variant == kConvClock || variant == kConvClockAligned) {
+            if (hipMemcpyToSymbolAsync(HIP_SYMBOL(g_clk_probe), &clk, sizeof(clk), 0, hipMemcpyHostToDevice, hs) != hipSuccess)
+                return false;
+            if (variant == kConvClockAligned) hipLaunchKernelGGL((k_conv_igemm<BM, BN, true, 0, false, true>), grid, dim3(256), 0, hs, p);
+            else hipLaunchKernelGGL((k_conv_igemm<BM, BN, true>), grid, dim3(256), 0, hs, p);
+            return true;
+        }
+        if (variant == kConvPrio) {
+            hipLaunchKernelGGL((k_conv_igemm<BM, BN, false, 1>), grid, dim3(256), 0, hs, p);
+            return true;
+        }
+    }
+#endif
+    return false;
+}
+
+}  // namespace
+#endif  // FIERY_CONV_KERNEL_TU
+
+}  // namespace fiery

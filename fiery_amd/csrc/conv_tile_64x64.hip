@@ -1,0 +1,10 @@
+// The 64 x 64 tile of the implicit-GEMM convolution (conv_igemm_kernel.h), a translation unit of its own so that
+// the tile shapes compile in parallel.
+#define FIERY_CONV_KERNEL_TU 1
+#include "conv_igemm_kernel.h"
+
+namespace fiery {
+bool conv_launch_64x64(const ConvP& p, dim3 grid, hipStream_t stream, int variant, unsigned long long* clk) {
+    return conv_launch_tile<64, 64, 3u>(p, grid, stream, variant, clk);      // variant mask: see ConvVariant
+}
+}  // namespace fiery

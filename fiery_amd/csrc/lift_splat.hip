@@ -801,9 +801,8 @@ struct PoolPlan {
     size_t lds, off_coldesc, off_colmask, off_counts, off_lists, total;
 };
 
-// LDS tile of the output plane.  Default 80 KiB (two 512-thread workgroups per CU): measured best and least
-// erratic on MI355X (profiles/r1_pool_tile_sweep.txt); the tile grows when the grid would otherwise need more than
-// kMaxTiles tiles.
+// LDS tile of the output plane (see the default below); the tile grows when the grid would otherwise need more
+// than kMaxTiles tiles.
 int plan_pool(int frames, int n_cam, int D, int H, int W, long long n_vox_ll, int requested, bool fixed, bool fused,
               PoolPlan* pl) {
     FIERY_REQUIRE(n_vox_ll > 0 && n_vox_ll < (1ll << 30), "voxel_pool: bad grid size");
@@ -812,7 +811,10 @@ int plan_pool(int frames, int n_cam, int D, int H, int W, long long n_vox_ll, in
     const int cell_bytes = fixed ? 8 : 4;
     const int cap = (fused ? 81920 : 160000) / cell_bytes;     // the fused form runs 512-thread workgroups at most
     pl->n_vox = static_cast<int>(n_vox_ll);
-    int tile = requested > 0 ? requested : 81920 / cell_bytes;
+    // default: the whole plane when it fits the CU's LDS (200 x 200 fp32 cells = 160,000 B, one 1024-thread workgroup
+    // per CU) - no row of a camera is then cut between two workgroups, which costs 12 % of the HBM reads with two
+    // tiles (profiles/r1_s3_pool_sweeps.txt); otherwise 80 KiB tiles, two 512-thread workgroups per CU
+    int tile = requested > 0 ? requested : (static_cast<long long>(n_vox_ll) * cell_bytes <= cap * cell_bytes && !fused ? static_cast<int>(n_vox_ll) : 81920 / cell_bytes);
     if (tile > cap) tile = cap;
     if (tile > pl->n_vox) tile = pl->n_vox;
     if (ceil_div(pl->n_vox, tile) > kMaxTiles) tile = ceil_div(pl->n_vox, kMaxTiles);
