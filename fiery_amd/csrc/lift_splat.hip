@@ -1075,66 +1075,84 @@ __global__ __launch_bounds__(256) void k_voxel_pool_bwd(const float* __restrict_
 //   grad_depth[f][n][d][h][w] = sum_c feat[f][n][c][h][w] * g[f][c][rank(f,n,d,h,w)]
 //   grad_feat [f][n][c][h][w] = sum_d depth[f][n][d][h][w] * g[f][c][rank(f,n,d,h,w)]
 // (autograd through fiery/models/encoder.py:99-100 and the pooling).  The (n, C, D, H, W) gradient of the outer
-// product - 372 MB per sample - never exists.  Sums run in a fixed order (c, respectively d, ascending): reproducible.
-// grid (ceil(D*H*W / 256), 1, frames * n_cam): one thread per point
-__global__ __launch_bounds__(256) void k_lift_splat_bwd_depth(const float* __restrict__ g, const int* __restrict__ rank,
-                                                               const float* __restrict__ feat, float* __restrict__ gdepth,
-                                                               int D, int HW, int C, int n_cam, int n_vox) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= D * HW) return;
-    const int fc = blockIdx.z;
-    const int f = fc / n_cam;
-    const int hw = p % HW;
-    const int r = rank[static_cast<long long>(fc) * D * HW + p];
-    float acc = 0.f;
-    if (r >= 0) {
-        const float* gp = g + static_cast<long long>(f) * C * n_vox + r;
-        const float* fp = feat + static_cast<long long>(fc) * C * HW + hw;
-        constexpr int kUnroll = 8;
-        for (int c = 0; c < C; c += kUnroll) {
-            float a[kUnroll], b[kUnroll];
-#pragma unroll
-            for (int j = 0; j < kUnroll; ++j) {
-                const bool in = c + j < C;
-                a[j] = in ? gp[static_cast<long long>(c + j) * n_vox] : 0.f;
-                b[j] = in ? fp[static_cast<long long>(c + j) * HW] : 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < kUnroll; ++j) acc += a[j] * b[j];
-        }
-    }
-    gdepth[static_cast<long long>(fc) * D * HW + p] = acc;
-}
-
-// grid (ceil(H*W / 64), ceil(C / kChan), frames * n_cam), 64 threads: one thread per pixel and kChan channels
-template <int kChan>
-__global__ __launch_bounds__(64) void k_lift_splat_bwd_feat(const float* __restrict__ g, const int* __restrict__ rank,
-                                                             const float* __restrict__ depth, float* __restrict__ gfeat,
-                                                             int D, int HW, int C, int n_cam, int n_vox) {
+// product - 372 MB per sample - never exists.  Both sums need, for every point, the C gradients of its voxel: in the
+// channel-planar g those are C cache lines, which made a first version gather-bound (2.0 ms per 9 frames).  So g is
+// first transposed to voxel-major gT[f][voxel][C] (workspace), where a point's gradients are C contiguous floats, and
+// one thread per *pixel* (f, n, h, w) keeps its feature vector and its grad_feat accumulators in registers and walks
+// the D points of its ray: 16-byte loads of gT rows (neighbouring pixels share them), a dot product for grad_depth, an
+// axpy for grad_feat.  Channels in chunks of kChunk (registers); sums run in a fixed order: reproducible.
+// grid (ceil(H*W / 64), 1, frames * n_cam), 64 threads
+template <int kChunk>
+__global__ __launch_bounds__(64) void k_lift_splat_bwd(const float* __restrict__ gT, int ld, const int* __restrict__ rank,
+                                                        const float* __restrict__ depth, const float* __restrict__ feat,
+                                                        float* __restrict__ gdepth, float* __restrict__ gfeat, int D, int HW,
+                                                        int C, int n_cam, int n_vox) {
     const int hw = blockIdx.x * blockDim.x + threadIdx.x;
     if (hw >= HW) return;
     const int fc = blockIdx.z;
     const int f = fc / n_cam;
-    const int c0 = blockIdx.y * kChan;
     const int* rp = rank + static_cast<long long>(fc) * D * HW + hw;
     const float* dp = depth + static_cast<long long>(fc) * D * HW + hw;
-    const float* gp = g + (static_cast<long long>(f) * C + c0) * n_vox;
-    float acc[kChan];
+    float* gdp = gdepth ? gdepth + static_cast<long long>(fc) * D * HW + hw : nullptr;
+    const float* gbase = gT + static_cast<long long>(f) * n_vox * ld;
+    for (int c0 = 0; c0 < C; c0 += kChunk) {
+        float ft[kChunk], acc[kChunk];
 #pragma unroll
-    for (int j = 0; j < kChan; ++j) acc[j] = 0.f;
-    for (int d = 0; d < D; ++d) {
-        const int r = rp[static_cast<long long>(d) * HW];
-        const float pd = dp[static_cast<long long>(d) * HW];
-        if (r < 0) continue;
-        float a[kChan];
+        for (int j = 0; j < kChunk; ++j) {
+            ft[j] = (c0 + j < C) ? feat[(static_cast<long long>(fc) * C + c0 + j) * HW + hw] : 0.f;
+            acc[j] = 0.f;
+        }
+        for (int d = 0; d < D; ++d) {
+            const int r = rp[static_cast<long long>(d) * HW];
+            const float pd = dp[static_cast<long long>(d) * HW];
+            float dot = 0.f;
+            if (r >= 0) {
+                const float4* row = reinterpret_cast<const float4*>(gbase + static_cast<long long>(r) * ld + c0);
+                float g[kChunk];
 #pragma unroll
-        for (int j = 0; j < kChan; ++j) a[j] = (c0 + j < C) ? gp[static_cast<long long>(j) * n_vox + r] : 0.f;
+                for (int j = 0; j < kChunk; j += 4) {
+                    // the padding columns of gT (C..ld) are zero, so a chunk that overhangs C reads zeros or stops
+                    const float4 t = (c0 + j < ld) ? row[j / 4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    g[j] = t.x;  g[j + 1] = t.y;  g[j + 2] = t.z;  g[j + 3] = t.w;
+                }
 #pragma unroll
-        for (int j = 0; j < kChan; ++j) acc[j] += pd * a[j];
+                for (int j = 0; j < kChunk; ++j) {
+                    dot += ft[j] * g[j];
+                    acc[j] += pd * g[j];
+                }
+            }
+            if (gdp) {
+                // later chunks add to what this same thread stored for the earlier ones
+                float* o = gdp + static_cast<long long>(d) * HW;
+                *o = c0 == 0 ? dot : *o + dot;
+            }
+        }
+        if (gfeat) {
+#pragma unroll
+            for (int j = 0; j < kChunk; ++j)
+                if (c0 + j < C) gfeat[(static_cast<long long>(fc) * C + c0 + j) * HW + hw] = acc[j];
+        }
     }
-#pragma unroll
-    for (int j = 0; j < kChan; ++j)
-        if (c0 + j < C) gfeat[(static_cast<long long>(fc) * C + c0 + j) * HW + hw] = acc[j];
+}
+
+// gT[f][v][0..ld) = g[f][0..C)[v], columns C..ld zero.  64 voxels per workgroup through LDS: unit-stride on both sides.
+__global__ __launch_bounds__(256) void k_voxel_major(const float* __restrict__ g, int C, int n_vox, int ld, float* __restrict__ gT) {
+    HIP_DYNAMIC_SHARED(float, vm_tile)   // [64][C + 1]
+    const int f = blockIdx.y;
+    const int v0 = blockIdx.x * 64;
+    const int nv = min(64, n_vox - v0);
+    const int row = C + 1;
+    const float* src = g + static_cast<long long>(f) * C * n_vox + v0;
+    for (int i = threadIdx.x; i < C * 64; i += blockDim.x) {
+        const int c = i >> 6, v = i & 63;
+        if (v < nv) vm_tile[v * row + c] = src[static_cast<long long>(c) * n_vox + v];
+    }
+    __syncthreads();
+    float* dst = gT + (static_cast<long long>(f) * n_vox + v0) * ld;
+    for (int i = threadIdx.x; i < nv * ld; i += blockDim.x) {
+        const int v = i / ld, c = i - v * ld;
+        dst[i] = c < C ? vm_tile[v * row + c] : 0.f;
+    }
 }
 
 }  // namespace
@@ -1163,28 +1181,37 @@ extern "C" int fiery_voxel_pool_bwd(const float* grad_out, const int32_t* rank, 
     return check_launch("voxel_pool_bwd");
 }
 
+extern "C" size_t fiery_lift_splat_bwd_workspace_bytes(int frames, int C, int n_voxels) {
+    if (frames <= 0 || C <= 0 || n_voxels <= 0) return 0;
+    return static_cast<size_t>(frames) * n_voxels * ((C + 3) / 4 * 4) * sizeof(float);
+}
+
 extern "C" int fiery_lift_splat_bwd(const float* grad_out, const int32_t* rank, const float* depth_prob,
                                     const float* features, int frames, int n_cameras, int D, int H, int W, int C,
-                                    int n_voxels, float* grad_depth, float* grad_features, fiery_stream_t stream) {
-    FIERY_REQUIRE(grad_out && rank && depth_prob && features, "lift_splat_bwd: null pointer");
+                                    int n_voxels, float* grad_depth, float* grad_features, void* workspace,
+                                    size_t workspace_bytes, fiery_stream_t stream) {
+    FIERY_REQUIRE(grad_out && rank && depth_prob && features && workspace, "lift_splat_bwd: null pointer");
     FIERY_REQUIRE(grad_depth || grad_features, "lift_splat_bwd: nothing to compute");
     FIERY_REQUIRE(frames > 0 && n_cameras > 0 && D > 0 && H > 0 && W > 0 && C > 0 && n_voxels > 0, "lift_splat_bwd: bad shape");
-    FIERY_REQUIRE(static_cast<long long>(frames) * n_cameras < 65536, "lift_splat_bwd: frames * cameras >= 65536");
+    FIERY_REQUIRE(static_cast<long long>(frames) * n_cameras < 65536 && frames < 65536, "lift_splat_bwd: frames * cameras >= 65536");
+    FIERY_REQUIRE(aligned16(workspace), "lift_splat_bwd: the workspace must be 16-byte aligned");
+    FIERY_REQUIRE(static_cast<size_t>(64) * (C + 1) * sizeof(float) <= 160 * 1024, "lift_splat_bwd: too many channels");
+    const size_t need = fiery_lift_splat_bwd_workspace_bytes(frames, C, n_voxels);
+    if (workspace_bytes < need) return fail(FIERY_ENOMEM, "lift_splat_bwd: workspace %zu B < required %zu B", workspace_bytes, need);
     const int HW = H * W;
+    const int ld = (C + 3) / 4 * 4;
+    float* gT = static_cast<float*>(workspace);
     hipStream_t s = as_stream(stream);
-    if (grad_depth) {
-        hipLaunchKernelGGL(fiery::k_lift_splat_bwd_depth, dim3(ceil_div(static_cast<long long>(D) * HW, 256), 1, frames * n_cameras),
-                           dim3(256), 0, s, grad_out, rank, features, grad_depth, D, HW, C, n_cameras, n_voxels);
-        const int rc = check_launch("lift_splat_bwd (depth)");
-        if (rc) return rc;
-    }
-    if (grad_features) {
-        constexpr int kChan = 8;
-        hipLaunchKernelGGL((fiery::k_lift_splat_bwd_feat<kChan>), dim3(ceil_div(HW, 64), ceil_div(C, kChan), frames * n_cameras),
-                           dim3(64), 0, s, grad_out, rank, depth_prob, grad_features, D, HW, C, n_cameras, n_voxels);
-        return check_launch("lift_splat_bwd (features)");
-    }
-    return FIERY_OK;
+    const size_t lds = static_cast<size_t>(64) * (C + 1) * sizeof(float);
+    if (lds > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(&fiery::k_voxel_major),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess)
+        return fail(FIERY_ELAUNCH, "lift_splat_bwd: cannot reserve %zu B of LDS", lds);
+    hipLaunchKernelGGL(fiery::k_voxel_major, dim3(ceil_div(n_voxels, 64), frames), dim3(256), lds, s, grad_out, C, n_voxels, ld, gT);
+    int rc = check_launch("lift_splat_bwd (transpose)");
+    if (rc) return rc;
+    hipLaunchKernelGGL((fiery::k_lift_splat_bwd<32>), dim3(ceil_div(HW, 64), 1, frames * n_cameras), dim3(64), 0, s, gT, ld, rank,
+                       depth_prob, features, grad_depth, grad_features, D, HW, C, n_cameras, n_voxels);
+    return check_launch("lift_splat_bwd");
 }
 
 namespace fiery {

@@ -99,7 +99,8 @@ _SIGNATURES = {
     'fiery_lift_splat_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6 +
                              [C.POINTER(BevGrid), C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_void_p]),
     'fiery_voxel_pool_bwd': (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, c_int64_p, C.c_void_p]),
-    'fiery_lift_splat_bwd': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fiery_lift_splat_bwd_workspace_bytes': (C.c_size_t, [C.c_int] * 3),
+    'fiery_lift_splat_bwd': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'fiery_depth_softmax': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'fiery_depth_softmax_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'fiery_warp_params': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
@@ -216,8 +217,11 @@ class Lib:
         n_vox = grad_out[0, 0].numel()
         gd = torch.empty_like(depth_prob) if want_depth else None
         gf = torch.empty_like(features) if want_features else None
+        ws = torch.empty(self.dll.fiery_lift_splat_bwd_workspace_bytes(frames, c, n_vox) // 4, dtype=torch.float32,
+                         device=grad_out.device)
         self.check(self.dll.fiery_lift_splat_bwd(_ptr(grad_out), _ptr(rank), _ptr(depth_prob), _ptr(features), frames,
-                                                 n_cam, d, h, w, c, n_vox, _ptr(gd), _ptr(gf), _stream_of(grad_out)))
+                                                 n_cam, d, h, w, c, n_vox, _ptr(gd), _ptr(gf), _ptr(ws), ws.numel() * 4,
+                                                 _stream_of(grad_out)))
         return gd, gf
 
     def depth_softmax(self, logits):

@@ -120,10 +120,13 @@ int fiery_voxel_pool_bwd(const float* grad_out, const int32_t* rank, int frames,
  * (n, C, D, H, W) gradient of the outer product:
  *   grad_depth[f][n][d][h][w]    = sum_c features[f][n][c][h][w]   * grad_out[f][c][rank[f][n][d][h][w]]
  *   grad_features[f][n][c][h][w] = sum_d depth_prob[f][n][d][h][w] * grad_out[f][c][rank[f][n][d][h][w]]
- * (points with rank -1 contribute nothing).  Either output may be NULL. */
+ * (points with rank -1 contribute nothing).  Either output may be NULL.  workspace: 16-byte aligned,
+ * fiery_lift_splat_bwd_workspace_bytes(frames, C, n_voxels) bytes (the voxel-major copy of grad_out). */
+size_t fiery_lift_splat_bwd_workspace_bytes(int frames, int C, int n_voxels);
 int fiery_lift_splat_bwd(const float* grad_out, const int32_t* rank, const float* depth_prob, const float* features,
                          int frames, int n_cameras, int D, int H, int W, int C, int n_voxels,
-                         float* grad_depth, float* grad_features, fiery_stream_t stream);
+                         float* grad_depth, float* grad_features, void* workspace, size_t workspace_bytes,
+                         fiery_stream_t stream);
 
 /* softmax over the depth axis: logits [n][D][HW] -> prob (reference: fiery/models/encoder.py:99). */
 int fiery_depth_softmax(const float* logits, int n, int D, int HW, float* prob, fiery_stream_t stream);

@@ -64,6 +64,28 @@ __global__ void k_read_columns(const float4* __restrict__ x, long long n4, float
     if (acc == 1.2345e-30f) sink[0] = acc;
 }
 
+// the same columns with their rows dealt out to R neighbouring lane groups: lane group r of a slice reads rows r, r + R, ...
+// so that one wavefront instruction covers R adjacent 240-byte rows (R * 240 contiguous bytes per slice) instead of one
+template <int R>
+__global__ void k_read_columns_interleaved(const float4* __restrict__ x, long long n4, float* __restrict__ sink) {
+    const long long n_items = n4 / 28 * R;
+    const long long per = (n_items + gridDim.x - 1) / gridDim.x;
+    const long long lo = per * blockIdx.x, hi = lo + per < n_items ? lo + per : n_items;
+    float acc = 0.f;
+    for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const long long slice = i / (15 * R);
+        const int within = static_cast<int>(i - slice * (15 * R));
+        const int r = within / 15, col = within - r * 15;
+        const float4* p = x + slice * 420 + col + r * 15;
+        float4 v[28 / R];
+#pragma unroll
+        for (int j = 0; j < 28 / R; ++j) v[j] = p[j * R * 15];
+#pragma unroll
+        for (int j = 0; j < 28 / R; ++j) acc += v[j].x + v[j].y + v[j].z + v[j].w;
+    }
+    if (acc == 1.2345e-30f) sink[0] = acc;
+}
+
 extern "C" int probe_read(const void* x, long long n_bytes, int blocks, int threads, int unroll, int mode, void* sink,
                           void* stream) {
     const float4* p = static_cast<const float4*>(x);
@@ -77,6 +99,9 @@ extern "C" int probe_read(const void* x, long long n_bytes, int blocks, int thre
     } else if (mode == 1) {
         if (unroll == 1) GO((k_read<1, true>), 1); else if (unroll == 4) GO((k_read<4, true>), 4);
         else if (unroll == 8) GO((k_read<8, true>), 8); else GO((k_read<16, true>), 16);
+    } else if (mode == 4) {
+        if (unroll == 2) GO((k_read_columns_interleaved<2>), 2); else if (unroll == 4) GO((k_read_columns_interleaved<4>), 4);
+        else GO((k_read_columns_interleaved<1>), 1);
     } else if (mode == 3) {
         if (unroll <= 8) GO((k_read_columns<8>), 8); else if (unroll <= 16) GO((k_read_columns<16>), 16);
         else GO((k_read_columns<28>), 28);
