@@ -24,9 +24,12 @@
 
 #pragma clang fp contract(off)
 
-// A/B switch for the streaming (non-temporal) row loads of the pooling kernel
+// Row loads of the pooling kernels: plain by default.  A non-temporal hint looks right for a tensor that is read once,
+// and a plain streaming sweep does gain from it - but consecutive 240-byte rows share a 64-byte sector, which a
+// non-temporal load does not leave behind for the next row: +13 % HBM fetch, 229 vs 209 us for the bare read pattern
+// (tools/probe/hbm_probe.hip k_read_planes, profiles/r1_s3_pool_sweeps.txt).
 #ifndef FIERY_POOL_NT_LOADS
-#define FIERY_POOL_NT_LOADS 1
+#define FIERY_POOL_NT_LOADS 0
 #endif
 
 namespace fiery {
@@ -161,9 +164,13 @@ constexpr int kPackW = 10, kPackD = 10;   // list entries pack (camera, d, w) in
 // An upright camera gives single-run columns; a fraction of a degree of pitch or roll makes columns straddle
 // two or three voxels (35 % / 7 % of the columns of the synthetic baseline rig).
 constexpr int kSplitBits = 12;
+// Compact form (`compact` != 0; grids below 65535 voxels, H < 64): 8 bytes per column,
+//   .x = rankA | rankB << 16, .y = rankC | (s1 | s2 << 6 | general << 12) << 16, a rank of 0xffff = outside the grid;
+// no tile masks are written (the whole-plane kernel that reads this form needs no lists).
+constexpr unsigned kNoRank16 = 0xffffu;
 __global__ void k_rank_columns(const float* __restrict__ geometry, int n_fc, int D, int H, int W, GridParams p,
                                int tile_vox, int* __restrict__ rank, int4* __restrict__ coldesc,
-                               int* __restrict__ colmask) {
+                               int* __restrict__ colmask, int compact) {
     const long long col = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     const long long n_cols = static_cast<long long>(n_fc) * D * W;
     if (col >= n_cols) return;
@@ -201,6 +208,12 @@ __global__ void k_rank_columns(const float* __restrict__ geometry, int n_fc, int
         }
     }
     const int general = (runs > 3 || H >= (1 << kSplitBits)) ? 1 : 0;
+    if (compact) {
+        auto r16 = [](int r) { return r < 0 ? kNoRank16 : static_cast<unsigned>(r); };
+        const unsigned w16 = static_cast<unsigned>(s1) | (static_cast<unsigned>(s2) << 6) | (static_cast<unsigned>(general) << 12);
+        reinterpret_cast<int2*>(coldesc)[col] = make_int2(static_cast<int>(r16(ra) | (r16(rb) << 16)), static_cast<int>(r16(rc) | (w16 << 16)));
+        return;
+    }
     coldesc[col] = make_int4(ra, rb, rc, s1 | (s2 << kSplitBits) | (general << (2 * kSplitBits)));
     colmask[col] = mask | (general ? static_cast<int>(0x80000000u) : 0);      // bit 31: walk this column row by row
 }
@@ -760,6 +773,189 @@ __global__ __launch_bounds__(kFused ? 512 : 1024) void k_voxel_pool(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// pooling, whole-plane form: one workgroup = (channel, frame), the entire output plane in LDS
+// ------------------------------------------------------------------------------------------------
+// The common case (a plane of fp32 cells fits the CU's LDS: 200 x 200; 16-byte rows; unfused) needs neither tile
+// lists nor tile masks: a workgroup enumerates the quads of its frame itself, reads their compact 8-byte column
+// descriptors (half the bytes of the general form - descriptors are 14 % of this kernel's reads, re-fetched by every
+// channel's workgroup), skips the quads that lie outside the grid without touching their rows, and parks the rare quads
+// with a many-run column in an LDS queue that full wavefronts drain afterwards (when the queue is full such a quad
+// is walked on the spot).  Arithmetic as in k_voxel_pool: packed run sums, neighbours merged, one LDS atomic per run.
+struct FastDiv {           // n / d for n < 2^22, d < 2^18: (n * ceil(2^40 / d)) >> 40
+    unsigned long long mul;
+    __device__ __forceinline__ int div(int n) const { return static_cast<int>((static_cast<unsigned long long>(n) * mul) >> 40); }
+};
+
+template <int kBatch>
+__global__ __launch_bounds__(1024) void k_voxel_pool_plane(const float* __restrict__ x, PoolStrides xs,
+                                                           const int* __restrict__ rank, const int2* __restrict__ coldesc,
+                                                           float* __restrict__ out, int n_cam, int D, int H, int W, int C,
+                                                           int n_vox, int queue_cap, FastDiv div_wg, FastDiv div_d,
+                                                           int tail_first, int tail_parts) {
+    constexpr int kVec = 4;
+    HIP_DYNAMIC_SHARED(unsigned char, plane_lds)
+    float* plane = reinterpret_cast<float*>(plane_lds);
+    int* queue = reinterpret_cast<int*>(plane_lds) + n_vox;          // [0] = entries pushed, then the entries
+    // Units past `tail_first` are the last, partly filled round of workgroups (one workgroup per CU: 576 planes on 256
+    // CUs leave 64).  Each of them is cut into `tail_parts` workgroups that take the quads block-cyclically and add
+    // their partial planes to the (pre-zeroed) output, so that the whole chip works on the tail too.
+    int unit = blockIdx.x, part = 0, parts = 1;
+    if (unit >= tail_first) {
+        const int t = unit - tail_first;
+        unit = tail_first + t / tail_parts;
+        part = t - (t / tail_parts) * tail_parts;
+        parts = tail_parts;
+    }
+    const int c = unit % C;
+    const int f = unit / C;
+    for (int i = threadIdx.x; i < n_vox; i += blockDim.x) plane[i] = 0.f;
+    if (threadIdx.x == 0) queue[0] = 0;
+    __syncthreads();
+
+    const int Wg = W / kVec;
+    const int n_items = n_cam * D * Wg;
+    const int HW = H * W;
+    const int2* cdesc = coldesc + static_cast<long long>(f) * n_items * kVec;
+    const int v0 = 0, v1 = n_vox;
+    const long long step = xs.h;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+
+    // a quad with a column of four or more runs: every element goes to the voxel its own rank names
+    auto walk_rows = [&](int item) {
+        const int nd = div_wg.div(item), wg = item - nd * Wg;
+        const int cam = div_d.div(nd), d = nd - cam * D;
+        const float* p = x + f * xs.f + cam * xs.n + d * xs.d + (wg * kVec) * xs.w + c * xs.c;
+        const int* rk = rank + ((static_cast<long long>(f) * n_cam + cam) * D + d) * HW + wg * kVec;
+        for (int h0 = 0; h0 < H; h0 += kBatch) {
+            vf4 v[kBatch];
+            int4 r[kBatch];
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                const bool in = h0 + j < H;
+                v[j] = vf4{0.f, 0.f, 0.f, 0.f};
+                r[j] = make_int4(-1, -1, -1, -1);
+                if (in) {
+                    v[j] = *reinterpret_cast<const vf4*>(p + (h0 + j) * step);
+                    r[j] = *reinterpret_cast<const int4*>(rk + (h0 + j) * W);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                if (r[j].x >= 0) atomicAdd(&plane[r[j].x], v[j][0]);
+                if (r[j].y >= 0) atomicAdd(&plane[r[j].y], v[j][1]);
+                if (r[j].z >= 0) atomicAdd(&plane[r[j].z], v[j][2]);
+                if (r[j].w >= 0) atomicAdd(&plane[r[j].w], v[j][3]);
+            }
+        }
+    };
+
+    int4 d_next[2];                        // the four columns' descriptors of the thread's next quad
+    auto fetch_desc = [&](int item) {
+        const int4* dp = reinterpret_cast<const int4*>(cdesc + static_cast<long long>(item) * kVec);
+        d_next[0] = dp[0];
+        d_next[1] = dp[1];
+    };
+    const int stride = nthr * parts;
+    if (tid + part * nthr < n_items) fetch_desc(tid + part * nthr);
+    for (int i = tid + part * nthr; i < n_items; i += stride) {
+        const int4 da = d_next[0], db = d_next[1];
+        if (i + stride < n_items) fetch_desc(i + stride);
+        const unsigned lo[kVec] = {static_cast<unsigned>(da.x), static_cast<unsigned>(da.z), static_cast<unsigned>(db.x),
+                                   static_cast<unsigned>(db.z)};
+        const unsigned hi[kVec] = {static_cast<unsigned>(da.y), static_cast<unsigned>(da.w), static_cast<unsigned>(db.y),
+                                   static_cast<unsigned>(db.w)};
+        int ra[kVec], rb[kVec], rc[kVec], s1[kVec], s2[kVec];
+        unsigned any_general = 0;
+        bool empty = true;
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) {
+            const unsigned a = lo[k] & 0xffffu, b = lo[k] >> 16, cc = hi[k] & 0xffffu, w16 = hi[k] >> 16;
+            ra[k] = a == kNoRank16 ? -1 : static_cast<int>(a);
+            rb[k] = b == kNoRank16 ? -1 : static_cast<int>(b);
+            rc[k] = cc == kNoRank16 ? -1 : static_cast<int>(cc);
+            s1[k] = w16 & 63u;
+            s2[k] = (w16 >> 6) & 63u;
+            any_general |= w16 >> 12;
+            empty = empty && a == kNoRank16 && b == kNoRank16 && cc == kNoRank16;
+        }
+        if (any_general) {
+            const int slot = atomicAdd(&queue[0], 1);
+            if (slot < queue_cap) queue[1 + slot] = i;
+            else walk_rows(i);
+            continue;
+        }
+        if (empty) continue;                                  // the whole quad lies outside the grid: its rows are not read
+        const int nd = div_wg.div(i), wg = i - nd * Wg;
+        const int cam = div_d.div(nd), d = nd - cam * D;
+        const float* p = x + f * xs.f + cam * xs.n + d * xs.d + (wg * kVec) * xs.w + c * xs.c;
+        constexpr int kPairs = 2;
+        v2f first[kPairs], mid[kPairs], third[kPairs], below[kPairs], above[kPairs];
+#pragma unroll
+        for (int q = 0; q < kPairs; ++q) {
+            first[q] = mid[q] = third[q] = pk_splat(0.f);
+            below[q] = pk_make(static_cast<float>(s1[2 * q]), static_cast<float>(s1[2 * q + 1]));
+            above[q] = pk_make(static_cast<float>(1 - s2[2 * q]), static_cast<float>(1 - s2[2 * q + 1]));
+        }
+        for (int h0 = 0; h0 < H; h0 += kBatch) {
+            vf4 v[kBatch];
+            auto load_rows = [&](auto full_tag) {
+                constexpr bool kFull = decltype(full_tag)::value;
+#pragma unroll
+                for (int j = 0; j < kBatch; ++j) {
+                    v[j] = vf4{0.f, 0.f, 0.f, 0.f};
+                    if (kFull || h0 + j < H) {
+                        const vf4* src = reinterpret_cast<const vf4*>(p + (h0 + j) * step);
+                        v[j] = FIERY_POOL_NT_LOADS ? __builtin_nontemporal_load(src) : *src;   // read exactly once
+                    }
+                }
+            };
+            if (h0 + kBatch <= H) load_rows(std::true_type{});
+            else load_rows(std::false_type{});
+            const float h0f = static_cast<float>(h0);
+            v2f b0[kPairs], a0[kPairs];
+#pragma unroll
+            for (int q = 0; q < kPairs; ++q) {
+                b0[q] = below[q] - pk_splat(h0f);
+                a0[q] = above[q] + pk_splat(h0f);
+            }
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j)
+#pragma unroll
+                for (int q = 0; q < kPairs; ++q) {
+                    const v2f val = pk_make(v[j][2 * q], v[j][2 * q + 1]);
+                    const v2f w_first = pk_add_sat_uniform(b0[q], pk_splat(-static_cast<float>(j)));
+                    const v2f w_third = pk_add_sat_uniform(a0[q], pk_splat(static_cast<float>(j)));
+                    const v2f w_mid = (pk_splat(1.f) - w_first) - w_third;
+                    first[q] = pk_fma(val, w_first, first[q]);
+                    mid[q] = pk_fma(val, w_mid, mid[q]);
+                    third[q] = pk_fma(val, w_third, third[q]);
+                }
+        }
+        Merge<false> merge;
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) {
+            const int q = k / 2;
+            const bool up = (k & 1) != 0;
+            merge.add(plane, v0, v1, ra[k], up ? pk_hi(first[q]) : pk_lo(first[q]));
+            if (s1[k] < H) merge.add(plane, v0, v1, rb[k], up ? pk_hi(mid[q]) : pk_lo(mid[q]));
+            if (s2[k] < H) merge.add(plane, v0, v1, rc[k], up ? pk_hi(third[q]) : pk_lo(third[q]));
+        }
+        merge.flush(plane, v0);
+    }
+    __syncthreads();
+    const int queued = min(queue[0], queue_cap);
+    for (int qi = tid; qi < queued; qi += nthr) walk_rows(queue[1 + qi]);
+    __syncthreads();
+    float* o = out + (static_cast<long long>(f) * C + c) * n_vox;
+    if (parts == 1) {
+        for (int i = threadIdx.x; i < n_vox; i += blockDim.x) o[i] = plane[i];
+    } else {
+        for (int i = threadIdx.x; i < n_vox; i += blockDim.x)
+            if (plane[i] != 0.f) atomicAdd(&o[i], plane[i]);
+    }
+}
+
 }  // namespace
 }  // namespace fiery
 
@@ -880,10 +1076,6 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
     if (getenv("FIERY_POOL_VERBOSE"))
         fprintf(stderr, "voxel_pool plan: frames=%d C=%d tile=%d x%d, %d threads, %zu B LDS\n", frames, C, pl.tile, pl.n_tiles,
                 threads, pl.lds);
-    hipLaunchKernelGGL(k_rank_columns, dim3(ceil_div(n_cols_all, 256)), dim3(256), 0, s, geometry, frames * n_cam, D, H,
-                       W, to_params(*grid), pl.tile, rank, coldesc, colmask);
-    rc = check_launch("rank_columns");
-    if (rc) return rc;
     PoolStrides st{0, 0, 0, 0, 0, 0};
     if (!fused) st = PoolStrides{xs[0], xs[1], xs[2], xs[3], xs[4], xs[5]};
     // 16-byte path: rows of four columns must be contiguous and 16-byte aligned
@@ -895,6 +1087,71 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
                 st.c % 4 == 0;
     }
     if (const char* forced = getenv("FIERY_POOL_VEC")) quads = quads && atoi(forced) == 4;      // tuning / tests
+    // the whole-plane kernel (compact descriptors, no lists): fp32 cells, unfused, one tile, a grid its 16-bit ranks reach
+    const long long n_quads = static_cast<long long>(n_cam) * D * (W / 4);
+    bool plane_form = quads && !fused && !fixed && pl.n_tiles == 1 && pl.n_vox < 65535 && H < 64 && n_quads < (1ll << 22) &&
+                      W / 4 < (1 << 18) && D < (1 << 18) && static_cast<long long>(C) * frames < (1ll << 31) &&
+                      !getenv("FIERY_POOL_PROBE");
+    if (const char* forced = getenv("FIERY_POOL_PLANE")) plane_form = plane_form && atoi(forced) != 0;   // tuning / A-B runs
+    hipLaunchKernelGGL(k_rank_columns, dim3(ceil_div(n_cols_all, 256)), dim3(256), 0, s, geometry, frames * n_cam, D, H,
+                       W, to_params(*grid), pl.tile, rank, coldesc, colmask, plane_form ? 1 : 0);
+    rc = check_launch("rank_columns");
+    if (rc) return rc;
+    if (plane_form) {
+        int batch = 16;
+        if (H % 16 != 0 && H % 7 == 0) batch = 7;
+        if (const char* forced = getenv("FIERY_POOL_BATCH")) {                                  // tuning / tests
+            const int b = atoi(forced);
+            if (b == 7 || b == 8 || b == 16) batch = b;
+        }
+        // what the plane leaves of the CU's LDS holds the queue of many-run quads
+        const long long spare = (163840 - static_cast<long long>(pl.n_vox) * 4) / 4 - 1;
+        int queue_cap = static_cast<int>(spare < n_quads ? (spare < 0 ? 0 : spare) : n_quads);
+        if (const char* forced = getenv("FIERY_POOL_QUEUE_CAP")) queue_cap = min(queue_cap, max(0, atoi(forced)));   // tests
+        const size_t lds = (static_cast<size_t>(pl.n_vox) + 1 + queue_cap) * 4;
+        const int wg_threads = lds <= 40960 ? 256 : (lds <= 81920 ? 512 : 1024);
+        auto fastdiv = [](int d) { return FastDiv{((1ull << 40) + d - 1) / static_cast<unsigned long long>(d)}; };
+        const int2* cd = reinterpret_cast<const int2*>(coldesc);
+        // one workgroup per CU (the plane takes more than half of the LDS): cut the units of the last, partly filled
+        // round into parts (see the kernel); 576 planes on 256 CUs -> the last 64 planes become 256 workgroups
+        const int n_units = C * frames;
+        int tail = 0, parts = 1;
+        if (lds > 81920) {
+            int dev = 0, n_cu = 0;
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+                n_cu = 256;
+            tail = n_units % n_cu;
+            parts = tail > 0 ? n_cu / tail : 1;
+        }
+        if (const char* forced = getenv("FIERY_POOL_TAIL_PARTS")) {                           // tuning / tests
+            parts = atoi(forced);
+            if (parts > 1 && tail == 0) tail = n_units < 3 ? n_units : 3;
+        }
+        if (parts > 8) parts = 8;
+        if (parts < 2) {
+            parts = 1;
+            tail = 0;
+        }
+        const int tail_first = n_units - tail;
+        if (tail > 0 && hipMemsetAsync(out + static_cast<long long>(tail_first) * pl.n_vox, 0,
+                                       static_cast<size_t>(tail) * pl.n_vox * sizeof(float), s) != hipSuccess)
+            return fail(FIERY_ELAUNCH, "voxel_pool: cannot clear the tail planes");
+        dim3 units(static_cast<unsigned>(tail_first + tail * parts));
+#define FIERY_POOL_PLANE_LAUNCH(BATCH)                                                                                   \
+    do {                                                                                                                 \
+        if (lds > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(&k_voxel_pool_plane<BATCH>),                \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) \
+            return fail(FIERY_ELAUNCH, "voxel_pool: cannot reserve %zu B of LDS", lds);                                 \
+        hipLaunchKernelGGL((k_voxel_pool_plane<BATCH>), units, dim3(wg_threads), lds, s, x, st, rank, cd, out, n_cam, D, H, W, \
+                           C, pl.n_vox, queue_cap, fastdiv(W / 4), fastdiv(D), tail_first, parts);                       \
+    } while (0)
+        if (batch == 7) FIERY_POOL_PLANE_LAUNCH(7);
+        else if (batch == 8) FIERY_POOL_PLANE_LAUNCH(8);
+        else FIERY_POOL_PLANE_LAUNCH(16);
+#undef FIERY_POOL_PLANE_LAUNCH
+        return check_launch("voxel_pool (plane)");
+    }
     hipLaunchKernelGGL(k_build_tile_lists, dim3(pl.n_tiles, frames), dim3(1024), 0, s, colmask, n_cam, D, W,
                        quads ? 4 : 1, pl.n_tiles, lists, counts);
     rc = check_launch("build_tile_lists");

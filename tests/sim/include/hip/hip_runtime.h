@@ -51,6 +51,7 @@ enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
 inline hipError_t hipGetDevice(int* dev) { *dev = 0; return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { __builtin_memset(p, v, n); return hipSuccess; }
 // a 4-CU device: small test problems then span several rounds of workgroups, like the real sizes do on 256 CUs
 inline hipError_t hipDeviceGetAttribute(int* value, hipDeviceAttribute_t, int) { *value = 4; return hipSuccess; }
 #define __builtin_nontemporal_load(p) (*(p))

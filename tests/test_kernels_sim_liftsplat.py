@@ -361,3 +361,48 @@ def test_pipelined_walk_has_the_bits_of_the_plain_loop(sim, monkeypatch, H, batc
         exact = ls.voxel_pool_exact(ls.lifted_to_points(lifted[f].numpy()), geo[f].reshape(-1, 3), res, start, dim)
         assert np.abs(out[f].numpy() - exact).max() < 5e-6
     assert (out != 0).any()
+
+
+@pytest.mark.parametrize('H,batch,queue_cap,tail_parts', [(28, 7, None, 0), (28, 7, 3, 3), (12, 16, None, 2), (12, 8, 0, 0)])
+def test_whole_plane_form(sim, monkeypatch, H, batch, queue_cap, tail_parts):
+    """The list-free kernel with compact 8-byte descriptors (one tile, fp32 cells, 16-byte rows): a rolled camera
+    fills the queue of many-run quads (a tiny queue makes the rest walk their rows on the spot), a pitched one gives
+    two- and three-run columns, part of the frustum lies outside the grid; `tail_parts` cuts the last units into
+    several workgroups that add their partial planes to the output.  Against the oracle and against the tiled kernel
+    on the same inputs."""
+    frustum, intr, extr, lifted = _small_problem(50, n_cam=3, D=16, H=H, W=40, C=2, frames=2)
+    roll = torch.tensor([[0.0, -1.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0], [0.0, 0.0, 1.0, 0.0], [0.0, 0.0, 0.0, 1.0]])
+    a = 0.06
+    pitch = torch.tensor([[1.0, 0.0, 0.0, 0.0], [0.0, float(np.cos(a)), -float(np.sin(a)), 0.0],
+                          [0.0, float(np.sin(a)), float(np.cos(a)), 0.0], [0.0, 0.0, 0.0, 1.0]])
+    extr = extr.clone()
+    extr[:, 0] = extr[:, 0] @ roll
+    extr[:, 1] = extr[:, 1] @ pitch
+    frames, n_cam, C, D, H, W = lifted.shape
+    geo = ls.get_geometry(frustum, intr.numpy(), extr.numpy())
+    grid, (res, start, dim) = _grid([-14.0, 30.0, 0.5], [-24.0, 10.0, 0.5], [-10.0, 10.0, 20.0])
+    st = lifted.stride()
+    strides = (st[0], st[1], st[3], st[4], st[5], st[2])
+    monkeypatch.setenv('FIERY_POOL_BATCH', str(batch))
+    if queue_cap is not None:
+        monkeypatch.setenv('FIERY_POOL_QUEUE_CAP', str(queue_cap))
+    if tail_parts:
+        monkeypatch.setenv('FIERY_POOL_TAIL_PARTS', str(tail_parts))
+    ws = sim.pool_workspace(frames, n_cam, D, H, W, lifted.device, grid)
+    garbage = torch.full((frames, C, int(dim[0]), int(dim[1])), 7.0)
+    out = sim.voxel_pool(lifted, strides, torch.from_numpy(geo), frames, n_cam, D, H, W, C, grid, out=garbage, workspace=ws)
+    rank_left = ws[:frames * n_cam * D * H * W].clone()
+    monkeypatch.setenv('FIERY_POOL_PLANE', '0')
+    tiled = sim.voxel_pool(lifted, strides, torch.from_numpy(geo), frames, n_cam, D, H, W, C, grid)
+    assert (out - tiled).abs().max() < 2e-5          # fp32 LDS atomics arrive in a different order in the two kernels
+    kept = 0
+    for f in range(frames):
+        pts = ls.lifted_to_points(lifted[f].numpy())
+        exact = ls.voxel_pool_exact(pts, geo[f].reshape(-1, 3), res, start, dim)
+        assert np.abs(out[f].numpy() - exact).max() < 2e-5          # hundreds of near-field points per voxel here
+        assert np.abs(tiled[f].numpy() - exact).max() < 2e-5
+        _, keep, rank_o = ls.voxel_indices(geo[f].reshape(-1, 3), res, start, dim)
+        got = rank_left.view(frames, -1)[f].numpy().astype(np.int64)
+        assert np.array_equal(got >= 0, keep) and np.array_equal(got[keep], rank_o[keep])      # the ranks backward needs
+        kept += keep.mean() / frames
+    assert 0.2 < kept < 0.95                      # some quads are skipped without being read, some are not

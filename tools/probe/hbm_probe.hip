@@ -86,6 +86,27 @@ __global__ void k_read_columns_interleaved(const float4* __restrict__ x, long lo
     if (acc == 1.2345e-30f) sink[0] = acc;
 }
 
+// the whole-plane pooling kernel's reads without its descriptors: workgroup (channel, frame) walks the 6 x 48 slices of
+// its channel (6 separate 322 KB regions, 20.6 MB apart), a lane owns a quad column, kBatch rows in flight
+template <int kBatch, bool kNT>
+__global__ __launch_bounds__(1024) void k_read_planes(const float4* __restrict__ x, long long n4, float* __restrict__ sink) {
+    extern __shared__ float lds[];
+    const int c = blockIdx.x % 64, f = blockIdx.x / 64;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < 6 * 48 * 15; i += blockDim.x) {
+        const int cam = i / (48 * 15), rem = i - cam * 48 * 15, d = rem / 15, col = rem - d * 15;
+        const float4* p = x + ((((long long)f * 6 + cam) * 64 + c) * 48 + d) * 420 + col;
+        for (int h0 = 0; h0 < 28; h0 += kBatch) {
+            float4 v[kBatch];
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) v[j] = kNT ? nt_load(p + (h0 + j) * 15) : p[(h0 + j) * 15];
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) acc += v[j].x + v[j].y + v[j].z + v[j].w;
+        }
+    }
+    if (acc == 1.2345e-30f) { sink[0] = acc; lds[threadIdx.x] = acc; }
+}
+
 extern "C" int probe_read(const void* x, long long n_bytes, int blocks, int threads, int unroll, int mode, void* sink,
                           void* stream) {
     const float4* p = static_cast<const float4*>(x);
@@ -99,6 +120,15 @@ extern "C" int probe_read(const void* x, long long n_bytes, int blocks, int thre
     } else if (mode == 1) {
         if (unroll == 1) GO((k_read<1, true>), 1); else if (unroll == 4) GO((k_read<4, true>), 4);
         else if (unroll == 8) GO((k_read<8, true>), 8); else GO((k_read<16, true>), 16);
+    } else if (mode == 5 || mode == 6) {
+        const int lds = 160000;
+        if (mode == 5) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_read_planes<7, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipLaunchKernelGGL((k_read_planes<7, true>), dim3(blocks), dim3(threads), lds, st, p, n4, s);
+        } else {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_read_planes<7, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipLaunchKernelGGL((k_read_planes<7, false>), dim3(blocks), dim3(threads), lds, st, p, n4, s);
+        }
     } else if (mode == 4) {
         if (unroll == 2) GO((k_read_columns_interleaved<2>), 2); else if (unroll == 4) GO((k_read_columns_interleaved<4>), 4);
         else GO((k_read_columns_interleaved<1>), 1);

@@ -30,3 +30,16 @@ for blocks, threads in ((1152, 512), (576, 1024), (2304, 256)):
         torch.cuda.synchronize()
         us = s.elapsed_time(e) * 1e3 / reps
         print(f'rows dealt to R={R} lane groups, blocks={blocks} threads={threads}: {us:7.1f} us -> {nbytes / us / 1e3:7.1f} GB/s', flush=True)
+
+for mode, name in ((5, 'non-temporal'), (6, 'plain')):
+    for _ in range(2):
+        probe.probe_read(x.data_ptr(), nbytes, 576, 1024, 7, mode, sink.data_ptr(), stream)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        probe.probe_read(x.data_ptr(), nbytes, 576, 1024, 7, mode, sink.data_ptr(), stream)
+    e.record()
+    torch.cuda.synchronize()
+    us = s.elapsed_time(e) * 1e3 / reps
+    print(f'rows dealt: plane-kernel pattern (576 x 1024 threads, 160 KB LDS, 7 rows in flight, {name} loads): {us:7.1f} us -> {nbytes / us / 1e3:7.1f} GB/s', flush=True)
