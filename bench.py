@@ -202,7 +202,7 @@ def main():
         if pool:
             t_pool, b_pool = sum(t for t, _ in pool), sum(w for _, w in pool)
             gbs = b_pool / t_pool / 1e9
-            pooling = {'kernel': 'k_rank_columns + k_voxel_pool (op boundary projection_to_birds_eye_view)', 'bound': 'hbm',
+            pooling = {'kernel': 'k_rank_columns + k_voxel_pool_plane (op boundary projection_to_birds_eye_view)', 'bound': 'hbm',
                        'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
                        'traffic': pmc_traffic('k_voxel_pool'), 'algorithmic_mb_per_step': round(b_pool / 1e6, 1),
                        'op_us_per_step': round(t_pool * 1e6, 1)}

@@ -219,7 +219,7 @@ __global__ void k_upsample2x_add(const float* __restrict__ in, int in_ld, int H,
     const float v10 = base[(static_cast<long long>(y1) * W + x0) * in_ld], v11 = base[(static_cast<long long>(y1) * W + x1) * in_ld];
     const float up = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
     const long long po = (static_cast<long long>(img) * Ho + y) * Wo + x;
-    out[po * out_ld + c] = up + (shift ? shift[c] : 0.f) + skip[po * skip_ld + c];
+    out[po * out_ld + c] = up + (shift ? shift[c] : 0.f) + (skip ? skip[po * skip_ld + c] : 0.f);
 }
 
 // the same, four channels (16 bytes) per thread: C, the leading dimensions and the base addresses are multiples of 4
@@ -245,7 +245,7 @@ __global__ void k_upsample2x_add4(const float* __restrict__ in, int in_ld, int H
     const float4 v10 = *reinterpret_cast<const float4*>(base + (static_cast<long long>(y1) * W + x0) * in_ld);
     const float4 v11 = *reinterpret_cast<const float4*>(base + (static_cast<long long>(y1) * W + x1) * in_ld);
     const long long po = (static_cast<long long>(img) * Ho + y) * Wo + x;
-    const float4 sk = *reinterpret_cast<const float4*>(skip + po * skip_ld + c);
+    const float4 sk = skip ? *reinterpret_cast<const float4*>(skip + po * skip_ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 sh = shift ? *reinterpret_cast<const float4*>(shift + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 o;
     o.x = (1.f - ly) * ((1.f - lx) * v00.x + lx * v01.x) + ly * ((1.f - lx) * v10.x + lx * v11.x) + sh.x + sk.x;
@@ -369,9 +369,9 @@ extern "C" int fiery_maxpool2x2_nhwc(const float* in, int in_ld, int n_img, int 
 
 extern "C" int fiery_upsample2x_add_nhwc(const float* in, int in_ld, int n_img, int H, int W, int C, const float* shift,
                                          const float* skip, int skip_ld, float* out, int out_ld, fiery_stream_t stream) {
-    FIERY_REQUIRE(in && skip && out && n_img > 0 && H > 0 && W > 0 && C > 0, "upsample2x_add: bad argument");
+    FIERY_REQUIRE(in && out && n_img > 0 && H > 0 && W > 0 && C > 0, "upsample2x_add: bad argument");
     auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    if (C % 4 == 0 && in_ld % 4 == 0 && skip_ld % 4 == 0 && out_ld % 4 == 0 && a16(in) && a16(skip) && a16(out) &&
+    if (C % 4 == 0 && in_ld % 4 == 0 && (!skip || skip_ld % 4 == 0) && out_ld % 4 == 0 && a16(in) && (!skip || a16(skip)) && a16(out) &&
         (!shift || a16(shift))) {
         const long long total4 = static_cast<long long>(n_img) * 4 * H * W * (C / 4);
         hipLaunchKernelGGL(k_upsample2x_add4, dim3(ceil_div(total4, 256)), dim3(256), 0, as_stream(stream), in, in_ld, H, W,

@@ -3,9 +3,11 @@
 Interface and `state_dict` names follow the reference's `Encoder`
 (reference: fiery/models/encoder.py:7-104): `backbone.*`, `upsampling_layer.conv.{0,1,3,4}.*`,
 `depth_layer.*`.  The trunk is outside this round's hand-written-kernel scope (SURVEY.md section 8,
-row a4 / section 8f rank 1) and runs on stock PyTorch-ROCm operators; the head's two results - depth
-logits and context features - feed the fused HIP lift-splat kernel directly, so the
-(n, C, D, h, w) outer product never has to exist unless a caller asks for it via `forward()`.
+row a4 / section 8f rank 1) and runs on stock PyTorch-ROCm operators.  The lift head behind it (x2 bilinear of the
+coarse level, concat, two 3x3 conv+BN+ReLU, the 1x1 depth layer) runs on the HIP engine when the model is on the GPU in
+inference (`engine.BevEngine.lift_head`); its two results - depth logits and context features - feed the fused HIP
+lift-splat kernel directly, so the (n, C, D, h, w) outer product never has to exist unless a caller asks for it via
+`forward()`.  The torch statement of the head below is what autograd and `encoder_forward` use.
 """
 import torch
 import torch.nn as nn
@@ -18,10 +20,10 @@ try:                                    # the real package, when a deployment ha
 except ImportError:                     # offline: architectural restatement with the same key names
     from .backbone import EfficientNet
 
-# (deep endpoint channels + shallow endpoint channels, fused channels) per (downsample, version)
+# ((deep endpoint channels, shallow endpoint channels), fused channels) per (downsample, version)
 _UPSAMPLING_PLAN = {
-    (16, 'b0'): (320 + 112, 512), (16, 'b4'): (448 + 160, 512),
-    (8, 'b0'): (112 + 40, 128), (8, 'b4'): (160 + 56, 128),
+    (16, 'b0'): ((320, 112), 512), (16, 'b4'): ((448, 160), 512),
+    (8, 'b0'): ((112, 40), 128), (8, 'b4'): ((160, 56), 128),
 }
 # index of the last trunk block that is kept when downsampling by 8 (reference: encoder.py:43-47)
 _LAST_BLOCK_DS8 = {'b0': 10, 'b4': 21}
@@ -41,8 +43,8 @@ class Encoder(nn.Module):
         self.backbone = EfficientNet.from_pretrained(cfg.NAME)
         self._drop_unused_trunk_layers()
 
-        cin, cout = _UPSAMPLING_PLAN[(self.downsample, self.version)]
-        self.upsampling_layer = UpsampleConcatWeights(cin, cout)
+        (self.c_deep, self.c_shallow), cout = _UPSAMPLING_PLAN[(self.downsample, self.version)]
+        self.upsampling_layer = UpsampleConcatWeights(self.c_deep + self.c_shallow, cout)
         head_out = self.C + self.D if self.use_depth_distribution else self.C
         self.depth_layer = nn.Conv2d(cout, head_out, kernel_size=1, padding=0)
 
@@ -54,8 +56,9 @@ class Encoder(nn.Module):
         for name in ('_conv_head', '_bn1', '_avg_pooling', '_dropout', '_fc'):
             delattr(self.backbone, name)
 
-    def get_features(self, x):
-        """Trunk -> two pyramid levels -> upsample-concat-conv (reference: encoder.py:58-91)."""
+    def trunk_endpoints(self, x):
+        """The image trunk: -> (deep, shallow) pyramid levels, the coarse one at half the resolution of the fine one
+        (reference: encoder.py:58-86)."""
         trunk = self.backbone
         endpoints = []
         x = trunk._swish(trunk._bn0(trunk._conv_stem(x)))
@@ -73,7 +76,11 @@ class Encoder(nn.Module):
                 break
         endpoints.append(x)
         # downsample 16 -> reductions 5 and 4; downsample 8 -> reductions 4 and 3
-        deep, shallow = (endpoints[4], endpoints[3]) if self.downsample == 16 else (endpoints[3], endpoints[2])
+        return (endpoints[4], endpoints[3]) if self.downsample == 16 else (endpoints[3], endpoints[2])
+
+    def get_features(self, x):
+        """Trunk -> two pyramid levels -> upsample-concat-conv (reference: encoder.py:58-91)."""
+        deep, shallow = self.trunk_endpoints(x)
         deep = F.interpolate(deep, scale_factor=2, mode='bilinear', align_corners=False)
         x = torch.cat([shallow, deep], dim=1)
         conv = self.upsampling_layer.conv

@@ -326,6 +326,21 @@ class BevEngine:
             fp = m.future_prediction
             self.grus = [_Gru(self, g, const_x=(i == 0)) for i, g in enumerate(fp.spatial_grus)]
             self.res_blocks = [[_Bottleneck(self, b) for b in seq] for seq in fp.res_blocks]
+        # lift head (reference: fiery/models/encoder.py:87-104, fiery/layers/convolutions.py:171-200): the coarse level is
+        # interpolated into a buffer of its own and the first 3x3 reads [shallow, deep] as a virtual concat
+        enc = m.encoder
+        conv = enc.upsampling_layer.conv
+        cs, cd, cf = enc.c_shallow, enc.c_deep, conv[0].out_channels
+        ps = round_up(cs, 8)
+        sc, sh = fold_bn(conv[1], cf)
+        self.lh_conv1 = ConvOp(lib, conv[0].weight, identity_chan_map(cs) + identity_chan_map(cd, offset=ps),
+                               (ps // 8, round_up(cd, 8) // 8), sc, sh, dev, act=RELU)
+        sc, sh = fold_bn(conv[4], cf)
+        self.lh_conv2 = ConvOp(lib, conv[3].weight, identity_chan_map(cf), (round_up(cf, 8) // 8, 0), sc, sh, dev, act=RELU)
+        ho = enc.depth_layer.out_channels
+        sc, sh = fold_bn(None, ho, enc.depth_layer.bias)
+        self.lh_conv3 = ConvOp(lib, enc.depth_layer.weight, identity_chan_map(cf), (round_up(cf, 8) // 8, 0), sc, sh, dev)
+        self.lh_channels = (cs, cd, cf, ho)
         # decoder
         d = m.decoder
         sc, sh = fold_bn(d.bn1, 64)
@@ -424,6 +439,39 @@ class BevEngine:
                                        extrinsics.reshape(-1, 4, 4).float().contiguous())
         geo = self.lib.lift_geometry(self.frustum, cam)
         return geo.view(f, n, *geo.shape[1:])
+
+    def lift_head(self, deep, shallow):
+        """`Encoder.forward` after the trunk (encoder.py:87-100): deep (n, cd, h/2, w/2) and shallow (n, cs, h, w) trunk
+        levels -> (depth logits (n, D, h, w) or None, context features (n, C, h, w)), planar like the trunk's tensors
+        because the splat kernels read them that way."""
+        lib = self.lib
+        cs, cd, cf, ho = self.lh_channels
+        n, _, hd, wd = deep.shape
+        h, w = shallow.shape[-2:]
+        assert (h, w) == (2 * hd, 2 * wd) and deep.shape[1] == cd and shallow.shape[1] == cs
+        fine = self.buf('lh_shallow', n, h, w, cs)
+        lib.nchw_to_nhwc(shallow.float().contiguous(), n, cs, h * w, fine.tensor, fine.ld, fine.img_stride)
+        coarse = self.buf('lh_deep_lo', n, hd, wd, cd)
+        lib.nchw_to_nhwc(deep.float().contiguous(), n, cd, hd * wd, coarse.tensor, coarse.ld, coarse.img_stride)
+        up = self.buf('lh_deep', n, h, w, cd)
+        lib.upsample2x_add(coarse, coarse.ld, n, hd, wd, coarse.C, None, None, 0, up, up.ld)
+        t1 = self.buf('lh_t1', n, h, w, cf)
+        self.lh_conv1([fine, up], t1)
+        t2 = self.buf('lh_t2', n, h, w, cf)
+        self.lh_conv2([t1], t2)
+        head = self.buf('lh_out', n, h, w, ho)
+        self.lh_conv3([t2], head)
+        D = self.m.depth_channels if self.m.encoder.use_depth_distribution else 0
+        C = self.C
+
+        def planar(c_off, c):
+            if c_off % 4 == 0:
+                out = torch.empty(n, c, h, w, dtype=torch.float32, device=self.device)
+                part = head.slice(c_off, c)
+                lib.nhwc_to_nchw(part, part.ld, part.img_stride, n, c, h * w, out)
+                return out
+            return head.nhwc()[..., c_off:c_off + c].permute(0, 3, 1, 2).contiguous()
+        return (planar(0, D) if D else None), planar(D, C)
 
     def _pool_workspace(self, f, n, d, h, w, device):
         key = ('poolws', f, n, d, h, w, self.pool_tile, self.pool_flags)

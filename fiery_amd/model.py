@@ -222,7 +222,11 @@ class Fiery(nn.Module):
         depth distribution and features go straight into the fused lift-splat kernel."""
         b, s, n, c, h, w = x.shape
         geometry = self.get_geometry(pack_sequence_dim(intrinsics), pack_sequence_dim(extrinsics))
-        depth_logits, features = self.encoder.lift_head(x.view(b * s * n, c, h, w))
+        if torch.is_grad_enabled():
+            depth_logits, features = self.encoder.lift_head(x.view(b * s * n, c, h, w))        # the differentiable statement
+        else:
+            deep, shallow = self.encoder.trunk_endpoints(x.view(b * s * n, c, h, w))
+            depth_logits, features = self.engine().lift_head(deep, shallow)
         bev = self._pool_head_outputs(depth_logits, features, geometry, b * s, n)
         return unpack_sequence_dim(bev, b, s)
 

@@ -302,7 +302,8 @@ int fiery_maxpool2x2_nhwc(const float* in, int in_ld, int n_img, int H, int W, i
                           float* out, int out_ld, fiery_stream_t stream);
 
 /* out = bilinear_x2(in) + shift[c] + skip  (align_corners=False; layers/convolutions.py:203-214 with
- * the 1x1 conv and BN scale already applied at low resolution - both commute with the interpolation). */
+ * the 1x1 conv and BN scale already applied at low resolution - both commute with the interpolation).
+ * shift and skip may be NULL: the plain x2 interpolation of `UpsamplingConcat` (layers/convolutions.py:171-200). */
 int fiery_upsample2x_add_nhwc(const float* in, int in_ld, int n_img, int H, int W, int C,
                               const float* shift, const float* skip, int skip_ld,
                               float* out, int out_ld, fiery_stream_t stream);

@@ -154,3 +154,45 @@ def test_method_seams_are_differentiable_through_the_pooling(sim):
         wl = prob[f] * (wd - (prob[f] * wd).sum(axis=1, keepdims=True))
         assert np.abs(logits.grad[f].numpy() - wl).max() < 1e-5
         assert np.abs(feats.grad[f].numpy() - wf).max() < 1e-5
+
+
+def test_lift_head_on_the_engine(sim):
+    """x2 bilinear + virtual concat + two 3x3 conv/BN/ReLU + the 1x1 depth layer (reference: fiery/models/encoder.py:87-100,
+    fiery/layers/convolutions.py:171-200) on the kernel sources, against the torch statement of the same head; then the
+    whole `calculate_birds_eye_view_features` seam, which feeds the head's outputs to the fused lift-splat."""
+    cfg = tiny_cfg('baseline.yml', bev=8)
+    torch.manual_seed(0)
+    model = Fiery(cfg).eval()
+    randomise_weights(model)
+    model._lib = sim
+    enc = model.encoder
+    g = torch.Generator().manual_seed(11)
+    n = 3
+    fh, fw = cfg.IMAGE.FINAL_DIM[0] // 8, cfg.IMAGE.FINAL_DIM[1] // 8
+    deep = torch.randn(n, enc.c_deep, fh // 2, fw // 2, generator=g)
+    shallow = torch.randn(n, enc.c_shallow, fh, fw, generator=g)
+    with torch.no_grad():
+        got_d, got_f = model.engine().lift_head(deep, shallow)
+        x = torch.cat([shallow, torch.nn.functional.interpolate(deep, scale_factor=2, mode='bilinear', align_corners=False)], 1)
+        conv = enc.upsampling_layer.conv
+        x = torch.relu(conv[4](conv[3](torch.relu(conv[1](conv[0](x))))))
+        want = enc.depth_layer(x)
+    D = model.depth_channels
+    for got, ref in ((got_d, want[:, :D]), (got_f, want[:, D:D + 64])):
+        assert got.shape == ref.shape
+        assert (got - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+    # the seam: images -> trunk (torch) -> head (engine) -> fused lift-splat, against the all-torch head + oracle pooling
+    import numpy as np
+    from oracle import lift_splat as ls
+    B, S, ncam = 1, 2, 2
+    _, K, E, _ = make_inputs(B, S, ncam, with_image=False, seed=5)
+    image = torch.randn(B, S, ncam, 3, *cfg.IMAGE.FINAL_DIM, generator=g)
+    with torch.no_grad():
+        bev = model.calculate_birds_eye_view_features(image, K, E)
+        lifted = enc(image.view(B * S * ncam, 3, *cfg.IMAGE.FINAL_DIM))
+    res, start, dim = ls.bev_parameters(cfg.LIFT.X_BOUND, cfg.LIFT.Y_BOUND, cfg.LIFT.Z_BOUND)
+    geo = ls.get_geometry(model.frustum.numpy(), K[0].numpy(), E[0].numpy())
+    lifted = lifted.view(B * S, ncam, *lifted.shape[1:]).numpy()
+    for f in range(B * S):
+        exact = ls.voxel_pool_exact(ls.lifted_to_points(lifted[f]), geo[f].reshape(-1, 3), res, start, dim)
+        assert np.abs(bev[0, f].numpy() - exact).max() <= 1e-4 * max(1.0, np.abs(exact).max())

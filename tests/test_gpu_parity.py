@@ -258,6 +258,31 @@ def test_projection_seam_under_autograd(hip):
 
 
 # ------------------------------------------------------------------------------------------------------
+# lift head (encoder.py:87-100) on the engine
+# ------------------------------------------------------------------------------------------------------
+def test_lift_head_real_shapes_vs_torch_cpu(hip):
+    cfg = get_preset_cfg('baseline.yml')
+    model, _ = _model(cfg)
+    enc = model.encoder
+    g = torch.Generator().manual_seed(21)
+    n = 12                                                        # two frames of six cameras
+    deep = torch.randn(n, enc.c_deep, 14, 30, generator=g)
+    shallow = torch.randn(n, enc.c_shallow, 28, 60, generator=g)
+    with torch.no_grad():
+        got_d, got_f = model.engine().lift_head(deep.to(DEV), shallow.to(DEV))
+        ref_enc = Fiery(cfg).eval().encoder
+        ref_enc.load_state_dict({k: v.cpu() for k, v in enc.state_dict().items()})
+        x = torch.cat([shallow, torch.nn.functional.interpolate(deep, scale_factor=2, mode='bilinear', align_corners=False)], 1)
+        conv = ref_enc.upsampling_layer.conv
+        x = torch.relu(conv[4](conv[3](torch.relu(conv[1](conv[0](x))))))
+        want = ref_enc.depth_layer(x)
+    D = model.depth_channels
+    for got, ref in ((got_d, want[:, :D]), (got_f, want[:, D:D + 64])):
+        assert got.shape == ref.shape
+        assert (got.cpu() - ref).abs().max().item() <= TOL * max(1.0, ref.abs().max().item())
+
+
+# ------------------------------------------------------------------------------------------------------
 # convolution kernel at the real shapes vs torch fp32 (CPU)
 # ------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('cin,cout,k,stride', [(64, 64, 3, 1), (64, 32, 1, 1), (64, 64, 7, 2), (32, 32, 3, 1),
