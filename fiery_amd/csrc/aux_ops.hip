@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void k_mean_partial4(const float* __restrict__
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == FIERY_ACT_RELU) return fmaxf(v, 0.f);
     if (act == FIERY_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    if (act == FIERY_ACT_SWISH) return v * (1.0f / (1.0f + expf(-v)));
     return v;
 }
 
@@ -255,6 +256,58 @@ __global__ void k_upsample2x_add4(const float* __restrict__ in, int in_ld, int H
     *reinterpret_cast<float4*>(out + po * out_ld + c) = o;
 }
 
+// Depthwise convolution (the image trunk's MBConv blocks), pixel-major: one thread = one output pixel x four channels.
+// w is tap-major [k*k][C] so that a tap's four weights are one 16-byte load next to the four activations they meet.
+// Zero padding is explicit (pad_top / pad_left before, whatever Hout / Wout imply after): the trunk's "static same"
+// padding is asymmetric.  Folded BatchNorm and the activation are applied on the way out.
+__global__ void k_depthwise4(const float* __restrict__ in, int in_ld, int H, int W, int C4, const float* __restrict__ w,
+                             int w_ld, int k, int stride, int pad_top, int pad_left, int Ho, int Wo,
+                             const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                             float* __restrict__ out, int out_ld, long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = static_cast<int>(i % C4) * 4;
+    long long r = i / C4;
+    const int x = static_cast<int>(r % Wo);
+    r /= Wo;
+    const int y = static_cast<int>(r % Ho);
+    const int img = static_cast<int>(r / Ho);
+    const float* base = in + static_cast<long long>(img) * H * W * in_ld + c;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ky = 0; ky < k; ++ky) {
+        const int iy = y * stride - pad_top + ky;
+        if (iy < 0 || iy >= H) continue;
+        for (int kx = 0; kx < k; ++kx) {
+            const int ix = x * stride - pad_left + kx;
+            if (ix < 0 || ix >= W) continue;
+            const float4 v = *reinterpret_cast<const float4*>(base + (static_cast<long long>(iy) * W + ix) * in_ld);
+            const float4 t = *reinterpret_cast<const float4*>(w + static_cast<long long>(ky * k + kx) * w_ld + c);
+            acc.x = fmaf(v.x, t.x, acc.x);  acc.y = fmaf(v.y, t.y, acc.y);  acc.z = fmaf(v.z, t.z, acc.z);  acc.w = fmaf(v.w, t.w, acc.w);
+        }
+    }
+    const float4 sc = scale ? *reinterpret_cast<const float4*>(scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 sh = shift ? *reinterpret_cast<const float4*>(shift + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 o;
+    o.x = apply_act(fmaf(acc.x, sc.x, sh.x), act);  o.y = apply_act(fmaf(acc.y, sc.y, sh.y), act);
+    o.z = apply_act(fmaf(acc.z, sc.z, sh.z), act);  o.w = apply_act(fmaf(acc.w, sc.w, sh.w), act);
+    *reinterpret_cast<float4*>(out + ((static_cast<long long>(img) * Ho + y) * Wo + x) * out_ld + c) = o;
+}
+
+// x[img][pixel][c] *= gate[img][c]   (squeeze-and-excite), four channels per thread, in place
+__global__ void k_scale_channels4(float* __restrict__ x, int ld, int HW, int C4, const float* __restrict__ gate, int gate_ld,
+                                  long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = static_cast<int>(i % C4) * 4;
+    const long long px = i / C4;
+    const int img = static_cast<int>(px / HW);
+    float4* p = reinterpret_cast<float4*>(x + px * ld + c);
+    const float4 g = *reinterpret_cast<const float4*>(gate + static_cast<long long>(img) * gate_ld + c);
+    float4 v = *p;
+    v.x *= g.x;  v.y *= g.y;  v.z *= g.z;  v.w *= g.w;
+    *p = v;
+}
+
 __global__ void k_broadcast(const float* __restrict__ v, int v_ld, int HW, int C, float* __restrict__ out, int out_ld,
                             long long out_img_stride, long long total) {
     const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -382,6 +435,36 @@ extern "C" int fiery_upsample2x_add_nhwc(const float* in, int in_ld, int n_img, 
     hipLaunchKernelGGL(k_upsample2x_add, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), in, in_ld, H, W, C,
                        shift, skip, skip_ld, out, out_ld, total);
     return check_launch("upsample2x_add");
+}
+
+extern "C" int fiery_depthwise_conv_nhwc(const float* in, int in_ld, int n_img, int H, int W, int C, const float* w, int w_ld,
+                                         int k, int stride, int pad_top, int pad_left, int Hout, int Wout, const float* scale,
+                                         const float* shift, int act, float* out, int out_ld, fiery_stream_t stream) {
+    FIERY_REQUIRE(in && w && out && n_img > 0 && H > 0 && W > 0 && C > 0, "depthwise_conv: bad argument");
+    FIERY_REQUIRE(k > 0 && k <= 7 && (stride == 1 || stride == 2) && pad_top >= 0 && pad_left >= 0 && Hout > 0 && Wout > 0,
+                  "depthwise_conv: bad kernel geometry");
+    FIERY_REQUIRE((Hout - 1) * stride - pad_top < H && (Wout - 1) * stride - pad_left < W, "depthwise_conv: output larger than the padded input");
+    auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    FIERY_REQUIRE(C % 4 == 0 && in_ld % 4 == 0 && out_ld % 4 == 0 && w_ld % 4 == 0 && in_ld >= C && out_ld >= C && w_ld >= C &&
+                  a16(in) && a16(out) && a16(w) && (!scale || a16(scale)) && (!shift || a16(shift)),
+                  "depthwise_conv: channels and leading dimensions must be multiples of 4, pointers 16-byte aligned");
+    FIERY_REQUIRE(act >= FIERY_ACT_NONE && act <= FIERY_ACT_SWISH, "depthwise_conv: unknown activation");
+    const long long total = static_cast<long long>(n_img) * Hout * Wout * (C / 4);
+    hipLaunchKernelGGL(k_depthwise4, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), in, in_ld, H, W, C / 4, w, w_ld,
+                       k, stride, pad_top, pad_left, Hout, Wout, scale, shift, act, out, out_ld, total);
+    return check_launch("depthwise_conv");
+}
+
+extern "C" int fiery_scale_channels_nhwc(float* x, int ld, int n_img, int HW, int C, const float* gate, int gate_ld,
+                                         fiery_stream_t stream) {
+    FIERY_REQUIRE(x && gate && n_img > 0 && HW > 0 && C > 0, "scale_channels: bad argument");
+    auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    FIERY_REQUIRE(C % 4 == 0 && ld % 4 == 0 && gate_ld % 4 == 0 && ld >= C && gate_ld >= C && a16(x) && a16(gate),
+                  "scale_channels: channels and leading dimensions must be multiples of 4, pointers 16-byte aligned");
+    const long long total = static_cast<long long>(n_img) * HW * (C / 4);
+    hipLaunchKernelGGL(k_scale_channels4, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), x, ld, HW, C / 4, gate,
+                       gate_ld, total);
+    return check_launch("scale_channels");
 }
 
 extern "C" int fiery_broadcast_nhwc(const float* v, int v_ld, int n_img, int HW, int C, float* out, int out_ld,

@@ -7,8 +7,9 @@ namespace {
 
 __device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(-v)); }
 
+constexpr int kMaxPackUnits = 128;      // 8-channel input units per convolution: 1024 channels (the trunk's 960-wide projections)
 struct ChanInverse {
-    short ci[kMaxCinUnits * 8];   // padded channel position -> logical input channel, -1 = padding
+    short ci[kMaxPackUnits * 8];   // padded channel position -> logical input channel, -1 = padding (2 KB of kernel arguments)
 };
 
 __global__ void k_pack_weights(const float* __restrict__ w, int cout, int cin_total, int taps, ChanInverse inv,
@@ -100,9 +101,9 @@ extern "C" int fiery_conv_pack_weights(const float* w, int cout, int cin_total, 
                                        int cin_units, float* packed, fiery_stream_t stream) {
     FIERY_REQUIRE(w && chan_map && packed, "conv_pack_weights: null pointer");
     FIERY_REQUIRE(cout > 0 && cin_total > 0 && taps > 0 && cin_units > 0, "conv_pack_weights: bad shape");
-    FIERY_REQUIRE(cin_units <= kMaxCinUnits, "conv_pack_weights: at most %d input channels", kMaxCinUnits * 8);
+    FIERY_REQUIRE(cin_units <= kMaxPackUnits, "conv_pack_weights: at most %d input channels", kMaxPackUnits * 8);
     ChanInverse inv;
-    for (int i = 0; i < kMaxCinUnits * 8; ++i) inv.ci[i] = -1;
+    for (int i = 0; i < kMaxPackUnits * 8; ++i) inv.ci[i] = -1;
     for (int ci = 0; ci < cin_total; ++ci) {
         const int pos = chan_map[ci];
         FIERY_REQUIRE(pos >= 0 && pos < cin_units * 8, "conv_pack_weights: chan_map[%d] = %d out of range", ci, pos);
@@ -125,6 +126,9 @@ extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) {
     FIERY_REQUIRE(d->n_img_out > 0 && d->T_out > 0 && d->n_img_out % d->T_out == 0, "conv_fwd: bad image counts");
     FIERY_REQUIRE(d->Hin > 0 && d->Win > 0 && d->Hout > 0 && d->Wout > 0, "conv_fwd: bad spatial shape");
     FIERY_REQUIRE(d->cout_pad > 0 && d->cout_pad % 32 == 0, "conv_fwd: cout_pad must be a multiple of 32");
+    FIERY_REQUIRE(d->act != FIERY_ACT_SWISH || (d->epi == FIERY_EPI_PLAIN && !d->weights2),
+                  "conv_fwd: the swish activation exists for the plain, unchained epilogue only");
+    FIERY_REQUIRE(d->act >= FIERY_ACT_NONE && d->act <= FIERY_ACT_SWISH, "conv_fwd: unknown activation %d", d->act);
     FIERY_REQUIRE(d->cout_store > 0 && (d->weights2 || d->cout_store <= d->cout_pad), "conv_fwd: bad cout_store");
     FIERY_REQUIRE(static_cast<long long>(d->n_img_out) * d->Hout * d->Wout < (1ll << 31) - 256, "conv_fwd: more than 2^31 output pixels");
     for (int s = 0; s < 2; ++s) {
@@ -135,7 +139,7 @@ extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) {
         FIERY_REQUIRE(d->src[s].ld >= d->src[s].units * 8, "conv_fwd: source %d narrower than its channel units", s);
     }
     const int cin_units = d->src[0].units + d->src[1].units;
-    FIERY_REQUIRE(cin_units <= kMaxCinUnits, "conv_fwd: too many input channels");
+    FIERY_REQUIRE(cin_units <= kMaxPackUnits, "conv_fwd: too many input channels");
     for (int s = 0; s < 2; ++s) {
         if (d->src[s].units == 0) continue;
         // the kernel addresses each source with 32-bit element offsets

@@ -543,6 +543,8 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
                     v.x = fmaxf(v.x, 0.f);  v.y = fmaxf(v.y, 0.f);  v.z = fmaxf(v.z, 0.f);  v.w = fmaxf(v.w, 0.f);
                 } else if (act == FIERY_ACT_SIGMOID) {
                     v.x = sigmoidf(v.x);  v.y = sigmoidf(v.y);  v.z = sigmoidf(v.z);  v.w = sigmoidf(v.w);
+                } else if (act == FIERY_ACT_SWISH) {
+                    v.x *= sigmoidf(v.x);  v.y *= sigmoidf(v.y);  v.z *= sigmoidf(v.z);  v.w *= sigmoidf(v.w);
                 }
                 if (!p.res_pre) { v.x += r.x;  v.y += r.y;  v.z += r.z;  v.w += r.w; }
                 *reinterpret_cast<float4*>(p.out.ptr + o * p.out.istride + pp * p.out.ld + co) = v;
@@ -785,6 +787,7 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
                 if (p.res.ptr && p.res_pre) v += p.res.ptr[o * p.res.istride + pp * p.res.ld + co];
                 if (p.act == FIERY_ACT_RELU) v = fmaxf(v, 0.f);
                 else if (p.act == FIERY_ACT_SIGMOID) v = sigmoidf(v);
+                else if (p.act == FIERY_ACT_SWISH) v *= sigmoidf(v);
                 if (p.res.ptr && !p.res_pre) v += p.res.ptr[o * p.res.istride + pp * p.res.ld + co];
                 p.out.ptr[o * p.out.istride + pp * p.out.ld + co] = v;
             } else if (p.epi == FIERY_EPI_GRU_GATES) {

@@ -103,6 +103,80 @@ class _Bottleneck:
         tail(s2)
 
 
+def _same_pads(conv):
+    """(left, right, top, bottom) of an efficientnet-pytorch 'static same padding' convolution."""
+    pad = getattr(conv, 'static_padding', None)
+    pads = getattr(pad, 'padding', None)
+    return tuple(int(v) for v in pads) if pads is not None else (0, 0, 0, 0)
+
+
+def _out_size(size, k, stride, before, after):
+    return (size + before + after - k) // stride + 1
+
+
+class _MBConv:
+    """One MBConv block of the image trunk (efficientnet-pytorch `MBConvBlock`, reached through
+    fiery/models/encoder.py:58-86): 1x1 expansion + BN + swish (MFMA conv kernel), depthwise k x k + BN + swish
+    (`fiery_depthwise_conv_nhwc`), squeeze-and-excite (spatial mean, two small dense layers, channel gate), 1x1 projection
+    + BN (+ identity skip) (MFMA conv kernel).  Inference only: drop-connect is the identity."""
+
+    def __init__(self, eng, blk):
+        lib, dev = eng.lib, eng.device
+        self.cin, self.cout, self.stride = blk.cin, blk.cout, blk.stride
+        dw = blk._depthwise_conv
+        self.mid = dw.in_channels
+        self.k = dw.kernel_size[0]
+        self.pads = _same_pads(dw)
+        self.expand = None
+        if hasattr(blk, '_expand_conv'):
+            assert _same_pads(blk._expand_conv) == (0, 0, 0, 0)
+            sc, sh = fold_bn(blk._bn0, self.mid)
+            self.expand = ConvOp(lib, blk._expand_conv.weight, identity_chan_map(self.cin), (round_up(self.cin, 8) // 8, 0),
+                                 sc, sh, dev, pad=(0, 0), act=native.ACT_SWISH)
+        wld = round_up(self.mid, 4)
+        w = torch.zeros(self.k * self.k, wld, dtype=torch.float32)
+        w[:, :self.mid] = dw.weight.detach().float().cpu().view(self.mid, self.k * self.k).t()
+        self.dw_w, self.dw_ld = w.to(dev), wld
+        sc, sh = fold_bn(blk._bn1, self.mid)
+        self.dw_scale, self.dw_shift = sc.to(dev), sh.to(dev)
+        self.sq = blk._se_reduce.out_channels
+        self.se_w1 = blk._se_reduce.weight.detach().float().view(self.sq, self.mid).contiguous().to(dev)
+        self.se_b1 = blk._se_reduce.bias.detach().float().contiguous().to(dev)
+        self.se_w2 = blk._se_expand.weight.detach().float().view(self.mid, self.sq).contiguous().to(dev)
+        self.se_b2 = blk._se_expand.bias.detach().float().contiguous().to(dev)
+        sc, sh = fold_bn(blk._bn2, self.cout)
+        self.project = ConvOp(lib, blk._project_conv.weight, identity_chan_map(self.mid), (round_up(self.mid, 8) // 8, 0),
+                              sc, sh, dev, pad=(0, 0))
+        self.skip = self.stride == 1 and self.cin == self.cout
+
+    def run(self, eng, x, tag, parity):
+        lib = eng.lib
+        n, H, W = x.n_img, x.H, x.W
+        e = x
+        if self.expand is not None:
+            e = eng.buf(tag + 'e', n, H, W, self.mid)
+            self.expand([x], e)
+        left, right, top, bottom = self.pads
+        Ho, Wo = _out_size(H, self.k, self.stride, top, bottom), _out_size(W, self.k, self.stride, left, right)
+        d = eng.buf(tag + 'd', n, Ho, Wo, self.mid)
+        lib.depthwise_conv(e, e.ld, n, H, W, self.mid, self.dw_w, self.dw_ld, self.k, self.stride, top, left, Ho, Wo,
+                           self.dw_scale, self.dw_shift, native.ACT_SWISH, d, d.ld)
+        cpad = round_up(self.mid, 4)
+        mean = eng.vec(tag + 'm', n, cpad)
+        ws = eng.vec(tag + 'mw', n, cpad * 64)
+        lib.spatial_mean(d, d.ld, d.img_stride, n, 0, 1, Ho * Wo, self.mid, mean, ws)
+        hid = eng.vec(tag + 'h', n, self.sq)
+        lib.rowwise_dense(mean, cpad, n, self.mid, self.se_w1, self.mid, 0, self.sq, None, self.se_b1, native.ACT_SWISH, False,
+                          hid, self.sq)
+        gate = eng.vec(tag + 'g', n, cpad)
+        lib.rowwise_dense(hid, self.sq, n, self.sq, self.se_w2, self.sq, 0, self.mid, None, self.se_b2, native.ACT_SIGMOID,
+                          False, gate, cpad)
+        lib.scale_channels(d, d.ld, n, Ho * Wo, self.mid, gate, cpad)
+        out = eng.buf(f'{tag}o{parity}', n, Ho, Wo, self.cout)
+        self.project([d], out, res=x if self.skip else None)
+        return out
+
+
 class _TemporalBlock:
     """fiery/layers/temporal.py:218-281 for the output frames that are still alive downstream."""
 
@@ -341,6 +415,15 @@ class BevEngine:
         sc, sh = fold_bn(None, ho, enc.depth_layer.bias)
         self.lh_conv3 = ConvOp(lib, enc.depth_layer.weight, identity_chan_map(cf), (round_up(cf, 8) // 8, 0), sc, sh, dev)
         self.lh_channels = (cs, cd, cf, ho)
+        # image trunk (efficientnet-pytorch through encoder.py:58-86): stem + the MBConv blocks the lift head keeps
+        bb = enc.backbone
+        stem = bb._conv_stem
+        sc, sh = fold_bn(bb._bn0, stem.out_channels)
+        self.stem_pads = _same_pads(stem)
+        self.stem = ConvOp(lib, stem.weight, identity_chan_map(stem.in_channels), (round_up(stem.in_channels, 8) // 8, 0), sc, sh,
+                           dev, stride=stem.stride[0], pad=(self.stem_pads[2], self.stem_pads[0]), act=native.ACT_SWISH)
+        self.stem_k = stem.kernel_size[0]
+        self.mbconv = [_MBConv(self, blk) for blk in bb._blocks]
         # decoder
         d = m.decoder
         sc, sh = fold_bn(d.bn1, 64)
@@ -440,19 +523,47 @@ class BevEngine:
         geo = self.lib.lift_geometry(self.frustum, cam)
         return geo.view(f, n, *geo.shape[1:])
 
+    def trunk_endpoints(self, image):
+        """`Encoder.get_features` up to its two pyramid levels (encoder.py:58-86): (n, 3, H, W) images -> (deep, shallow)
+        as pixel-major buffers (ops.Buf), the coarse level at half the resolution of the fine one."""
+        lib, enc = self.lib, self.m.encoder
+        n, c, H, W = image.shape
+        x0 = self.buf('tr_in', n, H, W, c)
+        lib.nchw_to_nhwc(image.float().contiguous(), n, c, H * W, x0.tensor, x0.ld, x0.img_stride)
+        left, right, top, bottom = self.stem_pads
+        s = self.stem.stride
+        x = self.buf('tr_stem', n, _out_size(H, self.stem_k, s, top, bottom), _out_size(W, self.stem_k, s, left, right),
+                     self.stem.cout)
+        self.stem([x0], x)
+        endpoints, previous = [], x
+        for idx, blk in enumerate(self.mbconv):
+            # buffers are shared by role (a shape gets one expansion and one depthwise buffer; block outputs alternate
+            # between two, so a block's input - its residual - and the stage's last output - an endpoint - stay intact)
+            x = blk.run(self, x, 'tr_', idx % 2)
+            if previous.H > x.H:
+                endpoints.append(previous)
+            previous = x
+        endpoints.append(x)
+        return (endpoints[4], endpoints[3]) if enc.downsample == 16 else (endpoints[3], endpoints[2])
+
     def lift_head(self, deep, shallow):
         """`Encoder.forward` after the trunk (encoder.py:87-100): deep (n, cd, h/2, w/2) and shallow (n, cs, h, w) trunk
         levels -> (depth logits (n, D, h, w) or None, context features (n, C, h, w)), planar like the trunk's tensors
         because the splat kernels read them that way."""
         lib = self.lib
         cs, cd, cf, ho = self.lh_channels
-        n, _, hd, wd = deep.shape
-        h, w = shallow.shape[-2:]
-        assert (h, w) == (2 * hd, 2 * wd) and deep.shape[1] == cd and shallow.shape[1] == cs
-        fine = self.buf('lh_shallow', n, h, w, cs)
-        lib.nchw_to_nhwc(shallow.float().contiguous(), n, cs, h * w, fine.tensor, fine.ld, fine.img_stride)
-        coarse = self.buf('lh_deep_lo', n, hd, wd, cd)
-        lib.nchw_to_nhwc(deep.float().contiguous(), n, cd, hd * wd, coarse.tensor, coarse.ld, coarse.img_stride)
+        if isinstance(deep, Buf):                                   # straight from `trunk_endpoints`
+            coarse, fine = deep, shallow
+            n, hd, wd, h, w = coarse.n_img, coarse.H, coarse.W, fine.H, fine.W
+            assert (h, w) == (2 * hd, 2 * wd) and coarse.C == round_up(cd, 8) and fine.C == round_up(cs, 8)
+        else:
+            n, _, hd, wd = deep.shape
+            h, w = shallow.shape[-2:]
+            assert (h, w) == (2 * hd, 2 * wd) and deep.shape[1] == cd and shallow.shape[1] == cs
+            fine = self.buf('lh_shallow', n, h, w, cs)
+            lib.nchw_to_nhwc(shallow.float().contiguous(), n, cs, h * w, fine.tensor, fine.ld, fine.img_stride)
+            coarse = self.buf('lh_deep_lo', n, hd, wd, cd)
+            lib.nchw_to_nhwc(deep.float().contiguous(), n, cd, hd * wd, coarse.tensor, coarse.ld, coarse.img_stride)
         up = self.buf('lh_deep', n, h, w, cd)
         lib.upsample2x_add(coarse, coarse.ld, n, hd, wd, coarse.C, None, None, 0, up, up.ld)
         t1 = self.buf('lh_t1', n, h, w, cf)

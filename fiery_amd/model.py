@@ -9,6 +9,8 @@ the reference class (reference: fiery/models/fiery.py:13-339), so `trainer.py` /
   in libfiery_hip.so through `fiery_amd.engine.BevEngine`.  No ATen fallback exists for that part: if the
   library is missing, or the model is on the CPU, or in training mode, the call raises.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -120,6 +122,9 @@ class Fiery(nn.Module):
         return nn.Parameter(torch.stack((us, vs, ds), -1), requires_grad=False)
 
     # -- engine management ----------------------------------------------------------------------------
+    # the image trunk on the HIP engine (stem + MBConv blocks); False runs it on stock PyTorch-ROCm operators
+    hip_trunk = os.environ.get('FIERY_HIP_TRUNK', '1') != '0'
+
     def _params_version(self):
         """Identity + in-place version of every tensor the kernel plan was built from (not the image trunk)."""
         mods = [m for name, m in self.named_children() if name != 'encoder']
@@ -222,13 +227,22 @@ class Fiery(nn.Module):
         depth distribution and features go straight into the fused lift-splat kernel."""
         b, s, n, c, h, w = x.shape
         geometry = self.get_geometry(pack_sequence_dim(intrinsics), pack_sequence_dim(extrinsics))
-        if torch.is_grad_enabled():
-            depth_logits, features = self.encoder.lift_head(x.view(b * s * n, c, h, w))        # the differentiable statement
-        else:
-            deep, shallow = self.encoder.trunk_endpoints(x.view(b * s * n, c, h, w))
-            depth_logits, features = self.engine().lift_head(deep, shallow)
+        depth_logits, features = self._lift_head(x.view(b * s * n, c, h, w))
         bev = self._pool_head_outputs(depth_logits, features, geometry, b * s, n)
         return unpack_sequence_dim(bev, b, s)
+
+    def _lift_head(self, images):
+        """(N, 3, H, W) images -> (depth logits (N, D, h, w) or None, context features (N, C, h, w)): the image trunk and
+        the lift head (reference: encoder.py:58-100) on the HIP engine; under autograd the torch statement of the same
+        layers (the engine has no backward for them), and with `hip_trunk = False` the trunk alone on PyTorch-ROCm."""
+        if torch.is_grad_enabled():
+            return self.encoder.lift_head(images)
+        eng = self.engine()
+        if self.hip_trunk:
+            deep, shallow = eng.trunk_endpoints(images)
+        else:
+            deep, shallow = self.encoder.trunk_endpoints(images)
+        return eng.lift_head(deep, shallow)
 
     def _pool_head_outputs(self, depth_logits, features, geometry, frames, n):
         eng = self.engine()
@@ -333,7 +347,7 @@ class Fiery(nn.Module):
         rf = self.receptive_field
         image = image[:, :rf].contiguous()
         b, s, n, c, h, w = image.shape
-        depth_logits, features = self.encoder.lift_head(image.view(b * s * n, c, h, w))
+        depth_logits, features = self._lift_head(image.view(b * s * n, c, h, w))
         fh, fw = features.shape[-2:]
         feats = features.view(b, s, n, -1, fh, fw)
         if depth_logits is None:

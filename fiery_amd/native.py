@@ -20,7 +20,7 @@ c_int32_p = C.POINTER(C.c_int32)
 c_int64_p = C.POINTER(C.c_int64)
 c_uint8_p = C.POINTER(C.c_uint8)
 
-ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SWISH = 0, 1, 2, 3
 EPI_PLAIN, EPI_GRU_GATES, EPI_GRU_OUT, EPI_HEADS = 0, 1, 2, 3
 POOL_DETERMINISTIC = 1
 
@@ -122,6 +122,9 @@ _SIGNATURES = {
     'fiery_maxpool2x2_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'fiery_upsample2x_add_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                             C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'fiery_depthwise_conv_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_int] * 6 +
+                                  [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'fiery_scale_channels_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'fiery_broadcast_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     'fiery_nchw_to_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     'fiery_nhwc_to_nchw': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -295,6 +298,15 @@ class Lib:
     def upsample2x_add(self, x, in_ld, n_img, h, w, c, shift, skip, skip_ld, out, out_ld):
         self.check(self.dll.fiery_upsample2x_add_nhwc(_ptr(x), in_ld, n_img, h, w, c, _ptr(shift), _ptr(skip), skip_ld,
                                                       _ptr(out), out_ld, _stream_of(out)))
+
+    def depthwise_conv(self, x, in_ld, n_img, h, w, c, weights, w_ld, k, stride, pad_top, pad_left, ho, wo, scale, shift, act,
+                       out, out_ld):
+        self.check(self.dll.fiery_depthwise_conv_nhwc(_ptr(x), in_ld, n_img, h, w, c, _ptr(weights), w_ld, k, stride, pad_top,
+                                                      pad_left, ho, wo, _ptr(scale), _ptr(shift), act, _ptr(out), out_ld,
+                                                      _stream_of(out)))
+
+    def scale_channels(self, x, ld, n_img, hw, c, gate, gate_ld):
+        self.check(self.dll.fiery_scale_channels_nhwc(_ptr(x), ld, n_img, hw, c, _ptr(gate), gate_ld, _stream_of(x)))
 
     def broadcast(self, v, v_ld, n_img, hw, c, out, out_ld, out_img_stride):
         self.check(self.dll.fiery_broadcast_nhwc(_ptr(v), v_ld, n_img, hw, c, _ptr(out), out_ld, out_img_stride,

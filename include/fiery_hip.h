@@ -177,6 +177,7 @@ typedef struct {
 #define FIERY_ACT_NONE 0
 #define FIERY_ACT_RELU 1
 #define FIERY_ACT_SIGMOID 2
+#define FIERY_ACT_SWISH 3        /* v * sigmoid(v): the image trunk's MBConv blocks; plain epilogue only */
 
 #define FIERY_EPI_PLAIN 0      /* out = act(acc*scale+shift [+res before act]) [+res after act]          */
 #define FIERY_EPI_GRU_GATES 1  /* channels [0,C/2): out=sigmoid -> update gate; [C/2,C): out2=(1-sigmoid)*aux0 */
@@ -300,6 +301,18 @@ int fiery_latent_sample(const float* mu, const float* log_sigma, const float* no
  * (layers/convolutions.py:150,166). */
 int fiery_maxpool2x2_nhwc(const float* in, int in_ld, int n_img, int H, int W, int C,
                           float* out, int out_ld, fiery_stream_t stream);
+
+/* Depthwise k x k convolution, NHWC, + folded BatchNorm (scale, shift; may be NULL) + activation: the MBConv blocks of the
+ * image trunk (efficientnet-pytorch `MBConvBlock._depthwise_conv` + `_bn1` + swish, behind fiery/models/encoder.py:58-86).
+ * w: tap-major [k*k][w_ld >= C].  Zero padding: pad_top / pad_left rows / columns before the image, after it whatever
+ * Hout / Wout ask for (the trunk's "static same" padding is asymmetric).  C and the leading dimensions multiples of 4. */
+int fiery_depthwise_conv_nhwc(const float* in, int in_ld, int n_img, int H, int W, int C, const float* w, int w_ld,
+                              int k, int stride, int pad_top, int pad_left, int Hout, int Wout, const float* scale,
+                              const float* shift, int act, float* out, int out_ld, fiery_stream_t stream);
+
+/* x[img][pixel][c] *= gate[img][c], in place (squeeze-and-excite: `torch.sigmoid(x_squeezed) * x`). */
+int fiery_scale_channels_nhwc(float* x, int ld, int n_img, int HW, int C, const float* gate, int gate_ld,
+                              fiery_stream_t stream);
 
 /* out = bilinear_x2(in) + shift[c] + skip  (align_corners=False; layers/convolutions.py:203-214 with
  * the 1x1 conv and BN scale already applied at low resolution - both commute with the interpolation).

@@ -196,3 +196,22 @@ def test_lift_head_on_the_engine(sim):
     for f in range(B * S):
         exact = ls.voxel_pool_exact(ls.lifted_to_points(lifted[f]), geo[f].reshape(-1, 3), res, start, dim)
         assert np.abs(bev[0, f].numpy() - exact).max() <= 1e-4 * max(1.0, np.abs(exact).max())
+
+
+def test_image_trunk_on_the_engine(sim):
+    """Stem + MBConv blocks (expansion, depthwise, squeeze-and-excite, projection, identity skips; 'static same'
+    padding) on the kernel sources against the torch statement of the same trunk, on a small image."""
+    cfg = tiny_cfg('baseline.yml', bev=8)
+    torch.manual_seed(0)
+    model = Fiery(cfg).eval()
+    randomise_weights(model)
+    model._lib = sim
+    g = torch.Generator().manual_seed(12)
+    image = torch.randn(2, 3, 32, 48, generator=g)
+    with torch.no_grad():
+        deep, shallow = model.engine().trunk_endpoints(image)
+        want_deep, want_shallow = model.encoder.trunk_endpoints(image)
+    for got, ref in ((deep, want_deep), (shallow, want_shallow)):
+        got = got.to_nchw()[:, :ref.shape[1]]
+        assert got.shape == ref.shape
+        assert (got - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())

@@ -282,6 +282,37 @@ def test_lift_head_real_shapes_vs_torch_cpu(hip):
         assert (got.cpu() - ref).abs().max().item() <= TOL * max(1.0, ref.abs().max().item())
 
 
+def test_image_trunk_real_size_vs_torch_cpu(hip):
+    """EfficientNet-b4 stem + blocks 0-21 at 224x480 on the engine against the torch statement on the CPU."""
+    cfg = get_preset_cfg('baseline.yml')
+    model, _ = _model(cfg)
+    g = torch.Generator().manual_seed(22)
+    image = torch.randn(2, 3, 224, 480, generator=g)
+    ref_enc = Fiery(cfg).eval().encoder
+    ref_enc.load_state_dict({k: v.cpu() for k, v in model.encoder.state_dict().items()})
+    with torch.no_grad():
+        deep, shallow = model.engine().trunk_endpoints(image.to(DEV))
+        want_deep, want_shallow = ref_enc.trunk_endpoints(image)
+    for got, ref in ((deep, want_deep), (shallow, want_shallow)):
+        got = got.to_nchw()[:, :ref.shape[1]].cpu()
+        assert got.shape == ref.shape
+        assert (got - ref).abs().max().item() <= TOL * max(1.0, ref.abs().max().item())
+
+
+def test_forward_from_images_hip_trunk_equals_torch_trunk(hip):
+    cfg = tiny_cfg('baseline.yml')
+    model, _ = _model(cfg)
+    image, K, E, ego = make_inputs(1, model.receptive_field + model.n_future, 2, image_hw=tuple(cfg.IMAGE.FINAL_DIM), seed=3)
+    with torch.no_grad():
+        model.hip_trunk = True
+        a = model(image.to(DEV), K.to(DEV), E.to(DEV), ego.to(DEV))
+        model.hip_trunk = False
+        b = model(image.to(DEV), K.to(DEV), E.to(DEV), ego.to(DEV))
+    for k, v in b.items():
+        if v is not None:
+            assert (a[k] - v).abs().max().item() <= TOL * max(1.0, v.abs().max().item()), k
+
+
 # ------------------------------------------------------------------------------------------------------
 # convolution kernel at the real shapes vs torch fp32 (CPU)
 # ------------------------------------------------------------------------------------------------------

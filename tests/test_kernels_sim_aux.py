@@ -157,3 +157,71 @@ def test_sequential_window_mean_reproduces_aten_avg_pool3d_on_constant_channels(
     sim.sequential_window_mean(None, prev, 8, 6, H * W, out, 6)     # window clipped at t = 0: first frame only
     want0 = F.avg_pool3d(x, kernel_size=(2, H, W), stride=(1, H, W), padding=(1, 0, 0), count_include_pad=False)[:, :, 0, 0, 0]
     assert torch.equal(out, want0)
+
+
+# ------------------------------------------------------------------------------------------------------
+# image-trunk helpers: depthwise convolution, squeeze-and-excite scaling, swish
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('k,stride,pads', [(3, 1, (1, 1, 1, 1)), (5, 1, (2, 2, 2, 2)), (3, 2, (0, 1, 0, 1)), (5, 2, (1, 2, 1, 2)),
+                                           (3, 2, (1, 1, 1, 1))])
+def test_depthwise_conv_bn_swish(sim, k, stride, pads):
+    """efficientnet-pytorch's `_depthwise_conv` (static 'same' zero padding, asymmetric when the stride is 2) + `_bn1` +
+    swish, against torch."""
+    from fiery_amd import native
+    g = torch.Generator().manual_seed(k * 10 + stride)
+    n, C, H, W = 2, 12, 9, 11
+    x = torch.randn(n, C, H, W, generator=g)
+    w = torch.randn(C, 1, k, k, generator=g)
+    scale, shift = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    left, right, top, bottom = pads
+    ref = torch.nn.functional.conv2d(torch.nn.functional.pad(x, pads), w, stride=stride, groups=C)
+    ref = ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    ref = ref * torch.sigmoid(ref)
+    Ho, Wo = ref.shape[-2:]
+    xin = torch.zeros(n, H, W, 16)
+    xin[..., :C] = x.permute(0, 2, 3, 1)
+    out = torch.full((n, Ho, Wo, 16), float('nan'))
+    wt = torch.zeros(k * k, 12)
+    wt[:, :C] = w.view(C, k * k).t()
+    sim.depthwise_conv(xin, 16, n, H, W, C, wt.contiguous(), 12, k, stride, top, left, Ho, Wo, scale, shift, native.ACT_SWISH, out, 16)
+    got = out[..., :C].permute(0, 3, 1, 2)
+    assert (got - ref).abs().max() < 1e-5
+    assert torch.isnan(out[..., C:]).all()                       # only the C channels asked for are written
+
+
+def test_scale_channels_and_swish_dense(sim):
+    from fiery_amd import native
+    g = torch.Generator().manual_seed(3)
+    n, HW, C = 3, 35, 8
+    x = torch.randn(n, HW, 12, generator=g)
+    gate = torch.rand(n, 8, generator=g)
+    want = x.clone()
+    want[..., :C] *= gate.view(n, 1, C)
+    sim.scale_channels(x, 12, n, HW, C, gate, 8)
+    assert torch.equal(x, want)
+    # the squeeze-and-excite MLP: swish(W1 v + b1), sigmoid(W2 . + b2)
+    v = torch.randn(n, C, generator=g)
+    w1, b1 = torch.randn(3, C, generator=g), torch.randn(3, generator=g)
+    h = torch.empty(n, 3)
+    sim.rowwise_dense(v, C, n, C, w1, C, 0, 3, None, b1, native.ACT_SWISH, False, h, 3)
+    ref = v @ w1.t() + b1
+    assert torch.allclose(h, ref * torch.sigmoid(ref), atol=1e-6)
+
+
+def test_conv_swish_epilogue(sim):
+    """1x1 expansion conv + folded BN + swish (MBConv `_expand_conv` + `_bn0` + swish)."""
+    from fiery_amd import native
+    from fiery_amd.ops import Buf, ConvOp, identity_chan_map
+    g = torch.Generator().manual_seed(4)
+    n, H, W, cin, cout = 2, 5, 7, 8, 40
+    x = torch.randn(n, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 1, 1, generator=g) * 0.3
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    op = ConvOp(sim, w, identity_chan_map(cin), (1, 0), scale, shift, 'cpu', act=native.ACT_SWISH)
+    src = Buf.alloc(n, H, W, cin, 'cpu')
+    src.nhwc()[..., :cin] = x.permute(0, 2, 3, 1)
+    dst = Buf.alloc(n, H, W, cout, 'cpu')
+    op([src], dst)
+    ref = torch.nn.functional.conv2d(x, w) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    ref = ref * torch.sigmoid(ref)
+    assert (dst.to_nchw()[:, :cout] - ref).abs().max() < 1e-5
