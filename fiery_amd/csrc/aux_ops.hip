@@ -3,6 +3,8 @@
 // the entry points in include/fiery_hip.h); all are unit-stride on the pixel-major (NHWC) layout.
 #include "common.h"
 
+#include <cstdlib>
+
 #include <cstdint>
 
 namespace fiery {
@@ -293,6 +295,63 @@ __global__ void k_depthwise4(const float* __restrict__ in, int in_ld, int H, int
     *reinterpret_cast<float4*>(out + ((static_cast<long long>(img) * Ho + y) * Wo + x) * out_ld + c) = o;
 }
 
+// The trunk's four depthwise shapes (K = 3 / 5, stride 1 / 2) with a register tile: one thread = four neighbouring
+// output pixels of a row x four channels.  A row of the window is loaded once - (4 - 1) * S + K columns - and feeds all
+// four outputs, which takes 18 / 40 / 27 / 55 16-byte loads per thread where the one-pixel form needs 36 / 100 / 36 / 100
+// for the same outputs.
+template <int K, int S>
+__global__ void k_depthwise4_tiled(const float* __restrict__ in, int in_ld, int H, int W, int C4, const float* __restrict__ w,
+                                   int w_ld, int pad_top, int pad_left, int Ho, int Wo, const float* __restrict__ scale,
+                                   const float* __restrict__ shift, int act, float* __restrict__ out, int out_ld, long long total) {
+    constexpr int TX = 4, NCOL = (TX - 1) * S + K;
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = static_cast<int>(i % C4) * 4;
+    long long r = i / C4;
+    const int Wt = (Wo + TX - 1) / TX;
+    const int x0 = static_cast<int>(r % Wt) * TX;
+    r /= Wt;
+    const int y = static_cast<int>(r % Ho);
+    const int img = static_cast<int>(r / Ho);
+    const float* base = in + static_cast<long long>(img) * H * W * in_ld + c;
+    float4 acc[TX];
+#pragma unroll
+    for (int t = 0; t < TX; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int ix0 = x0 * S - pad_left;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+        const int iy = y * S - pad_top + ky;
+        if (iy < 0 || iy >= H) continue;
+        float4 col[NCOL], wt[K];
+#pragma unroll
+        for (int j = 0; j < NCOL; ++j) {
+            const int ix = ix0 + j;
+            col[j] = (ix >= 0 && ix < W) ? *reinterpret_cast<const float4*>(base + (static_cast<long long>(iy) * W + ix) * in_ld)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) wt[kx] = *reinterpret_cast<const float4*>(w + static_cast<long long>(ky * K + kx) * w_ld + c);
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+            for (int t = 0; t < TX; ++t) {
+                const float4 v = col[t * S + kx];
+                acc[t].x = fmaf(v.x, wt[kx].x, acc[t].x);  acc[t].y = fmaf(v.y, wt[kx].y, acc[t].y);
+                acc[t].z = fmaf(v.z, wt[kx].z, acc[t].z);  acc[t].w = fmaf(v.w, wt[kx].w, acc[t].w);
+            }
+    }
+    const float4 sc = scale ? *reinterpret_cast<const float4*>(scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 sh = shift ? *reinterpret_cast<const float4*>(shift + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < TX; ++t) {
+        if (x0 + t >= Wo) break;
+        float4 o;
+        o.x = apply_act(fmaf(acc[t].x, sc.x, sh.x), act);  o.y = apply_act(fmaf(acc[t].y, sc.y, sh.y), act);
+        o.z = apply_act(fmaf(acc[t].z, sc.z, sh.z), act);  o.w = apply_act(fmaf(acc[t].w, sc.w, sh.w), act);
+        *reinterpret_cast<float4*>(out + ((static_cast<long long>(img) * Ho + y) * Wo + x0 + t) * out_ld + c) = o;
+    }
+}
+
 // x[img][pixel][c] *= gate[img][c]   (squeeze-and-excite), four channels per thread, in place
 __global__ void k_scale_channels4(float* __restrict__ x, int ld, int HW, int C4, const float* __restrict__ gate, int gate_ld,
                                   long long total) {
@@ -306,6 +365,45 @@ __global__ void k_scale_channels4(float* __restrict__ x, int ld, int HW, int C4,
     float4 v = *p;
     v.x *= g.x;  v.y *= g.y;  v.z *= g.z;  v.w *= g.w;
     *p = v;
+}
+
+// Squeeze-and-excite gate of one image per workgroup: gate = sigmoid(W2 . swish(W1 . mean + b1) + b2).
+// The channel means sit in LDS; a thread owns channels t, t + 256, ... and forms its share of every hidden unit (W1 rows
+// are read unit-stride across the workgroup), the shares meet in LDS and are summed in thread order (reproducible),
+// then a thread per channel finishes the gate.  C <= 1024, hidden units <= 64.
+constexpr int kSeMaxHidden = 64;
+__global__ __launch_bounds__(256) void k_se_gate(const float* __restrict__ mean, int ld, int C, const float* __restrict__ w1,
+                                                 const float* __restrict__ b1, int sq, const float* __restrict__ w2,
+                                                 const float* __restrict__ b2, float* __restrict__ gate, int gate_ld) {
+    __shared__ float part[256 * kSeMaxHidden];
+    __shared__ float hidden[kSeMaxHidden];
+    const int img = blockIdx.x, t = threadIdx.x;
+    const float* m = mean + static_cast<long long>(img) * ld;
+    float acc[kSeMaxHidden];
+#pragma unroll
+    for (int s_ = 0; s_ < kSeMaxHidden; ++s_) acc[s_] = 0.f;
+    for (int c = t; c < C; c += 256) {
+        const float mv = m[c];
+#pragma unroll
+        for (int s_ = 0; s_ < kSeMaxHidden; ++s_)
+            if (s_ < sq) acc[s_] = fmaf(w1[static_cast<long long>(s_) * C + c], mv, acc[s_]);
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < kSeMaxHidden; ++s_)
+        if (s_ < sq) part[t * kSeMaxHidden + s_] = acc[s_];
+    __syncthreads();
+    if (t < sq) {
+        float sum = 0.f;
+        for (int u = 0; u < 256; ++u) sum += part[u * kSeMaxHidden + t];
+        hidden[t] = apply_act(sum + b1[t], FIERY_ACT_SWISH);
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += 256) {
+        float a = b2[c];
+        const float* wr = w2 + static_cast<long long>(c) * sq;
+        for (int s_ = 0; s_ < sq; ++s_) a = fmaf(wr[s_], hidden[s_], a);
+        gate[static_cast<long long>(img) * gate_ld + c] = apply_act(a, FIERY_ACT_SIGMOID);
+    }
 }
 
 __global__ void k_broadcast(const float* __restrict__ v, int v_ld, int HW, int C, float* __restrict__ out, int out_ld,
@@ -449,10 +547,34 @@ extern "C" int fiery_depthwise_conv_nhwc(const float* in, int in_ld, int n_img, 
                   a16(in) && a16(out) && a16(w) && (!scale || a16(scale)) && (!shift || a16(shift)),
                   "depthwise_conv: channels and leading dimensions must be multiples of 4, pointers 16-byte aligned");
     FIERY_REQUIRE(act >= FIERY_ACT_NONE && act <= FIERY_ACT_SWISH, "depthwise_conv: unknown activation");
+    bool tiled = k == 3 || k == 5;                     // the register-tiled kernels; other sizes take the general one
+    if (const char* forced = getenv("FIERY_DEPTHWISE_TILED")) tiled = tiled && atoi(forced) != 0;          // tuning / tests
+    if (tiled) {
+        const long long total_t = static_cast<long long>(n_img) * Hout * ((Wout + 3) / 4) * (C / 4);
+#define FIERY_DW_LAUNCH(K_, S_)                                                                                            \
+    hipLaunchKernelGGL((k_depthwise4_tiled<K_, S_>), dim3(ceil_div(total_t, 256)), dim3(256), 0, as_stream(stream), in, in_ld, H, \
+                       W, C / 4, w, w_ld, pad_top, pad_left, Hout, Wout, scale, shift, act, out, out_ld, total_t)
+        if (k == 3 && stride == 1) FIERY_DW_LAUNCH(3, 1);
+        else if (k == 3) FIERY_DW_LAUNCH(3, 2);
+        else if (stride == 1) FIERY_DW_LAUNCH(5, 1);
+        else FIERY_DW_LAUNCH(5, 2);
+#undef FIERY_DW_LAUNCH
+        return check_launch("depthwise_conv");
+    }
     const long long total = static_cast<long long>(n_img) * Hout * Wout * (C / 4);
     hipLaunchKernelGGL(k_depthwise4, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), in, in_ld, H, W, C / 4, w, w_ld,
                        k, stride, pad_top, pad_left, Hout, Wout, scale, shift, act, out, out_ld, total);
     return check_launch("depthwise_conv");
+}
+
+extern "C" int fiery_se_gate(const float* mean, int mean_ld, int n_img, int C, const float* w1, const float* b1, int hidden,
+                             const float* w2, const float* b2, float* gate, int gate_ld, fiery_stream_t stream) {
+    FIERY_REQUIRE(mean && w1 && b1 && w2 && b2 && gate && n_img > 0, "se_gate: bad argument");
+    FIERY_REQUIRE(C > 0 && C <= 1024 && hidden > 0 && hidden <= kSeMaxHidden && mean_ld >= C && gate_ld >= C,
+                  "se_gate: at most 1024 channels and %d hidden units", kSeMaxHidden);
+    hipLaunchKernelGGL(k_se_gate, dim3(n_img), dim3(256), 0, as_stream(stream), mean, mean_ld, C, w1, b1, hidden, w2, b2, gate,
+                       gate_ld);
+    return check_launch("se_gate");
 }
 
 extern "C" int fiery_scale_channels_nhwc(float* x, int ld, int n_img, int HW, int C, const float* gate, int gate_ld,

@@ -165,12 +165,8 @@ class _MBConv:
         mean = eng.vec(tag + 'm', n, cpad)
         ws = eng.vec(tag + 'mw', n, cpad * 64)
         lib.spatial_mean(d, d.ld, d.img_stride, n, 0, 1, Ho * Wo, self.mid, mean, ws)
-        hid = eng.vec(tag + 'h', n, self.sq)
-        lib.rowwise_dense(mean, cpad, n, self.mid, self.se_w1, self.mid, 0, self.sq, None, self.se_b1, native.ACT_SWISH, False,
-                          hid, self.sq)
         gate = eng.vec(tag + 'g', n, cpad)
-        lib.rowwise_dense(hid, self.sq, n, self.sq, self.se_w2, self.sq, 0, self.mid, None, self.se_b2, native.ACT_SIGMOID,
-                          False, gate, cpad)
+        lib.se_gate(mean, cpad, n, self.mid, self.se_w1, self.se_b1, self.sq, self.se_w2, self.se_b2, gate, cpad)
         lib.scale_channels(d, d.ld, n, Ho * Wo, self.mid, gate, cpad)
         out = eng.buf(f'{tag}o{parity}', n, Ho, Wo, self.cout)
         self.project([d], out, res=x if self.skip else None)

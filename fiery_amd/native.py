@@ -124,6 +124,8 @@ _SIGNATURES = {
                                             C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'fiery_depthwise_conv_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_int] * 6 +
                                   [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'fiery_se_gate': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                      C.c_int, C.c_void_p]),
     'fiery_scale_channels_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'fiery_broadcast_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     'fiery_nchw_to_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
@@ -304,6 +306,10 @@ class Lib:
         self.check(self.dll.fiery_depthwise_conv_nhwc(_ptr(x), in_ld, n_img, h, w, c, _ptr(weights), w_ld, k, stride, pad_top,
                                                       pad_left, ho, wo, _ptr(scale), _ptr(shift), act, _ptr(out), out_ld,
                                                       _stream_of(out)))
+
+    def se_gate(self, mean, mean_ld, n_img, c, w1, b1, hidden, w2, b2, gate, gate_ld):
+        self.check(self.dll.fiery_se_gate(_ptr(mean), mean_ld, n_img, c, _ptr(w1), _ptr(b1), hidden, _ptr(w2), _ptr(b2),
+                                          _ptr(gate), gate_ld, _stream_of(gate)))
 
     def scale_channels(self, x, ld, n_img, hw, c, gate, gate_ld):
         self.check(self.dll.fiery_scale_channels_nhwc(_ptr(x), ld, n_img, hw, c, _ptr(gate), gate_ld, _stream_of(x)))

@@ -310,6 +310,12 @@ int fiery_depthwise_conv_nhwc(const float* in, int in_ld, int n_img, int H, int 
                               int k, int stride, int pad_top, int pad_left, int Hout, int Wout, const float* scale,
                               const float* shift, int act, float* out, int out_ld, fiery_stream_t stream);
 
+/* Squeeze-and-excite gate: gate[img][c] = sigmoid(w2[c][:] . swish(w1 . mean[img] + b1) + b2[c])
+ * (efficientnet-pytorch `MBConvBlock._se_reduce` / `_se_expand`).  w1 [hidden][C], w2 [C][hidden]; C <= 1024,
+ * hidden <= 64. */
+int fiery_se_gate(const float* mean, int mean_ld, int n_img, int C, const float* w1, const float* b1, int hidden,
+                  const float* w2, const float* b2, float* gate, int gate_ld, fiery_stream_t stream);
+
 /* x[img][pixel][c] *= gate[img][c], in place (squeeze-and-excite: `torch.sigmoid(x_squeezed) * x`). */
 int fiery_scale_channels_nhwc(float* x, int ld, int n_img, int HW, int C, const float* gate, int gate_ld,
                               fiery_stream_t stream);

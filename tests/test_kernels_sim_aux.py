@@ -164,10 +164,12 @@ def test_sequential_window_mean_reproduces_aten_avg_pool3d_on_constant_channels(
 # ------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('k,stride,pads', [(3, 1, (1, 1, 1, 1)), (5, 1, (2, 2, 2, 2)), (3, 2, (0, 1, 0, 1)), (5, 2, (1, 2, 1, 2)),
                                            (3, 2, (1, 1, 1, 1))])
-def test_depthwise_conv_bn_swish(sim, k, stride, pads):
+@pytest.mark.parametrize('tiled', ['1', '0'])
+def test_depthwise_conv_bn_swish(sim, monkeypatch, k, stride, pads, tiled):
     """efficientnet-pytorch's `_depthwise_conv` (static 'same' zero padding, asymmetric when the stride is 2) + `_bn1` +
     swish, against torch."""
     from fiery_amd import native
+    monkeypatch.setenv('FIERY_DEPTHWISE_TILED', tiled)          # the register-tiled kernels and the general one
     g = torch.Generator().manual_seed(k * 10 + stride)
     n, C, H, W = 2, 12, 9, 11
     x = torch.randn(n, C, H, W, generator=g)
@@ -225,3 +227,19 @@ def test_conv_swish_epilogue(sim):
     ref = torch.nn.functional.conv2d(x, w) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
     ref = ref * torch.sigmoid(ref)
     assert (dst.to_nchw()[:, :cout] - ref).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize('C,sq', [(48, 12), (960, 40), (20, 1)])
+def test_se_gate(sim, C, sq):
+    g = torch.Generator().manual_seed(C + sq)
+    n = 3
+    mean = torch.randn(n, C + 4, generator=g)
+    w1, b1 = torch.randn(sq, C, generator=g) * 0.2, torch.randn(sq, generator=g)
+    w2, b2 = torch.randn(C, sq, generator=g) * 0.2, torch.randn(C, generator=g)
+    gate = torch.full((n, C + 4), float('nan'))
+    sim.se_gate(mean, C + 4, n, C, w1, b1, sq, w2, b2, gate, C + 4)
+    h = mean[:, :C] @ w1.t() + b1
+    h = h * torch.sigmoid(h)
+    want = torch.sigmoid(h @ w2.t() + b2)
+    assert torch.allclose(gate[:, :C], want, atol=2e-6)
+    assert torch.isnan(gate[:, C:]).all()
