@@ -46,6 +46,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=3, help='samples per GPU (baseline.yml BATCHSIZE)')
     ap.add_argument('--config', default='baseline.yml')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-from-images', action='store_true', help='skip the secondary forward-from-images timing')
     ap.add_argument('--no-graph', action='store_true', help='enqueue every launch from the host each step instead of '
                                                             'replaying the captured hipGraph')
     ap.add_argument('--no-sample-streams', action='store_true', help='one stream for the whole batch instead of one '
@@ -207,6 +208,25 @@ def main():
                        'traffic': pmc_traffic('k_voxel_pool'), 'algorithmic_mb_per_step': round(b_pool / 1e6, 1),
                        'op_us_per_step': round(t_pool * 1e6, 1)}
 
+    # secondary figure: the whole `forward()` from images - image trunk and lift head on the engine as well -
+    # a few eager passes after everything above, reported beside the headline, never as `value`
+    from_images = None
+    if rank == 0 and world == 1 and not args.no_from_images:
+        image = torch.randn(B, rf + nf, n_cam, 3, *cfg.IMAGE.FINAL_DIM, device=dev)
+        with torch.no_grad():
+            for _ in range(2):
+                model(image, K_d, E_d, ego_d)
+            torch.cuda.synchronize()
+            t_img = time.perf_counter()
+            for _ in range(5):
+                model(image, K_d, E_d, ego_d)
+            torch.cuda.synchronize()
+        ms_img = (time.perf_counter() - t_img) / 5 * 1e3
+        from_images = {'ms_per_step': round(ms_img, 3), 'samples_per_s': round(B / ms_img * 1e3, 2),
+                       'what': f'Fiery.forward from {B * rf * n_cam} images of {cfg.IMAGE.FINAL_DIM[0]}x{cfg.IMAGE.FINAL_DIM[1]}: '
+                               'EfficientNet trunk + lift head + the hot path, eager launches, mean of 5'}
+        del image
+
     if rank == 0:
         line = {
             'metric': 'BEV samples/s (6 cams x 3 frames -> 200x200 BEV, hot path from encoder outputs to output dict)',
@@ -219,6 +239,7 @@ def main():
                        'global_batch': B * world, 'parallelism': f'batch-sharded x{world}, no data-path collective',
                        'launch': launch_mode + (', one stream per sample' if model.sample_streams else '')},
             'roofline': roofline, 'roofline_pooling': pooling, 'host_enqueue_ms_per_step': round(host_ms, 3),
+            'forward_from_images': from_images,
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(cfg, sd, lifted, K, E, ego)
