@@ -36,7 +36,6 @@ namespace fiery {
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;    // k per LDS stage (4 units of 8 input channels)
-constexpr int kMaxCinUnits = 64;
 struct SrcP {
     const float* ptr;
     int ld, units;

@@ -396,30 +396,7 @@ class BevEngine:
             fp = m.future_prediction
             self.grus = [_Gru(self, g, const_x=(i == 0)) for i, g in enumerate(fp.spatial_grus)]
             self.res_blocks = [[_Bottleneck(self, b) for b in seq] for seq in fp.res_blocks]
-        # lift head (reference: fiery/models/encoder.py:87-104, fiery/layers/convolutions.py:171-200): the coarse level is
-        # interpolated into a buffer of its own and the first 3x3 reads [shallow, deep] as a virtual concat
-        enc = m.encoder
-        conv = enc.upsampling_layer.conv
-        cs, cd, cf = enc.c_shallow, enc.c_deep, conv[0].out_channels
-        ps = round_up(cs, 8)
-        sc, sh = fold_bn(conv[1], cf)
-        self.lh_conv1 = ConvOp(lib, conv[0].weight, identity_chan_map(cs) + identity_chan_map(cd, offset=ps),
-                               (ps // 8, round_up(cd, 8) // 8), sc, sh, dev, act=RELU)
-        sc, sh = fold_bn(conv[4], cf)
-        self.lh_conv2 = ConvOp(lib, conv[3].weight, identity_chan_map(cf), (round_up(cf, 8) // 8, 0), sc, sh, dev, act=RELU)
-        ho = enc.depth_layer.out_channels
-        sc, sh = fold_bn(None, ho, enc.depth_layer.bias)
-        self.lh_conv3 = ConvOp(lib, enc.depth_layer.weight, identity_chan_map(cf), (round_up(cf, 8) // 8, 0), sc, sh, dev)
-        self.lh_channels = (cs, cd, cf, ho)
-        # image trunk (efficientnet-pytorch through encoder.py:58-86): stem + the MBConv blocks the lift head keeps
-        bb = enc.backbone
-        stem = bb._conv_stem
-        sc, sh = fold_bn(bb._bn0, stem.out_channels)
-        self.stem_pads = _same_pads(stem)
-        self.stem = ConvOp(lib, stem.weight, identity_chan_map(stem.in_channels), (round_up(stem.in_channels, 8) // 8, 0), sc, sh,
-                           dev, stride=stem.stride[0], pad=(self.stem_pads[2], self.stem_pads[0]), act=native.ACT_SWISH)
-        self.stem_k = stem.kernel_size[0]
-        self.mbconv = [_MBConv(self, blk) for blk in bb._blocks]
+        self._encoder_ops_built = False          # image trunk + lift head: planned on first use (_build_encoder_ops)
         # decoder
         d = m.decoder
         sc, sh = fold_bn(d.bn1, 64)
@@ -481,6 +458,38 @@ class BevEngine:
                                          [self.heads_final[g]['sigmoid'] for g in groups])
         self.head_c = cin
 
+    def _build_encoder_ops(self):
+        """Plan of the image trunk and the lift head; built on first use, because only the engine that serves
+        `Fiery.forward` from images needs it (the per-sample engines of the hot path do not)."""
+        if self._encoder_ops_built:
+            return
+        m, dev, lib = self.m, self.device, self.lib
+        # lift head (reference: fiery/models/encoder.py:87-104, fiery/layers/convolutions.py:171-200): the coarse level is
+        # interpolated into a buffer of its own and the first 3x3 reads [shallow, deep] as a virtual concat
+        enc = m.encoder
+        conv = enc.upsampling_layer.conv
+        cs, cd, cf = enc.c_shallow, enc.c_deep, conv[0].out_channels
+        ps = round_up(cs, 8)
+        sc, sh = fold_bn(conv[1], cf)
+        self.lh_conv1 = ConvOp(lib, conv[0].weight, identity_chan_map(cs) + identity_chan_map(cd, offset=ps),
+                               (ps // 8, round_up(cd, 8) // 8), sc, sh, dev, act=RELU)
+        sc, sh = fold_bn(conv[4], cf)
+        self.lh_conv2 = ConvOp(lib, conv[3].weight, identity_chan_map(cf), (round_up(cf, 8) // 8, 0), sc, sh, dev, act=RELU)
+        ho = enc.depth_layer.out_channels
+        sc, sh = fold_bn(None, ho, enc.depth_layer.bias)
+        self.lh_conv3 = ConvOp(lib, enc.depth_layer.weight, identity_chan_map(cf), (round_up(cf, 8) // 8, 0), sc, sh, dev)
+        self.lh_channels = (cs, cd, cf, ho)
+        # image trunk (efficientnet-pytorch through encoder.py:58-86): stem + the MBConv blocks the lift head keeps
+        bb = enc.backbone
+        stem = bb._conv_stem
+        sc, sh = fold_bn(bb._bn0, stem.out_channels)
+        self.stem_pads = _same_pads(stem)
+        self.stem = ConvOp(lib, stem.weight, identity_chan_map(stem.in_channels), (round_up(stem.in_channels, 8) // 8, 0), sc, sh,
+                           dev, stride=stem.stride[0], pad=(self.stem_pads[2], self.stem_pads[0]), act=native.ACT_SWISH)
+        self.stem_k = stem.kernel_size[0]
+        self.mbconv = [_MBConv(self, blk) for blk in bb._blocks]
+        self._encoder_ops_built = True
+
     def _distribution_ops(self, dm, in_split):
         blocks = []
         split = in_split
@@ -522,6 +531,7 @@ class BevEngine:
     def trunk_endpoints(self, image):
         """`Encoder.get_features` up to its two pyramid levels (encoder.py:58-86): (n, 3, H, W) images -> (deep, shallow)
         as pixel-major buffers (ops.Buf), the coarse level at half the resolution of the fine one."""
+        self._build_encoder_ops()
         lib, enc = self.lib, self.m.encoder
         n, c, H, W = image.shape
         x0 = self.buf('tr_in', n, H, W, c)
@@ -546,6 +556,7 @@ class BevEngine:
         """`Encoder.forward` after the trunk (encoder.py:87-100): deep (n, cd, h/2, w/2) and shallow (n, cs, h, w) trunk
         levels -> (depth logits (n, D, h, w) or None, context features (n, C, h, w)), planar like the trunk's tensors
         because the splat kernels read them that way."""
+        self._build_encoder_ops()
         lib = self.lib
         cs, cd, cf, ho = self.lh_channels
         if isinstance(deep, Buf):                                   # straight from `trunk_endpoints`
