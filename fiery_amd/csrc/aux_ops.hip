@@ -372,18 +372,29 @@ __global__ void k_scale_channels4(float* __restrict__ x, int ld, int HW, int C4,
 // are read unit-stride across the workgroup), the shares meet in LDS and are summed in thread order (reproducible),
 // then a thread per channel finishes the gate.  C <= 1024, hidden units <= 64.
 constexpr int kSeMaxHidden = 64;
-__global__ __launch_bounds__(256) void k_se_gate(const float* __restrict__ mean, int ld, int C, const float* __restrict__ w1,
-                                                 const float* __restrict__ b1, int sq, const float* __restrict__ w2,
-                                                 const float* __restrict__ b2, float* __restrict__ gate, int gate_ld) {
+// `mean` holds `chunks` rows of partial sums per image (row stride ld) that add up to the channel sums; inv_count turns
+// them into means (chunks = 1, inv_count = 1: the means themselves).
+__global__ __launch_bounds__(256) void k_se_gate(const float* __restrict__ mean, int ld, int chunks, float inv_count, int C,
+                                                 const float* __restrict__ w1, const float* __restrict__ b1, int sq,
+                                                 const float* __restrict__ w2, const float* __restrict__ b2,
+                                                 float* __restrict__ gate, int gate_ld) {
     __shared__ float part[256 * kSeMaxHidden];
     __shared__ float hidden[kSeMaxHidden];
     const int img = blockIdx.x, t = threadIdx.x;
-    const float* m = mean + static_cast<long long>(img) * ld;
+    const float* m = mean + static_cast<long long>(img) * chunks * ld;
     float acc[kSeMaxHidden];
 #pragma unroll
     for (int s_ = 0; s_ < kSeMaxHidden; ++s_) acc[s_] = 0.f;
     for (int c = t; c < C; c += 256) {
-        const float mv = m[c];
+        float mv = 0.f;
+        for (int k0 = 0; k0 < chunks; k0 += 8) {               // eight partial rows in flight, summed in order
+            float pv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pv[j] = k0 + j < chunks ? m[static_cast<long long>(k0 + j) * ld + c] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mv += pv[j];
+        }
+        mv *= inv_count;
 #pragma unroll
         for (int s_ = 0; s_ < kSeMaxHidden; ++s_)
             if (s_ < sq) acc[s_] = fmaf(w1[static_cast<long long>(s_) * C + c], mv, acc[s_]);
@@ -401,7 +412,14 @@ __global__ __launch_bounds__(256) void k_se_gate(const float* __restrict__ mean,
     for (int c = t; c < C; c += 256) {
         float a = b2[c];
         const float* wr = w2 + static_cast<long long>(c) * sq;
-        for (int s_ = 0; s_ < sq; ++s_) a = fmaf(wr[s_], hidden[s_], a);
+        for (int s0 = 0; s0 < sq; s0 += 8) {                  // eight weights in flight, summed in order
+            float wv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wv[j] = s0 + j < sq ? wr[s0 + j] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (s0 + j < sq) a = fmaf(wv[j], hidden[s0 + j], a);
+        }
         gate[static_cast<long long>(img) * gate_ld + c] = apply_act(a, FIERY_ACT_SIGMOID);
     }
 }
@@ -572,9 +590,36 @@ extern "C" int fiery_se_gate(const float* mean, int mean_ld, int n_img, int C, c
     FIERY_REQUIRE(mean && w1 && b1 && w2 && b2 && gate && n_img > 0, "se_gate: bad argument");
     FIERY_REQUIRE(C > 0 && C <= 1024 && hidden > 0 && hidden <= kSeMaxHidden && mean_ld >= C && gate_ld >= C,
                   "se_gate: at most 1024 channels and %d hidden units", kSeMaxHidden);
-    hipLaunchKernelGGL(k_se_gate, dim3(n_img), dim3(256), 0, as_stream(stream), mean, mean_ld, C, w1, b1, hidden, w2, b2, gate,
-                       gate_ld);
+    hipLaunchKernelGGL(k_se_gate, dim3(n_img), dim3(256), 0, as_stream(stream), mean, mean_ld, 1, 1.0f, C, w1, b1, hidden, w2, b2,
+                       gate, gate_ld);
     return check_launch("se_gate");
+}
+
+extern "C" int fiery_se_gate_nhwc(const float* x, int ld, int64_t img_stride, int n_img, int n_pixels, int C, const float* w1,
+                                  const float* b1, int hidden, const float* w2, const float* b2, float* gate, int gate_ld,
+                                  float* workspace, fiery_stream_t stream) {
+    FIERY_REQUIRE(x && w1 && b1 && w2 && b2 && gate && workspace && n_img > 0 && n_pixels > 0, "se_gate_nhwc: bad argument");
+    FIERY_REQUIRE(C > 0 && C <= 1024 && hidden > 0 && hidden <= kSeMaxHidden && ld >= C && gate_ld >= C,
+                  "se_gate_nhwc: at most 1024 channels and %d hidden units", kSeMaxHidden);
+    const bool vec = C % 4 == 0 && ld % 4 == 0 && img_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    // partial rows per image: enough workgroups to fill the chip (chunks * n_img >= ~512), few enough that the gate
+    // kernel - one workgroup per image, latency-bound - has little to add up
+    int chunks = kMeanChunks;
+    if (vec) {
+        chunks = 512 / n_img;
+        chunks = chunks < 4 ? 4 : (chunks > kMeanChunks ? kMeanChunks : chunks);
+    }
+    if (vec)
+        hipLaunchKernelGGL(k_mean_partial4, dim3(chunks, n_img), dim3(256), 0, as_stream(stream), x, ld,
+                           static_cast<long long>(img_stride), 0ll, 1, n_pixels, C, chunks, workspace);
+    else
+        hipLaunchKernelGGL(k_mean_partial, dim3(kMeanChunks, n_img), dim3(256), 0, as_stream(stream), x, ld,
+                           static_cast<long long>(img_stride), 0ll, 1, n_pixels, C, workspace);
+    const int rc = check_launch("se_gate_nhwc (channel sums)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_se_gate, dim3(n_img), dim3(256), 0, as_stream(stream), workspace, C, chunks,
+                       1.0f / static_cast<float>(n_pixels), C, w1, b1, hidden, w2, b2, gate, gate_ld);
+    return check_launch("se_gate_nhwc");
 }
 
 extern "C" int fiery_scale_channels_nhwc(float* x, int ld, int n_img, int HW, int C, const float* gate, int gate_ld,

@@ -162,11 +162,10 @@ class _MBConv:
         lib.depthwise_conv(e, e.ld, n, H, W, self.mid, self.dw_w, self.dw_ld, self.k, self.stride, top, left, Ho, Wo,
                            self.dw_scale, self.dw_shift, native.ACT_SWISH, d, d.ld)
         cpad = round_up(self.mid, 4)
-        mean = eng.vec(tag + 'm', n, cpad)
         ws = eng.vec(tag + 'mw', n, cpad * 64)
-        lib.spatial_mean(d, d.ld, d.img_stride, n, 0, 1, Ho * Wo, self.mid, mean, ws)
         gate = eng.vec(tag + 'g', n, cpad)
-        lib.se_gate(mean, cpad, n, self.mid, self.se_w1, self.se_b1, self.sq, self.se_w2, self.se_b2, gate, cpad)
+        lib.se_gate_nhwc(d, d.ld, d.img_stride, n, Ho * Wo, self.mid, self.se_w1, self.se_b1, self.sq, self.se_w2, self.se_b2,
+                         gate, cpad, ws)
         lib.scale_channels(d, d.ld, n, Ho * Wo, self.mid, gate, cpad)
         out = eng.buf(f'{tag}o{parity}', n, Ho, Wo, self.cout)
         self.project([d], out, res=x if self.skip else None)

@@ -126,6 +126,8 @@ _SIGNATURES = {
                                   [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'fiery_se_gate': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                       C.c_int, C.c_void_p]),
+    'fiery_se_gate_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'fiery_scale_channels_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'fiery_broadcast_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     'fiery_nchw_to_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
@@ -310,6 +312,10 @@ class Lib:
     def se_gate(self, mean, mean_ld, n_img, c, w1, b1, hidden, w2, b2, gate, gate_ld):
         self.check(self.dll.fiery_se_gate(_ptr(mean), mean_ld, n_img, c, _ptr(w1), _ptr(b1), hidden, _ptr(w2), _ptr(b2),
                                           _ptr(gate), gate_ld, _stream_of(gate)))
+
+    def se_gate_nhwc(self, x, ld, img_stride, n_img, n_pixels, c, w1, b1, hidden, w2, b2, gate, gate_ld, workspace):
+        self.check(self.dll.fiery_se_gate_nhwc(_ptr(x), ld, img_stride, n_img, n_pixels, c, _ptr(w1), _ptr(b1), hidden, _ptr(w2),
+                                               _ptr(b2), _ptr(gate), gate_ld, _ptr(workspace), _stream_of(gate)))
 
     def scale_channels(self, x, ld, n_img, hw, c, gate, gate_ld):
         self.check(self.dll.fiery_scale_channels_nhwc(_ptr(x), ld, n_img, hw, c, _ptr(gate), gate_ld, _stream_of(x)))

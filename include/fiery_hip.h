@@ -316,6 +316,12 @@ int fiery_depthwise_conv_nhwc(const float* in, int in_ld, int n_img, int H, int 
 int fiery_se_gate(const float* mean, int mean_ld, int n_img, int C, const float* w1, const float* b1, int hidden,
                   const float* w2, const float* b2, float* gate, int gate_ld, fiery_stream_t stream);
 
+/* The same gate straight from the feature map: channel means of x (n_pixels pixels per image, NHWC) and the two dense
+ * layers in two launches.  workspace >= n_img * C * 64 floats. */
+int fiery_se_gate_nhwc(const float* x, int ld, int64_t img_stride, int n_img, int n_pixels, int C, const float* w1,
+                       const float* b1, int hidden, const float* w2, const float* b2, float* gate, int gate_ld,
+                       float* workspace, fiery_stream_t stream);
+
 /* x[img][pixel][c] *= gate[img][c], in place (squeeze-and-excite: `torch.sigmoid(x_squeezed) * x`). */
 int fiery_scale_channels_nhwc(float* x, int ld, int n_img, int HW, int C, const float* gate, int gate_ld,
                               fiery_stream_t stream);

@@ -243,3 +243,18 @@ def test_se_gate(sim, C, sq):
     want = torch.sigmoid(h @ w2.t() + b2)
     assert torch.allclose(gate[:, :C], want, atol=2e-6)
     assert torch.isnan(gate[:, C:]).all()
+
+
+def test_se_gate_from_the_feature_map(sim):
+    g = torch.Generator().manual_seed(9)
+    n, H, W, C, sq = 2, 7, 9, 24, 6
+    x = torch.randn(n, H, W, 32, generator=g)
+    w1, b1 = torch.randn(sq, C, generator=g) * 0.3, torch.randn(sq, generator=g)
+    w2, b2 = torch.randn(C, sq, generator=g) * 0.3, torch.randn(C, generator=g)
+    gate = torch.zeros(n, 24)
+    ws = torch.zeros(n * C * 64)
+    sim.se_gate_nhwc(x, 32, H * W * 32, n, H * W, C, w1, b1, sq, w2, b2, gate, 24, ws)
+    mean = x[..., :C].mean(dim=(1, 2))
+    h = mean @ w1.t() + b1
+    h = h * torch.sigmoid(h)
+    assert torch.allclose(gate, torch.sigmoid(h @ w2.t() + b2), atol=2e-6)
