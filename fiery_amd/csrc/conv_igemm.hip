@@ -221,6 +221,20 @@ extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) {
         FIERY_REQUIRE(d->cout_store <= 64, "conv_fwd: a chained 1x1 produces at most 64 channels");
         FIERY_REQUIRE(!d->res.ptr || !d->res_before_act, "conv_fwd: chained 1x1 adds the residual after the activation");
     }
+    if (d->weights3) {
+        FIERY_REQUIRE(d->weights2 && d->cout_store == 64 && p.vec_epilogue, "conv_fwd: the third stage needs the chained 1x1, 64 stored channels and 16-byte addressable tensors");
+        FIERY_REQUIRE(d->scale3 && d->shift3 && d->out3.ptr && aligned16(d->weights3) && aligned16(d->scale3) && aligned16(d->shift3) &&
+                          aligned16(d->out3.ptr) && d->out3.ld % 4 == 0 && d->out3.img_stride % 4 == 0 && d->out3.ld >= 32,
+                      "conv_fwd: third-stage operands missing or misaligned");
+        FIERY_REQUIRE(d->act3 == FIERY_ACT_NONE || d->act3 == FIERY_ACT_RELU, "conv_fwd: third-stage activation must be none or ReLU");
+        FIERY_REQUIRE(!d->out2.ptr && !d->aux0.ptr && !d->aux1.ptr, "conv_fwd: the third stage and the GRU operands exclude each other");
+        // the kernel's argument block stays as it is: the operands ride in members the chained mode does not use
+        p.heads.w = d->weights3;
+        p.heads.n_out = d->act3;
+        p.aux0.ptr = const_cast<float*>(d->scale3);
+        p.aux1.ptr = const_cast<float*>(d->shift3);
+        p.out2 = TensP{d->out3.ptr, d->out3.ld, d->out3.img_stride};
+    }
     const int bn = (d->cout_pad % 128 == 0) ? 128 : (d->cout_pad % 64 == 0) ? 64 : 32;
     const int n_tiles = d->cout_pad / bn;
     // Tile height: workgroups run in rounds of (256 CUs x resident workgroups per CU); the default picks the height

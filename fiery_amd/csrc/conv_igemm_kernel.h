@@ -634,6 +634,125 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
                 }
             }
             // (4) second epilogue: folded BN, activation, residual, store
+            if (rows16 && p.heads.w) {
+                // (4') ... and a THIRD convolution on the finished tile: the next Bottleneck's 1x1 down-projection
+                // (64 -> 32, + BN + ReLU; layers/convolutions.py:110-116 of the following block).  On its own that layer
+                // is a memory-bound launch that re-reads what this kernel has just written; here its input is the tile in
+                // hand.  Operands ride in members the chained mode does not use: heads.w = packed 64 x 32 weights,
+                // aux0.ptr / aux1.ptr = scale3 / shift3 [32], heads.n_out = act3, out2 = destination.
+                __syncthreads();                                   // everyone is done reading the h and W tiles
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int pl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        smem[pl * 64 + nt * 32 + m] = acc2[nt][r];
+                    }
+                __syncthreads();
+                // rows of the 128 x 64 tile: 16 chunks of four channels per row, 16 rows per pass, 8 passes per thread
+                const int c4 = tid & 15, prow0 = tid >> 4;
+                const int co = c4 * 4;
+                const float4 sc2 = *reinterpret_cast<const float4*>(p.scale2 + co);
+                const float4 sh2 = *reinterpret_cast<const float4*>(p.shift2 + co);
+                float4 y[8];
+                {
+                    int gp = pix0 + prow0;
+                    int o = gp / HWout, ppi = gp - o * HWout;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int pl = prow0 + 16 * i;
+                        float4 v = *reinterpret_cast<const float4*>(&smem[pl * 64 + co]);
+                        v.x = fmaf(v.x, sc2.x, sh2.x);  v.y = fmaf(v.y, sc2.y, sh2.y);  v.z = fmaf(v.z, sc2.z, sh2.z);  v.w = fmaf(v.w, sc2.w, sh2.w);
+                        if (p.act2 == FIERY_ACT_RELU) {
+                            v.x = fmaxf(v.x, 0.f);  v.y = fmaxf(v.y, 0.f);  v.z = fmaxf(v.z, 0.f);  v.w = fmaxf(v.w, 0.f);
+                        } else if (p.act2 == FIERY_ACT_SIGMOID) {
+                            v.x = sigmoidf(v.x);  v.y = sigmoidf(v.y);  v.z = sigmoidf(v.z);  v.w = sigmoidf(v.w);
+                        }
+                        if (gp < M && co < p.cout_store) {
+                            const long long pp = ppi;
+                            if (p.res.ptr) {
+                                const float4 rr = *reinterpret_cast<const float4*>(p.res.ptr + o * p.res.istride + pp * p.res.ld + co);
+                                v.x += rr.x;  v.y += rr.y;  v.z += rr.z;  v.w += rr.w;
+                            }
+                            *reinterpret_cast<float4*>(p.out.ptr + o * p.out.istride + pp * p.out.ld + co) = v;
+                        } else {
+                            v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+                        y[i] = v;
+                        gp += 16;
+                        ppi += 16;
+                        while (ppi >= HWout) {
+                            ppi -= HWout;
+                            ++o;
+                        }
+                    }
+                }
+                __syncthreads();                                   // the staged tile has been read by everyone
+                // the finished tile as the A operand of the third GEMM: two K stages of [pixel][32 k], slot-swizzled
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int pl = prow0 + 16 * i;
+                    *reinterpret_cast<float4*>(&As[c4 >> 3][pl * BK + (((c4 & 7) ^ ((pl >> 1) & 7)) << 2)]) = y[i];
+                }
+                {
+                    float* bdst = &Bs[0][0];                        // 2 stages x 32 x 32 floats = the packed 64 x 32 weights
+                    const float4* wsrc = reinterpret_cast<const float4*>(p.heads.w);
+                    *reinterpret_cast<float4*>(bdst + tid * 4) = wsrc[tid];
+                    *reinterpret_cast<float4*>(bdst + (tid + 256) * 4) = wsrc[tid + 256];
+                }
+                __syncthreads();
+                v16f acc3;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc3[r] = 0.f;
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int pl = wm * 32 + m;
+                        const int slot = (2 * q + hi) ^ ((pl >> 1) & 7);
+                        const float4 a4 = *reinterpret_cast<const float4*>(&As[st][pl * BK + slot * 4]);
+                        const float4 b4 = *reinterpret_cast<const float4*>(&Bs[st][((2 * q + hi) * 32 + m) * 4]);
+                        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc3, 0, 0, 0);
+                        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc3, 0, 0, 0);
+                        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc3, 0, 0, 0);
+                        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc3, 0, 0, 0);
+                    }
+                __syncthreads();                                   // A and W tiles consumed; the staging tile aliases them
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    smem[pl * 32 + m] = acc3[r];
+                }
+                __syncthreads();
+                {
+                    const int d4 = tid & 7, drow0 = tid >> 3;       // 8 chunks per row of 32, 32 rows per pass, 4 passes
+                    const int dco = d4 * 4;
+                    const float4 sc3 = *reinterpret_cast<const float4*>(p.aux0.ptr + dco);
+                    const float4 sh3 = *reinterpret_cast<const float4*>(p.aux1.ptr + dco);
+                    int gp = pix0 + drow0;
+                    int o = gp / HWout, ppi = gp - o * HWout;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int pl = drow0 + 32 * i;
+                        if (gp < M) {
+                            float4 v = *reinterpret_cast<const float4*>(&smem[pl * 32 + dco]);
+                            v.x = fmaf(v.x, sc3.x, sh3.x);  v.y = fmaf(v.y, sc3.y, sh3.y);  v.z = fmaf(v.z, sc3.z, sh3.z);  v.w = fmaf(v.w, sc3.w, sh3.w);
+                            if (p.heads.n_out == FIERY_ACT_RELU) {
+                                v.x = fmaxf(v.x, 0.f);  v.y = fmaxf(v.y, 0.f);  v.z = fmaxf(v.z, 0.f);  v.w = fmaxf(v.w, 0.f);
+                            }
+                            const long long pp = ppi;
+                            *reinterpret_cast<float4*>(p.out2.ptr + o * p.out2.istride + pp * p.out2.ld + dco) = v;
+                        }
+                        gp += 32;
+                        ppi += 32;
+                        while (ppi >= HWout) {
+                            ppi -= HWout;
+                            ++o;
+                        }
+                    }
+                }
+                return;
+            }
             if (rows16) {
                 __syncthreads();                                   // everyone is done reading the h and W tiles
 #pragma unroll

@@ -61,6 +61,8 @@ class _Bottleneck:
             self.fused_tail = ConvOp(lib, L.conv.weight, identity_chan_map(mid), (round_up(mid, 8) // 8, 0), s2, b2, dev,
                                      stride=2 if self.down else 1, act=RELU).chain_pointwise(
                                          L.conv_up_project.weight, sc, sh, RELU)
+        self.next_tail = None            # the fused tail that also computes the next block's down-projection (attach_next)
+        self._down = (L.conv_down_project.weight, fold_bn(L.abn_down_project[0], mid))
         self.skip = None
         if mod.projection is not None:
             sc, sh = fold_bn(mod.projection.bn_skip_proj, cout)
@@ -70,17 +72,31 @@ class _Bottleneck:
     def out_hw(self, H, W):
         return ((H + 1) // 2, (W + 1) // 2) if self.down else (H, W)
 
-    def run(self, eng, srcs, out, scratch):
-        """srcs: one Buf, or two for a split input; scratch: dict name -> Buf factory results."""
+    def attach_next(self, nxt):
+        """Let this block's fused tail also compute the 1x1 down-projection of `nxt`, the block that consumes its output
+        (same kernel, the finished tile still on chip): `nxt` then starts from that tensor and skips its own first launch -
+        a memory-bound layer that would re-read what this block has just written."""
+        if (self.fused_tail is not None and self.skip is None and not self.down and self.cout == 64 and nxt.cin == 64 and
+                nxt.in_split[1] == 0 and nxt.mid <= 32 and os.environ.get('FIERY_CHAIN_NEXT', '1') != '0'):
+            w, (sc, sh) = nxt._down
+            self.next_tail = self.fused_tail.chain_next(w, sc, sh, RELU)
+
+    def run(self, eng, srcs, out, scratch, t1_ready=None, next_t1=None):
+        """srcs: one Buf, or two for a split input; scratch: dict name -> Buf factory results.  t1_ready: this block's
+        down-projection, already computed by the previous block's tail; next_t1: where to put the next block's."""
         x = srcs[0]
         n, H, W = x.n_img, x.H, x.W
         Ho, Wo = self.out_hw(H, W)
-        t1 = scratch('bn_t1', n, H, W, self.mid)
-        self.conv1(list(srcs), t1)
+        t1 = t1_ready
+        if t1 is None:
+            t1 = scratch('bn_t1', n, H, W, self.mid)
+            self.conv1(list(srcs), t1)
         if self.fused_tail is None:
             t2 = scratch('bn_t2', n, Ho, Wo, self.mid)
             self.conv2([t1], t2)
             tail = lambda res: self.conv3([t2], out, res=res)
+        elif next_t1 is not None and self.next_tail is not None:
+            tail = lambda res: self.next_tail([t1], out, res=res, out3=next_t1)
         else:
             tail = lambda res: self.fused_tail([t1], out, res=res)
         if self.skip is None:
@@ -395,6 +411,9 @@ class BevEngine:
             fp = m.future_prediction
             self.grus = [_Gru(self, g, const_x=(i == 0)) for i, g in enumerate(fp.spatial_grus)]
             self.res_blocks = [[_Bottleneck(self, b) for b in seq] for seq in fp.res_blocks]
+            for seq in self.res_blocks:
+                for a, b in zip(seq[:-1], seq[1:]):
+                    a.attach_next(b)
         self._encoder_ops_built = False          # image trunk + lift head: planned on first use (_build_encoder_ops)
         # decoder
         d = m.decoder
@@ -737,16 +756,24 @@ class BevEngine:
                 gru.tilde([x_t, RH], o_t, aux0=U, aux1=h_t)
             x = O
             blocks = self.res_blocks[i]
+            t1_ready = None
             for k, blk in enumerate(blocks):
                 last = (i == n_blocks - 1) and (k == len(blocks) - 1)
+                # a block whose tail also computes the next block's down-projection hands it over in `next_t1`
+                next_t1 = None
+                if k + 1 < len(blocks) and blk.next_tail is not None:
+                    next_t1 = self.buf(f'fpbn_next{k % 2}', B * nf, H, W, blocks[k + 1].mid)
                 if not last:
                     y = self.buf(f'res_{(k % 2)}', B * nf, H, W, ch)
-                    blk.run(self, [x], y, self._scratch('fp'))
+                    blk.run(self, [x], y, self._scratch('fp'), t1_ready=t1_ready, next_t1=next_t1)
                     x = y
+                    t1_ready = next_t1
                 else:
                     # the last convolution writes straight into frames 1.. of the decoder input, per batch element
-                    t1 = self.buf('fpbn_t1', B * nf, H, W, blk.mid)
-                    blk.conv1([x], t1)
+                    t1 = t1_ready
+                    if t1 is None:
+                        t1 = self.buf('fpbn_t1', B * nf, H, W, blk.mid)
+                        blk.conv1([x], t1)
                     if blk.fused_tail is None:
                         t2 = self.buf('fpbn_t2', B * nf, H, W, blk.mid)
                         blk.conv2([t1], t2)

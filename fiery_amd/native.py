@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libfiery_hip.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -60,6 +60,7 @@ class ConvDesc(C.Structure):
         ('res', Nhwc), ('out', Nhwc), ('cout_store', C.c_int32), ('out2', Nhwc),
         ('aux0', Nhwc), ('aux1', Nhwc),
         ('weights2', C.c_void_p), ('scale2', C.c_void_p), ('shift2', C.c_void_p), ('act2', C.c_int32),
+        ('weights3', C.c_void_p), ('scale3', C.c_void_p), ('shift3', C.c_void_p), ('act3', C.c_int32), ('out3', Nhwc),
         ('tile_m', C.c_int32), ('img_bias_border', C.c_int32), ('heads', ConvHeads),
     ]
 

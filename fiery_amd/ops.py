@@ -134,6 +134,7 @@ class ConvOp:
         self.scale, self.shift = sc.to(device), sh.to(device)
         self.act, self.epi, self.res_before_act = act, epi, res_before_act
         self.chain = None
+        self.chain3 = None
         self.heads = None
         self._tile_m = {}            # (n_img, H, W) of the output -> measured best tile height
 
@@ -153,6 +154,27 @@ class ConvOp:
         sc[:cout2], sh[:cout2] = scale, shift
         self.chain = dict(w=packed, scale=sc.to(device), shift=sh.to(device), act=act, cout=cout2)
         return self
+
+    def chain_next(self, weight, scale, shift, act):
+        """After a `chain_pointwise` up-projection: also apply the NEXT block's 1x1 down-projection (Cin = 64 = the chained
+        result, Cout <= 32) to the finished tile - residual included - and write it to `out3` of the call.  Returns a new
+        op that shares this one's packed weights (the plain op stays usable on its own)."""
+        assert self.chain is not None and self.chain['cout'] == 64, 'chain_next follows a 64-channel chained 1x1'
+        w = weight.detach().float().reshape(weight.shape[0], weight.shape[1])
+        cout3, cin3 = w.shape
+        assert cin3 == 64 and cout3 <= 32
+        device = self.packed.device
+        w32 = torch.zeros(32, 64, dtype=torch.float32, device=device)
+        w32[:cout3] = w.to(device)
+        import copy
+        op = copy.copy(self)
+        sc = torch.zeros(32, dtype=torch.float32)
+        sh = torch.zeros(32, dtype=torch.float32)
+        sc[:cout3], sh[:cout3] = scale, shift
+        op.chain3 = dict(w=self.lib.conv_pack_weights(w32.contiguous(), 32, 64, 1, list(range(64)), 8), scale=sc.to(device),
+                         shift=sh.to(device), act=act, cout=cout3)
+        op._tile_m = {}
+        return op
 
     def attach_heads(self, weight, bias, groups, sigmoids):
         """Turn this convolution into the decoder-heads form (FIERY_EPI_HEADS): its activated output - 64 hidden
@@ -198,7 +220,7 @@ class ConvOp:
         return choice
 
     def __call__(self, srcs, out, res=None, img_bias=None, out2=None, aux0=None, aux1=None,
-                 T_out=1, t_out0=0, t_in_add=0, cout_store=None, img_bias_border=False, head_planes=None):
+                 T_out=1, t_out0=0, t_in_add=0, cout_store=None, img_bias_border=False, head_planes=None, out3=None):
         """srcs: list of (Buf, batch_stride, time_stride) or Buf (plain image batch).  With attached heads `out` is a
         `HeadsOut(n_img, H, W, tensor)` and head_planes[o] = (address of row o's plane of image 0, floats between images)."""
         d = native.ConvDesc()
@@ -241,10 +263,18 @@ class ConvOp:
             d.act2 = 0
             d.cout_store = cout_store if cout_store is not None else min(self.cout_pad, round_up(self.cout, UNIT),
                                                                          getattr(out, 'C', self.cout_pad))
+        if self.chain3 is not None and out3 is not None:
+            c3 = self.chain3
+            d.weights3, d.scale3, d.shift3, d.act3 = c3['w'].data_ptr(), c3['scale'].data_ptr(), c3['shift'].data_ptr(), c3['act']
+            d.out3 = out3.as_nhwc_struct()
+        else:
+            d.weights3 = d.scale3 = d.shift3 = None
+            d.act3 = 0
+            d.out3 = _null_nhwc()
         d.out2 = out2.as_nhwc_struct() if out2 is not None else _null_nhwc()
         d.aux0 = aux0.as_nhwc_struct() if aux0 is not None else _null_nhwc()
         d.aux1 = aux1.as_nhwc_struct() if aux1 is not None else _null_nhwc()
-        self._keep = (srcs, out, res, img_bias, out2, aux0, aux1)
+        self._keep = (srcs, out, res, img_bias, out2, aux0, aux1, out3)
         d.tile_m = self._pick_tile(d, out)
         flops = 2.0 * out.n_img * out.H * out.W * self.cin_total * self.kT * self.kH * self.kW * self.cout
         if self.chain is not None:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FIERY_ABI_VERSION 3
+#define FIERY_ABI_VERSION 4
 
 #define FIERY_OK 0
 #define FIERY_EINVAL (-22)      /* bad argument (shape, alignment, null pointer) */
@@ -219,6 +219,15 @@ typedef struct {
     const float* scale2;               /* [64] */
     const float* shift2;               /* [64] */
     int32_t act2;
+    /* Optional third stage on the chained result (the NEXT Bottleneck's 1x1 down-projection, 64 -> 32 + BN + ReLU):
+     * when weights3 != NULL (requires weights2, 16-byte addressable tensors and cout_store == 64) the finished 64-channel
+     * tile - residual included - is multiplied, still on chip, by weights3 (packed for 8 input units and 32 outputs) and
+     * out3 = act3(.*scale3 + shift3) receives 32 channels.  act3: FIERY_ACT_NONE or FIERY_ACT_RELU. */
+    const float* weights3;
+    const float* scale3;               /* [32] */
+    const float* shift3;               /* [32] */
+    int32_t act3;
+    fiery_nhwc out3;
     /* Output pixels per workgroup tile: 0 = let the library choose, 64 or 128 = the caller's choice (a caller that
      * issues the same launch every step can time both once and keep the faster; 64 needs cout_pad % 64 == 0 and
      * no chained 1x1, otherwise the value is ignored).  Results do not depend on it. */

@@ -276,3 +276,36 @@ def test_chained_pointwise_conv_with_residual(sim, mid, cout, stride):
     h = F.relu(F.conv2d(x, w2, stride=stride, padding=1) * s2.view(1, -1, 1, 1) + b2.view(1, -1, 1, 1))
     want = F.relu(F.conv2d(h, w3) * s3.view(1, -1, 1, 1) + b3.view(1, -1, 1, 1)) + res
     assert torch.allclose(out.to_nchw()[:, :cout], want, **TOL), (out.to_nchw()[:, :cout] - want).abs().max()
+
+
+@pytest.mark.parametrize('shape', [(2, 9, 14), (1, 16, 16), (3, 5, 43)])
+def test_chained_tail_plus_the_next_blocks_down_projection(sim, shape):
+    """Bottleneck tail (3x3 + 1x1 + residual) AND the following Bottleneck's 1x1 down-projection (64 -> 32, BN, ReLU) in
+    one kernel: both outputs against torch; image counts and sizes that make tiles straddle images and end ragged."""
+    n, H, W = shape
+    g = torch.Generator().manual_seed(n * 100 + H)
+    mid, cout = 32, 64
+    x = torch.randn(n, mid, H, W, generator=g)
+    w2 = torch.randn(mid, mid, 3, 3, generator=g) * 0.15
+    w3 = torch.randn(cout, mid, 1, 1, generator=g) * 0.3
+    w4 = torch.randn(mid, cout, 1, 1, generator=g) * 0.2
+    s2, b2 = torch.rand(mid, generator=g) + 0.5, torch.randn(mid, generator=g)
+    s3, b3 = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    s4, b4 = torch.rand(mid, generator=g) + 0.5, torch.randn(mid, generator=g)
+    src = _to_buf(x)
+    base = ConvOp(sim, w2, identity_chan_map(mid), (src.C // 8, 0), s2, b2, 'cpu', act=native.ACT_RELU)
+    base.chain_pointwise(w3, s3, b3, native.ACT_RELU)
+    op = base.chain_next(w4, s4, b4, native.ACT_RELU)
+    res = torch.randn(n, cout, H, W, generator=g)
+    out = Buf.alloc(n, H, W, cout, 'cpu')
+    nxt = Buf.alloc(n, H, W, mid, 'cpu')
+    op([src], out, res=_to_buf(res), out3=nxt)
+    h = F.relu(F.conv2d(x, w2, padding=1) * s2.view(1, -1, 1, 1) + b2.view(1, -1, 1, 1))
+    y = F.relu(F.conv2d(h, w3) * s3.view(1, -1, 1, 1) + b3.view(1, -1, 1, 1)) + res
+    t = F.relu(F.conv2d(y, w4) * s4.view(1, -1, 1, 1) + b4.view(1, -1, 1, 1))
+    assert torch.allclose(out.to_nchw()[:, :cout], y, **TOL), (out.to_nchw()[:, :cout] - y).abs().max()
+    assert torch.allclose(nxt.to_nchw()[:, :mid], t, **TOL), (nxt.to_nchw()[:, :mid] - t).abs().max()
+    # the plain op still works on its own
+    out_b = Buf.alloc(n, H, W, cout, 'cpu')
+    base([src], out_b, res=_to_buf(res))
+    assert torch.equal(out_b.nhwc(), out.nhwc())
