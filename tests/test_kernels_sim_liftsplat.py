@@ -349,6 +349,7 @@ def test_pipelined_walk_has_the_bits_of_the_plain_loop(sim, monkeypatch, H, batc
     st = lifted.stride()
     strides = (st[0], st[1], st[3], st[4], st[5], st[2])
     monkeypatch.setenv('FIERY_POOL_BATCH', str(batch))
+    monkeypatch.setenv('FIERY_POOL_PLANE', '0')                  # the tiled kernel: the whole-plane form has no pipelined walk
     monkeypatch.setenv('FIERY_POOL_PIPE', '1')
     out = sim.voxel_pool(lifted, strides, torch.from_numpy(geo), frames, n_cam, D, H, W, C, grid, flags=flags)
     monkeypatch.setenv('FIERY_POOL_PIPE', '0')
