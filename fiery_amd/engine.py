@@ -570,10 +570,11 @@ class BevEngine:
         endpoints.append(x)
         return (endpoints[4], endpoints[3]) if enc.downsample == 16 else (endpoints[3], endpoints[2])
 
-    def lift_head(self, deep, shallow):
+    def lift_head(self, deep, shallow, out=None):
         """`Encoder.forward` after the trunk (encoder.py:87-100): deep (n, cd, h/2, w/2) and shallow (n, cs, h, w) trunk
         levels -> (depth logits (n, D, h, w) or None, context features (n, C, h, w)), planar like the trunk's tensors
-        because the splat kernels read them that way."""
+        because the splat kernels read them that way.  `out` = (logits or None, features): tensors to fill instead of
+        fresh ones (a caller that runs several engines on side streams allocates the results on its own stream)."""
         self._build_encoder_ops()
         lib = self.lib
         cs, cd, cf, ho = self.lh_channels
@@ -600,14 +601,20 @@ class BevEngine:
         D = self.m.depth_channels if self.m.encoder.use_depth_distribution else 0
         C = self.C
 
-        def planar(c_off, c):
+        def planar(c_off, c, dst):
             if c_off % 4 == 0:
-                out = torch.empty(n, c, h, w, dtype=torch.float32, device=self.device)
+                if dst is None:
+                    dst = torch.empty(n, c, h, w, dtype=torch.float32, device=self.device)
                 part = head.slice(c_off, c)
-                lib.nhwc_to_nchw(part, part.ld, part.img_stride, n, c, h * w, out)
-                return out
-            return head.nhwc()[..., c_off:c_off + c].permute(0, 3, 1, 2).contiguous()
-        return (planar(0, D) if D else None), planar(D, C)
+                lib.nhwc_to_nchw(part, part.ld, part.img_stride, n, c, h * w, dst)
+                return dst
+            res = head.nhwc()[..., c_off:c_off + c].permute(0, 3, 1, 2)
+            if dst is None:
+                return res.contiguous()
+            dst.copy_(res)
+            return dst
+        o_logits, o_feats = out if out is not None else (None, None)
+        return (planar(0, D, o_logits) if D else None), planar(D, C, o_feats)
 
     def _pool_workspace(self, f, n, d, h, w, device):
         key = ('poolws', f, n, d, h, w, self.pool_tile, self.pool_flags)

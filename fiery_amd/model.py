@@ -227,17 +227,40 @@ class Fiery(nn.Module):
         depth distribution and features go straight into the fused lift-splat kernel."""
         b, s, n, c, h, w = x.shape
         geometry = self.get_geometry(pack_sequence_dim(intrinsics), pack_sequence_dim(extrinsics))
-        depth_logits, features = self._lift_head(x.view(b * s * n, c, h, w))
+        depth_logits, features = self._lift_head(x.view(b * s * n, c, h, w), groups=b)
         bev = self._pool_head_outputs(depth_logits, features, geometry, b * s, n)
         return unpack_sequence_dim(bev, b, s)
 
-    def _lift_head(self, images):
+    def _lift_head(self, images, groups=1):
         """(N, 3, H, W) images -> (depth logits (N, D, h, w) or None, context features (N, C, h, w)): the image trunk and
         the lift head (reference: encoder.py:58-100) on the HIP engine; under autograd the torch statement of the same
-        layers (the engine has no backward for them), and with `hip_trunk = False` the trunk alone on PyTorch-ROCm."""
+        layers (the engine has no backward for them), and with `hip_trunk = False` the trunk alone on PyTorch-ROCm.
+        `groups`: the images are that many samples' worth; with `sample_streams` every sample's images run as a chain of
+        their own (own engine, own stream) - the late trunk stages are small, latency-bound launches that overlap well."""
         if torch.is_grad_enabled():
             return self.encoder.lift_head(images)
         eng = self.engine()
+        n_img = images.shape[0]
+        if self.hip_trunk and self.sample_streams and groups > 1 and n_img % groups == 0 and images.is_cuda:
+            engines, streams = self._lane_engines(groups)
+            per = n_img // groups
+            ds = self.encoder.downsample
+            fh, fw = images.shape[-2] // ds, images.shape[-1] // ds
+            f32 = dict(dtype=torch.float32, device=images.device)
+            D = self.depth_channels if self.encoder.use_depth_distribution else 0
+            logits = torch.empty(n_img, D, fh, fw, **f32) if D else None
+            feats = torch.empty(n_img, self.encoder_out_channels, fh, fw, **f32)
+            images = images.float().contiguous()
+            cur = torch.cuda.current_stream(images.device)
+            for i, (lane, stream) in enumerate(zip(engines, streams)):
+                stream.wait_stream(cur)
+                with torch.cuda.stream(stream):
+                    sl = slice(i * per, (i + 1) * per)
+                    deep, shallow = lane.trunk_endpoints(images[sl])
+                    lane.lift_head(deep, shallow, out=(None if logits is None else logits[sl], feats[sl]))
+            for stream in streams:
+                cur.wait_stream(stream)
+            return logits, feats
         if self.hip_trunk:
             deep, shallow = eng.trunk_endpoints(images)
         else:
@@ -347,7 +370,7 @@ class Fiery(nn.Module):
         rf = self.receptive_field
         image = image[:, :rf].contiguous()
         b, s, n, c, h, w = image.shape
-        depth_logits, features = self._lift_head(image.view(b * s * n, c, h, w))
+        depth_logits, features = self._lift_head(image.view(b * s * n, c, h, w), groups=b)
         fh, fw = features.shape[-2:]
         feats = features.view(b, s, n, -1, fh, fw)
         if depth_logits is None:
