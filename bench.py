@@ -213,18 +213,25 @@ def main():
     from_images = None
     if rank == 0 and world == 1 and not args.no_from_images:
         image = torch.randn(B, rf + nf, n_cam, 3, *cfg.IMAGE.FINAL_DIM, device=dev)
+        fwd, how = (lambda: model(image, K_d, E_d, ego_d)), 'eager launches'
+        if not args.no_graph:
+            try:
+                model.forward_graph(image, K_d, E_d, ego_d)
+                fwd, how = (lambda: model.forward_graph(image, K_d, E_d, ego_d)), 'hipGraph replay'
+            except Exception:                                        # noqa: BLE001  (measure the eager path instead)
+                pass
         with torch.no_grad():
             for _ in range(2):
-                model(image, K_d, E_d, ego_d)
+                fwd()
             torch.cuda.synchronize()
             t_img = time.perf_counter()
             for _ in range(5):
-                model(image, K_d, E_d, ego_d)
+                fwd()
             torch.cuda.synchronize()
         ms_img = (time.perf_counter() - t_img) / 5 * 1e3
         from_images = {'ms_per_step': round(ms_img, 3), 'samples_per_s': round(B / ms_img * 1e3, 2),
                        'what': f'Fiery.forward from {B * rf * n_cam} images of {cfg.IMAGE.FINAL_DIM[0]}x{cfg.IMAGE.FINAL_DIM[1]}: '
-                               'EfficientNet trunk + lift head + the hot path, eager launches, mean of 5'}
+                               f'EfficientNet trunk + lift head + the hot path, {how}, mean of 5'}
         del image
 
     if rank == 0:

@@ -362,6 +362,30 @@ class Fiery(nn.Module):
         entry[0].replay()
         return entry[1]
 
+    def forward_graph(self, image, intrinsics, extrinsics, future_egomotion, future_distribution_inputs=None, noise=None):
+        """`forward` from images replayed from a captured hipGraph (image trunk, lift head and the hot path: ~1,000
+        launches on one stream per sample).  Keyed on the argument buffers like `bev_forward_graph`; the returned tensors
+        belong to the graph."""
+        self._require_eval()
+        args = dict(image=image, intrinsics=intrinsics, extrinsics=extrinsics, future_egomotion=future_egomotion,
+                    future_distribution_inputs=future_distribution_inputs, noise=noise)
+        eng = self.engine()
+        key = ('images', id(eng), self.sample_streams, self.hip_trunk) + tuple(
+            (k,) if v is None else (k, v.data_ptr(), tuple(v.shape), tuple(v.stride()), v.dtype) for k, v in args.items())
+        entry = self._graphs.get(key)
+        if entry is None:
+            with torch.no_grad():
+                self.forward(**args)                  # eager once: plans, buffers, workspaces, tile choices
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    out = self.forward(**args)
+            while len(self._graphs) >= 4:
+                self._graphs.pop(next(iter(self._graphs)))
+            entry = self._graphs[key] = (graph, out, args)
+        entry[0].replay()
+        return entry[1]
+
     def forward(self, image, intrinsics, extrinsics, future_egomotion, future_distribution_inputs=None, noise=None):
         """reference: fiery.py:130-191.  image (B, S_total, n, 3, H, W); intrinsics (B, S_total, n, 3, 3);
         extrinsics (B, S_total, n, 4, 4); future_egomotion (B, S_total, 6); labels (B, 1+n_future, 6, X, Y);

@@ -313,6 +313,27 @@ def test_forward_from_images_hip_trunk_equals_torch_trunk(hip):
             assert (a[k] - v).abs().max().item() <= TOL * max(1.0, v.abs().max().item()), k
 
 
+def test_forward_graph_from_images_equals_eager(hip):
+    cfg = tiny_cfg('baseline.yml')
+    model, _ = _model(cfg)
+    image, K, E, ego = make_inputs(2, model.receptive_field + model.n_future, 2, image_hw=tuple(cfg.IMAGE.FINAL_DIM), seed=5)
+    args = [t.to(DEV) for t in (image, K, E, ego)]
+    with torch.no_grad():
+        want = {k: (None if v is None else v.clone()) for k, v in model(*args).items()}
+        got = model.forward_graph(*args)
+        torch.cuda.synchronize()
+        for k, v in want.items():
+            if v is not None:
+                assert (got[k] - v).abs().max().item() <= 1e-5 * max(1.0, v.abs().max().item()), k
+        args[0].mul_(0.5)                                            # refresh an input in place, replay
+        got = model.forward_graph(*args)
+        want = model(*args)
+        torch.cuda.synchronize()
+        for k, v in want.items():
+            if v is not None:
+                assert (got[k] - v).abs().max().item() <= 1e-5 * max(1.0, v.abs().max().item()), k
+
+
 def test_forward_from_images_per_sample_chains_equal_the_batched_pass(hip):
     """Trunk, lift head and hot path of every sample on its own stream (batch 2) against the same pass on one stream."""
     cfg = tiny_cfg('baseline.yml')

@@ -39,6 +39,11 @@ def main():
     x = image[:, :rf].reshape(-1, 3, *cfg.IMAGE.FINAL_DIM).contiguous()
     with torch.no_grad():
         ms_full = timed(lambda: model(image, K, E, ego))
+        try:
+            ms_graph = timed(lambda: model.forward_graph(image, K, E, ego))
+        except Exception as e:                      # noqa: BLE001
+            ms_graph = float('nan')
+            print('graph capture failed:', repr(e)[:200])
         ms_trunk = timed(lambda: model.encoder.trunk_endpoints(x))
         ms_trunk_hip = timed(lambda: model.engine().trunk_endpoints(x))
         model.hip_trunk = False
@@ -47,7 +52,7 @@ def main():
         deep, shallow = model.encoder.trunk_endpoints(x)
         ms_head = timed(lambda: model.engine().lift_head(deep, shallow))
         ms_head_torch = timed(lambda: model.encoder.depth_layer(model.encoder.get_features(x))) - ms_trunk
-    print(f'batch {B}: forward from images {ms_full:.2f} ms with the trunk on the engine, {ms_full_torch_trunk:.2f} ms with it on PyTorch-ROCm  '
+    print(f'batch {B}: forward from images {ms_full:.2f} ms with the trunk on the engine ({ms_graph:.2f} ms replayed from a hipGraph), {ms_full_torch_trunk:.2f} ms with it on PyTorch-ROCm  '
           f'(trunk alone: engine {ms_trunk_hip:.2f} ms, PyTorch-ROCm {ms_trunk:.2f} ms for {x.shape[0]} images; '
           f'lift head on the engine {ms_head:.2f} ms, on PyTorch-ROCm {ms_head_torch:.2f} ms)')
 
