@@ -367,6 +367,117 @@ __global__ void k_scale_channels4(float* __restrict__ x, int ld, int HW, int C4,
     *p = v;
 }
 
+// ------------------------------------------------------------------------------------------------
+// the step after the path: per-frame instance segmentation (evaluation)
+// ------------------------------------------------------------------------------------------------
+// One workgroup per frame; replaces the ATen chain of fiery/utils/instance.py:80-144 (threshold, 3x3 max-pool NMS,
+// nonzero, distance matrix + argmin over <= max_centers centres, foreground mask, unique + renumbering):
+//   1. centres = pixels above the threshold that equal the maximum of their 3x3 neighbourhood (of thresholded values,
+//      -inf outside the image), collected in row-major order by ballot/prefix compaction - `torch.nonzero`'s order -,
+//      the first max_centers kept;
+//   2. every pixel joins the first centre at minimal distance from (pixel + offset); background pixels get 0;
+//   3. the ids that occur are renumbered 0, 1, 2, ... in ascending order (`torch.unique` + `update_instance_ids`).
+// Index arithmetic throughout; the only floating-point decision is the argmin, evaluated as sqrtf(dx*dx + dy*dy) with
+// separately rounded products (ATen's vectorised norm differs from that in the last bit of some distances, which can
+// only matter for a pixel whose two nearest centres are equidistant to within one ulp).
+constexpr int kMaxInstanceCenters = 256;
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(1024) void k_instance_segmentation(const float* __restrict__ center, const float* __restrict__ offset,
+                                                                const unsigned char* __restrict__ foreground, int H, int W,
+                                                                float threshold, int max_centers, int* __restrict__ seg,
+                                                                int* __restrict__ centers, int* __restrict__ n_centers) {
+    __shared__ int c_y[kMaxInstanceCenters], c_x[kMaxInstanceCenters];
+    __shared__ int present[kMaxInstanceCenters + 1], remap[kMaxInstanceCenters + 1];
+    __shared__ int wave_count[16];
+    __shared__ int running;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+    const int HW = H * W;
+    const float* c = center + static_cast<long long>(f) * HW;
+    const float* off = offset + static_cast<long long>(f) * 2 * HW;
+    const unsigned char* fg = foreground + static_cast<long long>(f) * HW;
+    int* out = seg + static_cast<long long>(f) * HW;
+    if (tid == 0) running = 0;
+    for (int k = tid; k <= kMaxInstanceCenters; k += blockDim.x) present[k] = 0;
+    __syncthreads();
+    auto thresholded = [&](int y, int x) {
+        const float v = c[y * W + x];
+        return v > threshold ? v : -1.0f;
+    };
+    // 1. ordered compaction of the local maxima
+    for (int p0 = 0; p0 < HW; p0 += blockDim.x) {
+        const int p = p0 + tid;
+        bool keep = false;
+        if (p < HW) {
+            const int y = p / W, x = p - y * W;
+            const float v = thresholded(y, x);
+            float m = v;
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int yy = y + dy, xx = x + dx;
+                    if (yy >= 0 && yy < H && xx >= 0 && xx < W) m = fmaxf(m, thresholded(yy, xx));
+                }
+            keep = v == m && v > 0.f;
+        }
+        const unsigned long long ballot = __ballot(keep);
+        const int before = __popcll(ballot & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_count[wave] = __popcll(ballot);
+        __syncthreads();
+        int slot = running + before;
+        for (int k = 0; k < wave; ++k) slot += wave_count[k];
+        if (keep && slot < max_centers) {
+            c_y[slot] = p / W;
+            c_x[slot] = p % W;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int total = 0;
+            for (int k = 0; k < n_waves; ++k) total += wave_count[k];
+            running += total;
+        }
+        __syncthreads();
+    }
+    const int n = min(running, max_centers);
+    if (tid == 0) n_centers[f] = n;
+    for (int k = tid; k < max_centers; k += blockDim.x) {
+        centers[(static_cast<long long>(f) * max_centers + k) * 2] = k < n ? c_y[k] : -1;
+        centers[(static_cast<long long>(f) * max_centers + k) * 2 + 1] = k < n ? c_x[k] : -1;
+    }
+    if (n == 0) {                                       // instance.py:129-131: nothing detected, all background
+        for (int p = tid; p < HW; p += blockDim.x) out[p] = 0;
+        return;
+    }
+    // 2. nearest centre of (pixel + offset)
+    for (int p = tid; p < HW; p += blockDim.x) {
+        const int y = p / W, x = p - y * W;
+        const float ly = static_cast<float>(y) + off[p], lx = static_cast<float>(x) + off[HW + p];
+        float best = 0.f;
+        int arg = 0;
+        for (int k = 0; k < n; ++k) {
+            const float dy = static_cast<float>(c_y[k]) - ly, dx = static_cast<float>(c_x[k]) - lx;
+            const float d = sqrtf(dy * dy + dx * dx);
+            if (k == 0 || d < best) {
+                best = d;
+                arg = k;
+            }
+        }
+        const int id = fg[p] ? arg + 1 : 0;
+        out[p] = id;
+        present[id] = 1;
+    }
+    __syncthreads();
+    // 3. renumber the ids that occur
+    if (tid == 0) {
+        int next = 0;
+        for (int k = 0; k <= n; ++k) {
+            remap[k] = next;
+            next += present[k];
+        }
+    }
+    __syncthreads();
+    for (int p = tid; p < HW; p += blockDim.x) out[p] = remap[out[p]];
+}
+#pragma clang fp contract(fast)
+
 // Squeeze-and-excite gate of one image per workgroup: gate = sigmoid(W2 . swish(W1 . mean + b1) + b2).
 // The channel means sit in LDS; a thread owns channels t, t + 256, ... and forms its share of every hidden unit (W1 rows
 // are read unit-stride across the workgroup), the shares meet in LDS and are summed in thread order (reproducible),
@@ -583,6 +694,18 @@ extern "C" int fiery_depthwise_conv_nhwc(const float* in, int in_ld, int n_img, 
     hipLaunchKernelGGL(k_depthwise4, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), in, in_ld, H, W, C / 4, w, w_ld,
                        k, stride, pad_top, pad_left, Hout, Wout, scale, shift, act, out, out_ld, total);
     return check_launch("depthwise_conv");
+}
+
+extern "C" int fiery_instance_segmentation(const float* center, const float* offset, const uint8_t* foreground, int n_frames,
+                                           int H, int W, float conf_threshold, int max_centers, int32_t* instance_seg,
+                                           int32_t* centers, int32_t* n_centers, fiery_stream_t stream) {
+    FIERY_REQUIRE(center && offset && foreground && instance_seg && centers && n_centers, "instance_segmentation: null pointer");
+    FIERY_REQUIRE(n_frames > 0 && H > 0 && W > 0 && static_cast<long long>(H) * W < (1ll << 30), "instance_segmentation: bad shape");
+    FIERY_REQUIRE(max_centers > 0 && max_centers <= kMaxInstanceCenters, "instance_segmentation: at most %d centres per frame",
+                  kMaxInstanceCenters);
+    hipLaunchKernelGGL(k_instance_segmentation, dim3(n_frames), dim3(1024), 0, as_stream(stream), center, offset, foreground, H, W,
+                       conf_threshold, max_centers, instance_seg, centers, n_centers);
+    return check_launch("instance_segmentation");
 }
 
 extern "C" int fiery_se_gate(const float* mean, int mean_ld, int n_img, int C, const float* w1, const float* b1, int hidden,

@@ -125,6 +125,8 @@ _SIGNATURES = {
                                             C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'fiery_depthwise_conv_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_int] * 6 +
                                   [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'fiery_instance_segmentation': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'fiery_se_gate': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                       C.c_int, C.c_void_p]),
     'fiery_se_gate_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
@@ -309,6 +311,17 @@ class Lib:
         self.check(self.dll.fiery_depthwise_conv_nhwc(_ptr(x), in_ld, n_img, h, w, c, _ptr(weights), w_ld, k, stride, pad_top,
                                                       pad_left, ho, wo, _ptr(scale), _ptr(shift), act, _ptr(out), out_ld,
                                                       _stream_of(out)))
+
+    def instance_segmentation(self, center, offset, foreground, conf_threshold=0.1, max_centers=100):
+        """center (n, H, W) f32, offset (n, 2, H, W) f32, foreground (n, H, W) uint8 ->
+        (instance ids (n, H, W) int32, centres (n, max_centers, 2) int32, n_centres (n,) int32)."""
+        n, h, w = center.shape
+        seg = torch.empty(n, h, w, dtype=torch.int32, device=center.device)
+        centers = torch.empty(n, max_centers, 2, dtype=torch.int32, device=center.device)
+        count = torch.empty(n, dtype=torch.int32, device=center.device)
+        self.check(self.dll.fiery_instance_segmentation(_ptr(center), _ptr(offset), _ptr(foreground), n, h, w, conf_threshold,
+                                                        max_centers, _ptr(seg), _ptr(centers), _ptr(count), _stream_of(seg)))
+        return seg, centers, count
 
     def se_gate(self, mean, mean_ld, n_img, c, w1, b1, hidden, w2, b2, gate, gate_ld):
         self.check(self.dll.fiery_se_gate(_ptr(mean), mean_ld, n_img, c, _ptr(w1), _ptr(b1), hidden, _ptr(w2), _ptr(b2),

@@ -353,6 +353,22 @@ int fiery_nchw_to_nhwc(const float* in, int n_img, int C, int HW, float* out, in
 int fiery_nhwc_to_nchw(const float* in, int in_ld, int64_t in_img_stride, int n_img, int C, int HW,
                        float* out, fiery_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * The step after the path (evaluation): per-frame instance segmentation
+ *                                  (reference: fiery/utils/instance.py:80-144
+ *                                   `get_instance_segmentation_and_centers`, called per frame from
+ *                                   `predict_instance_segmentation_and_trajectories`, evaluate.py:62)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* center [n_frames][H][W] (centerness), offset [n_frames][2][H][W], foreground uint8 [n_frames][H][W] (1 = vehicle).
+ * Centres = local 3x3 maxima above conf_threshold, row-major order, the first max_centers (<= 256) kept:
+ * centers [n_frames][max_centers][2] = (row, column), -1 past n_centers[f].  instance_seg [n_frames][H][W]: 0 =
+ * background, else the consecutive id of the nearest centre to (pixel + offset), ids renumbered in ascending order
+ * over those that occur (a frame without background pixels starts at 0, as `torch.unique` makes it). */
+int fiery_instance_segmentation(const float* center, const float* offset, const uint8_t* foreground, int n_frames,
+                                int H, int W, float conf_threshold, int max_centers, int32_t* instance_seg,
+                                int32_t* centers, int32_t* n_centers, fiery_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

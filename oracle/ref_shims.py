@@ -112,6 +112,7 @@ def load_reference():
     ns.distributions = importlib.import_module('fiery.models.distributions')
     ns.decoder = importlib.import_module('fiery.models.decoder')
     ns.encoder = importlib.import_module('fiery.models.encoder')
+    ns.instance = importlib.import_module('fiery.utils.instance')
     ns.fiery_model = importlib.import_module('fiery.models.fiery')
     ns.Fiery = ns.fiery_model.Fiery
     _REF = ns

@@ -353,6 +353,26 @@ def test_forward_from_images_per_sample_chains_equal_the_batched_pass(hip):
 
 
 # ------------------------------------------------------------------------------------------------------
+# the step after the path: per-frame instance segmentation (fiery/utils/instance.py:80-144)
+# ------------------------------------------------------------------------------------------------------
+def test_instance_segmentation_full_size_vs_oracle(hip):
+    from fiery_amd import instance as hip_instance
+    from oracle import instance as oi
+    from tests.test_kernels_sim_aux import _instance_case
+    cases = [_instance_case(s, H=200, W=200, n_blobs=nb) for s, nb in ((11, 25), (12, 130), (13, 3))]
+    center = torch.stack([c for c, _, _ in cases])
+    offset = torch.stack([o for _, o, _ in cases])
+    fg = torch.stack([m for _, _, m in cases])
+    seg, centers, count = hip_instance.instance_segmentation_frames(center.to(DEV), offset.to(DEV), fg.to(DEV))
+    for f in range(3):
+        want_seg, want_centers = oi.instance_segmentation_and_centers(center[f], offset[f], fg[f])
+        k = len(want_centers)
+        assert int(count[f]) == k and torch.equal(centers[f, :k].cpu(), want_centers.long())      # index work: bit-exact
+        # ids: a pixel can only differ where its two nearest centres are equidistant to within an ulp
+        assert (seg[f:f + 1].cpu() != want_seg).sum().item() <= 2
+
+
+# ------------------------------------------------------------------------------------------------------
 # convolution kernel at the real shapes vs torch fp32 (CPU)
 # ------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('cin,cout,k,stride', [(64, 64, 3, 1), (64, 32, 1, 1), (64, 64, 7, 2), (32, 32, 3, 1),

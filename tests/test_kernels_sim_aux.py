@@ -258,3 +258,54 @@ def test_se_gate_from_the_feature_map(sim):
     h = mean @ w1.t() + b1
     h = h * torch.sigmoid(h)
     assert torch.allclose(gate, torch.sigmoid(h @ w2.t() + b2), atol=2e-6)
+
+
+# ------------------------------------------------------------------------------------------------------
+# the step after the path: per-frame instance segmentation (reference: fiery/utils/instance.py:80-144)
+# ------------------------------------------------------------------------------------------------------
+def _instance_case(seed, H=40, W=56, n_blobs=7, all_foreground=False):
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float), torch.arange(W, dtype=torch.float), indexing='ij')
+    center = torch.zeros(H, W)
+    cy, cx = torch.rand(n_blobs, generator=g) * H, torch.rand(n_blobs, generator=g) * W
+    for k in range(n_blobs):
+        center = torch.maximum(center, torch.exp(-((yy - cy[k]) ** 2 + (xx - cx[k]) ** 2) / 9.0))
+    center = center + 0.01 * torch.rand(H, W, generator=g)
+    nearest = torch.stack([(yy - cy[k]) ** 2 + (xx - cx[k]) ** 2 for k in range(n_blobs)]).argmin(0)
+    offset = torch.stack([cy[nearest] - yy, cx[nearest] - xx]) + 0.3 * torch.randn(2, H, W, generator=g)
+    fg = torch.ones(H, W, dtype=torch.bool) if all_foreground else center > 0.05
+    return center, offset, fg
+
+
+@pytest.mark.parametrize('seed,kw', [(0, {}), (1, dict(n_blobs=1)), (2, dict(all_foreground=True)),
+                                     (3, dict(n_blobs=140, H=64, W=64)), (4, dict(H=33, W=70, n_blobs=12))])
+def test_instance_segmentation_matches_the_oracle(sim, seed, kw):
+    """Centres bit for bit (index work); ids bit for bit too on these seeds (a pixel could only differ if its two
+    nearest centres were equidistant to within an ulp); more than 100 centres, a frame without background, one blob."""
+    from fiery_amd import instance as hip_instance
+    from oracle import instance as oi
+    center, offset, fg = _instance_case(seed, **kw)
+    want_seg, want_centers = oi.instance_segmentation_and_centers(center, offset, fg)
+    got_seg, got_centers = hip_instance.get_instance_segmentation_and_centers(center, offset, fg, lib=sim)
+    assert torch.equal(got_centers, want_centers)
+    assert got_seg.shape == want_seg.shape and got_seg.dtype == want_seg.dtype
+    assert torch.equal(got_seg, want_seg)
+
+
+def test_instance_segmentation_batched_frames_and_empty_frame(sim):
+    from fiery_amd import instance as hip_instance
+    from oracle import instance as oi
+    cases = [_instance_case(s, H=24, W=40, n_blobs=4) for s in (5, 6, 7)]
+    center = torch.stack([c for c, _, _ in cases])
+    center[1] = 0.0                                                  # nothing above the threshold in frame 1
+    offset = torch.stack([o for _, o, _ in cases])
+    fg = torch.stack([m for _, _, m in cases])
+    seg, centers, count = hip_instance.instance_segmentation_frames(center, offset, fg, lib=sim)
+    for f in range(3):
+        want_seg, want_centers = oi.instance_segmentation_and_centers(center[f], offset[f], fg[f])
+        assert torch.equal(seg[f:f + 1], want_seg)
+        assert int(count[f]) == len(want_centers)
+        assert torch.equal(centers[f, :len(want_centers)], want_centers.long()) and (centers[f, len(want_centers):] == -1).all()
+    assert int(count[1]) == 0 and seg[1].abs().sum() == 0
+    with pytest.raises(ValueError):
+        hip_instance.instance_segmentation_frames(center, offset, fg, nms_kernel_size=5, lib=sim)

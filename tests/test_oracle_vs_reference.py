@@ -5,6 +5,7 @@ import torch
 
 from fiery_amd.synthetic import make_inputs, make_lifted_features
 from oracle import bev_stack
+from oracle import instance as oi
 from oracle import lift_splat as ls
 from tests.helpers import forward_case, randomise_weights, tiny_cfg
 
@@ -97,3 +98,30 @@ def test_hot_path_equals_reference_forward(ref, preset, B, labels):
         if v is None:
             continue
         assert torch.allclose(v, want[k], rtol=1e-5, atol=1e-5), k
+
+
+def _instance_case(seed, H=40, W=56, n_blobs=7, all_foreground=False):
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float), torch.arange(W, dtype=torch.float), indexing='ij')
+    center = torch.zeros(H, W)
+    cy, cx = torch.rand(n_blobs, generator=g) * H, torch.rand(n_blobs, generator=g) * W
+    for k in range(n_blobs):
+        center = torch.maximum(center, torch.exp(-((yy - cy[k]) ** 2 + (xx - cx[k]) ** 2) / 9.0))
+    center = center + 0.01 * torch.rand(H, W, generator=g)
+    nearest = torch.stack([(yy - cy[k]) ** 2 + (xx - cx[k]) ** 2 for k in range(n_blobs)]).argmin(0)
+    offset = torch.stack([cy[nearest] - yy, cx[nearest] - xx]) + 0.3 * torch.randn(2, H, W, generator=g)
+    fg = torch.ones(H, W, dtype=torch.bool) if all_foreground else center > 0.05
+    return center, offset, fg
+
+
+@pytest.mark.parametrize('seed,kw', [(0, {}), (1, dict(n_blobs=1)), (2, dict(all_foreground=True)), (3, dict(n_blobs=140, H=64, W=64))])
+def test_instance_segmentation_oracle_equals_reference(ref, seed, kw):
+    """fiery/utils/instance.py:116-144 run by the reference itself (more than 100 centres, no background pixel, ...)."""
+    center, offset, fg = _instance_case(seed, **kw)
+    want_seg, want_centers = ref.instance.get_instance_segmentation_and_centers(center.clone(), offset.clone(), fg.clone())
+    got_seg, got_centers = oi.instance_segmentation_and_centers(center, offset, fg)
+    assert torch.equal(got_seg, want_seg) and torch.equal(got_centers, want_centers)
+    assert got_seg.max() > 0
+    empty_seg, empty_centers = oi.instance_segmentation_and_centers(torch.zeros_like(center), offset, fg)
+    ref_seg, ref_centers = ref.instance.get_instance_segmentation_and_centers(torch.zeros_like(center), offset, fg)
+    assert torch.equal(empty_seg, ref_seg) and len(empty_centers) == len(ref_centers) == 0
