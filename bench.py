@@ -254,6 +254,7 @@ def main():
         print(json.dumps(line), flush=True)
     if use_dist:
         import torch.distributed as dist
+        dist.barrier()                      # rank 0 ran its instrumented step meanwhile: leave together
         dist.destroy_process_group()
 
 
