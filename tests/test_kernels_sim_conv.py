@@ -309,3 +309,54 @@ def test_chained_tail_plus_the_next_blocks_down_projection(sim, shape):
     out_b = Buf.alloc(n, H, W, cout, 'cpu')
     base([src], out_b, res=_to_buf(res))
     assert torch.equal(out_b.nhwc(), out.nhwc())
+
+
+@pytest.mark.parametrize('case', range(20))
+def test_conv_random_shapes(sim, case):
+    """Seeded sweep: channel counts that are and are not whole 32-channel stages (scalar-addressed vs per-lane loop,
+    small-cin loop), one or two sources, kernel 1 / 3 / 5, stride 1 / 2, ragged image sizes and counts, both tile
+    heights, residual before / after the activation, all activations - against torch."""
+    rng = np.random.RandomState(500 + case)
+    c0 = int(rng.choice([8, 16, 24, 32, 35, 64, 96]))
+    c1 = int(rng.choice([0, 0, 8, 32, 64]))
+    cout = int(rng.choice([8, 24, 32, 40, 64, 100, 128]))
+    k = int(rng.choice([1, 3, 3, 5]))
+    stride = int(rng.choice([1, 1, 2]))
+    n, H, W = int(rng.randint(1, 4)), int(rng.randint(3, 14)), int(rng.randint(3, 20))
+    act = int(rng.choice([native.ACT_NONE, native.ACT_RELU, native.ACT_SIGMOID, native.ACT_SWISH]))
+    g = torch.Generator().manual_seed(case)
+    x0 = torch.randn(n, c0, H, W, generator=g)
+    x1 = torch.randn(n, c1, H, W, generator=g) if c1 else None
+    cin = c0 + c1
+    w = torch.randn(cout, cin, k, k, generator=g) * (0.5 / (cin ** 0.5 * k))
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    s0 = _to_buf(x0)
+    srcs, units = [s0], (s0.C // 8, 0)
+    cmap = identity_chan_map(c0)
+    if c1:
+        s1 = _to_buf(x1)
+        srcs.append(s1)
+        units = (s0.C // 8, s1.C // 8)
+        cmap = cmap + identity_chan_map(c1, offset=s0.C)
+    res_before = bool(rng.randint(2)) and act != native.ACT_SWISH
+    op = ConvOp(sim, w, cmap, units, scale, shift, 'cpu', stride=stride, act=act, res_before_act=res_before)
+    ho, wo = op.out_hw(H, W)
+    use_res = bool(rng.randint(2))
+    res = torch.randn(n, cout, ho, wo, generator=g) if use_res else None
+    out = Buf.alloc(n, ho, wo, cout, 'cpu')
+    import os
+    os.environ['FIERY_CONV_TILE_M'] = str(int(rng.choice([64, 128])))
+    try:
+        op(srcs, out, res=_to_buf(res) if use_res else None)
+    finally:
+        del os.environ['FIERY_CONV_TILE_M']
+    xin = x0 if x1 is None else torch.cat([x0, x1], 1)
+    y = F.conv2d(xin, w, stride=stride, padding=(k - 1) // 2) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    if use_res and res_before:
+        y = y + res
+    y = {native.ACT_NONE: lambda v: v, native.ACT_RELU: F.relu, native.ACT_SIGMOID: torch.sigmoid,
+         native.ACT_SWISH: lambda v: v * torch.sigmoid(v)}[act](y)
+    if use_res and not res_before:
+        y = y + res
+    got = out.to_nchw()[:, :cout]
+    assert torch.allclose(got, y, **TOL), (case, c0, c1, cout, k, stride, n, H, W, act, (got - y).abs().max().item())

@@ -407,3 +407,75 @@ def test_whole_plane_form(sim, monkeypatch, H, batch, queue_cap, tail_parts):
         assert np.array_equal(got >= 0, keep) and np.array_equal(got[keep], rank_o[keep])      # the ranks backward needs
         kept += keep.mean() / frames
     assert 0.2 < kept < 0.95                      # some quads are skipped without being read, some are not
+
+
+@pytest.mark.parametrize('case', range(24))
+def test_pooling_random_shapes_against_the_oracle(sim, case):
+    """Seeded sweep over camera counts, depth bins, feature-map sizes (row counts that do and do not divide the row
+    batches, quads and scalar columns), channel counts, frame counts, grid sizes (one tile, several tiles) and camera
+    attitudes: whichever kernel form the library picks, the sums equal the float64 pooling and the ranks left in the
+    workspace equal the oracle's; the backward gather from those ranks is checked on the way."""
+    rng = np.random.RandomState(1000 + case)
+    n_cam, D = int(rng.randint(1, 4)), int(rng.randint(1, 10))
+    H = int(rng.choice([1, 5, 7, 14, 16, 28]))
+    W = int(rng.choice([4, 8, 10, 12, 20]))
+    C, frames = int(rng.randint(1, 4)), int(rng.randint(1, 4))
+    frustum, intr, extr, lifted = _small_problem(2000 + case, n_cam=n_cam, D=D, H=H, W=W, C=C, frames=frames,
+                                                 jitter=bool(rng.randint(2)))
+    if rng.randint(3) == 0:                                            # roll one camera: many-run columns
+        roll = torch.tensor([[0.0, -1.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0], [0.0, 0.0, 1.0, 0.0], [0.0, 0.0, 0.0, 1.0]])
+        extr = extr.clone()
+        extr[:, 0] = extr[:, 0] @ roll
+    half = float(rng.choice([6.0, 15.0, 40.0]))
+    step = float(rng.choice([0.5, 1.0, 2.0]))
+    grid, (res, start, dim) = _grid([-half, half, step], [-half * 0.75, half * 0.75, step], [-10.0, 10.0, 20.0])
+    geo = ls.get_geometry(frustum, intr.numpy(), extr.numpy())
+    st = lifted.stride()
+    strides = (st[0], st[1], st[3], st[4], st[5], st[2])
+    tile = int(rng.choice([0, 0, 61]))                                 # default plan, or a small tile: several tiles
+    ws = sim.pool_workspace(frames, n_cam, D, H, W, lifted.device, grid, tile)
+    out = sim.voxel_pool(lifted, strides, torch.from_numpy(geo), frames, n_cam, D, H, W, C, grid, workspace=ws,
+                         tile_voxels=tile)
+    rank = ws[:frames * n_cam * D * H * W]
+    g = torch.randn(frames, C, int(dim[0]), int(dim[1]), generator=torch.Generator().manual_seed(case))
+    gx = torch.full((frames, n_cam, C, D, H, W), float('nan')).permute(0, 1, 3, 4, 5, 2)
+    sim.voxel_pool_bwd(g, rank, frames, n_cam, D, H, W, C, gx)
+    for f in range(frames):
+        pts = ls.lifted_to_points(lifted[f].numpy())
+        exact = ls.voxel_pool_exact(pts, geo[f].reshape(-1, 3), res, start, dim)
+        assert np.abs(out[f].numpy() - exact).max() < 2e-5, (case, n_cam, D, H, W, C, frames, tile)
+        _, keep, rank_o = ls.voxel_indices(geo[f].reshape(-1, 3), res, start, dim)
+        got = rank.view(frames, -1)[f].numpy().astype(np.int64)
+        assert np.array_equal(got >= 0, keep) and np.array_equal(got[keep], rank_o[keep])
+        want_gx = ls.voxel_pool_backward(g[f].numpy(), geo[f].reshape(-1, 3), res, start, dim)
+        assert np.array_equal(gx[f].reshape(-1, C).numpy(), want_gx)
+
+
+@pytest.mark.parametrize('case', range(12))
+def test_fused_and_reproducible_forms_random_shapes(sim, case):
+    """The same sweep for the fused lift (x) splat (depth softmax times features, never materialised) and for the
+    order-independent fixed-point mode, which must also give identical bits on a second call."""
+    rng = np.random.RandomState(3000 + case)
+    n_cam, D = int(rng.randint(1, 4)), int(rng.randint(2, 9))
+    H = int(rng.choice([4, 7, 8, 14, 28]))
+    W = int(rng.choice([4, 8, 10, 12]))
+    C, frames = int(rng.randint(1, 4)), int(rng.randint(1, 3))
+    frustum, intr, extr, _ = _small_problem(4000 + case, n_cam=n_cam, D=D, H=H, W=W, C=C, frames=frames)
+    grid, (res, start, dim) = _grid([-20.0, 20.0, 1.0], [-16.0, 16.0, 1.0], [-10.0, 10.0, 20.0])
+    geo = ls.get_geometry(frustum, intr.numpy(), extr.numpy())
+    gen = torch.Generator().manual_seed(case)
+    logits = torch.randn(frames * n_cam, D, H, W, generator=gen)
+    feats = torch.randn(frames, n_cam, C, H, W, generator=gen)
+    prob = sim.depth_softmax(logits)
+    lifted = prob.view(frames, n_cam, 1, D, H, W) * feats.view(frames, n_cam, C, 1, H, W)
+    flags = native.POOL_DETERMINISTIC if case % 2 else 0
+    fused = sim.lift_splat(prob, feats, torch.from_numpy(geo), frames, n_cam, D, H, W, C, grid, flags=flags)
+    st = lifted.stride()
+    plain = sim.voxel_pool(lifted, (st[0], st[1], st[3], st[4], st[5], st[2]), torch.from_numpy(geo), frames, n_cam, D, H, W,
+                           C, grid, flags=flags)
+    for f in range(frames):
+        exact = ls.voxel_pool_exact(ls.lifted_to_points(lifted[f].numpy()), geo[f].reshape(-1, 3), res, start, dim)
+        assert np.abs(fused[f].numpy() - exact).max() < 5e-6 and np.abs(plain[f].numpy() - exact).max() < 5e-6
+    if flags:
+        again = sim.lift_splat(prob, feats, torch.from_numpy(geo), frames, n_cam, D, H, W, C, grid, flags=flags)
+        assert torch.equal(again, fused)
