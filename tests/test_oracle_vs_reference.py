@@ -125,3 +125,47 @@ def test_instance_segmentation_oracle_equals_reference(ref, seed, kw):
     empty_seg, empty_centers = oi.instance_segmentation_and_centers(torch.zeros_like(center), offset, fg)
     ref_seg, ref_centers = ref.instance.get_instance_segmentation_and_centers(torch.zeros_like(center), offset, fg)
     assert torch.equal(empty_seg, ref_seg) and len(empty_centers) == len(ref_centers) == 0
+
+
+def _video_case(seed, B=2, T=3, H=48, W=64, n_obj=6):
+    """Model-output-like tensors for a few moving blobs: segmentation logits, centerness, offsets, flow."""
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float), torch.arange(W, dtype=torch.float), indexing='ij')
+    out = dict(segmentation=torch.zeros(B, T, 2, H, W), instance_center=torch.zeros(B, T, 1, H, W),
+               instance_offset=torch.zeros(B, T, 2, H, W), instance_flow=torch.zeros(B, T, 2, H, W))
+    for b in range(B):
+        pos = torch.stack([torch.rand(n_obj, generator=g) * (H - 12) + 6, torch.rand(n_obj, generator=g) * (W - 12) + 6], 1)
+        vel = torch.randn(n_obj, 2, generator=g) * 1.5
+        alive = torch.ones(n_obj, T, dtype=torch.bool)
+        alive[0, T - 1] = False                                       # one object disappears,
+        alive[1, 0] = False                                           # one appears later
+        for t in range(T):
+            p = pos + vel * t
+            d2 = torch.stack([(yy - p[k, 0]) ** 2 + (xx - p[k, 1]) ** 2 + (0 if alive[k, t] else 1e6) for k in range(n_obj)])
+            nearest = d2.argmin(0)
+            center = torch.exp(-d2.min(0).values / 9.0)
+            out['instance_center'][b, t, 0] = center + 0.01 * torch.rand(H, W, generator=g)
+            out['instance_offset'][b, t, 0] = p[nearest, 0] - yy
+            out['instance_offset'][b, t, 1] = p[nearest, 1] - xx
+            out['instance_flow'][b, t, 0] = vel[nearest, 0]
+            out['instance_flow'][b, t, 1] = vel[nearest, 1]
+            fg = center > 0.2
+            out['segmentation'][b, t, 1] = fg.float() * 4 - 2
+    return out
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_instance_trajectories_equal_the_reference(ref, sim, seed):
+    """`predict_instance_segmentation_and_trajectories` (evaluate.py:62): per-frame segmentation on the kernel sources
+    (simulator), temporal matching restated on the host - against the reference's own function, id for id."""
+    from fiery_amd import instance as hip_instance
+    out = _video_case(seed)
+    want = ref.instance.predict_instance_segmentation_and_trajectories({k: v.clone() for k, v in out.items()})
+    got = hip_instance.predict_instance_segmentation_and_trajectories(out, lib=sim)
+    assert got.shape == want.shape and got.dtype == want.dtype
+    assert torch.equal(got, want)
+    assert want.max() >= 4
+    no_flow = dict(out, instance_flow=None)
+    want = ref.instance.predict_instance_segmentation_and_trajectories({k: (None if v is None else v.clone()) for k, v in no_flow.items()})
+    got = hip_instance.predict_instance_segmentation_and_trajectories(dict(no_flow), lib=sim)
+    assert torch.equal(got, want)
