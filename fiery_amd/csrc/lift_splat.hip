@@ -1107,6 +1107,7 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
         // what the plane leaves of the CU's LDS holds the queue of many-run quads
         const long long spare = (163840 - static_cast<long long>(pl.n_vox) * 4) / 4 - 1;
         int queue_cap = static_cast<int>(spare < n_quads ? (spare < 0 ? 0 : spare) : n_quads);
+        if (queue_cap > 1024) queue_cap = 1024;       // many-run quads are rare; a small plane should leave LDS for more workgroups
         if (const char* forced = getenv("FIERY_POOL_QUEUE_CAP")) queue_cap = min(queue_cap, max(0, atoi(forced)));   // tests
         const size_t lds = (static_cast<size_t>(pl.n_vox) + 1 + queue_cap) * 4;
         const int wg_threads = lds <= 40960 ? 256 : (lds <= 81920 ? 512 : 1024);
