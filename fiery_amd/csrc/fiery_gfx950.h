@@ -25,6 +25,40 @@ __device__ __forceinline__ v2f pk_add_sat_uniform(v2f a, v2f b) {
     return r;
 }
 
+// min(max(a - b, 0), 1) on both halves in one instruction (neg modifier on the second source + clamp)
+__device__ __forceinline__ v2f pk_sub_sat(v2f a, v2f b) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1] clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// Reduce-scatter of three values over the wavefront's four 16-lane rows: every lane passes its (a, b, c); afterwards a lane
+// of row 0 holds the four rows' sum of a, row 1 that of b, row 2 that of c (row 3: unspecified).  gfx950's row swaps do a
+// reduce-scatter step in one instruction: v_permlane16_swap(x, y) leaves even rows with (own x, neighbour's x) and odd
+// rows with (neighbour's y, own y), so one add gives even rows the pair sum of x and odd rows that of y; v_permlane32_swap
+// does the same for the two halves.  Three swaps and three adds.
+__device__ __forceinline__ float rows_reduce_scatter3(float a, float b, float c) {
+    const auto ab = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    const float p = __uint_as_float(ab[0]) + __uint_as_float(ab[1]);           // even rows: a (pair sum), odd rows: b
+    const auto cz = __builtin_amdgcn_permlane16_swap(__float_as_uint(c), 0u, false, false);
+    const float t = __uint_as_float(cz[0]) + __uint_as_float(cz[1]);           // even rows: c (pair sum), odd rows: junk
+    const auto pt = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(t), false, false);
+    return __uint_as_float(pt[0]) + __uint_as_float(pt[1]);                    // rows 0, 1: p of both halves; rows 2, 3: t
+}
+
+// Sum of a value over the wavefront's four 16-lane rows (lanes l, l ^ 16, l ^ 32, l ^ 48), the same total in all four:
+// gfx950's row swaps exchange odd and even rows (v_permlane16_swap) and the two halves (v_permlane32_swap) of a register
+// pair in one vector-ALU instruction each - with both operands holding the value, the two results are "my row" and "the
+// other row" in every lane.
+__device__ __forceinline__ float rows_sum4(float v) {
+    const unsigned bits = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(bits, bits, false, false);
+    const float pair = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const unsigned pbits = __float_as_uint(pair);
+    const auto b = __builtin_amdgcn_permlane32_swap(pbits, pbits, false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 // Code-motion fence: everything that produces a, b, c is issued before, every memory access written after it
 // stays after.  (The compiler otherwise sinks a batch's arithmetic below the next batch's loads and then holds
 // three batches of rows in registers - or rather in scratch.)

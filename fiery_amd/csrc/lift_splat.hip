@@ -168,19 +168,37 @@ constexpr int kSplitBits = 12;
 //   .x = rankA | rankB << 16, .y = rankC | (s1 | s2 << 6 | general << 12) << 16, a rank of 0xffff = outside the grid;
 // no tile masks are written (the whole-plane kernel that reads this form needs no lists).
 constexpr unsigned kNoRank16 = 0xffffu;
+// `occ` (optional): one byte per voxel and frame, set to 1 for every voxel some column run lands in (plain stores of
+// the same value: no atomics) - the occupancy map the compact-plane kernel numbers its LDS cells from.
+template <int kRows>
 __global__ void k_rank_columns(const float* __restrict__ geometry, int n_fc, int D, int H, int W, GridParams p,
                                int tile_vox, int* __restrict__ rank, int4* __restrict__ coldesc,
-                               int* __restrict__ colmask, int compact) {
-    const long long col = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+                               int* __restrict__ colmask, int compact, unsigned char* __restrict__ occ, int n_cam,
+                               long long occ_stride, unsigned* __restrict__ live) {
+    // `live` (optional, pre-zeroed): one word per (frame, camera, depth) slice, bit q set when quad q (columns 4q .. 4q+3)
+    // has a point inside the grid - the compact-plane kernel does not request the rows of the others.  A workgroup's
+    // columns span a few slices: their bits meet in LDS first, then one global atomic per slice and workgroup.
+    __shared__ unsigned live_lds[72];                                    // 256 columns of at least 4: at most 65 slices
+    const long long col_first = static_cast<long long>(blockIdx.x) * blockDim.x;
+    if (live) {
+        if (threadIdx.x < 72) live_lds[threadIdx.x] = 0u;
+        __syncthreads();
+    }
+    const long long col = col_first + threadIdx.x;
     const long long n_cols = static_cast<long long>(n_fc) * D * W;
-    if (col >= n_cols) return;
+    bool any_inside = false;
+    long long fd_mine = 0;
+    int w_mine = 0;
+    if (col < n_cols) {
     const int w = static_cast<int>(col % W);
     const long long fd = col / W;                          // (frame*camera)*D + d
     const long long base = fd * H * W + w;                 // point index of (.., h = 0, w)
+    unsigned char* occ_f = occ ? occ + (fd / (static_cast<long long>(n_cam) * D)) * occ_stride : nullptr;
+    fd_mine = fd;
+    w_mine = w;
     int ra = -1, rb = -1, rc = -1, s1 = H, s2 = H, runs = 0, prev = 0, mask = 0;
-    // eight rows at a time: their 24 coordinate loads are independent and all in flight before the run bookkeeping,
-    // which is the only sequential part
-    constexpr int kRows = 8;
+    // kRows rows at a time: their 3 kRows coordinate loads are independent and all in flight before the run
+    // bookkeeping, which is the only sequential part
     for (int h0 = 0; h0 < H; h0 += kRows) {
         float gx[kRows], gy[kRows], gz[kRows];
 #pragma unroll
@@ -202,20 +220,54 @@ __global__ void k_rank_columns(const float* __restrict__ geometry, int n_fc, int
                 else if (runs == 1) { rb = r; s1 = h; }
                 else if (runs == 2) { rc = r; s2 = h; }
                 ++runs;
+                if (occ_f && r >= 0) occ_f[r] = 1;
             }
             prev = r;
-            if (r >= 0) mask |= 1 << (r / tile_vox);
+            if (r >= 0) {
+                mask |= 1 << (r / tile_vox);
+                any_inside = true;
+            }
         }
     }
     const int general = (runs > 3 || H >= (1 << kSplitBits)) ? 1 : 0;
-    if (compact) {
+    if (compact >= 2) {
+        // quad records of the compact-plane kernel (layout: see k_voxel_pool_compact); a run that does not exist is
+        // stored as "none", so the reader need not look at the splits to know
+        const int quad_w = W >> 2;
+        const long long quad = fd * quad_w + (w >> 2);
+        const int k = w & 3;
+        const unsigned w16 = static_cast<unsigned>(s1) | (static_cast<unsigned>(s2) << 6) | (static_cast<unsigned>(general) << 12);
+        const int vb = s1 < H ? rb : -1, vc = s2 < H ? rc : -1;
+        if (compact == 2) {
+            unsigned short* rec = reinterpret_cast<unsigned short*>(coldesc) + quad * 16;
+            auto r16 = [](int r) { return static_cast<unsigned short>(r < 0 ? kNoRank16 : static_cast<unsigned>(r)); };
+            rec[k] = static_cast<unsigned short>(w16);
+            rec[4 + k] = r16(ra);
+            rec[8 + k] = r16(vb);
+            rec[12 + k] = r16(vc);
+        } else {
+            char* rec = reinterpret_cast<char*>(coldesc) + quad * 64;
+            reinterpret_cast<unsigned short*>(rec)[k] = static_cast<unsigned short>(w16);
+            reinterpret_cast<int*>(rec + 16)[k] = ra;
+            reinterpret_cast<int*>(rec + 32)[k] = vb;
+            reinterpret_cast<int*>(rec + 48)[k] = vc;
+        }
+    } else if (compact) {
         auto r16 = [](int r) { return r < 0 ? kNoRank16 : static_cast<unsigned>(r); };
         const unsigned w16 = static_cast<unsigned>(s1) | (static_cast<unsigned>(s2) << 6) | (static_cast<unsigned>(general) << 12);
         reinterpret_cast<int2*>(coldesc)[col] = make_int2(static_cast<int>(r16(ra) | (r16(rb) << 16)), static_cast<int>(r16(rc) | (w16 << 16)));
-        return;
+    } else {
+        coldesc[col] = make_int4(ra, rb, rc, s1 | (s2 << kSplitBits) | (general << (2 * kSplitBits)));
+        if (colmask) colmask[col] = mask | (general ? static_cast<int>(0x80000000u) : 0);      // bit 31: walk this column row by row
     }
-    coldesc[col] = make_int4(ra, rb, rc, s1 | (s2 << kSplitBits) | (general << (2 * kSplitBits)));
-    colmask[col] = mask | (general ? static_cast<int>(0x80000000u) : 0);      // bit 31: walk this column row by row
+    }   // col < n_cols
+    if (live) {
+        const long long fd_first = col_first / W;                     // slice of the workgroup's first column
+        if (any_inside) atomicOr(&live_lds[static_cast<int>(fd_mine - fd_first)], 1u << (w_mine >> 2));
+        __syncthreads();
+        if (threadIdx.x < 72 && live_lds[threadIdx.x] != 0u && fd_first + threadIdx.x < static_cast<long long>(n_fc) * D)
+            atomicOr(&live[fd_first + threadIdx.x], live_lds[threadIdx.x]);
+    }
 }
 
 // Ordered (ascending id) list of the work-items that touch one tile of one frame; adjacent entries are adjacent
@@ -956,6 +1008,357 @@ __global__ __launch_bounds__(1024) void k_voxel_pool_plane(const float* __restri
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// pooling, compact-plane form: one workgroup = (channel, frame); only OCCUPIED voxels have an LDS cell
+// ------------------------------------------------------------------------------------------------
+// Two thirds of a frame's voxels receive no point at all (rays thin out with range: 15,037 of 40,000 voxels are hit on
+// the jittered baseline rig, 12,696 of 80,000 at pon's 400 x 200), so the channel plane a workgroup accumulates needs
+// 60 KB of LDS, not 160 KB: two workgroups share a CU - while one clears, drains or writes its plane out, the other
+// keeps the memory pipeline busy - and grids whose dense plane does not fit a CU at all (pon) need no tiles, no lists
+// and no second fetch of the rows at a tile cut.
+//   * the prepass marks every voxel some column run lands in (one byte per voxel and frame, plain stores);
+//   * a workgroup packs its frame's bytes into a bit map in LDS and prefix-sums the words' popcounts: the cell of
+//     voxel v is  prefix[v / 32] + popcount(bits[v / 32] below bit v % 32)  - two LDS reads and a handful of integer
+//     instructions per column RUN (not per point);
+//   * row dealing: a wavefront takes one (camera, depth) slice at a time - H rows of W / 4 quads, contiguous in the
+//     encoder's layout - and deals its rows to four 16-lane groups: lane 16 g + q reads rows g, g + 4, ... of quad q,
+//     so one wavefront load covers 4 adjacent rows (960 contiguous bytes at W = 60) instead of one 240-byte row of four
+//     different slices.  That makes a row's cache lines the business of ONE load instruction, and with that the
+//     non-temporal hint pays (it cost 13 % extra fetch with the column-per-lane mapping, where consecutive rows of a
+//     column share a line across instructions): the bare read pattern goes from 210 us (column per lane) to 197 us
+//     (rows dealt) to 177 us (rows dealt, non-temporal) - profiles/r2_pool_probes.txt;
+//   * rolling requests: a lane's seven rows of a slice live in seven 16-byte registers that are never idle - as soon
+//     as row j of the running slice has been folded into the run sums, the same slot is asked for row j of the
+//     wavefront's next slice, so a full slice per wavefront is in flight also while sums are exchanged and filed;
+//   * the groups' run sums meet through two row swaps (v_permlane16_swap / v_permlane32_swap, new in gfx950:
+//     vector-ALU instructions, no trip through the LDS crossbar), then group g files run g of its quad's columns;
+//   * the finished plane is expanded on the way out: every voxel of the dense (X, Y) plane is stored, occupied or zero;
+//   * more occupied voxels than cells (a rig unlike the one the caller sized for): the workgroup simply makes
+//     several passes over its rows, one per window of cells - slower, never wrong.
+// The last, partly filled round of workgroups is cut into parts that add to the pre-zeroed output, as in the
+// whole-plane form.
+//
+// Quad records (written by the prepass for this kernel, `desc_mode` 2 / 3 of k_rank_columns): what one lane needs is one
+// or two aligned loads - the four columns' split words, and the voxel of run g of each column, "no such run" already
+// folded in:
+//   narrow (grids below 65,535 voxels), 32 B:  u16 split[4] | u16 A[4] | u16 B[4] | u16 C[4]       (0xffff = none)
+//   wide, 64 B:                                u16 split[4] | 8 B pad | i32 A[4] | i32 B[4] | i32 C[4]   (-1 = none)
+//   split = s1 | s2 << 6 | many_runs << 12   (rows [0, s1) are run A, [s1, s2) run B, [s2, H) run C)
+constexpr int kCompactRows = 7;            // rows per lane: the form takes H <= 4 * 7
+constexpr int kCompactGroupLanes = 16;     // lanes per row group: the form takes W / 4 <= 16
+
+// kThreads: 512 (two workgroups per CU) or 1024 (one): sixteen wavefronts per CU either way; kWide: 64-byte quad records and 32-bit cell prefixes;
+// kExactRows: H == 28 exactly, no row of a lane ever lies past the end of its column.
+template <int kThreads, bool kWide, bool kExactRows, bool kNonTemporal>
+__global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
+    const float* __restrict__ x, PoolStrides xs, const int* __restrict__ rank, const void* __restrict__ quads,
+    const unsigned char* __restrict__ occ, const unsigned* __restrict__ live, float* __restrict__ out,
+    int* __restrict__ occupied, int n_cam, int D, int H, int W, int C, int n_vox, int n_words, int capacity, int tail_first,
+    int tail_parts) {
+    using prefix_t = std::conditional_t<kWide, unsigned, unsigned short>;
+    HIP_DYNAMIC_SHARED(unsigned char, cp_lds)
+    const int n_w32 = 2 * n_words;
+    unsigned* bits = reinterpret_cast<unsigned*>(cp_lds);                                    // [n_w32]
+    prefix_t* prefix = reinterpret_cast<prefix_t*>(bits + n_w32);                            // [n_w32]
+    float* plane = reinterpret_cast<float*>(cp_lds + ((static_cast<size_t>(n_w32) * (4 + sizeof(prefix_t)) + 15) & ~size_t(15)));
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    // (told to the compiler in so many words: the wavefront index is the same in all lanes, so everything derived from it -
+    // the slice a wavefront works on, its scalar load offsets - lives in scalar registers; left to itself the compiler
+    // treats tid >> 6 as divergent and wraps every buffer load in a loop over the "different" values)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int kWaves = kThreads / 64;
+    int unit = blockIdx.x, part = 0, parts = 1;
+    if (unit >= tail_first) {
+        const int t = unit - tail_first;
+        unit = tail_first + t / tail_parts;
+        part = t - (t / tail_parts) * tail_parts;
+        parts = tail_parts;
+    }
+    const int c = unit % C;
+    const int f = unit / C;
+
+    // ---- occupancy bytes -> bit map + exclusive prefix of the words' popcounts --------------------------------
+    int total;
+    {
+        const unsigned char* occ_f = occ + static_cast<long long>(f) * n_words * 64;
+        const int wpt = (n_w32 + kThreads - 1) / kThreads;               // consecutive 32-voxel words per thread
+        int local = 0;
+        for (int k = 0; k < wpt; ++k) {
+            const int w = tid * wpt + k;
+            if (w >= n_w32) break;
+            const uint4* src = reinterpret_cast<const uint4*>(occ_f + static_cast<long long>(w) * 32);
+            const uint4 lo4 = src[0], hi4 = src[1];
+            // four bytes (0 or 1) -> four bits: the products' partial terms fall on distinct bits, so nothing carries
+            auto nib = [](unsigned m) { return ((m & 0x01010101u) * 0x10204080u) >> 28; };
+            const unsigned b = nib(lo4.x) | nib(lo4.y) << 4 | nib(lo4.z) << 8 | nib(lo4.w) << 12 | nib(hi4.x) << 16 |
+                               nib(hi4.y) << 20 | nib(hi4.z) << 24 | nib(hi4.w) << 28;
+            bits[w] = b;
+            local += __popc(b);
+        }
+        int* tsum = reinterpret_cast<int*>(plane);                       // scratch: the plane is cleared afterwards
+        int* wsum = tsum + kThreads;
+        tsum[tid] = local;
+        __syncthreads();
+        if (tid < kWaves) {
+            int a = 0;
+            for (int l = 0; l < 64; ++l) a += tsum[tid * 64 + l];
+            wsum[tid] = a;
+        }
+        __syncthreads();
+        int before = 0;
+        total = 0;
+        for (int w = 0; w < kWaves; ++w) {
+            before += w < wave ? wsum[w] : 0;
+            total += wsum[w];
+        }
+        for (int l = 0; l < lane; ++l) before += tsum[wave * 64 + l];
+        for (int k = 0; k < wpt; ++k) {
+            const int w = tid * wpt + k;
+            if (w >= n_w32) break;
+            prefix[w] = static_cast<prefix_t>(before);
+            before += __popc(bits[w]);
+        }
+        __syncthreads();                                                  // scratch read, bits / prefix written
+        if (occupied && c == 0 && part == 0 && tid == 0) occupied[f] = total;
+    }
+    auto cell_of = [&](int r) {                                           // r: a voxel that is occupied
+        return static_cast<int>(prefix[r >> 5]) + __popc(bits[r >> 5] & ((1u << (r & 31)) - 1u));
+    };
+
+    const int g = lane / kCompactGroupLanes, q = lane % kCompactGroupLanes;
+    const float gf = static_cast<float>(g);
+    const int Wq = W >> 2;
+    const bool lane_ok = q < Wq;
+    const int n_slices = n_cam * D;
+    const int HW = H * W;
+    float* o = out + (static_cast<long long>(f) * C + c) * n_vox;
+    const int n_pass = total > 0 ? (total + capacity - 1) / capacity : 1;
+
+    // Row and record loads are buffer loads: descriptor (wave-uniform base of this workgroup's (frame, channel) rows / of
+    // the frame's quad records) + one loop-invariant 32-bit lane offset + a scalar offset that the scalar unit advances
+    // per slice and row - no 64-bit address arithmetic on the vector ALU.  A lane without work points past the
+    // descriptor (reads zeros).
+    constexpr int kOob = static_cast<int>(0x80000000u);
+    constexpr int kRecBytes = kWide ? 64 : 32;
+    const __amdgpu_buffer_rsrc_t rows = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + f * xs.f + c * xs.c), 0, 0x7fffffff,
+                                                                          0x00020000);
+    const __amdgpu_buffer_rsrc_t recs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(static_cast<const char*>(quads) + static_cast<long long>(f) * n_slices * Wq * kRecBytes), 0, 0x7fffffff,
+        0x00020000);
+    const int split_voff = lane_ok ? q * kRecBytes : kOob;
+    const int rank_voff = (lane_ok && g < 3) ? q * kRecBytes + (kWide ? 16 + 16 * g : 8 + 8 * g) : kOob;
+    const int row_voff = lane_ok ? 4 * static_cast<int>(g * xs.h + q * 4 * xs.w) : kOob;
+    const int row4_bytes = 4 * static_cast<int>(4 * xs.h);
+    auto slice_offset = [&](int s) {
+        const int cam = s / D, d = s - cam * D;
+        return 4 * static_cast<int>(cam * xs.n + d * xs.d);
+    };
+    const unsigned* live_f = live + static_cast<long long>(f) * n_slices;
+
+    for (int pass = 0; pass < n_pass; ++pass) {
+        const int lo = pass * capacity;
+        const int span = min(capacity, total - lo);
+        for (int i = tid; i < span; i += kThreads) plane[i] = 0.f;
+        __syncthreads();
+
+        // A lane's seven rows of the running slice and the record of its four columns; both are re-requested for the
+        // wavefront's next slice as soon as they have been moved aside (requests are never conditional - a slot that is
+        // conditionally reloaded becomes two registers and a copy; when there is no next slice the lane offset points past
+        // the descriptor, which costs no memory access).
+        struct Record {
+            unsigned split_lo = 0, split_hi = 0;
+            int rk0 = 0, rk1 = 0, rk2 = 0, rk3 = 0;
+        };
+        auto request_row = [&](vf4& slot, int j, int slice_off, int lane_off) {
+            const int voff = (kExactRows || 4 * j + g < H) ? lane_off : kOob;
+            const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rows, voff, slice_off + j * row4_bytes, kNonTemporal ? 2 : 0);
+            __builtin_memcpy(&slot, &raw, 16);
+        };
+        // the split words of the lane's four columns and the voxels of "its" run
+        auto fetch_record = [&](Record& rec, int s, bool real) {
+            const int soff = real ? s * Wq * kRecBytes : 0;
+            const int split_off = real ? split_voff : kOob, rank_off = real ? rank_voff : kOob;
+            const auto sp = __builtin_amdgcn_raw_buffer_load_b64(recs, split_off, soff, 0);
+            rec.split_lo = sp[0];
+            rec.split_hi = sp[1];
+            if constexpr (kWide) {
+                const auto rr = __builtin_amdgcn_raw_buffer_load_b128(recs, rank_off, soff, 0);
+                rec.rk0 = static_cast<int>(rr[0]);  rec.rk1 = static_cast<int>(rr[1]);
+                rec.rk2 = static_cast<int>(rr[2]);  rec.rk3 = static_cast<int>(rr[3]);
+            } else {
+                const auto rr = __builtin_amdgcn_raw_buffer_load_b64(recs, rank_off, soff, 0);
+                rec.rk0 = static_cast<int>(rr[0]);                            // two 16-bit ranks per word
+                rec.rk1 = static_cast<int>(rr[1]);
+            }
+        };
+        // one slice: `set` / `rec` hold its rows and record; they are refilled with those of slice `s_refill`
+        auto process = [&](vf4 (&set)[kCompactRows], Record& rec_io, int s, int s_refill) {
+            // The slice's rows have arrived: move them aside and ask for the refill slice's rows at once, all seven back
+            // to back - 6,720 contiguous bytes per wavefront in one burst, before anything else is computed.  (Measured
+            // alternatives, profiles/r2_pool_variants.txt: requests dealt out row by row between the arithmetic reach the
+            // DRAM as seven separate visits to the same pages, microseconds apart - 434 us; two slices per wavefront in
+            // flight with twelve wavefronts per CU - 341 us; this form, sixteen wavefronts with one slice ahead - 270 us.)
+            vf4 cur[kCompactRows];
+            const Record rec = rec_io;
+            const bool refill = s_refill < n_slices;
+            {
+                const int refill_off = refill ? slice_offset(s_refill) : 0;
+                // quads without a point inside the grid (a third of pon's, a twentieth of baseline's) are not fetched: the
+                // prepass left one bit per quad of every slice; the word comes through the scalar cache
+                const unsigned alive = refill ? live_f[s_refill] : 0u;
+                const int refill_lane_off = ((alive >> q) & 1u) ? row_voff : kOob;
+#pragma unroll
+                for (int j = 0; j < kCompactRows; ++j) cur[j] = set[j];
+#pragma unroll
+                for (int j = 0; j < kCompactRows; ++j) request_row(set[j], j, refill_off, refill_lane_off);
+                fetch_record(rec_io, s_refill, refill);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- what survives the row loop: two weight counters per column (packed pairs) and the cells of the runs
+            // this lane files.  Row h of a column belongs to run A while s1 - h >= 1 and to run C once h + 1 - s2 >= 1:
+            //   w_A = sat(below),  w_C = sat(delta - below),  below = s1 - h,  delta = s1 + 1 - s2  (a constant <= 1)
+            constexpr int kPairs = 2;
+            v2f below[kPairs], delta[kPairs];
+            int my_cell[4];
+            bool many_runs;
+            {
+                const unsigned w16[4] = {rec.split_lo & 0xffffu, rec.split_lo >> 16, rec.split_hi & 0xffffu, rec.split_hi >> 16};
+                many_runs = lane_ok && ((w16[0] | w16[1] | w16[2] | w16[3]) >> 12) != 0;
+                float s1f[4], df[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    // (out-of-range lanes read zeros: s1 = s2 = 0 puts every row into run C, whose cell is "none")
+                    const int s1 = static_cast<int>(w16[k] & 63u), s2 = static_cast<int>((w16[k] >> 6) & 63u);
+                    s1f[k] = static_cast<float>(s1);
+                    df[k] = static_cast<float>(s1 + 1 - s2);
+                }
+#pragma unroll
+                for (int u = 0; u < kPairs; ++u) {
+                    below[u] = pk_make(s1f[2 * u], s1f[2 * u + 1]) - pk_splat(gf);
+                    delta[u] = pk_make(df[2 * u], df[2 * u + 1]);
+                }
+                int r[4];
+                if constexpr (kWide) {
+                    r[0] = rec.rk0;  r[1] = rec.rk1;  r[2] = rec.rk2;  r[3] = rec.rk3;
+                } else {
+                    const unsigned a16 = static_cast<unsigned>(rec.rk0), b16 = static_cast<unsigned>(rec.rk1);
+                    const unsigned h16[4] = {a16 & 0xffffu, a16 >> 16, b16 & 0xffffu, b16 >> 16};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) r[k] = h16[k] == kNoRank16 ? -1 : static_cast<int>(h16[k]);
+                }
+                const bool files = lane_ok && g < 3 && !many_runs;         // (an out-of-range record reads 0 = a valid voxel)
+                // looked up now, so that the LDS reads complete under the row loop
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool valid = files && r[k] >= 0;
+                    const int cell = cell_of(valid ? r[k] : 0) - lo;
+                    my_cell[k] = (valid && static_cast<unsigned>(cell) < static_cast<unsigned>(span)) ? cell : -1;
+                }
+            }
+            // Six packed instructions per row and column pair: the two weights, run A's and run C's sums, the sum of
+            // everything (run B is what is left of it), the counter.  No branch in here: idle lanes and many-run quads
+            // (whose cells are all "none"; they are walked separately below) carry sums nobody files.
+            v2f first[kPairs], third[kPairs], all[kPairs];
+#pragma unroll
+            for (int u = 0; u < kPairs; ++u) first[u] = third[u] = all[u] = pk_splat(0.f);
+#pragma unroll
+            for (int j = 0; j < kCompactRows; ++j) {
+                const vf4 row = cur[j];
+#pragma unroll
+                for (int u = 0; u < kPairs; ++u) {
+                    const v2f val = pk_make(row[2 * u], row[2 * u + 1]);
+                    all[u] = all[u] + val;
+                    const v2f w_first = pk_add_sat_uniform(below[u], pk_splat(0.f));
+                    const v2f w_third = pk_sub_sat(delta[u], below[u]);
+                    first[u] = pk_fma(val, w_first, first[u]);
+                    third[u] = pk_fma(val, w_third, third[u]);
+                    below[u] = below[u] - pk_splat(4.f);
+                }
+            }
+            // The four row groups' sums meet as a reduce-scatter over the wavefront's four 16-lane rows, one row swap and
+            // one add per step (rows_reduce_scatter3): afterwards group 0 holds the four columns' run-A totals, group 1
+            // the run-B totals, group 2 the run-C totals - exactly the runs whose cells each group looked up.
+            {
+                float mine[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float sa = (k & 1) ? pk_hi(first[k >> 1]) : pk_lo(first[k >> 1]);
+                    const float sc = (k & 1) ? pk_hi(third[k >> 1]) : pk_lo(third[k >> 1]);
+                    const float sb = (((k & 1) ? pk_hi(all[k >> 1]) : pk_lo(all[k >> 1])) - sa) - sc;
+                    mine[k] = rows_reduce_scatter3(sa, sb, sc);
+                }
+                // neighbours that share a voxel are merged before they reach the LDS
+                int cur = -1;
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int cell = my_cell[k];
+                    if (cell < 0) continue;
+                    if (cell != cur) {
+                        if (cur >= 0) atomicAdd(&plane[cur], acc);
+                        cur = cell;
+                        acc = 0.f;
+                    }
+                    acc += mine[k];
+                }
+                if (cur >= 0) atomicAdd(&plane[cur], acc);
+            }
+            if (many_runs) {
+                // a column with four or more runs in this quad (a rolled camera; 1.5 % of the quads of the jittered
+                // baseline rig): this lane fetches its rows again, with their ranks, and every element goes to the voxel
+                // its own rank names
+                const int* rk = rank + (static_cast<long long>(f) * n_slices + s) * HW + q * 4;
+                const int off = slice_offset(s);
+#pragma unroll 1
+                for (int j = 0; j < kCompactRows; ++j) {
+                    if (!kExactRows && 4 * j + g >= H) break;
+                    const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rows, row_voff, off + j * row4_bytes, 0);
+                    vf4 row;
+                    __builtin_memcpy(&row, &raw, 16);
+                    const int4 r = *reinterpret_cast<const int4*>(rk + (4 * j + g) * W);
+                    const int rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (rr[e] < 0) continue;
+                        const int cell = cell_of(rr[e]) - lo;
+                        if (static_cast<unsigned>(cell) < static_cast<unsigned>(span)) atomicAdd(&plane[cell], row[e]);
+                    }
+                }
+            }
+        };
+        vf4 rows_in_flight[kCompactRows];
+        Record record;
+        const int s_first = wave + part * kWaves, s_step = kWaves * parts;
+        {
+            const bool has = s_first < n_slices;
+            fetch_record(record, s_first, has);
+            const int off = has ? slice_offset(s_first) : 0;
+            const unsigned alive = has ? live_f[s_first] : 0u;
+#pragma unroll
+            for (int j = 0; j < kCompactRows; ++j) request_row(rows_in_flight[j], j, off, ((alive >> q) & 1u) ? row_voff : kOob);
+        }
+        for (int s = s_first; s < n_slices; s += s_step) process(rows_in_flight, record, s, s + s_step);
+        __syncthreads();
+        // ---- expand the window of cells into the dense plane --------------------------------------------------
+        for (int v0 = tid; v0 < n_vox; v0 += kThreads) {
+            const unsigned wbits = bits[v0 >> 5];
+            const bool hit = (wbits >> (v0 & 31)) & 1u;
+            const int cell = static_cast<int>(prefix[v0 >> 5]) + __popc(wbits & ((1u << (v0 & 31)) - 1u)) - lo;
+            const bool mine = hit && static_cast<unsigned>(cell) < static_cast<unsigned>(span);
+            if (parts == 1) {
+                if (mine) o[v0] = plane[cell];
+                else if (!hit && pass == 0) o[v0] = 0.f;
+            } else if (mine) {
+                const float val = plane[cell];
+                if (val != 0.f) atomicAdd(&o[v0], val);
+            }
+        }
+        __syncthreads();                                                  // the plane is cleared again by the next pass
+    }
+}
+
 }  // namespace
 }  // namespace fiery
 
@@ -993,8 +1396,8 @@ extern "C" int fiery_voxel_index(const float* geometry, int64_t n_points, const 
 namespace {
 
 struct PoolPlan {
-    int n_vox, tile, n_tiles;
-    size_t lds, off_coldesc, off_colmask, off_counts, off_lists, total;
+    int n_vox, tile, n_tiles, n_words;
+    size_t lds, off_coldesc, off_colmask, off_counts, off_lists, off_occ, off_live, off_occupied, total;
 };
 
 // LDS tile of the output plane (see the default below); the tile grows when the grid would otherwise need more
@@ -1025,7 +1428,13 @@ int plan_pool(int frames, int n_cam, int D, int H, int W, long long n_vox_ll, in
     pl->off_colmask = align(pl->off_coldesc + cols * sizeof(int4));
     pl->off_counts = align(pl->off_colmask + cols * 4);
     pl->off_lists = align(pl->off_counts + static_cast<size_t>(frames) * pl->n_tiles * 2 * 4);
-    pl->total = pl->off_lists + cols * pl->n_tiles * sizeof(int);
+    // compact-plane form: one occupancy byte per voxel and frame (rounded up to whole 64-voxel words), and the
+    // number of occupied voxels of every frame (int32), which the kernel leaves for callers that size its LDS plane
+    pl->n_words = ceil_div(pl->n_vox, 64);
+    pl->off_occ = align(pl->off_lists + cols * pl->n_tiles * sizeof(int));
+    pl->off_live = align(pl->off_occ + static_cast<size_t>(frames) * pl->n_words * 64);     // (cleared together with the bytes)
+    pl->off_occupied = align(pl->off_live + static_cast<size_t>(frames) * n_cam * D * 4);
+    pl->total = align(pl->off_occupied + static_cast<size_t>(frames) * 4);
     return FIERY_OK;
 }
 
@@ -1038,6 +1447,14 @@ extern "C" size_t fiery_voxel_pool_workspace_bytes(int frames, int n_cameras, in
     // sized for the fused form too (its tile cap is the smaller one, so it never needs fewer list slots)
     if (plan_pool(frames, n_cameras, D, H, W, n_voxels, tile_voxels, (flags & FIERY_POOL_DETERMINISTIC) != 0, true, &pl)) return 0;
     return pl.total;
+}
+
+extern "C" size_t fiery_voxel_pool_occupied_offset(int frames, int n_cameras, int D, int H, int W, int n_voxels,
+                                                   int tile_voxels, uint32_t flags) {
+    PoolPlan pl;
+    if (frames <= 0 || n_cameras <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    if (plan_pool(frames, n_cameras, D, H, W, n_voxels, tile_voxels, (flags & FIERY_POOL_DETERMINISTIC) != 0, true, &pl)) return 0;
+    return pl.off_occupied;
 }
 
 namespace {
@@ -1093,10 +1510,124 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
                       W / 4 < (1 << 18) && D < (1 << 18) && static_cast<long long>(C) * frames < (1ll << 31) &&
                       !getenv("FIERY_POOL_PROBE");
     if (const char* forced = getenv("FIERY_POOL_PLANE")) plane_form = plane_form && atoi(forced) != 0;   // tuning / A-B runs
-    hipLaunchKernelGGL(k_rank_columns, dim3(ceil_div(n_cols_all, 256)), dim3(256), 0, s, geometry, frames * n_cam, D, H,
-                       W, to_params(*grid), pl.tile, rank, coldesc, colmask, plane_form ? 1 : 0);
+    // The compact-plane kernel (LDS cells for occupied voxels only; see k_voxel_pool_compact) - the default for the
+    // unfused 16-byte path whenever a slice fits its row dealing: any grid whose occupancy bit map plus a useful number
+    // of cells fit a CU's LDS, dense plane or not.  `tile_voxels` > 0 asks for that many cells (a caller that has read
+    // the occupied counts of an earlier call from the workspace sizes the plane to its rig: fewer cells = more
+    // workgroups per CU); 0 = as many as let two workgroups share a CU.
+    int cp_cells = 0, cp_threads = 0;
+    size_t cp_lds = 0;
+    bool compact_form = quads && !fused && !fixed && H <= 4 * kCompactRows && W / 4 <= kCompactGroupLanes &&
+                        static_cast<long long>(C) * frames < (1ll << 30) && pl.n_vox < (1 << 24) && !getenv("FIERY_POOL_PROBE");
+    if (compact_form) {
+        // its buffer loads address a (frame, channel) set of rows with 31-bit byte offsets
+        const long long reach = 4 * ((n_cam - 1) * st.n + (D - 1) * st.d + (H - 1) * st.h + (W - 1) * st.w + 4);
+        compact_form = st.n >= 0 && st.d >= 0 && st.h >= 0 && reach < (1ll << 31) &&
+                       static_cast<long long>(n_cam) * D * W * 16 < (1ll << 31);
+    }
+    if (const char* forced = getenv("FIERY_POOL_COMPACT")) compact_form = compact_form && atoi(forced) != 0;   // tuning / A-B runs
+    if (compact_form) {
+        // LDS: bit map (4 B per 32 voxels) + cell prefixes (2 B, or 4 B for grids of 65,535 voxels or more), then the cells
+        const long long fixed_bytes = ((static_cast<long long>(pl.n_words) * 2 * (4 + (pl.n_vox >= 65535 ? 4 : 2))) + 15) / 16 * 16;
+        const long long cells_max = (163840 - fixed_bytes) / 4;
+        const long long cells_two = (81920 - fixed_bytes) / 4;
+        long long cells = tile_voxels > 0 ? tile_voxels : cells_two;
+        if (const char* forced = getenv("FIERY_POOL_CELLS")) cells = atoll(forced);              // tuning / tests
+        if (cells > pl.n_vox) cells = pl.n_vox;
+        if (cells < 576) cells = 576;                                    // the prefix scan borrows the plane as scratch
+        if (cells > cells_max) cells = cells_max;
+        if (cells_max < 1088) compact_form = false;                      // the bit map alone fills the LDS: tiled kernel
+        cp_cells = static_cast<int>(cells);
+        cp_lds = static_cast<size_t>(fixed_bytes + cells * 4);
+        cp_threads = 2 * cp_lds <= 163840 ? 512 : 1024;                  // two workgroups per CU, or one: 16 wavefronts either way
+    }
+    if (compact_form) plane_form = false;
+    const bool compact_desc = plane_form;
+    const bool wide_records = pl.n_vox >= 65535;
+    const int desc_mode = compact_form ? (wide_records ? 3 : 2) : (plane_form ? 1 : 0);
+    unsigned char* occ = reinterpret_cast<unsigned char*>(ws + pl.off_occ);
+    int* occupied = reinterpret_cast<int*>(ws + pl.off_occupied);
+    unsigned* live = reinterpret_cast<unsigned*>(ws + pl.off_live);
+    if (compact_form && hipMemsetAsync(occ, 0, pl.off_occupied - pl.off_occ, s) != hipSuccess)     // occupancy bytes + live masks
+        return fail(FIERY_ELAUNCH, "voxel_pool: cannot clear the occupancy map");
+    {
+        int rows = 8;                                                    // rows of a column in flight in the prepass
+        if (const char* forced = getenv("FIERY_POOL_PREPASS_ROWS")) rows = atoi(forced);         // tuning
+        unsigned char* occ_arg = compact_form ? occ : nullptr;
+        const long long occ_stride = static_cast<long long>(pl.n_words) * 64;
+        int* mask_arg = (plane_form || compact_form) ? nullptr : colmask;
+        const dim3 pgrid(ceil_div(n_cols_all, 256));
+        if (rows >= 28)
+            hipLaunchKernelGGL((k_rank_columns<28>), pgrid, dim3(256), 0, s, geometry, frames * n_cam, D, H, W, to_params(*grid),
+                               pl.tile, rank, coldesc, mask_arg, desc_mode, occ_arg, n_cam, occ_stride, compact_form ? live : nullptr);
+        else if (rows >= 14)
+            hipLaunchKernelGGL((k_rank_columns<14>), pgrid, dim3(256), 0, s, geometry, frames * n_cam, D, H, W, to_params(*grid),
+                               pl.tile, rank, coldesc, mask_arg, desc_mode, occ_arg, n_cam, occ_stride, compact_form ? live : nullptr);
+        else
+            hipLaunchKernelGGL((k_rank_columns<8>), pgrid, dim3(256), 0, s, geometry, frames * n_cam, D, H, W, to_params(*grid),
+                               pl.tile, rank, coldesc, mask_arg, desc_mode, occ_arg, n_cam, occ_stride, compact_form ? live : nullptr);
+    }
     rc = check_launch("rank_columns");
     if (rc) return rc;
+    if (compact_form) {
+        // workgroups that fit the chip at once; the units of the last, partly filled round are cut into parts
+        const int n_units = C * frames;
+        int dev = 0, n_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+            n_cu = 256;
+        const int per_cu = cp_threads == 512 ? 2 : 1;
+        const int slots = n_cu * per_cu;
+        int tail = n_units % slots, parts = 1;
+        if (tail > 0) parts = slots / tail;
+        if (n_units < slots) parts = 1;                                  // a single, partly filled round: nothing to balance
+        if (const char* forced = getenv("FIERY_POOL_TAIL_PARTS")) {                           // tuning / tests
+            parts = atoi(forced);
+            if (parts > 1 && tail == 0) tail = n_units < 3 ? n_units : 3;
+        }
+        if (parts > 4 && !getenv("FIERY_POOL_TAIL_PARTS")) parts = 4;     // (a part pays the bit-map set-up again: 4 measured best)
+        if (parts > 8) parts = 8;
+        if (parts < 2) {
+            parts = 1;
+            tail = 0;
+        }
+        const int tail_first = n_units - tail;
+        if (tail > 0 && hipMemsetAsync(out + static_cast<long long>(tail_first) * pl.n_vox, 0,
+                                       static_cast<size_t>(tail) * pl.n_vox * sizeof(float), s) != hipSuccess)
+            return fail(FIERY_ELAUNCH, "voxel_pool: cannot clear the tail planes");
+        if (getenv("FIERY_POOL_VERBOSE"))
+            fprintf(stderr, "voxel_pool compact: %d cells, %zu B LDS, %d threads, %d per CU, %d units + %d x %d parts\n", cp_cells,
+                    cp_lds, cp_threads, per_cu, tail_first, tail, parts);
+        dim3 units(static_cast<unsigned>(tail_first + tail * parts));
+        bool nt = true;                                                  // non-temporal row loads (see the kernel)
+        if (const char* forced = getenv("FIERY_POOL_NT")) nt = atoi(forced) != 0;                // tuning / A-B runs
+#define FIERY_POOL_COMPACT_LAUNCH(THREADS, WIDE, EXACT, NT)                                                              \
+    do {                                                                                                                 \
+        if (cp_lds > 65536 &&                                                                                            \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_voxel_pool_compact<THREADS, WIDE, EXACT, NT>),          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(cp_lds)) != hipSuccess)     \
+            return fail(FIERY_ELAUNCH, "voxel_pool: cannot reserve %zu B of LDS", cp_lds);                              \
+        hipLaunchKernelGGL((k_voxel_pool_compact<THREADS, WIDE, EXACT, NT>), units, dim3(THREADS), cp_lds, s, x, st, rank, \
+                           static_cast<const void*>(coldesc), occ, live, out, occupied, n_cam, D, H, W, C, pl.n_vox, pl.n_words, \
+                           cp_cells, tail_first, parts);                                                                 \
+    } while (0)
+#define FIERY_POOL_COMPACT_ROWS(THREADS, WIDE)                            \
+    do {                                                                 \
+        if (H == 4 * kCompactRows && nt) FIERY_POOL_COMPACT_LAUNCH(THREADS, WIDE, true, true);  \
+        else if (H == 4 * kCompactRows) FIERY_POOL_COMPACT_LAUNCH(THREADS, WIDE, true, false);  \
+        else FIERY_POOL_COMPACT_LAUNCH(THREADS, WIDE, false, false);      \
+    } while (0)
+        if (!wide_records) {
+            if (cp_threads == 512) FIERY_POOL_COMPACT_ROWS(512, false);
+            else FIERY_POOL_COMPACT_ROWS(1024, false);
+        } else {
+            if (cp_threads == 512) FIERY_POOL_COMPACT_ROWS(512, true);
+            else FIERY_POOL_COMPACT_ROWS(1024, true);
+        }
+#undef FIERY_POOL_COMPACT_ROWS
+#undef FIERY_POOL_COMPACT_LAUNCH
+        return check_launch("voxel_pool (compact)");
+    }
     if (plane_form) {
         int batch = 16;
         if (H % 16 != 0 && H % 7 == 0) batch = 7;

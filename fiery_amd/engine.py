@@ -538,11 +538,16 @@ class BevEngine:
         return lambda name, n, H, W, C: self.buf(prefix + name, n, H, W, C)
 
     # -- stages -------------------------------------------------------------------------------------
-    def geometry(self, intrinsics, extrinsics):
-        """`get_geometry`: (F, n, 3, 3), (F, n, 4, 4) -> (F, n, D, fH, fW, 3)."""
+    def geometry(self, intrinsics, extrinsics, camera_matrices=None):
+        """`get_geometry`: (F, n, 3, 3), (F, n, 4, 4) -> (F, n, D, fH, fW, 3).  `camera_matrices` (F*n, 12) = the nine
+        entries of R.K^-1 and the translation, computed by the caller (`host_camera_matrices`): the device then only
+        evaluates the per-point product, which is bit-exact for any K."""
         f, n = intrinsics.shape[:2]
-        cam = self.lib.camera_matrices(intrinsics.reshape(-1, 3, 3).float().contiguous(),
-                                       extrinsics.reshape(-1, 4, 4).float().contiguous())
+        if camera_matrices is None:
+            cam = self.lib.camera_matrices(intrinsics.reshape(-1, 3, 3).float().contiguous(),
+                                           extrinsics.reshape(-1, 4, 4).float().contiguous())
+        else:
+            cam = camera_matrices.to(device=self.device, dtype=torch.float32).reshape(f * n, 12).contiguous()
         geo = self.lib.lift_geometry(self.frustum, cam)
         return geo.view(f, n, *geo.shape[1:])
 
@@ -623,30 +628,33 @@ class BevEngine:
             ws = self._bufs[key] = self.lib.pool_workspace(f, n, d, h, w, device, self.grid, self.pool_tile, self.pool_flags)
         return ws
 
-    def pool(self, x, geometry):
-        """`projection_to_birds_eye_view`: x logical (F, n, D, h, w, C) of any strides -> (F, C, X, Y).
-        Differentiable with respect to x (ops.VoxelPool) when autograd is recording."""
+    def pool(self, x, geometry, out=None):
+        """`projection_to_birds_eye_view`: x logical (F, n, D, h, w, C) of any strides -> (F, C, X, Y) (written into
+        `out` when given).  Differentiable with respect to x (ops.VoxelPool) when autograd is recording."""
         f, n, d, h, w, c = x.shape
         if torch.is_grad_enabled() and x.requires_grad:
-            return ops.VoxelPool.apply(x, geometry, self)
+            res = ops.VoxelPool.apply(x, geometry, self)
+            return res if out is None else out.copy_(res)
         ws = self._pool_workspace(f, n, d, h, w, x.device)
-        # algorithmic bytes of the op: every point's C features + its geometry + the dense output (SURVEY 8d);
-        # out-of-grid points are charged too here (an upper bound that needs no device read-back)
-        work = 4.0 * c * f * n * d * h * w + 12.0 * f * n * d * h * w + 4.0 * c * f * self.X * self.Y
-        return ops.profiled('voxel_pool', work, x, lambda: self.lib.voxel_pool(
-            x, x.stride(), geometry.contiguous(), f, n, d, h, w, c, self.grid, workspace=ws,
-            tile_voxels=self.pool_tile, flags=self.pool_flags))
+        # The op's algorithmic bytes (SURVEY 8d: 4.C.N_kept + 12.N + 4.C.X.Y per frame) need N_kept, the number of
+        # in-grid points; the prepass leaves every point's voxel rank (-1 = outside) at the head of the workspace, so
+        # the profiling consumer counts them after the run (`pool_algorithmic_bytes`) - no device read-back here.
+        detail = dict(workspace=ws, points=f * n * d * h * w, channels=c, frames=f, voxels=self.X * self.Y)
+        return ops.profiled('voxel_pool', None, x, lambda: self.lib.voxel_pool(
+            x, x.stride(), geometry.contiguous(), f, n, d, h, w, c, self.grid, out=out, workspace=ws,
+            tile_voxels=self.pool_tile, flags=self.pool_flags), detail=detail)
 
-    def pool_fused(self, depth_logits, features, geometry):
+    def pool_fused(self, depth_logits, features, geometry, out=None):
         """depth logits (F, n, D, h, w) + features (F, n, C, h, w) -> (F, C, X, Y) without the outer product."""
         f, n, d, h, w = depth_logits.shape
         c = features.shape[2]
         if torch.is_grad_enabled() and (depth_logits.requires_grad or features.requires_grad):
-            return ops.LiftSplat.apply(depth_logits, features, geometry, self)
+            res = ops.LiftSplat.apply(depth_logits, features, geometry, self)
+            return res if out is None else out.copy_(res)
         prob = self.lib.depth_softmax(depth_logits.reshape(f * n, d, h, w).contiguous())
         ws = self._pool_workspace(f, n, d, h, w, features.device)
         return self.lib.lift_splat(prob, features.contiguous(), geometry.contiguous(), f, n, d, h, w, c, self.grid,
-                                   workspace=ws, tile_voxels=self.pool_tile, flags=self.pool_flags)
+                                   out=out, workspace=ws, tile_voxels=self.pool_tile, flags=self.pool_flags)
 
     def _run_distribution(self, ops, srcs, tag, mu=None, log_sigma=None):
         lib = self.lib

@@ -31,6 +31,18 @@ def unpack_sequence_dim(x, b, s):
     return x.view(b, s, *x.shape[1:])
 
 
+def host_camera_matrices(intrinsics, extrinsics):
+    """(..., 3, 3), (..., 4, 4) -> (N, 12): rows of R.K^-1 followed by the translation, evaluated with the very ATen
+    CPU operators the reference's CPU path runs (`torch.inverse` = LAPACK, `matmul`; fiery/models/fiery.py:195,203).
+    A few hundred flops per camera; the result feeds `fiery_lift_geometry`, so geometry and voxel indices equal the
+    reference's CPU path bit for bit for ANY intrinsics matrix (skew, K[2,2] != 1, ...), not only for the zero-skew
+    pinhole form the device kernel inverts in closed form."""
+    K = intrinsics.detach().to(device='cpu', dtype=torch.float32).reshape(-1, 3, 3)
+    E = extrinsics.detach().to(device='cpu', dtype=torch.float32).reshape(-1, 4, 4)
+    combined = E[:, :3, :3].matmul(torch.inverse(K))
+    return torch.cat([combined.reshape(-1, 9), E[:, :3, 3]], dim=1).contiguous()
+
+
 def calculate_birds_eye_view_parameters(x_bounds, y_bounds, z_bounds):
     """`gen_dx_bx` (reference: fiery/utils/geometry.py:39-58): resolution, first cell centre, cell count
     per axis; the count is a python-float quotient truncated by the long conversion."""
@@ -101,8 +113,14 @@ class Fiery(nn.Module):
                                       predict_future_flow=cfg.INSTANCE_FLOW.ENABLED)
         set_bn_momentum(self, cfg.MODEL.BN_MOMENTUM)
 
+        # 'device': K^-1 and R.K^-1 on the GPU (closed form for zero-skew pinhole intrinsics: bit-equal to LAPACK on
+        # every calibration of that form tried but 1 ulp off on ~0.005 % of random ones; adjugate otherwise).
+        # 'host': the reference's own CPU operators on the 3x3 matrices (`host_camera_matrices`), then the device product:
+        # bit-exact indices for any K, at the price of a device-to-host read of the calibration (not graph-capturable).
+        self.camera_matrix_mode = os.environ.get('FIERY_CAMERA_MATRICES', 'device')
         self._engine = None
         self._engine_key = None
+        self._engine_generation = 0   # counts plan rebuilds: graph cache keys name the plan by it, never by id()
         self._lib = None          # tests substitute the CPU-simulated build of the same kernel sources
         self._graphs = {}         # captured hipGraphs of bev_forward, keyed on the argument buffers
         self.sample_streams = True    # run the samples of a batch as independent chains on their own HIP streams
@@ -126,16 +144,17 @@ class Fiery(nn.Module):
     hip_trunk = os.environ.get('FIERY_HIP_TRUNK', '1') != '0'
 
     def _params_version(self):
-        """Identity + in-place version of every tensor the kernel plan was built from (not the image trunk)."""
-        mods = [m for name, m in self.named_children() if name != 'encoder']
-        sig = [(p.data_ptr(), p._version) for p in self.parameters(recurse=False)]
-        for m in mods:
-            sig.extend((p.data_ptr(), p._version) for p in m.parameters())
-            sig.extend((b.data_ptr(), b._version) for b in m.buffers())
+        """Identity + in-place version of every tensor a kernel plan is built from - the image trunk and the lift head
+        included: `BevEngine._build_encoder_ops` folds and packs their weights too, so loading a backbone checkpoint or
+        fine-tuning the encoder after the first forward must invalidate the plan like any other weight change."""
+        sig = [(p.data_ptr(), p._version) for p in self.parameters()]
+        sig.extend((b.data_ptr(), b._version) for b in self.buffers())
         return tuple(sig)
 
     def engine(self):
-        """The kernel plan for the current weights/device; rebuilt when either changes."""
+        """The kernel plan for the current weights/device; rebuilt when either changes.  A rebuild drops everything
+        derived from the old plan: the per-sample lane engines and every captured hipGraph (their kernel arguments point
+        into the old plan's buffers and packed weights)."""
         device = self.frustum.device
         lib = self._lib
         if lib is None:
@@ -146,8 +165,11 @@ class Fiery(nn.Module):
         key = (str(device), id(lib), self._params_version())
         if self._engine is None or self._engine_key != key:
             from .engine import BevEngine
+            self._graphs.clear()
+            self._lanes = []
             self._engine = BevEngine(self, lib, device)
             self._engine_key = key
+            self._engine_generation += 1
         return self._engine
 
     def refresh_engine(self):
@@ -205,7 +227,13 @@ class Fiery(nn.Module):
     # -- reference method seams -------------------------------------------------------------------------
     def get_geometry(self, intrinsics, extrinsics):
         """(B, N, 3, 3), (B, N, 4, 4) -> (B, N, D, fH, fW, 3) ego-frame positions (reference: fiery.py:193-208)."""
-        return self.engine().geometry(intrinsics, extrinsics)
+        return self.engine().geometry(intrinsics, extrinsics, self._camera_matrices(intrinsics, extrinsics))
+
+    def _camera_matrices(self, intrinsics, extrinsics):
+        if self.camera_matrix_mode == 'host':
+            return host_camera_matrices(intrinsics, extrinsics)
+        assert self.camera_matrix_mode == 'device', self.camera_matrix_mode
+        return None
 
     def encoder_forward(self, x):
         """(b, n, c, h, w) images -> (b, n, D, fH, fW, C) lifted features as a permuted view
@@ -320,7 +348,8 @@ class Fiery(nn.Module):
         ego = future_egomotion[:, :rf].contiguous()
         b = intrinsics.shape[0]
         n = intrinsics.shape[2]
-        geometry = eng.geometry(pack_sequence_dim(intrinsics), pack_sequence_dim(extrinsics))
+        Kf, Ef = pack_sequence_dim(intrinsics), pack_sequence_dim(extrinsics)
+        geometry = eng.geometry(Kf, Ef, self._camera_matrices(Kf, Ef))
         if lifted is not None:
             lifted = lifted[:, :rf]
             x = lifted.reshape(b * rf, *lifted.shape[2:]).permute(0, 1, 3, 4, 5, 2)      # view: (F, n, D, h, w, C)
@@ -347,7 +376,7 @@ class Fiery(nn.Module):
                     future_distribution_inputs=future_distribution_inputs, noise=noise, depth_logits=depth_logits,
                     features=features)
         eng = self.engine()
-        key = (id(eng), self.sample_streams) + tuple(
+        key = (self._engine_generation, self.sample_streams) + tuple(
             (k,) if v is None else (k, v.data_ptr(), tuple(v.shape), tuple(v.stride()), v.dtype) for k, v in args.items())
         entry = self._graphs.get(key)
         if entry is None:
@@ -370,7 +399,7 @@ class Fiery(nn.Module):
         args = dict(image=image, intrinsics=intrinsics, extrinsics=extrinsics, future_egomotion=future_egomotion,
                     future_distribution_inputs=future_distribution_inputs, noise=noise)
         eng = self.engine()
-        key = ('images', id(eng), self.sample_streams, self.hip_trunk) + tuple(
+        key = ('images', self._engine_generation, self.sample_streams, self.hip_trunk) + tuple(
             (k,) if v is None else (k, v.data_ptr(), tuple(v.shape), tuple(v.stride()), v.dtype) for k, v in args.items())
         entry = self._graphs.get(key)
         if entry is None:

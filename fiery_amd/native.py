@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libfiery_hip.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -95,6 +95,7 @@ _SIGNATURES = {
     'fiery_lift_geometry': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'fiery_voxel_index': (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(BevGrid), C.c_void_p, C.c_void_p, C.c_void_p]),
     'fiery_voxel_pool_workspace_bytes': (C.c_size_t, [C.c_int] * 7 + [C.c_uint32]),
+    'fiery_voxel_pool_occupied_offset': (C.c_size_t, [C.c_int] * 7 + [C.c_uint32]),
     'fiery_voxel_pool_fwd': (C.c_int, [C.c_void_p, c_int64_p, C.c_void_p] + [C.c_int] * 6 +
                              [C.POINTER(BevGrid), C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_void_p]),
     'fiery_lift_splat_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6 +
@@ -190,6 +191,14 @@ class Lib:
         if nbytes == 0:
             raise NativeError('libfiery_hip: unusable pooling problem size (see fiery_voxel_pool_workspace_bytes)')
         return torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=device)
+
+    def pool_occupied(self, workspace, frames, n_cam, d, h, w, grid, tile_voxels=0, flags=0):
+        """Occupied voxels per frame, as the last compact-plane pooling call on `workspace` counted them (int32 view of the
+        workspace: read it after the stream has finished)."""
+        off = self.dll.fiery_voxel_pool_occupied_offset(frames, n_cam, d, h, w, grid.dim[0] * grid.dim[1], tile_voxels, flags)
+        if off == 0:
+            raise NativeError('libfiery_hip: unusable pooling problem size (see fiery_voxel_pool_occupied_offset)')
+        return workspace[off // 4:off // 4 + frames]
 
     def voxel_pool(self, x, strides, geometry, frames, n_cam, d, h, w, c, grid, out=None, workspace=None,
                    tile_voxels=0, flags=0):

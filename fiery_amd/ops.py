@@ -29,6 +29,16 @@ def profiled(kind, work, stream_tensor, fn, detail=None):
     return out
 
 
+def pool_algorithmic_bytes(detail):
+    """Algorithmic HBM bytes of one pooling call recorded by `profiled('voxel_pool', ...)`:
+    every in-grid point's C features once, every point's geometry once, the dense output once.  Call after the
+    launch has completed: N_kept is counted from the voxel ranks the prepass left in the workspace."""
+    n_points = detail['points']
+    n_kept = int((detail['workspace'][:n_points] >= 0).sum().item())
+    c = detail['channels']
+    return 4.0 * c * n_kept + 12.0 * n_points + 4.0 * c * detail['voxels'] * detail['frames'], n_kept
+
+
 def round_up(v, m):
     return (v + m - 1) // m * m
 

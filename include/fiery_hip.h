@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FIERY_ABI_VERSION 4
+#define FIERY_ABI_VERSION 5
 
 #define FIERY_OK 0
 #define FIERY_EINVAL (-22)      /* bad argument (shape, alignment, null pointer) */
@@ -77,6 +77,14 @@ int fiery_voxel_index(const float* geometry, int64_t n_points, const fiery_bev_g
 size_t fiery_voxel_pool_workspace_bytes(int frames, int n_cameras, int D, int H, int W, int n_voxels,
                                         int tile_voxels, uint32_t flags);
 
+/* Byte offset, inside that workspace, of `frames` int32 counters: after a fiery_voxel_pool_fwd call that took the
+ * compact-plane form, counter f holds the number of voxels of frame f that at least one point falls in.  A caller that
+ * repeats a call on the same rig reads them once (after the stream has finished) and passes a little more than their
+ * maximum as `tile_voxels`: the kernel's LDS plane then has one cell per occupied voxel and more workgroups share a CU.
+ * Same arguments as fiery_voxel_pool_workspace_bytes; 0 if they are unusable. */
+size_t fiery_voxel_pool_occupied_offset(int frames, int n_cameras, int D, int H, int W, int n_voxels,
+                                        int tile_voxels, uint32_t flags);
+
 /* out[f][c][ix][iy] = sum of x over the points of frame f that fall in voxel (ix, iy, 0); voxels no
  * point reaches are 0.
  *   x        : logical [frames][n_cameras][D][H][W][C]; element (f,n,d,h,w,c) lives at
@@ -85,7 +93,12 @@ size_t fiery_voxel_pool_workspace_bytes(int frames, int n_cameras, int D, int H,
  *              returns - is the fast case (xs[4] == 1).
  *   geometry : [frames][n_cameras][D][H][W][3] contiguous
  *   out      : [frames][C][X][Y]
- *   tile_voxels : voxels per LDS tile, 0 = choose.                                                */
+ *   tile_voxels : 0 = choose.  Compact-plane form (the default for 16-byte addressable rows with H <= 28 and
+ *              W <= 64): number of LDS cells = occupied voxels the plane can hold in one pass (frames with more take
+ *              several passes over their rows: slower, same result).  Other forms: voxels per LDS tile.
+ * Kernel forms (chosen per call): compact plane (cells for occupied voxels only, two or three
+ * workgroups per CU, any grid up to 2^24 voxels), tiled (several LDS tiles per plane with ordered work lists: the
+ * bit-reproducible mode, the fused form, scalar strides), whole dense plane (FIERY_POOL_COMPACT=0).          */
 int fiery_voxel_pool_fwd(const float* x, const int64_t* x_strides /* host [6] */, const float* geometry,
                          int frames, int n_cameras, int D, int H, int W, int C,
                          const fiery_bev_grid* grid /* host */, float* out,

@@ -38,3 +38,14 @@ def hip():
     from fiery_amd import native
     assert torch.cuda.is_available(), 'gpu tests need a GPU'
     return native.get()
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """The achieved max-abs errors of every float comparison of the GPU tier (tests/parity_report.py): printed into
+    the log and written where gpurun merges files back from."""
+    from tests import parity_report
+    text = parity_report.table()
+    if text:
+        terminalreporter.write_sep('=', 'parity: achieved errors (literal tolerance 1e-4, asserted bound 1e-4 * max(1, |ref|_inf))')
+        terminalreporter.write_line(text)
+        parity_report.dump(os.path.join(ROOT, 'gpurun_out', 'parity_errors.json'))

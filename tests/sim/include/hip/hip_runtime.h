@@ -39,6 +39,7 @@ struct float2 { float x, y; };
 struct int2 { int x, y; };
 inline int2 make_int2(int x, int y) { return {x, y}; }
 struct int4 { int x, y, z, w; };
+struct uint4 { unsigned x, y, z, w; };
 inline int4 make_int4(int x, int y, int z, int w) { return {x, y, z, w}; }
 inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
 
@@ -218,7 +219,13 @@ inline unsigned long long atomicAdd(unsigned long long* addr, unsigned long long
     return old;
 }
 
+inline unsigned atomicOr(unsigned* addr, unsigned v) {
+    const unsigned old = *addr;
+    *addr = old | v;
+    return old;
+}
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
 // wave-wide vote: bit l of the result is lane l's predicate
 inline unsigned long long __ballot(int predicate) {
     ::hipsim::Run& run = *::hipsim::run_ptr();
@@ -231,6 +238,18 @@ inline unsigned long long __ballot(int predicate) {
         if (flags[l] != 0.f) mask |= 1ull << l;
     ::hipsim::barrier_wait(run.waves[t.wave]);
     return mask;
+}
+
+// wave-wide exchange: every lane of the wavefront calls it; lane l receives lane (l ^ mask)'s value
+inline float __shfl_xor(float v, int mask) {
+    ::hipsim::Run& run = *::hipsim::run_ptr();
+    const ::hipsim::Tls& t = ::hipsim::tls();
+    float* slot = run.wave_a[t.wave].data();
+    slot[t.lane] = v;
+    ::hipsim::barrier_wait(run.waves[t.wave]);
+    const float got = slot[(t.lane ^ mask) & 63];
+    ::hipsim::barrier_wait(run.waves[t.wave]);
+    return got;
 }
 
 // f32 MFMA 32x32x2: D = A(32x2) . B(2x32) + C, one wave.
@@ -254,9 +273,17 @@ inline hipsim_v4u __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r
         __builtin_memcpy(&v, r.base + static_cast<unsigned>(voff) + static_cast<long long>(soff), 16);
     return v;
 }
+typedef unsigned hipsim_v2u __attribute__((vector_size(8)));
+inline hipsim_v2u __builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
+    hipsim_v2u v = {0, 0};
+    if (static_cast<unsigned long long>(static_cast<unsigned>(voff)) + 8ull <= r.num)
+        __builtin_memcpy(&v, r.base + static_cast<unsigned>(voff) + static_cast<long long>(soff), 8);
+    return v;
+}
 inline unsigned long long clock64() { return 0; }
 inline unsigned long long wall_clock64() { return 0; }
 // instruction-scheduling hints have no effect on results
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }      // only ever applied to wave-uniform values
 inline void __builtin_amdgcn_sched_barrier(int) {}
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __builtin_amdgcn_s_waitcnt(int) {}

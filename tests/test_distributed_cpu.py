@@ -27,7 +27,7 @@ def _worker(rank, world, port, batch, S, results):
     try:
         calls = []
 
-        def pool_frames(lo, hi):
+        def pool_frames(lo, hi, out=None):
             calls.append((lo, hi))
             return torch.stack([_frame_value(f) for f in range(lo, hi)]) if hi > lo else torch.zeros(0, 2, 3, 3)
 
@@ -83,3 +83,64 @@ def test_frame_sharding_all_gathers_the_bev_maps():
             assert res[r]['layout'] == 'frames'
             assert torch.equal(res[r]['out']['bev'], want)                       # every rank sees all frames, in order
             assert res[r]['out']['range'] == (0, 1)
+
+
+# ---- the real entry point (`sharded_bev_forward`) on the CPU-simulated kernels, 2 ranks over gloo -------------------
+def _sim_worker(rank, world, port, batch, layout, results):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from fiery_amd import native
+        from fiery_amd.model import Fiery
+        from fiery_amd.parallel import sharded_bev_forward
+        from fiery_amd.synthetic import make_inputs, make_lifted_features
+        from tests.helpers import randomise_weights, tiny_cfg
+        from tests.sim.build_sim import build
+        torch.set_num_threads(1)
+        cfg = tiny_cfg('baseline.yml', bev=8, **{'MODEL.FUTURE_PRED.N_GRU_BLOCKS': 1, 'MODEL.FUTURE_PRED.N_RES_LAYERS': 1,
+                                                  'N_FUTURE_FRAMES': 1})
+        torch.manual_seed(0)
+        model = Fiery(cfg).eval()
+        randomise_weights(model)
+        model._lib = native.Lib(build())
+        rf, n = model.receptive_field, 2
+        _, K, E, ego = make_inputs(batch, rf + model.n_future, n, with_image=False, seed=7)
+        fh, fw = cfg.IMAGE.FINAL_DIM[0] // 8, cfg.IMAGE.FINAL_DIM[1] // 8
+        _, _, lifted = make_lifted_features(batch * rf * n, 64, model.depth_channels, (fh, fw), seed=8)
+        lifted = lifted.view(batch, rf, n, 64, model.depth_channels, fh, fw)
+        noise = torch.randn(batch, 1, 32, generator=torch.Generator().manual_seed(9))
+        with torch.no_grad():
+            out, rng = sharded_bev_forward(model, K, E, ego, lifted=lifted, noise=noise, layout=layout)
+            out2, _ = sharded_bev_forward(model, K, E, ego, lifted=lifted, noise=noise, layout=layout)   # buffers reused
+            whole = model.bev_forward(lifted, K, E, ego, None, noise)
+        results[rank] = dict(range=rng, out={k: v.clone() for k, v in out.items() if v is not None},
+                             again={k: v.clone() for k, v in out2.items() if v is not None},
+                             whole={k: v.clone() for k, v in whole.items() if v is not None},
+                             n_exchange=len(model._sharder._exchange))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('batch,layout', [(2, 'batch'), (1, 'auto'), (3, 'frames')])
+def test_sharded_bev_forward_on_the_simulated_kernels(batch, layout):
+    """Every rank's share of `sharded_bev_forward` equals the same samples of the single-process pass - batch layout (no
+    collective), frame layout (one all-gather through the preallocated exchange) and the small-batch latency mode."""
+    from tests.sim.build_sim import build
+    build()                                                  # compile once, before the ranks start
+    world = 2
+    port = _free_port()
+    with mp.Manager() as manager:
+        results = manager.dict()
+        mp.spawn(_sim_worker, args=(world, port, batch, layout, results), nprocs=world, join=True)
+        res = dict(results)
+    covered = set()
+    for r in range(world):
+        lo, hi = res[r]['range']
+        covered.update(range(lo, hi))
+        for k, v in res[r]['out'].items():
+            want = res[r]['whole'][k][lo:hi]
+            assert v.shape == want.shape, k
+            assert (v - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item()), (k, r)
+            assert torch.equal(res[r]['again'][k], v), k
+        assert res[r]['n_exchange'] == (0 if (layout == 'batch') else 1)        # allocated once, reused by the second call
+    assert covered == set(range(batch))

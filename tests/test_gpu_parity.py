@@ -15,6 +15,7 @@ from fiery_amd.ops import Buf, ConvOp, identity_chan_map
 from fiery_amd.synthetic import make_inputs, make_lifted_features
 from oracle import bev_stack
 from oracle import lift_splat as ls
+from tests import parity_report
 from tests.helpers import forward_case, randomise_weights, tiny_cfg
 
 pytestmark = pytest.mark.gpu
@@ -63,6 +64,28 @@ def test_geometry_and_indices_bit_exact_full_size(hip, name, preset, n_cam, jitt
     assert rank.sum() == gold[key + '_rank_sum']
     assert (rank * (np.arange(rank.size) % 1009)).sum() == gold[key + '_rank_wsum']
     assert np.array_equal(rank[::97].astype(np.int32), gold[key + '_rank_sample'])
+
+
+def test_host_camera_matrices_bit_exact_for_skewed_intrinsics(hip):
+    """`camera_matrix_mode = 'host'`: geometry and voxel ranks equal the oracle's (LAPACK inverse, as the reference's CPU
+    path) bit for bit for intrinsics the device closed form does not cover - full-size baseline grid, 6 cameras."""
+    cfg = get_preset_cfg('baseline.yml')
+    grid, (res, start, dim) = _grid_of(cfg)
+    model, _ = _model(cfg)
+    model.camera_matrix_mode = 'host'
+    _, K, E, _ = make_inputs(1, 1, 6, with_image=False)
+    gen = torch.Generator().manual_seed(9)
+    K = K.clone()
+    K[..., 0, 1] = 1.5 * torch.randn(K.shape[:3], generator=gen)
+    K[..., 1, 0] = 0.2 * torch.randn(K.shape[:3], generator=gen)
+    K[..., 2, 2] = 1.0 + 0.01 * torch.randn(K.shape[:3], generator=gen)
+    geo = model.get_geometry(K[:, 0].to(DEV), E[:, 0].to(DEV))
+    want = ls.get_geometry(_frustum(cfg), K[:, 0].numpy(), E[:, 0].numpy())
+    assert np.array_equal(geo.cpu().numpy(), want)
+    rank, _ = hip.voxel_index(geo, grid, want_idx=False)
+    _, keep_o, rank_o = ls.voxel_indices(want.reshape(-1, 3), res, start, dim)
+    rank = rank.cpu().numpy().astype(np.int64)
+    assert np.array_equal(rank >= 0, keep_o) and np.array_equal(rank[keep_o], rank_o[keep_o])
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -402,22 +425,54 @@ def _model(cfg):
     return model.to(DEV), sd
 
 
-def _check_against_fixture(out, gold, sub):
+def _check_against_fixture(out, gold, sub, test=''):
     """Strict: within 1e-4 (relative to the tensor's scale) of what the reference produced.  Sanity: within
-    1e-4 + the reference's own fp32 rounding noise of the float64 evaluation of the same network."""
+    1e-4 + the reference's own fp32 rounding noise of the float64 evaluation of the same network.  The achieved
+    errors go to the parity ledger (tests/parity_report.py)."""
     for k, v in out.items():
         if v is None:
             continue
         a = v.cpu().numpy()
         if a.ndim == 5:
             scale = max(1.0, float(gold[k + '_absmax']))
-            assert np.abs(a[..., ::sub, ::sub] - gold[k + '_sub']).max() <= TOL * scale, k
-            assert np.abs(a.mean(axis=(-1, -2)) - gold[k + '_mean']).max() <= TOL * scale, k
+            err = np.abs(a[..., ::sub, ::sub] - gold[k + '_sub']).max()
+            err_exact = noise = None
             if k + '_exact' in gold:
-                assert np.abs(a[..., ::sub, ::sub] - gold[k + '_exact']).max() <= TOL * scale + float(gold[k + '_refnoise']), k
+                err_exact = np.abs(a[..., ::sub, ::sub] - gold[k + '_exact']).max()
+                noise = float(gold[k + '_refnoise'])
+            parity_report.record(test, k, err, float(gold[k + '_absmax']), err_exact, noise)
+            assert err <= TOL * scale, k
+            assert np.abs(a.mean(axis=(-1, -2)) - gold[k + '_mean']).max() <= TOL * scale, k
+            if err_exact is not None:
+                assert err_exact <= TOL * scale + noise, k
         elif k in gold:
             scale = max(1.0, float(np.abs(gold[k]).max()))
-            assert np.abs(a - gold[k]).max() <= TOL * scale, k
+            err = np.abs(a - gold[k]).max()
+            err_exact = np.abs(a - gold[k + '_exact']).max() if k + '_exact' in gold else None
+            noise = float(gold[k + '_refnoise']) if k + '_refnoise' in gold else None
+            parity_report.record(test, k, err, float(np.abs(gold[k]).max()), err_exact, noise)
+            assert err <= TOL * scale, k
+
+
+def _check_against_oracle(got, want, test, exact=None):
+    """Every output element against the live oracle (fp32, the reference's ATen CPU kernels); `exact`: the float64
+    evaluation of the same network, when the caller computed it."""
+    assert set(k for k, v in want.items() if v is not None) == set(k for k, v in got.items() if v is not None)
+    failures = []
+    for k, v in want.items():
+        if v is None:
+            continue
+        assert got[k].shape == v.shape, k
+        g = got[k].cpu()
+        err = (g - v).abs().max().item()
+        err_exact = noise = None
+        if exact is not None and exact.get(k) is not None:
+            err_exact = (g.double() - exact[k]).abs().max().item()
+            noise = (v.double() - exact[k]).abs().max().item()
+        parity_report.record(test, k, err, v.abs().max().item(), err_exact, noise)
+        if err > TOL * max(1.0, v.abs().max().item()):
+            failures.append((k, err))
+    assert not failures, failures
 
 
 @pytest.mark.parametrize('fixture,preset,tiny,B,n_cam,sub,labels', [
@@ -434,7 +489,7 @@ def test_hot_path_against_reference_fixture(hip, fixture, preset, tiny, B, n_cam
     dev = lambda t: None if t is None else t.to(DEV)
     with torch.no_grad():
         out = model.bev_forward(dev(lifted), dev(K), dev(E), dev(ego), dev(lab), dev(noise))
-    _check_against_fixture(out, np.load(os.path.join(GOLD, fixture)), sub)
+    _check_against_fixture(out, np.load(os.path.join(GOLD, fixture)), sub, test=f'fixture:{fixture}')
 
 
 def test_hot_path_baseline_batch3_against_live_oracle_and_fused_variant(hip):
@@ -451,23 +506,21 @@ def test_hot_path_baseline_batch3_against_live_oracle_and_fused_variant(hip):
         got = model.bev_forward(lifted.to(DEV), K.to(DEV), E.to(DEV), ego.to(DEV))
         fused = model.bev_forward(None, K.to(DEV), E.to(DEV), ego.to(DEV),
                                   depth_logits=dl.view(B, rf, n, D, 28, 60).to(DEV), features=ft.view(B, rf, n, 64, 28, 60).to(DEV))
-    for k, v in want.items():
-        if v is None:
-            assert got[k] is None
-            continue
-        scale = max(1.0, v.abs().max().item())
-        assert (got[k].cpu() - v).abs().max().item() <= TOL * scale, k
-        assert (fused[k].cpu() - v).abs().max().item() <= TOL * scale, k
+    _check_against_oracle(got, want, 'live:baseline.yml b3 (configs[1])')
+    _check_against_oracle(fused, want, 'live:baseline.yml b3 fused lift-splat')
 
 
-@pytest.mark.parametrize('preset', ['literature/fishing_setting.yml', 'lyft/baseline.yml', 'temporal_single_timeframe.yml',
-                                    'literature/pon_setting.yml', 'single_timeframe.yml'])
-def test_other_reference_configs_against_the_live_oracle(hip, preset):
+@pytest.mark.parametrize('preset,n_cam', [('literature/fishing_setting.yml', None), ('lyft/baseline.yml', None),
+                                          ('lyft/baseline.yml', 7),          # BASELINE.json configs[4]: seven cameras
+                                          ('temporal_single_timeframe.yml', None), ('literature/pon_setting.yml', None),
+                                          ('single_timeframe.yml', None)])
+def test_other_reference_configs_against_the_live_oracle(hip, preset, n_cam):
     """The reference's other YAML files (different grids, receptive fields, horizons, camera counts, with and without
-    the probabilistic / future branches), one sample each, every output element against the oracle on the CPU."""
+    the probabilistic / future branches), one sample each, every output element against the oracle on the CPU - and
+    against the float64 evaluation of the same network, so the ledger shows where the reference itself stands."""
     cfg = get_preset_cfg(preset)
     model, sd = _model(cfg)
-    n = len(cfg.IMAGE.NAMES)
+    n = n_cam or len(cfg.IMAGE.NAMES)
     rf, D = model.receptive_field, model.depth_channels
     fh, fw = cfg.IMAGE.FINAL_DIM[0] // 8, cfg.IMAGE.FINAL_DIM[1] // 8
     C = cfg.MODEL.ENCODER.OUT_CHANNELS
@@ -476,14 +529,40 @@ def test_other_reference_configs_against_the_live_oracle(hip, preset):
     lifted = lifted.view(1, rf, n, C, D, fh, fw)
     with torch.no_grad():
         want = bev_stack.bev_hot_path(sd, cfg, lifted, K, E, ego)
+        exact = bev_stack.bev_hot_path_exact(sd, cfg, lifted, K, E, ego) if preset.startswith('lyft') or 'pon' in preset else None
         got = model.bev_forward(lifted.to(DEV), K.to(DEV), E.to(DEV), ego.to(DEV))
-    assert set(k for k, v in want.items() if v is not None) == set(k for k, v in got.items() if v is not None)
-    for k, v in want.items():
-        if v is None:
-            continue
-        assert got[k].shape == v.shape, k
-        scale = max(1.0, v.abs().max().item())
-        assert (got[k].cpu() - v).abs().max().item() <= TOL * scale, k
+    _check_against_oracle(got, want, f'live:{preset} n_cam={n}', exact)
+
+
+# ------------------------------------------------------------------------------------------------------
+# ego-warp in isolation (row a7): cumulative_warp_features, utils/geometry.py:225-253
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('extent,hw', [((50.0, 50.0), (200, 200)), ((50.0, 25.0), (400, 200))])
+def test_cumulative_warp_vs_oracle_full_size(hip, extent, hw):
+    """`fiery_warp_params` + `fiery_bev_warp_nchw_to_nhwc` against the oracle's `cumulative_warp_features` (bitwise equal
+    to the reference's, tests/test_oracle_vs_reference.py) at the real map sizes: thetas and every warped element."""
+    B, S, C = 2, 3, 64
+    H, W = hw
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, S, C, H, W, generator=g)
+    ego = torch.zeros(B, S, 6)
+    ego[..., 0] = 2.5 + 0.5 * torch.rand(B, S, generator=g)           # SURVEY 8d: tx ~ U(2.5, 3), rz ~ N(0, 0.02)
+    ego[..., 1] = 0.1 * torch.randn(B, S, generator=g)
+    ego[..., 5] = 0.02 * torch.randn(B, S, generator=g)
+    want = bev_stack.cumulative_warp_features(x, ego, 'bilinear', extent)
+    want_theta = bev_stack.cumulative_warp_thetas(ego, extent)
+    theta = hip.warp_params(ego.to(DEV), extent)
+    out = Buf.alloc(B * S, H, W, C, DEV)
+    identity = [(i % S) == S - 1 for i in range(B * S)]
+    hip.bev_warp_nchw_to_nhwc(x.view(B * S, C, H, W).to(DEV), theta.view(B * S, 6), identity, out.tensor, out.ld, out.img_stride)
+    got = out.to_nchw().view(B, S, C, H, W).cpu()
+    t_err = max((theta[:, t].view(B, 2, 3).cpu() - want_theta[t]).abs().max().item() for t in range(S - 1))
+    parity_report.record(f'warp {H}x{W}', 'theta', t_err, 1.0, bound=1e-6)
+    assert t_err <= 1e-6
+    err = (got - want).abs().max().item()
+    parity_report.record(f'warp {H}x{W}', 'warped features', err, want.abs().max().item(), bound=2e-5)
+    assert torch.equal(got[:, S - 1], x[:, S - 1])                    # the present frame is untouched
+    assert err <= 2e-5 * max(1.0, want.abs().max().item())            # bilinear weights from near-identical thetas
 
 
 def test_graph_replay_equals_eager_and_follows_in_place_input_updates(hip):

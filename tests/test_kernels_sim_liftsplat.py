@@ -50,6 +50,27 @@ def test_general_intrinsics_fall_back_to_adjugate(sim):
     assert torch.allclose(cam[0, :9].view(3, 3), want, rtol=1e-5, atol=1e-7)
 
 
+def test_host_camera_matrices_make_geometry_bit_exact_for_any_intrinsics(sim):
+    """Skewed / non-unit intrinsics (the device kernel's adjugate path is only close to LAPACK): with the 3x3 algebra
+    done by `host_camera_matrices` - the reference's own CPU operators - the device product is bit-exact."""
+    from fiery_amd.model import host_camera_matrices
+    frustum, intr, extr, _ = _small_problem(3, n_cam=6)
+    gen = torch.Generator().manual_seed(5)
+    intr = intr.clone()
+    intr[..., 0, 1] = 2.0 * torch.randn(intr.shape[:2], generator=gen)          # skew
+    intr[..., 1, 0] = 0.3 * torch.randn(intr.shape[:2], generator=gen)
+    intr[..., 2, 2] = 1.0 + 0.01 * torch.randn(intr.shape[:2], generator=gen)
+    intr[..., 0, 0] *= 0.3                                                       # fx < cx: LAPACK pivots
+    cam = host_camera_matrices(intr, extr)
+    comb, trans = ls.camera_matrices(intr.numpy(), extr.numpy())
+    assert np.array_equal(cam[:, :9].numpy().reshape(-1, 3, 3), comb.reshape(-1, 3, 3))
+    geo = sim.lift_geometry(torch.from_numpy(frustum), cam)
+    want = ls.get_geometry(frustum, intr.numpy(), extr.numpy()).reshape(geo.shape)
+    assert np.array_equal(geo.numpy(), want)
+    device_cam = sim.camera_matrices(intr.reshape(-1, 3, 3).contiguous(), extr.reshape(-1, 4, 4).contiguous())
+    assert torch.allclose(device_cam, cam, rtol=1e-4, atol=1e-6)                 # the device form is close, not equal
+
+
 @pytest.mark.parametrize('jitter', [True, False])
 def test_voxel_index_bit_exact(sim, jitter):
     frustum, intr, extr, _ = _small_problem(1, jitter=jitter)
@@ -350,6 +371,7 @@ def test_pipelined_walk_has_the_bits_of_the_plain_loop(sim, monkeypatch, H, batc
     strides = (st[0], st[1], st[3], st[4], st[5], st[2])
     monkeypatch.setenv('FIERY_POOL_BATCH', str(batch))
     monkeypatch.setenv('FIERY_POOL_PLANE', '0')                  # the tiled kernel: the whole-plane form has no pipelined walk
+    monkeypatch.setenv('FIERY_POOL_COMPACT', '0')                # ... and neither has the compact-plane form
     monkeypatch.setenv('FIERY_POOL_PIPE', '1')
     out = sim.voxel_pool(lifted, strides, torch.from_numpy(geo), frames, n_cam, D, H, W, C, grid, flags=flags)
     monkeypatch.setenv('FIERY_POOL_PIPE', '0')
@@ -407,6 +429,58 @@ def test_whole_plane_form(sim, monkeypatch, H, batch, queue_cap, tail_parts):
         assert np.array_equal(got >= 0, keep) and np.array_equal(got[keep], rank_o[keep])      # the ranks backward needs
         kept += keep.mean() / frames
     assert 0.2 < kept < 0.95                      # some quads are skipped without being read, some are not
+
+
+@pytest.mark.parametrize('H,cells,tail_parts,big_grid', [(28, 0, 0, False), (28, 576, 0, False), (28, 576, 3, False),
+                                                         (14, 0, 2, False), (27, 600, 0, False), (28, 0, 0, True)])
+def test_compact_plane_form(sim, monkeypatch, H, cells, tail_parts, big_grid):
+    """The compact-plane kernel (LDS cells for occupied voxels only, rows dealt to four lane groups): a rolled camera
+    gives many-run quads (the per-element path), a pitched one two- and three-run columns, part of the frustum lies
+    outside the grid.  `cells` below the number of occupied voxels forces several passes over the rows; `tail_parts`
+    cuts the last units into workgroups that add to the output; the big grid (more than 65,535 voxels) takes the
+    16-byte descriptors; H = 27 / 14 leaves some lanes' last rows past the end of the column.  Against the float64
+    pooling, the dense whole-plane kernel, and the oracle's ranks; the occupied-voxel counts the kernel leaves in the
+    workspace must equal the oracle's."""
+    frustum, intr, extr, lifted = _small_problem(60, n_cam=3, D=16, H=H, W=40, C=2, frames=2)
+    roll = torch.tensor([[0.0, -1.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0], [0.0, 0.0, 1.0, 0.0], [0.0, 0.0, 0.0, 1.0]])
+    a = 0.06
+    pitch = torch.tensor([[1.0, 0.0, 0.0, 0.0], [0.0, float(np.cos(a)), -float(np.sin(a)), 0.0],
+                          [0.0, float(np.sin(a)), float(np.cos(a)), 0.0], [0.0, 0.0, 0.0, 1.0]])
+    extr = extr.clone()
+    extr[:, 0] = extr[:, 0] @ roll
+    extr[:, 1] = extr[:, 1] @ pitch
+    frames, n_cam, C, D, H, W = lifted.shape
+    geo = ls.get_geometry(frustum, intr.numpy(), extr.numpy())
+    if big_grid:
+        grid, (res, start, dim) = _grid([-14.0, 30.0, 0.125], [-24.0, 10.0, 0.125], [-10.0, 10.0, 20.0])     # 352 x 272
+    else:
+        grid, (res, start, dim) = _grid([-14.0, 30.0, 0.5], [-24.0, 10.0, 0.5], [-10.0, 10.0, 20.0])
+    st = lifted.stride()
+    strides = (st[0], st[1], st[3], st[4], st[5], st[2])
+    if cells:
+        monkeypatch.setenv('FIERY_POOL_CELLS', str(cells))
+    if tail_parts:
+        monkeypatch.setenv('FIERY_POOL_TAIL_PARTS', str(tail_parts))
+    ws = sim.pool_workspace(frames, n_cam, D, H, W, lifted.device, grid)
+    ws.fill_(-7)                                                           # garbage: the call must not rely on a clean workspace
+    garbage = torch.full((frames, C, int(dim[0]), int(dim[1])), 7.0)
+    out = sim.voxel_pool(lifted, strides, torch.from_numpy(geo), frames, n_cam, D, H, W, C, grid, out=garbage, workspace=ws)
+    occupied = sim.pool_occupied(ws, frames, n_cam, D, H, W, grid).clone()
+    rank_left = ws[:frames * n_cam * D * H * W].clone()
+    monkeypatch.setenv('FIERY_POOL_COMPACT', '0')
+    dense = sim.voxel_pool(lifted, strides, torch.from_numpy(geo), frames, n_cam, D, H, W, C, grid)
+    assert (out - dense).abs().max() < 2e-5          # fp32 LDS atomics arrive in a different order in the two kernels
+    for f in range(frames):
+        pts = ls.lifted_to_points(lifted[f].numpy())
+        exact = ls.voxel_pool_exact(pts, geo[f].reshape(-1, 3), res, start, dim)
+        assert np.abs(out[f].numpy() - exact).max() < 2e-5
+        _, keep, rank_o = ls.voxel_indices(geo[f].reshape(-1, 3), res, start, dim)
+        got = rank_left.view(frames, -1)[f].numpy().astype(np.int64)
+        assert np.array_equal(got >= 0, keep) and np.array_equal(got[keep], rank_o[keep])
+        assert int(occupied[f]) == len(np.unique(rank_o[keep]))              # this IS the compact form, and it counted right
+        if cells:
+            assert int(occupied[f]) > cells                                    # several passes were needed
+    assert (out != 0).any()
 
 
 @pytest.mark.parametrize('case', range(24))

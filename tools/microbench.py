@@ -61,8 +61,9 @@ def bench_probe(reps):
 
 
 def bench_pool(lib, reps, frames=9, tiles=(0,)):
-    cfg = get_preset_cfg('baseline.yml')
+    cfg = get_preset_cfg(os.environ.get('POOL_PRESET', 'baseline.yml'))
     res, start, dim = ls.bev_parameters(cfg.LIFT.X_BOUND, cfg.LIFT.Y_BOUND, cfg.LIFT.Z_BOUND)
+    X, Y = int(dim[0]), int(dim[1])
     grid = native.make_grid((start - res / np.float32(2)).astype(np.float32), res, dim)
     frustum = torch.from_numpy(ls.create_frustum(cfg.IMAGE.FINAL_DIM, 8, cfg.LIFT.D_BOUND)).to(DEV)
     D, fh, fw = frustum.shape[:3]
@@ -82,10 +83,10 @@ def bench_pool(lib, reps, frames=9, tiles=(0,)):
     rank, _ = lib.voxel_index(geo, grid, want_idx=False)
     n_kept = int((rank >= 0).sum())
     n_pts = rank.numel()
-    algo = 4.0 * 64 * n_kept + 12.0 * n_pts + 4.0 * 64 * frames * 200 * 200
+    algo = 4.0 * 64 * n_kept + 12.0 * n_pts + 4.0 * 64 * frames * X * Y
     for tile in tiles:
         ws = lib.pool_workspace(frames, 6, D, fh, fw, DEV, grid, tile, 0)
-        out = torch.empty(frames, 64, 200, 200, device=DEV)
+        out = torch.empty(frames, 64, X, Y, device=DEV)
         us = timed(lambda: lib.voxel_pool(x, strides, geo, frames, 6, D, fh, fw, 64, grid, out=out, workspace=ws,
                                           tile_voxels=tile), reps)
         # the same op with the caches (L2, 256 MB Infinity Cache) flushed by an unrelated 2 GB copy before every call -

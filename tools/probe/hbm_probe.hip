@@ -142,3 +142,149 @@ extern "C" int probe_read(const void* x, long long n_bytes, int blocks, int thre
 #undef GO
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
+
+// ---- round 2: the (channel, frame) unit with a SMALLER LDS footprint (compact plane of occupied voxels only), so that
+// two or three workgroups share a CU; R = 1: a lane owns a quad column and reads kBatch rows at a time; R = 4: the 28 rows
+// of a slice are dealt to four 15-lane groups (lanes 16 g + col, lane 15 of each group idle), 7 loads per lane and item,
+// every wavefront instruction covers 960 contiguous bytes
+template <int kBatch, int kThreads, int R>
+__global__ __launch_bounds__(kThreads) void k_read_planes2(const float4* __restrict__ x, long long n4, float* __restrict__ sink) {
+    extern __shared__ float lds[];
+    const int c = blockIdx.x % 64, f = blockIdx.x / 64;
+    float acc = 0.f;
+    if (R == 1) {
+        for (int i = threadIdx.x; i < 6 * 48 * 15; i += kThreads) {
+            const int cam = i / (48 * 15), rem = i - cam * 48 * 15, d = rem / 15, col = rem - d * 15;
+            const float4* p = x + ((((long long)f * 6 + cam) * 64 + c) * 48 + d) * 420 + col;
+            for (int h0 = 0; h0 < 28; h0 += kBatch) {
+                float4 v[kBatch];
+#pragma unroll
+                for (int j = 0; j < kBatch; ++j) v[j] = p[(h0 + j) * 15];
+#pragma unroll
+                for (int j = 0; j < kBatch; ++j) acc += v[j].x + v[j].y + v[j].z + v[j].w;
+            }
+        }
+    } else {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = kThreads / 64;
+        const int g = lane >> 4, col = lane & 15;
+        for (int s = wave; s < 6 * 48; s += n_waves) {            // one (camera, depth) slice per wavefront and step
+            const int cam = s / 48, d = s - cam * 48;
+            const float4* p = x + ((((long long)f * 6 + cam) * 64 + c) * 48 + d) * 420 + g * 15 + col;
+            float4 v[7];
+            if (col < 15) {
+#pragma unroll
+                for (int j = 0; j < 7; ++j) v[j] = p[j * 60];
+#pragma unroll
+                for (int j = 0; j < 7; ++j) acc += v[j].x + v[j].y + v[j].z + v[j].w;
+            }
+        }
+    }
+    if (acc == 1.2345e-30f) { sink[0] = acc; lds[threadIdx.x] = acc; }
+}
+
+extern "C" int probe_planes2(const void* x, long long n_bytes, int blocks, int threads, int batch, int R, int lds_bytes,
+                             void* sink, void* stream) {
+    const float4* p = static_cast<const float4*>(x);
+    const long long n4 = n_bytes / 16;
+    float* s = static_cast<float*>(sink);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define GO2(B, T, RR)                                                                                                        \
+    do {                                                                                                                     \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_read_planes2<B, T, RR>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+        hipLaunchKernelGGL((k_read_planes2<B, T, RR>), dim3(blocks), dim3(T), lds_bytes, st, p, n4, s);                       \
+    } while (0)
+#define GOT(T)                                                        \
+    do {                                                              \
+        if (R == 4) GO2(7, T, 4);                                     \
+        else if (batch == 14) GO2(14, T, 1);                          \
+        else if (batch == 28) GO2(28, T, 1);                          \
+        else GO2(7, T, 1);                                            \
+    } while (0)
+    if (threads == 256) GOT(256);
+    else if (threads == 384) GOT(384);
+    else if (threads == 512) GOT(512);
+    else if (threads == 768) GOT(768);
+    else GOT(1024);
+#undef GOT
+#undef GO2
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// ---- round 2, second probe: the row-dealt slice pattern with more slices in flight per wavefront (kSlices x 7 loads per
+// lane before anything is consumed), plain or non-temporal, and a rolling variant (kRolling: a slot is re-requested for
+// the next slice as soon as its row is consumed, so 7 loads per lane are in flight at ALL times)
+template <int kThreads, int kSlices, bool kNT, bool kRolling>
+__global__ __launch_bounds__(kThreads) void k_read_planes3(const float4* __restrict__ x, long long n4, float* __restrict__ sink) {
+    extern __shared__ float lds[];
+    const int c = blockIdx.x % 64, f = blockIdx.x / 64;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int n_waves = kThreads / 64;
+    const int g = lane >> 4, col = lane & 15;
+    float acc = 0.f;
+    auto slice_ptr = [&](int s) {
+        const int cam = s / 48, d = s - cam * 48;
+        return x + ((((long long)f * 6 + cam) * 64 + c) * 48 + d) * 420 + g * 15 + col;
+    };
+    auto ld = [&](const float4* p) { return kNT ? nt_load(p) : *p; };
+    if (col < 15) {
+        if (kRolling) {
+            float4 v[7];
+            int s = wave;
+            const float4* p = slice_ptr(s);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) v[j] = ld(p + j * 60);
+            for (; s < 6 * 48; s += n_waves) {
+                const bool more = s + n_waves < 6 * 48;
+                const float4* pn = slice_ptr(more ? s + n_waves : s);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    const float4 r = v[j];
+                    if (more) v[j] = ld(pn + j * 60);
+                    acc += r.x + r.y + r.z + r.w;
+                }
+            }
+        } else {
+            for (int s0 = wave * kSlices; s0 < 6 * 48; s0 += n_waves * kSlices) {
+                float4 v[kSlices][7];
+#pragma unroll
+                for (int u = 0; u < kSlices; ++u) {
+                    const float4* p = slice_ptr(s0 + u < 6 * 48 ? s0 + u : s0);
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) v[u][j] = ld(p + j * 60);
+                }
+#pragma unroll
+                for (int u = 0; u < kSlices; ++u)
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) acc += v[u][j].x + v[u][j].y + v[u][j].z + v[u][j].w;
+            }
+        }
+    }
+    if (acc == 1.2345e-30f) { sink[0] = acc; lds[threadIdx.x] = acc; }
+}
+
+extern "C" int probe_planes3(const void* x, long long n_bytes, int blocks, int threads, int slices, int nt, int rolling,
+                             int lds_bytes, void* sink, void* stream) {
+    const float4* p = static_cast<const float4*>(x);
+    const long long n4 = n_bytes / 16;
+    float* s = static_cast<float*>(sink);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define GO3(T, S, N, R)                                                                                                      \
+    do {                                                                                                                     \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_read_planes3<T, S, N, R>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+        hipLaunchKernelGGL((k_read_planes3<T, S, N, R>), dim3(blocks), dim3(T), lds_bytes, st, p, n4, s);                     \
+    } while (0)
+#define GO3T(T)                                                                     \
+    do {                                                                            \
+        if (rolling) { if (nt) GO3(T, 1, true, true); else GO3(T, 1, false, true); }  \
+        else if (slices == 2) { if (nt) GO3(T, 2, true, false); else GO3(T, 2, false, false); } \
+        else if (slices == 4) { if (nt) GO3(T, 4, true, false); else GO3(T, 4, false, false); } \
+        else { if (nt) GO3(T, 1, true, false); else GO3(T, 1, false, false); }          \
+    } while (0)
+    if (threads == 256) GO3T(256);
+    else if (threads == 384) GO3T(384);
+    else if (threads == 512) GO3T(512);
+    else GO3T(1024);
+#undef GO3T
+#undef GO3
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}

@@ -1,10 +1,16 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
-O=gpurun_out/r2
+O=$PWD/gpurun_out/r2p2
 mkdir -p $O
-for o in 1 2; do for nt in 1 0; do
-  echo "== ORDER=$o NT=$nt"
-  FIERY_POOL_ORDER=$o FIERY_POOL_NT=$nt POOL_TILES=20480,40000,13334,10000 timeout 300 python tools/microbench.py pool --reps 10 2>&1 | grep "^pool"
-done; done > $O/pool2.txt 2>&1
-cat $O/pool2.txt
+(
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -k "pool or projection or splat" 2>&1 | tail -3
+echo "== compact default"; timeout 200 python tools/microbench.py pool --reps 20 2>&1 | grep "^pool frames"
+echo "== compact=0 (dense plane)"; FIERY_POOL_COMPACT=0 timeout 200 python tools/microbench.py pool --reps 20 2>&1 | grep "^pool frames"
+echo "== compact cells 37000 (one 1024-thread wg per CU)"; FIERY_POOL_CELLS=37000 timeout 200 python tools/microbench.py pool --reps 20 2>&1 | grep "^pool frames"
+echo "== compact tail parts 4"; FIERY_POOL_TAIL_PARTS=4 timeout 200 python tools/microbench.py pool --reps 20 2>&1 | grep "^pool frames"
+cd /tmp; rm -rf /tmp/kt
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $GRAFT_REPO_ROOT/tools/microbench.py pool --reps 10 > /tmp/kt.log 2>&1
+DB=$(find /tmp/kt -name "*.db" | head -1)
+python $GRAFT_REPO_ROOT/tools/rocprof_summary.py $DB $O/kernel_stats.csv "microbench pool --reps 10, compact form" && grep "fiery::k_voxel_pool_compact\|k_rank_columns\|fillBuffer" $O/kernel_stats.csv
+) 2>&1 | tee $O/pool2.txt
