@@ -10,7 +10,10 @@ distribution -> SpatialGRU future prediction -> decoder) over one batch of synth
 resident in HBM: BASELINE.json configs[1], `baseline.yml`, 6 cameras x 3 past frames -> 200x200 BEV, batch 3
 per GPU, fp32.  The inputs are the image encoder's outputs (the trunk is upstream of the path).
 With N > 1 every rank runs its own batch of 3 (the path is independent per sample: no data-path collective),
-so the job processes 3*N samples per step: weak scaling.  Rank 0 prints ONE JSON line.
+so the job processes 3*N samples per step: weak scaling.  `--layout frames` measures BASELINE.json configs[2] instead:
+the global batch's frames are split across the ranks for geometry + pooling, ONE RCCL all-gather moves the pooled BEV
+maps, then every rank runs the temporal / future / decoder stack of its own samples (same work per rank, plus the
+exchange).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -31,11 +34,12 @@ def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over
     this bench command, folded by tools/pmc_traffic.py with the gfx950 correction); None when the summary is absent.
     Counters cannot be collected from inside the timed process, so this is the one roofline field not measured live."""
-    path = os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')
-    try:
-        return json.load(open(path))[kernel]['traffic_bytes']
-    except (OSError, KeyError, ValueError):
-        return None
+    for name in ('r2_pmc_traffic.json', 'r1_pmc_traffic.json'):
+        try:
+            return json.load(open(os.path.join(ROOT, 'profiles', name)))[kernel]['traffic_bytes']
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def parse():
@@ -45,6 +49,10 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=3, help='samples per GPU (baseline.yml BATCHSIZE)')
     ap.add_argument('--config', default='baseline.yml')
+    ap.add_argument('--cams', type=int, default=0, help='cameras per frame (0 = the preset\'s IMAGE.NAMES; lyft runs use 7)')
+    ap.add_argument('--layout', choices=('batch', 'frames'), default='batch',
+                    help='batch: every rank owns whole samples, no collective.  frames: frames sharded for pooling, one '
+                         'all-gather of the BEV maps, then batch-sharded (BASELINE.json configs[2])')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-from-images', action='store_true', help='skip the secondary forward-from-images timing')
     ap.add_argument('--no-graph', action='store_true', help='enqueue every launch from the host each step instead of '
@@ -56,9 +64,10 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, sd, lifted, K, E, ego, runs=2):
+def cpu_baseline(cfg, sd, lifted, K, E, ego, runs=3):
     """The oracle (a port of the reference's CPU path on the same ATen CPU kernels) on the host cores, on a
-    bounded sample: one batch element of the same workload."""
+    bounded sample: one batch element of the same workload.  Returns the baseline dict and the sample's outputs (the
+    parity check of the GPU result rides on them)."""
     from oracle import bev_stack
     cores = len(os.sched_getaffinity(0))
     try:                                               # a cgroup CPU quota caps the usable cores below the affinity mask
@@ -70,14 +79,17 @@ def cpu_baseline(cfg, sd, lifted, K, E, ego, runs=2):
     torch.set_num_threads(cores)
     one = [t[:1].cpu() for t in (lifted, K, E, ego)]
     sd_cpu = {k: v.cpu() for k, v in sd.items()}
+    times = []
     with torch.no_grad():
-        bev_stack.bev_hot_path(sd_cpu, cfg, *one)          # warm-up (first-call allocator / oneDNN primitive caches)
-        t0 = time.perf_counter()
+        out = bev_stack.bev_hot_path(sd_cpu, cfg, *one)    # warm-up (first-call allocator / oneDNN primitive caches)
         for _ in range(runs):
-            bev_stack.bev_hot_path(sd_cpu, cfg, *one)
-        dt = (time.perf_counter() - t0) / runs
+            t0 = time.perf_counter()
+            out = bev_stack.bev_hot_path(sd_cpu, cfg, *one)
+            times.append(time.perf_counter() - t0)
+    dt = sorted(times)[len(times) // 2]
     return {'value': 1.0 / dt, 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'1 sample (batch 1 of the same workload), mean of {runs} runs after 1 warm-up, {dt:.2f} s each'}
+            'sample': f'1 sample (batch 1 of the same workload), median of {runs} runs after 1 warm-up '
+                      f'({", ".join(f"{t:.2f}" for t in times)} s)'}, out
 
 
 def main():
@@ -101,21 +113,40 @@ def main():
     cfg = get_preset_cfg(args.config)
     torch.manual_seed(0)
     model = Fiery(cfg).eval()
-    from tests.helpers import randomise_weights
+    from fiery_amd.synthetic import randomise_weights
     sd = randomise_weights(model)                          # random-init weights, non-trivial BN statistics
     model = model.to(dev)
     model.sample_streams = not args.no_sample_streams
 
     B, rf, nf = args.batch, model.receptive_field, model.n_future
-    n_cam = len(cfg.IMAGE.NAMES)
+    n_cam = args.cams or len(cfg.IMAGE.NAMES)
     D = model.depth_channels
     fh, fw = cfg.IMAGE.FINAL_DIM[0] // 8, cfg.IMAGE.FINAL_DIM[1] // 8
     C = cfg.MODEL.ENCODER.OUT_CHANNELS
-    _, K, E, ego = make_inputs(B, rf + nf, n_cam, with_image=False, seed=rank)
-    dl, ft, lifted = make_lifted_features(B * rf * n_cam, C, D, (fh, fw), seed=100 + rank)
-    lifted = lifted.view(B, rf, n_cam, C, D, fh, fw)
+    frames_layout = args.layout == 'frames'
+    if frames_layout:
+        # the layout's entry point takes the GLOBAL batch (B samples per rank: B * world) and pools only this rank's share of
+        # its frames.  Calibrations and ego-motion of every sample are generated everywhere (one generator per rank's
+        # samples, so sample b is the same tensor whatever the world size); of the lifted features - 1.1 GB per rank - a rank
+        # only materialises its own samples' (the frames it pools) inside a device tensor of the global shape.
+        assert use_dist or world == 1
+        parts = [make_inputs(B, rf + nf, n_cam, with_image=False, seed=r) for r in range(world)]
+        K, E, ego = (torch.cat([p[i] for p in parts]) for i in (1, 2, 3))
+        _, _, mine = make_lifted_features(B * rf * n_cam, C, D, (fh, fw), seed=100 + rank)
+        lifted = mine.view(B, rf, n_cam, C, D, fh, fw)
+    else:
+        _, K, E, ego = make_inputs(B, rf + nf, n_cam, with_image=False, seed=rank)
+        dl, ft, lifted = make_lifted_features(B * rf * n_cam, C, D, (fh, fw), seed=100 + rank)
+        lifted = lifted.view(B, rf, n_cam, C, D, fh, fw)
     K_d, E_d, ego_d = K.to(dev), E.to(dev), ego.to(dev)
-    if args.fused:
+    if frames_layout:
+        from fiery_amd.parallel import block_range, sharded_bev_forward
+        lifted_d = torch.empty((B * world,) + tuple(lifted.shape[1:]), device=dev)
+        assert block_range(B * world * rf, world, rank) == (rank * B * rf, (rank + 1) * B * rf)     # this rank pools its own samples' frames
+        lifted_d[rank * B:(rank + 1) * B].copy_(lifted)
+        eager_step = lambda: sharded_bev_forward(model, K_d, E_d, ego_d, lifted=lifted_d, layout='frames')[0]
+        graph_step = None                                  # the collective is enqueued by torch.distributed: eager launches
+    elif args.fused:
         dl_d = dl.view(B, rf, n_cam, D, fh, fw).to(dev)
         ft_d = ft.view(B, rf, n_cam, C, fh, fw).to(dev)
         eager_step = lambda: model.bev_forward(None, K_d, E_d, ego_d, depth_logits=dl_d, features=ft_d)
@@ -127,7 +158,7 @@ def main():
     # The timed step replays the whole path (every kernel, same work) from one captured hipGraph; the first call
     # captures it and is checked against the eager path.
     step, launch_mode = eager_step, 'host enqueue per launch'
-    if not args.no_graph:
+    if not args.no_graph and graph_step is not None:
         try:
             with torch.no_grad():
                 ref = {k: v.clone() for k, v in eager_step().items() if v is not None}
@@ -185,10 +216,17 @@ def main():
         model.sample_streams = streams_on
         recs, ops.PROFILE_SINK = ops.PROFILE_SINK, None
         conv = [(s.elapsed_time(e) * 1e-3, w) for k, s, e, w, _ in recs if k == 'conv_igemm']
-        pool = [(s.elapsed_time(e) * 1e-3, w) for k, s, e, w, _ in recs if k == 'voxel_pool']
+        # pooling: algorithmic bytes with N_kept, counted from the voxel ranks the op left in its workspace
+        pool, kept_frac = [], None
+        for k, s_, e_, _, d in recs:
+            if k == 'voxel_pool':
+                nbytes, n_kept = ops.pool_algorithmic_bytes(d)
+                pool.append((s_.elapsed_time(e_) * 1e-3, nbytes))
+                kept_frac = n_kept / d['points']
         dump = os.environ.get('FIERY_BENCH_DUMP')
         if dump:                                           # per-launch table for kernel tuning
-            rows = [dict(kind=k, us=round(s.elapsed_time(e) * 1e3, 2), work=w, detail=d) for k, s, e, w, d in recs]
+            rows = [dict(kind=k, us=round(s.elapsed_time(e) * 1e3, 2), work=w, detail=d if k == 'conv_igemm' else None)
+                    for k, s, e, w, d in recs]
             json.dump(rows, open(dump, 'w'))
         t_conv, f_conv = sum(t for t, _ in conv), sum(w for _, w in conv)
         achieved = f_conv / t_conv / 1e12
@@ -198,15 +236,22 @@ def main():
                     'avg_launch_us': round(t_conv / len(conv) * 1e6, 2),
                     'algorithmic_gflop_per_step': round(f_conv / 1e9, 1), 'kernel_ms_per_step': round(t_conv * 1e3, 3),
                     'measured': 'HIP events around every launch of one instrumented step after the timed region, whole '
-                                'batch on one stream (`--no-sample-streams` mode)',
+                                'batch on one stream (`--no-sample-streams` mode): the kernel alone on the GPU',
+                    # the same kernel in the TIMED launch mode (hipGraph, one chain per sample: kernels of different
+                    # samples share the CUs, so no per-launch bracket exists): its flops over the whole step time - a lower
+                    # bound of what it reaches there, because the step also holds every other kernel
+                    'timed_mode': {'achieved': round(f_conv / (elapsed / args.steps) / 1e12, 2), 'unit': 'TFLOP/s',
+                                   'frac': round(f_conv / (elapsed / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                   'what': 'conv flops of a step / timed ms_per_step (lower bound: the step holds all kernels)'},
                     'step_tflops': round(f_conv / (elapsed / args.steps) / 1e12, 2)}
         if pool:
             t_pool, b_pool = sum(t for t, _ in pool), sum(w for _, w in pool)
             gbs = b_pool / t_pool / 1e9
-            pooling = {'kernel': 'k_rank_columns + k_voxel_pool_plane (op boundary projection_to_birds_eye_view)', 'bound': 'hbm',
+            pooling = {'kernel': 'k_rank_columns + k_voxel_pool_compact (op boundary projection_to_birds_eye_view)', 'bound': 'hbm',
                        'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
                        'traffic': pmc_traffic('k_voxel_pool'), 'algorithmic_mb_per_step': round(b_pool / 1e6, 1),
-                       'op_us_per_step': round(t_pool * 1e6, 1)}
+                       'op_us_per_step': round(t_pool * 1e6, 1), 'kept_fraction': round(kept_frac, 4),
+                       'bytes': '4*C*N_kept + 12*N + 4*C*X*Y per frame (SURVEY 8d), N_kept counted from the ranks the op left'}
 
     # secondary figure: the whole `forward()` from images - image trunk and lift head on the engine as well -
     # a few eager passes after everything above, reported beside the headline, never as `value`
@@ -236,21 +281,33 @@ def main():
 
     if rank == 0:
         line = {
-            'metric': 'BEV samples/s (6 cams x 3 frames -> 200x200 BEV, hot path from encoder outputs to output dict)',
+            'metric': f'BEV samples/s ({n_cam} cams x {rf} frames -> {model.bev_size[0]}x{model.bev_size[1]} BEV, hot path from '
+                      'encoder outputs to output dict)',
             'value': round(B * world * args.steps / elapsed, 3), 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'{args.config}: {n_cam} cams x {rf} past frames -> {model.bev_size[0]}x{model.bev_size[1]} BEV, '
                                    f'{nf} future frames, batch {B} per GPU, fp32, '
                                    f'{"fused lift-splat from depth+features" if args.fused else "lifted features (n,C,D,h,w) resident in HBM"}',
-                       'global_batch': B * world, 'parallelism': f'batch-sharded x{world}, no data-path collective',
+                       'global_batch': B * world,
+                       'parallelism': (f'frames sharded x{world} for geometry + pooling, one all-gather of the pooled BEV maps '
+                                       f'({"RCCL" if use_dist else "local copy: 1 rank, no process group"}), then batch-sharded'
+                                       if frames_layout else f'batch-sharded x{world}, no data-path collective'),
                        'launch': launch_mode + (', one stream per sample' if model.sample_streams else '')},
             'roofline': roofline, 'roofline_pooling': pooling, 'host_enqueue_ms_per_step': round(host_ms, 3),
             'forward_from_images': from_images,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(cfg, sd, lifted, K, E, ego)
+            line['cpu_baseline'], want = cpu_baseline(cfg, sd, lifted, K, E, ego)
             line['speedup_vs_cpu_baseline'] = round(line['value'] / line['cpu_baseline']['value'], 1)
+            # parity of this run: sample 0 of the GPU step against the oracle's outputs for the same sample - achieved
+            # max-abs error per output, next to the literal 1e-4 of the north star and the scale the relative bound uses
+            with torch.no_grad():
+                got = {k: (None if v is None else v[:1].float().cpu()) for k, v in step().items()}
+            line['parity'] = {k: {'max_abs_err': float(f'{(got[k] - v).abs().max().item():.3e}'),
+                                  'ref_abs_max': round(v.abs().max().item(), 3),
+                                  'within_1e-4': bool((got[k] - v).abs().max().item() <= 1e-4)}
+                              for k, v in want.items() if v is not None}
         print(json.dumps(line), flush=True)
     if use_dist:
         import torch.distributed as dist

@@ -178,8 +178,8 @@ __global__ void k_latent_sample(const float* __restrict__ mu, const float* __res
         mu[static_cast<long long>(r) * ld + j] + expf(log_sigma[static_cast<long long>(r) * ld + j]) * eps;
 }
 
-__global__ void k_maxpool2x2(const float* __restrict__ in, int in_ld, int H, int W, int C, int Ho, int Wo,
-                             float* __restrict__ out, int out_ld, long long total) {
+__global__ void k_maxpool2x2(const float* __restrict__ in, int in_ld, long long in_img_stride, int H, int W, int C, int Ho,
+                             int Wo, float* __restrict__ out, int out_ld, long long total) {
     const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int c = static_cast<int>(i % C);
@@ -188,7 +188,7 @@ __global__ void k_maxpool2x2(const float* __restrict__ in, int in_ld, int H, int
     r /= Wo;
     const int yo = static_cast<int>(r % Ho);
     const int img = static_cast<int>(r / Ho);
-    const float* base = in + static_cast<long long>(img) * H * W * in_ld;
+    const float* base = in + static_cast<long long>(img) * in_img_stride;
     float m = -INFINITY;
     for (int dy = 0; dy < 2; ++dy)
         for (int dx = 0; dx < 2; ++dx) {
@@ -637,13 +637,14 @@ extern "C" int fiery_latent_sample(const float* mu, const float* log_sigma, cons
     return check_launch("latent_sample");
 }
 
-extern "C" int fiery_maxpool2x2_nhwc(const float* in, int in_ld, int n_img, int H, int W, int C, float* out, int out_ld,
-                                     fiery_stream_t stream) {
+extern "C" int fiery_maxpool2x2_nhwc(const float* in, int in_ld, int64_t in_img_stride, int n_img, int H, int W, int C,
+                                     float* out, int out_ld, fiery_stream_t stream) {
     FIERY_REQUIRE(in && out && n_img > 0 && H > 0 && W > 0 && C > 0, "maxpool: bad argument");
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     const long long total = static_cast<long long>(n_img) * Ho * Wo * C;
-    hipLaunchKernelGGL(k_maxpool2x2, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), in, in_ld, H, W, C, Ho, Wo,
-                       out, out_ld, total);
+    const long long istride = in_img_stride > 0 ? in_img_stride : static_cast<long long>(H) * W * in_ld;
+    hipLaunchKernelGGL(k_maxpool2x2, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), in, in_ld, istride, H, W, C, Ho,
+                       Wo, out, out_ld, total);
     return check_launch("maxpool2x2");
 }
 

@@ -52,9 +52,16 @@ __device__ void pose_to_mat(const float* v, float* m) {
 }
 
 __global__ void k_warp_params(const float* __restrict__ ego, int B, int S, float ext_x, float ext_y,
-                              float* __restrict__ theta) {
+                              float* __restrict__ theta, float* __restrict__ ego_shifted) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    if (ego_shifted) {
+        // the temporal model's ego-pose channels: frame s carries the motion that led to it (fiery.py:152-154)
+        float* sh = ego_shifted + static_cast<long long>(b) * S * 6;
+        const float* src = ego + static_cast<long long>(b) * S * 6;
+        for (int i = 0; i < 6; ++i) sh[i] = 0.f;
+        for (int i = 6; i < S * 6; ++i) sh[i] = src[i - 6];
+    }
     float* th = theta + static_cast<long long>(b) * S * 6;
     // the present frame is never resampled (geometry.py:245)
     float* last = th + (S - 1) * 6;
@@ -154,12 +161,12 @@ __global__ __launch_bounds__(256) void k_bev_warp(const float* __restrict__ in, 
 using namespace fiery;
 
 extern "C" int fiery_warp_params(const float* future_egomotion, int B, int S, float extent_x, float extent_y,
-                                 float* theta, fiery_stream_t stream) {
+                                 float* theta, float* ego_shifted, fiery_stream_t stream) {
     FIERY_REQUIRE(future_egomotion && theta && B > 0 && S > 0, "warp_params: bad argument");
     FIERY_REQUIRE(S <= kMaxFrames, "warp_params: at most %d frames", kMaxFrames);
     FIERY_REQUIRE(extent_x != 0.f && extent_y != 0.f, "warp_params: zero spatial extent");
     hipLaunchKernelGGL(k_warp_params, dim3(ceil_div(B, 64)), dim3(64), 0, as_stream(stream), future_egomotion, B, S,
-                       extent_x, extent_y, theta);
+                       extent_x, extent_y, theta, ego_shifted);
     return check_launch("warp_params");
 }
 

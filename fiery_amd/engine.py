@@ -239,8 +239,9 @@ class _TemporalBlock:
                                (cf_pad // 8, 0), s_, b_, dev)
             self.proj_ego_w = wp[:, self.cf:].contiguous().to(dev) if ego_channels else None
 
-    def run(self, eng, xin, t_in0, ego_in, B, S, tag):
-        """xin: frames t >= t_in0 of every batch element, images ordered (b, t).  Returns frames >= t_in0 + 1."""
+    def run(self, eng, xin, t_in0, ego_in, B, S, tag, out=None):
+        """xin: frames t >= t_in0 of every batch element, images ordered (b, t).  Returns frames >= t_in0 + 1 (in `out`,
+        a Buf of B * T_out images, when given: the last block writes the present state where its consumers read it)."""
         lib, dev = eng.lib, eng.device
         H, W = xin.H, xin.W
         T_in = S - t_in0
@@ -290,7 +291,9 @@ class _TemporalBlock:
             lib.rowwise_dense(z, z.shape[1], B * T_out, red, self.pool['wagg'], red, 0, self.cout, None, None, NONE, False,
                               agg_bias, self.agg.cout_pad)
         # -- skip connection + aggregation (x + relu(bn(agg)), layers/temporal.py:276-280)
-        out = eng.buf(tag + 'O', B * T_out, H, W, self.cout)
+        if out is None:
+            out = eng.buf(tag + 'O', B * T_out, H, W, self.cout)
+        assert out.n_img == B * T_out and out.C >= round_up(self.cout, 8)
         q_ld = H * W * Q.ld
         if self.proj is not None:
             R = eng.buf(tag + 'R', B * T_out, H, W, self.cout)
@@ -692,19 +695,28 @@ class BevEngine:
         ego = future_egomotion.float().contiguous()
         # -- ego-warp + layout change ---------------------------------------------------------------
         x0 = self.buf('x0', B * S, H, W, C)
-        theta = lib.warp_params(ego, self.extent)
+        theta = self.vec('warp_theta', B * S, 6)
+        ego_in = self.vec('ego_in', B * S, 6).view(B, S, 6) if self.egopose else None          # fiery.py:152-154
+        lib.warp_params(ego, self.extent, theta=theta.view(B, S, 6), ego_shifted=ego_in)
         identity = [(i % S) == S - 1 for i in range(B * S)]
-        lib.bev_warp_nchw_to_nhwc(bev.contiguous(), theta.view(B * S, 6), identity, x0.tensor, x0.ld, x0.img_stride)
+        lib.bev_warp_nchw_to_nhwc(bev.contiguous(), theta, identity, x0.tensor, x0.ld, x0.img_stride)
+        # the decoder's input holds (present, future 1 .. nf) per batch element; the temporal model's last block writes the
+        # present state straight into slot 0 (no copy), and everything that reads "present" reads it there
+        dec_in = present_slot = None
+        if self.nf > 0:
+            dec_in = self.buf('dec_in', B * (self.nf + 1), H, W, self.state_c)
+            present_slot = dec_in.images(0, B, step=self.nf + 1)
         # -- temporal model --------------------------------------------------------------------------
         if self.temporal_identity:
             present = x0.images(S - 1, B, step=S) if S > 1 else x0
+            if present_slot is not None:                  # (no shipped configuration: identity temporal model + future prediction)
+                present_slot.nhwc().copy_(present.nhwc())
+                present = present_slot
         else:
-            ego_in = None
-            if self.egopose:
-                ego_in = torch.cat([torch.zeros_like(ego[:, :1]), ego[:, :S - 1]], dim=1).contiguous()   # fiery.py:152-154
             x = x0
+            last = len(self.temporal) - 1
             for j, blk in enumerate(self.temporal):
-                x = blk.run(self, x, j, ego_in, B, S, f't{j}')
+                x = blk.run(self, x, j, ego_in, B, S, f't{j}', out=present_slot if (j == last and S - j - 1 == 1) else None)
             present = x                                   # (B images) = the last frame
         # -- distributions ---------------------------------------------------------------------------
         if self.nf > 0:
@@ -729,7 +741,9 @@ class BevEngine:
             if not self.grus[0].const_x:                            # the broadcast input is only materialised if needed
                 gx = self.buf('gru_x0', B, H, W, self.latent)
                 lib.broadcast(sample, self.latent, B, H * W, self.latent, gx.tensor, gx.ld, gx.img_stride)
-            dec_in = self.buf('dec_in', B * (self.nf + 1), H, W, self.state_c)
+            if present.tensor is not dec_in.tensor:       # (a temporal model with several live output frames)
+                present_slot.nhwc().copy_(present.nhwc())
+                present = present_slot
             self._future_prediction(gx, sample, present, dec_in, B)
             n_dec_t = self.nf + 1
         else:
@@ -751,8 +765,6 @@ class BevEngine:
                               False, gates_bias, 9 * 2 * ch)
             lib.rowwise_dense(sample, self.latent, B, self.latent, g0.tilde_xw, self.latent, 0, 9 * ch, None, None, NONE,
                               False, tilde_bias, 9 * ch)
-        # present state -> slot 0 of every batch element of the decoder input (plain copy)
-        dec_in.nhwc().view(B, nf + 1, H, W, -1)[:, 0].copy_(present.nhwc())
         seq_in = None
         n_blocks = len(self.grus)
         for i, gru in enumerate(self.grus):

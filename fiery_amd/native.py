@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libfiery_hip.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -105,7 +105,7 @@ _SIGNATURES = {
     'fiery_lift_splat_bwd': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'fiery_depth_softmax': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'fiery_depth_softmax_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
-    'fiery_warp_params': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    'fiery_warp_params': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     'fiery_bev_warp_nchw_to_nhwc': (C.c_int, [C.c_void_p, C.c_void_p, c_uint8_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                               C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     'fiery_conv_packed_floats': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
@@ -121,7 +121,7 @@ _SIGNATURES = {
     'fiery_sequential_window_mean': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'fiery_latent_sample': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                       C.c_void_p]),
-    'fiery_maxpool2x2_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'fiery_maxpool2x2_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'fiery_upsample2x_add_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                             C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'fiery_depthwise_conv_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_int] * 6 +
@@ -258,11 +258,13 @@ class Lib:
         return out
 
     # -- warp -------------------------------------------------------------------------------------
-    def warp_params(self, future_egomotion, extent):
+    def warp_params(self, future_egomotion, extent, theta=None, ego_shifted=None):
+        """-> theta (B, S, 6); `ego_shifted` (B, S, 6), when given, receives the temporal model's ego-pose input."""
         b, s, _ = future_egomotion.shape
-        theta = torch.empty(b, s, 6, dtype=torch.float32, device=future_egomotion.device)
+        if theta is None:
+            theta = torch.empty(b, s, 6, dtype=torch.float32, device=future_egomotion.device)
         self.check(self.dll.fiery_warp_params(_ptr(future_egomotion), b, s, float(extent[0]), float(extent[1]),
-                                              _ptr(theta), _stream_of(theta)))
+                                              _ptr(theta), _ptr(ego_shifted), _stream_of(theta)))
         return theta
 
     def bev_warp_nchw_to_nhwc(self, x, theta, identity, out, out_ld, out_img_stride):
@@ -309,7 +311,8 @@ class Lib:
                                                 _stream_of(sample)))
 
     def maxpool2x2(self, x, in_ld, n_img, h, w, c, out, out_ld):
-        self.check(self.dll.fiery_maxpool2x2_nhwc(_ptr(x), in_ld, n_img, h, w, c, _ptr(out), out_ld, _stream_of(out)))
+        self.check(self.dll.fiery_maxpool2x2_nhwc(_ptr(x), in_ld, getattr(x, 'img_stride', 0), n_img, h, w, c, _ptr(out), out_ld,
+                                                  _stream_of(out)))
 
     def upsample2x_add(self, x, in_ld, n_img, h, w, c, shift, skip, skip_ld, out, out_ld):
         self.check(self.dll.fiery_upsample2x_add_nhwc(_ptr(x), in_ld, n_img, h, w, c, _ptr(shift), _ptr(skip), skip_ld,

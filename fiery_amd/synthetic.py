@@ -86,3 +86,30 @@ def make_lifted_features(n_images, channels, depth, feat_hw, seed=1, materialise
     if materialise:
         lifted = depth_logits.softmax(dim=1).unsqueeze(1) * features.unsqueeze(2)
     return depth_logits, features, lifted
+
+
+def randomise_weights(model, seed=2):
+    """Non-trivial values everywhere, BatchNorm statistics included (fresh BN is the identity: a weak test).
+    Deterministic per key name, so any module tree with the same state_dict keys gets the same values."""
+    sd = model.state_dict()
+    new = {}
+    for i, key in enumerate(sorted(sd)):
+        t = sd[key]
+        if key in ('frustum', 'bev_resolution', 'bev_start_position', 'bev_dimension') or key.endswith('num_batches_tracked'):
+            new[key] = t
+            continue
+        g = torch.Generator().manual_seed(seed * 1000003 + i)
+        if key.endswith('running_var'):
+            v = 0.5 + torch.rand(t.shape, generator=g)
+        elif key.endswith('running_mean'):
+            v = 0.2 * torch.randn(t.shape, generator=g)
+        elif t.dim() == 1 and key.endswith('weight'):          # BN / affine scale
+            v = 0.75 + 0.5 * torch.rand(t.shape, generator=g)
+        elif t.dim() == 1:
+            v = 0.1 * torch.randn(t.shape, generator=g)
+        else:
+            fan_in = t[0].numel()
+            v = torch.randn(t.shape, generator=g) * (1.0 / fan_in ** 0.5)     # keeps activations O(1..10) through the stack
+        new[key] = v.to(t.dtype)
+    model.load_state_dict(new)
+    return new

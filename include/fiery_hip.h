@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FIERY_ABI_VERSION 5
+#define FIERY_ABI_VERSION 6
 
 #define FIERY_OK 0
 #define FIERY_EINVAL (-22)      /* bad argument (shape, alignment, null pointer) */
@@ -155,9 +155,11 @@ int fiery_depth_softmax_bwd(const float* prob, const float* grad_prob, int n, in
 
 /* theta[b][s][6]: the 2x3 sampling transform warp_features builds (geometry.py:192-215) for frame s of
  * batch b, i.e. flow[s] @ ... @ flow[S-2] reduced to (cos, -sin, ty/extent_y, sin, cos, -tx/extent_x);
- * entries for s = S-1 are the identity.  future_egomotion [B][S][6]. */
+ * entries for s = S-1 are the identity.  future_egomotion [B][S][6].
+ * ego_shifted (optional): the temporal model's ego-pose input, row (b, 0) = 0 and row (b, s) = future_egomotion[b][s-1]
+ * (fiery.py:152-154: `cat([zeros_like(ego[:, :1]), ego[:, :-1]])`), written by the same launch. */
 int fiery_warp_params(const float* future_egomotion, int B, int S, float extent_x, float extent_y,
-                      float* theta, fiery_stream_t stream);
+                      float* theta, float* ego_shifted /* [B][S][6] or NULL */, fiery_stream_t stream);
 
 /* Bilinear grid-sample with zero padding, align_corners=False (geometry.py:219-220), reading NCHW
  * [n_img][C][H][W] and writing NHWC (ld, img_stride as given).  Images whose `identity[i]` (host
@@ -321,8 +323,8 @@ int fiery_latent_sample(const float* mu, const float* log_sigma, const float* no
 
 /* 2x2 stride-2 max pooling, NHWC, odd sizes padded with one zero row/column first
  * (layers/convolutions.py:150,166). */
-int fiery_maxpool2x2_nhwc(const float* in, int in_ld, int n_img, int H, int W, int C,
-                          float* out, int out_ld, fiery_stream_t stream);
+int fiery_maxpool2x2_nhwc(const float* in, int in_ld, int64_t in_img_stride /* floats between images; 0 = H*W*in_ld */,
+                          int n_img, int H, int W, int C, float* out, int out_ld, fiery_stream_t stream);
 
 /* Depthwise k x k convolution, NHWC, + folded BatchNorm (scale, shift; may be NULL) + activation: the MBConv blocks of the
  * image trunk (efficientnet-pytorch `MBConvBlock._depthwise_conv` + `_bn1` + swish, behind fiery/models/encoder.py:58-86).

@@ -14,31 +14,7 @@ def tiny_cfg(preset='baseline.yml', bev=16, **overrides):
     return get_preset_cfg(preset, opts)
 
 
-def randomise_weights(model, seed=2):
-    """Non-trivial values everywhere, BatchNorm statistics included (fresh BN is the identity: a weak test).
-    Deterministic per key name, so any module tree with the same state_dict keys gets the same values."""
-    sd = model.state_dict()
-    new = {}
-    for i, key in enumerate(sorted(sd)):
-        t = sd[key]
-        if key in ('frustum', 'bev_resolution', 'bev_start_position', 'bev_dimension') or key.endswith('num_batches_tracked'):
-            new[key] = t
-            continue
-        g = torch.Generator().manual_seed(seed * 1000003 + i)
-        if key.endswith('running_var'):
-            v = 0.5 + torch.rand(t.shape, generator=g)
-        elif key.endswith('running_mean'):
-            v = 0.2 * torch.randn(t.shape, generator=g)
-        elif t.dim() == 1 and key.endswith('weight'):          # BN / affine scale
-            v = 0.75 + 0.5 * torch.rand(t.shape, generator=g)
-        elif t.dim() == 1:
-            v = 0.1 * torch.randn(t.shape, generator=g)
-        else:
-            fan_in = t[0].numel()
-            v = torch.randn(t.shape, generator=g) * (1.0 / fan_in ** 0.5)     # keeps activations O(1..10) through the stack
-        new[key] = v.to(t.dtype)
-    model.load_state_dict(new)
-    return new
+from fiery_amd.synthetic import randomise_weights  # noqa: E402,F401  (lives with the other synthetic-input generators)
 
 
 def forward_case(cfg, rf, n_future, depth, bev_size, B, n_cam, with_labels=False, with_noise=False, seed=0):

@@ -560,9 +560,12 @@ def test_cumulative_warp_vs_oracle_full_size(hip, extent, hw):
     parity_report.record(f'warp {H}x{W}', 'theta', t_err, 1.0, bound=1e-6)
     assert t_err <= 1e-6
     err = (got - want).abs().max().item()
-    parity_report.record(f'warp {H}x{W}', 'warped features', err, want.abs().max().item(), bound=2e-5)
+    parity_report.record(f'warp {H}x{W}', 'warped features', err, want.abs().max().item())
     assert torch.equal(got[:, S - 1], x[:, S - 1])                    # the present frame is untouched
-    assert err <= 2e-5 * max(1.0, want.abs().max().item())            # bilinear weights from near-identical thetas
+    # white-noise maps are the worst case for a resampler (neighbouring pixels are unrelated, so a 1e-5-pixel difference in
+    # a sampling position shows up at full size); ATen builds its base grid with linspace and a BLAS product, the kernel
+    # evaluates (2x + 1) / W - 1 directly: same positions to ~1e-5 pixel
+    assert err <= TOL * max(1.0, want.abs().max().item())
 
 
 def test_graph_replay_equals_eager_and_follows_in_place_input_updates(hip):
@@ -622,6 +625,42 @@ def test_per_sample_streams_give_the_batched_result(hip):
         for k, v in batched.items():
             if v is not None:
                 assert (replay[k] - v).abs().max().item() <= 1e-5 * max(1.0, v.abs().max().item()), k
+
+
+def test_frame_sharded_layout_through_rccl_on_one_gpu(hip):
+    """BASELINE.json configs[2] on the one GPU there is: `sharded_bev_forward(layout='frames')` with a 1-rank RCCL process
+    group - frames pooled into the preallocated exchange buffer, `all_gather_into_tensor` over the nccl (= RCCL) backend,
+    the stack on the gathered maps - must give what `bev_forward` gives; a second call reuses the exchange buffers."""
+    import socket
+    import torch.distributed as dist
+    from fiery_amd.parallel import sharded_bev_forward
+    cfg = tiny_cfg('baseline.yml')
+    model, sd = _model(cfg)
+    lifted, K, E, ego, _, noise = forward_case(cfg, model.receptive_field, model.n_future, model.depth_channels,
+                                               model.bev_size, 2, 2, False, True)
+    args = [t.to(DEV) for t in (lifted, K, E, ego)]
+    noise = noise.to(DEV)
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        with torch.no_grad():
+            want = {k: None if v is None else v.clone() for k, v in model.bev_forward(*args, None, noise).items()}
+            got, rng = sharded_bev_forward(model, args[1], args[2], args[3], lifted=args[0], noise=noise, layout='frames')
+            got = {k: None if v is None else v.clone() for k, v in got.items()}
+            again, _ = sharded_bev_forward(model, args[1], args[2], args[3], lifted=args[0], noise=noise, layout='frames')
+            torch.cuda.synchronize()
+        assert rng == (0, 2) and len(model._sharder._exchange) == 1
+        for k, v in want.items():
+            if v is None:
+                assert got[k] is None
+                continue
+            assert (got[k] - v).abs().max().item() <= 1e-5 * max(1.0, v.abs().max().item()), k
+            assert (again[k] - v).abs().max().item() <= 1e-5 * max(1.0, v.abs().max().item()), k
+    finally:
+        dist.destroy_process_group()
 
 
 def test_method_seams_keep_the_reference_signatures(hip):
