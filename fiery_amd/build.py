@@ -22,6 +22,8 @@ SOURCES = [
     ('conv_tile_128x128_rest.hip', []),
     ('conv_tile_64x64.hip', []),
     ('conv_tile_64x128.hip', []),
+    ('conv_tile_bf16_a.hip', []),
+    ('conv_tile_bf16_b.hip', []),
     ('aux_ops.hip', []),
 ]
 # FIERY_CONV_TUNING=1: also build the convolution's clock-probe / priority variants (tools/microbench.py conv --clk)

@@ -37,6 +37,31 @@ __global__ void k_pack_weights(const float* __restrict__ w, int cout, int cin_to
     packed[i] = v;
 }
 
+// bf16 image of the weights: inside a (chunk, cout tile) block [k / 8][cout][k % 8] - a lane's eight k of one
+// v_mfma_f32_32x32x16_bf16 are one 16-byte LDS read
+__global__ void k_pack_weights_bf16(const float* __restrict__ w, int cout, int cin_total, int taps, ChanInverse inv,
+                                    int cin_units, int bn, int k_chunks, long long total, unsigned short* __restrict__ packed) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int kj = static_cast<int>(i & 7);
+    const int nn = static_cast<int>((i >> 3) % bn);
+    long long r = (i >> 3) / bn;
+    const int kk = static_cast<int>(r % (BK / 8)) * 8 + kj;
+    r /= BK / 8;
+    const int chunk = static_cast<int>(r % k_chunks);
+    const int tile = static_cast<int>(r / k_chunks);
+    const int n = tile * bn + nn;
+    const int k = chunk * BK + kk;
+    const int u = k >> 3, ch = k & 7;
+    const int tap = u / cin_units, cc = u - tap * cin_units;
+    float v = 0.f;
+    if (n < cout && tap < taps) {
+        const int ci = inv.ci[cc * 8 + ch];
+        if (ci >= 0) v = w[(static_cast<long long>(n) * cin_total + ci) * taps + tap];
+    }
+    packed[i] = bf16_bits(v);
+}
+
 struct Geometry {
     int cout_pad, bn, n_tiles, k_chunks, n_units;
 };
@@ -117,7 +142,43 @@ extern "C" int fiery_conv_pack_weights(const float* w, int cout, int cin_total, 
     return check_launch("conv_pack_weights");
 }
 
-extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) {
+extern "C" int fiery_conv_pack_weights_bf16(const float* w, int cout, int cin_total, int taps, const int32_t* chan_map,
+                                            int cin_units, void* packed, fiery_stream_t stream) {
+    FIERY_REQUIRE(w && chan_map && packed, "conv_pack_weights_bf16: null pointer");
+    FIERY_REQUIRE(cout > 0 && cin_total > 0 && taps > 0 && cin_units > 0, "conv_pack_weights_bf16: bad shape");
+    FIERY_REQUIRE(cin_units <= kMaxPackUnits, "conv_pack_weights_bf16: at most %d input channels", kMaxPackUnits * 8);
+    ChanInverse inv;
+    for (int i = 0; i < kMaxPackUnits * 8; ++i) inv.ci[i] = -1;
+    for (int ci = 0; ci < cin_total; ++ci) {
+        const int pos = chan_map[ci];
+        FIERY_REQUIRE(pos >= 0 && pos < cin_units * 8, "conv_pack_weights_bf16: chan_map[%d] = %d out of range", ci, pos);
+        FIERY_REQUIRE(inv.ci[pos] < 0, "conv_pack_weights_bf16: chan_map maps two channels to position %d", pos);
+        inv.ci[pos] = static_cast<short>(ci);
+    }
+    const Geometry g = conv_geometry(cout, cin_units, taps);
+    const long long total = static_cast<long long>(g.n_tiles) * g.k_chunks * BK * g.bn;
+    hipLaunchKernelGGL(k_pack_weights_bf16, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w, cout, cin_total,
+                       taps, inv, cin_units, g.bn, g.k_chunks, total, static_cast<unsigned short*>(packed));
+    return check_launch("conv_pack_weights_bf16");
+}
+
+namespace {
+// does the bf16 form take this launch?  (the scalar-addressed loop's conditions, a tile shape that has a bf16 kernel)
+bool conv_takes_bf16(const fiery_conv_desc* d, bool aligned, int bm, int bn, int cin_units) {
+    if (d->precision != FIERY_PRECISION_BF16 || !d->weights_bf16 || !aligned || cin_units < 4) return false;
+    if (getenv("FIERY_CONV_CLKPROBE") || getenv("FIERY_CONV_PRIO")) return false;
+    return (bm == 128 && (bn == 32 || bn == 64 || bn == 128)) || (bm == 64 && (bn == 64 || bn == 128));
+}
+int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, bool launch);
+}  // namespace
+
+extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) { return conv_run(d, stream, true); }
+
+extern "C" int fiery_conv_precision_used(const fiery_conv_desc* d) { return conv_run(d, nullptr, false); }
+
+namespace {
+// validates the descriptor, plans the launch; `launch` = false: returns the precision the launch would run in
+int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, bool launch) {
     FIERY_REQUIRE(d, "conv_fwd: null descriptor");
     FIERY_REQUIRE(d->src[0].ptr && d->src[0].units > 0, "conv_fwd: source 0 missing");
     FIERY_REQUIRE(d->src[1].units == 0 || d->src[1].ptr, "conv_fwd: source 1 missing");
@@ -278,6 +339,15 @@ extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) {
     if (cin_units < 4) variant = kConvSmallCin;       // the loop whose unit advance may carry several times per stage
     else if (clk) variant = aligned ? kConvClockAligned : kConvClock;
     else if (prio) variant = kConvPrio;
+    const int bm = half_tiles ? 64 : 128;
+    const bool bf16 = conv_takes_bf16(d, aligned, bm, bn, cin_units);
+    if (!launch) return bf16 ? FIERY_PRECISION_BF16 : FIERY_PRECISION_F32;
+    if (bf16) {
+        FIERY_REQUIRE(aligned16(d->weights_bf16), "conv_fwd: bf16 weights must be 16-byte aligned");
+        p.w = static_cast<const float*>(d->weights_bf16);
+        if (!conv_launch_bf16(p, bm, bn, grid, hs)) return fail(FIERY_EINVAL, "conv_fwd: no bf16 kernel for the %d x %d tile", bm, bn);
+        return check_launch("conv_fwd (bf16)");
+    }
     bool launched;
     if (half_tiles) launched = bn == 128 ? conv_launch_64x128(p, grid, hs, variant, clk) : conv_launch_64x64(p, grid, hs, variant, clk);
     else if (bn == 128) launched = conv_launch_128x128(p, grid, hs, variant, clk);
@@ -288,6 +358,7 @@ extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) {
                                   "FIERY_CONV_TUNING=1 at build time)", variant, half_tiles ? 64 : 128, bn);
     return check_launch("conv_fwd");
 }
+}  // namespace
 
 extern "C" int fiery_heads_1x1_nchw(const float* in, int in_ld, int n_img, int HW, int C, int head_c, int n_out,
                                     const float* w, const float* bias, const int32_t* c_off, const uint8_t* sigmoid,

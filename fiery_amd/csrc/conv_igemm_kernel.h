@@ -25,6 +25,7 @@
 // (conv_tile_<BM>x<BN>.hip) so that the five shapes compile side by side, and conv_igemm.hip holds the C ABI.
 #pragma once
 #include "common.h"
+#include <fiery_gfx950.h>
 
 #include <cmath>
 #include <cstdlib>
@@ -92,6 +93,9 @@ bool conv_launch_128x128(const ConvP& p, dim3 grid, hipStream_t stream, int vari
 bool conv_launch_128x128_rest(const ConvP& p, dim3 grid, hipStream_t stream, int variant, unsigned long long* clk);
 bool conv_launch_64x64(const ConvP& p, dim3 grid, hipStream_t stream, int variant, unsigned long long* clk);
 bool conv_launch_64x128(const ConvP& p, dim3 grid, hipStream_t stream, int variant, unsigned long long* clk);
+// bf16 matrix-core form of the scalar-addressed kernel (weights packed by fiery_conv_pack_weights_bf16 in p.w); returns
+// false when (bm, bn) has no such kernel
+bool conv_launch_bf16(const ConvP& p, int bm, int bn, dim3 grid, hipStream_t stream);
 
 #ifdef FIERY_CONV_KERNEL_TU
 namespace {
@@ -116,8 +120,14 @@ constexpr int conv_waves_per_simd(int bm, int bn) {
     return by_lds < cap ? by_lds : cap;
 }
 
-template <int BM, int BN, bool CLK = false, int PRIO = 0, bool SMALLCIN = false, bool ALIGNED = false>
+// BF16: the matrix cores run v_mfma_f32_32x32x16_bf16 - sixteen k per instruction instead of two, an eighth of the
+// matrix-pipe time per stage.  Activations stay fp32 in HBM and in LDS (the gather, the LDS image of the A tile and
+// every epilogue are the fp32 kernel's); a lane rounds its eight k of an A row to bf16 (round to nearest even,
+// v_cvt_pk_bf16_f32) on the way from LDS to the matrix core, the weights arrive already rounded and packed
+// [k / 8][cout][k % 8], products are exact and accumulate in fp32.  Scalar-addressed loop only.
+template <int BM, int BN, bool CLK = false, int PRIO = 0, bool SMALLCIN = false, bool ALIGNED = false, bool BF16 = false>
 __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm(ConvP p) {
+    static_assert(!BF16 || (ALIGNED && !SMALLCIN && !CLK), "the bf16 form exists for the scalar-addressed loop");
     if constexpr (PRIO == 1) {
         // experiment: workgroups that share a CU (dispatch order puts b and b + 256 on one CU first) get different wave
         // priorities, so that they do not march through their MFMA and load/store phases in lockstep
@@ -132,7 +142,8 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
     constexpr int WM = 4 / WN;             // wavefronts along pixels
     constexpr int MT = BM / (32 * WM);     // 32-pixel MFMA tiles per wavefront   (BN=32: 1, else 2)
     constexpr int NT = BN / (32 * WN);     // 32-cout MFMA tiles per wavefront    (BN=128: 2, else 1)
-    constexpr int BLOADS = (BK * BN / 4) / 256;
+    constexpr int W_BYTES = BF16 ? 2 : 4;                      // bytes per packed weight
+    constexpr int BLOADS = BF16 ? (BN >= 64 ? BN / 64 : 1) : (BK * BN / 4) / 256;      // 16-byte W loads per thread and stage
 
     // one LDS block: two A stages, two W stages; the epilogue reuses it as a BM x BN staging tile
     __shared__ __attribute__((aligned(16))) float smem[2 * BM * BK + 2 * BK * BN];
@@ -270,8 +281,10 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
     }
     // weights: one descriptor for this cout tile's packed image; thread t reads bytes [16 t, 16 t + 16) of every 4 KiB
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.w + static_cast<long long>(tile_n) * p.k_chunks * (BK * BN)), 0, 0x7fffffff, 0x00020000);
-    const int w_voff = tid * 16;
+        const_cast<char*>(reinterpret_cast<const char*>(p.w) + static_cast<long long>(tile_n) * p.k_chunks * (BK * BN * W_BYTES)), 0,
+        0x7fffffff, 0x00020000);
+    // (bf16, BN = 32: a stage's weights are 2 KiB, half the threads have nothing to fetch and point past the descriptor)
+    const int w_voff = (BF16 && BN == 32 && tid >= 128) ? static_cast<int>(0x80000000u) : tid * 16;
     int w_soff = 0;
     auto to_float4 = [](auto raw) {
         float4 f;
@@ -290,7 +303,7 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
                 s_base = s_second ? src1_ptr : src0_ptr;
                 s_ld = s_second ? src1_ld : src0_ld;
                 s_ts = s_second ? src1_ts : src0_ts;
-                w_soff = (ld_stage < c_k_chunks ? ld_stage : c_k_chunks - 1) * (BK * BN * 4);      // past the end: repeat
+                w_soff = (ld_stage < c_k_chunks ? ld_stage : c_k_chunks - 1) * (BK * BN * W_BYTES);      // past the end: repeat
             } else if (part == 1) {
                 // the descriptor's base sits (kT-1) frames and (padH, padW) pixels before the source, so that the
                 // tap's offset below is never negative; its size only has to exceed every real offset
@@ -393,6 +406,12 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
 #pragma unroll
     for (int q = 0; q < 4; ++q) a_rd[q] = a_row * BK + (((2 * q + hi) ^ ((a_row >> 1) & 7)) << 2);
     const int b_rd = 2 * BM * BK + (hi * BN + wn * (32 * NT) + m) * 4;                 // + (2 q BN + 32 nt) 4 + buf BK BN
+    // bf16: a lane's eight k of MFMA kh (k = 16 kh + 8 hi ..) are the two 16-byte slots 4 kh + 2 hi, + 1 of its A row
+    int a_rd16[2][2];
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) a_rd16[kh][e] = a_row * BK + (((4 * kh + 2 * hi + e) ^ ((a_row >> 1) & 7)) << 2);
     auto store_a = [&](int buf, int j) {
         *reinterpret_cast<float4*>(&smem[a_st + 32 * j * BK + buf * BM * BK]) = j == 0 ? areg0 : j == 1 ? areg1 : j == 2 ? areg2 : areg3;
     };
@@ -440,9 +459,40 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
     for (int i = 0; i < N_PIECES; ++i) side_piece(1, i);
     __syncthreads();
 
-    constexpr int N_MFMA = 16 * MT * NT;
+    constexpr int N_MFMA = (BF16 ? 2 : 16) * MT * NT;
     auto stage_body = [&](auto buf_c) {
         constexpr int buf = decltype(buf_c)::value;
+        if constexpr (BF16) {
+            // two MFMAs of sixteen k per 32 x 32 block and stage; the W image is [k / 8][cout][k % 8] bf16, so a lane's
+            // operand is one 16-byte read; its A operand is two 16-byte reads of fp32 and four packed conversions
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                bf16x8 a8[MT], b8[NT];
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const float4 lo = *reinterpret_cast<const float4*>(&smem[a_rd16[kh][0] + 32 * t * BK + buf * BM * BK]);
+                    const float4 hi4 = *reinterpret_cast<const float4*>(&smem[a_rd16[kh][1] + 32 * t * BK + buf * BM * BK]);
+                    a8[t] = pack_bf16x8(lo, hi4);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    b8[nt] = load_bf16x8(&smem[2 * BM * BK + buf * BK * BN + ((2 * kh + hi) * BN + wn * (32 * NT) + nt * 32 + m) * 4]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) {
+                        acc[t * NT + nt] = mfma_bf16_32x32x16(a8[t], b8[nt], acc[t * NT + nt]);
+                        const int s = (kh * NT + nt) * MT + t;
+#pragma unroll
+                        for (int i = 0; i < N_PIECES; ++i)
+                            if ((i * N_MFMA) / N_PIECES == s) side_piece(buf, i);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            }
+            __syncthreads();
+            return;
+        }
         // operands of k-group q+1 are read from LDS while the MFMAs of group q run (one b128 per 32x4 operand
         // block: A rows are [pixel][k], the W image is [k/4][cout][k%4])
         float4 a_cur[MT], b_cur[NT];
@@ -945,6 +995,11 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
 // compile time and nothing in the product path launches them).
 // kMask: which variants this translation unit instantiates (bit = ConvVariant); the 128 x 128 tile, whose kernels take
 // minutes each to compile, is spread over two units.
+template <int BM, int BN>
+void conv_launch_tile_bf16(const ConvP& p, dim3 grid, hipStream_t hs) {
+    hipLaunchKernelGGL((k_conv_igemm<BM, BN, false, 0, false, true, true>), grid, dim3(256), 0, hs, p);
+}
+
 template <int BM, int BN, unsigned kMask>
 bool conv_launch_tile(const ConvP& p, dim3 grid, hipStream_t hs, int variant, unsigned long long* clk) {
     (void)clk;

@@ -59,6 +59,30 @@ __device__ __forceinline__ float rows_sum4(float v) {
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// ---- bf16 matrix-core operands ---------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float fiery_v16f __attribute__((ext_vector_type(16)));
+
+// eight fp32 -> eight bf16, round to nearest even (four v_cvt_pk_bf16_f32)
+__device__ __forceinline__ bf16x8 pack_bf16x8(float4 lo, float4 hi) {
+    bf16x8 v;
+    v[0] = static_cast<__bf16>(lo.x);  v[1] = static_cast<__bf16>(lo.y);  v[2] = static_cast<__bf16>(lo.z);  v[3] = static_cast<__bf16>(lo.w);
+    v[4] = static_cast<__bf16>(hi.x);  v[5] = static_cast<__bf16>(hi.y);  v[6] = static_cast<__bf16>(hi.z);  v[7] = static_cast<__bf16>(hi.w);
+    return v;
+}
+__device__ __forceinline__ bf16x8 load_bf16x8(const float* p) { return *reinterpret_cast<const bf16x8*>(p); }
+// D(32 x 32) += A(32 x 16) . B(16 x 32): lane l holds A[l & 31][8 (l >> 5) + j], B[8 (l >> 5) + j][l & 31], j < 8
+__device__ __forceinline__ fiery_v16f mfma_bf16_32x32x16(bf16x8 a, bf16x8 b, fiery_v16f c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// one fp32 -> bf16 bits (round to nearest even), for the weight packer
+__device__ __forceinline__ unsigned short bf16_bits(float v) {
+    const __bf16 b = static_cast<__bf16>(v);
+    unsigned short r;
+    __builtin_memcpy(&r, &b, 2);
+    return r;
+}
+
 // Code-motion fence: everything that produces a, b, c is issued before, every memory access written after it
 // stays after.  (The compiler otherwise sinks a batch's arithmetic below the next batch's loads and then holds
 // three batches of rows in registers - or rather in scratch.)

@@ -386,7 +386,13 @@ class BevEngine:
         self.frustum = model.frustum.detach().float().contiguous().to(self.device)
         self.pool_tile = int(os.environ.get('FIERY_POOL_TILE', '0'))      # voxels per LDS tile, 0 = library default
         self.pool_flags = 0
-        self._build()
+        # matrix-core precision of every convolution of this plan ('f32' | 'bf16'; model.conv_precision)
+        self.precision = {'f32': native.PRECISION_F32, 'bf16': native.PRECISION_BF16}[getattr(model, 'conv_precision', 'f32')]
+        previous, ops.DEFAULT_PRECISION = ops.DEFAULT_PRECISION, self.precision
+        try:
+            self._build()
+        finally:
+            ops.DEFAULT_PRECISION = previous
 
     # -- plan ---------------------------------------------------------------------------------------
     def _build(self):
@@ -485,6 +491,14 @@ class BevEngine:
         if self._encoder_ops_built:
             return
         m, dev, lib = self.m, self.device, self.lib
+        previous, ops.DEFAULT_PRECISION = ops.DEFAULT_PRECISION, self.precision
+        try:
+            self._plan_encoder_ops(m, dev, lib)
+        finally:
+            ops.DEFAULT_PRECISION = previous
+        self._encoder_ops_built = True
+
+    def _plan_encoder_ops(self, m, dev, lib):
         # lift head (reference: fiery/models/encoder.py:87-104, fiery/layers/convolutions.py:171-200): the coarse level is
         # interpolated into a buffer of its own and the first 3x3 reads [shallow, deep] as a virtual concat
         enc = m.encoder

@@ -118,6 +118,10 @@ class Fiery(nn.Module):
         # 'host': the reference's own CPU operators on the 3x3 matrices (`host_camera_matrices`), then the device product:
         # bit-exact indices for any K, at the price of a device-to-host read of the calibration (not graph-capturable).
         self.camera_matrix_mode = os.environ.get('FIERY_CAMERA_MATRICES', 'device')
+        # matrix-core precision of the convolutions: 'f32' = the reference's arithmetic (the parity configuration);
+        # 'bf16' = operands rounded to bf16 at the matrix cores, fp32 accumulation and epilogues (BASELINE.json configs[3-4]).
+        # Set before the first forward, or call refresh_engine() after changing it.
+        self.conv_precision = os.environ.get('FIERY_CONV_PRECISION', 'f32')
         self._engine = None
         self._engine_key = None
         self._engine_generation = 0   # counts plan rebuilds: graph cache keys name the plan by it, never by id()
@@ -162,7 +166,7 @@ class Fiery(nn.Module):
                 raise RuntimeError('fiery_amd.Fiery runs its BEV path on MI355X kernels only: move the model to a '
                                    'HIP device (model.cuda()); there is no CPU fallback')
             lib = native.get()
-        key = (str(device), id(lib), self._params_version())
+        key = (str(device), id(lib), self.conv_precision, self._params_version())
         if self._engine is None or self._engine_key != key:
             from .engine import BevEngine
             self._graphs.clear()

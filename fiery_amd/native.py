@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libfiery_hip.so')
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -21,6 +21,7 @@ c_int64_p = C.POINTER(C.c_int64)
 c_uint8_p = C.POINTER(C.c_uint8)
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SWISH = 0, 1, 2, 3
+PRECISION_F32, PRECISION_BF16 = 0, 1
 EPI_PLAIN, EPI_GRU_GATES, EPI_GRU_OUT, EPI_HEADS = 0, 1, 2, 3
 POOL_DETERMINISTIC = 1
 
@@ -62,6 +63,7 @@ class ConvDesc(C.Structure):
         ('weights2', C.c_void_p), ('scale2', C.c_void_p), ('shift2', C.c_void_p), ('act2', C.c_int32),
         ('weights3', C.c_void_p), ('scale3', C.c_void_p), ('shift3', C.c_void_p), ('act3', C.c_int32), ('out3', Nhwc),
         ('tile_m', C.c_int32), ('img_bias_border', C.c_int32), ('heads', ConvHeads),
+        ('weights_bf16', C.c_void_p), ('precision', C.c_int32),
     ]
 
 
@@ -111,6 +113,8 @@ _SIGNATURES = {
     'fiery_conv_packed_floats': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'fiery_conv_pack_weights': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_int32_p, C.c_int, C.c_void_p, C.c_void_p]),
     'fiery_conv_fwd': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    'fiery_conv_pack_weights_bf16': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_int32_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'fiery_conv_precision_used': (C.c_int, [C.POINTER(ConvDesc)]),
     'fiery_heads_1x1_nchw': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        c_int32_p, c_uint8_p, C.c_void_p, C.c_void_p]),
     'fiery_spatial_mean': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
@@ -281,6 +285,20 @@ class Lib:
         self.check(self.dll.fiery_conv_pack_weights(_ptr(w), cout, cin_total, taps, cmap, cin_units, _ptr(packed),
                                                     _stream_of(packed)))
         return packed
+
+    def conv_pack_weights_bf16(self, w, cout, cin_total, taps, chan_map, cin_units):
+        n = self.dll.fiery_conv_packed_floats(cout, cin_units, taps)
+        packed = torch.empty(n, dtype=torch.bfloat16, device=w.device)
+        cmap = (C.c_int32 * cin_total)(*chan_map)
+        self.check(self.dll.fiery_conv_pack_weights_bf16(_ptr(w), cout, cin_total, taps, cmap, cin_units, _ptr(packed),
+                                                         _stream_of(packed)))
+        return packed
+
+    def conv_precision_used(self, desc):
+        rc = self.dll.fiery_conv_precision_used(C.byref(desc))
+        if rc < 0:
+            self.check(rc)
+        return rc
 
     def conv_fwd(self, desc, stream_tensor):
         self.check(self.dll.fiery_conv_fwd(C.byref(desc), _stream_of(stream_tensor)))

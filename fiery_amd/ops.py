@@ -15,6 +15,9 @@ UNIT = 8          # input channels are consumed in units of 8 floats
 # When a list is installed here (bench.py does, for its instrumented step), every launch appends
 # (kind, start_event, end_event, algorithmic_work) - flops for convolutions, bytes for pooling.
 PROFILE_SINK = None
+# matrix-core precision of the convolutions built from here on: native.PRECISION_F32 (the reference's arithmetic, the parity
+# configuration) or native.PRECISION_BF16 (BASELINE.json configs[3] / [4]); `BevEngine` sets it from `model.conv_precision`
+DEFAULT_PRECISION = native.PRECISION_F32
 AUTOTUNE = os.environ.get('FIERY_CONV_AUTOTUNE', '1') != '0'     # time both tile heights once per conv shape (GPU only)
 
 
@@ -122,8 +125,11 @@ class ConvOp:
     """
 
     def __init__(self, lib, weight, chan_map, units, scale, shift, device, stride=1, pad=None,
-                 act=native.ACT_NONE, epi=native.EPI_PLAIN, res_before_act=False):
+                 act=native.ACT_NONE, epi=native.EPI_PLAIN, res_before_act=False, precision=None):
+        """precision: native.PRECISION_F32 / PRECISION_BF16 (None: `ops.DEFAULT_PRECISION`) - bf16 rounds the matrix-core
+        operands (weights here, activations on chip), accumulates in fp32; launches the bf16 kernel does not cover run in fp32."""
         self.lib = lib
+        self.precision = DEFAULT_PRECISION if precision is None else precision
         w = weight.detach().to(device=device, dtype=torch.float32).contiguous()
         self.cout, self.cin_total = w.shape[0], w.shape[1]
         kernel = tuple(w.shape[2:])
@@ -136,6 +142,10 @@ class ConvOp:
         assert len(chan_map) == self.cin_total
         self.packed = lib.conv_pack_weights(w.view(self.cout, self.cin_total, taps), self.cout, self.cin_total, taps,
                                             list(chan_map), cin_units)
+        self.packed_bf16 = None
+        if self.precision == native.PRECISION_BF16:
+            self.packed_bf16 = lib.conv_pack_weights_bf16(w.view(self.cout, self.cin_total, taps), self.cout, self.cin_total,
+                                                          taps, list(chan_map), cin_units)
         self.cout_pad = round_up(self.cout, 32)
         sc = torch.zeros(self.cout_pad, dtype=torch.float32)
         sh = torch.zeros(self.cout_pad, dtype=torch.float32)
@@ -285,14 +295,19 @@ class ConvOp:
         d.aux0 = aux0.as_nhwc_struct() if aux0 is not None else _null_nhwc()
         d.aux1 = aux1.as_nhwc_struct() if aux1 is not None else _null_nhwc()
         self._keep = (srcs, out, res, img_bias, out2, aux0, aux1, out3)
+        d.weights_bf16 = self.packed_bf16.data_ptr() if self.packed_bf16 is not None else None
+        d.precision = self.precision if self.packed_bf16 is not None else native.PRECISION_F32
         d.tile_m = self._pick_tile(d, out)
         flops = 2.0 * out.n_img * out.H * out.W * self.cin_total * self.kT * self.kH * self.kW * self.cout
         if self.chain is not None:
             flops += 2.0 * out.n_img * out.H * out.W * self.cout * self.chain['cout']
         if self.heads is not None:
             flops += 2.0 * out.n_img * out.H * out.W * 64 * self.heads['n_out']
+        used = 'f32'
+        if PROFILE_SINK is not None and d.precision == native.PRECISION_BF16:
+            used = 'bf16' if self.lib.conv_precision_used(d) == native.PRECISION_BF16 else 'f32'
         profiled('conv_igemm', flops, out.tensor, lambda: self.lib.conv_fwd(d, out.tensor),
-                 detail=(self.kT, self.kH, self.kW, self.stride, self.cin_total, self.cout, out.n_img, out.H, out.W))
+                 detail=(self.kT, self.kH, self.kW, self.stride, self.cin_total, self.cout, out.n_img, out.H, out.W, used))
 
 
 class HeadsOut:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FIERY_ABI_VERSION 6
+#define FIERY_ABI_VERSION 7
 
 #define FIERY_OK 0
 #define FIERY_EINVAL (-22)      /* bad argument (shape, alignment, null pointer) */
@@ -267,7 +267,18 @@ typedef struct {
         float* out[FIERY_MAX_HEAD_OUTPUTS];          /* plane of image 0                                */
         int64_t img_stride[FIERY_MAX_HEAD_OUTPUTS];  /* floats between the planes of consecutive images */
     } heads;
+    /* Matrix-core precision.  FIERY_PRECISION_BF16 with weights_bf16 != NULL: operands rounded to bf16 (round to nearest
+     * even) at the matrix-core inputs - v_mfma_f32_32x32x16_bf16, an eighth of the fp32 matrix-pipe time - with fp32
+     * accumulation; activations stay fp32 in memory and every epilogue (BatchNorm, activation, residual, GRU gates,
+     * chained 1x1s, heads) is the fp32 one.  Launches the bf16 form does not cover (channel layouts the scalar-addressed
+     * loop cannot take: fewer than 32 channels per tap or source, 35- / 70-channel temporal layers) run the fp32 kernel
+     * with `weights`, which therefore must always be set; fiery_conv_precision_used tells which form a descriptor gets. */
+    const void* weights_bf16;          /* packed by fiery_conv_pack_weights_bf16, or NULL                  */
+    int32_t precision;                 /* FIERY_PRECISION_F32 (0) or FIERY_PRECISION_BF16                  */
 } fiery_conv_desc;
+
+#define FIERY_PRECISION_F32 0
+#define FIERY_PRECISION_BF16 1
 
 /* Packs a dense weight W[cout][cin_total][taps] (taps = kT*kH*kW, row-major as PyTorch stores conv
  * weights) into the kernel's layout.  Input channel ci of the logical concat maps to padded position
@@ -277,7 +288,17 @@ int fiery_conv_pack_weights(const float* w, int cout, int cin_total, int taps,
                             const int32_t* chan_map /* host */, int cin_units,
                             float* packed, fiery_stream_t stream);
 
+/* The bf16 packing of the same weights ([k / 8][cout][k % 8] bf16 per 32-k stage and cout tile; values rounded to nearest
+ * even): fiery_conv_packed_floats(...) / 2 floats' worth of bytes. */
+int fiery_conv_pack_weights_bf16(const float* w, int cout, int cin_total, int taps,
+                                 const int32_t* chan_map /* host */, int cin_units,
+                                 void* packed, fiery_stream_t stream);
+
 int fiery_conv_fwd(const fiery_conv_desc* desc /* host */, fiery_stream_t stream);
+
+/* FIERY_PRECISION_F32 or FIERY_PRECISION_BF16: the matrix-core form fiery_conv_fwd runs this descriptor in (negative:
+ * an error code - the descriptor is invalid). */
+int fiery_conv_precision_used(const fiery_conv_desc* desc /* host */);
 
 /* Final 1x1 heads: out_nchw[img][o][y][x] = act_o(bias[o] + sum_{c<head_c} w[o][c] * in[img][y][x][c_off[o] + c])
  * (fiery/models/decoder.py:30-51, the last conv (+ Sigmoid) of each head), NCHW result.

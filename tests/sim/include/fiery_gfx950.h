@@ -22,6 +22,61 @@ inline v2f pk_add_sat_uniform(v2f a, v2f b) { return {hipsim_sat(a.x + b.x), hip
 
 inline void pk_pin(v2f&, v2f&, v2f&) {}
 
+// ---- bf16 matrix-core operands: eight bf16 values as their bit patterns ---------------------------------------------
+struct bf16x8 {
+    unsigned short v[8];
+};
+typedef hipsim_v16f fiery_v16f;
+inline unsigned short bf16_bits(float f) {                               // round to nearest even, NaN kept quiet
+    unsigned u;
+    __builtin_memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<unsigned short>((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return static_cast<unsigned short>(u >> 16);
+}
+inline float bf16_value(unsigned short b) {
+    const unsigned u = static_cast<unsigned>(b) << 16;
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+inline bf16x8 pack_bf16x8(float4 lo, float4 hi) {
+    return {{bf16_bits(lo.x), bf16_bits(lo.y), bf16_bits(lo.z), bf16_bits(lo.w), bf16_bits(hi.x), bf16_bits(hi.y), bf16_bits(hi.z),
+             bf16_bits(hi.w)}};
+}
+inline bf16x8 load_bf16x8(const float* p) {
+    bf16x8 r;
+    __builtin_memcpy(&r, p, 16);
+    return r;
+}
+// D(32 x 32) += A(32 x 16) . B(16 x 32), one wave: lane l holds A[l & 31][8 (l >> 5) + j], B[8 (l >> 5) + j][l & 31]; D as the
+// fp32 32 x 32 MFMA (row = (r & 3) + 8 (r >> 2) + 4 (l >> 5), col = l & 31).  Products of bf16 values are exact in fp32.
+inline fiery_v16f mfma_bf16_32x32x16(bf16x8 a, bf16x8 b, fiery_v16f c) {
+    ::hipsim::Run& run = *::hipsim::run_ptr();
+    const ::hipsim::Tls& t = ::hipsim::tls();
+    const int l = t.lane, w = t.wave;
+    float* wa = run.wave_a[w].data();
+    float* wb = run.wave_b[w].data();
+    for (int j = 0; j < 8; ++j) {
+        wa[l * 8 + j] = bf16_value(a.v[j]);
+        wb[l * 8 + j] = bf16_value(b.v[j]);
+    }
+    ::hipsim::barrier_wait(run.waves[w]);
+    const int col = l & 31, hi = l >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) {
+            const int src_a = (row + 32 * (k >> 3)) * 8 + (k & 7);       // lane (row, k / 8) holds A[row][k]
+            const int src_b = (col + 32 * (k >> 3)) * 8 + (k & 7);
+            acc = std::fmaf(wa[src_a], wb[src_b], acc);
+        }
+        c[r] = acc;
+    }
+    ::hipsim::barrier_wait(run.waves[w]);
+    return c;
+}
+
 inline v2f pk_sub_sat(v2f a, v2f b) { return {hipsim_sat(a.x - b.x), hipsim_sat(a.y - b.y)}; }
 
 // reduce-scatter of (a, b, c) over the four 16-lane rows: row 0 gets sum(a), row 1 sum(b), row 2 sum(c); same order of

@@ -153,8 +153,8 @@ void launch(Kernel kernel, dim3 grid, dim3 block, size_t shmem, Args... args) {
             for (unsigned bx = 0; bx < grid.x; ++bx) {
                 run.fibers.assign(n_threads, Fiber());
                 run.waves.assign(n_waves, Barrier());
-                run.wave_a.assign(n_waves, std::vector<float>(64));
-                run.wave_b.assign(n_waves, std::vector<float>(64));
+                run.wave_a.assign(n_waves, std::vector<float>(64 * 8));     // (8 values per lane: the bf16 MFMA's operands)
+                run.wave_b.assign(n_waves, std::vector<float>(64 * 8));
                 run.block = Barrier();
                 run.block.alive = static_cast<int>(n_threads);
                 for (unsigned t = 0; t < n_threads; ++t) {

@@ -360,3 +360,80 @@ def test_conv_random_shapes(sim, case):
         y = y + res
     got = out.to_nchw()[:, :cout]
     assert torch.allclose(got, y, **TOL), (case, c0, c1, cout, k, stride, n, H, W, act, (got - y).abs().max().item())
+
+
+# ---- bf16 matrix-core form (v_mfma_f32_32x32x16_bf16; activations fp32 in memory, operands rounded on chip) ------------
+def _bf16(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,hw,tile_m', [
+    (32, 64, 3, 1, (9, 14), None),       # 128 x 64 or 64 x 64 tile
+    (64, 32, 3, 1, (10, 12), None),      # BN = 32: half the threads fetch the 2 KiB of weights
+    (32, 128, 1, 1, (7, 20), '64'),      # 64 x 128
+    (64, 128, 3, 2, (11, 13), '128'),    # 128 x 128, stride 2, odd size
+    (64, 64, 7, 2, (12, 12), '64'),      # 7 x 7 stride 2 like the decoder stem
+])
+def test_conv2d_bf16_form(sim, monkeypatch, cin, cout, k, stride, hw, tile_m):
+    """The bf16 form against a convolution of the bf16-rounded operands in fp32 (exact products, fp32 sums: what the
+    matrix core computes up to the order of additions), and - loosely - against the fp32 convolution it approximates."""
+    if tile_m:
+        monkeypatch.setenv('FIERY_CONV_TILE_M', tile_m)
+    g = torch.Generator().manual_seed(cin * 10 + cout + k)
+    x = torch.randn(2, cin, *hw, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g)
+    src = _to_buf(x)
+    op = ConvOp(sim, w, identity_chan_map(cin), (src.C // 8, 0), scale, shift, 'cpu', stride=stride, act=native.ACT_RELU,
+                precision=native.PRECISION_BF16)
+    ho, wo = op.out_hw(*hw)
+    out = Buf.alloc(2, ho, wo, cout, 'cpu')
+    op([src], out)
+    pad = (k - 1) // 2
+    want = F.relu(F.conv2d(_bf16(x), _bf16(w), stride=stride, padding=pad) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    full = F.relu(F.conv2d(x, w, stride=stride, padding=pad) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    got = out.to_nchw()[:, :cout]
+    assert torch.allclose(got, want, rtol=2e-5, atol=2e-5), (got - want).abs().max()
+    assert (got - full).abs().max() < 0.05 and (got - full).abs().max() > 1e-5       # it IS the rounded-operand result
+
+
+def test_bf16_form_falls_back_to_fp32_where_it_does_not_apply(sim):
+    """13 input channels cannot take the scalar-addressed loop: the launch runs the fp32 kernel and is exact again."""
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(1, 13, 9, 11, generator=g)
+    w = torch.randn(32, 13, 3, 3, generator=g) * 0.2
+    src = _to_buf(x)
+    op = ConvOp(sim, w, identity_chan_map(13), (src.C // 8, 0), torch.ones(32), torch.zeros(32), 'cpu', precision=native.PRECISION_BF16)
+    out = Buf.alloc(1, 9, 11, 32, 'cpu')
+    op([src], out)
+    assert torch.allclose(out.to_nchw()[:, :32], F.conv2d(x, w, padding=1), **TOL)
+
+
+def test_gru_epilogues_and_chained_tail_on_the_bf16_form(sim):
+    """The epilogues are the fp32 kernel's: GRU gate GEMM (two sources) and a Bottleneck tail with its chained 1x1."""
+    g = torch.Generator().manual_seed(91)
+    ch = 32
+    x, h = torch.randn(1, ch, 8, 10, generator=g), torch.randn(1, ch, 8, 10, generator=g)
+    wg = torch.randn(2 * ch, 2 * ch, 3, 3, generator=g) / (2 * ch * 9) ** 0.5
+    bg = torch.randn(2 * ch, generator=g) * 0.1
+    xb, hb = _to_buf(x), _to_buf(h)
+    gates = ConvOp(sim, wg, identity_chan_map(ch) + identity_chan_map(ch, offset=ch), (ch // 8, ch // 8), torch.ones(2 * ch), bg,
+                   'cpu', epi=native.EPI_GRU_GATES, precision=native.PRECISION_BF16)
+    U, RH = Buf.alloc(1, 8, 10, ch, 'cpu'), Buf.alloc(1, 8, 10, ch, 'cpu')
+    gates([xb, hb], U, out2=RH, aux0=hb)
+    pre = F.conv2d(torch.cat([_bf16(x), _bf16(h)], 1), _bf16(wg), padding=1) + bg.view(1, -1, 1, 1)
+    assert torch.allclose(U.to_nchw(), torch.sigmoid(pre[:, :ch]), rtol=2e-5, atol=2e-5)
+    assert torch.allclose(RH.to_nchw(), (1 - torch.sigmoid(pre[:, ch:])) * h, rtol=2e-5, atol=2e-5)
+    # Bottleneck tail: 3x3 32 -> 32 (+BN+ReLU) in bf16, chained 1x1 32 -> 64 (+BN+ReLU, + residual) in fp32 on chip
+    t1 = torch.randn(1, 32, 8, 10, generator=g)
+    w3 = torch.randn(32, 32, 3, 3, generator=g) / (32 * 9) ** 0.5
+    w1 = torch.randn(64, 32, 1, 1, generator=g) / 32 ** 0.5
+    res = torch.randn(1, 64, 8, 10, generator=g)
+    tail = ConvOp(sim, w3, identity_chan_map(32), (4, 0), torch.ones(32), torch.zeros(32), 'cpu', act=native.ACT_RELU,
+                  precision=native.PRECISION_BF16).chain_pointwise(w1, torch.ones(64), torch.zeros(64), native.ACT_RELU)
+    out = Buf.alloc(1, 8, 10, 64, 'cpu')
+    tail([_to_buf(t1)], out, res=_to_buf(res))
+    mid = F.relu(F.conv2d(_bf16(t1), _bf16(w3), padding=1))
+    want = F.relu(F.conv2d(mid, w1)) + res
+    assert torch.allclose(out.to_nchw(), want, rtol=3e-5, atol=3e-5), (out.to_nchw() - want).abs().max()

@@ -159,8 +159,9 @@ def bench_conv(lib, reps):
     for k, stride, cin, cout, n, H, W, residual in CONV_CASES:
         x = Buf(torch.randn(n, H, W, cin, device=DEV), n, H, W, cin)
         w = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
+        prec = native.PRECISION_BF16 if os.environ.get('CONV_PRECISION') == 'bf16' else native.PRECISION_F32
         op = ConvOp(lib, w, identity_chan_map(cin), (cin // 8, 0), torch.ones(cout), torch.zeros(cout), DEV, stride=stride,
-                    act=native.ACT_RELU)
+                    act=native.ACT_RELU, precision=prec)
         ho, wo = op.out_hw(H, W)
         out = Buf.alloc(n, ho, wo, cout, DEV)
         res = Buf(torch.randn(n, ho, wo, cout, device=DEV), n, ho, wo, cout) if residual else None
