@@ -20,8 +20,10 @@ def reference_available():
 
 
 def _install_shims():
+    """The stand-ins for the two networks come from `oracle/third_party.py`, a restatement written independently of the
+    product's (`fiery_amd/backbone.py`, `fiery_amd/modules.py`): checker and product do not share a definition."""
     import torch.nn as nn
-    from fiery_amd import backbone, modules
+    from oracle import third_party
 
     if 'pyquaternion' not in sys.modules:
         mod = types.ModuleType('pyquaternion')
@@ -40,15 +42,7 @@ def _install_shims():
         transforms.Normalize = Normalize
         models = types.ModuleType('torchvision.models')
         resnet = types.ModuleType('torchvision.models.resnet')
-
-        def resnet18(pretrained=False, zero_init_residual=False):
-            # fiery/models/decoder.py:10-17 only touches bn1, relu, layer1..3
-            holder = types.SimpleNamespace()
-            holder.bn1, holder.relu, holder.layer1, holder.layer2, holder.layer3 = \
-                _forwardable_resnet_stages(zero_init_residual)
-            return holder
-
-        resnet.resnet18 = resnet18
+        resnet.resnet18 = third_party.resnet18       # fiery/models/decoder.py:10-17 only touches bn1, relu, layer1..3
         models.resnet = resnet
         tv.transforms, tv.models = transforms, models
         sys.modules.update({'torchvision': tv, 'torchvision.transforms': transforms,
@@ -56,36 +50,8 @@ def _install_shims():
 
     if 'efficientnet_pytorch' not in sys.modules:
         eff = types.ModuleType('efficientnet_pytorch')
-        eff.EfficientNet = backbone.EfficientNet
+        eff.EfficientNet = third_party.EfficientNet
         sys.modules['efficientnet_pytorch'] = eff
-
-
-def _forwardable_resnet_stages(zero_init_residual):
-    """resnet18 bn1/relu/layer1-3 that can actually run (the product's holders carry weights only).
-
-    The BasicBlock arithmetic restated here is torchvision 0.8.1's published one:
-    relu(bn2(conv2(relu(bn1(conv1(x))))) + downsample(x)).
-    """
-    import torch.nn as nn
-    from fiery_amd import modules
-
-    class _Block(modules.BasicBlockWeights):
-        def forward(self, x):
-            identity = x if self.downsample is None else self.downsample(x)
-            out = self.relu(self.bn1(self.conv1(x)))
-            out = self.bn2(self.conv2(out))
-            return self.relu(out + identity)
-
-    bn1, relu, l1, l2, l3 = modules.resnet18_stages(zero_init_residual)
-    rebuilt = []
-    for layer in (l1, l2, l3):
-        blocks = []
-        for blk in layer:
-            new = _Block(blk.conv1.in_channels, blk.conv1.out_channels, blk.stride)
-            new.load_state_dict(blk.state_dict())
-            blocks.append(new)
-        rebuilt.append(nn.Sequential(*blocks))
-    return bn1, relu, rebuilt[0], rebuilt[1], rebuilt[2]
 
 
 _REF = None
