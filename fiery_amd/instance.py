@@ -84,10 +84,14 @@ def make_instance_id_temporally_consistent(pred_inst, future_flow, matching_thre
         old_ids = cols[good] + 1
         lut = torch.zeros(n_next + 1, dtype=torch.long, device=device)
         lut[torch.as_tensor(old_ids, dtype=torch.long, device=device)] = torch.as_tensor(new_ids, dtype=torch.long, device=device)
-        present = torch.nonzero(nxt_counts[1:] > 0).flatten().cpu().numpy() + 1
-        for rid in sorted(set(present.tolist()) - set(old_ids.tolist())):       # new instances: fresh ids
+        # new instances get fresh ids in the order the reference visits them: it iterates a Python set of numpy integers
+        # built exactly like this one (instance.py:256-262) - a set's order is not ascending in general, and the ids
+        # handed out follow it, so the same set is built the same way here
+        remaining = set(torch.unique(nxt).cpu().numpy()).difference(set(old_ids))
+        remaining.remove(0)
+        for rid in list(remaining):
             largest += 1
-            lut[rid] = largest
+            lut[int(rid)] = largest
         frames.append(lut[nxt])
     return torch.stack(frames).unsqueeze(0)
 
@@ -96,8 +100,6 @@ def predict_instance_segmentation_and_trajectories(output, compute_matched_cente
                                                    lib=None):
     """The reference's post-processing entry point (fiery/utils/instance.py:272-330, called from evaluate.py:62): model
     outputs -> (B, T, H, W) instance ids, consistent through time.  All B*T frames are segmented by one HIP launch."""
-    if compute_matched_centers:
-        raise NotImplementedError('matched centres (the visualisation branch, instance.py:308-328) are not built')
     seg = output['segmentation'].detach()
     b, t = seg.shape[:2]
     h, w = seg.shape[-2:]
@@ -106,9 +108,35 @@ def predict_instance_segmentation_and_trajectories(output, compute_matched_cente
                                              output['instance_offset'].detach().reshape(b * t, 2, h, w),
                                              foreground.reshape(b * t, h, w), lib=lib)
     pred_inst = ids.view(b, t, h, w)
-    if not make_consistent:
-        return pred_inst
-    flow = output.get('instance_flow')
-    if flow is None:
-        flow = torch.zeros_like(output['instance_offset'])
-    return torch.cat([make_instance_id_temporally_consistent(pred_inst[i:i + 1], flow[i:i + 1].detach()) for i in range(b)], 0)
+    if make_consistent:
+        flow = output.get('instance_flow')
+        if flow is None:
+            flow = torch.zeros_like(output['instance_offset'])
+        consistent = torch.cat([make_instance_id_temporally_consistent(pred_inst[i:i + 1], flow[i:i + 1].detach())
+                                for i in range(b)], 0)
+    else:
+        consistent = pred_inst
+    if not compute_matched_centers:
+        return consistent
+    return consistent, matched_centers(consistent)
+
+
+def matched_centers(consistent_instance_seg):
+    """The visualiser's trajectories (fiery/utils/instance.py:308-328): for every instance present in the first frame,
+    the mean pixel position of its mask in every frame where it appears, as an (n_frames_present, 2) numpy array in (x, y)
+    order.  One scatter-add per frame instead of a loop over instances x frames."""
+    assert consistent_instance_seg.shape[0] == 1
+    seg = consistent_instance_seg[0].long()
+    t_len, h, w = seg.shape
+    device = seg.device
+    yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float, device=device), torch.arange(w, dtype=torch.float, device=device),
+                            indexing='ij')
+    grid = torch.stack((yy, xx))
+    n_ids = int(seg.max().item()) + 1
+    per_frame = [_instance_means(seg[t], grid, n_ids) for t in range(t_len)]
+    centers = {}
+    for instance_id in torch.unique(seg[0])[1:].cpu().numpy():
+        rows = [means[int(instance_id)].float() for means, counts in per_frame if counts[int(instance_id)] > 0]
+        if rows:
+            centers[instance_id] = torch.stack(rows).cpu().numpy()[:, ::-1]
+    return centers

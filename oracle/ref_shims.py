@@ -48,6 +48,60 @@ def _install_shims():
         sys.modules.update({'torchvision': tv, 'torchvision.transforms': transforms,
                             'torchvision.models': models, 'torchvision.models.resnet': resnet})
 
+    if 'pytorch_lightning' not in sys.modules:
+        # fiery/metrics.py:4-6 needs the Metric base class (state registration only) and two small functions; their
+        # semantics are pytorch-lightning 1.1's documented ones: per-class tp / fp / tn / fn / support of class-index
+        # maps, and a none / mean / sum reduction
+        import torch
+        pl = types.ModuleType('pytorch_lightning')
+        metrics = types.ModuleType('pytorch_lightning.metrics')
+        metric_mod = types.ModuleType('pytorch_lightning.metrics.metric')
+        functional = types.ModuleType('pytorch_lightning.metrics.functional')
+        classification = types.ModuleType('pytorch_lightning.metrics.functional.classification')
+        reduction_mod = types.ModuleType('pytorch_lightning.metrics.functional.reduction')
+
+        class Metric(nn.Module):
+            def __init__(self, compute_on_step=False):
+                super().__init__()
+                self._defaults = {}
+
+            def add_state(self, name, default, dist_reduce_fx=None):
+                self._defaults[name] = default.clone()
+                setattr(self, name, default.clone())
+
+            def forward(self, *args):
+                self.update(*args)
+
+            def reset(self):
+                for name, default in self._defaults.items():
+                    setattr(self, name, default.clone())
+
+        def stat_scores_multiple_classes(pred, target, num_classes):
+            pred, target = pred.reshape(-1), target.reshape(-1)
+            tps = torch.stack([((pred == c) & (target == c)).sum() for c in range(num_classes)]).float()
+            fps = torch.stack([((pred == c) & (target != c)).sum() for c in range(num_classes)]).float()
+            tns = torch.stack([((pred != c) & (target != c)).sum() for c in range(num_classes)]).float()
+            fns = torch.stack([((pred != c) & (target == c)).sum() for c in range(num_classes)]).float()
+            sups = torch.stack([(target == c).sum() for c in range(num_classes)]).float()
+            return tps, fps, tns, fns, sups
+
+        def reduce(to_reduce, reduction):
+            if reduction == 'elementwise_mean':
+                return torch.mean(to_reduce)
+            if reduction == 'none':
+                return to_reduce
+            if reduction == 'sum':
+                return torch.sum(to_reduce)
+            raise ValueError('Reduction parameter unknown.')
+
+        metric_mod.Metric = Metric
+        classification.stat_scores_multiple_classes = stat_scores_multiple_classes
+        reduction_mod.reduce = reduce
+        sys.modules.update({'pytorch_lightning': pl, 'pytorch_lightning.metrics': metrics,
+                            'pytorch_lightning.metrics.metric': metric_mod, 'pytorch_lightning.metrics.functional': functional,
+                            'pytorch_lightning.metrics.functional.classification': classification,
+                            'pytorch_lightning.metrics.functional.reduction': reduction_mod})
+
     if 'efficientnet_pytorch' not in sys.modules:
         eff = types.ModuleType('efficientnet_pytorch')
         eff.EfficientNet = third_party.EfficientNet
@@ -79,6 +133,7 @@ def load_reference():
     ns.decoder = importlib.import_module('fiery.models.decoder')
     ns.encoder = importlib.import_module('fiery.models.encoder')
     ns.instance = importlib.import_module('fiery.utils.instance')
+    ns.metrics = importlib.import_module('fiery.metrics')
     ns.fiery_model = importlib.import_module('fiery.models.fiery')
     ns.Fiery = ns.fiery_model.Fiery
     _REF = ns

@@ -169,3 +169,76 @@ def test_instance_trajectories_equal_the_reference(ref, sim, seed):
     want = ref.instance.predict_instance_segmentation_and_trajectories({k: (None if v is None else v.clone()) for k, v in no_flow.items()})
     got = hip_instance.predict_instance_segmentation_and_trajectories(dict(no_flow), lib=sim)
     assert torch.equal(got, want)
+
+
+# ---- the step after the path, continued: metrics and the visualiser's trajectories ------------------------------------
+def test_matched_centers_equal_the_reference(ref, sim):
+    """`compute_matched_centers=True` (fiery/utils/instance.py:308-328; batch 1): same instances, same trajectories."""
+    from fiery_amd import instance as hip_instance
+    out = {k: v[:1] for k, v in _video_case(3, B=1, T=4).items()}
+    want_seg, want = ref.instance.predict_instance_segmentation_and_trajectories({k: v.clone() for k, v in out.items()},
+                                                                                  compute_matched_centers=True)
+    got_seg, got = hip_instance.predict_instance_segmentation_and_trajectories(out, compute_matched_centers=True, lib=sim)
+    assert torch.equal(got_seg, want_seg)
+    assert sorted(got) == sorted(want) and len(want) >= 4
+    for key in want:
+        assert got[key].shape == want[key].shape
+        assert np.allclose(got[key], want[key], rtol=0, atol=1e-4), key
+
+
+def _instance_video(seed, B=2, T=4, H=40, W=48, n_obj=7, drift=True):
+    """Ground-truth-like and prediction-like instance id videos: blobs that move; the prediction loses one object, invents
+    one, swaps an id halfway through (a temporal inconsistency) and is a little smaller than the truth."""
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float), torch.arange(W, dtype=torch.float), indexing='ij')
+    gt = torch.zeros(B, T, H, W, dtype=torch.long)
+    pred = torch.zeros(B, T, H, W, dtype=torch.long)
+    for b in range(B):
+        pos = torch.stack([torch.rand(n_obj, generator=g) * (H - 10) + 5, torch.rand(n_obj, generator=g) * (W - 10) + 5], 1)
+        vel = torch.randn(n_obj, 2, generator=g)
+        for t in range(T):
+            p = pos + vel * t
+            for k in range(n_obj):
+                d2 = (yy - p[k, 0]) ** 2 + (xx - p[k, 1]) ** 2
+                gt[b, t][d2 < 12] = k + 1
+                if k == 0:
+                    continue                                          # never detected
+                pid = k + 1
+                if drift and k == 2 and t >= 2:
+                    pid = n_obj + 5                                    # its id changes: not temporally consistent
+                pred[b, t][d2 < (9 if k % 2 else 12)] = pid
+            pred[b, t][(yy - 3) ** 2 + (xx - 3) ** 2 < 6] = n_obj + 9  # a false alarm
+    return pred, gt
+
+
+@pytest.mark.parametrize('seed,consistent', [(0, True), (1, True), (2, False)])
+def test_panoptic_metric_equals_the_reference(ref, seed, consistent):
+    from fiery_amd.metrics import PanopticMetric
+    pred, gt = _instance_video(seed)
+    want_metric = ref.metrics.PanopticMetric(n_classes=2, temporally_consistent=consistent)
+    got_metric = PanopticMetric(n_classes=2, temporally_consistent=consistent)
+    for _ in range(2):                                                 # states accumulate over updates
+        want_metric(pred, gt)
+        got_metric(pred, gt)
+    want, got = want_metric.compute(), got_metric.compute()
+    assert set(want) == set(got)
+    for key in want:
+        assert torch.allclose(got[key], want[key], rtol=1e-6, atol=1e-6), (key, got[key], want[key])
+    assert want['pq'][1] > 0.1 and want_metric.false_positive[1] > 0 and want_metric.false_negative[1] > 0
+    got_metric.reset()
+    assert float(got_metric.iou.sum()) == 0.0
+
+
+@pytest.mark.parametrize('ignore_index,reduction', [(None, 'none'), (0, 'none'), (None, 'elementwise_mean')])
+def test_intersection_over_union_equals_the_reference(ref, ignore_index, reduction):
+    from fiery_amd.metrics import IntersectionOverUnion
+    g = torch.Generator().manual_seed(4)
+    n_classes = 4
+    want_metric = ref.metrics.IntersectionOverUnion(n_classes, ignore_index=ignore_index, absent_score=0.5, reduction=reduction)
+    got_metric = IntersectionOverUnion(n_classes, ignore_index=ignore_index, absent_score=0.5, reduction=reduction)
+    for _ in range(3):
+        target = torch.randint(0, 3, (2, 5, 1, 20, 24), generator=g)   # class 3 never occurs: the absent score applies
+        pred = torch.where(torch.rand(target.shape, generator=g) < 0.7, target, torch.randint(0, 3, target.shape, generator=g))
+        want_metric(pred, target)
+        got_metric(pred, target)
+    assert torch.allclose(got_metric.compute(), want_metric.compute(), rtol=1e-6, atol=1e-7)
