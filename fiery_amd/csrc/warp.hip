@@ -85,6 +85,67 @@ __global__ void k_warp_params(const float* __restrict__ ego, int B, int S, float
     }
 }
 
+// cumulative_warp_features_reverse (geometry.py:256-280): frame 0 is the reference frame; frame i is sampled with
+// inverse(flow[0]) @ ... @ inverse(flow[i-1]), the inverse of a pose matrix being [R^T | -R^T t] (geometry.py:160-178)
+__device__ void invert_pose(const float* m, float* out) {
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) out[i * 4 + j] = m[j * 4 + i];
+        float acc = 0.f;
+        for (int k = 0; k < 3; ++k) acc += m[k * 4 + i] * m[k * 4 + 3];
+        out[i * 4 + 3] = -acc;
+    }
+    out[12] = out[13] = out[14] = 0.f;
+    out[15] = 1.f;
+}
+
+__global__ void k_warp_params_reverse(const float* __restrict__ ego, int B, int S, float ext_x, float ext_y,
+                                      float* __restrict__ theta) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float* th = theta + static_cast<long long>(b) * S * 6;
+    th[0] = 1.f; th[1] = 0.f; th[2] = 0.f; th[3] = 0.f; th[4] = 1.f; th[5] = 0.f;      // frame 0 is never resampled
+    float cum[16], step[16], inv[16], next[16];
+    for (int i = 1; i < S; ++i) {
+        pose_to_mat(ego + (static_cast<long long>(b) * S + (i - 1)) * 6, step);
+        invert_pose(step, inv);
+        if (i == 1) {
+            for (int k = 0; k < 16; ++k) cum[k] = inv[k];
+        } else {
+            mat4_mul(cum, inv, next);
+            for (int k = 0; k < 16; ++k) cum[k] = next[k];
+        }
+        const float rz = atan2f(-cum[1], cum[0]);
+        const float c = cosf(rz), s = sinf(rz);
+        float* o = th + i * 6;
+        o[0] = c;  o[1] = -s;  o[2] = cum[7] / ext_y;
+        o[3] = s;  o[4] = c;   o[5] = -(cum[3] / ext_x);
+    }
+}
+
+// grid_sample(mode='nearest', padding_mode='zeros', align_corners=False) of channel planes: labels stay NCHW.
+// One thread per output pixel walks the channels (1 .. 6 for the label tensors of trainer.py:133-191).
+__global__ __launch_bounds__(256) void k_bev_warp_nearest(const float* __restrict__ in, const float* __restrict__ theta,
+                                                          int C, int H, int W, float* __restrict__ out, long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int x = static_cast<int>(i % W);
+    const int y = static_cast<int>((i / W) % H);
+    const int img = static_cast<int>(i / (static_cast<long long>(W) * H));
+    const float* th = theta + img * 6;
+    const float xn = (2.0f * x + 1.0f) / W - 1.0f;
+    const float yn = (2.0f * y + 1.0f) / H - 1.0f;
+    const float gx = th[0] * xn + th[1] * yn + th[2];
+    const float gy = th[3] * xn + th[4] * yn + th[5];
+    // nearest: the un-normalised coordinate rounded half to even (ATen uses nearbyint)
+    const float fx = nearbyintf(((gx + 1.0f) * W - 1.0f) * 0.5f);
+    const float fy = nearbyintf(((gy + 1.0f) * H - 1.0f) * 0.5f);
+    const bool inside = fx >= 0.f && fx < static_cast<float>(W) && fy >= 0.f && fy < static_cast<float>(H);
+    const long long plane = static_cast<long long>(H) * W;
+    const float* src = in + static_cast<long long>(img) * C * plane + (inside ? static_cast<long long>(fy) * W + static_cast<long long>(fx) : 0);
+    float* dst = out + static_cast<long long>(img) * C * plane + static_cast<long long>(y) * W + x;
+    for (int c = 0; c < C; ++c) dst[c * plane] = inside ? src[c * plane] : 0.f;
+}
+
 constexpr int kWarpTile = 64;   // pixels per workgroup (one row segment)
 constexpr int kMaxWarpImages = 256;
 
@@ -188,4 +249,23 @@ extern "C" int fiery_bev_warp_nchw_to_nhwc(const float* in, const float* theta, 
         if (rc) return rc;
     }
     return FIERY_OK;
+}
+
+extern "C" int fiery_warp_params_reverse(const float* future_egomotion, int B, int S, float extent_x, float extent_y,
+                                         float* theta, fiery_stream_t stream) {
+    FIERY_REQUIRE(future_egomotion && theta && B > 0 && S > 0, "warp_params_reverse: bad argument");
+    FIERY_REQUIRE(extent_x != 0.f && extent_y != 0.f, "warp_params_reverse: zero spatial extent");
+    hipLaunchKernelGGL(k_warp_params_reverse, dim3(ceil_div(B, 64)), dim3(64), 0, as_stream(stream), future_egomotion, B, S,
+                       extent_x, extent_y, theta);
+    return check_launch("warp_params_reverse");
+}
+
+extern "C" int fiery_bev_warp_nearest_nchw(const float* in, const float* theta, int n_img, int C, int H, int W, float* out,
+                                           fiery_stream_t stream) {
+    FIERY_REQUIRE(in && theta && out && in != out, "bev_warp_nearest: null pointer or in-place call");
+    FIERY_REQUIRE(n_img > 0 && C > 0 && H > 0 && W > 0, "bev_warp_nearest: bad shape");
+    const long long total = static_cast<long long>(n_img) * H * W;
+    hipLaunchKernelGGL(k_bev_warp_nearest, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), in, theta, C, H, W, out,
+                       total);
+    return check_launch("bev_warp_nearest");
 }

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libfiery_hip.so')
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -108,6 +108,8 @@ _SIGNATURES = {
     'fiery_depth_softmax': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'fiery_depth_softmax_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'fiery_warp_params': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fiery_warp_params_reverse': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    'fiery_bev_warp_nearest_nchw': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'fiery_bev_warp_nchw_to_nhwc': (C.c_int, [C.c_void_p, C.c_void_p, c_uint8_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                               C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     'fiery_conv_packed_floats': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
@@ -270,6 +272,20 @@ class Lib:
         self.check(self.dll.fiery_warp_params(_ptr(future_egomotion), b, s, float(extent[0]), float(extent[1]),
                                               _ptr(theta), _ptr(ego_shifted), _stream_of(theta)))
         return theta
+
+    def warp_params_reverse(self, future_egomotion, extent):
+        b, s, _ = future_egomotion.shape
+        theta = torch.empty(b, s, 6, dtype=torch.float32, device=future_egomotion.device)
+        self.check(self.dll.fiery_warp_params_reverse(_ptr(future_egomotion), b, s, float(extent[0]), float(extent[1]),
+                                                      _ptr(theta), _stream_of(theta)))
+        return theta
+
+    def bev_warp_nearest(self, x, theta):
+        """x (n, C, H, W) f32 contiguous, theta (n, 6) -> the nearest-neighbour resampling (n, C, H, W)."""
+        n, c, h, w = x.shape
+        out = torch.empty_like(x)
+        self.check(self.dll.fiery_bev_warp_nearest_nchw(_ptr(x), _ptr(theta), n, c, h, w, _ptr(out), _stream_of(out)))
+        return out
 
     def bev_warp_nchw_to_nhwc(self, x, theta, identity, out, out_ld, out_img_stride):
         n, c, h, w = x.shape

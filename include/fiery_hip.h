@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FIERY_ABI_VERSION 7
+#define FIERY_ABI_VERSION 8
 
 #define FIERY_OK 0
 #define FIERY_EINVAL (-22)      /* bad argument (shape, alignment, null pointer) */
@@ -160,6 +160,18 @@ int fiery_depth_softmax_bwd(const float* prob, const float* grad_prob, int n, in
  * (fiery.py:152-154: `cat([zeros_like(ego[:, :1]), ego[:, :-1]])`), written by the same launch. */
 int fiery_warp_params(const float* future_egomotion, int B, int S, float extent_x, float extent_y,
                       float* theta, float* ego_shifted /* [B][S][6] or NULL */, fiery_stream_t stream);
+
+/* Label warping of the training side (fiery/trainer.py:133-191 -> `cumulative_warp_features_reverse`,
+ * fiery/utils/geometry.py:256-280): theta[b][0] = identity, theta[b][i] = the sampling transform of
+ * inverse(flow[0]) @ ... @ inverse(flow[i-1]), same six numbers per frame as fiery_warp_params. */
+int fiery_warp_params_reverse(const float* future_egomotion, int B, int S, float extent_x, float extent_y,
+                              float* theta, fiery_stream_t stream);
+
+/* out[img][c][y][x] = in[img][c][nearest source pixel of (y, x) under theta[img]] or 0 outside the map:
+ * grid_sample(mode='nearest', padding_mode='zeros', align_corners=False) on channel planes (the label tensors are
+ * NCHW with 1 .. 6 channels).  in and out [n_img][C][H][W], theta [n_img][6]; not in place. */
+int fiery_bev_warp_nearest_nchw(const float* in, const float* theta, int n_img, int C, int H, int W, float* out,
+                                fiery_stream_t stream);
 
 /* Bilinear grid-sample with zero padding, align_corners=False (geometry.py:219-220), reading NCHW
  * [n_img][C][H][W] and writing NHWC (ld, img_stride as given).  Images whose `identity[i]` (host

@@ -120,6 +120,36 @@ def cumulative_warp_features(x, flow, mode, spatial_extent):
     return torch.stack(out[::-1], 1)
 
 
+def invert_pose_matrix(x):
+    """[B, 4, 4] pose matrices -> their inverses [R^T | -R^T t] (fiery/utils/geometry.py:160-178)."""
+    rt = x[:, :3, :3].transpose(1, 2)
+    inv = torch.cat([rt, -torch.bmm(rt, x[:, :3, 3:])], dim=-1)
+    inv = F.pad(inv, [0, 0, 0, 1], value=0)
+    inv[..., 3, 3] = 1.0
+    return inv
+
+
+def cumulative_warp_features_reverse(x, flow, mode, spatial_extent):
+    """fiery/utils/geometry.py:256-280: frame 0 unchanged, frame i warped by inverse(flow[0]) @ ... @ inverse(flow[i-1])."""
+    mats = pose_to_matrix(flow)
+    out = [x[:, 0]]
+    cum = None
+    for i in range(1, x.shape[1]):
+        cum = invert_pose_matrix(mats[:, 0]) if i == 1 else cum @ invert_pose_matrix(mats[:, i - 1])
+        out.append(warp_features(x[:, i], matrix_to_pose(cum), mode, spatial_extent))
+    return torch.stack(out, 1)
+
+
+def cumulative_warp_reverse_thetas(flow, spatial_extent):
+    """The sampling transforms of frames 1 .. S-1 of `cumulative_warp_features_reverse`."""
+    mats = pose_to_matrix(flow)
+    thetas, cum = [], None
+    for i in range(1, flow.shape[1]):
+        cum = invert_pose_matrix(mats[:, 0]) if i == 1 else cum @ invert_pose_matrix(mats[:, i - 1])
+        thetas.append(warp_affine_params(matrix_to_pose(cum), spatial_extent))
+    return thetas
+
+
 # ---------------------------------------------------------------------------------------------
 # building blocks.  reference: fiery/layers/convolutions.py, fiery/layers/temporal.py
 # ---------------------------------------------------------------------------------------------

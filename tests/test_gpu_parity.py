@@ -685,6 +685,33 @@ def test_per_sample_streams_give_the_batched_result(hip):
                 assert (replay[k] - v).abs().max().item() <= 1e-5 * max(1.0, v.abs().max().item()), k
 
 
+def test_label_warping_full_size_vs_oracle(hip):
+    """`prepare_future_labels`' kernels at 200 x 200: the reverse cumulative transforms and the nearest-neighbour resampling
+    of an instance-id video against the oracle (bitwise the reference's on the CPU)."""
+    from fiery_amd import labels as hip_labels
+    g = torch.Generator().manual_seed(41)
+    B, S, H, W = 2, 5, 200, 200
+    inst = torch.zeros(B, S, 1, H, W)
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float), torch.arange(W, dtype=torch.float), indexing='ij')
+    for b in range(B):
+        for k in range(30):
+            cy, cx = torch.rand(2, generator=g) * 180 + 10
+            for t in range(S):
+                inst[b, t, 0][((yy - cy - 1.5 * t) ** 2 + (xx - cx) ** 2) < 30] = k + 1
+    ego = torch.zeros(B, S, 6)
+    ego[..., 0] = 2.5 + 0.5 * torch.rand(B, S, generator=g)
+    ego[..., 5] = 0.02 * torch.randn(B, S, generator=g)
+    extent = (50.0, 50.0)
+    want = bev_stack.cumulative_warp_features_reverse(inst, ego, 'nearest', extent)
+    got = hip_labels.cumulative_warp_features_reverse(inst.to(DEV), ego.to(DEV), 'nearest', extent).cpu()
+    assert torch.equal(got[:, 0], inst[:, 0])
+    mismatch = (got != want).float().mean().item()
+    parity_report.record('label warp 200x200 (nearest)', 'fraction of differing pixels', mismatch, 1.0, bound=1e-3,
+                         note='id maps: a pixel differs when its sampling position rounds across a pixel boundary')
+    assert mismatch < 1e-3
+    assert (want[:, 1:] != inst[:, 1:]).float().mean() > 0.01
+
+
 def test_frame_sharded_layout_through_rccl_on_one_gpu(hip):
     """BASELINE.json configs[2] on the one GPU there is: `sharded_bev_forward(layout='frames')` with a 1-rank RCCL process
     group - frames pooled into the preallocated exchange buffer, `all_gather_into_tensor` over the nccl (= RCCL) backend,

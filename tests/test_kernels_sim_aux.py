@@ -309,3 +309,28 @@ def test_instance_segmentation_batched_frames_and_empty_frame(sim):
     assert int(count[1]) == 0 and seg[1].abs().sum() == 0
     with pytest.raises(ValueError):
         hip_instance.instance_segmentation_frames(center, offset, fg, nms_kernel_size=5, lib=sim)
+
+
+def test_reverse_warp_params_and_nearest_warp_match_the_oracle(sim):
+    """`fiery_warp_params_reverse` + `fiery_bev_warp_nearest_nchw` (label warping, trainer.py:133-191) against the oracle's
+    `cumulative_warp_features_reverse` (bitwise equal to the reference's, tests/test_oracle_vs_reference.py)."""
+    g = torch.Generator().manual_seed(8)
+    B, S, C, H, W = 2, 5, 3, 20, 28
+    x = torch.randn(B, S, C, H, W, generator=g)
+    ego = torch.zeros(B, S, 6)
+    ego[..., 0] = 0.8 + 0.4 * torch.rand(B, S, generator=g)
+    ego[..., 1] = 0.2 * torch.randn(B, S, generator=g)
+    ego[..., 5] = 0.05 * torch.randn(B, S, generator=g)
+    ego[..., 3:5] = 0.01 * torch.randn(B, S, 2, generator=g)
+    extent = (7.0, 10.0)
+    theta = sim.warp_params_reverse(ego, extent)
+    want_theta = bev_stack.cumulative_warp_reverse_thetas(ego, extent)
+    assert torch.equal(theta[:, 0], torch.tensor([1.0, 0, 0, 0, 1, 0]).expand(B, 6))
+    for i in range(1, S):
+        assert torch.allclose(theta[:, i].view(B, 2, 3), want_theta[i - 1], **TOL)
+    got = sim.bev_warp_nearest(x.view(B * S, C, H, W).contiguous(), theta.view(B * S, 6)).view(B, S, C, H, W)
+    want = bev_stack.cumulative_warp_features_reverse(x, ego, 'nearest', extent)
+    assert torch.equal(got[:, 0], x[:, 0])
+    mismatch = (got != want).any(dim=2).float().mean().item()          # pixels whose nearest source differs (boundary ties)
+    assert mismatch < 5e-3, mismatch
+    assert (want[:, 1:] == 0).float().mean() > 0.01                    # some of the map leaves the grid: zeros padding
