@@ -1,0 +1,128 @@
+// Weight gradient of the implicit-GEMM convolution (training).
+//
+// Replaces what autograd runs for `conv2d`'s weight in the reference's BEV stack (cuDNN / MIOpen wgrad behind
+// fiery/layers/convolutions.py:9-168, fiery/layers/temporal.py:10-62, fiery/models/decoder.py:53-91):
+//   dW[cout][tap][c] = sum over output pixels p of  dY[p][cout] * X[p * stride + tap - pad][c]
+// - a GEMM whose reduction dimension is the PIXELS (120,000 per GRU layer) and whose result is small (cout x taps x cin).
+// Mapping to CDNA4: v_mfma_f32_32x32x2_f32 with k = two neighbouring output pixels of a row; a workgroup owns a
+// (64 couts) x (one tap, 64 input channels) block of dW and a share of the output rows, its four wavefronts take rows
+// round-robin, add their accumulators up through LDS and hand the block to HBM with fp32 atomics (the caller zeroes dW;
+// the order of those additions moves the last bits from run to run).  Both operands are read pixel-major (NHWC) straight
+// from global memory: a lane's two couts (or channels) of a pixel are 128 bytes apart in the same row, so a wavefront load
+// is two full 128-byte lines per pixel - no staging needed for a kernel that is far from the critical path of a training
+// step (the data gradient reuses the forward kernel with transposed, mirrored weights: fiery_amd/train_graph.py).
+#include "common.h"
+
+namespace fiery {
+namespace {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+struct WgradP {
+    const float* x;
+    const float* g;
+    float* dw;
+    long long x_istride, g_istride;
+    int x_ld, g_ld, cin_pad, cout;
+    int n_img, Hin, Win, Hout, Wout, kH, kW, stride, padH, padW;
+    int c_tiles;            // 64-channel tiles per tap
+};
+
+// grid (cout tiles of 64, taps * c_tiles, row shares); 256 threads
+__global__ __launch_bounds__(256) void k_conv_wgrad(WgradP p) {
+    __shared__ float red[4][64 * 64 / 4];                   // one quarter of the 64 x 64 block per pass, four wavefronts
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 31, kk = lane >> 5;
+    const int co0 = blockIdx.x * 64;
+    const int tap = blockIdx.y / p.c_tiles, c0 = (blockIdx.y - tap * p.c_tiles) * 64;
+    const int dy = tap / p.kW, dx = tap - dy * p.kW;
+    const int n_rows = p.n_img * p.Hout;
+    v16f acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const bool co_ok[2] = {co0 + m < p.cout, co0 + 32 + m < p.cout};
+    const bool c_ok[2] = {c0 + m < p.cin_pad, c0 + 32 + m < p.cin_pad};
+    // output rows (image, y) of this workgroup's share, dealt to its wavefronts
+    for (int row = blockIdx.z * 4 + wave; row < n_rows; row += gridDim.z * 4) {
+        const int img = row / p.Hout, y = row - img * p.Hout;
+        const int iy = y * p.stride + dy - p.padH;
+        if (iy < 0 || iy >= p.Hin) continue;                // the tap looks at the zero padding: nothing to add
+        const float* grow = p.g + img * p.g_istride + static_cast<long long>(y) * p.Wout * p.g_ld + co0 + m;
+        const float* xrow = p.x + img * p.x_istride + static_cast<long long>(iy) * p.Win * p.x_ld + c0 + m;
+        for (int x0 = 0; x0 < p.Wout; x0 += 2) {
+            const int x = x0 + kk;                          // this lane's pixel of the pair
+            const int ix = x * p.stride + dx - p.padW;
+            const bool px_ok = x < p.Wout;
+            const bool in_ok = px_ok && ix >= 0 && ix < p.Win;
+            float a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = (px_ok && co_ok[t]) ? grow[static_cast<long long>(x) * p.g_ld + 32 * t] : 0.f;
+                b[t] = (in_ok && c_ok[t]) ? xrow[static_cast<long long>(ix) * p.x_ld + 32 * t] : 0.f;
+            }
+#pragma unroll
+            for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+        }
+    }
+    // the four wavefronts' blocks -> one, a 32 x 32 quarter at a time; then one atomic per element and workgroup
+    const int taps = p.kH * p.kW;
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rowm = (r & 3) + 8 * (r >> 2) + 4 * kk;
+                red[wave][rowm * 32 + m] = acc[ta][tb][r];
+            }
+            __syncthreads();
+            for (int e = threadIdx.x; e < 32 * 32; e += 256) {
+                const int rowm = e >> 5, col = e & 31;
+                const int co = co0 + 32 * ta + rowm, c = c0 + 32 * tb + col;
+                if (co < p.cout && c < p.cin_pad) {
+                    const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+                    if (v != 0.f) atomicAdd(&p.dw[(static_cast<long long>(co) * taps + tap) * p.cin_pad + c], v);
+                }
+            }
+        }
+}
+
+}  // namespace
+}  // namespace fiery
+
+using namespace fiery;
+
+extern "C" int fiery_conv_wgrad(const float* in, int in_ld, int64_t in_img_stride, int cin_units, const float* grad_out,
+                                int g_ld, int64_t g_img_stride, int cout, int n_img, int Hin, int Win, int Hout, int Wout, int kH,
+                                int kW, int stride, int padH, int padW, float* dw, fiery_stream_t stream) {
+    FIERY_REQUIRE(in && grad_out && dw, "conv_wgrad: null pointer");
+    FIERY_REQUIRE(cin_units > 0 && cout > 0 && n_img > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "conv_wgrad: bad shape");
+    FIERY_REQUIRE(kH >= 1 && kW >= 1 && stride >= 1 && padH >= 0 && padW >= 0, "conv_wgrad: bad kernel geometry");
+    FIERY_REQUIRE(in_ld >= cin_units * 8 && g_ld >= cout, "conv_wgrad: leading dimension smaller than the channel count");
+    FIERY_REQUIRE((Hin + 2 * padH - kH) / stride + 1 == Hout && (Win + 2 * padW - kW) / stride + 1 == Wout,
+                  "conv_wgrad: output size does not belong to this convolution");
+    WgradP p;
+    p.x = in;  p.g = grad_out;  p.dw = dw;
+    p.x_istride = in_img_stride > 0 ? in_img_stride : static_cast<long long>(Hin) * Win * in_ld;
+    p.g_istride = g_img_stride > 0 ? g_img_stride : static_cast<long long>(Hout) * Wout * g_ld;
+    p.x_ld = in_ld;  p.g_ld = g_ld;  p.cin_pad = cin_units * 8;  p.cout = cout;
+    p.n_img = n_img;  p.Hin = Hin;  p.Win = Win;  p.Hout = Hout;  p.Wout = Wout;
+    p.kH = kH;  p.kW = kW;  p.stride = stride;  p.padH = padH;  p.padW = padW;
+    p.c_tiles = ceil_div(p.cin_pad, 64);
+    const int n_rows = n_img * Hout;
+    // enough row shares to fill the chip (256 CUs x a few workgroups) without leaving a share fewer than four rows
+    const int blocks_xy = ceil_div(cout, 64) * kH * kW * p.c_tiles;
+    int shares = ceil_div(2048, blocks_xy);
+    if (shares > ceil_div(n_rows, 4)) shares = ceil_div(n_rows, 4);
+    if (shares < 1) shares = 1;
+    FIERY_REQUIRE(static_cast<long long>(kH) * kW * p.c_tiles < 65536 && shares < 65536, "conv_wgrad: grid too large");
+    hipLaunchKernelGGL(k_conv_wgrad, dim3(ceil_div(cout, 64), kH * kW * p.c_tiles, shares), dim3(256), 0, as_stream(stream), p);
+    return check_launch("conv_wgrad");
+}

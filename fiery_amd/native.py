@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libfiery_hip.so')
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -117,6 +117,8 @@ _SIGNATURES = {
     'fiery_conv_fwd': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     'fiery_conv_pack_weights_bf16': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_int32_p, C.c_int, C.c_void_p, C.c_void_p]),
     'fiery_conv_precision_used': (C.c_int, [C.POINTER(ConvDesc)]),
+    'fiery_conv_wgrad': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int64] + [C.c_int] * 11 +
+                         [C.c_void_p, C.c_void_p]),
     'fiery_heads_1x1_nchw': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        c_int32_p, c_uint8_p, C.c_void_p, C.c_void_p]),
     'fiery_spatial_mean': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
@@ -315,6 +317,18 @@ class Lib:
         if rc < 0:
             self.check(rc)
         return rc
+
+    def conv_wgrad(self, x, grad_out, cout, k, stride, pad):
+        """x: pixel-major (n, Hin, Win, cin_pad) f32 (cin_pad a multiple of 8), grad_out: (n, Hout, Wout, >= cout) f32, both
+        with contiguous rows -> dw (cout, k*k, cin_pad) f32."""
+        n, hin, win, cin_pad = x.shape
+        _, hout, wout, g_ld = grad_out.shape
+        assert cin_pad % 8 == 0 and x.stride(3) == 1 and grad_out.stride(3) == 1
+        dw = torch.zeros(cout, k * k, cin_pad, dtype=torch.float32, device=x.device)
+        self.check(self.dll.fiery_conv_wgrad(_ptr(x), x.stride(2), x.stride(0), cin_pad // 8, _ptr(grad_out), grad_out.stride(2),
+                                             grad_out.stride(0), cout, n, hin, win, hout, wout, k, k, stride, pad, pad, _ptr(dw),
+                                             _stream_of(dw)))
+        return dw
 
     def conv_fwd(self, desc, stream_tensor):
         self.check(self.dll.fiery_conv_fwd(C.byref(desc), _stream_of(stream_tensor)))

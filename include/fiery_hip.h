@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FIERY_ABI_VERSION 8
+#define FIERY_ABI_VERSION 9
 
 #define FIERY_OK 0
 #define FIERY_EINVAL (-22)      /* bad argument (shape, alignment, null pointer) */
@@ -307,6 +307,18 @@ int fiery_conv_pack_weights_bf16(const float* w, int cout, int cin_total, int ta
                                  void* packed, fiery_stream_t stream);
 
 int fiery_conv_fwd(const fiery_conv_desc* desc /* host */, fiery_stream_t stream);
+
+/* Weight gradient of a 2-D convolution of this library (training: what autograd computes for `conv2d`'s weight in
+ * fiery/layers/convolutions.py:9-168, layers/temporal.py:10-62, models/decoder.py:53-91):
+ *   dw[cout][tap][c] += sum over output pixels p of grad_out[p][cout] * in[p * stride + tap - pad][c]
+ * in: pixel-major [n_img][Hin][Win] rows of in_ld floats, cin_units * 8 (padded) channels; grad_out: pixel-major
+ * [n_img][Hout][Wout] rows of g_ld floats; *_img_stride: floats between images (0 = contiguous).  dw is
+ * [cout][kH * kW][cin_units * 8] and must be ZERO on entry (partial sums arrive by fp32 atomics: the last bits depend on
+ * their order).  The data gradient needs no entry point of its own: it is fiery_conv_fwd with the weights transposed and
+ * mirrored (and the gradient zero-stuffed for stride 2), see fiery_amd/train_graph.py. */
+int fiery_conv_wgrad(const float* in, int in_ld, int64_t in_img_stride, int cin_units, const float* grad_out, int g_ld,
+                     int64_t g_img_stride, int cout, int n_img, int Hin, int Win, int Hout, int Wout, int kH, int kW,
+                     int stride, int padH, int padW, float* dw, fiery_stream_t stream);
 
 /* FIERY_PRECISION_F32 or FIERY_PRECISION_BF16: the matrix-core form fiery_conv_fwd runs this descriptor in (negative:
  * an error code - the descriptor is invalid). */

@@ -437,3 +437,24 @@ def test_gru_epilogues_and_chained_tail_on_the_bf16_form(sim):
     mid = F.relu(F.conv2d(_bf16(t1), _bf16(w3), padding=1))
     want = F.relu(F.conv2d(mid, w1)) + res
     assert torch.allclose(out.to_nchw(), want, rtol=3e-5, atol=3e-5), (out.to_nchw() - want).abs().max()
+
+
+# ---- training: weight gradient ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('cin,cout,k,stride,hw', [(16, 32, 3, 1, (9, 14)), (24, 70, 1, 1, (6, 11)), (40, 64, 3, 2, (11, 9)),
+                                                   (8, 130, 7, 2, (12, 12))])
+def test_conv_wgrad_matches_autograd(sim, cin, cout, k, stride, hw):
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(2, cin, *hw, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g, requires_grad=True)
+    pad = (k - 1) // 2
+    y = F.conv2d(x, w, stride=stride, padding=pad)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    cin_pad = round_up(cin, 8)
+    xb = torch.zeros(2, hw[0], hw[1], cin_pad)
+    xb[..., :cin] = x.permute(0, 2, 3, 1)
+    gb = gy.permute(0, 2, 3, 1).contiguous()
+    dw = sim.conv_wgrad(xb, gb, cout, k, stride, pad)                      # (cout, taps, cin_pad)
+    got = dw[:, :, :cin].permute(0, 2, 1).reshape(cout, cin, k, k)
+    assert torch.allclose(got, w.grad, rtol=1e-4, atol=1e-4), (got - w.grad).abs().max()
+    assert dw[:, :, cin:].abs().max() == 0 if cin_pad > cin else True      # padded channels see zero inputs
