@@ -258,6 +258,41 @@ __global__ void k_upsample2x_add4(const float* __restrict__ in, int in_ld, int H
     *reinterpret_cast<float4*>(out + po * out_ld + c) = o;
 }
 
+// Gradient of the x2 bilinear interpolation above with respect to its input (training; the transpose of the operator):
+// input pixel (y, x) feeds output rows 2y-1, 2y, 2y+1, 2y+2 with weights 1/4, 3/4, 3/4, 1/4 - except at the borders, where
+// the clamped neighbour folds onto the pixel itself (output row 0 takes input row 0 whole, output row 2H-1 takes input row
+// H-1 whole) - and the same along x.  A gather: one thread = one input pixel x four channels, no atomics.
+__global__ void k_upsample2x_bwd4(const float* __restrict__ g, int g_ld, int H, int W, int C4, float* __restrict__ gx, int gx_ld,
+                                  long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = static_cast<int>(i % C4) * 4;
+    long long r = i / C4;
+    const int x = static_cast<int>(r % W);
+    r /= W;
+    const int y = static_cast<int>(r % H);
+    const int img = static_cast<int>(r / H);
+    const int Wo = 2 * W;
+    const float wy[4] = {y >= 1 ? 0.25f : 0.f, y == 0 ? 1.f : 0.75f, y == H - 1 ? 1.f : 0.75f, y <= H - 2 ? 0.25f : 0.f};
+    const float wx[4] = {x >= 1 ? 0.25f : 0.f, x == 0 ? 1.f : 0.75f, x == W - 1 ? 1.f : 0.75f, x <= W - 2 ? 0.25f : 0.f};
+    const float* base = g + static_cast<long long>(img) * 4 * H * W * g_ld + c;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy) {
+        if (wy[dy] == 0.f) continue;
+        const long long row = static_cast<long long>(2 * y - 1 + dy) * Wo;
+        float4 line = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) {
+            if (wx[dx] == 0.f) continue;
+            const float4 v = *reinterpret_cast<const float4*>(base + (row + 2 * x - 1 + dx) * g_ld);
+            line.x += wx[dx] * v.x;  line.y += wx[dx] * v.y;  line.z += wx[dx] * v.z;  line.w += wx[dx] * v.w;
+        }
+        acc.x += wy[dy] * line.x;  acc.y += wy[dy] * line.y;  acc.z += wy[dy] * line.z;  acc.w += wy[dy] * line.w;
+    }
+    *reinterpret_cast<float4*>(gx + ((static_cast<long long>(img) * H + y) * W + x) * gx_ld + c) = acc;
+}
+
 // Depthwise convolution (the image trunk's MBConv blocks), pixel-major: one thread = one output pixel x four channels.
 // w is tap-major [k*k][C] so that a tap's four weights are one 16-byte load next to the four activations they meet.
 // Zero padding is explicit (pad_top / pad_left before, whatever Hout / Wout imply after): the trunk's "static same"
@@ -663,6 +698,18 @@ extern "C" int fiery_upsample2x_add_nhwc(const float* in, int in_ld, int n_img, 
     hipLaunchKernelGGL(k_upsample2x_add, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), in, in_ld, H, W, C,
                        shift, skip, skip_ld, out, out_ld, total);
     return check_launch("upsample2x_add");
+}
+
+extern "C" int fiery_upsample2x_bwd_nhwc(const float* grad_out, int g_ld, int n_img, int H, int W, int C, float* grad_in, int gi_ld,
+                                         fiery_stream_t stream) {
+    FIERY_REQUIRE(grad_out && grad_in && n_img > 0 && H > 0 && W > 0 && C > 0, "upsample2x_bwd: bad argument");
+    auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    FIERY_REQUIRE(C % 4 == 0 && g_ld % 4 == 0 && gi_ld % 4 == 0 && g_ld >= C && gi_ld >= C && a16(grad_out) && a16(grad_in),
+                  "upsample2x_bwd: channels and leading dimensions must be multiples of 4, buffers 16-byte aligned");
+    const long long total4 = static_cast<long long>(n_img) * H * W * (C / 4);
+    hipLaunchKernelGGL(k_upsample2x_bwd4, dim3(ceil_div(total4, 256)), dim3(256), 0, as_stream(stream), grad_out, g_ld, H, W, C / 4,
+                       grad_in, gi_ld, total4);
+    return check_launch("upsample2x_bwd");
 }
 
 extern "C" int fiery_depthwise_conv_nhwc(const float* in, int in_ld, int n_img, int H, int W, int C, const float* w, int w_ld,

@@ -368,7 +368,8 @@ class _Gru:
 
 
 class BevEngine:
-    def __init__(self, model, lib, device):
+    def __init__(self, model, lib, device, plan=True):
+        """plan=False: geometry and pooling only (what the training graph uses - nothing derived from the weights)."""
         self.m, self.lib, self.device = model, lib, torch.device(device)
         self._bufs = {}
         cfg = model.cfg
@@ -390,7 +391,8 @@ class BevEngine:
         self.precision = {'f32': native.PRECISION_F32, 'bf16': native.PRECISION_BF16}[getattr(model, 'conv_precision', 'f32')]
         previous, ops.DEFAULT_PRECISION = ops.DEFAULT_PRECISION, self.precision
         try:
-            self._build()
+            if plan:
+                self._build()
         finally:
             ops.DEFAULT_PRECISION = previous
 

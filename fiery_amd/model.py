@@ -176,6 +176,23 @@ class Fiery(nn.Module):
             self._engine_generation += 1
         return self._engine
 
+    def pool_engine(self):
+        """Geometry + voxel pooling without the folded-weight plan: independent of the parameters, so an optimiser step
+        does not invalidate it (the training graph's pooling stage)."""
+        device = self.frustum.device
+        lib = self._lib
+        if lib is None:
+            if device.type != 'cuda':
+                raise RuntimeError('fiery_amd.Fiery runs its BEV path on MI355X kernels only: move the model to a '
+                                   'HIP device (model.cuda()); there is no CPU fallback')
+            lib = native.get()
+        key = (str(device), id(lib))
+        if getattr(self, '_pool_engine_key', None) != key:
+            from .engine import BevEngine
+            self._pool_engine_obj = BevEngine(self, lib, device, plan=False)
+            self._pool_engine_key = key
+        return self._pool_engine_obj
+
     def refresh_engine(self):
         self._engine = None
         self._graphs.clear()
@@ -225,8 +242,20 @@ class Fiery(nn.Module):
 
     def _require_eval(self):
         if self.training:
-            raise RuntimeError('fiery_amd.Fiery: the HIP path implements inference; call model.eval(). Training needs '
-                               'the backward kernels (SURVEY.md section 8f, rank 2), which are not built yet')
+            raise RuntimeError('fiery_amd.Fiery: this entry point replays the folded inference plan; call model.eval() '
+                               '(training-mode passes go through forward / bev_forward, see fiery_amd/train_graph.py)')
+
+    def train_graph(self):
+        """The autograd form of the path (`fiery_amd.train_graph.TrainGraph`): what `forward` / `bev_forward` run while
+        `self.training` is set; callable directly for gradients in eval mode."""
+        from .train_graph import TrainGraph
+        lib = self._lib
+        if lib is None:
+            if self.frustum.device.type != 'cuda':
+                raise RuntimeError('fiery_amd.Fiery trains on MI355X kernels only: move the model to a HIP device '
+                                   '(model.cuda()); there is no CPU fallback')
+            lib = native.get()
+        return TrainGraph(self, lib)
 
     # -- reference method seams -------------------------------------------------------------------------
     def get_geometry(self, intrinsics, extrinsics):
@@ -343,8 +372,12 @@ class Fiery(nn.Module):
         Either `lifted` (B, S, n, C, D, fH, fW) - what `Encoder.forward` returns per frame and camera, the
         operand of the reference's `projection_to_birds_eye_view` - or the lift head's two factors
         `depth_logits` (B, S, n, D, fH, fW) and `features` (B, S, n, C, fH, fW) for the fused kernel.
+        In training mode the pass is the autograd graph of `fiery_amd.train_graph` (batch-statistics BatchNorm, latent
+        sampled from the future distribution, gradients for the weights and for the lifted features).
         """
-        self._require_eval()
+        if self.training:
+            return self.train_graph().bev_forward(lifted, intrinsics, extrinsics, future_egomotion, future_distribution_inputs,
+                                                  noise, depth_logits=depth_logits, features=features)
         eng = self.engine()
         rf = self.receptive_field
         intrinsics = intrinsics[:, :rf].contiguous()
@@ -422,8 +455,9 @@ class Fiery(nn.Module):
     def forward(self, image, intrinsics, extrinsics, future_egomotion, future_distribution_inputs=None, noise=None):
         """reference: fiery.py:130-191.  image (B, S_total, n, 3, H, W); intrinsics (B, S_total, n, 3, 3);
         extrinsics (B, S_total, n, 4, 4); future_egomotion (B, S_total, 6); labels (B, 1+n_future, 6, X, Y);
-        noise (B, 1, latent)."""
-        self._require_eval()
+        noise (B, 1, latent).  In training mode: the autograd graph of `fiery_amd.train_graph`."""
+        if self.training:
+            return self.train_graph().forward(image, intrinsics, extrinsics, future_egomotion, future_distribution_inputs, noise)
         rf = self.receptive_field
         image = image[:, :rf].contiguous()
         b, s, n, c, h, w = image.shape

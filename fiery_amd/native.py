@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libfiery_hip.so')
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -132,6 +132,7 @@ _SIGNATURES = {
     'fiery_maxpool2x2_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'fiery_upsample2x_add_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                             C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'fiery_upsample2x_bwd_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'fiery_depthwise_conv_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_int] * 6 +
                                   [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'fiery_instance_segmentation': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
@@ -323,10 +324,11 @@ class Lib:
         with contiguous rows -> dw (cout, k*k, cin_pad) f32."""
         n, hin, win, cin_pad = x.shape
         _, hout, wout, g_ld = grad_out.shape
-        assert cin_pad % 8 == 0 and x.stride(3) == 1 and grad_out.stride(3) == 1
+        # (strides of size-1 dimensions are arbitrary in torch: derive them from the shapes of the dense tensors)
+        assert cin_pad % 8 == 0 and x.is_contiguous() and grad_out.is_contiguous()
         dw = torch.zeros(cout, k * k, cin_pad, dtype=torch.float32, device=x.device)
-        self.check(self.dll.fiery_conv_wgrad(_ptr(x), x.stride(2), x.stride(0), cin_pad // 8, _ptr(grad_out), grad_out.stride(2),
-                                             grad_out.stride(0), cout, n, hin, win, hout, wout, k, k, stride, pad, pad, _ptr(dw),
+        self.check(self.dll.fiery_conv_wgrad(_ptr(x), cin_pad, hin * win * cin_pad, cin_pad // 8, _ptr(grad_out), g_ld,
+                                             hout * wout * g_ld, cout, n, hin, win, hout, wout, k, k, stride, pad, pad, _ptr(dw),
                                              _stream_of(dw)))
         return dw
 
@@ -365,6 +367,13 @@ class Lib:
     def upsample2x_add(self, x, in_ld, n_img, h, w, c, shift, skip, skip_ld, out, out_ld):
         self.check(self.dll.fiery_upsample2x_add_nhwc(_ptr(x), in_ld, n_img, h, w, c, _ptr(shift), _ptr(skip), skip_ld,
                                                       _ptr(out), out_ld, _stream_of(out)))
+
+    def upsample2x_bwd(self, grad_out, n_img, h, w, c):
+        """grad_out: dense pixel-major (n_img, 2h, 2w, c) -> (n_img, h, w, c)."""
+        assert grad_out.is_contiguous() and tuple(grad_out.shape) == (n_img, 2 * h, 2 * w, c)
+        gx = torch.empty(n_img, h, w, c, dtype=torch.float32, device=grad_out.device)
+        self.check(self.dll.fiery_upsample2x_bwd_nhwc(_ptr(grad_out), c, n_img, h, w, c, _ptr(gx), c, _stream_of(gx)))
+        return gx
 
     def depthwise_conv(self, x, in_ld, n_img, h, w, c, weights, w_ld, k, stride, pad_top, pad_left, ho, wo, scale, shift, act,
                        out, out_ld):

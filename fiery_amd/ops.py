@@ -125,8 +125,9 @@ class ConvOp:
     """
 
     def __init__(self, lib, weight, chan_map, units, scale, shift, device, stride=1, pad=None,
-                 act=native.ACT_NONE, epi=native.EPI_PLAIN, res_before_act=False, precision=None):
-        """precision: native.PRECISION_F32 / PRECISION_BF16 (None: `ops.DEFAULT_PRECISION`) - bf16 rounds the matrix-core
+                 act=native.ACT_NONE, epi=native.EPI_PLAIN, res_before_act=False, precision=None, tune=True):
+        """tune: time both tile heights the first time a shape is launched (`_pick_tile`); False for one-shot ops.
+        precision: native.PRECISION_F32 / PRECISION_BF16 (None: `ops.DEFAULT_PRECISION`) - bf16 rounds the matrix-core
         operands (weights here, activations on chip), accumulates in fp32; launches the bf16 kernel does not cover run in fp32."""
         self.lib = lib
         self.precision = DEFAULT_PRECISION if precision is None else precision
@@ -147,12 +148,16 @@ class ConvOp:
             self.packed_bf16 = lib.conv_pack_weights_bf16(w.view(self.cout, self.cin_total, taps), self.cout, self.cin_total,
                                                           taps, list(chan_map), cin_units)
         self.cout_pad = round_up(self.cout, 32)
-        sc = torch.zeros(self.cout_pad, dtype=torch.float32)
-        sh = torch.zeros(self.cout_pad, dtype=torch.float32)
-        sc[:self.cout] = scale
-        sh[:self.cout] = shift
-        self.scale, self.shift = sc.to(device), sh.to(device)
+        if torch.is_tensor(scale) and scale.device == w.device and scale.numel() == self.cout_pad:
+            self.scale, self.shift = scale, shift          # already padded, already resident
+        else:
+            sc = torch.zeros(self.cout_pad, dtype=torch.float32)
+            sh = torch.zeros(self.cout_pad, dtype=torch.float32)
+            sc[:self.cout] = scale
+            sh[:self.cout] = shift
+            self.scale, self.shift = sc.to(device), sh.to(device)
         self.act, self.epi, self.res_before_act = act, epi, res_before_act
+        self.tune = tune
         self.chain = None
         self.chain3 = None
         self.heads = None
@@ -217,8 +222,8 @@ class ConvOp:
         the GPU both heights are timed (HIP events, on the launch stream) and the faster one is kept - the partly
         filled last round of workgroups makes the better choice shape-dependent.  The
         convolution is a pure function of its inputs, so the extra launches leave the same result behind."""
-        if self.cout_pad % 64 != 0 or self.chain is not None or self.heads is not None:
-            return 0                                   # one tile shape only
+        if self.cout_pad % 64 != 0 or self.chain is not None or self.heads is not None or not self.tune:
+            return 0                                   # one tile shape only (or: library heuristic)
         key = (out.n_img, out.H, out.W)
         choice = self._tile_m.get(key)
         if choice is None:

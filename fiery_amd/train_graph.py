@@ -1,0 +1,483 @@
+"""Training-mode forward of `fiery_amd.Fiery` as an autograd graph.
+
+The inference engine (`fiery_amd.engine`) folds BatchNorm into the convolutions and fuses epilogues - neither survives
+training, where BatchNorm normalises with batch statistics and every intermediate is needed again for the backward pass.
+Training therefore runs the reference's data flow (fiery/models/fiery.py:130-191, 288-339 and the modules it calls) as a
+PyTorch autograd graph over pixel-major (channels-last) tensors in which
+
+* every convolution - 95 % of the step's flops - is `HipConv2d`: forward on the MFMA implicit-GEMM kernel
+  (`fiery_conv_fwd`), gradient with respect to the input on the same kernel with the weights transposed and mirrored
+  (the gradient zero-stuffed first for stride 2), gradient with respect to the weights on `fiery_conv_wgrad`;
+  the causal (kT, kH, kW) convolutions of the temporal model are kT such 2-D convolutions on time-shifted frames;
+* voxel pooling is `ops.VoxelPool` / `ops.LiftSplat` (HIP forward and backward);
+* BatchNorm with batch statistics (and its running-average update), activations, the GRU gate arithmetic, pooling /
+  bilinear resampling and the ego-warp run on PyTorch-ROCm operators over the same memory - their backward comes from
+  autograd.  (They are memory-bound passes; kernels of their own are a later step.)
+
+`Fiery.forward` dispatches here when `model.training` is set; in training mode the latent sample is drawn from the FUTURE
+distribution (fiery.py:319-325), so `future_distribution_inputs` is required.  The weight holders of `fiery_amd.modules`
+are read in place: parameters receive `.grad` like those of any `nn.Module`.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import native
+from .ops import Buf, ConvOp, identity_chan_map, round_up
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# convolution on the HIP kernels, differentiable
+# ---------------------------------------------------------------------------------------------------------------------
+def _pixel_major(x, pad_to=8):
+    """(N, C, H, W) of any layout -> contiguous (N, H, W, Cp) with Cp = C rounded up to `pad_to` (zeros in the padding)."""
+    n, c, h, w = x.shape
+    t = x.permute(0, 2, 3, 1)
+    cp = round_up(c, pad_to)
+    if cp != c:
+        return F.pad(t, (0, cp - c)).contiguous()
+    return t.contiguous()
+
+
+_UNIT_EPILOGUE = {}
+
+
+def _unit_epilogue(cout, device):
+    """(scale = 1, shift = 0) rows of the kernel's epilogue, padded to its 32-channel tiles; one pair per width/device."""
+    key = (round_up(cout, 32), str(device))
+    if key not in _UNIT_EPILOGUE:
+        _UNIT_EPILOGUE[key] = (torch.ones(key[0], dtype=torch.float32, device=device),
+                               torch.zeros(key[0], dtype=torch.float32, device=device))
+    return _UNIT_EPILOGUE[key]
+
+
+def _launch_conv(lib, x_nhwc, weight, stride, pad):
+    """Plain convolution (no bias, no activation) of a pixel-major tensor on the implicit-GEMM kernel.  The weights change
+    every optimiser step, so they are packed per call (a device kernel) and no tile-height timing is done."""
+    n, h, w, cp = x_nhwc.shape
+    cout, cin, k, _ = weight.shape
+    dev = x_nhwc.device
+    scale, shift = _unit_epilogue(cout, dev)
+    op = ConvOp(lib, weight, identity_chan_map(cin), (cp // 8, 0), scale, shift, dev, stride=stride, pad=(pad, pad),
+                precision=native.PRECISION_F32, tune=False)
+    ho, wo = op.out_hw(h, w)
+    out = Buf.alloc(n, ho, wo, cout, dev, zero=False)
+    op([Buf(x_nhwc, n, h, w, cp)], out)
+    return out.tensor                                            # (n, ho, wo, round_up(cout, 8)); padding channels are 0
+
+
+class HipConv2d(torch.autograd.Function):
+    """conv2d(x, weight, stride, padding) with square kernels, no bias (callers add it), on libfiery_hip.so."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad, lib):
+        x_nhwc = _pixel_major(x.detach().float())
+        cout = weight.shape[0]
+        y = _launch_conv(lib, x_nhwc, weight.detach().float(), stride, pad)
+        ctx.save_for_backward(x_nhwc, weight)
+        ctx.meta = (x.shape, stride, pad, lib)
+        return y[..., :cout].permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x_nhwc, weight = ctx.saved_tensors
+        (n, c, h, w), stride, pad, lib = ctx.meta
+        cout, _, k, _ = weight.shape
+        g = _pixel_major(gy.float())                                            # (n, ho, wo, round_up(cout, 8))
+        gx = gw = None
+        if ctx.needs_input_grad[1]:
+            dw = lib.conv_wgrad(x_nhwc, g, cout, k, stride, pad)                # (cout, taps, cp)
+            gw = dw[:, :, :c].permute(0, 2, 1).reshape(cout, c, k, k)
+        if ctx.needs_input_grad[0]:
+            # dL/dx = correlation of the (zero-stuffed, for stride > 1) output gradient with the transposed, mirrored
+            # weights, padding k - 1 - pad: the forward kernel again
+            size_h, size_w = h + 2 * pad - k + 1, w + 2 * pad - k + 1
+            if stride == 1:
+                gs = g
+            else:
+                gs = g.new_zeros(n, size_h, size_w, g.shape[-1])
+                gs[:, ::stride, ::stride][:, :g.shape[1], :g.shape[2]] = g
+            w_t = weight.detach().float().transpose(0, 1).flip(2, 3).contiguous()
+            gx = _launch_conv(lib, gs, w_t, 1, k - 1 - pad)[..., :c].permute(0, 3, 1, 2)
+        return gx, gw, None, None, None
+
+
+class HipUpsample2x(torch.autograd.Function):
+    """`nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False)` (layers/convolutions.py:203-214): forward
+    `fiery_upsample2x_add_nhwc` (no shift, no skip), backward `fiery_upsample2x_bwd_nhwc` - a gather, where the stock
+    backward scatters with atomics."""
+
+    @staticmethod
+    def forward(ctx, x, lib):
+        n, c, h, w = x.shape
+        x_nhwc = _pixel_major(x.detach().float(), 4)
+        cp = x_nhwc.shape[-1]
+        out = torch.empty(n, 2 * h, 2 * w, cp, dtype=torch.float32, device=x.device)
+        lib.upsample2x_add(x_nhwc, cp, n, h, w, cp, None, None, 0, out, cp)
+        ctx.meta = (n, c, h, w, cp, lib)
+        return out[..., :c].permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        n, c, h, w, cp, lib = ctx.meta
+        return lib.upsample2x_bwd(_pixel_major(gy.float(), 4), n, h, w, cp)[..., :c].permute(0, 3, 1, 2), None
+
+
+class TrainGraph:
+    def __init__(self, model, lib=None, conv2d=None):
+        """conv2d: the differentiable convolution `(x, weight, stride, pad, lib) -> y`; `HipConv2d.apply` unless a test
+        substitutes its own statement of the operator to check the graph's wiring apart from the kernels."""
+        self.m = model
+        self.lib = lib or model._lib or native.get()
+        self._conv = conv2d or HipConv2d.apply
+        self.whole_plane_pooling_as_means = True      # False: avg_pool3d + interpolate, operator for operator as the reference
+        # (with a substituted convolution the graph may run in fp64 / on the host: resampling then stays on torch too)
+        self._upsample2x = (lambda x: HipUpsample2x.apply(x, self.lib)) if conv2d is None else (
+            lambda x: F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False))
+
+    # -- primitives ---------------------------------------------------------------------------------------------------
+    def conv2d(self, x, conv):
+        assert conv.kernel_size[0] == conv.kernel_size[1] and conv.stride[0] == conv.stride[1] and conv.groups == 1
+        y = self._conv(x, conv.weight, conv.stride[0], conv.padding[0], self.lib)
+        if conv.bias is not None:
+            y = y + conv.bias.view(1, -1, 1, 1)
+        return y
+
+    @staticmethod
+    def bn(x, norm):
+        """BatchNorm in the module's own mode, as `nn.BatchNorm*.forward` runs it: batch statistics, the running-average
+        update and the batch counter while training; the running statistics otherwise."""
+        factor = 0.0 if norm.momentum is None else norm.momentum
+        if norm.training and norm.track_running_stats and norm.num_batches_tracked is not None:
+            norm.num_batches_tracked.add_(1)
+            if norm.momentum is None:
+                factor = 1.0 / float(norm.num_batches_tracked)
+        use_batch = norm.training or (norm.running_mean is None and norm.running_var is None)
+        return F.batch_norm(x, norm.running_mean if not norm.training or norm.track_running_stats else None,
+                            norm.running_var if not norm.training or norm.track_running_stats else None, norm.weight, norm.bias,
+                            use_batch, factor, norm.eps)
+
+    def conv3d_frames(self, x, weight):
+        """(B, C, T, H, W) x (Cout, Cin, kT, k, k) -> (B, Cout, T, H, W): `CausalConv3d`'s convolution (kT - 1 zero frames
+        before the first, 'same' in space; fiery/layers/temporal.py:65-85) through the frames-major form below."""
+        b, c, t, h, w = x.shape
+        y = self._conv_frames(x.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w), weight, b, t)
+        return y.reshape(b, t, -1, h, w).permute(0, 2, 1, 3, 4)
+
+    def _conv_frames(self, x, weight, b, t):
+        """Frames-major: x (B T, C, H, W), any memory format -> (B T, Cout, H, W).  A (kT, k, k) kernel is kT 2-D
+        convolutions, tap dt reading the frames kT - 1 - dt steps back (zeros before the first frame of every sample)."""
+        cout, c, kt, k, _ = weight.shape
+        h, w = x.shape[-2:]
+        out = None
+        for dt in range(kt):
+            shift = kt - 1 - dt
+            src = x
+            if shift:
+                frames = x.permute(0, 2, 3, 1).reshape(b, t, h, w, c)                       # pixel-major view
+                src = torch.cat([frames.new_zeros(b, shift, h, w, c), frames[:, :t - shift]], dim=1).view(b * t, h, w, c).permute(0, 3, 1, 2)
+            y = self._conv(src, weight[:, :, dt], 1, (k - 1) // 2, self.lib)
+            out = y if out is None else out + y
+        return out
+
+    def _unit3d(self, x, blk, b, t):
+        """conv + BatchNorm3d + ReLU of a (1, 1, 1) block (temporal.py:107-117) or a `CausalConv3d` (temporal.py:65-85) on
+        frames-major activations: BatchNorm3d's statistics over (B, T, H, W) are BatchNorm2d's over (B T, H, W)."""
+        return F.relu(self.bn(self._conv_frames(x, blk.conv.weight, b, t), blk.norm))
+
+    def _project3d(self, x, proj, b, t):
+        return self.bn(self._conv_frames(x, proj[0].weight, b, t), proj[1])
+
+    def _pyramid(self, x, pp, b, t):
+        """`PyramidSpatioTemporalPooling` (temporal.py:167-215) on frames-major x -> list of (B T, C', H, W).  For the size
+        the reference configures - the whole plane, two frames ((2, H, W), temporal_model.py:31) - the pooled map is one
+        value per frame and channel: the mean of the frame and of the one before it (padding not counted), T + 1 of them
+        with the padded step on the right, which the 1x1x1 block's BatchNorm sees before it is dropped; its 'bilinear
+        upsampling' is a broadcast."""
+        h, w = x.shape[-2:]
+        c = x.shape[1]
+        outs = []
+        for size, branch in zip(pp.pool_sizes, pp.features):
+            if tuple(size) == (2, h, w) and self.whole_plane_pooling_as_means:
+                per_frame = x.mean(dim=(2, 3)).view(b, t, c)
+                pooled = torch.cat([per_frame[:, :1], 0.5 * (per_frame[:, :-1] + per_frame[:, 1:]), per_frame[:, -1:]], dim=1)
+                y = self._unit3d(pooled.reshape(b * (t + 1), c, 1, 1), branch.conv_bn_relu, b, t + 1)
+                y = y.reshape(b, t + 1, -1)[:, :t].reshape(b * t, -1, 1, 1)
+                outs.append(y.expand(b * t, y.shape[1], h, w))
+                continue
+            x5 = x.reshape(b, t, c, h, w).permute(0, 2, 1, 3, 4)
+            pooled = F.avg_pool3d(x5, kernel_size=size, stride=(1, *size[1:]), padding=(size[0] - 1, 0, 0), count_include_pad=False)
+            tp, hp, wp = pooled.shape[2:]
+            y = self._unit3d(pooled.permute(0, 2, 1, 3, 4).reshape(b * tp, c, hp, wp), branch.conv_bn_relu, b, tp)
+            y = y.reshape(b, tp, -1, hp, wp)[:, :t].reshape(b * t, -1, hp, wp)
+            outs.append(F.interpolate(y, (h, w), mode='bilinear', align_corners=False))
+        return outs
+
+    def temporal_block(self, x, tb, b, t):
+        """fiery/layers/temporal.py:218-281 on frames-major x (B T, C, H, W)."""
+        paths = [self._unit3d(self._unit3d(x, tb.convolution_paths[i][0], b, t), tb.convolution_paths[i][1], b, t) for i in range(2)]
+        paths.append(self._unit3d(x, tb.convolution_paths[2], b, t))
+        if tb.use_pyramid_pooling:
+            paths.extend(self._pyramid(x, tb.pyramid_pooling, b, t))
+        res = self._unit3d(torch.cat(paths, dim=1), tb.aggregation[0], b, t)
+        if tb.projection is not None:
+            x = self._project3d(x, tb.projection, b, t)
+        return x + res
+
+    def bottleneck3d(self, x, blk, b, t):
+        """fiery/layers/temporal.py:120-164 on frames-major x."""
+        L = blk.layers
+        r = self._unit3d(self._unit3d(self._unit3d(x, L.conv_down_project, b, t), L.conv, b, t), L.conv_up_project, b, t)
+        if blk.projection is not None:
+            x = self._project3d(x, blk.projection, b, t)
+        return r + x
+
+    def temporal_model(self, x):
+        """fiery/models/temporal_model.py:47-52; x (B, T, C, H, W) -> (B, 1, C', H, W)."""
+        tm = self.m.temporal_model
+        if not hasattr(tm, 'model'):
+            return x[:, (tm.receptive_field - 1):]
+        b, t, c, h, w = x.shape
+        y = x.reshape(b * t, c, h, w).contiguous(memory_format=torch.channels_last)
+        for stage in tm.model:
+            y = self.temporal_block(y, stage, b, t) if hasattr(stage, 'convolution_paths') else self.bottleneck3d(y, stage, b, t)
+        return y.view(b, t, -1, h, w)[:, (tm.receptive_field - 1):]
+
+    def bottleneck(self, x, blk):
+        """fiery/layers/convolutions.py:64-168 (Dropout2d(p=0) is the identity)."""
+        L = blk.layers
+        r = F.relu(self.bn(self.conv2d(x, L.conv_down_project), L.abn_down_project[0]))
+        r = F.relu(self.bn(self.conv2d(r, L.conv), L.abn[0]))
+        r = F.relu(self.bn(self.conv2d(r, L.conv_up_project), L.abn_up_project[0]))
+        if blk.projection is None:
+            return r + x
+        skip = x
+        if blk.downsample:
+            # odd sizes are padded first so that the pooled skip meets the strided convolution's size (convolutions.py:160-162)
+            skip = F.max_pool2d(F.pad(skip, (0, skip.shape[-1] % 2, 0, skip.shape[-2] % 2), value=0), 2, 2)
+        skip = self.bn(self.conv2d(skip, blk.projection.conv_skip_proj), blk.projection.bn_skip_proj)
+        return r + skip
+
+    def gru_cell(self, x, state, gru):
+        """fiery/layers/temporal.py:49-62 (note (1 - reset) * state)."""
+        xs = torch.cat([x, state], dim=1)
+        update = torch.sigmoid(self.conv2d(xs, gru.conv_update) + gru.gru_bias_init)
+        reset = torch.sigmoid(self.conv2d(xs, gru.conv_reset) + gru.gru_bias_init)
+        tilde = gru.conv_state_tilde
+        proposal = F.relu(self.bn(self.conv2d(torch.cat([x, (1.0 - reset) * state], dim=1), tilde.conv), tilde.norm))
+        return (1.0 - update) * state + update * proposal
+
+    def future_prediction(self, x, hidden):
+        """fiery/models/future_prediction.py:27-36; x (B, T, C, H, W), every GRU block starts from `hidden`."""
+        fp = self.m.future_prediction
+        for gru, blocks in zip(fp.spatial_grus, fp.res_blocks):
+            state, outs = hidden, []
+            for t in range(x.shape[1]):
+                state = self.gru_cell(x[:, t], state, gru)
+                outs.append(state)
+            x = torch.stack(outs, dim=1)
+            b, n, c, h, w = x.shape
+            y = x.reshape(b * n, c, h, w)
+            for blk in blocks:
+                y = self.bottleneck(y, blk)
+            x = y.view(b, n, c, h, w)
+        return x
+
+    def distribution(self, s_t, dm):
+        """fiery/models/distributions.py:28-39, 52-56; s_t (B, 1, C, H, W) -> mu, log_sigma (B, 1, latent)."""
+        b = s_t.shape[0]
+        y = s_t[:, 0]
+        for blk in dm.encoder.model:
+            y = self.bottleneck(y, blk)
+        y = F.adaptive_avg_pool2d(y, 1)
+        conv = dm.last_conv[1]
+        y = (F.conv2d(y, conv.weight, conv.bias)).view(b, 1, 2 * dm.latent_dim)          # a (B, C) x (C, 2 latent) product
+        mu, log_sigma = y[:, :, :dm.latent_dim], y[:, :, dm.latent_dim:]
+        return mu, torch.clamp(log_sigma, dm.min_log_sigma, dm.max_log_sigma)
+
+    def distribution_forward(self, present, future_distribution_inputs, noise):
+        """fiery/models/fiery.py:288-339 in the model's current mode: training samples from the FUTURE distribution."""
+        m = self.m
+        b, s, _, h, w = present.shape
+        present_mu, present_log_sigma = self.distribution(present, m.present_distribution)
+        future_mu = future_log_sigma = None
+        if future_distribution_inputs is not None:
+            future_features = future_distribution_inputs[:, 1:].contiguous().view(b, 1, -1, h, w)
+            future_mu, future_log_sigma = self.distribution(torch.cat([present, future_features.to(present.dtype)], dim=2),
+                                                            m.future_distribution)
+        if noise is None:
+            noise = torch.randn_like(present_mu) if m.training else torch.zeros_like(present_mu)
+        if m.training:
+            if future_mu is None:
+                raise ValueError('training mode samples the latent from the future distribution (fiery/models/fiery.py:319-325): '
+                                 'pass future_distribution_inputs')
+            mu, sigma = future_mu, torch.exp(future_log_sigma)
+        else:
+            mu, sigma = present_mu, torch.exp(present_log_sigma)
+        sample = (mu + sigma * noise).view(b, s, m.latent_dim, 1, 1).expand(b, s, m.latent_dim, h, w)
+        return sample, dict(present_mu=present_mu, present_log_sigma=present_log_sigma, future_mu=future_mu,
+                            future_log_sigma=future_log_sigma)
+
+    def basic_block(self, x, blk):
+        """torchvision resnet BasicBlock (fiery/models/decoder.py:10-17)."""
+        out = F.relu(self.bn(self.conv2d(x, blk.conv1), blk.bn1))
+        out = self.bn(self.conv2d(out, blk.conv2), blk.bn2)
+        if blk.downsample is not None:
+            x = self.bn(self.conv2d(x, blk.downsample[0]), blk.downsample[1])
+        return F.relu(out + x)
+
+    def upsample_add(self, x, skip, up):
+        """fiery/layers/convolutions.py:203-214."""
+        x = self._upsample2x(x)
+        return self.bn(self.conv2d(x, up.upsample_layer[1]), up.upsample_layer[2]) + skip
+
+    def head(self, x, h):
+        y = F.relu(self.bn(self.conv2d(x, h[0]), h[1]))
+        y = self.conv2d(y, h[3])
+        return torch.sigmoid(y) if len(h) > 4 else y
+
+    def decoder(self, x):
+        """fiery/models/decoder.py:53-91; x (B, S, C, H, W)."""
+        d = self.m.decoder
+        b, s, c, h, w = x.shape
+        x = x.reshape(b * s, c, h, w)
+        skip1 = x
+        x = F.relu(self.bn(self.conv2d(x, d.first_conv), d.bn1))
+        for blk in d.layer1:
+            x = self.basic_block(x, blk)
+        skip2 = x
+        for blk in d.layer2:
+            x = self.basic_block(x, blk)
+        skip3 = x
+        for blk in d.layer3:
+            x = self.basic_block(x, blk)
+        x = self.upsample_add(x, skip3, d.up3_skip)
+        x = self.upsample_add(x, skip2, d.up2_skip)
+        x = self.upsample_add(x, skip1, d.up1_skip)
+        out = dict(segmentation=self.head(x, d.segmentation_head), instance_center=self.head(x, d.instance_center_head),
+                   instance_offset=self.head(x, d.instance_offset_head),
+                   instance_flow=self.head(x, d.instance_future_head) if d.predict_future_flow else None)
+        return {k: (None if v is None else v.reshape(b, s, *v.shape[1:])) for k, v in out.items()}
+
+    # -- the path -----------------------------------------------------------------------------------------------------
+    def bev_stack(self, x, future_egomotion, future_distribution_inputs=None, noise=None):
+        """Everything after pooling; x (B, S, C, X, Y) pooled BEV features, future_egomotion (B, S, 6)."""
+        m = self.m
+        cfg = m.cfg
+        x = cumulative_warp_features(x.clone(), future_egomotion, 'bilinear', m.spatial_extent)
+        if cfg.MODEL.TEMPORAL_MODEL.INPUT_EGOPOSE:
+            b, s, c = future_egomotion.shape
+            h, w = x.shape[-2:]
+            spatial = future_egomotion.view(b, s, c, 1, 1).expand(b, s, c, h, w)
+            spatial = torch.cat([torch.zeros_like(spatial[:, :1]), spatial[:, :(m.receptive_field - 1)]], dim=1)
+            x = torch.cat([x, spatial], dim=-3)
+        states = self.temporal_model(x)
+        output = {}
+        if m.n_future > 0:
+            present = states[:, :1].contiguous()
+            b, _, _, h, w = present.shape
+            hidden = present[:, 0]
+            if cfg.PROBABILISTIC.ENABLED:
+                sample, dist = self.distribution_forward(present, future_distribution_inputs, noise)
+                output.update(dist)
+                fut_in = sample.expand(-1, m.n_future, -1, -1, -1)
+            else:
+                fut_in = hidden.new_zeros(b, m.n_future, m.latent_dim, h, w)
+            states_out = torch.cat([present, self.future_prediction(fut_in, hidden)], dim=1)
+        else:
+            states_out = states[:, -1:]
+        output.update(self.decoder(states_out))
+        return output
+
+    def _pooled(self, intrinsics, extrinsics, lifted=None, depth_logits=None, features=None):
+        """Voxel pooling of all frames through `BevEngine.pool` / `pool_fused` (ops.VoxelPool / ops.LiftSplat under
+        autograd: HIP forward and backward) -> (B, S, C, X, Y)."""
+        from .model import pack_sequence_dim
+        m = self.m
+        b, s, n = intrinsics.shape[:3]
+        K, E = pack_sequence_dim(intrinsics), pack_sequence_dim(extrinsics)
+        eng = m.pool_engine()
+        with torch.no_grad():
+            geometry = eng.geometry(K, E, m._camera_matrices(K, E))
+        if lifted is not None:
+            x = lifted.reshape(b * s, *lifted.shape[2:]).permute(0, 1, 3, 4, 5, 2)           # view: (F, n, D, h, w, C)
+            bev = eng.pool(x, geometry)
+        else:
+            bev = eng.pool_fused(depth_logits.reshape(b * s, n, *depth_logits.shape[3:]),
+                                 features.reshape(b * s, n, *features.shape[3:]), geometry)
+        return bev.view(b, s, *bev.shape[1:])
+
+    def bev_forward(self, lifted, intrinsics, extrinsics, future_egomotion, future_distribution_inputs=None, noise=None,
+                    depth_logits=None, features=None):
+        """The hot path from the encoder's outputs (`Fiery.bev_forward`'s arguments), differentiable in them and in the
+        weights."""
+        rf = self.m.receptive_field
+        cut = lambda t: None if t is None else t[:, :rf]
+        bev = self._pooled(intrinsics[:, :rf].contiguous(), extrinsics[:, :rf].contiguous(), cut(lifted), cut(depth_logits),
+                           cut(features))
+        return self.bev_stack(bev, future_egomotion[:, :rf].contiguous(), future_distribution_inputs, noise)
+
+    def forward(self, image, intrinsics, extrinsics, future_egomotion, future_distribution_inputs=None, noise=None):
+        """`Fiery.forward` (fiery.py:130-191) with autograd.  The image trunk and the lift head run as the torch statement
+        of their layers (`Encoder.lift_head`; upstream of the section-8 path), their two factors go into the fused
+        lift-splat kernel, then `bev_stack`."""
+        m = self.m
+        rf = m.receptive_field
+        image = image[:, :rf].contiguous()
+        b, s, n, c, h, w = image.shape
+        depth_logits, features = m.encoder.lift_head(image.view(b * s * n, c, h, w))
+        fh, fw = features.shape[-2:]
+        feats = features.view(b, s, n, -1, fh, fw)
+        if depth_logits is None:
+            lifted = feats.unsqueeze(4).expand(b, s, n, feats.shape[3], m.depth_channels, fh, fw)
+            return self.bev_forward(lifted, intrinsics, extrinsics, future_egomotion, future_distribution_inputs, noise)
+        return self.bev_forward(None, intrinsics, extrinsics, future_egomotion, future_distribution_inputs, noise,
+                                depth_logits=depth_logits.view(b, s, n, -1, fh, fw), features=feats)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ego-warp with autograd (fiery/utils/geometry.py:82-157, 181-253) - torch operators, differentiable in the features
+# ---------------------------------------------------------------------------------------------------------------------
+def _euler_to_matrix(angle):
+    """Rx . Ry . Rz of the three angles (geometry.py:109-140)."""
+    x, y, z = angle[:, 0], angle[:, 1], angle[:, 2]
+    zeros, ones = torch.zeros_like(x), torch.ones_like(x)
+    rot_z = torch.stack([torch.cos(z), -torch.sin(z), zeros, torch.sin(z), torch.cos(z), zeros, zeros, zeros, ones], 1).view(-1, 3, 3)
+    rot_y = torch.stack([torch.cos(y), zeros, torch.sin(y), zeros, ones, zeros, -torch.sin(y), zeros, torch.cos(y)], 1).view(-1, 3, 3)
+    rot_x = torch.stack([ones, zeros, zeros, zeros, torch.cos(x), -torch.sin(x), zeros, torch.sin(x), torch.cos(x)], 1).view(-1, 3, 3)
+    return rot_x.bmm(rot_y).bmm(rot_z)
+
+
+def _pose_to_matrix(vec):
+    """(..., 6) -> (..., 4, 4) (geometry.py:143-157)."""
+    shape = vec.shape[:-1]
+    v = vec.reshape(-1, 6)
+    top = torch.cat([_euler_to_matrix(v[:, 3:]), v[:, :3].unsqueeze(-1)], dim=2)
+    mat = torch.cat([top, top.new_zeros(top.shape[0], 1, 4)], dim=1)
+    mat[:, 3, 3] = 1.0
+    return mat.view(*shape, 4, 4)
+
+
+def _warp(x, matrix, mode, spatial_extent):
+    """warp_features (geometry.py:181-222) given the accumulated 4x4 pose: only (tx, ty, rz) matter."""
+    angle = torch.atan2(-matrix[:, 0, 1], matrix[:, 0, 0])                       # mat2pose_vec's rz (geometry.py:82-106)
+    tx, ty = matrix[:, 0, 3], matrix[:, 1, 3]
+    c, s = torch.cos(angle), torch.sin(angle)
+    theta = torch.stack([c, -s, ty / spatial_extent[1], s, c, -(tx / spatial_extent[0])], dim=-1).view(-1, 2, 3)
+    grid = F.affine_grid(theta, size=x.shape, align_corners=False)
+    return F.grid_sample(x, grid.to(x.dtype), mode=mode, padding_mode='zeros', align_corners=False)
+
+
+def cumulative_warp_features(x, flow, mode, spatial_extent):
+    """geometry.py:225-253: frame t is warped by flow[t] @ ... @ flow[S-2]; the last frame stays."""
+    s = x.shape[1]
+    if s == 1:
+        return x
+    mats = _pose_to_matrix(flow)
+    out = [x[:, -1]]
+    cum = mats[:, -2]
+    for t in reversed(range(s - 1)):
+        out.append(_warp(x[:, t], cum, mode, spatial_extent))
+        cum = mats[:, t - 1] @ cum
+    return torch.stack(out[::-1], 1)

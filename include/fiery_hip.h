@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FIERY_ABI_VERSION 9
+#define FIERY_ABI_VERSION 10
 
 #define FIERY_OK 0
 #define FIERY_EINVAL (-22)      /* bad argument (shape, alignment, null pointer) */
@@ -401,6 +401,12 @@ int fiery_scale_channels_nhwc(float* x, int ld, int n_img, int HW, int C, const 
 int fiery_upsample2x_add_nhwc(const float* in, int in_ld, int n_img, int H, int W, int C,
                               const float* shift, const float* skip, int skip_ld,
                               float* out, int out_ld, fiery_stream_t stream);
+
+/* Gradient of the plain x2 interpolation (fiery_upsample2x_add_nhwc without shift / skip) with respect to its input -
+ * what autograd computes for `nn.Upsample(scale_factor=2, mode='bilinear')` in layers/convolutions.py:203-214 (training).
+ * grad_out: [n_img][2H][2W] rows of g_ld floats; grad_in: [n_img][H][W] rows of gi_ld floats; C a multiple of 4. */
+int fiery_upsample2x_bwd_nhwc(const float* grad_out, int g_ld, int n_img, int H, int W, int C, float* grad_in, int gi_ld,
+                              fiery_stream_t stream);
 
 /* out[img][p][c0 + c] = v[img][c] for every pixel (spatial broadcast of the latent sample,
  * fiery/models/fiery.py:329-330). */

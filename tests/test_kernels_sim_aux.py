@@ -334,3 +334,16 @@ def test_reverse_warp_params_and_nearest_warp_match_the_oracle(sim):
     mismatch = (got != want).any(dim=2).float().mean().item()          # pixels whose nearest source differs (boundary ties)
     assert mismatch < 5e-3, mismatch
     assert (want[:, 1:] == 0).float().mean() > 0.01                    # some of the map leaves the grid: zeros padding
+
+
+@pytest.mark.parametrize('shape', [(2, 8, 5, 7), (1, 4, 1, 1), (1, 12, 1, 6), (2, 4, 3, 1)])
+def test_upsample2x_backward_is_the_transpose_of_the_interpolation(sim, shape):
+    """`fiery_upsample2x_bwd_nhwc` against autograd through F.interpolate (borders included: one-pixel rows/columns)."""
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(h * 10 + w)
+    x = torch.randn(n, c, h, w, generator=g, requires_grad=True)
+    up = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
+    gy = torch.randn(up.shape, generator=g)
+    (want,) = torch.autograd.grad(up, x, gy)
+    got = sim.upsample2x_bwd(gy.permute(0, 2, 3, 1).contiguous(), n, h, w, c).permute(0, 3, 1, 2)
+    assert torch.allclose(got, want, rtol=1e-6, atol=1e-6)

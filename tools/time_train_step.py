@@ -1,0 +1,77 @@
+"""Time one training step (forward + backward of the BEV path from the lifted features) on the GPU, with the per-operator
+split: python tools/time_train_step.py [--preset baseline.yml] [--batch 2] [--steps 5] [--torch-conv]
+
+--torch-conv substitutes PyTorch-ROCm's convolution (MIOpen) for `HipConv2d` in the same graph - the comparison leg.
+Prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--preset', default='baseline.yml')
+    ap.add_argument('--batch', type=int, default=2)
+    ap.add_argument('--cams', type=int, default=6)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--torch-conv', action='store_true')
+    ap.add_argument('--profile', action='store_true', help='torch profiler table of one step')
+    args = ap.parse_args()
+    from fiery_amd.config import get_preset_cfg
+    from fiery_amd.model import Fiery
+    from fiery_amd.synthetic import make_inputs, make_lifted_features, randomise_weights
+    from fiery_amd.train_graph import TrainGraph
+    cfg = get_preset_cfg(args.preset)
+    torch.manual_seed(0)
+    model = Fiery(cfg)
+    randomise_weights(model)
+    model = model.cuda().train()
+    B, n, rf = args.batch, args.cams, model.receptive_field
+    _, K, E, ego = [None if t is None else t.cuda() for t in make_inputs(B, rf + model.n_future, n, with_image=False)]
+    fh, fw = cfg.IMAGE.FINAL_DIM[0] // cfg.MODEL.ENCODER.DOWNSAMPLE, cfg.IMAGE.FINAL_DIM[1] // cfg.MODEL.ENCODER.DOWNSAMPLE
+    _, _, lifted = make_lifted_features(B * rf * n, model.encoder_out_channels, model.depth_channels, (fh, fw), seed=1)
+    lifted = lifted.view(B, rf, n, model.encoder_out_channels, model.depth_channels, fh, fw).cuda().requires_grad_()
+    labels = torch.randn(B, 1 + model.n_future, 6, *model.bev_size, device='cuda') if model.n_future > 0 else None
+    conv = (lambda x, w, s, p, lib: F.conv2d(x, w, None, s, p)) if args.torch_conv else None
+    graph = TrainGraph(model, conv2d=conv)
+    params = [p for name, p in model.named_parameters() if not name.startswith('encoder.')]
+    opt = torch.optim.SGD(params, lr=1e-4)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        lifted.grad = None
+        out = graph.bev_forward(lifted, K, E, ego, labels)
+        loss = sum((v ** 2).mean() for v in out.values() if v is not None)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    line = dict(tool='time_train_step', preset=args.preset, batch=B, cams=n, conv='torch(MIOpen)' if args.torch_conv else 'hip',
+                ms_per_step=round(ms, 2), samples_per_s=round(B / ms * 1e3, 2), peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 2))
+    if args.profile:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            step()
+            torch.cuda.synchronize()
+        print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=25), file=sys.stderr)
+    print(json.dumps(line))
+
+
+if __name__ == '__main__':
+    main()
