@@ -13,6 +13,8 @@
 // step (the data gradient reuses the forward kernel with transposed, mirrored weights: fiery_amd/train_graph.py).
 #include "common.h"
 
+#include <cstdlib>
+
 namespace fiery {
 namespace {
 
@@ -119,7 +121,11 @@ extern "C" int fiery_conv_wgrad(const float* in, int in_ld, int64_t in_img_strid
     const int n_rows = n_img * Hout;
     // enough row shares to fill the chip (256 CUs x a few workgroups) without leaving a share fewer than four rows
     const int blocks_xy = ceil_div(cout, 64) * kH * kW * p.c_tiles;
-    int shares = ceil_div(2048, blocks_xy);
+    static const int target_wgs = [] {
+        const char* e = getenv("FIERY_WGRAD_WGS");
+        return e && atoi(e) > 0 ? atoi(e) : 2048;
+    }();
+    int shares = ceil_div(target_wgs, blocks_xy);
     if (shares > ceil_div(n_rows, 4)) shares = ceil_div(n_rows, 4);
     if (shares < 1) shares = 1;
     FIERY_REQUIRE(static_cast<long long>(kH) * kW * p.c_tiles < 65536 && shares < 65536, "conv_wgrad: grid too large");

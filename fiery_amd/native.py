@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libfiery_hip.so')
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -132,6 +132,13 @@ _SIGNATURES = {
     'fiery_maxpool2x2_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'fiery_upsample2x_add_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                             C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'fiery_bn_workspace_floats': (C.c_int64, [C.c_int]),
+    'fiery_bn_train_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]),
+    'fiery_bn_train_bwd': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]),
     'fiery_upsample2x_bwd_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'fiery_depthwise_conv_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_int] * 6 +
                                   [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
@@ -367,6 +374,32 @@ class Lib:
     def upsample2x_add(self, x, in_ld, n_img, h, w, c, shift, skip, skip_ld, out, out_ld):
         self.check(self.dll.fiery_upsample2x_add_nhwc(_ptr(x), in_ld, n_img, h, w, c, _ptr(shift), _ptr(skip), skip_ld,
                                                       _ptr(out), out_ld, _stream_of(out)))
+
+    def _bn_workspace(self, c, device):
+        key = (int(c), str(device))
+        cache = self.__dict__.setdefault('_bn_ws', {})
+        if key not in cache:
+            cache[key] = torch.empty(self.dll.fiery_bn_workspace_floats(int(c)), dtype=torch.float32, device=device)
+        return cache[key]
+
+    def bn_train_fwd(self, x, ld, n_pixels, c, gamma, beta, running_mean, running_var, batch_stats, momentum, eps, relu, c_store):
+        """x: rows of `ld` floats (a tensor whose data pointer is the first row) -> (y dense [n_pixels, c_store], mean, invstd)."""
+        y = torch.empty(n_pixels, c_store, dtype=torch.float32, device=x.device)
+        mean = torch.empty(c, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(c, dtype=torch.float32, device=x.device)
+        self.check(self.dll.fiery_bn_train_fwd(_ptr(x), ld, n_pixels, c, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                               int(bool(batch_stats)), float(momentum), float(eps), int(bool(relu)), _ptr(y), c_store,
+                                               c_store, _ptr(mean), _ptr(invstd), _ptr(self._bn_workspace(c, x.device)), _stream_of(y)))
+        return y, mean, invstd
+
+    def bn_train_bwd(self, grad_out, g_ld, x, ld, y, y_ld, n_pixels, c, gamma, mean, invstd, batch_stats, c_store):
+        gx = torch.empty(n_pixels, c_store, dtype=torch.float32, device=x.device)
+        dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+        self.check(self.dll.fiery_bn_train_bwd(_ptr(grad_out), g_ld, _ptr(x), ld, _ptr(y), y_ld, n_pixels, c, _ptr(gamma), _ptr(mean),
+                                               _ptr(invstd), int(bool(batch_stats)), _ptr(gx), c_store, c_store, _ptr(dgamma), _ptr(dbeta),
+                                               _ptr(self._bn_workspace(c, x.device)), _stream_of(gx)))
+        return gx, dgamma, dbeta
 
     def upsample2x_bwd(self, grad_out, n_img, h, w, c):
         """grad_out: dense pixel-major (n_img, 2h, 2w, c) -> (n_img, h, w, c)."""

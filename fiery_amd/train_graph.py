@@ -31,13 +31,21 @@ from .ops import Buf, ConvOp, identity_chan_map, round_up
 # convolution on the HIP kernels, differentiable
 # ---------------------------------------------------------------------------------------------------------------------
 def _pixel_major(x, pad_to=8):
-    """(N, C, H, W) of any layout -> contiguous (N, H, W, Cp) with Cp = C rounded up to `pad_to` (zeros in the padding)."""
+    """(N, C, H, W) of any layout -> contiguous (N, H, W, Cp) with Cp = C rounded up to `pad_to`.  The channels past C are
+    zeros - or, when x already is a channel slice of pixel-major rows Cp wide (the outputs of the operators below: their row
+    padding is written as zeros), whatever those rows hold there: every consumer multiplies them by zero weights or drops
+    the result."""
     n, c, h, w = x.shape
     t = x.permute(0, 2, 3, 1)
     cp = round_up(c, pad_to)
-    if cp != c:
-        return F.pad(t, (0, cp - c)).contiguous()
-    return t.contiguous()
+    if cp == c:
+        return t.contiguous()
+    if min(n, h, w) > 1 and t.stride() == (h * w * cp, w * cp, cp, 1):
+        try:
+            return torch.as_strided(t, (n, h, w, cp), t.stride())
+        except RuntimeError:                                  # rows that end with the storage: not padded after all
+            pass
+    return F.pad(t, (0, cp - c)).contiguous()
 
 
 _UNIT_EPILOGUE = {}
@@ -124,6 +132,63 @@ class HipUpsample2x(torch.autograd.Function):
         return lib.upsample2x_bwd(_pixel_major(gy.float(), 4), n, h, w, cp)[..., :c].permute(0, 3, 1, 2), None
 
 
+def _rows(x):
+    """(N, C, H, W) tensor -> (tensor whose first element starts pixel 0, floats between pixels): the tensor itself when its
+    memory is pixel-major rows (a channels-last tensor, or a convolution output with padded rows), else a dense copy."""
+    n, c, h, w = x.shape
+    sn, sc, sh, sw = x.stride()
+    if min(n, h, w) > 1 and sc == 1 and sw >= c and sw % 4 == 0 and sh == w * sw and sn == h * sh:
+        return x, sw
+    t = x.permute(0, 2, 3, 1)
+    return (t if t.is_contiguous() else t.contiguous()), c
+
+
+class HipBatchNormAct(torch.autograd.Function):
+    """BatchNorm (batch statistics + running-average update while training, running statistics otherwise) with an optional
+    fused ReLU: `fiery_bn_train_fwd` / `fiery_bn_train_bwd`.  Output rows are padded to a multiple of 8 channels (zeros), the
+    form the next convolution reads in place."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, batch_stats, momentum, eps, relu, lib):
+        n, c, h, w = x.shape
+        xr, ld = _rows(x.detach().float())
+        c_store = round_up(c, 8)
+        y, mean, invstd = lib.bn_train_fwd(xr, ld, n * h * w, c, None if weight is None else weight.detach(),
+                                           None if bias is None else bias.detach(), running_mean, running_var, batch_stats, momentum,
+                                           eps, relu, c_store)
+        ctx.save_for_backward(xr, y if relu else None, mean, invstd, None if weight is None else weight.detach())
+        ctx.meta = (n, c, h, w, ld, c_store, batch_stats, lib)
+        return y.view(n, h, w, c_store)[..., :c].permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xr, y, mean, invstd, weight = ctx.saved_tensors
+        n, c, h, w, ld, c_store, batch_stats, lib = ctx.meta
+        gr, g_ld = _rows(gy.float())
+        gx, dgamma, dbeta = lib.bn_train_bwd(gr, g_ld, xr, ld, y, c_store, n * h * w, c, weight, mean, invstd, batch_stats, c_store)
+        return (gx.view(n, h, w, c_store)[..., :c].permute(0, 3, 1, 2), dgamma if ctx.needs_input_grad[1] else None,
+                dbeta if ctx.needs_input_grad[2] else None, None, None, None, None, None, None, None)
+
+
+class HipSpatialMean(torch.autograd.Function):
+    """(N, C, H, W) -> (N, C) means over the plane (`fiery_spatial_mean`); the gradient is a broadcast."""
+
+    @staticmethod
+    def forward(ctx, x, lib):
+        n, c, h, w = x.shape
+        xr, ld = _rows(x.detach().float())
+        out = torch.empty(n, c, dtype=torch.float32, device=x.device)
+        ws = torch.empty(n * 64 * c, dtype=torch.float32, device=x.device)          # kMeanChunks partial rows per image
+        lib.spatial_mean(xr, ld, h * w * ld, n, 0, 1, h * w, c, out, ws)
+        ctx.meta = (n, c, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n, c, h, w = ctx.meta
+        return (g * (1.0 / (h * w))).view(n, c, 1, 1).expand(n, c, h, w), None
+
+
 class TrainGraph:
     def __init__(self, model, lib=None, conv2d=None):
         """conv2d: the differentiable convolution `(x, weight, stride, pad, lib) -> y`; `HipConv2d.apply` unless a test
@@ -131,6 +196,7 @@ class TrainGraph:
         self.m = model
         self.lib = lib or model._lib or native.get()
         self._conv = conv2d or HipConv2d.apply
+        self._hip_ops = conv2d is None
         self.whole_plane_pooling_as_means = True      # False: avg_pool3d + interpolate, operator for operator as the reference
         # (with a substituted convolution the graph may run in fp64 / on the host: resampling then stays on torch too)
         self._upsample2x = (lambda x: HipUpsample2x.apply(x, self.lib)) if conv2d is None else (
@@ -154,9 +220,29 @@ class TrainGraph:
             if norm.momentum is None:
                 factor = 1.0 / float(norm.num_batches_tracked)
         use_batch = norm.training or (norm.running_mean is None and norm.running_var is None)
-        return F.batch_norm(x, norm.running_mean if not norm.training or norm.track_running_stats else None,
-                            norm.running_var if not norm.training or norm.track_running_stats else None, norm.weight, norm.bias,
-                            use_batch, factor, norm.eps)
+        stats = (norm.running_mean, norm.running_var) if not norm.training or norm.track_running_stats else (None, None)
+        # PyTorch's own BatchNorm kernels, not MIOpen's: the convolution outputs are pixel-major views (padded rows when the
+        # channel count is not a multiple of 8), and MIOpen's host code crashes on them for a single image (measured: B = 1)
+        with torch.backends.cudnn.flags(enabled=False):
+            return F.batch_norm(x, stats[0], stats[1], norm.weight, norm.bias, use_batch, factor, norm.eps)
+
+    def bn_act(self, x, norm, relu):
+        """BatchNorm in the module's own mode (+ ReLU): the HIP kernels, or torch's operators when the graph runs with a
+        substituted convolution (tests: fp64 / host evaluation)."""
+        if not self._hip_ops:
+            y = self.bn(x, norm)
+            return F.relu(y) if relu else y
+        factor = 0.0 if norm.momentum is None else norm.momentum
+        tracking = norm.track_running_stats and norm.running_mean is not None
+        if norm.training and tracking and norm.num_batches_tracked is not None:
+            norm.num_batches_tracked.add_(1)
+            if norm.momentum is None:
+                factor = 1.0 / float(norm.num_batches_tracked)
+        batch_stats = norm.training or not tracking
+        update = norm.training and tracking
+        return HipBatchNormAct.apply(x, norm.weight, norm.bias, norm.running_mean if (update or not batch_stats) else None,
+                                     norm.running_var if (update or not batch_stats) else None, batch_stats, factor, norm.eps, relu,
+                                     self.lib)
 
     def conv3d_frames(self, x, weight):
         """(B, C, T, H, W) x (Cout, Cin, kT, k, k) -> (B, Cout, T, H, W): `CausalConv3d`'s convolution (kT - 1 zero frames
@@ -184,10 +270,10 @@ class TrainGraph:
     def _unit3d(self, x, blk, b, t):
         """conv + BatchNorm3d + ReLU of a (1, 1, 1) block (temporal.py:107-117) or a `CausalConv3d` (temporal.py:65-85) on
         frames-major activations: BatchNorm3d's statistics over (B, T, H, W) are BatchNorm2d's over (B T, H, W)."""
-        return F.relu(self.bn(self._conv_frames(x, blk.conv.weight, b, t), blk.norm))
+        return self.bn_act(self._conv_frames(x, blk.conv.weight, b, t), blk.norm, relu=True)
 
     def _project3d(self, x, proj, b, t):
-        return self.bn(self._conv_frames(x, proj[0].weight, b, t), proj[1])
+        return self.bn_act(self._conv_frames(x, proj[0].weight, b, t), proj[1], relu=False)
 
     def _pyramid(self, x, pp, b, t):
         """`PyramidSpatioTemporalPooling` (temporal.py:167-215) on frames-major x -> list of (B T, C', H, W).  For the size
@@ -200,7 +286,7 @@ class TrainGraph:
         outs = []
         for size, branch in zip(pp.pool_sizes, pp.features):
             if tuple(size) == (2, h, w) and self.whole_plane_pooling_as_means:
-                per_frame = x.mean(dim=(2, 3)).view(b, t, c)
+                per_frame = (HipSpatialMean.apply(x, self.lib) if self._hip_ops else x.mean(dim=(2, 3))).view(b, t, c)
                 pooled = torch.cat([per_frame[:, :1], 0.5 * (per_frame[:, :-1] + per_frame[:, 1:]), per_frame[:, -1:]], dim=1)
                 y = self._unit3d(pooled.reshape(b * (t + 1), c, 1, 1), branch.conv_bn_relu, b, t + 1)
                 y = y.reshape(b, t + 1, -1)[:, :t].reshape(b * t, -1, 1, 1)
@@ -247,16 +333,16 @@ class TrainGraph:
     def bottleneck(self, x, blk):
         """fiery/layers/convolutions.py:64-168 (Dropout2d(p=0) is the identity)."""
         L = blk.layers
-        r = F.relu(self.bn(self.conv2d(x, L.conv_down_project), L.abn_down_project[0]))
-        r = F.relu(self.bn(self.conv2d(r, L.conv), L.abn[0]))
-        r = F.relu(self.bn(self.conv2d(r, L.conv_up_project), L.abn_up_project[0]))
+        r = self.bn_act(self.conv2d(x, L.conv_down_project), L.abn_down_project[0], relu=True)
+        r = self.bn_act(self.conv2d(r, L.conv), L.abn[0], relu=True)
+        r = self.bn_act(self.conv2d(r, L.conv_up_project), L.abn_up_project[0], relu=True)
         if blk.projection is None:
             return r + x
         skip = x
         if blk.downsample:
             # odd sizes are padded first so that the pooled skip meets the strided convolution's size (convolutions.py:160-162)
             skip = F.max_pool2d(F.pad(skip, (0, skip.shape[-1] % 2, 0, skip.shape[-2] % 2), value=0), 2, 2)
-        skip = self.bn(self.conv2d(skip, blk.projection.conv_skip_proj), blk.projection.bn_skip_proj)
+        skip = self.bn_act(self.conv2d(skip, blk.projection.conv_skip_proj), blk.projection.bn_skip_proj, relu=False)
         return r + skip
 
     def gru_cell(self, x, state, gru):
@@ -265,7 +351,7 @@ class TrainGraph:
         update = torch.sigmoid(self.conv2d(xs, gru.conv_update) + gru.gru_bias_init)
         reset = torch.sigmoid(self.conv2d(xs, gru.conv_reset) + gru.gru_bias_init)
         tilde = gru.conv_state_tilde
-        proposal = F.relu(self.bn(self.conv2d(torch.cat([x, (1.0 - reset) * state], dim=1), tilde.conv), tilde.norm))
+        proposal = self.bn_act(self.conv2d(torch.cat([x, (1.0 - reset) * state], dim=1), tilde.conv), tilde.norm, relu=True)
         return (1.0 - update) * state + update * proposal
 
     def future_prediction(self, x, hidden):
@@ -321,19 +407,19 @@ class TrainGraph:
 
     def basic_block(self, x, blk):
         """torchvision resnet BasicBlock (fiery/models/decoder.py:10-17)."""
-        out = F.relu(self.bn(self.conv2d(x, blk.conv1), blk.bn1))
-        out = self.bn(self.conv2d(out, blk.conv2), blk.bn2)
+        out = self.bn_act(self.conv2d(x, blk.conv1), blk.bn1, relu=True)
+        out = self.bn_act(self.conv2d(out, blk.conv2), blk.bn2, relu=False)
         if blk.downsample is not None:
-            x = self.bn(self.conv2d(x, blk.downsample[0]), blk.downsample[1])
+            x = self.bn_act(self.conv2d(x, blk.downsample[0]), blk.downsample[1], relu=False)
         return F.relu(out + x)
 
     def upsample_add(self, x, skip, up):
         """fiery/layers/convolutions.py:203-214."""
         x = self._upsample2x(x)
-        return self.bn(self.conv2d(x, up.upsample_layer[1]), up.upsample_layer[2]) + skip
+        return self.bn_act(self.conv2d(x, up.upsample_layer[1]), up.upsample_layer[2], relu=False) + skip
 
     def head(self, x, h):
-        y = F.relu(self.bn(self.conv2d(x, h[0]), h[1]))
+        y = self.bn_act(self.conv2d(x, h[0]), h[1], relu=True)
         y = self.conv2d(y, h[3])
         return torch.sigmoid(y) if len(h) > 4 else y
 
@@ -343,7 +429,7 @@ class TrainGraph:
         b, s, c, h, w = x.shape
         x = x.reshape(b * s, c, h, w)
         skip1 = x
-        x = F.relu(self.bn(self.conv2d(x, d.first_conv), d.bn1))
+        x = self.bn_act(self.conv2d(x, d.first_conv), d.bn1, relu=True)
         for blk in d.layer1:
             x = self.basic_block(x, blk)
         skip2 = x

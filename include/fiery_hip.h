@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FIERY_ABI_VERSION 10
+#define FIERY_ABI_VERSION 11
 
 #define FIERY_OK 0
 #define FIERY_EINVAL (-22)      /* bad argument (shape, alignment, null pointer) */
@@ -401,6 +401,23 @@ int fiery_scale_channels_nhwc(float* x, int ld, int n_img, int HW, int C, const 
 int fiery_upsample2x_add_nhwc(const float* in, int in_ld, int n_img, int H, int W, int C,
                               const float* shift, const float* skip, int skip_ld,
                               float* out, int out_ld, fiery_stream_t stream);
+
+/* BatchNorm with batch statistics (+ fused ReLU) on pixel-major rows - what `nn.BatchNorm2d / BatchNorm3d (+ nn.ReLU)` of the
+ * BEV stack compute in train() mode (layers/convolutions.py:27-34, 85-105; layers/temporal.py:77-84, 107-117; autograd's
+ * backward of the pair).  x: [n_pixels] rows of ld floats, C channels (all images and frames of the batch together).
+ * forward: batch_stats != 0: mean / biased variance over the rows, running_mean / running_var (may be NULL) updated with
+ *   `momentum` (unbiased variance), as torch does; batch_stats == 0: the running statistics are used.
+ *   y = [relu] ((x - mean) * invstd * gamma + beta), gamma / beta may be NULL (1 / 0); channels C .. C_store of y are written
+ *   as zeros.  mean, invstd: [C] outputs the backward pass takes.
+ * backward: y = the forward's output when it applied the ReLU (gates the gradient), else NULL.  grad_in, dgamma[C], dbeta[C].
+ * workspace: fiery_bn_workspace_floats(C) floats, 16-byte aligned; results are deterministic (fixed-order sums). */
+int64_t fiery_bn_workspace_floats(int C);
+int fiery_bn_train_fwd(const float* x, int ld, int64_t n_pixels, int C, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, int batch_stats, float momentum, float eps, int relu,
+                       float* y, int y_ld, int C_store, float* mean, float* invstd, float* workspace, fiery_stream_t stream);
+int fiery_bn_train_bwd(const float* grad_out, int g_ld, const float* x, int ld, const float* y, int y_ld, int64_t n_pixels,
+                       int C, const float* gamma, const float* mean, const float* invstd, int batch_stats, float* grad_in,
+                       int gi_ld, int C_store, float* dgamma, float* dbeta, float* workspace, fiery_stream_t stream);
 
 /* Gradient of the plain x2 interpolation (fiery_upsample2x_add_nhwc without shift / skip) with respect to its input -
  * what autograd computes for `nn.Upsample(scale_factor=2, mode='bilinear')` in layers/convolutions.py:203-214 (training).

@@ -293,7 +293,7 @@ def test_hip_conv2d_real_shapes_against_fp64(hip, cin, cout, k, stride, pad, hw)
 @pytest.mark.gpu
 def test_training_step_on_the_gpu_is_as_close_to_exact_as_fp32_torch(hip):
     """The kernels test of the CPU tier on the real kernels at a quarter-size BEV grid (104 x 104 - the decoder's x2 stages need a multiple of 8 -, full image size, six
-    cameras): the HIP training step against the fp64 evaluation of the same graph (host), bounded by the all-torch fp32
+    cameras): the HIP training step against the fp64 evaluation of the same graph (PyTorch-ROCm operators in double), bounded by the all-torch fp32
     evaluation's error."""
     from fiery_amd.config import get_preset_cfg
     from fiery_amd.model import Fiery
@@ -303,8 +303,8 @@ def test_training_step_on_the_gpu_is_as_close_to_exact_as_fp32_torch(hip):
     state = {k: v.clone() for k, v in randomise_weights(model).items()}
     inputs = forward_case(cfg, model.receptive_field, model.n_future, model.depth_channels, model.bev_size, 1, 6, with_labels=True,
                           with_noise=True)
-    exact = graph_step(cfg, state, hip, _torch_conv, torch.float64, *inputs, device='cpu', pool_device='cuda')
-    torch32 = graph_step(cfg, state, hip, _torch_conv, torch.float32, *inputs, device='cpu', pool_device='cuda')
+    exact = graph_step(cfg, state, hip, _torch_conv, torch.float64, *inputs, device='cuda')
+    torch32 = graph_step(cfg, state, hip, _torch_conv, torch.float32, *inputs, device='cuda')
     got = graph_step(cfg, state, hip, None, torch.float32, *inputs, device='cuda')
     assert as_close_to_exact_as_fp32_torch(got, torch32, exact, 'train_step[baseline 104x104 B1]') > 100
 
@@ -343,4 +343,47 @@ def test_full_size_training_steps_reduce_the_loss(hip):
     with torch.no_grad():
         a = model(image, K, E, ego, None, torch.zeros(B, 1, model.latent_dim, device='cuda'))
         b = model(image, K, E, ego, None, torch.zeros(B, 1, model.latent_dim, device='cuda'))
-    assert all(torch.equal(a[k], b[k]) for k in a if a[k] is not None)
+    # (bit-equal is not on offer: the pooling kernel merges runs with LDS atomics, whose order is free)
+    assert all(torch.allclose(a[k], b[k], rtol=1e-4, atol=1e-4) for k in a if a[k] is not None)
+
+
+@pytest.mark.parametrize('c,relu,training,padded', [(64, True, True, False), (35, True, True, True), (35, False, True, True), (6, True, True, False),
+                                                    (64, True, False, False), (21, False, False, True), (256, False, True, False)])
+def test_hip_batchnorm_act_matches_torch(sim, c, relu, training, padded):
+    """`HipBatchNormAct` (forward, running-statistics update, all three gradients) against F.batch_norm (+ relu): dense rows,
+    rows padded to a multiple of 8 (a convolution output read in place) and a plain NCHW tensor."""
+    from fiery_amd.train_graph import HipBatchNormAct
+    g = torch.Generator().manual_seed(c)
+    n, h, w = 3, 5, 7
+    base = torch.randn(n, c, h, w, generator=g) * 2.0 + 3.0
+    if padded:
+        store = torch.full((n, h, w, (c + 7) // 8 * 8), 7.0)
+        store[..., :c] = base.permute(0, 2, 3, 1)
+        x = store[..., :c].permute(0, 3, 1, 2).requires_grad_()
+    else:
+        x = base.clone().requires_grad_()
+    x_ref = base.clone().requires_grad_()
+    weight, bias = (torch.rand(c, generator=g) + 0.5).requires_grad_(), torch.randn(c, generator=g).requires_grad_()
+    w_ref, b_ref = weight.detach().clone().requires_grad_(), bias.detach().clone().requires_grad_()
+    rm, rv = torch.randn(c, generator=g), torch.rand(c, generator=g) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y = HipBatchNormAct.apply(x, weight, bias, rm, rv, training, 0.1, 1e-5, relu, sim)
+    ref = F.batch_norm(x_ref, rm_ref, rv_ref, w_ref, b_ref, training, 0.1, 1e-5)
+    ref = F.relu(ref) if relu else ref
+    assert torch.allclose(y, ref, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(rm, rm_ref, rtol=1e-5, atol=1e-6) and torch.allclose(rv, rv_ref, rtol=1e-5, atol=1e-6)
+    gy = torch.randn(ref.shape, generator=g)
+    got = torch.autograd.grad(y, (x, weight, bias), gy)
+    want = torch.autograd.grad(ref, (x_ref, w_ref, b_ref), gy)
+    for a, b in zip(got, want):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * max(1.0, b.abs().max().item())), (a - b).abs().max()
+
+
+def test_hip_spatial_mean_and_its_gradient(sim):
+    from fiery_amd.train_graph import HipSpatialMean
+    x = torch.randn(4, 70, 9, 11, generator=torch.Generator().manual_seed(0)).contiguous(memory_format=torch.channels_last).requires_grad_()
+    y = HipSpatialMean.apply(x, sim)
+    assert torch.allclose(y, x.mean(dim=(2, 3)), rtol=1e-5, atol=1e-6)
+    gy = torch.randn(4, 70)
+    (got,), (want,) = torch.autograd.grad(y, x, gy), torch.autograd.grad(x.mean(dim=(2, 3)), x, gy)
+    assert torch.allclose(got, want, rtol=1e-6, atol=1e-7)
