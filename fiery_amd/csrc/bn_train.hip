@@ -21,7 +21,7 @@ namespace fiery {
 namespace {
 
 constexpr int kBnThreads = 256;
-constexpr int kBnMaxBlocks = 1024;          // partial rows (workspace contract: see fiery_bn_workspace_floats)
+constexpr int kBnMaxBlocks = 512;          // partial rows (workspace contract: see fiery_bn_workspace_floats)
 
 // thread layout: c4 = t % groups (a float4 of channels), r = t / groups (pixel lane); `rows` pixel lanes per block
 struct BnShape {
@@ -107,17 +107,39 @@ __global__ __launch_bounds__(kBnThreads) void k_bn_partial_stats(const float* __
     }
 }
 
-// pass 2: totals in a fixed order -> mean, invstd (and the running statistics, torch's update rule)
-__global__ void k_bn_finish_stats(const float* __restrict__ x, const float* __restrict__ partial, int blocks, int Cp, int C, long long P,
-                                  float eps, float momentum, float* __restrict__ mean, float* __restrict__ invstd,
-                                  float* __restrict__ running_mean, float* __restrict__ running_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < blocks; ++b) {
-        s1 += partial[static_cast<long long>(b) * 2 * Cp + c];
-        s2 += partial[static_cast<long long>(b) * 2 * Cp + Cp + c];
+// sum of partial[b][which][c] over the partial rows b, by one 64-lane group per channel: lane l adds rows l, l + 64, ...
+// in double, the 64 lane sums are added in lane order by lane 0 (fixed order: deterministic)
+__device__ __forceinline__ void sum_partials(const float* __restrict__ partial, int blocks, int Cp, int c, int lane, int grp,
+                                             double (*lds)[2][64], double& s1, double& s2) {
+    double a = 0.0, b = 0.0;
+    for (int r = lane; r < blocks; r += 64) {
+        a += partial[static_cast<long long>(r) * 2 * Cp + c];
+        b += partial[static_cast<long long>(r) * 2 * Cp + Cp + c];
     }
+    lds[grp][0][lane] = a;
+    lds[grp][1][lane] = b;
+    __syncthreads();
+    s1 = 0.0;
+    s2 = 0.0;
+    if (lane == 0)
+        for (int l = 0; l < 64; ++l) {
+            s1 += lds[grp][0][l];
+            s2 += lds[grp][1][l];
+        }
+}
+
+// pass 2: totals in a fixed order -> mean, invstd (and the running statistics, torch's update rule); 4 channels per block
+__global__ __launch_bounds__(256) void k_bn_finish_stats(const float* __restrict__ x, const float* __restrict__ partial, int blocks,
+                                                         int Cp, int C, long long P, float eps, float momentum,
+                                                         float* __restrict__ mean, float* __restrict__ invstd,
+                                                         float* __restrict__ running_mean, float* __restrict__ running_var) {
+    __shared__ double lds[4][2][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int c = blockIdx.x * 4 + grp;
+    const int cc = c < C ? c : C - 1;                            // (spare groups repeat the last channel and drop the result)
+    double s1, s2;
+    sum_partials(partial, blocks, Cp, cc, lane, grp, lds, s1, s2);
+    if (lane != 0 || c >= C) return;
     const double n = static_cast<double>(P);
     const double d = s1 / n;
     double var = s2 / n - d * d;
@@ -214,15 +236,15 @@ __global__ __launch_bounds__(kBnThreads) void k_bn_bwd_partial(const float* __re
     }
 }
 
-__global__ void k_bn_bwd_finish(const float* __restrict__ partial, int blocks, int Cp, int C, float* __restrict__ dgamma,
-                                float* __restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < blocks; ++b) {
-        s1 += partial[static_cast<long long>(b) * 2 * Cp + c];
-        s2 += partial[static_cast<long long>(b) * 2 * Cp + Cp + c];
-    }
+__global__ __launch_bounds__(256) void k_bn_bwd_finish(const float* __restrict__ partial, int blocks, int Cp, int C,
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ double lds[4][2][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int c = blockIdx.x * 4 + grp;
+    const int cc = c < C ? c : C - 1;
+    double s1, s2;
+    sum_partials(partial, blocks, Cp, cc, lane, grp, lds, s1, s2);
+    if (lane != 0 || c >= C) return;
     dbeta[c] = static_cast<float>(s1);
     dgamma[c] = static_cast<float>(s2);
 }
@@ -290,7 +312,7 @@ extern "C" int fiery_bn_train_fwd(const float* x, int ld, int64_t n_pixels, int 
     if (batch_stats) {
         hipLaunchKernelGGL(k_bn_partial_stats, dim3(s.blocks), dim3(kBnThreads), 0, hs, x, ld, static_cast<long long>(n_pixels), C, vec, s,
                            Cp, workspace);
-        hipLaunchKernelGGL(k_bn_finish_stats, dim3(ceil_div(C, 64)), dim3(64), 0, hs, x, workspace, s.blocks, Cp, C,
+        hipLaunchKernelGGL(k_bn_finish_stats, dim3(ceil_div(C, 4)), dim3(256), 0, hs, x, workspace, s.blocks, Cp, C,
                            static_cast<long long>(n_pixels), eps, momentum, mean, invstd, running_mean, running_var);
     } else {
         hipLaunchKernelGGL(k_bn_running_stats, dim3(ceil_div(C, 64)), dim3(64), 0, hs, running_mean, running_var, C, eps, mean, invstd);
@@ -316,7 +338,7 @@ extern "C" int fiery_bn_train_bwd(const float* grad_out, int g_ld, const float* 
     const int vec = rows_vec(x, ld, C) ? 1 : 0, g_vec = rows_vec(grad_out, g_ld, C) ? 1 : 0, y_vec = (y && rows_vec(y, y_ld, C)) ? 1 : 0;
     hipLaunchKernelGGL(k_bn_bwd_partial, dim3(s.blocks), dim3(kBnThreads), 0, hs, grad_out, g_ld, g_vec, x, ld, vec, y, y_ld, y_vec,
                        static_cast<long long>(n_pixels), C, mean, invstd, s, Cp, workspace);
-    hipLaunchKernelGGL(k_bn_bwd_finish, dim3(ceil_div(C, 64)), dim3(64), 0, hs, workspace, s.blocks, Cp, C, dgamma, dbeta);
+    hipLaunchKernelGGL(k_bn_bwd_finish, dim3(ceil_div(C, 4)), dim3(256), 0, hs, workspace, s.blocks, Cp, C, dgamma, dbeta);
     const int groups_out = (C_store + 3) / 4;
     const int dx_vec = (C_store % 4 == 0 && gi_ld % 4 == 0 && aligned16(grad_in)) ? 1 : 0;
     const long long total = static_cast<long long>(n_pixels) * groups_out;

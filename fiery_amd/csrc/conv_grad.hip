@@ -4,13 +4,15 @@
 // fiery/layers/convolutions.py:9-168, fiery/layers/temporal.py:10-62, fiery/models/decoder.py:53-91):
 //   dW[cout][tap][c] = sum over output pixels p of  dY[p][cout] * X[p * stride + tap - pad][c]
 // - a GEMM whose reduction dimension is the PIXELS (120,000 per GRU layer) and whose result is small (cout x taps x cin).
-// Mapping to CDNA4: v_mfma_f32_32x32x2_f32 with k = two neighbouring output pixels of a row; a workgroup owns a
-// (64 couts) x (one tap, 64 input channels) block of dW and a share of the output rows, its four wavefronts take rows
-// round-robin, add their accumulators up through LDS and hand the block to HBM with fp32 atomics (the caller zeroes dW;
-// the order of those additions moves the last bits from run to run).  Both operands are read pixel-major (NHWC) straight
-// from global memory: a lane's two couts (or channels) of a pixel are 128 bytes apart in the same row, so a wavefront load
-// is two full 128-byte lines per pixel - no staging needed for a kernel that is far from the critical path of a training
-// step (the data gradient reuses the forward kernel with transposed, mirrored weights: fiery_amd/train_graph.py).
+// Mapping to CDNA4: v_mfma_f32_32x32x2_f32 with k = two neighbouring output pixels of a row; a wavefront owns a
+// (64 couts) x (one tap, 64 input channels) block of dW over a share of the output rows and hands it to HBM with fp32
+// atomics (the caller zeroes dW; the order of those additions moves the last bits from run to run).  Both operands are
+// read pixel-major (NHWC) straight from global memory: a lane's two couts (or channels) of a pixel are 128 bytes apart in
+// the same row, so a wavefront load is two full 128-byte lines per pixel.  At 16 flop per loaded byte the loop would need
+// ~10 TB/s from L2 to keep the matrix cores busy, so the four wavefronts of a workgroup take NEIGHBOURING blocks - the
+// taps of one (cout tile, channel tile) - over the SAME rows: they read the same dY lines and overlapping X lines within
+// a few hundred cycles of each other, and three of four requests are served by the CU's vector cache.
+// (The data gradient reuses the forward kernel with transposed, mirrored weights: fiery_amd/train_graph.py.)
 #include "common.h"
 
 #include <cstdlib>
@@ -27,16 +29,23 @@ struct WgradP {
     long long x_istride, g_istride;
     int x_ld, g_ld, cin_pad, cout;
     int n_img, Hin, Win, Hout, Wout, kH, kW, stride, padH, padW;
-    int c_tiles;            // 64-channel tiles per tap
+    int c_tiles, co_tiles;  // 64-channel tiles per tap, 64-cout tiles
 };
 
-// grid (cout tiles of 64, taps * c_tiles, row shares); 256 threads
+// blocks q = (cout tile, channel tile, tap), taps fastest; grid (ceil(Q / per_wg), 1, row shares); 256 threads.
+// per_wg = min(4, Q) blocks per workgroup, one per wavefront; with fewer than four blocks the spare wavefronts split rows.
 __global__ __launch_bounds__(256) void k_conv_wgrad(WgradP p) {
-    __shared__ float red[4][64 * 64 / 4];                   // one quarter of the 64 x 64 block per pass, four wavefronts
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = lane & 31, kk = lane >> 5;
-    const int co0 = blockIdx.x * 64;
-    const int tap = blockIdx.y / p.c_tiles, c0 = (blockIdx.y - tap * p.c_tiles) * 64;
+    const int taps = p.kH * p.kW;
+    const int Q = p.co_tiles * p.c_tiles * taps;
+    const int per_wg = Q < 4 ? Q : 4;
+    const int n_sub = 4 / per_wg;                            // row sub-shares inside the workgroup
+    const int slot = wave % per_wg, sub = wave / per_wg;
+    const int q = blockIdx.x * per_wg + slot;
+    if (q >= Q || sub >= n_sub) return;
+    const int tap = q % taps, ct = (q / taps) % p.c_tiles, cot = q / (taps * p.c_tiles);
+    const int co0 = cot * 64, c0 = ct * 64;
     const int dy = tap / p.kW, dx = tap - dy * p.kW;
     const int n_rows = p.n_img * p.Hout;
     v16f acc[2][2];
@@ -48,50 +57,48 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradP p) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     const bool co_ok[2] = {co0 + m < p.cout, co0 + 32 + m < p.cout};
     const bool c_ok[2] = {c0 + m < p.cin_pad, c0 + 32 + m < p.cin_pad};
-    // output rows (image, y) of this workgroup's share, dealt to its wavefronts
-    for (int row = blockIdx.z * 4 + wave; row < n_rows; row += gridDim.z * 4) {
+    const int row_step = gridDim.z * n_sub;
+    for (int row = blockIdx.z * n_sub + sub; row < n_rows; row += row_step) {
         const int img = row / p.Hout, y = row - img * p.Hout;
         const int iy = y * p.stride + dy - p.padH;
         if (iy < 0 || iy >= p.Hin) continue;                // the tap looks at the zero padding: nothing to add
         const float* grow = p.g + img * p.g_istride + static_cast<long long>(y) * p.Wout * p.g_ld + co0 + m;
         const float* xrow = p.x + img * p.x_istride + static_cast<long long>(iy) * p.Win * p.x_ld + c0 + m;
-        for (int x0 = 0; x0 < p.Wout; x0 += 2) {
-            const int x = x0 + kk;                          // this lane's pixel of the pair
-            const int ix = x * p.stride + dx - p.padW;
-            const bool px_ok = x < p.Wout;
-            const bool in_ok = px_ok && ix >= 0 && ix < p.Win;
-            float a[2], b[2];
+        // two pixel pairs per trip: eight loads in flight before the first of eight MFMAs
+        for (int x0 = 0; x0 < p.Wout; x0 += 4) {
+            float a[2][2], b[2][2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                a[t] = (px_ok && co_ok[t]) ? grow[static_cast<long long>(x) * p.g_ld + 32 * t] : 0.f;
-                b[t] = (in_ok && c_ok[t]) ? xrow[static_cast<long long>(ix) * p.x_ld + 32 * t] : 0.f;
+            for (int h = 0; h < 2; ++h) {
+                const int x = x0 + 2 * h + kk;                  // this lane's pixel of the pair
+                const int ix = x * p.stride + dx - p.padW;
+                const bool px_ok = x < p.Wout;
+                const bool in_ok = px_ok && ix >= 0 && ix < p.Win;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    a[h][t] = (px_ok && co_ok[t]) ? grow[static_cast<long long>(x) * p.g_ld + 32 * t] : 0.f;
+                    b[h][t] = (in_ok && c_ok[t]) ? xrow[static_cast<long long>(ix) * p.x_ld + 32 * t] : 0.f;
+                }
             }
 #pragma unroll
-            for (int ta = 0; ta < 2; ++ta)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int tb = 0; tb < 2; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+                for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < 2; ++tb)
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[h][ta], b[h][tb], acc[ta][tb], 0, 0, 0);
         }
     }
-    // the four wavefronts' blocks -> one, a 32 x 32 quarter at a time; then one atomic per element and workgroup
-    const int taps = p.kH * p.kW;
+    // the block goes out from the accumulators: for a fixed register the 32 lanes of a half hold 32 consecutive channels
 #pragma unroll
     for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb) {
-            __syncthreads();
+            const int c = c0 + 32 * tb + m;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int rowm = (r & 3) + 8 * (r >> 2) + 4 * kk;
-                red[wave][rowm * 32 + m] = acc[ta][tb][r];
-            }
-            __syncthreads();
-            for (int e = threadIdx.x; e < 32 * 32; e += 256) {
-                const int rowm = e >> 5, col = e & 31;
-                const int co = co0 + 32 * ta + rowm, c = c0 + 32 * tb + col;
-                if (co < p.cout && c < p.cin_pad) {
-                    const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
-                    if (v != 0.f) atomicAdd(&p.dw[(static_cast<long long>(co) * taps + tap) * p.cin_pad + c], v);
-                }
+                const int co = co0 + 32 * ta + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                const float v = acc[ta][tb][r];
+                if (co < p.cout && c < p.cin_pad && v != 0.f) atomicAdd(&p.dw[(static_cast<long long>(co) * taps + tap) * p.cin_pad + c], v);
             }
         }
 }
@@ -118,17 +125,21 @@ extern "C" int fiery_conv_wgrad(const float* in, int in_ld, int64_t in_img_strid
     p.n_img = n_img;  p.Hin = Hin;  p.Win = Win;  p.Hout = Hout;  p.Wout = Wout;
     p.kH = kH;  p.kW = kW;  p.stride = stride;  p.padH = padH;  p.padW = padW;
     p.c_tiles = ceil_div(p.cin_pad, 64);
+    p.co_tiles = ceil_div(cout, 64);
     const int n_rows = n_img * Hout;
-    // enough row shares to fill the chip (256 CUs x a few workgroups) without leaving a share fewer than four rows
-    const int blocks_xy = ceil_div(cout, 64) * kH * kW * p.c_tiles;
+    // enough row shares to fill the chip (256 CUs x a few workgroups) without leaving a wavefront fewer than two rows
+    const long long Q = static_cast<long long>(p.co_tiles) * p.c_tiles * kH * kW;
+    const int per_wg = Q < 4 ? static_cast<int>(Q) : 4;
+    const int n_sub = 4 / per_wg;
+    const int wgs_q = ceil_div(Q, per_wg);
     static const int target_wgs = [] {
         const char* e = getenv("FIERY_WGRAD_WGS");
         return e && atoi(e) > 0 ? atoi(e) : 2048;
     }();
-    int shares = ceil_div(target_wgs, blocks_xy);
-    if (shares > ceil_div(n_rows, 4)) shares = ceil_div(n_rows, 4);
+    int shares = ceil_div(target_wgs, wgs_q);
+    if (shares > ceil_div(n_rows, 2 * n_sub)) shares = ceil_div(n_rows, 2 * n_sub);
     if (shares < 1) shares = 1;
-    FIERY_REQUIRE(static_cast<long long>(kH) * kW * p.c_tiles < 65536 && shares < 65536, "conv_wgrad: grid too large");
-    hipLaunchKernelGGL(k_conv_wgrad, dim3(ceil_div(cout, 64), kH * kW * p.c_tiles, shares), dim3(256), 0, as_stream(stream), p);
+    FIERY_REQUIRE(wgs_q < (1 << 30) && shares < 65536, "conv_wgrad: grid too large");
+    hipLaunchKernelGGL(k_conv_wgrad, dim3(wgs_q, 1, shares), dim3(256), 0, as_stream(stream), p);
     return check_launch("conv_wgrad");
 }

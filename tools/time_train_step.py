@@ -1,7 +1,9 @@
 """Time one training step (forward + backward of the BEV path from the lifted features) on the GPU, with the per-operator
 split: python tools/time_train_step.py [--preset baseline.yml] [--batch 2] [--steps 5] [--torch-conv]
 
---torch-conv substitutes PyTorch-ROCm's convolution (MIOpen) for `HipConv2d` in the same graph - the comparison leg.
+--torch-conv substitutes PyTorch-ROCm's operators (MIOpen convolution, ATen BatchNorm / interpolate) for the HIP ones in the
+same graph; --reference-ops additionally takes the pyramid pooling operator for operator as the reference does (avg_pool3d +
+interpolate) - the step the reference's own modules run on this GPU.
 Prints one JSON line.
 """
 import argparse
@@ -23,7 +25,11 @@ def main():
     ap.add_argument('--cams', type=int, default=6)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--torch-conv', action='store_true')
+    ap.add_argument('--reference-ops', action='store_true',
+                    help="the reference's own operator sequence on PyTorch-ROCm: MIOpen convolutions, avg_pool3d + interpolate for the "
+                         'pyramid pooling, F.interpolate for the decoder (implies --torch-conv)')
     ap.add_argument('--profile', action='store_true', help='torch profiler table of one step')
+    ap.add_argument('--ops', action='store_true', help='with --profile: also the operator table grouped by input shape')
     args = ap.parse_args()
     from fiery_amd.config import get_preset_cfg
     from fiery_amd.model import Fiery
@@ -40,8 +46,9 @@ def main():
     _, _, lifted = make_lifted_features(B * rf * n, model.encoder_out_channels, model.depth_channels, (fh, fw), seed=1)
     lifted = lifted.view(B, rf, n, model.encoder_out_channels, model.depth_channels, fh, fw).cuda().requires_grad_()
     labels = torch.randn(B, 1 + model.n_future, 6, *model.bev_size, device='cuda') if model.n_future > 0 else None
-    conv = (lambda x, w, s, p, lib: F.conv2d(x, w, None, s, p)) if args.torch_conv else None
+    conv = (lambda x, w, s, p, lib: F.conv2d(x, w, None, s, p)) if (args.torch_conv or args.reference_ops) else None
     graph = TrainGraph(model, conv2d=conv)
+    graph.whole_plane_pooling_as_means = not args.reference_ops
     params = [p for name, p in model.named_parameters() if not name.startswith('encoder.')]
     opt = torch.optim.SGD(params, lr=1e-4)
 
@@ -62,7 +69,7 @@ def main():
         step()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / args.steps * 1e3
-    line = dict(tool='time_train_step', preset=args.preset, batch=B, cams=n, conv='torch(MIOpen)' if args.torch_conv else 'hip',
+    line = dict(tool='time_train_step', preset=args.preset, batch=B, cams=n, conv='reference operator sequence (MIOpen / ATen)' if args.reference_ops else 'torch(MIOpen)' if args.torch_conv else 'hip',
                 ms_per_step=round(ms, 2), samples_per_s=round(B / ms * 1e3, 2), peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 2))
     if args.profile:
         from torch.profiler import ProfilerActivity, profile
@@ -70,6 +77,12 @@ def main():
             step()
             torch.cuda.synchronize()
         print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=25), file=sys.stderr)
+        if args.ops:
+            with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+                step()
+                torch.cuda.synchronize()
+            print(prof.key_averages(group_by_input_shape=True).table(sort_by='self_cuda_time_total', row_limit=45, max_name_column_width=40,
+                                                                     max_shapes_column_width=70), file=sys.stderr)
     print(json.dumps(line))
 
 
