@@ -62,11 +62,20 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradP p) {
         const int img = row / p.Hout, y = row - img * p.Hout;
         const int iy = y * p.stride + dy - p.padH;
         if (iy < 0 || iy >= p.Hin) continue;                // the tap looks at the zero padding: nothing to add
-        const float* grow = p.g + img * p.g_istride + static_cast<long long>(y) * p.Wout * p.g_ld + co0 + m;
-        const float* xrow = p.x + img * p.x_istride + static_cast<long long>(iy) * p.Win * p.x_ld + c0 + m;
-        // two pixel pairs per trip: eight loads in flight before the first of eight MFMAs
-        for (int x0 = 0; x0 < p.Wout; x0 += 4) {
-            float a[2][2], b[2][2];
+        // the two rows as buffers of their own (wave-uniform bases, 32-bit lane offsets): a lane whose pixel, cout or channel
+        // is outside gets an offset past the descriptor and reads 0 - no branch around any load, so the loads of a trip are a
+        // fixed count the hardware counter (vmcnt) can be waited on partially
+        const __amdgpu_buffer_rsrc_t grow = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.g + img * p.g_istride + static_cast<long long>(y) * p.Wout * p.g_ld), 0, p.Wout * p.g_ld * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t xrow = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.x + img * p.x_istride + static_cast<long long>(iy) * p.Win * p.x_ld), 0, p.Win * p.x_ld * 4, 0x00020000);
+        constexpr int kOutside = static_cast<int>(0x80000000u);
+        const int g_lane[2] = {co_ok[0] ? (co0 + m) * 4 : kOutside, co_ok[1] ? (co0 + 32 + m) * 4 : kOutside};
+        const int x_lane[2] = {c_ok[0] ? (c0 + m) * 4 : kOutside, c_ok[1] ? (c0 + 32 + m) * 4 : kOutside};
+        // two pixel pairs per trip, and the operands of trip i + 1 are requested before the eight MFMAs of trip i: with
+        // three wavefronts per SIMD a wavefront has to cover most of its own memory latency
+        float a[2][2], b[2][2];
+        auto request = [&](int x0, float (&fa)[2][2], float (&fb)[2][2]) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int x = x0 + 2 * h + kk;                  // this lane's pixel of the pair
@@ -75,10 +84,17 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradP p) {
                 const bool in_ok = px_ok && ix >= 0 && ix < p.Win;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    a[h][t] = (px_ok && co_ok[t]) ? grow[static_cast<long long>(x) * p.g_ld + 32 * t] : 0.f;
-                    b[h][t] = (in_ok && c_ok[t]) ? xrow[static_cast<long long>(ix) * p.x_ld + 32 * t] : 0.f;
+                    const int go = (px_ok && g_lane[t] != kOutside) ? x * p.g_ld * 4 + g_lane[t] : kOutside;
+                    const int xo = (in_ok && x_lane[t] != kOutside) ? ix * p.x_ld * 4 + x_lane[t] : kOutside;
+                    fa[h][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grow, go, 0, 0));
+                    fb[h][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrow, xo, 0, 0));
                 }
             }
+        };
+        request(0, a, b);
+        for (int x0 = 0; x0 < p.Wout; x0 += 4) {
+            float na[2][2], nb[2][2];
+            request(x0 + 4, na, nb);                             // past the row's end every predicate is false: zeros, no access
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -86,6 +102,13 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradP p) {
 #pragma unroll
                     for (int tb = 0; tb < 2; ++tb)
                         acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[h][ta], b[h][tb], acc[ta][tb], 0, 0, 0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    a[h][t] = na[h][t];
+                    b[h][t] = nb[h][t];
+                }
         }
     }
     // the block goes out from the accumulators: for a fixed register the 32 lanes of a half hold 32 consecutive channels

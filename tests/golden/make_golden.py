@@ -140,6 +140,100 @@ def golden_forward(name, cfg, B, n_cam, sub, with_labels=False, with_noise=False
     return {k: (None if v is None else tuple(v.shape)) for k, v in got.items()}
 
 
+def training_cases():
+    """The seeded inputs of the training fixtures - shared with the tests that replay them."""
+    g = torch.Generator().manual_seed(2024)
+    return dict(
+        bottleneck=dict(x=torch.randn(2, 64, 24, 24, generator=g), gy=torch.randn(2, 64, 24, 24, generator=g)),
+        bottleneck_down=dict(x=torch.randn(2, 70, 25, 25, generator=g), gy=torch.randn(2, 35, 13, 13, generator=g)),
+        gru=dict(x=torch.randn(2, 3, 32, 20, 20, generator=g), h=torch.randn(2, 64, 20, 20, generator=g),
+                 gy=torch.randn(2, 3, 64, 20, 20, generator=g)))
+
+
+def _grads(module, inputs, out, gy):
+    names, params = zip(*module.named_parameters())
+    grads = torch.autograd.grad(out, list(inputs) + list(params), gy)
+    res = {f'd_input{i}': g.numpy() for i, g in enumerate(grads[:len(inputs)])}
+    res.update({'d_' + n: g.numpy() for n, g in zip(names, grads[len(inputs):])})
+    return res
+
+
+def golden_training_blocks():
+    """Forward + autograd of the reference's own modules in train() mode: one Bottleneck (identity skip), one down-sampling
+    Bottleneck with 70 -> 35 channels on an odd-sized map (the future-distribution encoder's first block), one SpatialGRU over
+    three steps.  Weights: the seeded `randomise_weights`; stored: outputs, input gradients, every parameter's gradient and
+    the BatchNorm running statistics after the step."""
+    ref = load_reference()
+    cases = training_cases()
+    out = {}
+    for name, module, args in (
+            ('bottleneck', ref.convolutions.Bottleneck(64), ('x',)),
+            ('bottleneck_down', ref.convolutions.Bottleneck(70, 35, downsample=True), ('x',)),
+            ('gru', ref.temporal.SpatialGRU(32, 64), ('x', 'h'))):
+        torch.manual_seed(0)
+        randomise_weights(module)
+        module.train()
+        inputs = [cases[name][a].clone().requires_grad_() for a in args]
+        y = module(*inputs)
+        res = _grads(module, inputs, y, cases[name]['gy'])
+        res['y'] = y.detach().numpy()
+        for k, v in module.state_dict().items():
+            if k.endswith(('running_mean', 'running_var')):
+                res['after_' + k] = v.numpy()
+        out.update({f'{name}.{k}': v for k, v in res.items()})
+    np.savez_compressed(os.path.join(OUT, 'train_blocks.npz'), **out)
+
+
+def training_model_case():
+    cfg = tiny_cfg('baseline.yml', bev=48, **{'MODEL.FUTURE_PRED.N_GRU_BLOCKS': 1, 'MODEL.FUTURE_PRED.N_RES_LAYERS': 1, 'N_FUTURE_FRAMES': 2})
+    return cfg, 2, 2
+
+
+def training_loss(out):
+    g = torch.Generator().manual_seed(123)
+    total = 0.0
+    for k in sorted(out):
+        if out[k] is not None:
+            total = total + (out[k] * torch.randn(out[k].shape, generator=g).to(out[k])).sum()
+    return total
+
+
+def golden_training_model():
+    """One training step of the reference's `Fiery` in train() mode from the lifted features (tiny configuration, 48 x 48 BEV,
+    B = 2): outputs, d loss / d lifted (sub-sampled), and per parameter tensor of the BEV stack two numbers - the gradient's
+    norm and its projection on a seeded random direction - plus the same from a second run whose input was perturbed by 1e-6
+    (relative): how much of each number is conditioning of the step itself."""
+    ref = load_reference()
+    cfg, B, n_cam = training_model_case()
+    res = {}
+    for tag, eps in (('', 0.0), ('nudged_', 1e-6)):
+        torch.manual_seed(0)
+        model = ref.Fiery(cfg)
+        randomise_weights(model)
+        model.train()
+        lifted, K, E, ego, labels, noise = forward_case(cfg, model.receptive_field, model.n_future, model.depth_channels, model.bev_size,
+                                                        B, n_cam, with_labels=True, with_noise=True)
+        lifted = lifted * (1.0 + eps * torch.randn(lifted.shape, generator=torch.Generator().manual_seed(77)))
+        leaf = lifted.clone().requires_grad_()
+        S, n = lifted.shape[1:3]
+        flat = leaf.reshape(B * S, n, *lifted.shape[3:]).permute(0, 1, 3, 4, 5, 2)
+        model.encoder_forward = lambda x: flat
+        out = model(torch.zeros(B, K.shape[1], n, 3, 2, 2), K, E, ego, labels, noise)
+        training_loss(out).backward()
+        if not tag:
+            for k, v in out.items():
+                if v is not None:
+                    res['out_' + k] = v.detach().numpy()
+        res[tag + 'd_lifted_sub'] = leaf.grad.numpy()[..., ::2, ::3]
+        g = torch.Generator().manual_seed(5)
+        for name, p in model.named_parameters():
+            if p.grad is None or name.startswith('encoder.'):
+                continue
+            direction = torch.randn(p.shape, generator=g)
+            res[tag + 'g_' + name] = np.array([p.grad.norm().item(), (p.grad * direction).sum().item()], dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, 'train_model_tiny.npz'), **res)
+
+
 if __name__ == '__main__':
     golden_index_path()
     golden_pooling_small()
@@ -148,6 +242,8 @@ if __name__ == '__main__':
     print(golden_forward('tiny_static', tiny_cfg('literature/static_lss_setting.yml'), 1, 2, 1))
     print(golden_forward('baseline_b1', get_preset_cfg('baseline.yml'), 1, 6, SUB))
     print(golden_forward('static_lss_1cam', get_preset_cfg('literature/static_lss_setting.yml'), 1, 1, SUB))
+    golden_training_blocks()
+    golden_training_model()
     for f in sorted(os.listdir(OUT)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -280,6 +280,12 @@ inline hipsim_v2u __builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rsrc_t r,
         __builtin_memcpy(&v, r.base + static_cast<unsigned>(voff) + static_cast<long long>(soff), 8);
     return v;
 }
+inline unsigned __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
+    unsigned v = 0;
+    if (static_cast<unsigned long long>(static_cast<unsigned>(voff)) + 4ull <= r.num)
+        __builtin_memcpy(&v, r.base + static_cast<unsigned>(voff) + static_cast<long long>(soff), 4);
+    return v;
+}
 inline unsigned long long clock64() { return 0; }
 inline unsigned long long wall_clock64() { return 0; }
 // instruction-scheduling hints have no effect on results

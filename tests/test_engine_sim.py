@@ -97,12 +97,16 @@ def test_future_distribution_with_labels(sim):
     assert torch.allclose(got['future_log_sigma'], flog, atol=1e-4)
 
 
-def test_training_mode_and_cpu_without_library_raise():
+def test_cpu_without_library_raises_in_both_modes_and_graph_replay_needs_eval():
+    """No CPU fallback: a model on the host raises in train() and in eval() mode alike; the hipGraph replay entry points
+    serve the folded inference plan only."""
     cfg = tiny_cfg('baseline.yml')
     model = Fiery(cfg)
     _, K, E, ego = make_inputs(1, 7, 2, with_image=False)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        model.bev_forward(torch.zeros(1, 3, 2, 64, 4, 8, 12), K, E, ego)                 # train() mode: the autograd graph
     with pytest.raises(RuntimeError, match='eval'):
-        model.bev_forward(torch.zeros(1, 3, 2, 64, 4, 8, 12), K, E, ego)
+        model.bev_forward_graph(torch.zeros(1, 3, 2, 64, 4, 8, 12), K, E, ego)
     model.eval()
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         model.bev_forward(torch.zeros(1, 3, 2, 64, 4, 8, 12), K, E, ego)

@@ -387,3 +387,108 @@ def test_hip_spatial_mean_and_its_gradient(sim):
     gy = torch.randn(4, 70)
     (got,), (want,) = torch.autograd.grad(y, x, gy), torch.autograd.grad(x.mean(dim=(2, 3)), x, gy)
     assert torch.allclose(got, want, rtol=1e-6, atol=1e-7)
+
+
+# ---- fixtures produced by the reference in train() mode (tests/golden/make_golden.py) ---------------------------------
+def _replay_training_blocks(lib, device, tol):
+    import os
+    import numpy as np
+    from fiery_amd.modules import ResidualBottleneck, SpatialGRUWeights
+    from fiery_amd.train_graph import TrainGraph
+    from tests import parity_report
+    from tests.golden.make_golden import training_cases
+    gold = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'train_blocks.npz'))
+    cases = training_cases()
+    graph = TrainGraph(None, lib)
+
+    def run_gru(module, x, h):
+        outs = []
+        for t in range(x.shape[1]):
+            h = graph.gru_cell(x[:, t], h, module)
+            outs.append(h)
+        return torch.stack(outs, dim=1)
+
+    for name, module, args, fn in (
+            ('bottleneck', ResidualBottleneck(64), ('x',), lambda m, x: graph.bottleneck(x, m)),
+            ('bottleneck_down', ResidualBottleneck(70, 35, downsample=True), ('x',), lambda m, x: graph.bottleneck(x, m)),
+            ('gru', SpatialGRUWeights(32, 64), ('x', 'h'), run_gru)):
+        torch.manual_seed(0)
+        randomise_weights(module)
+        module = module.train().to(device)
+        inputs = [cases[name][a].clone().to(device).requires_grad_() for a in args]
+        y = fn(module, *inputs)
+        names, params = zip(*module.named_parameters())
+        grads = torch.autograd.grad(y, list(inputs) + list(params), cases[name]['gy'].to(device))
+        got = {'y': y, **{f'd_input{i}': g for i, g in enumerate(grads[:len(inputs)])},
+               **{'d_' + n: g for n, g in zip(names, grads[len(inputs):])},
+               **{'after_' + k: v for k, v in module.state_dict().items() if k.endswith(('running_mean', 'running_var'))}}
+        worst = (0.0, '')
+        for key, value in got.items():
+            want = torch.from_numpy(gold[f'{name}.{key}'])
+            err = (value.detach().cpu() - want).abs().max().item()
+            scale = max(want.abs().max().item(), 1e-3)
+            worst = max(worst, (err / scale, key))
+            assert err <= tol * scale, (name, key, err, scale)
+        parity_report.record(f'train_block[{name}] vs reference autograd fixture', f'{len(got)} tensors, worst: {worst[1]}', worst[0], 1.0,
+                             None, None, tol, 'max-abs error relative to the tensor\'s magnitude')
+
+
+def test_training_blocks_equal_the_reference_autograd_fixture_on_the_simulated_kernels(sim):
+    """One Bottleneck, one down-sampling Bottleneck (70 -> 35 channels, odd-sized map), one SpatialGRU over three steps:
+    outputs, input gradients, every parameter gradient and the running statistics against what the reference's own modules
+    produced in train() mode (fixture `train_blocks.npz`)."""
+    _replay_training_blocks(sim, 'cpu', 2e-4)
+
+
+@pytest.mark.gpu
+def test_training_blocks_equal_the_reference_autograd_fixture(hip):
+    _replay_training_blocks(hip, 'cuda', 2e-4)
+
+
+@pytest.mark.gpu
+def test_tiny_model_training_step_equals_the_reference_autograd_fixture(hip):
+    """One training step of the tiny configuration (48 x 48 BEV, B = 2, two future frames) against the reference's `Fiery` in
+    train() mode (fixture `train_model_tiny.npz`): outputs, d loss / d lifted, and per parameter tensor the gradient's norm
+    and its projection on a seeded direction.  The fixture carries the same numbers from a run whose input was perturbed by
+    1e-6: the bound per tensor is 5x that sensitivity + 2e-3 of the norm (a flipped ReLU gate upstream is worth 2 %: at most a
+    tenth of the tensors may use that looser bound)."""
+    import os
+    import numpy as np
+    from fiery_amd.model import Fiery
+    from tests import parity_report
+    from tests.golden.make_golden import training_loss, training_model_case
+    gold = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'train_model_tiny.npz'))
+    cfg, B, n_cam = training_model_case()
+    torch.manual_seed(0)
+    model = Fiery(cfg)
+    randomise_weights(model)
+    model = model.cuda().train()
+    lifted, K, E, ego, labels, noise = forward_case(cfg, model.receptive_field, model.n_future, model.depth_channels, model.bev_size, B, n_cam,
+                                                    with_labels=True, with_noise=True)
+    leaf = lifted.clone().cuda().requires_grad_()
+    out = model.bev_forward(leaf, K.cuda(), E.cuda(), ego.cuda(), labels.cuda(), noise.cuda())
+    training_loss(out).backward()
+    for k, v in out.items():
+        if v is not None:
+            want = torch.from_numpy(gold['out_' + k])
+            err, scale = (v.detach().cpu() - want).abs().max().item(), max(1.0, want.abs().max().item())
+            parity_report.record('train_model_tiny vs reference fixture', k, err, scale, None, None, 2e-4 * scale)
+            assert err <= 2e-4 * scale, k
+    got_dx, want_dx, nudged_dx = leaf.grad.cpu()[..., ::2, ::3], torch.from_numpy(gold['d_lifted_sub']), torch.from_numpy(gold['nudged_d_lifted_sub'])
+    assert (got_dx - want_dx).abs().max().item() <= 5 * (nudged_dx - want_dx).abs().max().item() + 2e-2 * want_dx.abs().max().item()
+    g = torch.Generator().manual_seed(5)
+    loose, rows = 0, []
+    for name, p in model.named_parameters():
+        if p.grad is None or name.startswith('encoder.'):
+            continue
+        direction = torch.randn(p.shape, generator=g)
+        got = np.array([p.grad.norm().item(), (p.grad.cpu() * direction).sum().item()])
+        want, nudged = gold['g_' + name], gold['nudged_g_' + name]
+        err = np.abs(got - want).max()
+        tight = 5 * np.abs(nudged - want).max() + 2e-3 * want[0] + 1e-6
+        assert err <= max(tight, 2e-2 * want[0] + 1e-5), (name, got, want)
+        loose += err > tight
+        rows.append(err / (want[0] + 1e-6))
+    assert len(rows) > 100 and loose <= len(rows) // 10, (loose, len(rows))
+    parity_report.record('train_model_tiny vs reference fixture', f'gradient norm / projection of {len(rows)} tensors, median rel. error',
+                         float(np.median(rows)), 1.0, None, None, 2e-2, f'{loose} tensors past 5x the reference\'s own 1e-6 sensitivity')
