@@ -773,5 +773,7 @@ def test_method_seams_keep_the_reference_signatures(hip):
         sample, dist = model.distribution_forward(torch.randn(1, 1, 64, 16, 16, device=DEV))
         assert sample.shape == (1, 1, 32, 16, 16) and dist['future_mu'] is None
     model.train()
-    with pytest.raises(RuntimeError, match='eval'):
+    with pytest.raises(ValueError, match='future distribution'):       # training samples the latent from the future distribution
         model(image, K, E, ego)
+    with pytest.raises(RuntimeError, match='eval'):                    # graph replay serves the folded inference plan only
+        model.forward_graph(image, K, E, ego)
