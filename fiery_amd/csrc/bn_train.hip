@@ -132,7 +132,8 @@ __device__ __forceinline__ void sum_partials(const float* __restrict__ partial, 
 __global__ __launch_bounds__(256) void k_bn_finish_stats(const float* __restrict__ x, const float* __restrict__ partial, int blocks,
                                                          int Cp, int C, long long P, float eps, float momentum,
                                                          float* __restrict__ mean, float* __restrict__ invstd,
-                                                         float* __restrict__ running_mean, float* __restrict__ running_var) {
+                                                         float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                         float* __restrict__ var_out) {
     __shared__ double lds[4][2][64];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int c = blockIdx.x * 4 + grp;
@@ -146,7 +147,8 @@ __global__ __launch_bounds__(256) void k_bn_finish_stats(const float* __restrict
     if (var < 0.0) var = 0.0;
     const float m = static_cast<float>(static_cast<double>(x[c]) + d);
     mean[c] = m;
-    invstd[c] = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
+    if (invstd) invstd[c] = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
+    if (var_out) var_out[c] = static_cast<float>(var);
     if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
     if (running_var) {
         const double unbiased = P > 1 ? var * n / (n - 1.0) : var;
@@ -255,8 +257,8 @@ __global__ __launch_bounds__(kBnThreads) void k_bn_bwd_dx(const float* __restric
                                                           long long P, int C, const float* __restrict__ mean,
                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                           const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                                          int batch_stats, float* __restrict__ dx, int dx_ld, int C_store, int dx_vec,
-                                                          int groups) {
+                                                          int batch_stats, long long P_total, float* __restrict__ dx, int dx_ld,
+                                                          int C_store, int dx_vec, int groups) {
     const long long i = static_cast<long long>(blockIdx.x) * kBnThreads + threadIdx.x;
     const long long p = i / groups;
     const int c = static_cast<int>(i - p * groups) * 4;
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(kBnThreads) void k_bn_bwd_dx(const float* __restric
         float4 yv4 = make_float4(1.f, 1.f, 1.f, 1.f);
         if (y) yv4 = load4(y + p * y_ld, c, C, y_vec);
         const float gv[4] = {gv4.x, gv4.y, gv4.z, gv4.w}, xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w}, yv[4] = {yv4.x, yv4.y, yv4.z, yv4.w};
-        const float inv_p = 1.f / static_cast<float>(P);
+        const float inv_p = 1.f / static_cast<float>(P_total);       // the statistics' pixel count (all processes' for SyncBatchNorm)
         float out[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -313,7 +315,8 @@ extern "C" int fiery_bn_train_fwd(const float* x, int ld, int64_t n_pixels, int 
         hipLaunchKernelGGL(k_bn_partial_stats, dim3(s.blocks), dim3(kBnThreads), 0, hs, x, ld, static_cast<long long>(n_pixels), C, vec, s,
                            Cp, workspace);
         hipLaunchKernelGGL(k_bn_finish_stats, dim3(ceil_div(C, 4)), dim3(256), 0, hs, x, workspace, s.blocks, Cp, C,
-                           static_cast<long long>(n_pixels), eps, momentum, mean, invstd, running_mean, running_var);
+                           static_cast<long long>(n_pixels), eps, momentum, mean, invstd, running_mean, running_var,
+                           static_cast<float*>(nullptr));
     } else {
         hipLaunchKernelGGL(k_bn_running_stats, dim3(ceil_div(C, 64)), dim3(64), 0, hs, running_mean, running_var, C, eps, mean, invstd);
     }
@@ -325,6 +328,32 @@ extern "C" int fiery_bn_train_fwd(const float* x, int ld, int64_t n_pixels, int 
     return check_launch("bn_train_fwd");
 }
 
+namespace {
+int bn_bwd_reduce(const float* grad_out, int g_ld, const float* x, int ld, const float* y, int y_ld, int64_t n_pixels, int C,
+                  const float* mean, const float* invstd, float* dgamma, float* dbeta, float* workspace, hipStream_t hs) {
+    const BnShape s = bn_shape(n_pixels, C);
+    const int Cp = (C + 3) / 4 * 4;
+    const int vec = rows_vec(x, ld, C) ? 1 : 0, g_vec = rows_vec(grad_out, g_ld, C) ? 1 : 0, y_vec = (y && rows_vec(y, y_ld, C)) ? 1 : 0;
+    hipLaunchKernelGGL(k_bn_bwd_partial, dim3(s.blocks), dim3(kBnThreads), 0, hs, grad_out, g_ld, g_vec, x, ld, vec, y, y_ld, y_vec,
+                       static_cast<long long>(n_pixels), C, mean, invstd, s, Cp, workspace);
+    hipLaunchKernelGGL(k_bn_bwd_finish, dim3(ceil_div(C, 4)), dim3(256), 0, hs, workspace, s.blocks, Cp, C, dgamma, dbeta);
+    return check_launch("bn_train_bwd (sums)");
+}
+
+int bn_bwd_dx(const float* grad_out, int g_ld, const float* x, int ld, const float* y, int y_ld, int64_t n_pixels, int C,
+              const float* gamma, const float* mean, const float* invstd, const float* dgamma, const float* dbeta, int batch_stats,
+              int64_t total_pixels, float* grad_in, int gi_ld, int C_store, hipStream_t hs) {
+    const int vec = rows_vec(x, ld, C) ? 1 : 0, g_vec = rows_vec(grad_out, g_ld, C) ? 1 : 0, y_vec = (y && rows_vec(y, y_ld, C)) ? 1 : 0;
+    const int groups_out = (C_store + 3) / 4;
+    const int dx_vec = (C_store % 4 == 0 && gi_ld % 4 == 0 && aligned16(grad_in)) ? 1 : 0;
+    const long long total = static_cast<long long>(n_pixels) * groups_out;
+    hipLaunchKernelGGL(k_bn_bwd_dx, dim3(ceil_div(total, kBnThreads)), dim3(kBnThreads), 0, hs, grad_out, g_ld, g_vec, x, ld, vec, y, y_ld,
+                       y_vec, static_cast<long long>(n_pixels), C, mean, invstd, gamma, dgamma, dbeta, batch_stats,
+                       static_cast<long long>(total_pixels), grad_in, gi_ld, C_store, dx_vec, groups_out);
+    return check_launch("bn_train_bwd (dx)");
+}
+}  // namespace
+
 extern "C" int fiery_bn_train_bwd(const float* grad_out, int g_ld, const float* x, int ld, const float* y, int y_ld, int64_t n_pixels,
                                   int C, const float* gamma, const float* mean, const float* invstd, int batch_stats, float* grad_in,
                                   int gi_ld, int C_store, float* dgamma, float* dbeta, float* workspace, fiery_stream_t stream) {
@@ -332,18 +361,55 @@ extern "C" int fiery_bn_train_bwd(const float* grad_out, int g_ld, const float* 
     FIERY_REQUIRE(n_pixels > 0 && C > 0 && ld >= C && g_ld >= C && (!y || y_ld >= C) && C_store >= C && gi_ld >= C_store,
                   "bn_train_bwd: bad shape");
     FIERY_REQUIRE(C <= 4 * kBnThreads, "bn_train_bwd: at most %d channels", 4 * kBnThreads);
-    hipStream_t hs = as_stream(stream);
+    const int rc = bn_bwd_reduce(grad_out, g_ld, x, ld, y, y_ld, n_pixels, C, mean, invstd, dgamma, dbeta, workspace, as_stream(stream));
+    if (rc) return rc;
+    return bn_bwd_dx(grad_out, g_ld, x, ld, y, y_ld, n_pixels, C, gamma, mean, invstd, dgamma, dbeta, batch_stats, n_pixels, grad_in, gi_ld,
+                     C_store, as_stream(stream));
+}
+
+// ---- the same passes one at a time, for statistics that span several processes (SyncBatchNorm) ---------------------------------
+extern "C" int fiery_bn_train_stats(const float* x, int ld, int64_t n_pixels, int C, float* mean, float* var, float* workspace,
+                                    fiery_stream_t stream) {
+    FIERY_REQUIRE(x && mean && var && workspace, "bn_train_stats: null pointer");
+    FIERY_REQUIRE(n_pixels > 0 && C > 0 && ld >= C && C <= 4 * kBnThreads, "bn_train_stats: bad shape");
     const BnShape s = bn_shape(n_pixels, C);
     const int Cp = (C + 3) / 4 * 4;
-    const int vec = rows_vec(x, ld, C) ? 1 : 0, g_vec = rows_vec(grad_out, g_ld, C) ? 1 : 0, y_vec = (y && rows_vec(y, y_ld, C)) ? 1 : 0;
-    hipLaunchKernelGGL(k_bn_bwd_partial, dim3(s.blocks), dim3(kBnThreads), 0, hs, grad_out, g_ld, g_vec, x, ld, vec, y, y_ld, y_vec,
-                       static_cast<long long>(n_pixels), C, mean, invstd, s, Cp, workspace);
-    hipLaunchKernelGGL(k_bn_bwd_finish, dim3(ceil_div(C, 4)), dim3(256), 0, hs, workspace, s.blocks, Cp, C, dgamma, dbeta);
+    hipLaunchKernelGGL(k_bn_partial_stats, dim3(s.blocks), dim3(kBnThreads), 0, as_stream(stream), x, ld, static_cast<long long>(n_pixels), C,
+                       rows_vec(x, ld, C) ? 1 : 0, s, Cp, workspace);
+    hipLaunchKernelGGL(k_bn_finish_stats, dim3(ceil_div(C, 4)), dim3(256), 0, as_stream(stream), x, workspace, s.blocks, Cp, C,
+                       static_cast<long long>(n_pixels), 0.f, 0.f, mean, static_cast<float*>(nullptr), static_cast<float*>(nullptr),
+                       static_cast<float*>(nullptr), var);
+    return check_launch("bn_train_stats");
+}
+
+extern "C" int fiery_bn_apply(const float* x, int ld, int64_t n_pixels, int C, const float* mean, const float* invstd, const float* gamma,
+                              const float* beta, int relu, float* y, int y_ld, int C_store, fiery_stream_t stream) {
+    FIERY_REQUIRE(x && y && mean && invstd, "bn_apply: null pointer");
+    FIERY_REQUIRE(n_pixels > 0 && C > 0 && ld >= C && C_store >= C && y_ld >= C_store, "bn_apply: bad shape");
     const int groups_out = (C_store + 3) / 4;
-    const int dx_vec = (C_store % 4 == 0 && gi_ld % 4 == 0 && aligned16(grad_in)) ? 1 : 0;
+    const int y_vec = (C_store % 4 == 0 && y_ld % 4 == 0 && aligned16(y)) ? 1 : 0;
     const long long total = static_cast<long long>(n_pixels) * groups_out;
-    hipLaunchKernelGGL(k_bn_bwd_dx, dim3(ceil_div(total, kBnThreads)), dim3(kBnThreads), 0, hs, grad_out, g_ld, g_vec, x, ld, vec, y, y_ld,
-                       y_vec, static_cast<long long>(n_pixels), C, mean, invstd, gamma, dgamma, dbeta, batch_stats, grad_in, gi_ld, C_store,
-                       dx_vec, groups_out);
-    return check_launch("bn_train_bwd");
+    hipLaunchKernelGGL(k_bn_apply, dim3(ceil_div(total, kBnThreads)), dim3(kBnThreads), 0, as_stream(stream), x, ld,
+                       static_cast<long long>(n_pixels), C, rows_vec(x, ld, C) ? 1 : 0, mean, invstd, gamma, beta, relu, y, y_ld, C_store, y_vec,
+                       groups_out);
+    return check_launch("bn_apply");
+}
+
+extern "C" int fiery_bn_train_bwd_sums(const float* grad_out, int g_ld, const float* x, int ld, const float* y, int y_ld, int64_t n_pixels,
+                                       int C, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* workspace,
+                                       fiery_stream_t stream) {
+    FIERY_REQUIRE(grad_out && x && mean && invstd && dgamma && dbeta && workspace, "bn_train_bwd_sums: null pointer");
+    FIERY_REQUIRE(n_pixels > 0 && C > 0 && ld >= C && g_ld >= C && (!y || y_ld >= C) && C <= 4 * kBnThreads, "bn_train_bwd_sums: bad shape");
+    return bn_bwd_reduce(grad_out, g_ld, x, ld, y, y_ld, n_pixels, C, mean, invstd, dgamma, dbeta, workspace, as_stream(stream));
+}
+
+extern "C" int fiery_bn_train_bwd_dx(const float* grad_out, int g_ld, const float* x, int ld, const float* y, int y_ld, int64_t n_pixels,
+                                     int C, const float* gamma, const float* mean, const float* invstd, const float* dgamma,
+                                     const float* dbeta, int64_t total_pixels, float* grad_in, int gi_ld, int C_store,
+                                     fiery_stream_t stream) {
+    FIERY_REQUIRE(grad_out && x && mean && invstd && dgamma && dbeta && grad_in, "bn_train_bwd_dx: null pointer");
+    FIERY_REQUIRE(n_pixels > 0 && total_pixels >= n_pixels && C > 0 && ld >= C && g_ld >= C && (!y || y_ld >= C) && C_store >= C &&
+                      gi_ld >= C_store, "bn_train_bwd_dx: bad shape");
+    return bn_bwd_dx(grad_out, g_ld, x, ld, y, y_ld, n_pixels, C, gamma, mean, invstd, dgamma, dbeta, 1, total_pixels, grad_in, gi_ld, C_store,
+                     as_stream(stream));
 }

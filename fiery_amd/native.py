@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libfiery_hip.so')
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -139,6 +139,13 @@ _SIGNATURES = {
     'fiery_bn_train_bwd': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),
+    'fiery_bn_train_stats': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fiery_bn_apply': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                 C.c_int, C.c_int, C.c_void_p]),
+    'fiery_bn_train_bwd_sums': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fiery_bn_train_bwd_dx': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'fiery_upsample2x_bwd_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'fiery_depthwise_conv_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_int] * 6 +
                                   [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
@@ -400,6 +407,34 @@ class Lib:
                                                _ptr(invstd), int(bool(batch_stats)), _ptr(gx), c_store, c_store, _ptr(dgamma), _ptr(dbeta),
                                                _ptr(self._bn_workspace(c, x.device)), _stream_of(gx)))
         return gx, dgamma, dbeta
+
+    def bn_train_stats(self, x, ld, n_pixels, c):
+        """-> (mean, biased variance) of this process's rows."""
+        mean = torch.empty(c, dtype=torch.float32, device=x.device)
+        var = torch.empty(c, dtype=torch.float32, device=x.device)
+        self.check(self.dll.fiery_bn_train_stats(_ptr(x), ld, n_pixels, c, _ptr(mean), _ptr(var), _ptr(self._bn_workspace(c, x.device)),
+                                                 _stream_of(mean)))
+        return mean, var
+
+    def bn_apply(self, x, ld, n_pixels, c, mean, invstd, gamma, beta, relu, c_store):
+        y = torch.empty(n_pixels, c_store, dtype=torch.float32, device=x.device)
+        self.check(self.dll.fiery_bn_apply(_ptr(x), ld, n_pixels, c, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), int(bool(relu)), _ptr(y),
+                                           c_store, c_store, _stream_of(y)))
+        return y
+
+    def bn_train_bwd_sums(self, grad_out, g_ld, x, ld, y, y_ld, n_pixels, c, mean, invstd):
+        dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+        self.check(self.dll.fiery_bn_train_bwd_sums(_ptr(grad_out), g_ld, _ptr(x), ld, _ptr(y), y_ld, n_pixels, c, _ptr(mean), _ptr(invstd),
+                                                    _ptr(dgamma), _ptr(dbeta), _ptr(self._bn_workspace(c, x.device)), _stream_of(dgamma)))
+        return dgamma, dbeta
+
+    def bn_train_bwd_dx(self, grad_out, g_ld, x, ld, y, y_ld, n_pixels, c, gamma, mean, invstd, dgamma, dbeta, total_pixels, c_store):
+        gx = torch.empty(n_pixels, c_store, dtype=torch.float32, device=x.device)
+        self.check(self.dll.fiery_bn_train_bwd_dx(_ptr(grad_out), g_ld, _ptr(x), ld, _ptr(y), y_ld, n_pixels, c, _ptr(gamma), _ptr(mean),
+                                                  _ptr(invstd), _ptr(dgamma), _ptr(dbeta), total_pixels, _ptr(gx), c_store, c_store,
+                                                  _stream_of(gx)))
+        return gx
 
     def upsample2x_bwd(self, grad_out, n_img, h, w, c):
         """grad_out: dense pixel-major (n_img, 2h, 2w, c) -> (n_img, h, w, c)."""

@@ -170,6 +170,56 @@ class HipBatchNormAct(torch.autograd.Function):
                 dbeta if ctx.needs_input_grad[2] else None, None, None, None, None, None, None, None)
 
 
+class HipSyncBatchNormAct(torch.autograd.Function):
+    """`nn.SyncBatchNorm` in train() mode (what `sync_batchnorm=True` of train.py:35-37 turns every BatchNorm into) with an
+    optional fused ReLU: this process's mean / variance (`fiery_bn_train_stats`), one all-gather of (mean, variance, count)
+    combined with Chan's formula, `fiery_bn_apply`; backward: this process's sums (`fiery_bn_train_bwd_sums`), one
+    all-reduce, `fiery_bn_train_bwd_dx` with the pixel count of all processes.  The parameter gradients are the LOCAL sums,
+    as torch's SyncBatchNorm returns them (DistributedDataParallel averages them afterwards)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, group, lib):
+        import torch.distributed as dist
+        n, c, h, w = x.shape
+        xr, ld = _rows(x.detach().float())
+        pixels = n * h * w
+        mean, var = lib.bn_train_stats(xr, ld, pixels, c)
+        world = dist.get_world_size(group)
+        mine = torch.cat([mean, var, torch.full((1,), float(pixels), dtype=torch.float32, device=x.device)])
+        everyone = torch.empty(world * (2 * c + 1), dtype=torch.float32, device=x.device)
+        dist.all_gather_into_tensor(everyone, mine, group=group)
+        everyone = everyone.view(world, 2 * c + 1)
+        means, variances, counts = everyone[:, :c].double(), everyone[:, c:2 * c].double(), everyone[:, 2 * c:].double()
+        total = counts.sum()
+        g_mean = (means * counts).sum(0) / total
+        g_var = ((variances + (means - g_mean) ** 2) * counts).sum(0) / total                  # biased, over all processes
+        mean, invstd = g_mean.float(), torch.rsqrt(g_var + eps).float()
+        if running_mean is not None:
+            running_mean.mul_(1.0 - momentum).add_(mean, alpha=momentum)
+            running_var.mul_(1.0 - momentum).add_((g_var * (total / (total - 1.0))).float(), alpha=momentum)
+        c_store = round_up(c, 8)
+        y = lib.bn_apply(xr, ld, pixels, c, mean, invstd, None if weight is None else weight.detach(),
+                         None if bias is None else bias.detach(), relu, c_store)
+        ctx.save_for_backward(xr, y if relu else None, mean, invstd, None if weight is None else weight.detach())
+        ctx.meta = (n, c, h, w, ld, c_store, int(total.item()), group, lib)
+        return y.view(n, h, w, c_store)[..., :c].permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        import torch.distributed as dist
+        xr, y, mean, invstd, weight = ctx.saved_tensors
+        n, c, h, w, ld, c_store, total, group, lib = ctx.meta
+        gr, g_ld = _rows(gy.float())
+        pixels = n * h * w
+        dgamma, dbeta = lib.bn_train_bwd_sums(gr, g_ld, xr, ld, y, c_store, pixels, c, mean, invstd)
+        sums = torch.cat([dgamma, dbeta])
+        dist.all_reduce(sums, group=group)
+        gx = lib.bn_train_bwd_dx(gr, g_ld, xr, ld, y, c_store, pixels, c, weight, mean, invstd, sums[:c].contiguous(), sums[c:].contiguous(),
+                                 total, c_store)
+        return (gx.view(n, h, w, c_store)[..., :c].permute(0, 3, 1, 2), dgamma if ctx.needs_input_grad[1] else None,
+                dbeta if ctx.needs_input_grad[2] else None, None, None, None, None, None, None, None)
+
+
 class HipSpatialMean(torch.autograd.Function):
     """(N, C, H, W) -> (N, C) means over the plane (`fiery_spatial_mean`); the gradient is a broadcast."""
 
@@ -240,6 +290,13 @@ class TrainGraph:
                 factor = 1.0 / float(norm.num_batches_tracked)
         batch_stats = norm.training or not tracking
         update = norm.training and tracking
+        if isinstance(norm, torch.nn.SyncBatchNorm) and norm.training:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                group = norm.process_group if norm.process_group is not None else dist.group.WORLD
+                if dist.get_world_size(group) > 1:
+                    return HipSyncBatchNormAct.apply(x, norm.weight, norm.bias, norm.running_mean if update else None,
+                                                     norm.running_var if update else None, factor, norm.eps, relu, group, self.lib)
         return HipBatchNormAct.apply(x, norm.weight, norm.bias, norm.running_mean if (update or not batch_stats) else None,
                                      norm.running_var if (update or not batch_stats) else None, batch_stats, factor, norm.eps, relu,
                                      self.lib)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FIERY_ABI_VERSION 11
+#define FIERY_ABI_VERSION 12
 
 #define FIERY_OK 0
 #define FIERY_EINVAL (-22)      /* bad argument (shape, alignment, null pointer) */
@@ -418,6 +418,21 @@ int fiery_bn_train_fwd(const float* x, int ld, int64_t n_pixels, int C, const fl
 int fiery_bn_train_bwd(const float* grad_out, int g_ld, const float* x, int ld, const float* y, int y_ld, int64_t n_pixels,
                        int C, const float* gamma, const float* mean, const float* invstd, int batch_stats, float* grad_in,
                        int gi_ld, int C_store, float* dgamma, float* dbeta, float* workspace, fiery_stream_t stream);
+
+/* The same passes one at a time, for statistics that span several processes (`nn.SyncBatchNorm`, train.py:35-37): the
+ * caller combines the local mean / biased variance / pixel count of every process (Chan's formula) between
+ * fiery_bn_train_stats and fiery_bn_apply, and all-reduces the local sums between fiery_bn_train_bwd_sums and
+ * fiery_bn_train_bwd_dx (whose total_pixels is the pixel count of all processes). */
+int fiery_bn_train_stats(const float* x, int ld, int64_t n_pixels, int C, float* mean, float* var, float* workspace,
+                         fiery_stream_t stream);
+int fiery_bn_apply(const float* x, int ld, int64_t n_pixels, int C, const float* mean, const float* invstd, const float* gamma,
+                   const float* beta, int relu, float* y, int y_ld, int C_store, fiery_stream_t stream);
+int fiery_bn_train_bwd_sums(const float* grad_out, int g_ld, const float* x, int ld, const float* y, int y_ld, int64_t n_pixels,
+                            int C, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* workspace,
+                            fiery_stream_t stream);
+int fiery_bn_train_bwd_dx(const float* grad_out, int g_ld, const float* x, int ld, const float* y, int y_ld, int64_t n_pixels,
+                          int C, const float* gamma, const float* mean, const float* invstd, const float* dgamma,
+                          const float* dbeta, int64_t total_pixels, float* grad_in, int gi_ld, int C_store, fiery_stream_t stream);
 
 /* Gradient of the plain x2 interpolation (fiery_upsample2x_add_nhwc without shift / skip) with respect to its input -
  * what autograd computes for `nn.Upsample(scale_factor=2, mode='bilinear')` in layers/convolutions.py:203-214 (training).

@@ -144,3 +144,64 @@ def test_sharded_bev_forward_on_the_simulated_kernels(batch, layout):
             assert torch.equal(res[r]['again'][k], v), k
         assert res[r]['n_exchange'] == (0 if (layout == 'batch') else 1)        # allocated once, reused by the second call
     assert covered == set(range(batch))
+
+
+# ---- SyncBatchNorm on the kernels: statistics over all processes ------------------------------------------------------
+def _syncbn_worker(rank, world, port, results):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from fiery_amd import native
+        from fiery_amd.modules import ResidualBottleneck
+        from fiery_amd.train_graph import TrainGraph
+        from tests.helpers import randomise_weights
+        from tests.sim.build_sim import build
+        torch.set_num_threads(1)
+        lib = native.Lib(build())
+        g = torch.Generator().manual_seed(11)
+        x_all = torch.randn(4, 64, 10, 12, generator=g)
+        gy_all = torch.randn(4, 32, 5, 6, generator=g)
+        torch.manual_seed(0)
+        block = ResidualBottleneck(64, 32, downsample=True)
+        randomise_weights(block)
+        whole = ResidualBottleneck(64, 32, downsample=True)
+        whole.load_state_dict(block.state_dict())
+        block = torch.nn.SyncBatchNorm.convert_sync_batchnorm(block).train()
+        whole.train()
+        graph = TrainGraph(None, lib)
+        # this rank's half of the batch through the SyncBatchNorm block ...
+        lo, hi = rank * 2, rank * 2 + 2
+        x = x_all[lo:hi].clone().requires_grad_()
+        y = graph.bottleneck(x, block)
+        y.backward(gy_all[lo:hi])
+        # ... against the whole batch through the plain-BatchNorm block in one process
+        xw = x_all.clone().requires_grad_()
+        yw = graph.bottleneck(xw, whole)
+        yw.backward(gy_all)
+        results[rank] = dict(
+            y=(y.detach() - yw.detach()[lo:hi]).abs().max().item(), dx=(x.grad - xw.grad[lo:hi]).abs().max().item(),
+            stats=max((b - dict(whole.named_buffers())[n]).abs().max().item() for n, b in block.named_buffers() if 'running' in n),
+            grads={n: p.grad.clone() for n, p in block.named_parameters()}, whole={n: p.grad.clone() for n, p in whole.named_parameters()},
+            scale=yw.detach().abs().max().item(), converted=sum(isinstance(m, torch.nn.SyncBatchNorm) for m in block.modules()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sync_batchnorm_on_the_kernels_equals_the_whole_batch_in_one_process():
+    """A down-sampling Bottleneck whose BatchNorms were converted by `nn.SyncBatchNorm.convert_sync_batchnorm` (what
+    `sync_batchnorm=True` of train.py:37 does), two processes with half the batch each: outputs, input gradients and running
+    statistics equal the whole batch in one process; the parameter gradients are the local sums (they add up to the whole
+    batch's - DistributedDataParallel averages them afterwards)."""
+    from tests.sim.build_sim import build
+    build()
+    world, port = 2, _free_port()
+    with mp.Manager() as manager:
+        results = manager.dict()
+        mp.spawn(_syncbn_worker, args=(world, port, results), nprocs=world, join=True)
+        res = dict(results)
+    for r in range(world):
+        assert res[r]['converted'] == 4
+        assert res[r]['y'] <= 1e-5 * max(1.0, res[r]['scale']) and res[r]['dx'] <= 1e-4 and res[r]['stats'] <= 1e-5
+    for name, want in res[0]['whole'].items():
+        total = res[0]['grads'][name] + res[1]['grads'][name]
+        assert torch.allclose(total, want, rtol=1e-4, atol=1e-4 * max(1.0, want.abs().max().item())), name
