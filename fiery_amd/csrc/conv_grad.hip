@@ -126,6 +126,148 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradP p) {
         }
 }
 
+// ---- 3 x 3, stride 1 (87 % of a training step's weight-gradient work): operands staged once in LDS for all nine taps -----------
+// The kernel above reads dY and X from L2 once per tap.  Here a workgroup owns a (64 couts) x (64 channels) block of dW for
+// ALL nine taps over a column strip of the map - `seg` (<= 56) output pixels wide, a range of output rows - and walks down the
+// strip: per output row it stages that row's dY segment and ONE new X row (the other two of the 3-row window are already in a
+// ring in LDS), so every dY and X element is fetched from global memory once per (cout tile, channel tile) instead of nine
+// times.  Each wavefront owns a 32 x 32 quarter of the block for the nine taps (144 accumulator registers) and reads its
+// operands from LDS with one ds_read_b32 per MFMA; when the layer is narrower than 64 couts or channels the spare wavefronts
+// split the segment's pixels instead.  The next row's global loads are issued before the current row's 288 MFMAs and written
+// to LDS after them (register staging: 33 KB per workgroup and step).
+constexpr int kSegMax = 56;
+
+struct Wgrad3P {
+    const float* x;
+    const float* g;
+    float* dw;
+    long long x_istride, g_istride;
+    int x_ld, g_ld, cin_pad, cout;
+    int n_img, H, W;            // 3 x 3, stride 1, pad 1: input and output maps have the same size
+    int c_tiles, co_tiles, seg, n_seg, rows_per_wg, row_parts;
+};
+
+__global__ __launch_bounds__(256, 2) void k_conv_wgrad3x3(Wgrad3P p) {
+    __shared__ float s_g[kSegMax * 64];                       // dY segment [pixel][cout]
+    __shared__ float s_x[3][(kSegMax + 2) * 64];              // ring of X rows [pixel + 1][channel]; ring slot = input row % 3
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31, kk = lane >> 5;
+    // which strip: blockIdx.x = ((co tile * c_tiles + c tile) * n_seg + segment), blockIdx.y = (image, row part)
+    int b = blockIdx.x;
+    const int sg = b % p.n_seg;  b /= p.n_seg;
+    const int ct = b % p.c_tiles, cot = b / p.c_tiles;
+    const int img = blockIdx.y / p.row_parts, part = blockIdx.y - img * p.row_parts;
+    const int y0 = part * p.rows_per_wg;
+    const int y1 = min(y0 + p.rows_per_wg, p.H);
+    const int x0 = sg * p.seg;
+    const int co0 = cot * 64, c0 = ct * 64;
+    // wavefront roles: 32-wide sub-blocks that exist, spare wavefronts split the K-steps
+    const int n_cow = (p.cout - co0 > 32) ? 2 : 1, n_cw = (p.cin_pad - c0 > 32) ? 2 : 1;
+    const int k_parts = 4 / (n_cow * n_cw);
+    const int cw = wave % n_cw, cow = (wave / n_cw) % n_cow, k_part = wave / (n_cw * n_cow);
+    // staging roles: thread -> (pixel slot, 16-byte channel group); 16 groups per pixel
+    const int q = tid & 15, prow = tid >> 4;                  // 16 pixel slots per pass, 16 passes cover 256 pixels
+    const bool g_q_ok = co0 + 4 * q + 3 < p.g_ld, x_q_ok = c0 + 4 * q + 3 < p.x_ld;
+    constexpr int kOutside = static_cast<int>(0x80000000u);
+    constexpr int G_SLOTS = (kSegMax + 15) / 16, X_SLOTS = (kSegMax + 2 + 15) / 16;
+    float4 g_reg[G_SLOTS], x_reg[X_SLOTS];
+    const float* g_img = p.g + img * p.g_istride;
+    const float* x_img = p.x + img * p.x_istride;
+    auto request_g = [&](int y) {                              // dY row y, pixels x0 .. x0 + seg - 1
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(g_img + static_cast<long long>(y) * p.W * p.g_ld), 0, p.W * p.g_ld * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < G_SLOTS; ++i) {
+            const int px = prow + 16 * i;
+            const bool ok = g_q_ok && px < p.seg && x0 + px < p.W && y < p.H;
+            const int off = ok ? ((x0 + px) * p.g_ld + co0 + 4 * q) * 4 : kOutside;
+            const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+            __builtin_memcpy(&g_reg[i], &raw, 16);
+        }
+    };
+    auto request_x = [&](int iy) {                             // X row iy, pixels x0 - 1 .. x0 + seg (zeros outside the map)
+        const int row = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(x_img + static_cast<long long>(row) * p.W * p.x_ld), 0, p.W * p.x_ld * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < X_SLOTS; ++i) {
+            const int px = prow + 16 * i;                      // slot px holds input pixel x0 - 1 + px
+            const int ix = x0 - 1 + px;
+            const bool ok = x_q_ok && px < p.seg + 2 && ix >= 0 && ix < p.W && iy >= 0 && iy < p.H;
+            const int off = ok ? (ix * p.x_ld + c0 + 4 * q) * 4 : kOutside;
+            const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+            __builtin_memcpy(&x_reg[i], &raw, 16);
+        }
+    };
+    auto store_g = [&]() {
+#pragma unroll
+        for (int i = 0; i < G_SLOTS; ++i) {
+            const int px = prow + 16 * i;
+            if (px < kSegMax) *reinterpret_cast<float4*>(&s_g[px * 64 + 4 * q]) = g_reg[i];
+        }
+    };
+    auto store_x = [&](int iy) {
+        float* dst = s_x[(iy + 3) % 3];
+#pragma unroll
+        for (int i = 0; i < X_SLOTS; ++i) {
+            const int px = prow + 16 * i;
+            if (px < kSegMax + 2) *reinterpret_cast<float4*>(&dst[px * 64 + 4 * q]) = x_reg[i];
+        }
+    };
+    v16f acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    if (y0 < y1) {
+        // prologue: rows y0 - 1 and y0 of X into the ring, then the first step's operands into registers
+        request_x(y0 - 1);
+        store_x(y0 - 1);
+        request_x(y0);
+        store_x(y0);
+        request_g(y0);
+        request_x(y0 + 1);
+        const int k_steps = (p.seg + 1) >> 1;
+        for (int y = y0; y < y1; ++y) {
+            __syncthreads();                                   // the previous row's readers are done with s_g and the oldest ring slot
+            store_g();
+            store_x(y + 1);
+            __syncthreads();
+            if (y + 1 < y1) {                                  // the next step's operands travel during this step's MFMAs
+                request_g(y + 1);
+                request_x(y + 2);
+            }
+            const float* xr0 = s_x[(y + 2) % 3];               // input rows y - 1, y, y + 1
+            const float* xr1 = s_x[y % 3];
+            const float* xr2 = s_x[(y + 1) % 3];
+            const int a_off = cow * 32 + m, b_off = cw * 32 + m;
+            for (int j = k_part; j < k_steps; j += k_parts) {
+                const int px = 2 * j + kk;                     // this lane's output pixel of the pair (segment-relative)
+                const float a = s_g[px * 64 + a_off];
+                float bv[9];
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    bv[dx] = xr0[(px + dx) * 64 + b_off];
+                    bv[3 + dx] = xr1[(px + dx) * 64 + b_off];
+                    bv[6 + dx] = xr2[(px + dx) * 64 + b_off];
+                }
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[t], acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // out: for a fixed register the 32 lanes of a half hold 32 consecutive channels of one cout
+    const int c = c0 + cw * 32 + m;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + cow * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            const float v = acc[t][r];
+            if (co < p.cout && c < p.cin_pad && v != 0.f) atomicAdd(&p.dw[(static_cast<long long>(co) * 9 + t) * p.cin_pad + c], v);
+        }
+}
+
 }  // namespace
 }  // namespace fiery
 
@@ -140,6 +282,38 @@ extern "C" int fiery_conv_wgrad(const float* in, int in_ld, int64_t in_img_strid
     FIERY_REQUIRE(in_ld >= cin_units * 8 && g_ld >= cout, "conv_wgrad: leading dimension smaller than the channel count");
     FIERY_REQUIRE((Hin + 2 * padH - kH) / stride + 1 == Hout && (Win + 2 * padW - kW) / stride + 1 == Wout,
                   "conv_wgrad: output size does not belong to this convolution");
+    static const int staged = [] {
+        const char* e = getenv("FIERY_WGRAD_STAGED");
+        return e ? atoi(e) : 1;
+    }();
+    if (staged && kH == 3 && kW == 3 && stride == 1 && padH == 1 && padW == 1 && in_ld % 4 == 0 && g_ld % 4 == 0 && aligned16(in) &&
+        aligned16(grad_out) && static_cast<long long>(Win) * (in_ld > g_ld ? in_ld : g_ld) * 4 < (1ll << 31)) {
+        Wgrad3P q;
+        q.x = in;  q.g = grad_out;  q.dw = dw;
+        q.x_istride = in_img_stride > 0 ? in_img_stride : static_cast<long long>(Hin) * Win * in_ld;
+        q.g_istride = g_img_stride > 0 ? g_img_stride : static_cast<long long>(Hout) * Wout * g_ld;
+        if (q.x_istride % 4 == 0 && q.g_istride % 4 == 0) {
+            q.x_ld = in_ld;  q.g_ld = g_ld;  q.cin_pad = cin_units * 8;  q.cout = cout;
+            q.n_img = n_img;  q.H = Hout;  q.W = Wout;
+            q.c_tiles = ceil_div(q.cin_pad, 64);
+            q.co_tiles = ceil_div(cout, 64);
+            q.n_seg = ceil_div(Wout, kSegMax);
+            q.seg = ceil_div(Wout, q.n_seg);
+            q.seg += q.seg & 1;                                   // whole pixel pairs
+            q.n_seg = ceil_div(Wout, q.seg);
+            // column strips x row parts: about two workgroups per CU, no part shorter than four rows (two X rows are loaded
+            // just to start a part)
+            const int strips = q.co_tiles * q.c_tiles * q.n_seg * n_img;
+            int parts = ceil_div(512, strips);
+            if (parts > ceil_div(Hout, 4)) parts = ceil_div(Hout, 4);
+            if (parts < 1) parts = 1;
+            q.rows_per_wg = ceil_div(Hout, parts);
+            q.row_parts = ceil_div(Hout, q.rows_per_wg);
+            FIERY_REQUIRE(static_cast<long long>(n_img) * q.row_parts < 65536, "conv_wgrad: grid too large");
+            hipLaunchKernelGGL(k_conv_wgrad3x3, dim3(q.co_tiles * q.c_tiles * q.n_seg, n_img * q.row_parts), dim3(256), 0, as_stream(stream), q);
+            return check_launch("conv_wgrad (3x3 staged)");
+        }
+    }
     WgradP p;
     p.x = in;  p.g = grad_out;  p.dw = dw;
     p.x_istride = in_img_stride > 0 ? in_img_stride : static_cast<long long>(Hin) * Win * in_ld;
