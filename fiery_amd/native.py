@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libfiery_hip.so')
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -146,6 +146,14 @@ _SIGNATURES = {
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'fiery_bn_train_bwd_dx': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'fiery_gru_reset_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                      C.c_void_p]),
+    'fiery_gru_reset_bwd': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                      C.c_void_p]),
+    'fiery_gru_out_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p,
+                                    C.c_void_p, C.c_int, C.c_void_p]),
+    'fiery_gru_out_bwd': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     'fiery_upsample2x_bwd_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'fiery_depthwise_conv_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_int] * 6 +
                                   [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
@@ -435,6 +443,31 @@ class Lib:
                                                   _ptr(invstd), _ptr(dgamma), _ptr(dbeta), total_pixels, _ptr(gx), c_store, c_store,
                                                   _stream_of(gx)))
         return gx
+
+    def _rows_out(self, n_pixels, c_store, like, count):
+        return [torch.empty(n_pixels, c_store, dtype=torch.float32, device=like.device) for _ in range(count)]
+
+    def gru_reset_fwd(self, pre, pre_ld, bias, h, h_ld, n_pixels, c, c_store):
+        r, rh = self._rows_out(n_pixels, c_store, pre, 2)
+        self.check(self.dll.fiery_gru_reset_fwd(_ptr(pre), pre_ld, _ptr(bias), _ptr(h), h_ld, n_pixels, c, _ptr(r), _ptr(rh), c_store, _stream_of(r)))
+        return r, rh
+
+    def gru_reset_bwd(self, d_rh, g_ld, r, h, h_ld, n_pixels, c, c_store):
+        d_pre, dh = self._rows_out(n_pixels, c_store, r, 2)
+        self.check(self.dll.fiery_gru_reset_bwd(_ptr(d_rh), g_ld, _ptr(r), _ptr(h), h_ld, n_pixels, c, _ptr(d_pre), _ptr(dh), c_store, _stream_of(dh)))
+        return d_pre, dh
+
+    def gru_out_fwd(self, pre, pre_ld, bias, h, h_ld, cand, cand_ld, n_pixels, c, c_store):
+        u, hn = self._rows_out(n_pixels, c_store, pre, 2)
+        self.check(self.dll.fiery_gru_out_fwd(_ptr(pre), pre_ld, _ptr(bias), _ptr(h), h_ld, _ptr(cand), cand_ld, n_pixels, c, _ptr(u), _ptr(hn), c_store,
+                                              _stream_of(u)))
+        return u, hn
+
+    def gru_out_bwd(self, d_hn, g_ld, u, h, h_ld, cand, cand_ld, n_pixels, c, c_store):
+        d_pre, dh, dcand = self._rows_out(n_pixels, c_store, u, 3)
+        self.check(self.dll.fiery_gru_out_bwd(_ptr(d_hn), g_ld, _ptr(u), _ptr(h), h_ld, _ptr(cand), cand_ld, n_pixels, c, _ptr(d_pre), _ptr(dh), _ptr(dcand),
+                                              c_store, _stream_of(dh)))
+        return d_pre, dh, dcand
 
     def upsample2x_bwd(self, grad_out, n_img, h, w, c):
         """grad_out: dense pixel-major (n_img, 2h, 2w, c) -> (n_img, h, w, c)."""

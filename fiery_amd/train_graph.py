@@ -220,6 +220,59 @@ class HipSyncBatchNormAct(torch.autograd.Function):
                 dbeta if ctx.needs_input_grad[2] else None, None, None, None, None, None, None, None)
 
 
+def _nchw_view(rows, n, h, w, c, c_store):
+    return rows.view(n, h, w, c_store)[..., :c].permute(0, 3, 1, 2)
+
+
+class HipGruReset(torch.autograd.Function):
+    """(1 - sigmoid(pre + bias)) * h: the state the candidate convolution of `SpatialGRU.gru_cell` sees
+    (layers/temporal.py:55-58); `fiery_gru_reset_fwd / _bwd`."""
+
+    @staticmethod
+    def forward(ctx, pre, bias, h, lib):
+        n, c, hh, ww = pre.shape
+        pr, pre_ld = _rows(pre.detach().float())
+        hr, h_ld = _rows(h.detach().float())
+        c_store = round_up(c, 8)
+        r, rh = lib.gru_reset_fwd(pr, pre_ld, bias.detach().float().contiguous(), hr, h_ld, n * hh * ww, c, c_store)
+        ctx.save_for_backward(r, hr)
+        ctx.meta = (n, c, hh, ww, h_ld, c_store, lib)
+        return _nchw_view(rh, n, hh, ww, c, c_store)
+
+    @staticmethod
+    def backward(ctx, g):
+        r, hr = ctx.saved_tensors
+        n, c, hh, ww, h_ld, c_store, lib = ctx.meta
+        gr, g_ld = _rows(g.float())
+        d_pre, dh = lib.gru_reset_bwd(gr, g_ld, r, hr, h_ld, n * hh * ww, c, c_store)
+        return _nchw_view(d_pre, n, hh, ww, c, c_store), d_pre[:, :c].sum(dim=0), _nchw_view(dh, n, hh, ww, c, c_store), None
+
+
+class HipGruOut(torch.autograd.Function):
+    """h' = (1 - u) * h + u * candidate with u = sigmoid(pre + bias) (layers/temporal.py:53-54, 60-61); `fiery_gru_out_fwd / _bwd`."""
+
+    @staticmethod
+    def forward(ctx, pre, bias, h, cand, lib):
+        n, c, hh, ww = pre.shape
+        pr, pre_ld = _rows(pre.detach().float())
+        hr, h_ld = _rows(h.detach().float())
+        cr, c_ld = _rows(cand.detach().float())
+        c_store = round_up(c, 8)
+        u, hn = lib.gru_out_fwd(pr, pre_ld, bias.detach().float().contiguous(), hr, h_ld, cr, c_ld, n * hh * ww, c, c_store)
+        ctx.save_for_backward(u, hr, cr)
+        ctx.meta = (n, c, hh, ww, h_ld, c_ld, c_store, lib)
+        return _nchw_view(hn, n, hh, ww, c, c_store)
+
+    @staticmethod
+    def backward(ctx, g):
+        u, hr, cr = ctx.saved_tensors
+        n, c, hh, ww, h_ld, c_ld, c_store, lib = ctx.meta
+        gr, g_ld = _rows(g.float())
+        d_pre, dh, dcand = lib.gru_out_bwd(gr, g_ld, u, hr, h_ld, cr, c_ld, n * hh * ww, c, c_store)
+        return (_nchw_view(d_pre, n, hh, ww, c, c_store), d_pre[:, :c].sum(dim=0), _nchw_view(dh, n, hh, ww, c, c_store),
+                _nchw_view(dcand, n, hh, ww, c, c_store), None)
+
+
 class HipSpatialMean(torch.autograd.Function):
     """(N, C, H, W) -> (N, C) means over the plane (`fiery_spatial_mean`); the gradient is a broadcast."""
 
@@ -405,9 +458,17 @@ class TrainGraph:
     def gru_cell(self, x, state, gru):
         """fiery/layers/temporal.py:49-62 (note (1 - reset) * state)."""
         xs = torch.cat([x, state], dim=1)
+        tilde = gru.conv_state_tilde
+        hidden = state.shape[1]
+        if self._hip_ops and hidden % 4 == 0:
+            # the gate convolutions without their bias; bias + gru_bias_init and both sigmoids inside the element-wise kernels
+            pre_u = self._conv(xs, gru.conv_update.weight, 1, gru.conv_update.padding[0], self.lib)
+            pre_r = self._conv(xs, gru.conv_reset.weight, 1, gru.conv_reset.padding[0], self.lib)
+            rh = HipGruReset.apply(pre_r, gru.conv_reset.bias + gru.gru_bias_init, state, self.lib)
+            proposal = self.bn_act(self.conv2d(torch.cat([x, rh], dim=1), tilde.conv), tilde.norm, relu=True)
+            return HipGruOut.apply(pre_u, gru.conv_update.bias + gru.gru_bias_init, state, proposal, self.lib)
         update = torch.sigmoid(self.conv2d(xs, gru.conv_update) + gru.gru_bias_init)
         reset = torch.sigmoid(self.conv2d(xs, gru.conv_reset) + gru.gru_bias_init)
-        tilde = gru.conv_state_tilde
         proposal = self.bn_act(self.conv2d(torch.cat([x, (1.0 - reset) * state], dim=1), tilde.conv), tilde.norm, relu=True)
         return (1.0 - update) * state + update * proposal
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FIERY_ABI_VERSION 12
+#define FIERY_ABI_VERSION 13
 
 #define FIERY_OK 0
 #define FIERY_EINVAL (-22)      /* bad argument (shape, alignment, null pointer) */
@@ -433,6 +433,21 @@ int fiery_bn_train_bwd_sums(const float* grad_out, int g_ld, const float* x, int
 int fiery_bn_train_bwd_dx(const float* grad_out, int g_ld, const float* x, int ld, const float* y, int y_ld, int64_t n_pixels,
                           int C, const float* gamma, const float* mean, const float* invstd, const float* dgamma,
                           const float* dbeta, int64_t total_pixels, float* grad_in, int gi_ld, int C_store, fiery_stream_t stream);
+
+/* The element-wise half of `SpatialGRU.gru_cell` (layers/temporal.py:49-62) for training, one streaming pass per direction:
+ *   reset:  r = sigmoid(pre + bias),  rh = (1 - r) * h                      backward: d_pre = -d_rh * h * r (1 - r),  dh = d_rh * (1 - r)
+ *   out:    u = sigmoid(pre + bias),  h_new = (1 - u) * h + u * cand        backward: d_pre = d_hn (cand - h) u (1 - u),  dh = d_hn (1 - u),
+ *                                                                                     dcand = d_hn * u
+ * pre = the gate convolution's raw output (no bias), bias[C] = conv bias + gru_bias_init.  Inputs are pixel-major rows with their
+ * own leading dimensions; every output is dense [n_pixels][C_store] with channels C .. C_store zero; C, C_store multiples of 4. */
+int fiery_gru_reset_fwd(const float* pre, int pre_ld, const float* bias, const float* h, int h_ld, int64_t n_pixels, int C,
+                        float* r, float* rh, int C_store, fiery_stream_t stream);
+int fiery_gru_reset_bwd(const float* d_rh, int g_ld, const float* r, const float* h, int h_ld, int64_t n_pixels, int C,
+                        float* d_pre, float* dh, int C_store, fiery_stream_t stream);
+int fiery_gru_out_fwd(const float* pre, int pre_ld, const float* bias, const float* h, int h_ld, const float* cand, int cand_ld,
+                      int64_t n_pixels, int C, float* u, float* h_new, int C_store, fiery_stream_t stream);
+int fiery_gru_out_bwd(const float* d_hn, int g_ld, const float* u, const float* h, int h_ld, const float* cand, int cand_ld,
+                      int64_t n_pixels, int C, float* d_pre, float* dh, float* dcand, int C_store, fiery_stream_t stream);
 
 /* Gradient of the plain x2 interpolation (fiery_upsample2x_add_nhwc without shift / skip) with respect to its input -
  * what autograd computes for `nn.Upsample(scale_factor=2, mode='bilinear')` in layers/convolutions.py:203-214 (training).
