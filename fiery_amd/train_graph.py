@@ -292,6 +292,17 @@ class HipSpatialMean(torch.autograd.Function):
         return (g * (1.0 / (h * w))).view(n, c, 1, 1).expand(n, c, h, w), None
 
 
+def _stack_frames(frames):
+    """[(B, C, H, W)] * T -> (B, T, C, H, W) whose memory is (B, T, H, W, C): merged to (B T, C, H, W) it is a channels-last
+    batch the pixel-major operators read in place (a plain torch.stack would hand them NCHW)."""
+    return torch.stack([f.permute(0, 2, 3, 1) for f in frames], dim=1).permute(0, 1, 4, 2, 3)
+
+
+def _cat_frames(parts):
+    """The same for (B, t_i, C, H, W) pieces along the frame axis."""
+    return torch.cat([p.permute(0, 1, 3, 4, 2) for p in parts], dim=1).permute(0, 1, 4, 2, 3)
+
+
 class TrainGraph:
     def __init__(self, model, lib=None, conv2d=None):
         """conv2d: the differentiable convolution `(x, weight, stride, pad, lib) -> y`; `HipConv2d.apply` unless a test
@@ -480,12 +491,12 @@ class TrainGraph:
             for t in range(x.shape[1]):
                 state = self.gru_cell(x[:, t], state, gru)
                 outs.append(state)
-            x = torch.stack(outs, dim=1)
+            x = _stack_frames(outs)                                # (B, T, C, H, W) over pixel-major memory
             b, n, c, h, w = x.shape
-            y = x.reshape(b * n, c, h, w)
+            y = x.reshape(b * n, c, h, w)                          # a view: channels-last images, frames of a sample consecutive
             for blk in blocks:
                 y = self.bottleneck(y, blk)
-            x = y.view(b, n, c, h, w)
+            x = y.reshape(b, n, c, h, w)
         return x
 
     def distribution(self, s_t, dm):
@@ -562,7 +573,8 @@ class TrainGraph:
         out = dict(segmentation=self.head(x, d.segmentation_head), instance_center=self.head(x, d.instance_center_head),
                    instance_offset=self.head(x, d.instance_offset_head),
                    instance_flow=self.head(x, d.instance_future_head) if d.predict_future_flow else None)
-        return {k: (None if v is None else v.reshape(b, s, *v.shape[1:])) for k, v in out.items()}
+        # (contiguous NCHW like the reference's: its losses `.view` these tensors)
+        return {k: (None if v is None else v.contiguous().view(b, s, *v.shape[1:])) for k, v in out.items()}
 
     # -- the path -----------------------------------------------------------------------------------------------------
     def bev_stack(self, x, future_egomotion, future_distribution_inputs=None, noise=None):
@@ -579,16 +591,17 @@ class TrainGraph:
         states = self.temporal_model(x)
         output = {}
         if m.n_future > 0:
-            present = states[:, :1].contiguous()
+            # one dense pixel-major copy of the present state: it is read by both distributions, every GRU block and the decoder
+            hidden = states[:, 0].contiguous(memory_format=torch.channels_last)
+            present = hidden.unsqueeze(1)
             b, _, _, h, w = present.shape
-            hidden = present[:, 0]
             if cfg.PROBABILISTIC.ENABLED:
                 sample, dist = self.distribution_forward(present, future_distribution_inputs, noise)
                 output.update(dist)
                 fut_in = sample.expand(-1, m.n_future, -1, -1, -1)
             else:
                 fut_in = hidden.new_zeros(b, m.n_future, m.latent_dim, h, w)
-            states_out = torch.cat([present, self.future_prediction(fut_in, hidden)], dim=1)
+            states_out = _cat_frames([present, self.future_prediction(fut_in, hidden)])
         else:
             states_out = states[:, -1:]
         output.update(self.decoder(states_out))
