@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libfiery_hip.so')
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -154,6 +154,9 @@ _SIGNATURES = {
                                     C.c_void_p, C.c_int, C.c_void_p]),
     'fiery_gru_out_bwd': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    'fiery_instance_labels_workspace_ints': (C.c_int64, [C.c_int, C.c_int]),
+    'fiery_instance_labels': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'fiery_upsample2x_bwd_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'fiery_depthwise_conv_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_int] * 6 +
                                   [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
@@ -468,6 +471,17 @@ class Lib:
         self.check(self.dll.fiery_gru_out_bwd(_ptr(d_hn), g_ld, _ptr(u), _ptr(h), h_ld, _ptr(cand), cand_ld, n_pixels, c, _ptr(d_pre), _ptr(dh), _ptr(dcand),
                                               c_store, _stream_of(dh)))
         return d_pre, dh, dcand
+
+    def instance_labels(self, ids, warped_ids, n_instances, sigma, ignore_index):
+        """ids, warped_ids: (T, H, W) int32 -> centerness (T, 1, H, W), offset (T, 2, H, W), flow (T, 2, H, W)."""
+        t, h, w = ids.shape
+        assert ids.dtype == torch.int32 and warped_ids.dtype == torch.int32 and ids.is_contiguous() and warped_ids.is_contiguous()
+        f32 = dict(dtype=torch.float32, device=ids.device)
+        center, offset, flow = torch.empty(t, 1, h, w, **f32), torch.empty(t, 2, h, w, **f32), torch.empty(t, 2, h, w, **f32)
+        ws = torch.empty(self.dll.fiery_instance_labels_workspace_ints(t, n_instances), dtype=torch.int32, device=ids.device)
+        self.check(self.dll.fiery_instance_labels(_ptr(ids), _ptr(warped_ids), t, h, w, n_instances, float(sigma), float(ignore_index),
+                                                  _ptr(center), _ptr(offset), _ptr(flow), _ptr(ws), _stream_of(center)))
+        return center, offset, flow
 
     def upsample2x_bwd(self, grad_out, n_img, h, w, c):
         """grad_out: dense pixel-major (n_img, 2h, 2w, c) -> (n_img, h, w, c)."""

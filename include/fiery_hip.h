@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FIERY_ABI_VERSION 13
+#define FIERY_ABI_VERSION 14
 
 #define FIERY_OK 0
 #define FIERY_EINVAL (-22)      /* bad argument (shape, alignment, null pointer) */
@@ -448,6 +448,17 @@ int fiery_gru_out_fwd(const float* pre, int pre_ld, const float* bias, const flo
                       int64_t n_pixels, int C, float* u, float* h_new, int C_store, fiery_stream_t stream);
 int fiery_gru_out_bwd(const float* d_hn, int g_ld, const float* u, const float* h, int h_ld, const float* cand, int cand_ld,
                       int64_t n_pixels, int C, float* d_pre, float* dh, float* dcand, int C_store, fiery_stream_t stream);
+
+/* Instance labels of the input pipeline - `convert_instance_mask_to_center_and_offset_label` (fiery/utils/instance.py:12-77,
+ * called per sample by fiery/data.py): ids[T][H][W] instance-id maps (0 = background, 1 .. n_instances), warped_ids[T][H][W]
+ * the same maps resampled (nearest) into the previous frame's ego frame (frame 0 unused) ->
+ * centerness[T][1][H][W] = max over the frame's instances of exp(-d^2 / sigma^2) around their rounded centres of mass,
+ * offset[T][2][H][W] = (centre - pixel) for the pixel's own instance, flow[T][2][H][W] = (warped centre in t + 1) - (centre in t)
+ * for instances present in both frames; `ignore_index` where undefined.  workspace: fiery_instance_labels_workspace_ints ints. */
+int64_t fiery_instance_labels_workspace_ints(int T, int n_instances);
+int fiery_instance_labels(const int32_t* ids, const int32_t* warped_ids, int T, int H, int W, int n_instances, float sigma,
+                          float ignore_index, float* centerness, float* offset, float* flow, int32_t* workspace,
+                          fiery_stream_t stream);
 
 /* Gradient of the plain x2 interpolation (fiery_upsample2x_add_nhwc without shift / skip) with respect to its input -
  * what autograd computes for `nn.Upsample(scale_factor=2, mode='bilinear')` in layers/convolutions.py:203-214 (training).

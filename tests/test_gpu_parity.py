@@ -777,3 +777,20 @@ def test_method_seams_keep_the_reference_signatures(hip):
         model(image, K, E, ego)
     with pytest.raises(RuntimeError, match='eval'):                    # graph replay serves the folded inference plan only
         model.forward_graph(image, K, E, ego)
+
+
+@pytest.mark.gpu
+def test_instance_labels_full_size_vs_oracle(hip):
+    """The dataset's instance labels at the real size (7 frames of 200 x 200, 30 moving instances, host tensors in and out as a
+    dataloader worker hands them over) against the oracle: offsets and displacements exactly, the heat map to rounding of exp."""
+    from fiery_amd.labels import convert_instance_mask_to_center_and_offset_label
+    from oracle.labels import instance_labels
+    from tests.test_kernels_sim_aux import _label_blobs
+    ids, ego = _label_blobs(11, 7, 200, 200, 30)
+    want = instance_labels(ids, ego, 30, 255, 3, (50.0, 50.0))
+    got = convert_instance_mask_to_center_and_offset_label(ids, ego, 30, ignore_index=255, spatial_extent=(50.0, 50.0))
+    assert all(t.device.type == 'cpu' for t in got)
+    err = (got[0] - want[0]).abs().max().item()
+    parity_report.record('instance_labels[7 x 200 x 200, 30 instances]', 'centerness', err, 1.0, None, None, 1e-6)
+    assert err <= 1e-6
+    assert torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])

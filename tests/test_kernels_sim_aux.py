@@ -347,3 +347,36 @@ def test_upsample2x_backward_is_the_transpose_of_the_interpolation(sim, shape):
     (want,) = torch.autograd.grad(up, x, gy)
     got = sim.upsample2x_bwd(gy.permute(0, 2, 3, 1).contiguous(), n, h, w, c).permute(0, 3, 1, 2)
     assert torch.allclose(got, want, rtol=1e-6, atol=1e-6)
+
+
+def _label_blobs(seed, T, H, W, n_obj):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.zeros(T, H, W, dtype=torch.int64)
+    centres = torch.rand(n_obj, 2, generator=g) * torch.tensor([H - 10.0, W - 10.0]) + 5.0
+    speed = torch.randn(n_obj, 2, generator=g) * 1.5
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing='ij')
+    for t in range(T):
+        for k in range(n_obj):
+            if (k + t + seed) % 5 == 0:
+                continue
+            c = centres[k] + speed[k] * t
+            ids[t][((yy - c[0]).abs() < 2.5 + k % 3) & ((xx - c[1]).abs() < 3.5)] = k + 1
+    ego = torch.zeros(T, 6)
+    ego[:, 0] = 1.0 + torch.rand(T, generator=g)
+    ego[:, 1] = 0.3 * torch.randn(T, generator=g)
+    ego[:, 5] = 0.05 * torch.randn(T, generator=g)
+    return ids, ego
+
+
+@pytest.mark.parametrize('seed,T,hw,n_obj', [(0, 4, (32, 48), 6), (3, 1, (20, 20), 3), (5, 6, (50, 50), 40)])
+def test_instance_labels_against_the_oracle(sim, seed, T, hw, n_obj):
+    """`fiery_instance_labels` (+ the nearest warp of the id maps) against oracle/labels.py - itself pinned to the reference's
+    `convert_instance_mask_to_center_and_offset_label` -: integer-valued outputs exactly, the heat map to an ulp of exp."""
+    from fiery_amd.labels import convert_instance_mask_to_center_and_offset_label
+    from oracle.labels import instance_labels
+    ids, ego = _label_blobs(seed, T, *hw, n_obj)
+    extent = (hw[0] / 2.0, hw[1] / 2.0)
+    want = instance_labels(ids, ego, n_obj, 255, 3, extent)
+    got = convert_instance_mask_to_center_and_offset_label(ids, ego, n_obj, ignore_index=255, spatial_extent=extent, lib=sim, device='cpu')
+    assert torch.allclose(got[0], want[0], rtol=0, atol=2e-7)
+    assert torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])

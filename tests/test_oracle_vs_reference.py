@@ -303,3 +303,40 @@ def test_prepare_future_labels_equals_the_reference(ref, sim):
         assert torch.equal(got[key][:, 0], want[key][:, 0])            # the present frame is never resampled
     assert got_inputs.shape == want_inputs.shape == (2, 5, 6, 40, 48)
     assert (got['instance'] != batch['instance'][:, rf - 1:]).float().mean() > 0.01     # the warp does move things
+
+
+def _instance_label_case(seed, T=5, H=40, W=56, n_obj=7):
+    """Moving blobs with appearing / disappearing objects + ego-motion with translation and yaw."""
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.zeros(T, H, W, dtype=torch.int64)
+    centres = torch.rand(n_obj, 2, generator=g) * torch.tensor([H - 10.0, W - 10.0]) + 5.0
+    speed = torch.randn(n_obj, 2, generator=g) * 1.5
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing='ij')
+    for t in range(T):
+        for k in range(n_obj):
+            if (k + t + seed) % 5 == 0:                    # the object is missing in this frame
+                continue
+            c = centres[k] + speed[k] * t
+            ids[t][((yy - c[0]).abs() < 2.5 + k % 3) & ((xx - c[1]).abs() < 3.5)] = k + 1
+    ego = torch.zeros(T, 6)
+    ego[:, 0] = 1.0 + torch.rand(T, generator=g)
+    ego[:, 1] = 0.3 * torch.randn(T, generator=g)
+    ego[:, 5] = 0.05 * torch.randn(T, generator=g)
+    return ids, ego, n_obj
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_instance_label_oracle_and_kernels_equal_the_reference(ref, sim, seed):
+    """`convert_instance_mask_to_center_and_offset_label` (fiery/utils/instance.py:12-77): the oracle and the product on the
+    simulated kernels against the reference function - offsets and displacements exactly, the heat map to an ulp of exp."""
+    from fiery_amd.labels import convert_instance_mask_to_center_and_offset_label
+    from oracle.labels import instance_labels
+    ids, ego, n = _instance_label_case(seed)
+    extent = (20.0, 28.0)
+    want = ref.instance.convert_instance_mask_to_center_and_offset_label(ids, ego, n, ignore_index=255, subtract_egomotion=True,
+                                                                         spatial_extent=extent)
+    for got in (instance_labels(ids, ego, n, 255, 3, extent),
+                convert_instance_mask_to_center_and_offset_label(ids, ego, n, ignore_index=255, spatial_extent=extent, lib=sim, device='cpu')):
+        assert torch.allclose(got[0], want[0], rtol=0, atol=2e-7)
+        assert torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])
+    assert (want[2] != 255).any() and (want[1] != 255).any()
