@@ -29,6 +29,7 @@ SOURCES = [
     ('bn_train.hip', []),
     ('gru_train.hip', []),
     ('labels.hip', []),
+    ('images.hip', []),
 ]
 # FIERY_CONV_TUNING=1: also build the convolution's clock-probe / priority variants (tools/microbench.py conv --clk)
 TUNING = ['-DFIERY_CONV_TUNING=1'] if os.environ.get('FIERY_CONV_TUNING') == '1' else ['-DFIERY_CONV_TUNING=0']

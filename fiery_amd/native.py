@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libfiery_hip.so')
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -157,6 +157,8 @@ _SIGNATURES = {
     'fiery_instance_labels_workspace_ints': (C.c_int64, [C.c_int, C.c_int]),
     'fiery_instance_labels': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fiery_image_resize_crop_normalise': (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int] +
+                                          [C.c_int] * 6 + [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'fiery_upsample2x_bwd_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'fiery_depthwise_conv_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_int] * 6 +
                                   [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
@@ -482,6 +484,21 @@ class Lib:
         self.check(self.dll.fiery_instance_labels(_ptr(ids), _ptr(warped_ids), t, h, w, n_instances, float(sigma), float(ignore_index),
                                                   _ptr(center), _ptr(offset), _ptr(flow), _ptr(ws), _stream_of(center)))
         return center, offset, flow
+
+    def image_resize_crop_normalise(self, images, res_hw, tables, window, mean, std):
+        """images (n, H, W, 3) uint8 on the device; tables = (bounds_h, kk_h, bounds_v, kk_v) int32 device tensors, window =
+        (y_first, tmp_h, crop_left, crop_top, crop_w, crop_h) -> (n, 3, crop_h, crop_w) float32."""
+        n, in_h, in_w, _ = images.shape
+        assert images.dtype == torch.uint8 and images.is_contiguous() and images.shape[3] == 3
+        bounds_h, kk_h, bounds_v, kk_v = tables
+        y_first, tmp_h, crop_left, crop_top, crop_w, crop_h = window
+        tmp = torch.empty(n, tmp_h, crop_w, 3, dtype=torch.uint8, device=images.device)
+        out = torch.empty(n, 3, crop_h, crop_w, dtype=torch.float32, device=images.device)
+        mean3, std3 = (C.c_float * 3)(*[float(v) for v in mean]), (C.c_float * 3)(*[float(v) for v in std])
+        self.check(self.dll.fiery_image_resize_crop_normalise(_ptr(images), n, in_h, in_w, res_hw[0], res_hw[1], _ptr(bounds_h), _ptr(kk_h),
+                                                              kk_h.shape[1], _ptr(bounds_v), _ptr(kk_v), kk_v.shape[1], y_first, tmp_h, crop_left,
+                                                              crop_top, crop_w, crop_h, mean3, std3, _ptr(tmp), _ptr(out), _stream_of(out)))
+        return out
 
     def upsample2x_bwd(self, grad_out, n_img, h, w, c):
         """grad_out: dense pixel-major (n_img, 2h, 2w, c) -> (n_img, h, w, c)."""

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FIERY_ABI_VERSION 14
+#define FIERY_ABI_VERSION 15
 
 #define FIERY_OK 0
 #define FIERY_EINVAL (-22)      /* bad argument (shape, alignment, null pointer) */
@@ -459,6 +459,20 @@ int64_t fiery_instance_labels_workspace_ints(int T, int n_instances);
 int fiery_instance_labels(const int32_t* ids, const int32_t* warped_ids, int T, int H, int W, int n_instances, float sigma,
                           float ignore_index, float* centerness, float* offset, float* flow, int32_t* workspace,
                           fiery_stream_t stream);
+
+/* Camera-image preparation of the input pipeline: `resize_and_crop_image` (fiery/utils/geometry.py:8-12: PIL resize BILINEAR +
+ * crop) followed by `normalise_image` (fiery/data.py:53-57: ToTensor + Normalize).  images: [n][in_h][in_w][3] uint8 (decoded RGB).
+ * The resized image (res_h x res_w) is Pillow's 8-bit resampling byte for byte: two separable passes with the coefficient tables
+ * of Pillow's precompute_coeffs / normalize_coeffs_8bpc, computed by the caller on the host (bounds_*[size][2] = first tap, tap
+ * count; kk_*[size][ksize_*] = 22-bit fixed-point weights).  Only the crop window (crop_left, crop_top, crop_w, crop_h; parts
+ * outside the resized image are black, as Image.crop pads) is produced: out[n][3][crop_h][crop_w] = ((v / 255) - mean) / std.
+ * tmp: n * tmp_h * crop_w * 3 bytes for rows y_first .. y_first + tmp_h - 1 of the horizontal pass (the input rows the window's
+ * vertical taps read).  mean3 / std3 are HOST arrays. */
+int fiery_image_resize_crop_normalise(const uint8_t* images, int n, int in_h, int in_w, int res_h, int res_w,
+                                      const int32_t* bounds_h, const int32_t* kk_h, int ksize_h, const int32_t* bounds_v,
+                                      const int32_t* kk_v, int ksize_v, int y_first, int tmp_h, int crop_left, int crop_top,
+                                      int crop_w, int crop_h, const float* mean3 /* host */, const float* std3 /* host */,
+                                      uint8_t* tmp, float* out, fiery_stream_t stream);
 
 /* Gradient of the plain x2 interpolation (fiery_upsample2x_add_nhwc without shift / skip) with respect to its input -
  * what autograd computes for `nn.Upsample(scale_factor=2, mode='bilinear')` in layers/convolutions.py:203-214 (training).

@@ -286,6 +286,11 @@ inline unsigned __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t r, i
         __builtin_memcpy(&v, r.base + static_cast<unsigned>(voff) + static_cast<long long>(soff), 4);
     return v;
 }
+// correctly rounded single operations (no contraction): plain IEEE arithmetic on the host
+inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
+inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
+inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
 inline unsigned long long clock64() { return 0; }
 inline unsigned long long wall_clock64() { return 0; }
 // instruction-scheduling hints have no effect on results

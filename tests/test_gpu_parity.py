@@ -794,3 +794,23 @@ def test_instance_labels_full_size_vs_oracle(hip):
     parity_report.record('instance_labels[7 x 200 x 200, 30 instances]', 'centerness', err, 1.0, None, None, 1e-6)
     assert err <= 1e-6
     assert torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])
+
+
+@pytest.mark.gpu
+def test_image_preparation_real_size_is_pillow_byte_for_byte(hip):
+    """Six nuScenes-sized frames (900 x 1600) through baseline.yml's resize (x 0.3 -> 270 x 480) and crop (top 46 -> 224 x 480) on
+    the GPU against the real Pillow + ToTensor / Normalize on the host: every float equal."""
+    from fiery_amd.config import get_preset_cfg
+    from fiery_amd.images import get_resizing_and_cropping_parameters, resize_crop_normalise
+    from oracle.images import prepare
+    cfg = get_preset_cfg('baseline.yml')
+    aug = get_resizing_and_cropping_parameters(cfg)
+    assert aug['resize_dims'] == (480, 270) and aug['crop'] == (0, 46, 480, 270)
+    g = torch.Generator().manual_seed(3)
+    low = torch.randint(0, 256, (6, 90, 160, 3), generator=g, dtype=torch.uint8)
+    images = low.repeat_interleave(10, dim=1).repeat_interleave(10, dim=2).contiguous()          # blocky 900 x 1600 frames ...
+    images[:, ::7, ::5] = torch.randint(0, 256, images[:, ::7, ::5].shape, generator=g, dtype=torch.uint8)   # ... with pixel noise
+    want = prepare(images.numpy(), aug['resize_dims'], aug['crop'])
+    got = resize_crop_normalise(images, aug['resize_dims'], aug['crop'])
+    assert got.is_cuda and got.shape == (6, 3, 224, 480)
+    assert torch.equal(got.cpu(), want)

@@ -380,3 +380,23 @@ def test_instance_labels_against_the_oracle(sim, seed, T, hw, n_obj):
     got = convert_instance_mask_to_center_and_offset_label(ids, ego, n_obj, ignore_index=255, spatial_extent=extent, lib=sim, device='cpu')
     assert torch.allclose(got[0], want[0], rtol=0, atol=2e-7)
     assert torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])
+
+
+@pytest.mark.parametrize('in_hw,scale,final,top_crop', [((90, 160), 0.3, (20, 44), 5), ((45, 80), 0.7, (28, 60), 2), ((64, 64), 1.0, (64, 64), 0),
+                                                        ((30, 50), 1.6, (40, 70), 4), ((40, 72), 0.5, (24, 40), 3)])
+def test_image_resize_crop_normalise_is_pillow_byte_for_byte(sim, in_hw, scale, final, top_crop):
+    """`fiery_image_resize_crop_normalise` + the host coefficient tables against the real Pillow resize / crop and the
+    ToTensor + Normalize restatement: down-scaling (antialiased), up-scaling, identity, and a crop window that reaches past the
+    resized image (Pillow pads with black).  The normalised floats must be equal bit for bit."""
+    from fiery_amd.images import resize_crop_normalise
+    from oracle.images import prepare
+    g = torch.Generator().manual_seed(in_hw[0] * 7 + in_hw[1])
+    images = torch.randint(0, 256, (3, in_hw[0], in_hw[1], 3), generator=g, dtype=torch.uint8)
+    images[0, ::2] = 255                                       # hard edges: every tap's rounding matters
+    resize_dims = (int(in_hw[1] * scale), int(in_hw[0] * scale))
+    left = int(max(0, (resize_dims[0] - final[1]) / 2))
+    crop = (left, top_crop, left + final[1], top_crop + final[0])
+    want = prepare(images.numpy(), resize_dims, crop)
+    got = resize_crop_normalise(images, resize_dims, crop, lib=sim, device='cpu')
+    assert got.shape == want.shape
+    assert torch.equal(got, want), (got - want).abs().max()
