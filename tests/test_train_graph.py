@@ -146,9 +146,9 @@ def as_close_to_exact_as_fp32_torch(hip, torch32, exact, test='train_step'):
     return len(g_e)
 
 
-def _case(preset, B=2, bev=16):
+def _case(preset, B=2, bev=16, **extra):
     from fiery_amd.model import Fiery
-    cfg = _train_cfg(preset, bev=bev)
+    cfg = _train_cfg(preset, bev=bev, **extra)
     torch.manual_seed(0)
     model = Fiery(cfg)
     state = {k: v.clone() for k, v in randomise_weights(model).items()}
@@ -209,7 +209,7 @@ def test_whole_plane_pooling_as_means_is_the_pooling_operator(sim):
 def test_training_step_on_the_kernels_is_as_close_to_exact_as_fp32_torch(sim, preset):
     """Kernels: the same graph with `HipConv2d` (forward, input gradient and weight gradient on the simulated kernels)
     against its own fp64 evaluation, bounded by the error of the all-torch fp32 evaluation."""
-    cfg, state, inputs = _case(preset)
+    cfg, state, inputs = _case(preset, **{'TIME_RECEPTIVE_FIELD': 2})          # (one temporal block: the simulator pays per launch)
     exact = graph_step(cfg, state, sim, _torch_conv, torch.float64, *inputs)
     torch32 = graph_step(cfg, state, sim, _torch_conv, torch.float32, *inputs)
     hip = graph_step(cfg, state, sim, None, torch.float32, *inputs)
@@ -250,11 +250,9 @@ def test_forward_from_images_in_training_mode_reaches_every_parameter(sim):
     missing = [name for name, p in model.named_parameters() if p.requires_grad and p.grad is None]
     assert not missing, missing[:5]
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
     opt.step()
-    with torch.no_grad():
-        again = model(image, K, E, ego, labels)
-    changed = sum((again[k] - out[k]).abs().max().item() for k in out if out[k] is not None)
-    assert changed > 0 and changed == changed
+    assert any(not torch.equal(p, before[n]) for n, p in model.named_parameters())
 
 
 # ---- on the MI355X ---------------------------------------------------------------------------------------------------
