@@ -268,6 +268,75 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad3x3(Wgrad3P p) {
         }
 }
 
+// ---- 1 x 1, stride 1: a plain (cout x pixels) . (pixels x channels) product, memory-bound -------------------------------------
+// No spatial structure: the map is a flat list of pixels.  A workgroup owns a 64 x 64 block of dW and walks over chunks of 96
+// pixels; both operands of a chunk are staged in LDS with 16-byte loads (the first kernel reads them with 4-byte loads, which the
+// memory system serves at a third of the rate), the next chunk's loads travel during the current chunk's MFMAs.
+constexpr int kChunk = 96;
+
+struct Wgrad1P {
+    const float* x;
+    const float* g;
+    float* dw;
+    long long pixels;
+    int x_ld, g_ld, cin_pad, cout, c_tiles, co_tiles, parts;
+};
+
+__global__ __launch_bounds__(256, 2) void k_conv_wgrad1x1(Wgrad1P p) {
+    __shared__ float s_g[kChunk * 64];
+    __shared__ float s_x[kChunk * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31, kk = lane >> 5;
+    const int ct = blockIdx.x % p.c_tiles, cot = blockIdx.x / p.c_tiles;
+    const int co0 = cot * 64, c0 = ct * 64;
+    const int n_cow = (p.cout - co0 > 32) ? 2 : 1, n_cw = (p.cin_pad - c0 > 32) ? 2 : 1;
+    const int k_parts = 4 / (n_cow * n_cw);
+    const int cw = wave % n_cw, cow = (wave / n_cw) % n_cow, k_part = wave / (n_cw * n_cow);
+    const int q = tid & 15, prow = tid >> 4;
+    const bool g_q_ok = co0 + 4 * q + 3 < p.g_ld, x_q_ok = c0 + 4 * q + 3 < p.x_ld;
+    constexpr int SLOTS = kChunk / 16;
+    float4 g_reg[SLOTS], x_reg[SLOTS];
+    const long long n_chunks = (p.pixels + kChunk - 1) / kChunk;
+    auto request = [&](long long chunk) {
+        const long long p0 = chunk * kChunk;
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const long long px = p0 + prow + 16 * i;
+            const bool ok = px < p.pixels && chunk < n_chunks;
+            g_reg[i] = (ok && g_q_ok) ? *reinterpret_cast<const float4*>(p.g + px * p.g_ld + co0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            x_reg[i] = (ok && x_q_ok) ? *reinterpret_cast<const float4*>(p.x + px * p.x_ld + c0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    v16f acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int a_off = cow * 32 + m, b_off = cw * 32 + m;
+    long long chunk = blockIdx.y;
+    if (chunk < n_chunks) request(chunk);
+    for (; chunk < n_chunks; chunk += p.parts) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const int px = prow + 16 * i;
+            *reinterpret_cast<float4*>(&s_g[px * 64 + 4 * q]) = g_reg[i];
+            *reinterpret_cast<float4*>(&s_x[px * 64 + 4 * q]) = x_reg[i];
+        }
+        __syncthreads();
+        request(chunk + p.parts);                              // past the last chunk: zeros, no access
+        for (int j = k_part; j < kChunk / 2; j += k_parts) {
+            const int px = 2 * j + kk;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s_g[px * 64 + a_off], s_x[px * 64 + b_off], acc, 0, 0, 0);
+        }
+    }
+    const int c = c0 + cw * 32 + m;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + cow * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        const float v = acc[r];
+        if (co < p.cout && c < p.cin_pad && v != 0.f) atomicAdd(&p.dw[static_cast<long long>(co) * p.cin_pad + c], v);
+    }
+}
+
 }  // namespace
 }  // namespace fiery
 
@@ -286,6 +355,25 @@ extern "C" int fiery_conv_wgrad(const float* in, int in_ld, int64_t in_img_strid
         const char* e = getenv("FIERY_WGRAD_STAGED");
         return e ? atoi(e) : 1;
     }();
+    if (staged && kH == 1 && kW == 1 && stride == 1 && padH == 0 && padW == 0 && in_ld % 4 == 0 && g_ld % 4 == 0 && aligned16(in) &&
+        aligned16(grad_out) && (in_img_stride <= 0 || in_img_stride == static_cast<long long>(Hin) * Win * in_ld) &&
+        (g_img_stride <= 0 || g_img_stride == static_cast<long long>(Hout) * Wout * g_ld)) {
+        Wgrad1P q;
+        q.x = in;  q.g = grad_out;  q.dw = dw;
+        q.pixels = static_cast<long long>(n_img) * Hout * Wout;
+        q.x_ld = in_ld;  q.g_ld = g_ld;  q.cin_pad = cin_units * 8;  q.cout = cout;
+        q.c_tiles = ceil_div(q.cin_pad, 64);
+        q.co_tiles = ceil_div(cout, 64);
+        const int tiles = q.c_tiles * q.co_tiles;
+        const long long n_chunks = (q.pixels + kChunk - 1) / kChunk;
+        long long parts = ceil_div(768, tiles);
+        if (parts > (n_chunks + 1) / 2) parts = (n_chunks + 1) / 2;
+        if (parts < 1) parts = 1;
+        if (parts > 65535) parts = 65535;
+        q.parts = static_cast<int>(parts);
+        hipLaunchKernelGGL(k_conv_wgrad1x1, dim3(tiles, q.parts), dim3(256), 0, as_stream(stream), q);
+        return check_launch("conv_wgrad (1x1 staged)");
+    }
     if (staged && kH == 3 && kW == 3 && stride == 1 && padH == 1 && padW == 1 && in_ld % 4 == 0 && g_ld % 4 == 0 && aligned16(in) &&
         aligned16(grad_out) && static_cast<long long>(Win) * (in_ld > g_ld ? in_ld : g_ld) * 4 < (1ll << 31)) {
         Wgrad3P q;

@@ -445,7 +445,10 @@ def test_gru_epilogues_and_chained_tail_on_the_bf16_form(sim):
                                                    # the LDS-staged 3 x 3 form: several segments, pixel-split wavefronts (32 x 32), a
                                                    # second channel tile with one sub-block, padded channels, one-row and odd maps
                                                    (32, 32, 3, 1, (9, 120)), (96, 64, 3, 1, (7, 60)), (35, 36, 3, 1, (6, 25)),
-                                                   (128, 64, 3, 1, (5, 58)), (16, 32, 3, 1, (1, 9)), (64, 128, 3, 1, (13, 13))])
+                                                   (128, 64, 3, 1, (5, 58)), (16, 32, 3, 1, (1, 9)), (64, 128, 3, 1, (13, 13)),
+                                                   # the staged 1 x 1 form: flat 96-pixel chunks, ragged last chunk, narrow blocks, padded channels
+                                                   (64, 32, 1, 1, (9, 14)), (32, 64, 1, 1, (7, 11)), (35, 36, 1, 1, (6, 25)), (128, 128, 1, 1, (5, 20)),
+                                                   (70, 64, 1, 1, (1, 1))])
 def test_conv_wgrad_matches_autograd(sim, cin, cout, k, stride, hw):
     g = torch.Generator().manual_seed(cin + cout)
     x = torch.randn(2, cin, *hw, generator=g)
