@@ -309,6 +309,25 @@ def test_training_step_on_the_gpu_is_as_close_to_exact_as_fp32_torch(hip):
 
 @pytest.mark.gpu
 def test_full_size_training_steps_reduce_the_loss(hip):
+    """Runs in a process of its own: after the ~70 other GPU tests in one long-lived process, the backward pass of this one - the only
+    test whose graph also holds PyTorch-ROCm's EfficientNet trunk under autograd - died twice with "Memory access fault by GPU" (a
+    2 MB-aligned address), and not with stream synchronisations at the test's seams, never in a fresh process (eight runs), never for
+    the training tests that start from the lifted features.  Root cause not found this round (open issue)."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get('FIERY_TEST_CHILD') != '1':
+        env = dict(os.environ, FIERY_TEST_CHILD='1')
+        here = os.path.abspath(__file__)
+        res = subprocess.run([sys.executable, '-m', 'pytest', f'{here}::test_full_size_training_steps_reduce_the_loss', '-m', 'gpu', '-q', '-x',
+                              '-p', 'no:cacheprovider'], env=env, cwd=os.path.dirname(os.path.dirname(here)), capture_output=True, text=True,
+                             timeout=1200)
+        assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+        return
+    _full_size_training_steps_reduce_the_loss()
+
+
+def _full_size_training_steps_reduce_the_loss():
     """baseline.yml at full size, B = 2, from images: three SGD steps on a fixed batch bring the loss down, every gradient
     is finite, and the weights the inference plan was folded from are refreshed when the model goes back to eval()."""
     from fiery_amd.config import get_preset_cfg
@@ -326,16 +345,43 @@ def test_full_size_training_steps_reduce_the_loss(hip):
     targets = None
     opt = torch.optim.SGD([p for n, p in model.named_parameters() if not n.startswith('encoder.')], lr=0.05)
     losses = []
+    import os
+    trace = os.environ.get('FIERY_TEST_TRACE') == '1'
+
+    def mark(what):
+        if trace:
+            torch.cuda.synchronize()
+            print('[trace]', what, flush=True)
+
+    if trace:                                    # where in the backward pass a device fault happens: synchronise at the seams
+        pool = model.pool_engine()
+        for name in ('pool', 'pool_fused'):
+            inner = getattr(pool, name)
+
+            def traced(*a, _inner=inner, _name=name, **kw):
+                mark(f'before {_name} forward')
+                res = _inner(*a, **kw)
+                mark(f'after {_name} forward')
+                if res.requires_grad:
+                    res.register_hook(lambda g, _n=_name: (mark(f'gradient reached {_n} output (BEV stack backward done)'), g)[1])
+                for t in a[:2]:
+                    if torch.is_tensor(t) and t.requires_grad:
+                        t.register_hook(lambda g, _n=_name: (mark(f'{_n} backward done'), g)[1])
+                return res
+            setattr(pool, name, traced)
     for _ in range(3):
         opt.zero_grad()
         out = model(image, K, E, ego, labels)
+        mark('forward done')
         if targets is None:
             targets = {k: torch.randn(v.shape, generator=gen).cuda() * 0.1 for k, v in out.items() if v is not None}
         loss = sum(((out[k] - t) ** 2).mean() for k, t in targets.items())
         loss.backward()
+        mark('backward done')
         assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
         losses.append(loss.item())
         opt.step()
+        mark('optimiser step done')
     assert losses[-1] < losses[0], losses
     model.eval()
     with torch.no_grad():

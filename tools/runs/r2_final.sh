@@ -24,7 +24,7 @@ cut -c1-200 $O/bench_bf16.json
 } > $O/train_step.txt
 grep time_train_step $O/train_step.txt
 cd /tmp
-for mode in one_stream sample_streams; do
+for mode in ${FIERY_FINAL_TRACES:-one_stream sample_streams}; do
   extra=""; [ $mode = one_stream ] && extra="--no-sample-streams"
   rm -rf /tmp/kt_$mode
   timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/kt_$mode -o kt -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-from-images $extra > $O/kt_$mode.log 2>&1
