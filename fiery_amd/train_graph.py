@@ -9,10 +9,15 @@ PyTorch autograd graph over pixel-major (channels-last) tensors in which
   (`fiery_conv_fwd`), gradient with respect to the input on the same kernel with the weights transposed and mirrored
   (the gradient zero-stuffed first for stride 2), gradient with respect to the weights on `fiery_conv_wgrad`;
   the causal (kT, kH, kW) convolutions of the temporal model are kT such 2-D convolutions on time-shifted frames;
+* BatchNorm (+ReLU) in the module's mode is `HipBatchNormAct` (`fiery_bn_train_fwd / _bwd`: batch statistics, running-average
+  update, deterministic two-stage sums), `nn.SyncBatchNorm` modules run `HipSyncBatchNormAct` (one all-gather forward, one
+  all-reduce backward per layer);
+* the element-wise half of the GRU cell is `HipGruReset` / `HipGruOut`, the decoder's x2 upsampling `HipUpsample2x` (gather
+  backward), the (2, H, W) pyramid pooling per-frame plane means (`HipSpatialMean`) + a broadcast;
 * voxel pooling is `ops.VoxelPool` / `ops.LiftSplat` (HIP forward and backward);
-* BatchNorm with batch statistics (and its running-average update), activations, the GRU gate arithmetic, pooling /
-  bilinear resampling and the ego-warp run on PyTorch-ROCm operators over the same memory - their backward comes from
-  autograd.  (They are memory-bound passes; kernels of their own are a later step.)
+* what is left on PyTorch-ROCm operators over the same memory: max-pool of the skip paths, the ego-warp (`grid_sample`),
+  concatenations, residual adds, the two small dense layers of the distributions - their backward comes from autograd - and
+  the image trunk upstream of the path.
 
 `Fiery.forward` dispatches here when `model.training` is set; in training mode the latent sample is drawn from the FUTURE
 distribution (fiery.py:319-325), so `future_distribution_inputs` is required.  The weight holders of `fiery_amd.modules`
