@@ -400,3 +400,29 @@ def test_image_resize_crop_normalise_is_pillow_byte_for_byte(sim, in_hw, scale, 
     got = resize_crop_normalise(images, resize_dims, crop, lib=sim, device='cpu')
     assert got.shape == want.shape
     assert torch.equal(got, want), (got - want).abs().max()
+
+
+@pytest.mark.parametrize('preset', ['baseline.yml', 'lyft/baseline.yml'])
+def test_image_preparation_with_the_presets_own_sizes(sim, preset):
+    """One frame at the dataset's original size through the preset's own resize / crop parameters (nuScenes 900 x 1600 x 0.3,
+    Lyft 1080 x 1920 x 0.25 - whatever the YAML says) on the simulated kernels: Pillow's bytes, and the intrinsics update as the
+    reference computes it."""
+    from fiery_amd.config import get_preset_cfg
+    from fiery_amd.images import get_resizing_and_cropping_parameters, resize_crop_normalise, update_intrinsics
+    from oracle.images import prepare
+    cfg = get_preset_cfg(preset)
+    aug = get_resizing_and_cropping_parameters(cfg)
+    h, w = cfg.IMAGE.ORIGINAL_HEIGHT, cfg.IMAGE.ORIGINAL_WIDTH
+    g = torch.Generator().manual_seed(h)
+    low = torch.randint(0, 256, (1, h // 8 + 1, w // 8 + 1, 3), generator=g, dtype=torch.uint8)
+    image = low.repeat_interleave(8, dim=1).repeat_interleave(8, dim=2)[:, :h, :w].contiguous()
+    image[:, ::5, ::3] = torch.randint(0, 256, image[:, ::5, ::3].shape, generator=g, dtype=torch.uint8)
+    want = prepare(image.numpy(), aug['resize_dims'], aug['crop'])
+    got = resize_crop_normalise(image, aug['resize_dims'], aug['crop'], lib=sim, device='cpu')
+    assert tuple(got.shape[-2:]) == tuple(cfg.IMAGE.FINAL_DIM)
+    assert torch.equal(got, want)
+    K = torch.tensor([[1266.4, 0.0, 816.3], [0.0, 1266.4, 491.5], [0.0, 0.0, 1.0]])
+    new = update_intrinsics(K, aug['crop'][1], aug['crop'][0], scale_width=aug['scale_width'], scale_height=aug['scale_height'])
+    s = cfg.IMAGE.RESIZE_SCALE
+    assert torch.allclose(new, torch.tensor([[1266.4 * s, 0.0, 816.3 * s - aug['crop'][0]], [0.0, 1266.4 * s, 491.5 * s - aug['crop'][1]],
+                                             [0.0, 0.0, 1.0]]))
