@@ -340,3 +340,10 @@ def test_instance_label_oracle_and_kernels_equal_the_reference(ref, sim, seed):
         assert torch.allclose(got[0], want[0], rtol=0, atol=2e-7)
         assert torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])
     assert (want[2] != 255).any() and (want[1] != 255).any()
+
+
+def test_update_intrinsics_equals_the_reference(ref):
+    from fiery_amd.images import update_intrinsics
+    K = torch.tensor([[1266.417, 0.0, 816.267], [0.0, 1266.417, 491.507], [0.0, 0.0, 1.0]])
+    for args in ((46, 0, 0.3, 0.3), (0.0, 12.0, 0.25, 0.3), (0, 0, 1.0, 1.0)):
+        assert torch.equal(update_intrinsics(K, *args), ref.geometry.update_intrinsics(K, *args))
