@@ -39,9 +39,40 @@ def guarded(src, where):
     return t
 
 
+def guard_allocations(where):
+    """From here on `torch.empty / zeros / empty_like` hand out guarded host memory: the outputs and workspaces the bindings
+    (fiery_amd/native.py) and the autograd Functions allocate are checked like the inputs."""
+    real_empty, real_zeros, real_empty_like = torch.empty, torch.zeros, torch.empty_like
+
+    def shape_of(args):
+        return tuple(args[0]) if len(args) == 1 and isinstance(args[0], (tuple, list, torch.Size)) else tuple(args)
+
+    def make(shape, dtype, fill):
+        src = real_zeros(shape, dtype=dtype) if fill else real_empty(shape, dtype=dtype)
+        return guarded(src, where) if src.numel() else src
+
+    def empty(*args, dtype=None, device=None, **kw):
+        if (device is None or str(device) == 'cpu') and not kw and dtype in (torch.float32, torch.int32, torch.uint8, torch.bfloat16):
+            return make(shape_of(args), dtype, False)
+        return real_empty(*args, dtype=dtype, device=device, **kw)
+
+    def zeros(*args, dtype=None, device=None, **kw):
+        if (device is None or str(device) == 'cpu') and not kw and dtype in (torch.float32, torch.int32, torch.uint8):
+            return make(shape_of(args), dtype, True)
+        return real_zeros(*args, dtype=dtype, device=device, **kw)
+
+    def empty_like(t, **kw):
+        if not kw and t.device.type == 'cpu' and t.dtype in (torch.float32, torch.int32) and t.is_contiguous():
+            return make(tuple(t.shape), t.dtype, False)
+        return real_empty_like(t, **kw)
+
+    torch.empty, torch.zeros, torch.empty_like = empty, zeros, empty_like
+
+
 def main():
     faulthandler.enable()
     case, where = sys.argv[1], sys.argv[2]
+    guard_allocations(where)
     from fiery_amd import native
     from fiery_amd import train_graph as tg
     from tests.sim.build_sim import build
@@ -116,7 +147,7 @@ def main():
             lib.lift_splat(prob, feats, guarded(geo, where), frames, n_cam, D, H, W, C, grid)
     else:
         raise SystemExit(f'unknown case {case}')
-    print('ok', case, where)
+    print('ok', case, where, f'({len(_keep)} guarded tensors)')
 
 
 if __name__ == '__main__':

@@ -14,4 +14,4 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_kernels_stay_inside_their_operands(sim, case, where):
     res = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'sim', 'guard_check.py'), case, where], cwd=ROOT, capture_output=True,
                          text=True, timeout=900)
-    assert res.returncode == 0 and f'ok {case} {where}' in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]
+    assert res.returncode == 0 and f'ok {case} {where} (' in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]
