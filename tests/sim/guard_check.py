@@ -145,6 +145,21 @@ def main():
             prob = guarded(torch.rand(frames * n_cam, D, H, W, generator=g), where)
             feats = guarded(torch.randn(frames, n_cam, C, H, W, generator=g), where)
             lib.lift_splat(prob, feats, guarded(geo, where), frames, n_cam, D, H, W, C, grid)
+    elif case == 'train_images':                         # a whole training step from images on a tiny configuration
+        from fiery_amd.model import Fiery
+        from fiery_amd.synthetic import make_inputs, randomise_weights
+        from tests.helpers import tiny_cfg
+        cfg = tiny_cfg('baseline.yml', bev=8, **{'MODEL.FUTURE_PRED.N_GRU_BLOCKS': 1, 'MODEL.FUTURE_PRED.N_RES_LAYERS': 1, 'N_FUTURE_FRAMES': 1,
+                                                  'TIME_RECEPTIVE_FIELD': 2})
+        torch.manual_seed(0)
+        model = Fiery(cfg)
+        randomise_weights(model)
+        model.train()
+        model._lib = lib
+        image, K, E, ego = make_inputs(2, model.receptive_field + model.n_future, 2, image_hw=tuple(cfg.IMAGE.FINAL_DIM), seed=3)
+        labels = torch.randn(2, 1 + model.n_future, 6, *model.bev_size, generator=g)
+        out = model(image, K, E, ego, labels)
+        sum((v.float() ** 2).mean() for v in out.values() if v is not None).backward()
     else:
         raise SystemExit(f'unknown case {case}')
     print('ok', case, where, f'({len(_keep)} guarded tensors)')
