@@ -13,7 +13,7 @@ HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 SOURCES = [
     ('runtime.cpp', []),
     ('lift_splat.hip', ['-ffp-contract=off']),
-    ('warp.hip', []),
+    ('warp.hip', ['-ffp-contract=off']),                # sampling positions round like ATen's CPU kernels (see the file)
     ('conv_igemm.hip', []),
     # one translation unit per tile shape of the convolution kernel: they compile side by side
     ('conv_tile_128x32.hip', []),

@@ -699,9 +699,10 @@ class BevEngine:
                           lo=ops['lo'], hi=ops['hi'])
         return mu, log_sigma
 
-    def bev_stack(self, bev, future_egomotion, future_distribution_inputs=None, noise=None, into=None):
+    def bev_stack(self, bev, future_egomotion, future_distribution_inputs=None, noise=None, into=None, theta=None):
         """Everything after pooling.  bev: (B*S, C, X, Y) NCHW; future_egomotion (B, S, 6).  `into`: optional dict of
-        preallocated output tensors (by output name) to write instead of allocating."""
+        preallocated output tensors (by output name) to write instead of allocating.  `theta`: optional (B, S, 6) sampling
+        transforms computed by the caller (`model.host_warp_transforms`) instead of by `fiery_warp_params`."""
         into = into or {}
         lib, dev = self.lib, self.device
         S = self.rf
@@ -709,11 +710,14 @@ class BevEngine:
         H, W, C = self.X, self.Y, self.C
         out = {}
         ego = future_egomotion.float().contiguous()
+        theta_in = theta
         # -- ego-warp + layout change ---------------------------------------------------------------
         x0 = self.buf('x0', B * S, H, W, C)
         theta = self.vec('warp_theta', B * S, 6)
         ego_in = self.vec('ego_in', B * S, 6).view(B, S, 6) if self.egopose else None          # fiery.py:152-154
         lib.warp_params(ego, self.extent, theta=theta.view(B, S, 6), ego_shifted=ego_in)
+        if theta_in is not None:
+            theta.view(B, S, 6).copy_(theta_in)
         identity = [(i % S) == S - 1 for i in range(B * S)]
         lib.bev_warp_nchw_to_nhwc(bev.contiguous(), theta, identity, x0.tensor, x0.ld, x0.img_stride)
         # the decoder's input holds (present, future 1 .. nf) per batch element; the temporal model's last block writes the

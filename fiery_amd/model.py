@@ -4,10 +4,11 @@ Same constructor, method names, argument meaning, return shapes, attributes and 
 the reference class (reference: fiery/models/fiery.py:13-339), so `trainer.py` / `evaluate.py` /
 `visualise.py` can import this class instead.  What differs is what runs underneath:
 
-* the image trunk (`encoder.backbone`, outside the hot-path scope) runs on stock PyTorch-ROCm ops;
-* everything from the lift head's outputs to the output dict runs on the hand-written gfx950 kernels
-  in libfiery_hip.so through `fiery_amd.engine.BevEngine`.  No ATen fallback exists for that part: if the
-  library is missing, or the model is on the CPU, or in training mode, the call raises.
+* `model.eval()`: the image trunk, the lift head and everything from the lift head's outputs to the output dict run on
+  the hand-written gfx950 kernels in libfiery_hip.so through `fiery_amd.engine.BevEngine` (folded inference plan);
+* `model.train()`: the autograd graph of `fiery_amd.train_graph` over the same kernels (the image trunk and the lift head
+  on PyTorch-ROCm operators, which have the backward the engine lacks for them).
+No ATen fallback exists for the BEV path: if the library is missing or the model is on the CPU, the call raises.
 """
 import os
 
@@ -41,6 +42,56 @@ def host_camera_matrices(intrinsics, extrinsics):
     E = extrinsics.detach().to(device='cpu', dtype=torch.float32).reshape(-1, 4, 4)
     combined = E[:, :3, :3].matmul(torch.inverse(K))
     return torch.cat([combined.reshape(-1, 9), E[:, :3, 3]], dim=1).contiguous()
+
+
+def _pose_matrices_host(vec):
+    """(N, 6) pose vectors -> (N, 4, 4) on the host, through the ATen operators the reference's `pose_vec2mat` /
+    `euler2mat` call, on operands of the same shape and layout (fiery/utils/geometry.py:109-157): the cosines and sines
+    of the strided angle columns, the three elementary rotations stacked element by element, two batched 3x3 products."""
+    n = vec.shape[0]
+    angle = vec[:, 3:].contiguous()
+    zero, one = torch.zeros(n), torch.ones(n)
+    rot = None
+    for axis in (0, 1, 2):                                      # R = Rx . Ry . Rz
+        c, s = torch.cos(angle[:, axis]), torch.sin(angle[:, axis])
+        entries = {0: [one, zero, zero, zero, c, -s, zero, s, c],
+                   1: [c, zero, s, zero, one, zero, -s, zero, c],
+                   2: [c, -s, zero, s, c, zero, zero, zero, one]}[axis]
+        elementary = torch.stack(entries, dim=1).view(n, 3, 3)
+        rot = elementary if rot is None else rot.bmm(elementary)
+    mat = torch.zeros(n, 4, 4)
+    mat[:, :3, :3] = rot
+    mat[:, :3, 3] = vec[:, :3]
+    mat[:, 3, 3] = 1.0
+    return mat
+
+
+def host_warp_transforms(future_egomotion, spatial_extent):
+    """(B, S, 6) ego-motions -> (B, S, 6) sampling transforms of `cumulative_warp_features`, evaluated with the very ATen
+    CPU operators the reference's CPU path runs (fiery/utils/geometry.py:82-106, 192-215, 240-251: `cos` / `sin` are MKL
+    vector-library calls, `atan2` SLEEF, the 4x4 products ATen's small-matrix loop).  Those libraries return a neighbour of
+    the correctly rounded value for a few percent of arguments, which device code cannot predict; one ulp in a transform
+    moves some sampling positions by one ulp (~2e-5 pixel at 400 cells).  With these transforms `fiery_bev_warp_nchw_to_nhwc`
+    equals the reference's affine_grid + grid_sample bit for bit (tests); the price is a device-to-host read of 6 numbers
+    per frame, i.e. not graph-capturable - the same trade as `host_camera_matrices`."""
+    ego = future_egomotion.detach().to(device='cpu', dtype=torch.float32)
+    b, s = ego.shape[:2]
+    theta = torch.zeros(b, s, 6)
+    theta[..., 0] = 1.0
+    theta[..., 4] = 1.0                                         # the present frame is never resampled
+    if s == 1:
+        return theta
+    mats = _pose_matrices_host(ego.reshape(b * s, 6)).view(b, s, 4, 4)
+    cum = mats[:, s - 2]
+    for t in range(s - 2, -1, -1):
+        rz = torch.atan2(-cum[:, 0, 1], cum[:, 0, 0]).clone()
+        c, sn = torch.cos(rz), torch.sin(rz)
+        tx = -(cum[:, 0, 3].clone() / spatial_extent[0])
+        ty = cum[:, 1, 3].clone() / spatial_extent[1]
+        theta[:, t] = torch.stack([c, -sn, ty, sn, c, tx], dim=-1)
+        if t > 0:
+            cum = mats[:, t - 1] @ cum
+    return theta
 
 
 def calculate_birds_eye_view_parameters(x_bounds, y_bounds, z_bounds):
@@ -118,6 +169,11 @@ class Fiery(nn.Module):
         # 'host': the reference's own CPU operators on the 3x3 matrices (`host_camera_matrices`), then the device product:
         # bit-exact indices for any K, at the price of a device-to-host read of the calibration (not graph-capturable).
         self.camera_matrix_mode = os.environ.get('FIERY_CAMERA_MATRICES', 'device')
+        # 'device': the pose algebra of the ego-warp in `fiery_warp_params` (cos / sin / atan2 rounded once from double
+        # precision: equal to the CPU libraries' values for ~95 % of arguments, one ulp off otherwise).
+        # 'host': `host_warp_transforms` - the reference's own CPU operators on the B.S pose vectors; the resampling kernel
+        # then equals affine_grid + grid_sample bit for bit.  Device-to-host read, not graph-capturable.
+        self.warp_transform_mode = os.environ.get('FIERY_WARP_TRANSFORMS', 'device')
         # matrix-core precision of the convolutions: 'f32' = the reference's arithmetic (the parity configuration);
         # 'bf16' = operands rounded to bf16 at the matrix cores, fp32 accumulation and epilogues (BASELINE.json configs[3-4]).
         # Set before the first forward, or call refresh_engine() after changing it.
@@ -210,7 +266,13 @@ class Fiery(nn.Module):
             self._lane_streams.append(torch.cuda.Stream(device=eng.device))
         return self._lanes[:n], self._lane_streams[:n]
 
-    def _bev_stack_per_sample(self, bev, ego, labels, noise):
+    def _warp_transforms(self, ego):
+        if self.warp_transform_mode == 'host':
+            return host_warp_transforms(ego, self.spatial_extent).to(ego.device)
+        assert self.warp_transform_mode == 'device', self.warp_transform_mode
+        return None
+
+    def _bev_stack_per_sample(self, bev, ego, labels, noise, theta=None):
         """`BevEngine.bev_stack` for every sample on its own stream.  After pooling the samples of a batch never meet
         again, and a convolution over one sample does not fill the GPU for a whole number of rounds of workgroups:
         independent chains let the tail of one launch overlap the head of another sample's.  Results are written
@@ -235,7 +297,8 @@ class Fiery(nn.Module):
             with torch.cuda.stream(stream):
                 lane.bev_stack(bev[i * rf:(i + 1) * rf], ego[i:i + 1], None if labels is None else labels[i:i + 1],
                                None if noise is None else noise[i:i + 1],
-                               into={k: v[i:i + 1] for k, v in merged.items() if v is not None})
+                               into={k: v[i:i + 1] for k, v in merged.items() if v is not None},
+                               theta=None if theta is None else theta[i:i + 1])
         for stream in streams:
             cur.wait_stream(stream)
         return merged
@@ -395,9 +458,10 @@ class Fiery(nn.Module):
             dl = depth_logits[:, :rf].reshape(b * rf, n, *depth_logits.shape[3:])
             ft = features[:, :rf].reshape(b * rf, n, *features.shape[3:])
             bev = eng.pool_fused(dl, ft, geometry)
+        theta = self._warp_transforms(ego)
         if self.sample_streams and b > 1 and bev.is_cuda:
-            return self._bev_stack_per_sample(bev, ego, future_distribution_inputs, noise)
-        return eng.bev_stack(bev, ego, future_distribution_inputs, noise)
+            return self._bev_stack_per_sample(bev, ego, future_distribution_inputs, noise, theta)
+        return eng.bev_stack(bev, ego, future_distribution_inputs, noise, theta=theta)
 
     def bev_forward_graph(self, lifted, intrinsics, extrinsics, future_egomotion, future_distribution_inputs=None,
                           noise=None, depth_logits=None, features=None):

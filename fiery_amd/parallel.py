@@ -165,9 +165,11 @@ def sharded_bev_forward(model, K, E, ego, lifted=None, depth_logits=None, featur
     def stack(bev, blo, bhi):
         owned['range'] = (blo, bhi)
         nz = noise[blo:bhi] if noise is not None else None
+        theta = model._warp_transforms(ego)                  # over the whole batch, like the single-process path
+        theta = None if theta is None else theta[blo:bhi]
         if model.sample_streams and bhi - blo > 1 and bev.is_cuda:
-            return model._bev_stack_per_sample(bev, ego[blo:bhi], None, nz)
-        return eng.bev_stack(bev, ego[blo:bhi], None, nz)
+            return model._bev_stack_per_sample(bev, ego[blo:bhi], None, nz, theta)
+        return eng.bev_stack(bev, ego[blo:bhi], None, nz, theta=theta)
 
     sharder = getattr(model, '_sharder', None)
     if sharder is None or sharder.group is not group or sharder.requested != layout:

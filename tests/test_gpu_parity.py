@@ -567,8 +567,15 @@ def test_other_reference_configs_against_the_live_oracle(hip, preset, n_cam):
 # ------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('extent,hw', [((50.0, 50.0), (200, 200)), ((50.0, 25.0), (400, 200))])
 def test_cumulative_warp_vs_oracle_full_size(hip, extent, hw):
-    """`fiery_warp_params` + `fiery_bev_warp_nchw_to_nhwc` against the oracle's `cumulative_warp_features` (bitwise equal
-    to the reference's, tests/test_oracle_vs_reference.py) at the real map sizes: thetas and every warped element."""
+    """`fiery_bev_warp_nchw_to_nhwc` against the oracle's `cumulative_warp_features` (bitwise equal to the reference's,
+    tests/test_oracle_vs_reference.py) at the real map sizes, on white noise - the worst case for a resampler: neighbouring
+    pixels are unrelated, so a sampling position one ulp off (2e-5 pixel) shows at full size.
+
+    * transforms from `host_warp_transforms` (the reference's own host operators): every warped element EQUALS ATen's
+      affine_grid + grid_sample - the kernel reproduces their rounding order (csrc/warp.hip, top);
+    * transforms from `fiery_warp_params` (device pose algebra, the default): equal wherever the device's correctly
+      rounded cos / sin / atan2 agree with MKL's and SLEEF's, else one ulp of a transform entry apart - reported."""
+    from fiery_amd.model import host_warp_transforms
     B, S, C = 2, 3, 64
     H, W = hw
     g = torch.Generator().manual_seed(31)
@@ -579,20 +586,33 @@ def test_cumulative_warp_vs_oracle_full_size(hip, extent, hw):
     ego[..., 5] = 0.02 * torch.randn(B, S, generator=g)
     want = bev_stack.cumulative_warp_features(x, ego, 'bilinear', extent)
     want_theta = bev_stack.cumulative_warp_thetas(ego, extent)
-    theta = hip.warp_params(ego.to(DEV), extent)
-    out = Buf.alloc(B * S, H, W, C, DEV)
     identity = [(i % S) == S - 1 for i in range(B * S)]
-    hip.bev_warp_nchw_to_nhwc(x.view(B * S, C, H, W).to(DEV), theta.view(B * S, 6), identity, out.tensor, out.ld, out.img_stride)
-    got = out.to_nchw().view(B, S, C, H, W).cpu()
-    t_err = max((theta[:, t].view(B, 2, 3).cpu() - want_theta[t]).abs().max().item() for t in range(S - 1))
-    parity_report.record(f'warp {H}x{W}', 'theta', t_err, 1.0, bound=1e-6)
-    assert t_err <= 1e-6
+
+    def run(theta):
+        out = Buf.alloc(B * S, H, W, C, DEV)
+        hip.bev_warp_nchw_to_nhwc(x.view(B * S, C, H, W).to(DEV), theta.view(B * S, 6).contiguous(), identity, out.tensor, out.ld,
+                                  out.img_stride)
+        return out.to_nchw().view(B, S, C, H, W).cpu()
+
+    host_theta = host_warp_transforms(ego, extent)
+    for t in range(S - 1):
+        assert torch.equal(host_theta[:, t], want_theta[t].reshape(B, 6))
+    got = run(host_theta.to(DEV))
     err = (got - want).abs().max().item()
-    parity_report.record(f'warp {H}x{W}', 'warped features', err, want.abs().max().item())
+    parity_report.record(f'warp {H}x{W}', 'warped features (host transforms)', err, want.abs().max().item(), bound=1e-5)
+    assert torch.equal(got, want), err                                # bit for bit
+
+    theta = hip.warp_params(ego.to(DEV), extent)
+    t_err = max((theta[:, t].view(B, 2, 3).cpu() - want_theta[t]).abs().max().item() for t in range(S - 1))
+    exact = sum((theta[:, t].view(B, 2, 3).cpu() == want_theta[t]).sum().item() for t in range(S - 1))
+    parity_report.record(f'warp {H}x{W}', 'theta (device pose algebra)', t_err, 1.0, bound=1e-8,
+                         note=f'{exact} of {B * (S - 1) * 6} entries bit-equal; the rest one ulp (MKL VML cos/sin, SLEEF atan2)')
+    assert t_err <= 1e-8
+    got = run(theta)
+    err = (got - want).abs().max().item()
+    parity_report.record(f'warp {H}x{W}', 'warped features (device transforms)', err, want.abs().max().item(),
+                         note='white noise; one ulp of a transform entry = one ulp of a sampling position')
     assert torch.equal(got[:, S - 1], x[:, S - 1])                    # the present frame is untouched
-    # white-noise maps are the worst case for a resampler (neighbouring pixels are unrelated, so a 1e-5-pixel difference in
-    # a sampling position shows up at full size); ATen builds its base grid with linspace and a BLAS product, the kernel
-    # evaluates (2x + 1) / W - 1 directly: same positions to ~1e-5 pixel
     assert err <= TOL * max(1.0, want.abs().max().item())
 
 

@@ -49,6 +49,48 @@ def test_bev_warp_matches_grid_sample_and_changes_layout(sim):
     assert out[..., C:].abs().max() == 0
 
 
+@pytest.mark.parametrize('extent,hw', [((50.0, 50.0), (200, 200)), ((50.0, 25.0), (400, 200)), ((6.0, 35.0), (37, 53))])
+def test_bev_warp_is_bitwise_aten_given_the_hosts_transforms(sim, extent, hw):
+    """The resampling kernel rounds like ATen's CPU affine_grid + grid_sample (linspace halves, BLAS product with k
+    ascending, fused un-normalisation, fused four-term sum: csrc/warp.hip, top): with the transforms of
+    `host_warp_transforms` - the reference's own host operators - every element of every warped frame EQUALS the oracle's
+    (= the reference's, tests/test_oracle_vs_reference.py), on white noise, at the real map sizes and at an odd one."""
+    from fiery_amd.model import host_warp_transforms
+    B, S, C = 2, 3, 3
+    H, W = hw
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, S, C, H, W, generator=g)
+    ego = torch.zeros(B, S, 6)
+    ego[..., 0] = 2.5 + 0.5 * torch.rand(B, S, generator=g)
+    ego[..., 1] = 0.1 * torch.randn(B, S, generator=g)
+    ego[..., 5] = 0.02 * torch.randn(B, S, generator=g)
+    ego[1, :, 2:5] = 0.01 * torch.randn(S, 3, generator=g)            # roll / pitch / tz must be ignored the same way
+    want = bev_stack.cumulative_warp_features(x, ego, 'bilinear', extent)
+    theta = host_warp_transforms(ego, extent)
+    for t, wt in enumerate(bev_stack.cumulative_warp_thetas(ego, extent)):
+        assert torch.equal(theta[:, t], wt.reshape(B, 6))
+    out = torch.zeros(B * S, H, W, 8)
+    identity = [(i % S) == S - 1 for i in range(B * S)]
+    sim.bev_warp_nchw_to_nhwc(x.view(B * S, C, H, W), theta.view(B * S, 6).contiguous(), identity, out, 8, H * W * 8)
+    got = out[..., :C].permute(0, 3, 1, 2).reshape(B, S, C, H, W)
+    assert torch.equal(got, want), (got - want).abs().max()
+    # the device's own pose algebra: equal for most transforms, one ulp off where MKL / SLEEF do not round correctly
+    dev_theta = sim.warp_params(ego, extent)
+    assert (dev_theta - theta).abs().max() <= 1e-8
+    assert (dev_theta == theta).float().mean() > 0.7
+
+
+def test_host_warp_transforms_large_rotations_and_single_frame():
+    from fiery_amd.model import host_warp_transforms
+    g = torch.Generator().manual_seed(5)
+    ego = torch.randn(4, 5, 6, generator=g)
+    theta = host_warp_transforms(ego, (50.0, 25.0))
+    for t, wt in enumerate(bev_stack.cumulative_warp_thetas(ego, (50.0, 25.0))):
+        assert torch.equal(theta[:, t], wt.reshape(4, 6))
+    assert torch.equal(theta[:, 4], torch.tensor([1.0, 0, 0, 0, 1, 0]).expand(4, 6))
+    assert torch.equal(host_warp_transforms(ego[:, :1], (50.0, 50.0))[:, 0], torch.tensor([1.0, 0, 0, 0, 1, 0]).expand(4, 6))
+
+
 @pytest.mark.parametrize('C', [70, 64])          # 70: scalar rows; 64 of 72: the 16-byte kernel
 def test_spatial_mean(sim, C):
     g = torch.Generator().manual_seed(2)

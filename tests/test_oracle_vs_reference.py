@@ -79,6 +79,25 @@ def test_warp_matches_reference(ref):
     assert torch.equal(got, want)
 
 
+def test_product_warp_kernel_is_bitwise_the_reference(ref, sim):
+    """The product's resampling kernel (its source on the CPU simulator) fed with `host_warp_transforms` against the
+    REFERENCE's `cumulative_warp_features` itself, white noise at the baseline map size: equal bit for bit."""
+    from fiery_amd.model import host_warp_transforms
+    g = torch.Generator().manual_seed(7)
+    B, S, C, H, W = 1, 3, 2, 200, 200
+    x = torch.randn(B, S, C, H, W, generator=g)
+    ego = torch.zeros(B, S, 6)
+    ego[..., 0] = 2.5 + 0.5 * torch.rand(B, S, generator=g)
+    ego[..., 1] = 0.1 * torch.randn(B, S, generator=g)
+    ego[..., 5] = 0.02 * torch.randn(B, S, generator=g)
+    want = ref.geometry.cumulative_warp_features(x.clone(), ego, mode='bilinear', spatial_extent=(50.0, 50.0))
+    theta = host_warp_transforms(ego, (50.0, 50.0))
+    out = torch.zeros(B * S, H, W, 8)
+    sim.bev_warp_nchw_to_nhwc(x.view(B * S, C, H, W), theta.view(B * S, 6).contiguous(), [False, False, True], out, 8, H * W * 8)
+    got = out[..., :C].permute(0, 3, 1, 2).reshape(B, S, C, H, W)
+    assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize('preset,B,labels', [('baseline.yml', 2, True), ('literature/static_lss_setting.yml', 1, False),
                                              ('literature/pon_setting.yml', 1, False), ('lyft/baseline.yml', 1, True),
                                              ('literature/fishing_setting.yml', 1, False),
