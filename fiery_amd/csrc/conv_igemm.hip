@@ -219,8 +219,17 @@ int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, bool launch) {
     }
     const int taps = d->kT * d->kH * d->kW;
     ConvP p;
-    for (int s = 0; s < 2; ++s)
-        p.src[s] = SrcP{d->src[s].ptr, d->src[s].ld, d->src[s].units, d->src[s].batch_stride, d->src[s].time_stride};
+    for (int s = 0; s < 2; ++s) {
+        // bytes from ptr to the end of the last row the launch may read: last batch element, last frame (output frame
+        // T_out - 1 reads source frame T_out - 1 + t_in_add at its latest tap), last pixel, the source's channel units.
+        // Meaningful (and used) for the scalar-addressed loop only, which requires non-negative strides and < 2^29 floats.
+        const long long n_batch = d->n_img_out / d->T_out;
+        const long long ext = (n_batch - 1) * d->src[s].batch_stride +
+                              (static_cast<long long>(d->T_out) - 1 + d->t_in_add) * d->src[s].time_stride +
+                              (static_cast<long long>(d->Hin) * d->Win - 1) * d->src[s].ld + d->src[s].units * 8;
+        const int ext_bytes = (d->src[s].units > 0 && ext > 0 && ext < (1ll << 29)) ? static_cast<int>(4 * ext) : 0;
+        p.src[s] = SrcP{d->src[s].ptr, d->src[s].ld, d->src[s].units, d->src[s].batch_stride, d->src[s].time_stride, ext_bytes};
+    }
     p.Hin = d->Hin; p.Win = d->Win; p.Hout = d->Hout; p.Wout = d->Wout;
     p.n_img = d->n_img_out; p.Tout = d->T_out; p.tout0 = d->t_out0; p.tinadd = d->t_in_add;
     p.kT = d->kT; p.kH = d->kH; p.kW = d->kW; p.stride = d->stride; p.padH = d->padH; p.padW = d->padW;

@@ -41,6 +41,8 @@ struct SrcP {
     const float* ptr;
     int ld, units;
     long long bstride, tstride;
+    int ext_bytes;        // bytes from ptr to the end of the last row this launch may read (scalar-addressed loop: the
+                          // buffer descriptor's size, so that the hardware returns zeros for anything beyond it)
 };
 struct TensP {
     float* ptr;
@@ -200,6 +202,7 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
     const float* const src1_ptr = p.src[1].ptr;
     const int src0_ld = p.src[0].ld, src1_ld = p.src[1].ld, src0_units = p.src[0].units;
     const int src0_ts = static_cast<int>(p.src[0].tstride), src1_ts = static_cast<int>(p.src[1].tstride);
+    const int src0_ext = p.src[0].ext_bytes, src1_ext = p.src[1].ext_bytes;
 
     float4 areg0, areg1, areg2, areg3;          // named, like breg*: an indexed array that lives across iterations ends up in scratch
     areg0 = areg1 = areg2 = areg3 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
     // weights: one descriptor for this cout tile's packed image; thread t reads bytes [16 t, 16 t + 16) of every 4 KiB
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(p.w) + static_cast<long long>(tile_n) * p.k_chunks * (BK * BN * W_BYTES)), 0,
-        0x7fffffff, 0x00020000);
+        p.k_chunks * (BK * BN * W_BYTES), 0x00020000);             // exactly this cout tile's packed image
     // (bf16, BN = 32: a stage's weights are 2 KiB, half the threads have nothing to fetch and point past the descriptor)
     const int w_voff = (BF16 && BN == 32 && tid >= 128) ? static_cast<int>(0x80000000u) : tid * 16;
     int w_soff = 0;
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
 
     // (the scalar unit issues in order with the MFMAs: the stage's scalar bookkeeping is cut in three so that no single
     // gap between two MFMAs has to take all of it)
-    int s_ld = 0, s_ts = 0;
+    int s_ld = 0, s_ts = 0, s_ext = 0;
     const float* s_base = nullptr;
     auto load_setup = [&](int part) {
         if constexpr (ALIGNED) {
@@ -303,12 +306,14 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
                 s_base = s_second ? src1_ptr : src0_ptr;
                 s_ld = s_second ? src1_ld : src0_ld;
                 s_ts = s_second ? src1_ts : src0_ts;
+                s_ext = s_second ? src1_ext : src0_ext;
                 w_soff = (ld_stage < c_k_chunks ? ld_stage : c_k_chunks - 1) * (BK * BN * W_BYTES);      // past the end: repeat
             } else if (part == 1) {
                 // the descriptor's base sits (kT-1) frames and (padH, padW) pixels before the source, so that the
-                // tap's offset below is never negative; its size only has to exceed every real offset
-                const float* base = s_base - ((p.kT - 1) * s_ts + (p.padH * c_Win + p.padW) * s_ld);
-                s_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+                // tap's offset below is never negative; it ends with the last row the launch may read: the range check
+                // covers vector + scalar offset (tools/probe/buffer_oob_probe.hip), so nothing beyond is ever touched
+                const int lead = (p.kT - 1) * s_ts + (p.padH * c_Win + p.padW) * s_ld;
+                s_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s_base - lead), 0, 4 * lead + s_ext, 0x00020000);
             } else {
                 s_off = 4 * (s_dt * s_ts + (s_dy * c_Win + s_dx) * s_ld + (s_g - (s_second ? s_groups0 : 0)) * 32);
             }

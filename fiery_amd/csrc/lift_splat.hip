@@ -684,8 +684,11 @@ __global__ __launch_bounds__(kFused ? 512 : 1024) void k_voxel_pool(
         // A row address is (wave-uniform plane base + row * stride) + a 32-bit lane offset.  As a buffer load that is
         // descriptor + scalar offset + one vector register per item: no vector instruction is spent on addresses and
         // no 64-bit pointer is held per lane.  (The host checks that the byte offsets fit 31 bits.)
-        const __amdgpu_buffer_rsrc_t rows = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + f * xs.f + c * xs.c), 0,
-                                                                              0x7fffffff, 0x00020000);
+        // (sized to this (frame, channel) slab's last element: the range check covers vector + scalar offset, so a row
+        // request beyond it returns zeros and touches no memory - tools/probe/buffer_oob_probe.hip)
+        const __amdgpu_buffer_rsrc_t rows = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(x + f * xs.f + c * xs.c), 0,
+            4 * static_cast<int>((n_cam - 1) * xs.n + (D - 1) * xs.d + (H - 1) * xs.h + (W - 1) * xs.w + 1), 0x00020000);
         auto rows_of = [&](int e) {
             const int w = (e & ((1 << kPackW) - 1)) * kVec;
             const int d = (e >> kPackW) & ((1 << kPackD) - 1);
@@ -1142,11 +1145,15 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
     // descriptor (reads zeros).
     constexpr int kOob = static_cast<int>(0x80000000u);
     constexpr int kRecBytes = kWide ? 64 : 32;
-    const __amdgpu_buffer_rsrc_t rows = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + f * xs.f + c * xs.c), 0, 0x7fffffff,
-                                                                          0x00020000);
+    // Both descriptors end with the last byte this workgroup may read (its (frame, channel) slab of rows, its frame's
+    // records): the hardware's range check covers vector + scalar offset (tools/probe/buffer_oob_probe.hip), so the
+    // look-ahead request past the last slice returns zeros and touches no memory.
+    const __amdgpu_buffer_rsrc_t rows = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(x + f * xs.f + c * xs.c), 0,
+        4 * static_cast<int>((n_cam - 1) * xs.n + (D - 1) * xs.d + (H - 1) * xs.h + (W - 1) * xs.w + 1), 0x00020000);
     const __amdgpu_buffer_rsrc_t recs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(static_cast<const char*>(quads) + static_cast<long long>(f) * n_slices * Wq * kRecBytes), 0, 0x7fffffff,
-        0x00020000);
+        const_cast<char*>(static_cast<const char*>(quads) + static_cast<long long>(f) * n_slices * Wq * kRecBytes), 0,
+        n_slices * Wq * kRecBytes, 0x00020000);
     const int split_voff = lane_ok ? q * kRecBytes : kOob;
     const int rank_voff = (lane_ok && g < 3) ? q * kRecBytes + (kWide ? 16 + 16 * g : 8 + 8 * g) : kOob;
     const int row_voff = lane_ok ? 4 * static_cast<int>(g * xs.h + q * 4 * xs.w) : kOob;

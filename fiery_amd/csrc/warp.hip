@@ -19,7 +19,10 @@ constexpr int kMaxFrames = 16;
 // (torch 2.x x86 build; determined by bit-comparison, tests/test_kernels_sim_aux.py keeps checking it):
 //   * torch.linspace(-1, 1, n): first half fma(step, i, -1), second half fma(-step, n-1-i, 1), step = 2/(n-1);
 //     affine_grid(align_corners=False) scales it as (v * (n-1)) / n            (AffineGridGenerator.cpp)
-//   * the base grid times theta^T is a BLAS product with k ascending: fma(1, t2, fma(y, t1, x*t0))
+//   * the base grid times theta^T is a BLAS (MKL sgemm) product, and MKL picks its kernel by the HOST CPU: on Intel parts
+//     it fuses, k ascending - fma(1, t2, fma(y, t1, x*t0)) -, on AMD EPYC parts it rounds every product and sum on its own
+//     - (x*t0 + y*t1) + t2.  Both were measured (tools/probe/aten_warp_probe.py); FIERY_WARP_FUSED_GRID_PRODUCT in the
+//     `flags` argument selects the form, and the Python binding asks the local ATen which one it is.
 //   * grid_sample un-normalises with fma(g + 1, size/2, -0.5), forms the weights as (1-tx)(1-ty) ... tx.ty and sums
 //     fma(v_se, w_se, fma(v_sw, w_sw, fma(v_ne, w_ne, v_nw*w_nw))) with 0 for corners outside (GridSamplerKernel.cpp)
 //   * 3x3 / 4x4 matrix products: ATen's small-matrix loop, products and sums rounded separately, k ascending
@@ -33,16 +36,16 @@ __device__ inline float sin_rn(float v) { return static_cast<float>(sin(static_c
 // element i of  linspace(-1, 1, n) * (n - 1) / n
 __device__ inline float base_coord(int i, int n) {
     if (n <= 1) return 0.f;
-    const float step = 2.0f / static_cast<float>(n - 1);
+    const float step = __fdiv_rn(2.0f, static_cast<float>(n - 1));      // (a plain '/' is not correctly rounded in device code)
     const float l = i < n / 2 ? fmaf(step, static_cast<float>(i), -1.0f) : fmaf(-step, static_cast<float>(n - 1 - i), 1.0f);
-    return (l * static_cast<float>(n - 1)) / static_cast<float>(n);
+    return __fdiv_rn(l * static_cast<float>(n - 1), static_cast<float>(n));
 }
 
 // un-normalised sampling position of output pixel (x, y) under the 2x3 transform th
-__device__ inline void sample_position(const float* th, int x, int y, int W, int H, float& fx, float& fy) {
+__device__ inline void sample_position(const float* th, int x, int y, int W, int H, bool fused, float& fx, float& fy) {
     const float xb = base_coord(x, W), yb = base_coord(y, H);
-    const float gx = fmaf(yb, th[1], xb * th[0]) + th[2];
-    const float gy = fmaf(yb, th[4], xb * th[3]) + th[5];
+    const float gx = (fused ? fmaf(yb, th[1], xb * th[0]) : xb * th[0] + yb * th[1]) + th[2];
+    const float gy = (fused ? fmaf(yb, th[4], xb * th[3]) : xb * th[3] + yb * th[4]) + th[5];
     fx = fmaf(gx + 1.0f, static_cast<float>(W) * 0.5f, -0.5f);
     fy = fmaf(gy + 1.0f, static_cast<float>(H) * 0.5f, -0.5f);
 }
@@ -109,8 +112,8 @@ __global__ void k_warp_params(const float* __restrict__ ego, int B, int S, float
         const float rz = static_cast<float>(atan2(static_cast<double>(-cum[1]), static_cast<double>(cum[0])));
         const float c = cos_rn(rz), s = sin_rn(rz);
         float* o = th + t * 6;
-        o[0] = c;  o[1] = -s;  o[2] = cum[7] / ext_y;
-        o[3] = s;  o[4] = c;   o[5] = -(cum[3] / ext_x);
+        o[0] = c;  o[1] = -s;  o[2] = __fdiv_rn(cum[7], ext_y);
+        o[3] = s;  o[4] = c;   o[5] = -__fdiv_rn(cum[3], ext_x);
         if (t > 0) {
             pose_to_mat(ego + (static_cast<long long>(b) * S + (t - 1)) * 6, step);
             mat4_mul(step, cum, next);
@@ -151,15 +154,16 @@ __global__ void k_warp_params_reverse(const float* __restrict__ ego, int B, int 
         const float rz = static_cast<float>(atan2(static_cast<double>(-cum[1]), static_cast<double>(cum[0])));
         const float c = cos_rn(rz), s = sin_rn(rz);
         float* o = th + i * 6;
-        o[0] = c;  o[1] = -s;  o[2] = cum[7] / ext_y;
-        o[3] = s;  o[4] = c;   o[5] = -(cum[3] / ext_x);
+        o[0] = c;  o[1] = -s;  o[2] = __fdiv_rn(cum[7], ext_y);
+        o[3] = s;  o[4] = c;   o[5] = -__fdiv_rn(cum[3], ext_x);
     }
 }
 
 // grid_sample(mode='nearest', padding_mode='zeros', align_corners=False) of channel planes: labels stay NCHW.
 // One thread per output pixel walks the channels (1 .. 6 for the label tensors of trainer.py:133-191).
 __global__ __launch_bounds__(256) void k_bev_warp_nearest(const float* __restrict__ in, const float* __restrict__ theta,
-                                                          int C, int H, int W, float* __restrict__ out, long long total) {
+                                                          int C, int H, int W, float* __restrict__ out, long long total,
+                                                          int flags) {
     const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int x = static_cast<int>(i % W);
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(256) void k_bev_warp_nearest(const float* __restric
     const int img = static_cast<int>(i / (static_cast<long long>(W) * H));
     const float* th = theta + img * 6;
     float px, py;
-    sample_position(th, x, y, W, H, px, py);
+    sample_position(th, x, y, W, H, (flags & FIERY_WARP_FUSED_GRID_PRODUCT) != 0, px, py);
     // nearest: the un-normalised coordinate rounded half to even (ATen uses nearbyint)
     const float fx = nearbyintf(px);
     const float fy = nearbyintf(py);
@@ -191,7 +195,7 @@ struct IdentityFlags {
 // the 64-pixel x C tile leaves LDS pixel-major with lanes along channels (unit-stride NHWC writes).
 __global__ __launch_bounds__(256) void k_bev_warp(const float* __restrict__ in, const float* __restrict__ theta,
                                                   IdentityFlags identity, int C, int H, int W,
-                                                  float* __restrict__ out, int out_ld, long long out_img_stride) {
+                                                  float* __restrict__ out, int out_ld, long long out_img_stride, int flags) {
     HIP_DYNAMIC_SHARED(float, tile)            // [kWarpTile][C + 1]
     const int img = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * kWarpTile;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(256) void k_bev_warp(const float* __restrict__ in, 
         const float* th = theta + img * 6;
         // affine_grid + grid_sample un-normalisation, align_corners=False, in ATen's rounding order (top of file)
         float fx, fy;
-        sample_position(th, x, y, W, H, fx, fy);
+        sample_position(th, x, y, W, H, (flags & FIERY_WARP_FUSED_GRID_PRODUCT) != 0, fx, fy);
         const float flx = floorf(fx), fly = floorf(fy);
         ix0 = static_cast<int>(flx);
         iy0 = static_cast<int>(fly);
@@ -261,19 +265,19 @@ extern "C" int fiery_warp_params(const float* future_egomotion, int B, int S, fl
 }
 
 extern "C" int fiery_bev_warp_nchw_to_nhwc(const float* in, const float* theta, const uint8_t* identity, int n_img, int C,
-                                           int H, int W, float* out, int out_ld, int64_t out_img_stride,
+                                           int H, int W, float* out, int out_ld, int64_t out_img_stride, int flags,
                                            fiery_stream_t stream) {
     FIERY_REQUIRE(in && theta && out, "bev_warp: null pointer");
     FIERY_REQUIRE(n_img > 0 && C > 0 && H > 0 && W > 0 && out_ld >= C, "bev_warp: bad shape");
     FIERY_REQUIRE(static_cast<size_t>(kWarpTile) * (C + 1) * sizeof(float) <= 160 * 1024, "bev_warp: too many channels");
     for (int i0 = 0; i0 < n_img; i0 += kMaxWarpImages) {
         const int n = n_img - i0 < kMaxWarpImages ? n_img - i0 : kMaxWarpImages;
-        IdentityFlags flags;
-        for (int i = 0; i < kMaxWarpImages; ++i) flags.v[i] = (identity && i < n && identity[i0 + i]) ? 1 : 0;
+        IdentityFlags ident;
+        for (int i = 0; i < kMaxWarpImages; ++i) ident.v[i] = (identity && i < n && identity[i0 + i]) ? 1 : 0;
         hipLaunchKernelGGL(k_bev_warp, dim3(ceil_div(W, kWarpTile), H, n), dim3(256),
                            static_cast<size_t>(kWarpTile) * (C + 1) * sizeof(float), as_stream(stream),
-                           in + static_cast<long long>(i0) * C * H * W, theta + static_cast<long long>(i0) * 6, flags, C, H, W,
-                           out + static_cast<long long>(i0) * out_img_stride, out_ld, static_cast<long long>(out_img_stride));
+                           in + static_cast<long long>(i0) * C * H * W, theta + static_cast<long long>(i0) * 6, ident, C, H, W,
+                           out + static_cast<long long>(i0) * out_img_stride, out_ld, static_cast<long long>(out_img_stride), flags);
         int rc = check_launch("bev_warp");
         if (rc) return rc;
     }
@@ -290,11 +294,11 @@ extern "C" int fiery_warp_params_reverse(const float* future_egomotion, int B, i
 }
 
 extern "C" int fiery_bev_warp_nearest_nchw(const float* in, const float* theta, int n_img, int C, int H, int W, float* out,
-                                           fiery_stream_t stream) {
+                                           int flags, fiery_stream_t stream) {
     FIERY_REQUIRE(in && theta && out && in != out, "bev_warp_nearest: null pointer or in-place call");
     FIERY_REQUIRE(n_img > 0 && C > 0 && H > 0 && W > 0, "bev_warp_nearest: bad shape");
     const long long total = static_cast<long long>(n_img) * H * W;
     hipLaunchKernelGGL(k_bev_warp_nearest, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), in, theta, C, H, W, out,
-                       total);
+                       total, flags);
     return check_launch("bev_warp_nearest");
 }

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libfiery_hip.so')
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -24,6 +24,7 @@ ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SWISH = 0, 1, 2, 3
 PRECISION_F32, PRECISION_BF16 = 0, 1
 EPI_PLAIN, EPI_GRU_GATES, EPI_GRU_OUT, EPI_HEADS = 0, 1, 2, 3
 POOL_DETERMINISTIC = 1
+WARP_FUSED_GRID_PRODUCT = 1
 
 
 class BevGrid(C.Structure):
@@ -109,9 +110,9 @@ _SIGNATURES = {
     'fiery_depth_softmax_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'fiery_warp_params': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     'fiery_warp_params_reverse': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
-    'fiery_bev_warp_nearest_nchw': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'fiery_bev_warp_nearest_nchw': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'fiery_bev_warp_nchw_to_nhwc': (C.c_int, [C.c_void_p, C.c_void_p, c_uint8_p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                              C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
+                                              C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p]),
     'fiery_conv_packed_floats': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'fiery_conv_pack_weights': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_int32_p, C.c_int, C.c_void_p, C.c_void_p]),
     'fiery_conv_fwd': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
@@ -175,6 +176,37 @@ _SIGNATURES = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_WARP_FLAGS = {}
+
+
+def warp_flags_of_this_host(h, w):
+    """`flags` for the resampling kernels such that they round like THIS host's ATen: affine_grid multiplies its base grid
+    with theta^T through MKL's sgemm, which fuses the three-term product on Intel CPUs and rounds every operation on AMD
+    ones (include/fiery_hip.h, FIERY_WARP_FUSED_GRID_PRODUCT).  The reference's CPU path is whatever the local ATen does,
+    so the local ATen is asked once per map size: one affine_grid of that size on a fixed transform, compared with the
+    two candidate evaluations.  `FIERY_WARP_GRID_PRODUCT=fused|plain` overrides (e.g. to reproduce another host's bits)."""
+    forced = os.environ.get('FIERY_WARP_GRID_PRODUCT')
+    if forced:
+        return WARP_FUSED_GRID_PRODUCT if forced == 'fused' else 0
+    key = (int(h), int(w))
+    if key not in _WARP_FLAGS:
+        import numpy as np
+        theta = torch.tensor([[[0.99981, -0.01937, 0.01234], [0.01937, 0.99981, -0.05678]]], dtype=torch.float32)
+        grid = torch.nn.functional.affine_grid(theta, (1, 1, key[0], key[1]), align_corners=False)[0, ..., 0].numpy()
+        lin = lambda n: (torch.linspace(-1, 1, n) * (n - 1) / n).numpy() if n > 1 else np.zeros(1, np.float32)
+        xs, ys = np.meshgrid(lin(key[1]), lin(key[0]))
+        t0, t1, t2 = (np.float32(v) for v in theta[0, 0].tolist())
+        first = (xs * t0).astype(np.float32)
+        plain = ((first + (ys * t1).astype(np.float32)).astype(np.float32) + t2).astype(np.float32)
+        fused = ((ys.astype(np.float64) * np.float64(t1) + first.astype(np.float64)).astype(np.float32) + t2).astype(np.float32)
+        if np.array_equal(grid, fused) and not np.array_equal(grid, plain):
+            _WARP_FLAGS[key] = WARP_FUSED_GRID_PRODUCT
+        elif np.array_equal(grid, plain):
+            _WARP_FLAGS[key] = 0
+        else:            # an ATen / BLAS build that does neither: keep the fused form (documented, 1 ulp of a position apart)
+            _WARP_FLAGS[key] = WARP_FUSED_GRID_PRODUCT
+    return _WARP_FLAGS[key]
 
 
 class Lib:
@@ -310,18 +342,20 @@ class Lib:
                                                       _ptr(theta), _stream_of(theta)))
         return theta
 
-    def bev_warp_nearest(self, x, theta):
+    def bev_warp_nearest(self, x, theta, flags=None):
         """x (n, C, H, W) f32 contiguous, theta (n, 6) -> the nearest-neighbour resampling (n, C, H, W)."""
         n, c, h, w = x.shape
         out = torch.empty_like(x)
-        self.check(self.dll.fiery_bev_warp_nearest_nchw(_ptr(x), _ptr(theta), n, c, h, w, _ptr(out), _stream_of(out)))
+        flags = warp_flags_of_this_host(h, w) if flags is None else flags
+        self.check(self.dll.fiery_bev_warp_nearest_nchw(_ptr(x), _ptr(theta), n, c, h, w, _ptr(out), flags, _stream_of(out)))
         return out
 
-    def bev_warp_nchw_to_nhwc(self, x, theta, identity, out, out_ld, out_img_stride):
+    def bev_warp_nchw_to_nhwc(self, x, theta, identity, out, out_ld, out_img_stride, flags=None):
         n, c, h, w = x.shape
         ident = (C.c_uint8 * n)(*[1 if v else 0 for v in identity]) if identity is not None else None
+        flags = warp_flags_of_this_host(h, w) if flags is None else flags
         self.check(self.dll.fiery_bev_warp_nchw_to_nhwc(_ptr(x), _ptr(theta), ident, n, c, h, w, _ptr(out), out_ld,
-                                                        out_img_stride, _stream_of(out)))
+                                                        out_img_stride, flags, _stream_of(out)))
 
     # -- conv -------------------------------------------------------------------------------------
     def conv_pack_weights(self, w, cout, cin_total, taps, chan_map, cin_units):

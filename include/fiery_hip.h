@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FIERY_ABI_VERSION 15
+#define FIERY_ABI_VERSION 16
 
 #define FIERY_OK 0
 #define FIERY_EINVAL (-22)      /* bad argument (shape, alignment, null pointer) */
@@ -167,11 +167,18 @@ int fiery_warp_params(const float* future_egomotion, int B, int S, float extent_
 int fiery_warp_params_reverse(const float* future_egomotion, int B, int S, float extent_x, float extent_y,
                               float* theta, fiery_stream_t stream);
 
+/* `flags` of the two resampling entry points.  The sampling positions are evaluated in the rounding order of ATen's CPU
+ * affine_grid + grid_sample (csrc/warp.hip), whose one host-dependent step is the BLAS product base_grid . theta^T: MKL
+ * fuses it (k ascending) on Intel hosts and rounds products and sums separately on AMD hosts.  Set
+ * FIERY_WARP_FUSED_GRID_PRODUCT for the fused form; with the right form for the host the reference's CPU path was
+ * timed on, and transforms computed by that host, the resampled maps equal the reference's bit for bit. */
+#define FIERY_WARP_FUSED_GRID_PRODUCT 1
+
 /* out[img][c][y][x] = in[img][c][nearest source pixel of (y, x) under theta[img]] or 0 outside the map:
  * grid_sample(mode='nearest', padding_mode='zeros', align_corners=False) on channel planes (the label tensors are
  * NCHW with 1 .. 6 channels).  in and out [n_img][C][H][W], theta [n_img][6]; not in place. */
 int fiery_bev_warp_nearest_nchw(const float* in, const float* theta, int n_img, int C, int H, int W, float* out,
-                                fiery_stream_t stream);
+                                int flags, fiery_stream_t stream);
 
 /* Bilinear grid-sample with zero padding, align_corners=False (geometry.py:219-220), reading NCHW
  * [n_img][C][H][W] and writing NHWC (ld, img_stride as given).  Images whose `identity[i]` (host
@@ -179,7 +186,7 @@ int fiery_bev_warp_nearest_nchw(const float* in, const float* theta, int n_img, 
  * geometry.py:245). */
 int fiery_bev_warp_nchw_to_nhwc(const float* in, const float* theta /* [n_img][6] */,
                                 const uint8_t* identity /* host */, int n_img, int C, int H, int W,
-                                float* out, int out_ld, int64_t out_img_stride, fiery_stream_t stream);
+                                float* out, int out_ld, int64_t out_img_stride, int flags, fiery_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * BEV convolution stack            (reference: fiery/layers/convolutions.py, fiery/layers/temporal.py,

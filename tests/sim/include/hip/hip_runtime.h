@@ -260,31 +260,38 @@ inline hipError_t hipMemcpyToSymbolAsync(void* symbol, const void* src, size_t n
     __builtin_memcpy(static_cast<char*>(symbol) + offset, src, n);
     return hipSuccess;
 }
-// raw buffer loads: a descriptor is (base, size in bytes); an offset past the size reads zeros; the scalar offset is
-// not range-checked (as on the hardware)
+// raw buffer loads as gfx950 executes them (measured: tools/probe/buffer_oob_probe.hip, profiles/r3_buffer_oob_probe.txt):
+// a descriptor is (base, size in bytes); the range check covers the vector offset PLUS the scalar offset (both taken as
+// unsigned, the sum not wrapped) and is applied per dword - a 16-byte load that straddles the end returns its leading
+// dwords and zeros; everything outside reads 0 and touches no memory.
 struct __amdgpu_buffer_rsrc_t { const char* base; unsigned num; };
 inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, int num, int) {
     return {static_cast<const char*>(p), static_cast<unsigned>(num)};
 }
+template <int DWORDS>
+inline void hipsim_buffer_load(__amdgpu_buffer_rsrc_t r, int voff, int soff, unsigned* dst) {
+    const unsigned long long off = static_cast<unsigned long long>(static_cast<unsigned>(voff)) + static_cast<unsigned>(soff);
+    for (int i = 0; i < DWORDS; ++i) {
+        dst[i] = 0;
+        if (off + 4ull * i + 4ull <= r.num) __builtin_memcpy(&dst[i], r.base + off + 4 * i, 4);
+    }
+}
 typedef unsigned hipsim_v4u __attribute__((vector_size(16)));
 inline hipsim_v4u __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
-    hipsim_v4u v = {0, 0, 0, 0};
-    if (static_cast<unsigned long long>(static_cast<unsigned>(voff)) + 16ull <= r.num)
-        __builtin_memcpy(&v, r.base + static_cast<unsigned>(voff) + static_cast<long long>(soff), 16);
-    return v;
+    unsigned d[4];
+    hipsim_buffer_load<4>(r, voff, soff, d);
+    return hipsim_v4u{d[0], d[1], d[2], d[3]};
 }
 typedef unsigned hipsim_v2u __attribute__((vector_size(8)));
 inline hipsim_v2u __builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
-    hipsim_v2u v = {0, 0};
-    if (static_cast<unsigned long long>(static_cast<unsigned>(voff)) + 8ull <= r.num)
-        __builtin_memcpy(&v, r.base + static_cast<unsigned>(voff) + static_cast<long long>(soff), 8);
-    return v;
+    unsigned d[2];
+    hipsim_buffer_load<2>(r, voff, soff, d);
+    return hipsim_v2u{d[0], d[1]};
 }
 inline unsigned __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
-    unsigned v = 0;
-    if (static_cast<unsigned long long>(static_cast<unsigned>(voff)) + 4ull <= r.num)
-        __builtin_memcpy(&v, r.base + static_cast<unsigned>(voff) + static_cast<long long>(soff), 4);
-    return v;
+    unsigned d[1];
+    hipsim_buffer_load<1>(r, voff, soff, d);
+    return d[0];
 }
 // correctly rounded single operations (no contraction): plain IEEE arithmetic on the host
 inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }

@@ -80,6 +80,35 @@ def test_bev_warp_is_bitwise_aten_given_the_hosts_transforms(sim, extent, hw):
     assert (dev_theta == theta).float().mean() > 0.7
 
 
+def test_bev_warp_both_grid_product_forms(sim):
+    """MKL multiplies affine_grid's base grid with theta^T fused on Intel hosts and with separate roundings on AMD hosts
+    (measured on the MI355X box's EPYC, tools/probe/aten_warp_probe.py).  flags = 0 must equal grid_sample on a grid whose
+    product was formed with separately rounded torch operations; the fused flag must equal the fma form; and
+    `warp_flags_of_this_host` must pick the one this machine's affine_grid produces."""
+    g = torch.Generator().manual_seed(8)
+    n, C, H, W = 2, 2, 200, 200
+    x = torch.randn(n, C, H, W, generator=g)
+    theta = torch.tensor([[0.99981, -0.01937, 0.01234, 0.01937, 0.99981, -0.05678],
+                          [0.9995, 0.0316, -0.0021, -0.0316, 0.9995, -0.0611]])
+    xs = (torch.linspace(-1, 1, W) * (W - 1) / W).view(1, 1, W)
+    ys = (torch.linspace(-1, 1, H) * (H - 1) / H).view(1, H, 1)
+    t = theta.view(n, 6, 1, 1)
+    first = [xs * t[:, 0], xs * t[:, 3]]
+    plain = torch.stack([(first[0] + ys * t[:, 1]) + t[:, 2], (first[1] + ys * t[:, 4]) + t[:, 5]], dim=-1)
+    fused = torch.stack([(ys.double() * t[:, 1].double() + first[0].double()).float() + t[:, 2],
+                         (ys.double() * t[:, 4].double() + first[1].double()).float() + t[:, 5]], dim=-1)
+    local = F.affine_grid(theta.view(n, 2, 3), (n, C, H, W), align_corners=False)
+    flags = native.warp_flags_of_this_host(H, W)
+    assert torch.equal(local, fused if flags else plain)
+    for grid, fl in ((plain, 0), (fused, native.WARP_FUSED_GRID_PRODUCT)):
+        want = F.grid_sample(x, grid, mode='bilinear', padding_mode='zeros', align_corners=False)
+        out = torch.zeros(n, H, W, 8)
+        sim.bev_warp_nchw_to_nhwc(x, theta, [False, False], out, 8, H * W * 8, flags=fl)
+        assert torch.equal(out[..., :C].permute(0, 3, 1, 2), want)
+        want = F.grid_sample(x, grid, mode='nearest', padding_mode='zeros', align_corners=False)
+        assert torch.equal(sim.bev_warp_nearest(x, theta, flags=fl), want)
+
+
 def test_host_warp_transforms_large_rotations_and_single_frame():
     from fiery_amd.model import host_warp_transforms
     g = torch.Generator().manual_seed(5)

@@ -378,7 +378,8 @@ def _full_size_training_steps_reduce_the_loss():
         loss = sum(((out[k] - t) ** 2).mean() for k, t in targets.items())
         loss.backward()
         mark('backward done')
-        assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+        bad = [n for n, p in model.named_parameters() if p.grad is not None and not torch.isfinite(p.grad).all()]
+        assert not bad, f'non-finite gradients in {len(bad)} tensors, e.g. {bad[:12]}'
         losses.append(loss.item())
         opt.step()
         mark('optimiser step done')
