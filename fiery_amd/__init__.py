@@ -3,6 +3,16 @@
 `Fiery` mirrors `fiery.models.fiery.Fiery` of wayveai/fiery; its BEV path runs on the hand-written HIP
 kernels in `fiery_amd/csrc` (libfiery_hip.so, C ABI in include/fiery_hip.h).
 """
+import os as _os
+
+# MIOpen's assembly implicit-GEMM backward-data kernels for pixel-major tensors (igemm_bwd_gtcx35_nhwc_fp32_*: what
+# PyTorch-ROCm's convolutions of the image trunk get in training on gfx950) read past the end of their operand - measured
+# with GPU guard pages on ROCm 7.0.2 / MIOpen of torch 2.10 (tools/guard_alloc, DESIGN.md section 9c): harmless when the
+# bytes behind the tensor are mapped, "Memory access fault by GPU" when the caching allocator put the tensor at the end of a
+# segment.  The solver is excluded (MIOpen then picks another one) unless the deployment decides otherwise; the library's
+# own kernels never go through MIOpen.  Must be set before MIOpen first evaluates the variable, hence here.
+_os.environ.setdefault('MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_BWD_GTC_XDLOPS_NHWC', '0')
+
 from .config import get_cfg, get_parser, get_preset_cfg, CfgNode   # noqa: F401
 
 

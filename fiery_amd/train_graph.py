@@ -512,7 +512,10 @@ class TrainGraph:
             y = self.bottleneck(y, blk)
         y = F.adaptive_avg_pool2d(y, 1)
         conv = dm.last_conv[1]
-        y = (F.conv2d(y, conv.weight, conv.bias)).view(b, 1, 2 * dm.latent_dim)          # a (B, C) x (C, 2 latent) product
+        # a (B, C) x (C, 2 latent) product.  As a matrix product (rocBLAS), not as the 1x1 convolution it is written as
+        # in the reference: MIOpen serves the backward of a convolution over a 1x1 map with igemm_bwd_gtcx35_nhwc_fp32_*,
+        # which reads past the end of its operand (found with GPU guard pages)
+        y = F.linear(y.flatten(1), conv.weight.flatten(1), conv.bias).view(b, 1, 2 * dm.latent_dim)
         mu, log_sigma = y[:, :, :dm.latent_dim], y[:, :, dm.latent_dim:]
         return mu, torch.clamp(log_sigma, dm.min_log_sigma, dm.max_log_sigma)
 
