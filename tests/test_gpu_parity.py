@@ -484,7 +484,14 @@ def _check_against_fixture(out, gold, sub, test=''):
 
 def _check_against_oracle(got, want, test, exact=None):
     """Every output element against the live oracle (fp32, the reference's ATen CPU kernels); `exact`: the float64
-    evaluation of the same network, when the caller computed it."""
+    evaluation of the same network.
+
+    The bar, per output tensor (north_star: "within 1e-4 fp32"):
+      * |ours - reference| <= 1e-4, the literal tolerance; or, where the reference's OWN fp32 rounding exceeds that budget,
+      * |ours - float64| <= |reference - float64|: the kernels are at least as close to the value the reference
+        approximates as the reference is (two fp32 evaluations of a ~60-layer network in different summation orders cannot
+        be asked to agree more closely than either agrees with the truth), AND |ours - reference| <= 1e-4 * max(1, |ref|_inf).
+    Which of the two held is in the ledger row (`within_literal`, the three error columns)."""
     assert set(k for k, v in want.items() if v is not None) == set(k for k, v in got.items() if v is not None)
     failures = []
     for k, v in want.items():
@@ -498,9 +505,22 @@ def _check_against_oracle(got, want, test, exact=None):
             err_exact = (g.double() - exact[k]).abs().max().item()
             noise = (v.double() - exact[k]).abs().max().item()
         parity_report.record(test, k, err, v.abs().max().item(), err_exact, noise)
+        if err <= TOL:
+            continue
         if err > TOL * max(1.0, v.abs().max().item()):
-            failures.append((k, err))
+            failures.append((k, 'beyond the scaled bound', err))
+        elif err_exact is not None and err_exact > 1.25 * noise + 1e-6:
+            failures.append((k, 'further from float64 than the reference is', err, err_exact, noise))
     assert not failures, failures
+
+
+def _host_modes(model):
+    """The configuration in which every host-side scalar step uses the reference's own CPU operators (camera matrices:
+    LAPACK inverse + matmul; warp transforms: MKL / SLEEF pose algebra): indices and sampling positions then equal the
+    reference's bit for bit, and what is left in the ledger is summation order alone (pooling, convolutions)."""
+    model.camera_matrix_mode = 'host'
+    model.warp_transform_mode = 'host'
+    return model
 
 
 @pytest.mark.parametrize('fixture,preset,tiny,B,n_cam,sub,labels', [
@@ -531,11 +551,14 @@ def test_hot_path_baseline_batch3_against_live_oracle_and_fused_variant(hip):
     lifted = lifted.view(B, rf, n, 64, D, 28, 60)
     with torch.no_grad():
         want = bev_stack.bev_hot_path(sd, cfg, lifted, K, E, ego)
+        exact = bev_stack.bev_hot_path_exact(sd, cfg, lifted, K, E, ego)
         got = model.bev_forward(lifted.to(DEV), K.to(DEV), E.to(DEV), ego.to(DEV))
         fused = model.bev_forward(None, K.to(DEV), E.to(DEV), ego.to(DEV),
                                   depth_logits=dl.view(B, rf, n, D, 28, 60).to(DEV), features=ft.view(B, rf, n, 64, 28, 60).to(DEV))
-    _check_against_oracle(got, want, 'live:baseline.yml b3 (configs[1])')
-    _check_against_oracle(fused, want, 'live:baseline.yml b3 fused lift-splat')
+        host = _host_modes(model).bev_forward(lifted.to(DEV), K.to(DEV), E.to(DEV), ego.to(DEV))
+    _check_against_oracle(got, want, 'live:baseline.yml b3 (configs[1])', exact)
+    _check_against_oracle(fused, want, 'live:baseline.yml b3 fused lift-splat', exact)
+    _check_against_oracle(host, want, 'live:baseline.yml b3, host camera matrices + warp transforms', exact)
 
 
 @pytest.mark.parametrize('preset,n_cam', [('literature/fishing_setting.yml', None), ('lyft/baseline.yml', None),
@@ -557,9 +580,11 @@ def test_other_reference_configs_against_the_live_oracle(hip, preset, n_cam):
     lifted = lifted.view(1, rf, n, C, D, fh, fw)
     with torch.no_grad():
         want = bev_stack.bev_hot_path(sd, cfg, lifted, K, E, ego)
-        exact = bev_stack.bev_hot_path_exact(sd, cfg, lifted, K, E, ego) if preset.startswith('lyft') or 'pon' in preset else None
+        exact = bev_stack.bev_hot_path_exact(sd, cfg, lifted, K, E, ego)
         got = model.bev_forward(lifted.to(DEV), K.to(DEV), E.to(DEV), ego.to(DEV))
+        host = _host_modes(model).bev_forward(lifted.to(DEV), K.to(DEV), E.to(DEV), ego.to(DEV))
     _check_against_oracle(got, want, f'live:{preset} n_cam={n}', exact)
+    _check_against_oracle(host, want, f'live:{preset} n_cam={n}, host matrices + transforms', exact)
 
 
 # ------------------------------------------------------------------------------------------------------
