@@ -13,6 +13,20 @@ __device__ __forceinline__ v2f pk_splat(float v) { return v2f{v, v}; }
 __device__ __forceinline__ float pk_lo(v2f v) { return v.x; }
 __device__ __forceinline__ float pk_hi(v2f v) { return v.y; }
 
+// ---- inter-workgroup hand-off (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility") ----
+// publish: plain stores -> every wave wait_own_stores() -> __syncthreads() -> ONE lane: agent_release() -> relaxed ticket
+// consume: ONE lane after the ticket / flag: agent_acquire() -> __syncthreads() -> plain loads
+// The asm wait restates the post-write-back wait where the compiler cannot drop it (the guide's ROCm 7.2 hazard).
+__device__ __forceinline__ void wait_own_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // every wave, before the barrier
+__device__ __forceinline__ void agent_release() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void agent_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+__device__ __forceinline__ int agent_ticket(int* counter) {
+    return __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // a * b + c, both halves, one rounding each
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
