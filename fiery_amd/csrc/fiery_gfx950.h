@@ -26,6 +26,14 @@ __device__ __forceinline__ void agent_acquire() { __builtin_amdgcn_fence(__ATOMI
 __device__ __forceinline__ int agent_ticket(int* counter) {
     return __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// data that travels by agent-scope atomics needs no fence on either side: the OR is performed at the memory side and the
+// load below bypasses this CU's L1 (the "8-byte agent atomics both sides" form of the guide, 4 bytes here)
+__device__ __forceinline__ void agent_or(unsigned* word, unsigned bits) {
+    (void)__hip_atomic_fetch_or(word, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned agent_load(const unsigned* word) {
+    return __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // a * b + c, both halves, one rounding each
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }

@@ -275,16 +275,20 @@ __global__ void k_rank_columns(const float* __restrict__ geometry, int n_fc, int
 // batches of loads - 23.7 us in front of a 244 us pooling kernel that cannot start without it.  Here a workgroup owns 64
 // adjacent columns of one frame and its wavefront g the rows [g R, (g + 1) R) of all of them (R = ceil(H / 4): one batch
 // of loads per thread, unit-stride across the wavefront, four times the wavefronts); the four partial run lists of a
-// column meet in LDS, wavefront 0 files the column's record.  The workgroup that finishes a frame LAST (a ticket per
-// frame) turns the frame's occupancy bytes into what every pooling workgroup of that frame needs - the 32-voxel bit
-// words, their exclusive popcount prefixes, the number of occupied voxels - so that 64 channel workgroups per frame copy
-// 7.5 KB instead of each re-deriving it from 40 KB of bytes with a serial scan.
-// grid (ceil(n_cam D W / 64), frames), 256 threads; W % 4 == 0; ticket[frames] zero on entry.
+// column meet in LDS, wavefront 0 files the column's record.
+// Occupancy goes straight into the frame's 32-voxel BIT words: marks meet in a bit map in LDS first, the workgroup's
+// non-zero words then reach global memory as agent-scope atomic ORs (no return value, performed at the memory side: no
+// cache write-back needed for another workgroup to see them).  The workgroup that finishes a frame LAST (a ticket per
+// frame) reads the finished words past its caches and leaves their exclusive popcount prefixes and the number of occupied
+// voxels - so the 64 channel workgroups of a frame copy 7.5 KB instead of each re-deriving it from 40 KB of occupancy
+// bytes with a serial scan.  (A first version published plain byte stores with a release fence per workgroup: 2,430
+// L2 write-backs, 125 us.  Fences are per phase, not per workgroup - MI355X_MICROARCH.md.)
+// grid (ceil(n_cam D W / 64), frames), 256 threads, dynamic LDS = 2 n_words words; W % 4 == 0; ticket[frames] and
+// bits_out[frames][2 n_words] zero on entry.
 constexpr int kQuadPrepassMaxRows = 16;     // rows per lane group this kernel takes (H <= 64)
 template <typename prefix_t>
 __global__ __launch_bounds__(256) void k_rank_columns_quad(const float* __restrict__ geometry, int n_cam, int D, int H, int W,
                                                            GridParams p, int* __restrict__ rank, void* __restrict__ records,
-                                                           unsigned char* __restrict__ occ, long long occ_stride,
                                                            unsigned* __restrict__ live, int* __restrict__ ticket,
                                                            unsigned* __restrict__ bits_out, prefix_t* __restrict__ prefix_out,
                                                            int n_words, int* __restrict__ occupied) {
@@ -294,9 +298,12 @@ __global__ __launch_bounds__(256) void k_rank_columns_quad(const float* __restri
         int pos[3], rk[3];                  // the first three of them: row, new rank
     };
     __shared__ Part part[4][64];
-    __shared__ unsigned live_lds[4];        // 64 columns of at least 4 rows of W >= 4: at most 17 slices ... see below
+    __shared__ unsigned live_lds[4];
     __shared__ int col_desc[64][4];         // w16, ra, vb, vc of the workgroup's columns
     __shared__ int is_last;
+    __shared__ int tsum[256];
+    HIP_DYNAMIC_SHARED(unsigned, occ_bits)  // [2 n_words]: this workgroup's marks
+    const int n_w32 = 2 * n_words;
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int f = blockIdx.y;
     const int cols_per_frame = n_cam * D * W;
@@ -304,10 +311,13 @@ __global__ __launch_bounds__(256) void k_rank_columns_quad(const float* __restri
     const int R = (H + 3) >> 2;
     const int h_lo = g * R, h_hi = min(H, h_lo + R);
     const bool active = col < cols_per_frame && h_lo < h_hi;
-    const int fd_local = active || col < cols_per_frame ? col / W : 0;
+    const int fd_local = col < cols_per_frame ? col / W : 0;
     const int w = col - fd_local * W;
     const long long fd = static_cast<long long>(f) * n_cam * D + fd_local;
-    unsigned char* occ_f = occ + static_cast<long long>(f) * occ_stride;
+    for (int i = threadIdx.x; i < n_w32; i += 256) occ_bits[i] = 0u;
+    if (threadIdx.x < 4) live_lds[threadIdx.x] = 0u;
+    __syncthreads();
+    auto mark = [&](int r) { atomicOr(&occ_bits[r >> 5], 1u << (r & 31)); };
     bool inside = false;
     Part mine;
     mine.first = mine.last = -1;
@@ -335,14 +345,13 @@ __global__ __launch_bounds__(256) void k_rank_columns_quad(const float* __restri
             rank[base + static_cast<long long>(h) * W] = r;
             if (j == 0) {
                 mine.first = r;
-                if (r >= 0) occ_f[r] = 1;                   // (a group start that continues a run marks its voxel again)
             } else if (r != prev) {
                 if (mine.n_inner < 3) {
                     mine.pos[mine.n_inner] = h;
                     mine.rk[mine.n_inner] = r;
                 }
                 ++mine.n_inner;
-                if (r >= 0) occ_f[r] = 1;
+                if (r >= 0) mark(r);                        // a run that starts inside the group
             }
             prev = r;
             inside = inside || r >= 0;
@@ -350,8 +359,6 @@ __global__ __launch_bounds__(256) void k_rank_columns_quad(const float* __restri
         mine.last = prev;
     }
     part[g][lane] = mine;
-    if (threadIdx.x < 4) live_lds[threadIdx.x] = 0u;
-    __syncthreads();
     // slices (camera, depth) of the workgroup's columns: 64 columns span at most 64 / W + 2 of them; the live bits of a
     // slice meet in LDS, then one global atomic per slice and workgroup.  (W >= 32 keeps that within four words;
     // narrower maps take the global atomic directly.)
@@ -361,6 +368,7 @@ __global__ __launch_bounds__(256) void k_rank_columns_quad(const float* __restri
         if (rel < 4) atomicOr(&live_lds[rel], 1u << (w >> 2));
         else atomicOr(&live[fd], 1u << (w >> 2));
     }
+    __syncthreads();
     if (g == 0 && col < cols_per_frame) {
         // the column's runs from its (up to four) groups' pieces, in row order
         int ra = -1, rb = -1, rc = -1, s1 = H, s2 = H, runs = 0, prev = 0;
@@ -373,7 +381,10 @@ __global__ __launch_bounds__(256) void k_rank_columns_quad(const float* __restri
         for (int gg = 0; gg < 4; ++gg) {
             if (gg * R >= H) break;
             const Part& pt = part[gg][lane];
-            if (gg == 0 || pt.first != prev) new_run(gg * R, pt.first);
+            if (gg == 0 || pt.first != prev) {              // a run that starts with the group
+                new_run(gg * R, pt.first);
+                if (pt.first >= 0) mark(pt.first);
+            }
             for (int i = 0; i < pt.n_inner && i < 3; ++i) new_run(pt.pos[i], pt.rk[i]);
             if (pt.n_inner > 3) runs += 4;                  // more changes than were kept: the column is "general" anyway
             prev = pt.last;
@@ -426,35 +437,26 @@ __global__ __launch_bounds__(256) void k_rank_columns_quad(const float* __restri
     }
     if (threadIdx.x < 4 && live_lds[threadIdx.x] != 0u && fd_first + threadIdx.x < n_cam * D)
         atomicOr(&live[static_cast<long long>(f) * n_cam * D + fd_first + threadIdx.x], live_lds[threadIdx.x]);
-    // ---- the frame's last workgroup derives the occupancy words -------------------------------------------------------
-    // release: every store of this workgroup (occupancy bytes among them) is made visible at agent scope before the
-    // ticket is drawn; acquire: the last arriver drops its L1 before it reads the other workgroups' bytes
-    // (MI355X_MICROARCH.md, inter-workgroup visibility; the explicit vmcnt waits are the guide's recipe).
+    // this workgroup's marks -> the frame's bit words (the __syncthreads above ordered the LDS ORs before these reads)
+    unsigned* bits_f = bits_out + static_cast<long long>(f) * n_w32;
+    for (int i = threadIdx.x; i < n_w32; i += 256) {
+        const unsigned b = occ_bits[i];
+        if (b) agent_or(&bits_f[i], b);
+    }
+    // ---- the frame's last workgroup derives the prefixes ------------------------------------------------------------
+    // every wave waits for its own atomics to be performed, the barrier collects the waves, one lane draws the ticket;
+    // whoever draws the last ticket of the frame reads the words past its caches (agent-scope loads)
     wait_own_stores();
     __syncthreads();
-    if (threadIdx.x == 0) {
-        agent_release();
-        is_last = agent_ticket(&ticket[f]) == static_cast<int>(gridDim.x) - 1;
-        if (is_last) agent_acquire();
-    }
+    if (threadIdx.x == 0) is_last = agent_ticket(&ticket[f]) == static_cast<int>(gridDim.x) - 1;
     __syncthreads();
     if (!is_last) return;
-    const int n_w32 = 2 * n_words;
     const int wpt = (n_w32 + 255) / 256;                     // consecutive 32-voxel words per thread
-    __shared__ int tsum[256];
     unsigned my_bits[16];                                     // wpt <= 16 (grids up to 131,072 voxels): checked on the host
     int local = 0;
     for (int k = 0; k < wpt && k < 16; ++k) {
         const int wd = threadIdx.x * wpt + k;
-        unsigned b = 0;
-        if (wd < n_w32) {
-            const uint4* src = reinterpret_cast<const uint4*>(occ_f + static_cast<long long>(wd) * 32);
-            const uint4 lo4 = src[0], hi4 = src[1];
-            // four bytes (0 or 1) -> four bits: the products' partial terms fall on distinct bits, so nothing carries
-            auto nib = [](unsigned m) { return ((m & 0x01010101u) * 0x10204080u) >> 28; };
-            b = nib(lo4.x) | nib(lo4.y) << 4 | nib(lo4.z) << 8 | nib(lo4.w) << 12 | nib(hi4.x) << 16 | nib(hi4.y) << 20 |
-                nib(hi4.z) << 24 | nib(hi4.w) << 28;
-        }
+        const unsigned b = wd < n_w32 ? agent_load(&bits_f[wd]) : 0u;
         my_bits[k] = b;
         local += __popc(b);
     }
@@ -471,7 +473,6 @@ __global__ __launch_bounds__(256) void k_rank_columns_quad(const float* __restri
     for (int k = 0; k < wpt && k < 16; ++k) {
         const int wd = threadIdx.x * wpt + k;
         if (wd >= n_w32) break;
-        bits_out[static_cast<long long>(f) * n_w32 + wd] = my_bits[k];
         prefix_out[static_cast<long long>(f) * n_w32 + wd] = static_cast<prefix_t>(before);
         before += __popc(my_bits[k]);
     }
@@ -1674,12 +1675,13 @@ int plan_pool(int frames, int n_cam, int D, int H, int W, long long n_vox_ll, in
     pl->n_words = ceil_div(pl->n_vox, 64);
     pl->off_occ = align(pl->off_lists + cols * pl->n_tiles * sizeof(int));
     pl->off_live = align(pl->off_occ + static_cast<size_t>(frames) * pl->n_words * 64);     // (cleared together with the bytes)
-    // (cleared per call: occupancy bytes, live masks, the prepass's per-frame tickets - one memset up to off_occupied)
+    // (cleared per call: occupancy bytes, live masks, the prepass's per-frame tickets and bit words - one memset up to off_occupied)
+    // the frames' occupancy words as the four-lane prepass leaves them for the pooling workgroups: 32-voxel bit words
+    // (OR-ed together by the prepass's workgroups: cleared per call too) and their popcount prefixes
     pl->off_ticket = align(pl->off_live + static_cast<size_t>(frames) * n_cam * D * 4);
-    pl->off_occupied = align(pl->off_ticket + static_cast<size_t>(frames) * 4);
-    // the frames' occupancy words as the prepass leaves them for the pooling workgroups: 32-voxel bit words + prefixes
-    pl->off_bits = align(pl->off_occupied + static_cast<size_t>(frames) * 4);
-    pl->off_prefix = align(pl->off_bits + static_cast<size_t>(frames) * pl->n_words * 2 * 4);
+    pl->off_bits = align(pl->off_ticket + static_cast<size_t>(frames) * 4);
+    pl->off_occupied = align(pl->off_bits + static_cast<size_t>(frames) * pl->n_words * 2 * 4);
+    pl->off_prefix = align(pl->off_occupied + static_cast<size_t>(frames) * 4);
     pl->total = align(pl->off_prefix + static_cast<size_t>(frames) * pl->n_words * 2 * 4);
     return FIERY_OK;
 }
@@ -1803,20 +1805,18 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
     if (const char* forced = getenv("FIERY_POOL_QUAD_PREPASS")) quad_prepass = quad_prepass && atoi(forced) != 0;
     unsigned* bits_g = reinterpret_cast<unsigned*>(ws + pl.off_bits);
     void* prefix_g = ws + pl.off_prefix;
-    bool prepass_words = true;                                           // pooling workgroups copy the prepass's occupancy words
-    if (const char* forced = getenv("FIERY_POOL_PREPASS_WORDS")) prepass_words = atoi(forced) != 0;       // tuning / A-B runs
     if (quad_prepass) {
-        const long long occ_stride = static_cast<long long>(pl.n_words) * 64;
+        const size_t qlds = static_cast<size_t>(pl.n_words) * 2 * 4;     // the workgroup's own bit map
         const dim3 pgrid(static_cast<unsigned>(ceil_div(static_cast<long long>(n_cam) * D * W, 64)), static_cast<unsigned>(frames));
         int* ticket = reinterpret_cast<int*>(ws + pl.off_ticket);
         if (wide_records)
-            hipLaunchKernelGGL((k_rank_columns_quad<unsigned>), pgrid, dim3(256), 0, s, geometry, n_cam, D, H, W, to_params(*grid), rank,
-                               static_cast<void*>(coldesc), occ, occ_stride, live, ticket, bits_g, static_cast<unsigned*>(prefix_g),
-                               pl.n_words, occupied);
+            hipLaunchKernelGGL((k_rank_columns_quad<unsigned>), pgrid, dim3(256), qlds, s, geometry, n_cam, D, H, W, to_params(*grid), rank,
+                               static_cast<void*>(coldesc), live, ticket, bits_g, static_cast<unsigned*>(prefix_g), pl.n_words,
+                               occupied);
         else
-            hipLaunchKernelGGL((k_rank_columns_quad<unsigned short>), pgrid, dim3(256), 0, s, geometry, n_cam, D, H, W, to_params(*grid),
-                               rank, static_cast<void*>(coldesc), occ, occ_stride, live, ticket, bits_g,
-                               static_cast<unsigned short*>(prefix_g), pl.n_words, occupied);
+            hipLaunchKernelGGL((k_rank_columns_quad<unsigned short>), pgrid, dim3(256), qlds, s, geometry, n_cam, D, H, W, to_params(*grid),
+                               rank, static_cast<void*>(coldesc), live, ticket, bits_g, static_cast<unsigned short*>(prefix_g),
+                               pl.n_words, occupied);
     } else {
         int rows = 8;                                                    // rows of a column in flight in the prepass
         if (const char* forced = getenv("FIERY_POOL_PREPASS_ROWS")) rows = atoi(forced);         // tuning
@@ -1876,7 +1876,7 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
             return fail(FIERY_ELAUNCH, "voxel_pool: cannot reserve %zu B of LDS", cp_lds);                              \
         hipLaunchKernelGGL((k_voxel_pool_compact<THREADS, WIDE, EXACT, NT>), units, dim3(THREADS), cp_lds, s, x, st, rank, \
                            static_cast<const void*>(coldesc), occ, live, out, occupied, n_cam, D, H, W, C, pl.n_vox, pl.n_words, \
-                           cp_cells, tail_first, parts, (quad_prepass && prepass_words) ? bits_g : nullptr, prefix_g);      \
+                           cp_cells, tail_first, parts, quad_prepass ? bits_g : nullptr, prefix_g);                           \
     } while (0)
 #define FIERY_POOL_COMPACT_ROWS(THREADS, WIDE)                            \
     do {                                                                 \

@@ -26,6 +26,8 @@ inline void wait_own_stores() {}
 inline void agent_release() {}
 inline void agent_acquire() {}
 inline int agent_ticket(int* counter) { return (*counter)++; }
+inline void agent_or(unsigned* word, unsigned bits) { *word |= bits; }
+inline unsigned agent_load(const unsigned* word) { return *word; }
 
 // ---- bf16 matrix-core operands: eight bf16 values as their bit patterns ---------------------------------------------
 struct bf16x8 {

@@ -8,7 +8,7 @@ O=$R/gpurun_out/r3_pool
 mkdir -p $O
 timeout 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "voxel_pool or pooling or indices" 2>&1 | tail -3
 for rep in 1 2; do
-  for cfg in "1 1" "0 1" "1 0"; do
+  for cfg in "1 1" "0 1"; do
     set -- $cfg
     echo "== quad prepass=$1 prepass words=$2 (rep $rep)"
     FIERY_POOL_QUAD_PREPASS=$1 FIERY_POOL_PREPASS_WORDS=$2 timeout 300 python tools/microbench.py pool --reps 30 2>&1 | grep -E "^pool frames=9 (tile|cold)" 
