@@ -13,28 +13,6 @@ __device__ __forceinline__ v2f pk_splat(float v) { return v2f{v, v}; }
 __device__ __forceinline__ float pk_lo(v2f v) { return v.x; }
 __device__ __forceinline__ float pk_hi(v2f v) { return v.y; }
 
-// ---- inter-workgroup hand-off (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility") ----
-// publish: plain stores -> every wave wait_own_stores() -> __syncthreads() -> ONE lane: agent_release() -> relaxed ticket
-// consume: ONE lane after the ticket / flag: agent_acquire() -> __syncthreads() -> plain loads
-// The asm wait restates the post-write-back wait where the compiler cannot drop it (the guide's ROCm 7.2 hazard).
-__device__ __forceinline__ void wait_own_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // every wave, before the barrier
-__device__ __forceinline__ void agent_release() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-__device__ __forceinline__ void agent_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
-__device__ __forceinline__ int agent_ticket(int* counter) {
-    return __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// data that travels by agent-scope atomics needs no fence on either side: the OR is performed at the memory side and the
-// load below bypasses this CU's L1 (the "8-byte agent atomics both sides" form of the guide, 4 bytes here)
-__device__ __forceinline__ void agent_or(unsigned* word, unsigned bits) {
-    (void)__hip_atomic_fetch_or(word, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned agent_load(const unsigned* word) {
-    return __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // a * b + c, both halves, one rounding each
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 

@@ -270,215 +270,6 @@ __global__ void k_rank_columns(const float* __restrict__ geometry, int n_fc, int
     }
 }
 
-// The prepass of the compact-plane kernel, four lanes to a column (round 3).  `k_rank_columns` gives a column's H rows to
-// ONE thread: 155,520 threads for baseline.yml's nine frames, 2.4 wavefronts per SIMD, each walking four dependent
-// batches of loads - 23.7 us in front of a 244 us pooling kernel that cannot start without it.  Here a workgroup owns 64
-// adjacent columns of one frame and its wavefront g the rows [g R, (g + 1) R) of all of them (R = ceil(H / 4): one batch
-// of loads per thread, unit-stride across the wavefront, four times the wavefronts); the four partial run lists of a
-// column meet in LDS, wavefront 0 files the column's record.
-// Occupancy goes straight into the frame's 32-voxel BIT words: marks meet in a bit map in LDS first, the workgroup's
-// non-zero words then reach global memory as agent-scope atomic ORs (no return value, performed at the memory side: no
-// cache write-back needed for another workgroup to see them).  The workgroup that finishes a frame LAST (a ticket per
-// frame) reads the finished words past its caches and leaves their exclusive popcount prefixes and the number of occupied
-// voxels - so the 64 channel workgroups of a frame copy 7.5 KB instead of each re-deriving it from 40 KB of occupancy
-// bytes with a serial scan.  (A first version published plain byte stores with a release fence per workgroup: 2,430
-// L2 write-backs, 125 us.  Fences are per phase, not per workgroup - MI355X_MICROARCH.md.)
-// grid (ceil(n_cam D W / 64), frames), 256 threads, dynamic LDS = 2 n_words words; W % 4 == 0; ticket[frames] and
-// bits_out[frames][2 n_words] zero on entry.
-constexpr int kQuadPrepassMaxRows = 16;     // rows per lane group this kernel takes (H <= 64)
-template <typename prefix_t>
-__global__ __launch_bounds__(256) void k_rank_columns_quad(const float* __restrict__ geometry, int n_cam, int D, int H, int W,
-                                                           GridParams p, int* __restrict__ rank, void* __restrict__ records,
-                                                           unsigned* __restrict__ live, int* __restrict__ ticket,
-                                                           unsigned* __restrict__ bits_out, prefix_t* __restrict__ prefix_out,
-                                                           int n_words, int* __restrict__ occupied) {
-    constexpr bool kWide = sizeof(prefix_t) == 4;
-    struct Part {                           // what row group g knows about its rows of one column
-        int first, last, n_inner;           // ranks of its first / last row, number of rank changes inside the group
-        int pos[3], rk[3];                  // the first three of them: row, new rank
-    };
-    __shared__ Part part[4][64];
-    __shared__ unsigned live_lds[4];
-    __shared__ int col_desc[64][4];         // w16, ra, vb, vc of the workgroup's columns
-    __shared__ int is_last;
-    __shared__ int tsum[256];
-    HIP_DYNAMIC_SHARED(unsigned, occ_bits)  // [2 n_words]: this workgroup's marks
-    const int n_w32 = 2 * n_words;
-    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int f = blockIdx.y;
-    const int cols_per_frame = n_cam * D * W;
-    const int col = blockIdx.x * 64 + lane;                 // column within the frame = (camera * D + d) * W + w
-    const int R = (H + 3) >> 2;
-    const int h_lo = g * R, h_hi = min(H, h_lo + R);
-    const bool active = col < cols_per_frame && h_lo < h_hi;
-    const int fd_local = col < cols_per_frame ? col / W : 0;
-    const int w = col - fd_local * W;
-    const long long fd = static_cast<long long>(f) * n_cam * D + fd_local;
-    for (int i = threadIdx.x; i < n_w32; i += 256) occ_bits[i] = 0u;
-    if (threadIdx.x < 4) live_lds[threadIdx.x] = 0u;
-    __syncthreads();
-    auto mark = [&](int r) { atomicOr(&occ_bits[r >> 5], 1u << (r & 31)); };
-    bool inside = false;
-    Part mine;
-    mine.first = mine.last = -1;
-    mine.n_inner = 0;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) mine.pos[i] = mine.rk[i] = 0;
-    if (active) {
-        const long long base = fd * H * W + w;              // point index of (.., h = 0, w)
-        float gx[kQuadPrepassMaxRows], gy[kQuadPrepassMaxRows], gz[kQuadPrepassMaxRows];
-#pragma unroll
-        for (int j = 0; j < kQuadPrepassMaxRows; ++j) {     // every load of the thread in flight before any use
-            const int h = min(h_lo + j, h_hi - 1);
-            const float* gp = geometry + 3 * (base + static_cast<long long>(h) * W);
-            gx[j] = gp[0];
-            gy[j] = gp[1];
-            gz[j] = gp[2];
-            if (j + 1 >= R) break;
-        }
-        int prev = 0;
-#pragma unroll
-        for (int j = 0; j < kQuadPrepassMaxRows; ++j) {
-            const int h = h_lo + j;
-            if (h >= h_hi) break;
-            const int r = voxel_rank(gx[j], gy[j], gz[j], p, nullptr);
-            rank[base + static_cast<long long>(h) * W] = r;
-            if (j == 0) {
-                mine.first = r;
-            } else if (r != prev) {
-                if (mine.n_inner < 3) {
-                    mine.pos[mine.n_inner] = h;
-                    mine.rk[mine.n_inner] = r;
-                }
-                ++mine.n_inner;
-                if (r >= 0) mark(r);                        // a run that starts inside the group
-            }
-            prev = r;
-            inside = inside || r >= 0;
-        }
-        mine.last = prev;
-    }
-    part[g][lane] = mine;
-    // slices (camera, depth) of the workgroup's columns: 64 columns span at most 64 / W + 2 of them; the live bits of a
-    // slice meet in LDS, then one global atomic per slice and workgroup.  (W >= 32 keeps that within four words;
-    // narrower maps take the global atomic directly.)
-    const int fd_first = (blockIdx.x * 64) / W;
-    if (inside) {
-        const int rel = fd_local - fd_first;
-        if (rel < 4) atomicOr(&live_lds[rel], 1u << (w >> 2));
-        else atomicOr(&live[fd], 1u << (w >> 2));
-    }
-    __syncthreads();
-    if (g == 0 && col < cols_per_frame) {
-        // the column's runs from its (up to four) groups' pieces, in row order
-        int ra = -1, rb = -1, rc = -1, s1 = H, s2 = H, runs = 0, prev = 0;
-        auto new_run = [&](int h, int r) {
-            if (runs == 0) ra = r;
-            else if (runs == 1) { rb = r; s1 = h; }
-            else if (runs == 2) { rc = r; s2 = h; }
-            ++runs;
-        };
-        for (int gg = 0; gg < 4; ++gg) {
-            if (gg * R >= H) break;
-            const Part& pt = part[gg][lane];
-            if (gg == 0 || pt.first != prev) {              // a run that starts with the group
-                new_run(gg * R, pt.first);
-                if (pt.first >= 0) mark(pt.first);
-            }
-            for (int i = 0; i < pt.n_inner && i < 3; ++i) new_run(pt.pos[i], pt.rk[i]);
-            if (pt.n_inner > 3) runs += 4;                  // more changes than were kept: the column is "general" anyway
-            prev = pt.last;
-        }
-        const int general = (runs > 3 || H >= (1 << kSplitBits)) ? 1 : 0;
-        col_desc[lane][0] = static_cast<int>(static_cast<unsigned>(s1) | (static_cast<unsigned>(s2) << 6) | (static_cast<unsigned>(general) << 12));
-        col_desc[lane][1] = ra;
-        col_desc[lane][2] = s1 < H ? rb : -1;
-        col_desc[lane][3] = s2 < H ? rc : -1;
-    }
-    __syncthreads();
-    if (g == 0 && (lane & 3) == 0 && col < cols_per_frame) {
-        // one lane files the quad's record (layout: see k_voxel_pool_compact) with 16-byte stores
-        const long long quad = (static_cast<long long>(f) * cols_per_frame + col) >> 2;
-        int v[4][4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[k][e] = col_desc[lane + k][e];
-        if constexpr (!kWide) {
-            auto r16 = [](int r) { return r < 0 ? kNoRank16 : static_cast<unsigned>(r); };
-            auto pair = [](unsigned lo, unsigned hi) { return lo | (hi << 16); };
-            uint4 a, b;
-            a.x = pair(static_cast<unsigned>(v[0][0]), static_cast<unsigned>(v[1][0]));
-            a.y = pair(static_cast<unsigned>(v[2][0]), static_cast<unsigned>(v[3][0]));
-            a.z = pair(r16(v[0][1]), r16(v[1][1]));
-            a.w = pair(r16(v[2][1]), r16(v[3][1]));
-            b.x = pair(r16(v[0][2]), r16(v[1][2]));
-            b.y = pair(r16(v[2][2]), r16(v[3][2]));
-            b.z = pair(r16(v[0][3]), r16(v[1][3]));
-            b.w = pair(r16(v[2][3]), r16(v[3][3]));
-            uint4* rec = reinterpret_cast<uint4*>(static_cast<char*>(records) + quad * 32);
-            rec[0] = a;
-            rec[1] = b;
-        } else {
-            uint4* rec = reinterpret_cast<uint4*>(static_cast<char*>(records) + quad * 64);
-            uint4 a;
-            a.x = static_cast<unsigned>(v[0][0]) | (static_cast<unsigned>(v[1][0]) << 16);
-            a.y = static_cast<unsigned>(v[2][0]) | (static_cast<unsigned>(v[3][0]) << 16);
-            a.z = a.w = 0u;
-            rec[0] = a;
-#pragma unroll
-            for (int e = 1; e < 4; ++e) {
-                uint4 t;
-                t.x = static_cast<unsigned>(v[0][e]);  t.y = static_cast<unsigned>(v[1][e]);
-                t.z = static_cast<unsigned>(v[2][e]);  t.w = static_cast<unsigned>(v[3][e]);
-                rec[e] = t;
-            }
-        }
-    }
-    if (threadIdx.x < 4 && live_lds[threadIdx.x] != 0u && fd_first + threadIdx.x < n_cam * D)
-        atomicOr(&live[static_cast<long long>(f) * n_cam * D + fd_first + threadIdx.x], live_lds[threadIdx.x]);
-    // this workgroup's marks -> the frame's bit words (the __syncthreads above ordered the LDS ORs before these reads)
-    unsigned* bits_f = bits_out + static_cast<long long>(f) * n_w32;
-    for (int i = threadIdx.x; i < n_w32; i += 256) {
-        const unsigned b = occ_bits[i];
-        if (b) agent_or(&bits_f[i], b);
-    }
-    // ---- the frame's last workgroup derives the prefixes ------------------------------------------------------------
-    // every wave waits for its own atomics to be performed, the barrier collects the waves, one lane draws the ticket;
-    // whoever draws the last ticket of the frame reads the words past its caches (agent-scope loads)
-    wait_own_stores();
-    __syncthreads();
-    if (threadIdx.x == 0) is_last = agent_ticket(&ticket[f]) == static_cast<int>(gridDim.x) - 1;
-    __syncthreads();
-    if (!is_last) return;
-    const int wpt = (n_w32 + 255) / 256;                     // consecutive 32-voxel words per thread
-    unsigned my_bits[16];                                     // wpt <= 16 (grids up to 131,072 voxels): checked on the host
-    int local = 0;
-    for (int k = 0; k < wpt && k < 16; ++k) {
-        const int wd = threadIdx.x * wpt + k;
-        const unsigned b = wd < n_w32 ? agent_load(&bits_f[wd]) : 0u;
-        my_bits[k] = b;
-        local += __popc(b);
-    }
-    tsum[threadIdx.x] = local;
-    __syncthreads();
-    // exclusive prefix over 256 thread totals: log-step scan in LDS
-    for (int step = 1; step < 256; step <<= 1) {
-        const int add = threadIdx.x >= step ? tsum[threadIdx.x - step] : 0;
-        __syncthreads();
-        tsum[threadIdx.x] += add;
-        __syncthreads();
-    }
-    int before = tsum[threadIdx.x] - local;
-    for (int k = 0; k < wpt && k < 16; ++k) {
-        const int wd = threadIdx.x * wpt + k;
-        if (wd >= n_w32) break;
-        prefix_out[static_cast<long long>(f) * n_w32 + wd] = static_cast<prefix_t>(before);
-        before += __popc(my_bits[k]);
-    }
-    if (threadIdx.x == 255) occupied[f] = tsum[255];
-}
-
 // Ordered (ascending id) list of the work-items that touch one tile of one frame; adjacent entries are adjacent
 // in memory, so the pooling kernel's wavefront loads stay unit-stride.  Items with a "general" column (more than
 // three runs) go to a second list that grows down from the end of the same array; counts = {front, back}.  A work-item is a column (group = 1) or
@@ -1267,7 +1058,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
     const float* __restrict__ x, PoolStrides xs, const int* __restrict__ rank, const void* __restrict__ quads,
     const unsigned char* __restrict__ occ, const unsigned* __restrict__ live, float* __restrict__ out,
     int* __restrict__ occupied, int n_cam, int D, int H, int W, int C, int n_vox, int n_words, int capacity, int tail_first,
-    int tail_parts, const unsigned* __restrict__ bits_g, const void* __restrict__ prefix_g) {
+    int tail_parts) {
     using prefix_t = std::conditional_t<kWide, unsigned, unsigned short>;
     HIP_DYNAMIC_SHARED(unsigned char, cp_lds)
     const int n_w32 = 2 * n_words;
@@ -1291,20 +1082,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
     const int c = unit % C;
     const int f = unit / C;
 
-    // ---- the frame's occupancy words: bit map + exclusive prefix of the words' popcounts ------------------------
-    // `bits_g` != null: the prepass (k_rank_columns_quad) derived them once per frame; copy them in.  Otherwise they are
-    // derived here from the occupancy bytes, by every workgroup for itself (the round-2 form, kept for the A/B run).
+    // ---- occupancy bytes -> bit map + exclusive prefix of the words' popcounts --------------------------------
     int total;
-    if (bits_g) {
-        const unsigned* bsrc = bits_g + static_cast<long long>(f) * n_w32;
-        const prefix_t* psrc = static_cast<const prefix_t*>(prefix_g) + static_cast<long long>(f) * n_w32;
-        for (int w = tid; w < n_w32; w += kThreads) {
-            bits[w] = bsrc[w];
-            prefix[w] = psrc[w];
-        }
-        total = occupied[f];
-        __syncthreads();
-    } else {
+    {
         const unsigned char* occ_f = occ + static_cast<long long>(f) * n_words * 64;
         const int wpt = (n_w32 + kThreads - 1) / kThreads;               // consecutive 32-voxel words per thread
         int local = 0;
@@ -1639,7 +1419,7 @@ namespace {
 
 struct PoolPlan {
     int n_vox, tile, n_tiles, n_words;
-    size_t lds, off_coldesc, off_colmask, off_counts, off_lists, off_occ, off_live, off_ticket, off_occupied, off_bits, off_prefix, total;
+    size_t lds, off_coldesc, off_colmask, off_counts, off_lists, off_occ, off_live, off_occupied, total;
 };
 
 // LDS tile of the output plane (see the default below); the tile grows when the grid would otherwise need more
@@ -1675,14 +1455,8 @@ int plan_pool(int frames, int n_cam, int D, int H, int W, long long n_vox_ll, in
     pl->n_words = ceil_div(pl->n_vox, 64);
     pl->off_occ = align(pl->off_lists + cols * pl->n_tiles * sizeof(int));
     pl->off_live = align(pl->off_occ + static_cast<size_t>(frames) * pl->n_words * 64);     // (cleared together with the bytes)
-    // (cleared per call: occupancy bytes, live masks, the prepass's per-frame tickets and bit words - one memset up to off_occupied)
-    // the frames' occupancy words as the four-lane prepass leaves them for the pooling workgroups: 32-voxel bit words
-    // (OR-ed together by the prepass's workgroups: cleared per call too) and their popcount prefixes
-    pl->off_ticket = align(pl->off_live + static_cast<size_t>(frames) * n_cam * D * 4);
-    pl->off_bits = align(pl->off_ticket + static_cast<size_t>(frames) * 4);
-    pl->off_occupied = align(pl->off_bits + static_cast<size_t>(frames) * pl->n_words * 2 * 4);
-    pl->off_prefix = align(pl->off_occupied + static_cast<size_t>(frames) * 4);
-    pl->total = align(pl->off_prefix + static_cast<size_t>(frames) * pl->n_words * 2 * 4);
+    pl->off_occupied = align(pl->off_live + static_cast<size_t>(frames) * n_cam * D * 4);
+    pl->total = align(pl->off_occupied + static_cast<size_t>(frames) * 4);
     return FIERY_OK;
 }
 
@@ -1798,26 +1572,7 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
     unsigned* live = reinterpret_cast<unsigned*>(ws + pl.off_live);
     if (compact_form && hipMemsetAsync(occ, 0, pl.off_occupied - pl.off_occ, s) != hipSuccess)     // occupancy bytes + live masks
         return fail(FIERY_ELAUNCH, "voxel_pool: cannot clear the occupancy map");
-    // the compact form's own prepass: four lanes to a column, occupancy words derived once per frame by the frame's last
-    // workgroup (k_rank_columns_quad); FIERY_POOL_QUAD_PREPASS=0 keeps the one-thread-per-column prepass (A/B runs)
-    bool quad_prepass = compact_form && H <= 4 * kQuadPrepassMaxRows && W % 4 == 0 && 2 * pl.n_words <= 16 * 256 &&
-                        static_cast<long long>(n_cam) * D * W < (1ll << 30);
-    if (const char* forced = getenv("FIERY_POOL_QUAD_PREPASS")) quad_prepass = quad_prepass && atoi(forced) != 0;
-    unsigned* bits_g = reinterpret_cast<unsigned*>(ws + pl.off_bits);
-    void* prefix_g = ws + pl.off_prefix;
-    if (quad_prepass) {
-        const size_t qlds = static_cast<size_t>(pl.n_words) * 2 * 4;     // the workgroup's own bit map
-        const dim3 pgrid(static_cast<unsigned>(ceil_div(static_cast<long long>(n_cam) * D * W, 64)), static_cast<unsigned>(frames));
-        int* ticket = reinterpret_cast<int*>(ws + pl.off_ticket);
-        if (wide_records)
-            hipLaunchKernelGGL((k_rank_columns_quad<unsigned>), pgrid, dim3(256), qlds, s, geometry, n_cam, D, H, W, to_params(*grid), rank,
-                               static_cast<void*>(coldesc), live, ticket, bits_g, static_cast<unsigned*>(prefix_g), pl.n_words,
-                               occupied);
-        else
-            hipLaunchKernelGGL((k_rank_columns_quad<unsigned short>), pgrid, dim3(256), qlds, s, geometry, n_cam, D, H, W, to_params(*grid),
-                               rank, static_cast<void*>(coldesc), live, ticket, bits_g, static_cast<unsigned short*>(prefix_g),
-                               pl.n_words, occupied);
-    } else {
+    {
         int rows = 8;                                                    // rows of a column in flight in the prepass
         if (const char* forced = getenv("FIERY_POOL_PREPASS_ROWS")) rows = atoi(forced);         // tuning
         unsigned char* occ_arg = compact_form ? occ : nullptr;
@@ -1876,7 +1631,7 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
             return fail(FIERY_ELAUNCH, "voxel_pool: cannot reserve %zu B of LDS", cp_lds);                              \
         hipLaunchKernelGGL((k_voxel_pool_compact<THREADS, WIDE, EXACT, NT>), units, dim3(THREADS), cp_lds, s, x, st, rank, \
                            static_cast<const void*>(coldesc), occ, live, out, occupied, n_cam, D, H, W, C, pl.n_vox, pl.n_words, \
-                           cp_cells, tail_first, parts, quad_prepass ? bits_g : nullptr, prefix_g);                           \
+                           cp_cells, tail_first, parts);                                                                 \
     } while (0)
 #define FIERY_POOL_COMPACT_ROWS(THREADS, WIDE)                            \
     do {                                                                 \

@@ -21,13 +21,6 @@ inline float hipsim_sat(float v) { return v != v ? 0.f : (v < 0.f ? 0.f : (v > 1
 inline v2f pk_add_sat_uniform(v2f a, v2f b) { return {hipsim_sat(a.x + b.x), hipsim_sat(a.y + b.y)}; }
 
 inline void pk_pin(v2f&, v2f&, v2f&) {}
-// inter-workgroup hand-off: the simulator runs workgroups one after the other on one host thread
-inline void wait_own_stores() {}
-inline void agent_release() {}
-inline void agent_acquire() {}
-inline int agent_ticket(int* counter) { return (*counter)++; }
-inline void agent_or(unsigned* word, unsigned bits) { *word |= bits; }
-inline unsigned agent_load(const unsigned* word) { return *word; }
 
 // ---- bf16 matrix-core operands: eight bf16 values as their bit patterns ---------------------------------------------
 struct bf16x8 {

@@ -467,27 +467,6 @@ def test_compact_plane_form(sim, monkeypatch, H, cells, tail_parts, big_grid):
     out = sim.voxel_pool(lifted, strides, torch.from_numpy(geo), frames, n_cam, D, H, W, C, grid, out=garbage, workspace=ws)
     occupied = sim.pool_occupied(ws, frames, n_cam, D, H, W, grid).clone()
     rank_left = ws[:frames * n_cam * D * H * W].clone()
-    # the four-lanes-per-column prepass (default; occupancy words derived once per frame) against the one-thread-per-column
-    # prepass of round 2 (every pooling workgroup derives them): same ranks, same quad records, same result bits
-    monkeypatch.setenv('FIERY_POOL_QUAD_PREPASS', '0')
-    ws2 = sim.pool_workspace(frames, n_cam, D, H, W, lifted.device, grid)
-    ws2.fill_(-3)
-    out2 = sim.voxel_pool(lifted, strides, torch.from_numpy(geo), frames, n_cam, D, H, W, C, grid, workspace=ws2)
-    monkeypatch.delenv('FIERY_POOL_QUAD_PREPASS')
-    # (the copied words change how many barriers the pooling workgroup passes before its row loop, and with that the
-    # order in which the simulator's wavefronts - like the hardware's - reach the LDS atomics: last-bit differences)
-    assert (out - out2).abs().max() < 2e-6
-    n_pts = frames * n_cam * D * H * W
-    n_rec = frames * n_cam * D * (W // 4) * (16 if big_grid else 8)             # floats of quad records behind the ranks
-    rec0 = -(-n_pts * 4 // 256) * 256 // 4
-    assert torch.equal(ws.view(torch.int32)[:n_pts], ws2.view(torch.int32)[:n_pts])
-    ra, rb = ws.view(torch.int32)[rec0:rec0 + n_rec], ws2.view(torch.int32)[rec0:rec0 + n_rec]
-    if big_grid:                                  # 64-byte records: words 2 and 3 of each are padding
-        keep = torch.ones(16, dtype=torch.bool)
-        keep[2:4] = False
-        ra, rb = ra.view(-1, 16)[:, keep], rb.view(-1, 16)[:, keep]
-    assert torch.equal(ra, rb)
-    assert torch.equal(occupied, sim.pool_occupied(ws2, frames, n_cam, D, H, W, grid))
     monkeypatch.setenv('FIERY_POOL_COMPACT', '0')
     dense = sim.voxel_pool(lifted, strides, torch.from_numpy(geo), frames, n_cam, D, H, W, C, grid)
     assert (out - dense).abs().max() < 2e-5          # fp32 LDS atomics arrive in a different order in the two kernels
