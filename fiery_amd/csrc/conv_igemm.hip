@@ -231,6 +231,18 @@ int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, bool launch) {
         p.src[s] = SrcP{d->src[s].ptr, d->src[s].ld, d->src[s].units, d->src[s].batch_stride, d->src[s].time_stride, ext_bytes};
     }
     p.Hin = d->Hin; p.Win = d->Win; p.Hout = d->Hout; p.Wout = d->Wout;
+    {
+        // (m, s) with g / div == (g * m) >> s for every 0 <= g < 2^31: m = floor(2^(31 + l) / div) + 1, l = ceil(log2 div)
+        auto conv_magic = [](long long div, unsigned* m, int* sh) {
+            int l = 0;
+            while ((1ll << l) < div) ++l;
+            *m = static_cast<unsigned>((1ull << (31 + l)) / static_cast<unsigned long long>(div) + 1ull);
+            *sh = 31 + l;
+        };
+        conv_magic(static_cast<long long>(d->Hout) * d->Wout, &p.mg_hw, &p.sh_hw);
+        conv_magic(d->Wout, &p.mg_w, &p.sh_w);
+        conv_magic(d->T_out, &p.mg_t, &p.sh_t);
+    }
     p.n_img = d->n_img_out; p.Tout = d->T_out; p.tout0 = d->t_out0; p.tinadd = d->t_in_add;
     p.kT = d->kT; p.kH = d->kH; p.kW = d->kW; p.stride = d->stride; p.padH = d->padH; p.padW = d->padW;
     p.w = d->weights;
@@ -334,7 +346,7 @@ int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, bool launch) {
     const bool prio = getenv("FIERY_CONV_PRIO") != nullptr;                                    // tuning experiment
     // The scalar-addressed K loop (ALIGNED): every tap must hold a whole number of 32-channel stages from one source,
     // and each source must be addressable with non-negative 31-bit byte offsets from (a little before) its base.
-    bool aligned = cin_units % 4 == 0 && d->src[0].units % 4 == 0 && taps <= 63 && d->t_in_add >= 0;
+    bool aligned = cin_units % 4 == 0 && d->src[0].units % 4 == 0 && d->kT <= 8 && d->kH <= 8 && d->kW <= 8 && d->t_in_add >= 0;
     for (int s = 0; s < 2 && aligned; ++s) {
         if (d->src[s].units == 0) continue;
         const long long n_batch = d->n_img_out / d->T_out;

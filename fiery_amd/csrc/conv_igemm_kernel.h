@@ -70,6 +70,11 @@ struct ConvP {
     TensP res, out, out2, aux0, aux1;
     int cout_store;
     long long M;
+    // exact division of a 31-bit pixel index by Hout Wout, Wout and Tout as multiply + shift (set by the host, see
+    // conv_magic): the kernel's set-up divides a dozen times per thread, and a run-time divisor costs ~25 vector
+    // instructions per division on this ISA
+    unsigned mg_hw, mg_w, mg_t;
+    int sh_hw, sh_w, sh_t;
     const float* w2;      // chained 1x1 (BN = 32 only)
     const float* scale2;
     const float* shift2;
@@ -110,6 +115,10 @@ __device__ unsigned long long* g_clk_probe = nullptr;
 __device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};   // (not const: it must live in the global address space like the sources, or the select makes the loads flat)
 
 __device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(-v)); }
+// g / d for 0 <= g < 2^31 with (m, s) = conv_magic(d): exact (Granlund-Montgomery, round-up form)
+__device__ __forceinline__ int fast_div(int g, unsigned m, int s) {
+    return static_cast<int>((static_cast<unsigned long long>(static_cast<unsigned>(g)) * m) >> s);
+}
 
 // BM output pixels x BN couts per workgroup: (128, 32|64|128) and (64, 64|128).  The 64-pixel tiles exist for
 // launches whose 128-pixel tile count would leave a badly filled last wave of workgroups.
@@ -118,6 +127,9 @@ __device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(
 // register allocation is held to (without it the compiler aims one notch too high for the 64 x 128 tile and spills).
 constexpr int conv_waves_per_simd(int bm, int bn) {
     const int by_lds = 163840 / ((2 * bm * BK + 2 * BK * bn) * 4);
+    // (a fourth workgroup per CU for the scalar-addressed 128 x 32 kernel - it fits 128 registers since its set-up lost
+    // the 64-bit tap masks - was measured in round 3: the chained epilogue then spills 35 registers and the Bottleneck
+    // tail got slower, 177 vs 163 us)
     const int cap = (bm == 64 && bn == 64) ? 4 : 3;
     return by_lds < cap ? by_lds : cap;
 }
@@ -130,6 +142,8 @@ constexpr int conv_waves_per_simd(int bm, int bn) {
 template <int BM, int BN, bool CLK = false, int PRIO = 0, bool SMALLCIN = false, bool ALIGNED = false, bool BF16 = false>
 __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm(ConvP p) {
     static_assert(!BF16 || (ALIGNED && !SMALLCIN && !CLK), "the bf16 form exists for the scalar-addressed loop");
+    unsigned long long clk_entry = 0;
+    if constexpr (CLK) clk_entry = clock64();
     if constexpr (PRIO == 1) {
         // experiment: workgroups that share a CU (dispatch order puts b and b + 256 on one CU first) get different wave
         // priorities, so that they do not march through their MFMA and load/store phases in lockstep
@@ -183,10 +197,10 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
         const int gp = pix0 + prow + 32 * j;
         pvalid[j] = gp < M;
         const int g = pvalid[j] ? gp : 0;
-        const int o = g / HWout;
+        const int o = fast_div(g, p.mg_hw, p.sh_hw);
         const int rem = g - o * HWout;
-        const int y = rem / p.Wout, x = rem - y * p.Wout;
-        const int b = o / p.Tout, tl = o - b * p.Tout;
+        const int y = fast_div(rem, p.mg_w, p.sh_w), x = rem - y * p.Wout;
+        const int b = fast_div(o, p.mg_t, p.sh_t), tl = o - b * p.Tout;
         py0[j] = y * p.stride - p.padH;
         px0[j] = x * p.stride - p.padW;
         ptmin[j] = tl + p.tout0 - (p.kT - 1);                       // absolute time of the dt = 0 tap
@@ -232,9 +246,12 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
     int ld_tap_off = 0;
     //   aligned path state
     int voff0[NA], voff1[NA];                   // this thread's pixels in the two sources, bytes, >= 0
-    unsigned long long vmask[NA];               // bit t: tap t of pixel j lies inside the image (and the pixel exists)
+    unsigned vmask[NA];                         // rows | columns << 8 | frames << 16 of the kernel window that lie inside the
+                                                // image for pixel j (0 when the pixel does not exist): tap (dt, dy, dx) is
+                                                // inside iff its three bits are set
     int s_tap = 0, s_g = 0, s_dt = 0, s_dy = 0, s_dx = 0;      // wave-uniform
     int s_off = 0;
+    unsigned s_sel = 0;                                        // the running tap's three bits (see vmask)
     bool s_second = false;
     __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src0_ptr), 0, 0, 0x00020000);
     const int s_groups = c_cin_units >> 2, s_groups0 = src0_units >> 2;
@@ -244,27 +261,28 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
             const int gp = pix0 + prow + 32 * j;
             const bool pv = gp < M;
             const int g = pv ? gp : 0;
-            const int o = g / HWout;
+            const int o = fast_div(g, p.mg_hw, p.sh_hw);
             const int rem = g - o * HWout;
-            const int y = rem / p.Wout, x = rem - y * p.Wout;
-            const int b = o / p.Tout, tl = o - b * p.Tout;
+            const int y = fast_div(rem, p.mg_w, p.sh_w), x = rem - y * p.Wout;
+            const int b = fast_div(o, p.mg_t, p.sh_t), tl = o - b * p.Tout;
             const int sp = (y * p.stride) * c_Win + x * p.stride;
             const int kofs = (f4 >> 1) * 8 + (f4 & 1) * 4;
-            voff0[j] = 4 * (static_cast<int>(b * p.src[0].bstride + (tl + p.tinadd) * p.src[0].tstride) + sp * src0_ld + kofs);
-            voff1[j] = 4 * (static_cast<int>(b * p.src[1].bstride + (tl + p.tinadd) * p.src[1].tstride) + sp * src1_ld + kofs);
-            unsigned rowm = 0, colm = 0, tm = 0;
-            for (int dy = 0; dy < c_kH; ++dy)
-                rowm |= (static_cast<unsigned>(y * p.stride - p.padH + dy) < static_cast<unsigned>(c_Hin) ? 1u : 0u) << dy;
-            for (int dx = 0; dx < c_kW; ++dx)
-                colm |= (static_cast<unsigned>(x * p.stride - p.padW + dx) < static_cast<unsigned>(c_Win) ? 1u : 0u) << dx;
-            for (int dt = 0; dt < p.kT; ++dt) tm |= ((tl + p.tout0 - (p.kT - 1) + dt) >= 0 ? 1u : 0u) << dt;
-            unsigned long long mk = 0;
-            int tap = 0;
-            for (int dt = 0; dt < p.kT; ++dt)
-                for (int dy = 0; dy < c_kH; ++dy)
-                    for (int dx = 0; dx < c_kW; ++dx, ++tap)
-                        mk |= static_cast<unsigned long long>((tm >> dt) & (rowm >> dy) & (colm >> dx) & 1u) << tap;
-            vmask[j] = pv ? mk : 0ull;
+            // (32-bit throughout: the host takes this loop only for sources that span less than 2^29 floats)
+            voff0[j] = 4 * (b * static_cast<int>(p.src[0].bstride) + (tl + p.tinadd) * src0_ts + sp * src0_ld + kofs);
+            voff1[j] = 4 * (b * static_cast<int>(p.src[1].bstride) + (tl + p.tinadd) * src1_ts + sp * src1_ld + kofs);
+            // The window's valid rows / columns / frames are contiguous ranges, so each mask is two shifts - no loop over
+            // taps.  (The prologue used to build a 64-bit tap mask with loops over kH, kW, kT and all taps: ~1,500 vector
+            // instructions per workgroup, 19.8 k cycles measured - as long as the whole K loop of a 3x3 32 -> 32 layer,
+            // and every one of them taken from the matrix pipe of the wavefronts sharing the SIMD.)
+            auto range_bits = [](int lo, int hi) {             // bits [lo, hi) of a window of at most 8
+                lo = lo < 0 ? 0 : lo;
+                return hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+            };
+            const int y_in = y * p.stride - p.padH, x_in = x * p.stride - p.padW;      // window origin in the input
+            const unsigned rowm = range_bits(-y_in, c_kH < c_Hin - y_in ? c_kH : c_Hin - y_in);
+            const unsigned colm = range_bits(-x_in, c_kW < c_Win - x_in ? c_kW : c_Win - x_in);
+            const unsigned tm = range_bits(p.kT - 1 - tl - p.tout0, p.kT);
+            vmask[j] = pv ? (rowm | (colm << 8) | (tm << 16)) : 0u;
         }
     } else {
 #pragma unroll
@@ -316,6 +334,8 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
                 s_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s_base - lead), 0, 4 * lead + s_ext, 0x00020000);
             } else {
                 s_off = 4 * (s_dt * s_ts + (s_dy * c_Win + s_dx) * s_ld + (s_g - (s_second ? s_groups0 : 0)) * 32);
+                // (past the end of K the frame counter has run out of the window: bit 16 + kT is never set in a mask)
+                s_sel = (1u << s_dy) | (1u << (8 + s_dx)) | (1u << (16 + (s_dt < 15 ? s_dt : 15)));
             }
         } else if (part == 0) {
             ld_valid = u_tap < taps;
@@ -328,7 +348,7 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
     };
     auto gather = [&](int j) {
         if constexpr (ALIGNED) {
-            const bool ok = ((vmask[j] >> (s_tap < 63 ? s_tap : 63)) & 1ull) != 0;
+            const bool ok = (vmask[j] & s_sel) == s_sel;
             int voff = s_second ? voff1[j] : voff0[j];
             voff = ok ? voff : static_cast<int>(0x80000000u);               // beyond the descriptor: reads as zero
             return to_float4(__builtin_amdgcn_raw_buffer_load_b128(s_rsrc, voff, s_off, 0));
@@ -556,9 +576,17 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
         if (tid == 0 && (blockIdx.x & 15) == 0 && g_clk_probe) {
             atomicAdd(g_clk_probe, static_cast<unsigned long long>(clock64() - clk_c0));
             atomicAdd(g_clk_probe + 1, static_cast<unsigned long long>(wall_clock64() - clk_w0));
+            atomicAdd(g_clk_probe + 2, static_cast<unsigned long long>(clk_c0 - clk_entry));       // prologue (set-up + first loads)
             atomicAdd(g_clk_probe + 6, 1ull);
         }
     }
+    const unsigned long long clk_loop_end = CLK ? clock64() : 0ull;
+    auto clk_finish = [&]() {                                  // epilogue cycles of the sampled workgroups (staged paths)
+        if constexpr (CLK) {
+            if (tid == 0 && (blockIdx.x & 15) == 0 && g_clk_probe)
+                atomicAdd(g_clk_probe + 3, static_cast<unsigned long long>(clock64() - clk_loop_end));
+        }
+    };
 
     // ---- staged epilogue (plain mode): accumulators -> LDS tile [pixel][cout] -> 16-byte rows -----------------
     // A lane holds one cout for 16 scattered pixel rows, so storing from registers means 4-byte accesses 128 B
@@ -574,24 +602,55 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
         const float4 sc = *reinterpret_cast<const float4*>(scale + co);
         const float4 sh = *reinterpret_cast<const float4*>(shift + co);
         int gp = pix0 + prow0;
-        int o = gp / HWout, ppi = gp - o * HWout;
-        for (int pl = prow0; pl < BM; pl += rows_per_pass) {
-            if (gp >= M) break;
-            float4 v = *reinterpret_cast<const float4*>(&smem[pl * width + c4 * 4]);
+        int o = fast_div(gp, p.mg_hw, p.sh_hw), ppi = gp - o * HWout;
+        // The row's global operands - residual, or the GRU's state / update gate, and the per-image bias - are requested
+        // one row AHEAD of their use: destination and operands are not known to be distinct tensors, so the compiler keeps
+        // a row's loads behind the previous row's store, i.e. one exposed memory round trip per row (8 to 16 rows per
+        // thread; measured as ~11 k cycles of a 34 k-cycle chained epilogue).  Fetching row i + 1 before storing row i is
+        // correct even for an in-place residual: the rows are different pixels.
+        struct RowOperands {
+            float4 a, b, bias;
+        };
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool gates_upper = p.epi == FIERY_EPI_GRU_GATES && co >= half;
+        auto fetch = [&](int o_, int ppi_, bool live) {
+            RowOperands r{zero4, zero4, zero4};
+            if (!live) return r;
+            const long long pp = ppi_;
             if (with_bias && p.img_bias) {
-                long long brow = o;
+                long long brow = o_;
                 if (p.bias_border) {                        // 3x3 class of (y, x): which taps fall inside the image
-                    const int y = ppi / p.Wout, x = ppi - y * p.Wout;
+                    const int y = fast_div(ppi_, p.mg_w, p.sh_w), x = ppi_ - y * p.Wout;
                     brow = brow * 9 + (y == 0 ? 0 : y == p.Hout - 1 ? 2 : 1) * 3 + (x == 0 ? 0 : x == p.Wout - 1 ? 2 : 1);
                 }
-                const float4 b = *reinterpret_cast<const float4*>(p.img_bias + brow * p.cout_pad + co);
-                v.x += b.x;  v.y += b.y;  v.z += b.z;  v.w += b.w;
+                r.bias = *reinterpret_cast<const float4*>(p.img_bias + brow * p.cout_pad + co);
             }
+            if (p.epi == FIERY_EPI_PLAIN) {
+                if (p.res.ptr) r.a = *reinterpret_cast<const float4*>(p.res.ptr + o_ * p.res.istride + pp * p.res.ld + co);
+            } else if (p.epi == FIERY_EPI_GRU_GATES) {
+                if (gates_upper) r.a = *reinterpret_cast<const float4*>(p.aux0.ptr + o_ * p.aux0.istride + pp * p.aux0.ld + (co - half));
+            } else {                                                                        // FIERY_EPI_GRU_OUT
+                r.a = *reinterpret_cast<const float4*>(p.aux0.ptr + o_ * p.aux0.istride + pp * p.aux0.ld + co);
+                r.b = *reinterpret_cast<const float4*>(p.aux1.ptr + o_ * p.aux1.istride + pp * p.aux1.ld + co);
+            }
+            return r;
+        };
+        RowOperands cur = fetch(o, ppi, gp < M);
+        for (int pl = prow0; pl < BM; pl += rows_per_pass) {
+            if (gp >= M) break;
+            // next row of this thread: its pixel, and its operands on their way
+            int gp_n = gp + rows_per_pass, ppi_n = ppi + rows_per_pass, o_n = o;
+            while (ppi_n >= HWout) {
+                ppi_n -= HWout;
+                ++o_n;
+            }
+            const RowOperands nxt = fetch(o_n, ppi_n, pl + rows_per_pass < BM && gp_n < M);
+            float4 v = *reinterpret_cast<const float4*>(&smem[pl * width + c4 * 4]);
+            v.x += cur.bias.x;  v.y += cur.bias.y;  v.z += cur.bias.z;  v.w += cur.bias.w;
             v.x = fmaf(v.x, sc.x, sh.x);  v.y = fmaf(v.y, sc.y, sh.y);  v.z = fmaf(v.z, sc.z, sh.z);  v.w = fmaf(v.w, sc.w, sh.w);
             const long long pp = ppi;
             if (p.epi == FIERY_EPI_PLAIN) {
-                float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.res.ptr) r = *reinterpret_cast<const float4*>(p.res.ptr + o * p.res.istride + pp * p.res.ld + co);
+                const float4 r = cur.a;
                 if (p.res_pre) { v.x += r.x;  v.y += r.y;  v.z += r.z;  v.w += r.w; }
                 if (act == FIERY_ACT_RELU) {
                     v.x = fmaxf(v.x, 0.f);  v.y = fmaxf(v.y, 0.f);  v.z = fmaxf(v.z, 0.f);  v.w = fmaxf(v.w, 0.f);
@@ -604,17 +663,16 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
                 *reinterpret_cast<float4*>(p.out.ptr + o * p.out.istride + pp * p.out.ld + co) = v;
             } else if (p.epi == FIERY_EPI_GRU_GATES) {
                 float4 g = make_float4(sigmoidf(v.x), sigmoidf(v.y), sigmoidf(v.z), sigmoidf(v.w));
-                if (co < half) {                                                            // update gate
+                if (!gates_upper) {                                                         // update gate
                     *reinterpret_cast<float4*>(p.out.ptr + o * p.out.istride + pp * p.out.ld + co) = g;
                 } else {                                                                    // (1 - reset) * state
                     const int c2 = co - half;
-                    const float4 h = *reinterpret_cast<const float4*>(p.aux0.ptr + o * p.aux0.istride + pp * p.aux0.ld + c2);
+                    const float4 h = cur.a;
                     g.x = (1.0f - g.x) * h.x;  g.y = (1.0f - g.y) * h.y;  g.z = (1.0f - g.z) * h.z;  g.w = (1.0f - g.w) * h.w;
                     *reinterpret_cast<float4*>(p.out2.ptr + o * p.out2.istride + pp * p.out2.ld + c2) = g;
                 }
             } else {                                                                        // FIERY_EPI_GRU_OUT
-                const float4 u = *reinterpret_cast<const float4*>(p.aux0.ptr + o * p.aux0.istride + pp * p.aux0.ld + co);
-                const float4 h = *reinterpret_cast<const float4*>(p.aux1.ptr + o * p.aux1.istride + pp * p.aux1.ld + co);
+                const float4 u = cur.a, h = cur.b;
                 float4 hn;
                 { const float a = (1.0f - u.x) * h.x, b = u.x * fmaxf(v.x, 0.f); hn.x = a + b; }
                 { const float a = (1.0f - u.y) * h.y, b = u.y * fmaxf(v.y, 0.f); hn.y = a + b; }
@@ -623,12 +681,10 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
                 *reinterpret_cast<float4*>(p.out.ptr + o * p.out.istride + pp * p.out.ld + co) = hn;
                 if (p.out2.ptr) *reinterpret_cast<float4*>(p.out2.ptr + o * p.out2.istride + pp * p.out2.ld + co) = hn;
             }
-            gp += rows_per_pass;
-            ppi += rows_per_pass;
-            while (ppi >= HWout) {
-                ppi -= HWout;
-                ++o;
-            }
+            cur = nxt;
+            gp = gp_n;
+            ppi = ppi_n;
+            o = o_n;
         }
     };
     auto stage_tile = [&](const v16f& a, int t, int nt, int width) {
@@ -644,6 +700,9 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
     // ---- optional chained 1x1 convolution on the tile (Bottleneck up-projection) -----------------------------
     if constexpr (BN == 32 && BM == 128) {
         if (p.w2) {
+            // (0) the second GEMM's weights are requested first: their latency passes under (1)
+            const float4 w2_lo = reinterpret_cast<const float4*>(p.w2)[tid];
+            const float4 w2_hi = reinterpret_cast<const float4*>(p.w2)[tid + 256];
             // (1) h = act(acc*scale + shift) back into LDS as the A operand of a second GEMM: [pixel][32 k], same
             //     slot swizzle as the main loop.  Every wave passed the loop's last barrier, so stage 0 is free.
             {
@@ -661,9 +720,8 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
             // (2) the 32 x 64 weight tile, already in its LDS image, into the (now idle) W stages
             {
                 float* bdst = &Bs[0][0];                            // 2 stages x 32 x 32 floats = 32 x 64
-                const float4* wsrc = reinterpret_cast<const float4*>(p.w2);
-                *reinterpret_cast<float4*>(bdst + tid * 4) = wsrc[tid];
-                *reinterpret_cast<float4*>(bdst + (tid + 256) * 4) = wsrc[tid + 256];
+                *reinterpret_cast<float4*>(bdst + tid * 4) = w2_lo;
+                *reinterpret_cast<float4*>(bdst + (tid + 256) * 4) = w2_hi;
             }
             __syncthreads();
             // (3) 128 x 64 = (128 x 32) . (32 x 64): each wavefront 32 pixels x 64 couts
@@ -695,6 +753,36 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
                 // is a memory-bound launch that re-reads what this kernel has just written; here its input is the tile in
                 // hand.  Operands ride in members the chained mode does not use: heads.w = packed 64 x 32 weights,
                 // aux0.ptr / aux1.ptr = scale3 / shift3 [32], heads.n_out = act3, out2 = destination.
+                // rows of the 128 x 64 tile: 16 chunks of four channels per row, 16 rows per pass, 8 passes per thread.
+                // Their residual rows and the third GEMM's weights are requested NOW, all of them, before the tile is even
+                // staged: one memory round trip for the whole epilogue instead of one per row (destination and residual
+                // are not known to be distinct, so loads written next to their stores stay behind the previous store).
+                const int c4 = tid & 15, prow0 = tid >> 4;
+                const int co = c4 * 4;
+                float4 resid[8];
+                long long out_off[8];                              // < 0: the row does not exist / the chunk is not stored
+                {
+                    int gp = pix0 + prow0;
+                    int o = fast_div(gp, p.mg_hw, p.sh_hw), ppi = gp - o * HWout;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const bool live = gp < M && co < p.cout_store;
+                        const long long pp = ppi;
+                        out_off[i] = live ? o * p.out.istride + pp * p.out.ld + co : -1;
+                        resid[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (live && p.res.ptr) resid[i] = *reinterpret_cast<const float4*>(p.res.ptr + o * p.res.istride + pp * p.res.ld + co);
+                        gp += 16;
+                        ppi += 16;
+                        while (ppi >= HWout) {
+                            ppi -= HWout;
+                            ++o;
+                        }
+                    }
+                }
+                const float4 w3_lo = reinterpret_cast<const float4*>(p.heads.w)[tid];
+                const float4 w3_hi = reinterpret_cast<const float4*>(p.heads.w)[tid + 256];
+                const float4 sc2 = *reinterpret_cast<const float4*>(p.scale2 + co);
+                const float4 sh2 = *reinterpret_cast<const float4*>(p.shift2 + co);
                 __syncthreads();                                   // everyone is done reading the h and W tiles
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
@@ -704,43 +792,24 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
                         smem[pl * 64 + nt * 32 + m] = acc2[nt][r];
                     }
                 __syncthreads();
-                // rows of the 128 x 64 tile: 16 chunks of four channels per row, 16 rows per pass, 8 passes per thread
-                const int c4 = tid & 15, prow0 = tid >> 4;
-                const int co = c4 * 4;
-                const float4 sc2 = *reinterpret_cast<const float4*>(p.scale2 + co);
-                const float4 sh2 = *reinterpret_cast<const float4*>(p.shift2 + co);
                 float4 y[8];
-                {
-                    int gp = pix0 + prow0;
-                    int o = gp / HWout, ppi = gp - o * HWout;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int pl = prow0 + 16 * i;
-                        float4 v = *reinterpret_cast<const float4*>(&smem[pl * 64 + co]);
-                        v.x = fmaf(v.x, sc2.x, sh2.x);  v.y = fmaf(v.y, sc2.y, sh2.y);  v.z = fmaf(v.z, sc2.z, sh2.z);  v.w = fmaf(v.w, sc2.w, sh2.w);
-                        if (p.act2 == FIERY_ACT_RELU) {
-                            v.x = fmaxf(v.x, 0.f);  v.y = fmaxf(v.y, 0.f);  v.z = fmaxf(v.z, 0.f);  v.w = fmaxf(v.w, 0.f);
-                        } else if (p.act2 == FIERY_ACT_SIGMOID) {
-                            v.x = sigmoidf(v.x);  v.y = sigmoidf(v.y);  v.z = sigmoidf(v.z);  v.w = sigmoidf(v.w);
-                        }
-                        if (gp < M && co < p.cout_store) {
-                            const long long pp = ppi;
-                            if (p.res.ptr) {
-                                const float4 rr = *reinterpret_cast<const float4*>(p.res.ptr + o * p.res.istride + pp * p.res.ld + co);
-                                v.x += rr.x;  v.y += rr.y;  v.z += rr.z;  v.w += rr.w;
-                            }
-                            *reinterpret_cast<float4*>(p.out.ptr + o * p.out.istride + pp * p.out.ld + co) = v;
-                        } else {
-                            v = make_float4(0.f, 0.f, 0.f, 0.f);
-                        }
-                        y[i] = v;
-                        gp += 16;
-                        ppi += 16;
-                        while (ppi >= HWout) {
-                            ppi -= HWout;
-                            ++o;
-                        }
+                for (int i = 0; i < 8; ++i) {
+                    const int pl = prow0 + 16 * i;
+                    float4 v = *reinterpret_cast<const float4*>(&smem[pl * 64 + co]);
+                    v.x = fmaf(v.x, sc2.x, sh2.x);  v.y = fmaf(v.y, sc2.y, sh2.y);  v.z = fmaf(v.z, sc2.z, sh2.z);  v.w = fmaf(v.w, sc2.w, sh2.w);
+                    if (p.act2 == FIERY_ACT_RELU) {
+                        v.x = fmaxf(v.x, 0.f);  v.y = fmaxf(v.y, 0.f);  v.z = fmaxf(v.z, 0.f);  v.w = fmaxf(v.w, 0.f);
+                    } else if (p.act2 == FIERY_ACT_SIGMOID) {
+                        v.x = sigmoidf(v.x);  v.y = sigmoidf(v.y);  v.z = sigmoidf(v.z);  v.w = sigmoidf(v.w);
                     }
+                    if (out_off[i] >= 0) {
+                        v.x += resid[i].x;  v.y += resid[i].y;  v.z += resid[i].z;  v.w += resid[i].w;
+                        *reinterpret_cast<float4*>(p.out.ptr + out_off[i]) = v;
+                    } else {
+                        v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                    y[i] = v;
                 }
                 __syncthreads();                                   // the staged tile has been read by everyone
                 // the finished tile as the A operand of the third GEMM: two K stages of [pixel][32 k], slot-swizzled
@@ -751,9 +820,8 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
                 }
                 {
                     float* bdst = &Bs[0][0];                        // 2 stages x 32 x 32 floats = the packed 64 x 32 weights
-                    const float4* wsrc = reinterpret_cast<const float4*>(p.heads.w);
-                    *reinterpret_cast<float4*>(bdst + tid * 4) = wsrc[tid];
-                    *reinterpret_cast<float4*>(bdst + (tid + 256) * 4) = wsrc[tid + 256];
+                    *reinterpret_cast<float4*>(bdst + tid * 4) = w3_lo;
+                    *reinterpret_cast<float4*>(bdst + (tid + 256) * 4) = w3_hi;
                 }
                 __syncthreads();
                 v16f acc3;
@@ -785,7 +853,7 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
                     const float4 sc3 = *reinterpret_cast<const float4*>(p.aux0.ptr + dco);
                     const float4 sh3 = *reinterpret_cast<const float4*>(p.aux1.ptr + dco);
                     int gp = pix0 + drow0;
-                    int o = gp / HWout, ppi = gp - o * HWout;
+                    int o = fast_div(gp, p.mg_hw, p.sh_hw), ppi = gp - o * HWout;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int pl = drow0 + 32 * i;
@@ -806,6 +874,7 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
                         }
                     }
                 }
+                clk_finish();
                 return;
             }
             if (rows16) {
@@ -822,10 +891,11 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
                 p.res_pre = 0;                                     // the chained form adds the residual after the activation
                 store_rows(64, 0, p.scale2, p.shift2, p.act2, false);
                 p.res_pre = keep_res_pre;
+                clk_finish();
                 return;
             }
             const int gp_base = pix0 + wm * 32 + 4 * hi;
-            const int o_base = gp_base / HWout;
+            const int o_base = fast_div(gp_base, p.mg_hw, p.sh_hw);
             const int pp_base = gp_base - o_base * HWout;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
@@ -904,7 +974,7 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
                 if (p.heads.sigmoid[my_out]) a = sigmoidf(a);
                 const int gp = pix0 + lane;
                 if (gp < M) {
-                    const int o = gp / HWout, ppi = gp - o * HWout;
+                    const int o = fast_div(gp, p.mg_hw, p.sh_hw), ppi = gp - o * HWout;
                     p.heads.out[my_out][o * p.heads.istride[my_out] + ppi] = a;
                 }
             }
@@ -922,6 +992,7 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
         }
         __syncthreads();
         store_rows(BN, tile_n * BN, p.scale, p.shift, p.act, true);
+        clk_finish();
         return;
     }
 
@@ -933,7 +1004,7 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
         // image / in-image pixel of this lane's first row; the other 15 rows are small constant offsets away,
         // so one division per tile instead of one per element
         const int gp_base = pix0 + wm * (32 * MT) + t * 32 + 4 * hi;
-        const int o_base = gp_base / HWout;
+        const int o_base = fast_div(gp_base, p.mg_hw, p.sh_hw);
         const int pp_base = gp_base - o_base * HWout;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -949,7 +1020,7 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
             if (p.img_bias) {
                 long long brow = o;
                 if (p.bias_border) {
-                    const int y = ppi / p.Wout, x = ppi - y * p.Wout;
+                    const int y = fast_div(ppi, p.mg_w, p.sh_w), x = ppi - y * p.Wout;
                     brow = brow * 9 + (y == 0 ? 0 : y == p.Hout - 1 ? 2 : 1) * 3 + (x == 0 ? 0 : x == p.Wout - 1 ? 2 : 1);
                 }
                 v += p.img_bias[brow * p.cout_pad + co];
