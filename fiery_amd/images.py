@@ -96,6 +96,7 @@ def resize_crop_normalise(images, resize_dims, crop, mean=IMAGENET_MEAN, std=IMA
     resize_dims = (width, height) and crop = (left, top, right, bottom) as `get_resizing_and_cropping_parameters` returns them
     -> (n, 3, crop height, crop width) float32 = normalise_image(resize_and_crop_image(img, resize_dims, crop)) per image, on the
     device.  Host inputs are moved to `device` (default: the current HIP device; there is no CPU path)."""
+    native.require_usable_gpu_process('resize_crop_normalise')
     lib = lib or native.get()
     where = images.device
     device = torch.device(device) if device is not None else (where if where.type == 'cuda' else torch.device('cuda'))

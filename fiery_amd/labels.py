@@ -76,11 +76,13 @@ def convert_instance_mask_to_center_and_offset_label(instance_img, future_egomot
     (seq_len, 2, h, w), `ignore_index` where undefined.  Same arguments and results as the reference; the per-instance, per-frame
     Python loop is two kernel launches (`fiery_instance_labels`), the id maps are resampled into the previous frame by
     `fiery_bev_warp_nearest_nchw`.  The poses - a handful of 4 x 4 matrices - are inverted with the reference's own operators
-    on the host.  Tensors may live on the host (as in a dataloader worker) or on the GPU; host inputs are moved to `device`
-    (default: the current HIP device - there is no CPU path) and the results brought back to where the input was."""
+    on the host.  Tensors may live on the host or on the GPU; host inputs are moved to `device` (default: the current HIP device -
+    there is no CPU path) and the results brought back to where the input was.  In a DataLoader worker this needs the
+    'spawn' start method (a forked worker cannot use the parent's HIP context: the call raises and says so)."""
     if not subtract_egomotion:
         raise ValueError('convert_instance_mask_to_center_and_offset_label: the reference only defines the warped instance maps '
                          'with subtract_egomotion=True (fiery/utils/instance.py:22-31)')
+    native.require_usable_gpu_process('convert_instance_mask_to_center_and_offset_label')
     lib = lib or native.get()
     seq_len, h, w = instance_img.shape
     where = instance_img.device

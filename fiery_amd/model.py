@@ -357,12 +357,16 @@ class Fiery(nn.Module):
 
     def _lift_head(self, images, groups=1):
         """(N, 3, H, W) images -> (depth logits (N, D, h, w) or None, context features (N, C, h, w)): the image trunk and
-        the lift head (reference: encoder.py:58-100) on the HIP engine; under autograd the torch statement of the same
-        layers (the engine has no backward for them), and with `hip_trunk = False` the trunk alone on PyTorch-ROCm.
+        the lift head (reference: encoder.py:58-100) on the HIP engine whether or not autograd is recording (the inference
+        plan has no backward: results carry no grad_fn; training goes through `train_graph`), and with `hip_trunk = False`
+        the trunk alone on PyTorch-ROCm.
         `groups`: the images are that many samples' worth; with `sample_streams` every sample's images run as a chain of
         their own (own engine, own stream) - the late trunk stages are small, latency-bound launches that overlap well."""
-        if torch.is_grad_enabled():
-            return self.encoder.lift_head(images)
+        if images.requires_grad:
+            # (eval mode replays the folded inference plan, which has no backward; until round 3 a call with autograd enabled
+            # fell through to the torch statement of the trunk silently - slower, other rounding, and nobody asked for it)
+            raise RuntimeError('fiery_amd.Fiery: gradients with respect to the images were requested from the inference plan; '
+                               'use model.train() (or model.train_graph()) for a differentiable pass')
         eng = self.engine()
         n_img = images.shape[0]
         if self.hip_trunk and self.sample_streams and groups > 1 and n_img % groups == 0 and images.is_cuda:

@@ -177,6 +177,19 @@ _SIGNATURES = {
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
+
+def require_usable_gpu_process(what):
+    """The input-pipeline entry points keep the signatures of functions the reference calls inside `Dataset.__getitem__`,
+    i.e. in DataLoader worker processes.  With the default `fork` start method such a worker inherits an initialised HIP
+    context it cannot use; PyTorch reports that as 'Cannot re-initialize CUDA in forked subprocess' from somewhere deep in
+    the first tensor move.  Say it here, with the remedies."""
+    if torch.cuda.is_initialized() and getattr(torch.cuda, '_is_in_bad_fork', lambda: False)():
+        raise RuntimeError(
+            f'{what} launches HIP kernels, but this process was forked from one that had already initialised the GPU '
+            f'(a DataLoader worker with the fork start method).  Create the DataLoader with '
+            f"multiprocessing_context='spawn', or keep num_workers=0 for these labels, or call the function on the collated "
+            f'batch in the training process.')
+
 _WARP_FLAGS = {}
 
 
@@ -430,7 +443,10 @@ class Lib:
                                                       _ptr(out), out_ld, _stream_of(out)))
 
     def _bn_workspace(self, c, device):
-        key = (int(c), str(device))
+        """Partial-sum rows of the BatchNorm passes: one buffer per (width, device, STREAM) - launches on different streams
+        of a device (per-sample side streams, replicas in threads) must not share partial sums."""
+        stream = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == 'cuda' else 0
+        key = (int(c), str(device), stream)
         cache = self.__dict__.setdefault('_bn_ws', {})
         if key not in cache:
             cache[key] = torch.empty(self.dll.fiery_bn_workspace_floats(int(c)), dtype=torch.float32, device=device)

@@ -35,17 +35,28 @@ from .ops import Buf, ConvOp, identity_chan_map, round_up
 # ---------------------------------------------------------------------------------------------------------------------
 # convolution on the HIP kernels, differentiable
 # ---------------------------------------------------------------------------------------------------------------------
+def _padded_rows(t, c, cp):
+    """Marks `t` - an (N, C, H, W) view of the first C channels of pixel-major rows Cp wide whose remaining channels the
+    producing kernel wrote as zeros - so that `_pixel_major` may widen it again instead of copying.  Only this module's own
+    operators call it, on buffers they allocated at the padded width."""
+    if cp != c:
+        t._fiery_padded_rows = cp
+    return t
+
+
 def _pixel_major(x, pad_to=8):
     """(N, C, H, W) of any layout -> contiguous (N, H, W, Cp) with Cp = C rounded up to `pad_to`.  The channels past C are
-    zeros - or, when x already is a channel slice of pixel-major rows Cp wide (the outputs of the operators below: their row
-    padding is written as zeros), whatever those rows hold there: every consumer multiplies them by zero weights or drops
-    the result."""
+    zeros.  A tensor that one of the operators below produced as a channel slice of zero-padded rows (`_padded_rows`) is
+    widened in place - no copy; the mark, the stride pattern and the row alignment of the storage offset must all agree, so
+    that a slice of some other wide tensor (whose neighbouring floats are data, possibly Inf / NaN) is never mistaken for
+    one.  Everything else is padded by copy."""
     n, c, h, w = x.shape
     t = x.permute(0, 2, 3, 1)
     cp = round_up(c, pad_to)
     if cp == c:
         return t.contiguous()
-    if min(n, h, w) > 1 and t.stride() == (h * w * cp, w * cp, cp, 1):
+    if (getattr(x, '_fiery_padded_rows', 0) == cp and min(n, h, w) > 1 and t.stride() == (h * w * cp, w * cp, cp, 1) and
+            t.storage_offset() % cp == 0):
         try:
             return torch.as_strided(t, (n, h, w, cp), t.stride())
         except RuntimeError:                                  # rows that end with the storage: not padded after all
@@ -90,7 +101,7 @@ class HipConv2d(torch.autograd.Function):
         y = _launch_conv(lib, x_nhwc, weight.detach().float(), stride, pad)
         ctx.save_for_backward(x_nhwc, weight)
         ctx.meta = (x.shape, stride, pad, lib)
-        return y[..., :cout].permute(0, 3, 1, 2)
+        return _padded_rows(y[..., :cout].permute(0, 3, 1, 2), cout, y.shape[-1])
 
     @staticmethod
     def backward(ctx, gy):
@@ -112,7 +123,8 @@ class HipConv2d(torch.autograd.Function):
                 gs = g.new_zeros(n, size_h, size_w, g.shape[-1])
                 gs[:, ::stride, ::stride][:, :g.shape[1], :g.shape[2]] = g
             w_t = weight.detach().float().transpose(0, 1).flip(2, 3).contiguous()
-            gx = _launch_conv(lib, gs, w_t, 1, k - 1 - pad)[..., :c].permute(0, 3, 1, 2)
+            gx = _launch_conv(lib, gs, w_t, 1, k - 1 - pad)
+            gx = _padded_rows(gx[..., :c].permute(0, 3, 1, 2), c, gx.shape[-1])
         return gx, gw, None, None, None
 
 
@@ -129,7 +141,7 @@ class HipUpsample2x(torch.autograd.Function):
         out = torch.empty(n, 2 * h, 2 * w, cp, dtype=torch.float32, device=x.device)
         lib.upsample2x_add(x_nhwc, cp, n, h, w, cp, None, None, 0, out, cp)
         ctx.meta = (n, c, h, w, cp, lib)
-        return out[..., :c].permute(0, 3, 1, 2)
+        return _padded_rows(out[..., :c].permute(0, 3, 1, 2), c, cp)
 
     @staticmethod
     def backward(ctx, gy):
@@ -163,7 +175,7 @@ class HipBatchNormAct(torch.autograd.Function):
                                            eps, relu, c_store)
         ctx.save_for_backward(xr, y if relu else None, mean, invstd, None if weight is None else weight.detach())
         ctx.meta = (n, c, h, w, ld, c_store, batch_stats, lib)
-        return y.view(n, h, w, c_store)[..., :c].permute(0, 3, 1, 2)
+        return _padded_rows(y.view(n, h, w, c_store)[..., :c].permute(0, 3, 1, 2), c, c_store)
 
     @staticmethod
     def backward(ctx, gy):
@@ -171,7 +183,7 @@ class HipBatchNormAct(torch.autograd.Function):
         n, c, h, w, ld, c_store, batch_stats, lib = ctx.meta
         gr, g_ld = _rows(gy.float())
         gx, dgamma, dbeta = lib.bn_train_bwd(gr, g_ld, xr, ld, y, c_store, n * h * w, c, weight, mean, invstd, batch_stats, c_store)
-        return (gx.view(n, h, w, c_store)[..., :c].permute(0, 3, 1, 2), dgamma if ctx.needs_input_grad[1] else None,
+        return (_padded_rows(gx.view(n, h, w, c_store)[..., :c].permute(0, 3, 1, 2), c, c_store), dgamma if ctx.needs_input_grad[1] else None,
                 dbeta if ctx.needs_input_grad[2] else None, None, None, None, None, None, None, None)
 
 
@@ -207,7 +219,7 @@ class HipSyncBatchNormAct(torch.autograd.Function):
                          None if bias is None else bias.detach(), relu, c_store)
         ctx.save_for_backward(xr, y if relu else None, mean, invstd, None if weight is None else weight.detach())
         ctx.meta = (n, c, h, w, ld, c_store, int(total.item()), group, lib)
-        return y.view(n, h, w, c_store)[..., :c].permute(0, 3, 1, 2)
+        return _padded_rows(y.view(n, h, w, c_store)[..., :c].permute(0, 3, 1, 2), c, c_store)
 
     @staticmethod
     def backward(ctx, gy):
@@ -221,7 +233,7 @@ class HipSyncBatchNormAct(torch.autograd.Function):
         dist.all_reduce(sums, group=group)
         gx = lib.bn_train_bwd_dx(gr, g_ld, xr, ld, y, c_store, pixels, c, weight, mean, invstd, sums[:c].contiguous(), sums[c:].contiguous(),
                                  total, c_store)
-        return (gx.view(n, h, w, c_store)[..., :c].permute(0, 3, 1, 2), dgamma if ctx.needs_input_grad[1] else None,
+        return (_padded_rows(gx.view(n, h, w, c_store)[..., :c].permute(0, 3, 1, 2), c, c_store), dgamma if ctx.needs_input_grad[1] else None,
                 dbeta if ctx.needs_input_grad[2] else None, None, None, None, None, None, None, None)
 
 

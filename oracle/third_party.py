@@ -202,3 +202,41 @@ def resnet18(pretrained=False, zero_init_residual=False):
             for block in layer:
                 nn.init.zeros_(block.bn2.weight)
     return net
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference's use of the trunk, on THIS file's network (checker side; nothing here imports fiery_amd)
+# ---------------------------------------------------------------------------------------------------------------------
+def encoder_endpoints(net, x, downsample=8, version='b4'):
+    """fiery/models/encoder.py:58-86: stem, blocks with their drop-connect rates, the feature maps kept at every change
+    of resolution -> (deep, shallow) = the two levels the lift head fuses."""
+    endpoints = []
+    x = net._swish(net._bn0(net._conv_stem(x)))
+    previous = x
+    n_blocks = len(net._blocks)
+    for index, block in enumerate(net._blocks):
+        rate = net._global_params.drop_connect_rate
+        if rate:
+            rate *= float(index) / n_blocks
+        x = block(x, drop_connect_rate=rate)
+        if previous.size(2) > x.size(2):
+            endpoints.append(previous)
+        previous = x
+        if downsample == 8 and ((version == 'b0' and index == 10) or (version == 'b4' and index == 21)):
+            break
+    endpoints.append(x)
+    return (endpoints[4], endpoints[3]) if downsample == 16 else (endpoints[3], endpoints[2])
+
+
+def lift_head(sd, deep, shallow, prefix='encoder.'):
+    """fiery/models/encoder.py:87-96 + fiery/layers/convolutions.py:182-200 from a state_dict: x2 bilinear of the deep
+    level, concatenation behind the shallow one, two 3x3 conv + BatchNorm + ReLU, the 1x1 depth layer (with bias)."""
+    import torch.nn.functional as F
+    x = torch.cat([shallow, F.interpolate(deep, scale_factor=2, mode='bilinear', align_corners=False)], dim=1)
+    for conv, bn in ((0, 1), (3, 4)):
+        p = f'{prefix}upsampling_layer.conv.'
+        x = F.conv2d(x, sd[f'{p}{conv}.weight'], None, 1, 1)
+        x = F.batch_norm(x, sd[f'{p}{bn}.running_mean'], sd[f'{p}{bn}.running_var'], sd[f'{p}{bn}.weight'], sd[f'{p}{bn}.bias'],
+                         False, 0.0, 1e-5)
+        x = F.relu(x)
+    return F.conv2d(x, sd[f'{prefix}depth_layer.weight'], sd[f'{prefix}depth_layer.bias'])

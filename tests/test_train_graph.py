@@ -29,6 +29,74 @@ def test_hip_conv2d_gradients_match_torch_autograd(sim, cin, cout, k, stride, pa
     assert _rel(gx, rx) < 5e-6 and _rel(gw, rw) < 5e-6
 
 
+def _grads_vs_fp64(fn_hip, fn_ref, inputs, seed, tol=2e-5):
+    """Every output and every input gradient of an operator against the float64 autograd evaluation of its torch statement
+    on well-conditioned inputs: relative L2 error <= tol PER TENSOR (a wrong bias gradient, a mis-scaled dgamma or a missing
+    stride-2 tap is an O(1) error in one tensor - the 2 % median bound of the whole-step test would not see it)."""
+    g = torch.Generator().manual_seed(seed)
+    leaves32 = [t.clone().requires_grad_() for t in inputs]
+    leaves64 = [t.double().clone().requires_grad_() for t in inputs]
+    out32, out64 = fn_hip(*leaves32), fn_ref(*leaves64)
+    assert out32.shape == out64.shape
+    assert _rel(out32.double(), out64) < tol, ('output', _rel(out32.double(), out64))
+    gy = torch.randn(out64.shape, generator=g, dtype=torch.float64)
+    g32 = torch.autograd.grad(out32, leaves32, gy.float())
+    g64 = torch.autograd.grad(out64, leaves64, gy)
+    for i, (a, b) in enumerate(zip(g32, g64)):
+        assert a.shape == b.shape
+        assert _rel(a.double(), b) < tol, (f'gradient of input {i}', _rel(a.double(), b))
+
+
+def test_gru_elementwise_operators_all_gradients_vs_fp64(sim):
+    """HipGruReset / HipGruOut (layers/temporal.py:53-61): outputs and the gradients of the pre-activation, the BIAS, the state
+    and the candidate."""
+    from fiery_amd.train_graph import HipGruOut, HipGruReset
+    g = torch.Generator().manual_seed(3)
+    for c in (64, 32):                      # (the GRU's channel counts are multiples of 8: its kernels take 16-byte rows only)
+        pre, h, cand = (torch.randn(2, c, 7, 9, generator=g) for _ in range(3))
+        bias = 0.3 * torch.randn(c, generator=g)
+        _grads_vs_fp64(lambda p, b, hh: HipGruReset.apply(p, b, hh, sim),
+                       lambda p, b, hh: (1.0 - torch.sigmoid(p + b.view(1, -1, 1, 1))) * hh, [pre, bias, h], seed=c)
+        _grads_vs_fp64(lambda p, b, hh, cc: HipGruOut.apply(p, b, hh, cc, sim),
+                       lambda p, b, hh, cc: (1.0 - torch.sigmoid(p + b.view(1, -1, 1, 1))) * hh + torch.sigmoid(p + b.view(1, -1, 1, 1)) * cc,
+                       [pre, bias, h, cand], seed=c + 1)
+
+
+def test_upsampling_plane_mean_and_strided_convolution_gradients_vs_fp64(sim):
+    from fiery_amd.train_graph import HipConv2d, HipSpatialMean, HipUpsample2x
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 12, 6, 7, generator=g)
+    _grads_vs_fp64(lambda t: HipUpsample2x.apply(t, sim), lambda t: F.interpolate(t, scale_factor=2, mode='bilinear', align_corners=False),
+                   [x], seed=5)
+    _grads_vs_fp64(lambda t: HipSpatialMean.apply(t, sim), lambda t: t.mean(dim=(2, 3)), [torch.randn(3, 35, 9, 11, generator=g)], seed=6)
+    # stride 2 (zero-stuffed input gradient), odd and even maps, 3x3 and 7x7, padded channel counts
+    for cin, cout, k, pad, hw in ((8, 16, 3, 1, (9, 12)), (16, 16, 3, 1, (13, 13)), (11, 32, 7, 3, (12, 10)), (24, 40, 1, 0, (8, 6))):
+        xx = torch.randn(2, cin, *hw, generator=g)
+        ww = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+        _grads_vs_fp64(lambda a, b: HipConv2d.apply(a, b, 2, pad, sim), lambda a, b: F.conv2d(a, b, None, 2, pad), [xx, ww], seed=cin + k)
+
+
+def test_batchnorm_act_all_gradients_vs_fp64(sim):
+    """HipBatchNormAct in training mode with and without ReLU: y, dx, dgamma, dbeta (inputs kept away from the ReLU's kink: a
+    gate within rounding of zero is the one thing fp32 and fp64 may legitimately disagree on)."""
+    from fiery_amd.train_graph import HipBatchNormAct
+    g = torch.Generator().manual_seed(7)
+    for c, relu in ((64, False), (35, True), (6, True)):
+        x = torch.randn(3, c, 8, 9, generator=g)
+        gamma, beta = 0.5 + torch.rand(c, generator=g), 0.2 * torch.randn(c, generator=g)
+
+        def ref(t, ga, be, relu=relu):
+            y = F.batch_norm(t, None, None, ga, be, True, 0.0, 1e-5)
+            return F.relu(y) if relu else y
+        if relu:                                     # push pre-activations at least 1e-3 away from zero
+            with torch.no_grad():
+                y0 = ref(x.double(), gamma.double(), beta.double(), relu=False)
+                beta_shift = torch.where(y0.abs().amin(dim=(0, 2, 3)) < 1e-3, torch.full_like(beta, 2e-3).double(), torch.zeros_like(beta).double())
+            beta = (beta.double() + beta_shift).float()
+        _grads_vs_fp64(lambda t, ga, be: HipBatchNormAct.apply(t, ga, be, None, None, True, 0.0, 1e-5, relu, sim), ref, [x, gamma, beta],
+                       seed=c, tol=5e-5)
+
+
 @pytest.mark.parametrize('kt', [1, 2])
 def test_causal_conv3d_as_time_shifted_2d_convolutions(sim, kt):
     from fiery_amd.train_graph import TrainGraph
