@@ -21,7 +21,7 @@ def _frame_value(f):
     return torch.full((2, 3, 3), float(f)) + torch.arange(18, dtype=torch.float32).view(2, 3, 3) / 100.0
 
 
-def _worker(rank, world, port, batch, S, results):
+def _worker(rank, world, port, batch, S, results, layout='auto', exchange='all_gather'):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
@@ -34,22 +34,26 @@ def _worker(rank, world, port, batch, S, results):
         def stack(bev, blo, bhi):
             return {'sum': bev.view(bhi - blo, S, -1).sum(dim=(1, 2)), 'range': (blo, bhi), 'bev': bev.clone()}
 
-        sharder = ShardedBevPath()
+        sharder = ShardedBevPath(layout=layout, exchange=exchange)
         out = sharder.run(batch, S, pool_frames, stack)
+        out_again = sharder.run(batch, S, pool_frames, stack)              # the exchange buffers are reused
+        assert (out is None) == (out_again is None) and (out is None or torch.equal(out['bev'], out_again['bev']))
+        del calls[len(calls) // 2:]
         # gather_blocks round trip with an uneven split
         n = 5
         lo, hi = block_range(n, world, rank)
         full = gather_blocks(torch.arange(lo, hi, dtype=torch.float32).view(-1, 1), n)
-        results[rank] = dict(layout=sharder.layout(batch), calls=calls, out=out, full=full)
+        moved = [sc.bytes_received for key, sc in sharder._exchange.items() if key[0] == 'a2a']
+        results[rank] = dict(layout=sharder.layout(batch), calls=calls, out=out, full=full, n_exchange=len(sharder._exchange), moved=moved)
     finally:
         dist.destroy_process_group()
 
 
-def _run(world, batch, S):
+def _run(world, batch, S, layout='auto', exchange='all_gather'):
     port = _free_port()
     with mp.Manager() as manager:
         results = manager.dict()
-        mp.spawn(_worker, args=(world, port, batch, S, results), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, batch, S, results, layout, exchange), nprocs=world, join=True)
         return dict(results)
 
 
@@ -85,8 +89,35 @@ def test_frame_sharding_all_gathers_the_bev_maps():
             assert res[r]['out']['range'] == (0, 1)
 
 
+@pytest.mark.parametrize('world,batch', [(2, 1), (3, 2), (3, 4), (2, 5), (3, 3)])
+def test_frame_sharding_with_the_all_to_all_exchange_moves_each_frame_to_its_owner_only(world, batch):
+    """`FrameScatter`: frames split over the ranks for lift-splat, one all-to-all-v, every sample's S frames arrive - in
+    order - at the one rank that owns the sample and nowhere else; surplus ranks (batch < world) pool and own nothing."""
+    from fiery_amd.parallel import sample_owner_ranges
+    S = 3
+    res = _run(world=world, batch=batch, S=S, layout='frames', exchange='all_to_all')
+    pooled = sorted(f for r in range(world) for lo, hi in res[r]['calls'] for f in range(lo, hi))
+    assert pooled == list(range(batch * S))                                      # every frame pooled exactly once
+    owners = sample_owner_ranges(batch, world)
+    covered = []
+    for r in range(world):
+        blo, bhi = owners[r]
+        if bhi == blo:
+            assert res[r]['out'] is None
+            continue
+        assert res[r]['out']['range'] == (blo, bhi)
+        want = torch.stack([_frame_value(f) for f in range(blo * S, bhi * S)])
+        assert torch.equal(res[r]['out']['bev'], want)                           # its samples' frames, in order, nothing else
+        covered.extend(range(blo, bhi))
+        assert res[r]['n_exchange'] == 1                                         # allocated once, reused by the second call
+        own = set(range(*block_range(batch * S, world, r)))
+        n_foreign = len([f for f in range(blo * S, bhi * S) if f not in own])
+        assert res[r]['moved'] == [n_foreign * 18 * 4]                           # bytes that crossed ranks: foreign frames only
+    assert covered == list(range(batch))
+
+
 # ---- the real entry point (`sharded_bev_forward`) on the CPU-simulated kernels, 2 ranks over gloo -------------------
-def _sim_worker(rank, world, port, batch, layout, results):
+def _sim_worker(rank, world, port, batch, layout, results, exchange='all_gather'):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
@@ -110,10 +141,11 @@ def _sim_worker(rank, world, port, batch, layout, results):
         lifted = lifted.view(batch, rf, n, 64, model.depth_channels, fh, fw)
         noise = torch.randn(batch, 1, 32, generator=torch.Generator().manual_seed(9))
         with torch.no_grad():
-            out, rng = sharded_bev_forward(model, K, E, ego, lifted=lifted, noise=noise, layout=layout)
-            out2, _ = sharded_bev_forward(model, K, E, ego, lifted=lifted, noise=noise, layout=layout)   # buffers reused
+            out, rng = sharded_bev_forward(model, K, E, ego, lifted=lifted, noise=noise, layout=layout, exchange=exchange)
+            out2, _ = sharded_bev_forward(model, K, E, ego, lifted=lifted, noise=noise, layout=layout, exchange=exchange)   # buffers reused
             whole = model.bev_forward(lifted, K, E, ego, None, noise)
-        results[rank] = dict(range=rng, out={k: v.clone() for k, v in out.items() if v is not None},
+        out, out2 = out or {}, out2 or {}                     # (a rank that owns no sample gets None)
+        results[rank] = dict(range=rng or (0, 0), out={k: v.clone() for k, v in out.items() if v is not None},
                              again={k: v.clone() for k, v in out2.items() if v is not None},
                              whole={k: v.clone() for k, v in whole.items() if v is not None},
                              n_exchange=len(model._sharder._exchange))
@@ -121,8 +153,9 @@ def _sim_worker(rank, world, port, batch, layout, results):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('batch,layout', [(2, 'batch'), (1, 'auto'), (3, 'frames')])
-def test_sharded_bev_forward_on_the_simulated_kernels(batch, layout):
+@pytest.mark.parametrize('batch,layout,exchange', [(2, 'batch', 'all_gather'), (1, 'auto', 'all_gather'), (3, 'frames', 'all_gather'),
+                                                   (3, 'frames', 'all_to_all'), (1, 'frames', 'all_to_all')])
+def test_sharded_bev_forward_on_the_simulated_kernels(batch, layout, exchange):
     """Every rank's share of `sharded_bev_forward` equals the same samples of the single-process pass - batch layout (no
     collective), frame layout (one all-gather through the preallocated exchange) and the small-batch latency mode."""
     from tests.sim.build_sim import build
@@ -131,7 +164,7 @@ def test_sharded_bev_forward_on_the_simulated_kernels(batch, layout):
     port = _free_port()
     with mp.Manager() as manager:
         results = manager.dict()
-        mp.spawn(_sim_worker, args=(world, port, batch, layout, results), nprocs=world, join=True)
+        mp.spawn(_sim_worker, args=(world, port, batch, layout, results, exchange), nprocs=world, join=True)
         res = dict(results)
     covered = set()
     for r in range(world):
