@@ -33,9 +33,10 @@ PEAK_HBM_GBS = 8000.0             # MI355X HBM3E spec bandwidth
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over
-    this bench command, folded by tools/pmc_traffic.py with the gfx950 correction); None when the summary is absent.
+    this bench command - baseline.yml, fp32, batch 3 - folded by tools/pmc_traffic.py with the gfx950 correction); None when
+    the summary is absent.  Callers report it for THAT workload only: any other configuration's line carries null.
     Counters cannot be collected from inside the timed process, so this is the one roofline field not measured live."""
-    for name in ('r2_pmc_traffic.json', 'r1_pmc_traffic.json'):
+    for name in ('r3_pmc_traffic.json', 'r2_pmc_traffic.json', 'r1_pmc_traffic.json'):
         try:
             return json.load(open(os.path.join(ROOT, 'profiles', name)))[kernel]['traffic_bytes']
         except (OSError, KeyError, ValueError):
@@ -51,6 +52,9 @@ def parse():
     ap.add_argument('--batch', type=int, default=3, help='samples per GPU (baseline.yml BATCHSIZE)')
     ap.add_argument('--config', default='baseline.yml')
     ap.add_argument('--cams', type=int, default=0, help='cameras per frame (0 = the preset\'s IMAGE.NAMES; lyft runs use 7)')
+    ap.add_argument('--exchange', choices=('all_gather', 'all_to_all'), default='all_to_all',
+                    help="frames layout: 'all_gather' moves every pooled frame to every rank, 'all_to_all' each frame to the one "
+                         'rank that owns its sample (fiery_amd.parallel.FrameScatter)')
     ap.add_argument('--layout', choices=('batch', 'frames'), default='batch',
                     help='batch: every rank owns whole samples, no collective.  frames: frames sharded for pooling, one '
                          'all-gather of the BEV maps, then batch-sharded (BASELINE.json configs[2])')
@@ -149,7 +153,7 @@ def main():
         lifted_d = torch.empty((B * world,) + tuple(lifted.shape[1:]), device=dev)
         assert block_range(B * world * rf, world, rank) == (rank * B * rf, (rank + 1) * B * rf)     # this rank pools its own samples' frames
         lifted_d[rank * B:(rank + 1) * B].copy_(lifted)
-        eager_step = lambda: sharded_bev_forward(model, K_d, E_d, ego_d, lifted=lifted_d, layout='frames')[0]
+        eager_step = lambda: sharded_bev_forward(model, K_d, E_d, ego_d, lifted=lifted_d, layout='frames', exchange=args.exchange)[0]
         graph_step = None                                  # the collective is enqueued by torch.distributed: eager launches
     elif args.fused:
         dl_d = dl.view(B, rf, n_cam, D, fh, fw).to(dev)
@@ -250,7 +254,7 @@ def main():
                     'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                     'by_precision': {k_: {'launches': n_, 'ms_per_step': round(t_ * 1e3, 3), 'tflops': round(f_ / t_ / 1e12, 2)}
                                      for k_, (t_, f_, n_) in by_prec.items()},
-                    'traffic': pmc_traffic('k_conv_igemm (all tile shapes)') if args.precision == 'f32' and args.config == 'baseline.yml' else None,
+                    'traffic': pmc_traffic('k_conv_igemm (all tile shapes)') if args.precision == 'f32' and args.config == 'baseline.yml' and n_cam == 6 and B == 3 else None,
                     'launches': n_dom, 'avg_launch_us': round(t_dom / n_dom * 1e6, 2),
                     'algorithmic_gflop_per_step': round(f_conv / 1e9, 1), 'kernel_ms_per_step': round(t_conv * 1e3, 3),
                     'measured': 'HIP events around every launch of one instrumented step after the timed region, whole '
@@ -267,7 +271,8 @@ def main():
             gbs = b_pool / t_pool / 1e9
             pooling = {'kernel': 'k_rank_columns + k_voxel_pool_compact (op boundary projection_to_birds_eye_view)', 'bound': 'hbm',
                        'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
-                       'traffic': pmc_traffic('k_voxel_pool'), 'algorithmic_mb_per_step': round(b_pool / 1e6, 1),
+                       'traffic': pmc_traffic('k_voxel_pool') if args.config == 'baseline.yml' and n_cam == 6 and B == 3 else None,
+                       'algorithmic_mb_per_step': round(b_pool / 1e6, 1),
                        'op_us_per_step': round(t_pool * 1e6, 1), 'kept_fraction': round(kept_frac, 4),
                        'bytes': '4*C*N_kept + 12*N + 4*C*X*Y per frame (SURVEY 8d), N_kept counted from the ranks the op left'}
 
@@ -308,7 +313,7 @@ def main():
                                    f'{nf} future frames, batch {B} per GPU, {"fp32" if args.precision == "f32" else "bf16 convolutions"}, '
                                    f'{"fused lift-splat from depth+features" if args.fused else "lifted features (n,C,D,h,w) resident in HBM"}',
                        'global_batch': B * world,
-                       'parallelism': (f'frames sharded x{world} for geometry + pooling, one all-gather of the pooled BEV maps '
+                       'parallelism': (f'frames sharded x{world} for geometry + pooling, one {"all-to-all-v (frames to their sample owners)" if args.exchange == "all_to_all" else "all-gather"} of the pooled BEV maps '
                                        f'({"RCCL" if use_dist else "local copy: 1 rank, no process group"}), then batch-sharded'
                                        if frames_layout else f'batch-sharded x{world}, no data-path collective'),
                        'launch': launch_mode + (', one stream per sample' if model.sample_streams else '')},

@@ -1,0 +1,50 @@
+#!/bin/bash
+# Round 3 evidence run at HEAD: GPU parity suite (ledger), smoke(), bench lines (fp32 headline, frames layout at one rank with both
+# exchanges, bf16 / pon / lyft-7), training-step timing, kernel traces in both launch modes, PMC traffic passes, MFMA counter pass.
+# Files are copied to profiles/r3_* afterwards.
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r3_final
+mkdir -p $O
+timeout 1500 python -m pytest tests -q -m gpu > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
+cp $R/gpurun_out/parity_errors.json $O/parity_errors.json 2>/dev/null
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
+FIERY_BENCH_DUMP=$O/launches.json timeout 600 python bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
+cut -c1-300 $O/bench.json
+timeout 300 python bench.py --steps 20 --warmup 3 --no-graph --no-cpu-baseline --no-from-images > $O/bench_batch_layout_eager.json 2>> $O/bench.err
+for ex in all_to_all all_gather; do
+  MASTER_ADDR=127.0.0.1 MASTER_PORT=29541 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 timeout 300 python bench.py --steps 20 --warmup 3 --layout frames --exchange $ex --no-cpu-baseline --no-from-images > $O/bench_frames_layout_${ex}_1rank.json 2>> $O/bench.err
+done
+grep -h -o '"value": [0-9.]*' $O/bench_batch_layout_eager.json $O/bench_frames_layout_*_1rank.json
+FIERY_BENCH_DUMP=$O/launches_bf16.json timeout 600 python bench.py --steps 20 --warmup 3 --precision bf16 --no-from-images --no-cpu-baseline > $O/bench_baseline_bf16.json 2>> $O/bench.err
+timeout 600 python bench.py --steps 10 --warmup 3 --precision bf16 --config literature/pon_setting.yml --no-from-images > $O/bench_pon_bf16.json 2>> $O/bench.err
+timeout 600 python bench.py --steps 10 --warmup 3 --precision bf16 --config lyft/baseline.yml --cams 7 --no-from-images > $O/bench_lyft7_bf16.json 2>> $O/bench.err
+grep -h -o '"value": [0-9.]*' $O/bench_baseline_bf16.json $O/bench_pon_bf16.json $O/bench_lyft7_bf16.json
+{
+  echo "# round 3 - one training step of the path (forward + backward + SGD step from the lifted features), baseline.yml, B = 2, tools/time_train_step.py"
+  timeout 600 python tools/time_train_step.py --batch 2 --steps 5 2>&1 | grep time_train_step
+  echo "# the same graph with PyTorch-ROCm operators for convolution / BatchNorm / upsampling (MIOpen, ATen)"
+  timeout 600 python tools/time_train_step.py --batch 2 --steps 5 --torch-conv 2>&1 | grep time_train_step
+} > $O/train_step.txt
+cat $O/train_step.txt | grep time_train
+cd /tmp
+for mode in one_stream sample_streams; do
+  extra=""; [ $mode = one_stream ] && extra="--no-sample-streams"
+  rm -rf /tmp/kt_$mode
+  timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/kt_$mode -o kt -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-from-images $extra > $O/kt_$mode.log 2>&1
+  db=$(find /tmp/kt_$mode -name "*.db" | head -1)
+  python $R/tools/rocprof_summary.py "$db" $O/kernel_stats_$mode.csv "round 3 ($mode): rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-from-images $extra"
+  [ $mode = one_stream ] && python $R/tools/rocprof_sequence.py "$db" copyBuffer > $O/copybuffer_neighbours.txt 2>&1
+done
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_$ctr
+  timeout 400 rocprofv3 --pmc $ctr --kernel-trace -d /tmp/pmc_$ctr -o pmc -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-from-images --no-graph --no-sample-streams > $O/pmc_$ctr.log 2>&1
+  python $R/tools/pmc_dump.py "/tmp/pmc_$ctr/**/*.db" > $O/pmc_$ctr.txt 2>&1
+done
+python $R/tools/pmc_traffic.py $O/pmc_FETCH_SIZE.txt $O/pmc_WRITE_SIZE.txt $O/pmc_traffic.json
+rm -rf /tmp/pmc_mfma
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU --kernel-trace -d /tmp/pmc_mfma -o pmc -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-from-images --no-graph --no-sample-streams > $O/pmc_mfma.log 2>&1
+python $R/tools/pmc_dump.py "/tmp/pmc_mfma/**/*.db" > $O/pmc_mfma.txt 2>&1
+python $R/tools/pmc_mfma.py $O/pmc_mfma.txt > $O/mfma_util.txt 2>&1; tail -8 $O/mfma_util.txt
+head -10 $O/kernel_stats_one_stream.csv
