@@ -178,7 +178,7 @@ def bench_conv(lib, reps):
             nwg = max(nwg, 1)
             clk = (f'\n      shader clock {mhz:6.0f} MHz; probe run {us_p:.1f} us; per sampled workgroup (wave 0): K loop {cyc / nwg:9.0f} cycles = '
                    f'load issue {pa / nwg:8.0f} + LDS reads/MFMA {pb / nwg:8.0f} + load wait/LDS store {pc / nwg:8.0f} + barrier {pd / nwg:8.0f}')
-        print(f'conv k{k} s{stride} {cin:3d}->{cout:3d} n={n:2d} {H}x{W}: {us:8.1f} us  {flops / us / 1e6:6.1f} TFLOP/s '
+        print(f'conv k{k} s{stride} {cin:3d}->{cout:3d} n={n:2d} {H}x{W} [tile {list(op._tile_m.values())}]: {us:8.1f} us  {flops / us / 1e6:6.1f} TFLOP/s '
               f'({flops / us / 1e6 / 157.3:.1%} of fp32 MFMA peak){clk}', flush=True)
 
 
