@@ -293,6 +293,64 @@ __global__ void k_upsample2x_bwd4(const float* __restrict__ g, int g_ld, int H, 
     *reinterpret_cast<float4*>(gx + ((static_cast<long long>(img) * H + y) * W + x) * gx_ld + c) = acc;
 }
 
+// Weight gradient of the depthwise convolution (training of the image trunk):
+//   dw[tap][c] += sum over images and output pixels of grad_out[img][y][x][c] * in[img][y s - pad_top + ky][x s - pad_left + kx][c]
+// A workgroup = 16 channel quads x 16 row walkers: thread (q, r) keeps the K*K float4 partial sums of its four channels and
+// walks output rows r, r + 16 gridDim.y ... of the (image, row) list; the sixteen walkers' sums of a tap meet in LDS and one
+// lane per channel quad adds them to dw with fp32 atomics (K*K*C atomics per workgroup: the order of arrival decides the
+// last bit, as for the dense weight gradient).  dw must be zero on entry.
+template <int K>
+__global__ __launch_bounds__(256) void k_depthwise_wgrad(const float* __restrict__ in, int in_ld, int H, int W, int C4,
+                                                         const float* __restrict__ g, int g_ld, int Ho, int Wo, int stride, int pad_top,
+                                                         int pad_left, long long n_rows, float* __restrict__ dw, int dw_ld) {
+    __shared__ float4 part[16][16];
+    const int q = threadIdx.x & 15, r = threadIdx.x >> 4;
+    const int c4 = blockIdx.x * 16 + q;
+    const bool live = c4 < C4;
+    const int c = c4 * 4;
+    float4 acc[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        for (long long row = static_cast<long long>(blockIdx.y) * 16 + r; row < n_rows; row += 16ll * gridDim.y) {
+            const int img = static_cast<int>(row / Ho), y = static_cast<int>(row - static_cast<long long>(img) * Ho);
+            const float* grow = g + (static_cast<long long>(img) * Ho + y) * Wo * g_ld + c;
+            const float* ximg = in + static_cast<long long>(img) * H * W * in_ld + c;
+            for (int x = 0; x < Wo; ++x) {
+                const float4 gv = *reinterpret_cast<const float4*>(grow + static_cast<long long>(x) * g_ld);
+#pragma unroll
+                for (int ky = 0; ky < K; ++ky) {
+                    const int iy = y * stride - pad_top + ky;
+                    if (iy < 0 || iy >= H) continue;
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx) {
+                        const int ix = x * stride - pad_left + kx;
+                        if (ix < 0 || ix >= W) continue;
+                        const float4 xv = *reinterpret_cast<const float4*>(ximg + (static_cast<long long>(iy) * W + ix) * in_ld);
+                        float4& a = acc[ky * K + kx];
+                        a.x = fmaf(gv.x, xv.x, a.x);  a.y = fmaf(gv.y, xv.y, a.y);  a.z = fmaf(gv.z, xv.z, a.z);  a.w = fmaf(gv.w, xv.w, a.w);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) {
+        part[r][q] = acc[t];
+        __syncthreads();
+        if (r == 0 && live) {
+            float4 sum = part[0][q];
+            for (int i = 1; i < 16; ++i) {
+                const float4 v = part[i][q];
+                sum.x += v.x;  sum.y += v.y;  sum.z += v.z;  sum.w += v.w;
+            }
+            float* d = dw + static_cast<long long>(t) * dw_ld + c;
+            atomicAdd(d, sum.x);  atomicAdd(d + 1, sum.y);  atomicAdd(d + 2, sum.z);  atomicAdd(d + 3, sum.w);
+        }
+        __syncthreads();
+    }
+}
+
 // Depthwise convolution (the image trunk's MBConv blocks), pixel-major: one thread = one output pixel x four channels.
 // w is tap-major [k*k][C] so that a tap's four weights are one 16-byte load next to the four activations they meet.
 // Zero padding is explicit (pad_top / pad_left before, whatever Hout / Wout imply after): the trunk's "static same"
@@ -718,7 +776,8 @@ extern "C" int fiery_depthwise_conv_nhwc(const float* in, int in_ld, int n_img, 
     FIERY_REQUIRE(in && w && out && n_img > 0 && H > 0 && W > 0 && C > 0, "depthwise_conv: bad argument");
     FIERY_REQUIRE(k > 0 && k <= 7 && (stride == 1 || stride == 2) && pad_top >= 0 && pad_left >= 0 && Hout > 0 && Wout > 0,
                   "depthwise_conv: bad kernel geometry");
-    FIERY_REQUIRE((Hout - 1) * stride - pad_top < H && (Wout - 1) * stride - pad_left < W, "depthwise_conv: output larger than the padded input");
+    // (a window may lie wholly in the padding - its output is the shift alone: the input gradient, computed with this same
+    // kernel on the zero-stuffed output gradient, has such rows when no window of the forward pass reached them)
     auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     FIERY_REQUIRE(C % 4 == 0 && in_ld % 4 == 0 && out_ld % 4 == 0 && w_ld % 4 == 0 && in_ld >= C && out_ld >= C && w_ld >= C &&
                   a16(in) && a16(out) && a16(w) && (!scale || a16(scale)) && (!shift || a16(shift)),
@@ -742,6 +801,32 @@ extern "C" int fiery_depthwise_conv_nhwc(const float* in, int in_ld, int n_img, 
     hipLaunchKernelGGL(k_depthwise4, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), in, in_ld, H, W, C / 4, w, w_ld,
                        k, stride, pad_top, pad_left, Hout, Wout, scale, shift, act, out, out_ld, total);
     return check_launch("depthwise_conv");
+}
+
+extern "C" int fiery_depthwise_conv_wgrad_nhwc(const float* in, int in_ld, int n_img, int H, int W, int C, const float* grad_out,
+                                               int g_ld, int Hout, int Wout, int k, int stride, int pad_top, int pad_left, float* dw,
+                                               int dw_ld, fiery_stream_t stream) {
+    FIERY_REQUIRE(in && grad_out && dw && n_img > 0 && H > 0 && W > 0 && C > 0 && Hout > 0 && Wout > 0, "depthwise_conv_wgrad: bad argument");
+    FIERY_REQUIRE((k == 1 || k == 3 || k == 5 || k == 7) && (stride == 1 || stride == 2) && pad_top >= 0 && pad_left >= 0,
+                  "depthwise_conv_wgrad: kernel sizes 1, 3, 5, 7 and strides 1, 2");
+    auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    FIERY_REQUIRE(C % 4 == 0 && in_ld % 4 == 0 && g_ld % 4 == 0 && in_ld >= C && g_ld >= C && dw_ld >= C && a16(in) && a16(grad_out),
+                  "depthwise_conv_wgrad: channels and leading dimensions must be multiples of 4, pointers 16-byte aligned");
+    const long long n_rows = static_cast<long long>(n_img) * Hout;
+    const int c_groups = ceil_div(C / 4, 16);
+    long long walkers = ceil_div(n_rows, 16);                            // workgroups along the rows: fill the chip, a few rows each
+    const long long want = 2048 / c_groups > 0 ? 2048 / c_groups : 1;
+    if (walkers > want) walkers = want;
+    const dim3 grid(static_cast<unsigned>(c_groups), static_cast<unsigned>(walkers));
+#define FIERY_DWW_LAUNCH(K_)                                                                                              \
+    hipLaunchKernelGGL((k_depthwise_wgrad<K_>), grid, dim3(256), 0, as_stream(stream), in, in_ld, H, W, C / 4, grad_out, g_ld, Hout, \
+                       Wout, stride, pad_top, pad_left, n_rows, dw, dw_ld)
+    if (k == 1) FIERY_DWW_LAUNCH(1);
+    else if (k == 3) FIERY_DWW_LAUNCH(3);
+    else if (k == 5) FIERY_DWW_LAUNCH(5);
+    else FIERY_DWW_LAUNCH(7);
+#undef FIERY_DWW_LAUNCH
+    return check_launch("depthwise_conv_wgrad");
 }
 
 extern "C" int fiery_instance_segmentation(const float* center, const float* offset, const uint8_t* foreground, int n_frames,

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libfiery_hip.so')
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -163,6 +163,8 @@ _SIGNATURES = {
     'fiery_upsample2x_bwd_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'fiery_depthwise_conv_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_int] * 6 +
                                   [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'fiery_depthwise_conv_wgrad_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_int] * 6 +
+                                        [C.c_void_p, C.c_int, C.c_void_p]),
     'fiery_instance_segmentation': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'fiery_se_gate': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -562,6 +564,13 @@ class Lib:
         self.check(self.dll.fiery_depthwise_conv_nhwc(_ptr(x), in_ld, n_img, h, w, c, _ptr(weights), w_ld, k, stride, pad_top,
                                                       pad_left, ho, wo, _ptr(scale), _ptr(shift), act, _ptr(out), out_ld,
                                                       _stream_of(out)))
+
+    def depthwise_conv_wgrad(self, x, in_ld, n_img, h, w, c, grad_out, g_ld, ho, wo, k, stride, pad_top, pad_left):
+        """-> dw [k*k][c] (tap-major, like the forward's weights)."""
+        dw = torch.zeros(k * k, c, dtype=torch.float32, device=x.device)
+        self.check(self.dll.fiery_depthwise_conv_wgrad_nhwc(_ptr(x), in_ld, n_img, h, w, c, _ptr(grad_out), g_ld, ho, wo, k, stride,
+                                                            pad_top, pad_left, _ptr(dw), c, _stream_of(dw)))
+        return dw
 
     def instance_segmentation(self, center, offset, foreground, conf_threshold=0.1, max_centers=100):
         """center (n, H, W) f32, offset (n, 2, H, W) f32, foreground (n, H, W) uint8 ->

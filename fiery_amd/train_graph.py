@@ -15,15 +15,20 @@ PyTorch autograd graph over pixel-major (channels-last) tensors in which
 * the element-wise half of the GRU cell is `HipGruReset` / `HipGruOut`, the decoder's x2 upsampling `HipUpsample2x` (gather
   backward), the (2, H, W) pyramid pooling per-frame plane means (`HipSpatialMean`) + a broadcast;
 * voxel pooling is `ops.VoxelPool` / `ops.LiftSplat` (HIP forward and backward);
+* the image trunk and the lift head upstream of the path (round 3): `lift_head` - dense convolutions on `HipConv2d` after the
+  trunk's explicit 'static same' padding, depthwise ones on `HipDepthwiseConv2d` (`fiery_depthwise_conv_nhwc` in both
+  directions, `fiery_depthwise_conv_wgrad_nhwc`), BatchNorm on `HipBatchNormAct`, the squeeze-and-excite means on
+  `HipSpatialMean` and its two dense layers as matrix products;
 * what is left on PyTorch-ROCm operators over the same memory: max-pool of the skip paths, the ego-warp (`grid_sample`),
-  concatenations, residual adds, the two small dense layers of the distributions - their backward comes from autograd - and
-  the image trunk upstream of the path.
+  swish / sigmoid gates, concatenations, residual adds, the small dense layers (matrix products) - their backward comes from
+  autograd.  No MIOpen convolution is left in the graph.
 
 `Fiery.forward` dispatches here when `model.training` is set; in training mode the latent sample is drawn from the FUTURE
 distribution (fiery.py:319-325), so `future_distribution_inputs` is required.  The weight holders of `fiery_amd.modules`
 are read in place: parameters receive `.grad` like those of any `nn.Module`.
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -125,6 +130,50 @@ class HipConv2d(torch.autograd.Function):
             w_t = weight.detach().float().transpose(0, 1).flip(2, 3).contiguous()
             gx = _launch_conv(lib, gs, w_t, 1, k - 1 - pad)
             gx = _padded_rows(gx[..., :c].permute(0, 3, 1, 2), c, gx.shape[-1])
+        return gx, gw, None, None, None
+
+
+class HipDepthwiseConv2d(torch.autograd.Function):
+    """Depthwise k x k convolution with explicit (asymmetric) zero padding - `MBConvBlock._depthwise_conv` of the image trunk
+    (efficientnet-pytorch, behind fiery/models/encoder.py:58-86): forward `fiery_depthwise_conv_nhwc` (no BatchNorm, no
+    activation), input gradient the same kernel on the output gradient (zero-stuffed for stride 2) with the taps mirrored and
+    padding k - 1 - pad, weight gradient `fiery_depthwise_conv_wgrad_nhwc`.  weight (C, 1, k, k); pads = (top, left, bottom,
+    right); C a multiple of 4 (every width of the trunk is)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, pads, lib):
+        n, c, h, w = x.shape
+        k = weight.shape[-1]
+        top, left, bottom, right = pads
+        ho, wo = (h + top + bottom - k) // stride + 1, (w + left + right - k) // stride + 1
+        xr = x.detach().float().permute(0, 2, 3, 1).contiguous()                  # (n, h, w, c)
+        taps = weight.detach().float().reshape(c, k * k).t().contiguous()        # tap-major [k*k][c]
+        out = torch.empty(n, ho, wo, c, dtype=torch.float32, device=x.device)
+        lib.depthwise_conv(xr, c, n, h, w, c, taps, c, k, stride, top, left, ho, wo, None, None, native.ACT_NONE, out, c)
+        ctx.save_for_backward(xr, taps)
+        ctx.meta = (n, c, h, w, k, stride, top, left, ho, wo, lib)
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xr, taps = ctx.saved_tensors
+        n, c, h, w, k, stride, top, left, ho, wo, lib = ctx.meta
+        g = gy.float().permute(0, 2, 3, 1).contiguous()                           # (n, ho, wo, c)
+        gx = gw = None
+        if ctx.needs_input_grad[1]:
+            dw = lib.depthwise_conv_wgrad(xr, c, n, h, w, c, g, c, ho, wo, k, stride, top, left)
+            gw = dw.t().reshape(c, 1, k, k)
+        if ctx.needs_input_grad[0]:
+            if stride == 1:
+                gs, hs, ws = g, ho, wo
+            else:                                                                  # zeros between the gradient's pixels
+                hs, ws = (ho - 1) * stride + 1, (wo - 1) * stride + 1
+                gs = g.new_zeros(n, hs, ws, c)
+                gs[:, ::stride, ::stride] = g
+            flipped = taps.flip(0).contiguous()                                    # tap (ky, kx) -> (k-1-ky, k-1-kx)
+            gx = torch.empty(n, h, w, c, dtype=torch.float32, device=gy.device)
+            lib.depthwise_conv(gs, c, n, hs, ws, c, flipped, c, k, 1, k - 1 - top, k - 1 - left, h, w, None, None, native.ACT_NONE, gx, c)
+            gx = gx.permute(0, 3, 1, 2)
         return gx, gw, None, None, None
 
 
@@ -329,6 +378,7 @@ class TrainGraph:
         self._conv = conv2d or HipConv2d.apply
         self._hip_ops = conv2d is None
         self.whole_plane_pooling_as_means = True      # False: avg_pool3d + interpolate, operator for operator as the reference
+        self.hip_trunk = os.environ.get('FIERY_HIP_TRUNK', '1') != '0'      # False: the image trunk + lift head as `Encoder.lift_head` (PyTorch-ROCm / MIOpen)
         # (with a substituted convolution the graph may run in fp64 / on the host: resampling then stays on torch too)
         self._upsample2x = (lambda x: HipUpsample2x.apply(x, self.lib)) if conv2d is None else (
             lambda x: F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False))
@@ -655,15 +705,93 @@ class TrainGraph:
                            cut(features))
         return self.bev_stack(bev, future_egomotion[:, :rf].contiguous(), future_distribution_inputs, noise)
 
+    # -- the step before the path: image trunk + lift head under autograd (round 3) -------------------------------------------
+    def _same_pad_conv(self, x, conv):
+        """A convolution of the trunk with its 'static same' padding (fixed at construction, asymmetric: right / bottom get the
+        odd pixel): dense ones on `HipConv2d` after an explicit pad, depthwise ones on `HipDepthwiseConv2d`."""
+        pad = getattr(conv, 'static_padding', None)
+        left, right, top, bottom = tuple(pad.padding) if isinstance(pad, torch.nn.ZeroPad2d) else (0, 0, 0, 0)
+        if conv.groups == 1:
+            if left or right or top or bottom:
+                x = F.pad(x, (left, right, top, bottom))
+            y = self._conv(x, conv.weight, conv.stride[0], 0, self.lib)
+        else:
+            assert conv.groups == conv.in_channels == conv.out_channels
+            if self._hip_ops:
+                y = HipDepthwiseConv2d.apply(x, conv.weight, conv.stride[0], (top, left, bottom, right), self.lib)
+            else:
+                y = F.conv2d(F.pad(x, (left, right, top, bottom)), conv.weight, None, conv.stride, 0, 1, conv.groups)
+        return y if conv.bias is None else y + conv.bias.view(1, -1, 1, 1)
+
+    def _mbconv(self, blk, inputs, drop_connect_rate):
+        """efficientnet-pytorch `MBConvBlock.forward` (the package's published block: expansion 1x1 + BN + swish, depthwise
+        k x k + BN + swish, squeeze-and-excite, projection 1x1 + BN, drop-connect + identity skip) on this graph's operators.
+        The two dense layers of the squeeze-and-excite act on 1x1 maps: matrix products, not convolutions (section 9c)."""
+        swish = lambda t: t * torch.sigmoid(t)
+        x = inputs
+        if blk.expand != 1:
+            x = swish(self.bn_act(self._same_pad_conv(x, blk._expand_conv), blk._bn0, relu=False))
+        x = swish(self.bn_act(self._same_pad_conv(x, blk._depthwise_conv), blk._bn1, relu=False))
+        gate = (HipSpatialMean.apply(x, self.lib) if self._hip_ops else x.mean(dim=(2, 3)))
+        gate = swish(F.linear(gate, blk._se_reduce.weight.flatten(1), blk._se_reduce.bias))
+        gate = F.linear(gate, blk._se_expand.weight.flatten(1), blk._se_expand.bias)
+        x = torch.sigmoid(gate)[:, :, None, None] * x
+        x = self.bn_act(self._same_pad_conv(x, blk._project_conv), blk._bn2, relu=False)
+        if blk.stride == 1 and blk.cin == blk.cout:
+            if drop_connect_rate and blk.training:
+                keep = 1.0 - drop_connect_rate
+                mask = torch.floor(keep + torch.rand(x.shape[0], 1, 1, 1, dtype=x.dtype, device=x.device))
+                x = x / keep * mask
+            x = x + inputs
+        return x
+
+    def trunk_endpoints(self, x):
+        """`Encoder.trunk_endpoints` (fiery/models/encoder.py:58-86) on this graph's operators: (deep, shallow) levels."""
+        enc = self.m.encoder
+        trunk = enc.backbone
+        endpoints = []
+        x = self.bn_act(self._same_pad_conv(x, trunk._conv_stem), trunk._bn0, relu=False)
+        x = x * torch.sigmoid(x)
+        previous = x
+        n_blocks = len(trunk._blocks)
+        from .encoder import _LAST_BLOCK_DS8
+        for idx, block in enumerate(trunk._blocks):
+            rate = trunk._global_params.drop_connect_rate
+            if rate:
+                rate *= float(idx) / n_blocks
+            x = self._mbconv(block, x, rate)
+            if previous.size(2) > x.size(2):
+                endpoints.append(previous)
+            previous = x
+            if enc.downsample == 8 and idx == _LAST_BLOCK_DS8[enc.version]:
+                break
+        endpoints.append(x)
+        return (endpoints[4], endpoints[3]) if enc.downsample == 16 else (endpoints[3], endpoints[2])
+
+    def lift_head(self, images):
+        """`Encoder.lift_head` (encoder.py:58-100) under autograd: -> (depth logits or None, context features)."""
+        enc = self.m.encoder
+        deep, shallow = self.trunk_endpoints(images)
+        x = torch.cat([shallow, self._upsample2x(deep)], dim=1)
+        conv = enc.upsampling_layer.conv
+        x = self.bn_act(self.conv2d(x, conv[0]), conv[1], relu=True)
+        x = self.bn_act(self.conv2d(x, conv[3]), conv[4], relu=True)
+        x = self.conv2d(x, enc.depth_layer)
+        if enc.use_depth_distribution:
+            return x[:, :enc.D], x[:, enc.D:(enc.D + enc.C)]
+        return None, x
+
     def forward(self, image, intrinsics, extrinsics, future_egomotion, future_distribution_inputs=None, noise=None):
-        """`Fiery.forward` (fiery.py:130-191) with autograd.  The image trunk and the lift head run as the torch statement
-        of their layers (`Encoder.lift_head`; upstream of the section-8 path), their two factors go into the fused
-        lift-splat kernel, then `bev_stack`."""
+        """`Fiery.forward` (fiery.py:130-191) with autograd.  The image trunk and the lift head run on this graph's operators
+        too (`lift_head`: every convolution - dense and depthwise -, BatchNorm, the plane means and the x2 upsampling on the
+        HIP kernels in both directions; round 3 - until then they were the torch statement on MIOpen).  Their two factors go
+        into the fused lift-splat kernel, then `bev_stack`."""
         m = self.m
         rf = m.receptive_field
         image = image[:, :rf].contiguous()
         b, s, n, c, h, w = image.shape
-        depth_logits, features = m.encoder.lift_head(image.view(b * s * n, c, h, w))
+        flat = image.view(b * s * n, c, h, w)
+        depth_logits, features = self.lift_head(flat) if self.hip_trunk else m.encoder.lift_head(flat)
         fh, fw = features.shape[-2:]
         feats = features.view(b, s, n, -1, fh, fw)
         if depth_logits is None:

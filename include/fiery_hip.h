@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FIERY_ABI_VERSION 16
+#define FIERY_ABI_VERSION 17
 
 #define FIERY_OK 0
 #define FIERY_EINVAL (-22)      /* bad argument (shape, alignment, null pointer) */
@@ -385,6 +385,15 @@ int fiery_maxpool2x2_nhwc(const float* in, int in_ld, int64_t in_img_stride /* f
 int fiery_depthwise_conv_nhwc(const float* in, int in_ld, int n_img, int H, int W, int C, const float* w, int w_ld,
                               int k, int stride, int pad_top, int pad_left, int Hout, int Wout, const float* scale,
                               const float* shift, int act, float* out, int out_ld, fiery_stream_t stream);
+
+/* Weight gradient of the depthwise convolution (training of the image trunk; what autograd computes for the weight of
+ * `MBConvBlock._depthwise_conv`): dw[tap][c] += sum over images and output pixels of grad_out . in at the tap; dw is tap-major
+ * [k*k][dw_ld >= C] like the forward's weights and must be ZERO on entry (partial sums arrive by fp32 atomics).  The input
+ * gradient needs no entry point of its own: it is fiery_depthwise_conv_nhwc on the output gradient (zero-stuffed for stride
+ * 2) with the taps mirrored and the padding k - 1 - pad (fiery_amd/train_graph.py:HipDepthwiseConv2d).  k in {1, 3, 5, 7}. */
+int fiery_depthwise_conv_wgrad_nhwc(const float* in, int in_ld, int n_img, int H, int W, int C, const float* grad_out, int g_ld,
+                                    int Hout, int Wout, int k, int stride, int pad_top, int pad_left, float* dw, int dw_ld,
+                                    fiery_stream_t stream);
 
 /* Squeeze-and-excite gate: gate[img][c] = sigmoid(w2[c][:] . swish(w1 . mean[img] + b1) + b2[c])
  * (efficientnet-pytorch `MBConvBlock._se_reduce` / `_se_expand`).  w1 [hidden][C], w2 [C][hidden]; C <= 1024,

@@ -76,6 +76,62 @@ def test_upsampling_plane_mean_and_strided_convolution_gradients_vs_fp64(sim):
         _grads_vs_fp64(lambda a, b: HipConv2d.apply(a, b, 2, pad, sim), lambda a, b: F.conv2d(a, b, None, 2, pad), [xx, ww], seed=cin + k)
 
 
+@pytest.mark.parametrize('c,k,stride,pads,hw', [(8, 3, 1, (1, 1, 1, 1), (7, 9)), (12, 3, 2, (0, 0, 1, 1), (9, 12)), (8, 5, 1, (2, 2, 2, 2), (6, 7)),
+                                                 (16, 5, 2, (1, 1, 2, 2), (11, 10)), (8, 5, 2, (2, 2, 2, 2), (8, 8)), (4, 3, 2, (0, 1, 1, 0), (5, 5))])
+def test_depthwise_convolution_all_gradients_vs_fp64(sim, c, k, stride, pads, hw):
+    """`HipDepthwiseConv2d` (the image trunk's MBConv depthwise layers, 'static same' padding - asymmetric): output, input
+    gradient (stride 2: zero-stuffed gradient, mirrored taps; rows no window reaches get zeros) and weight gradient
+    (`fiery_depthwise_conv_wgrad_nhwc`) against float64 autograd of pad + conv2d(groups = C)."""
+    from fiery_amd.train_graph import HipDepthwiseConv2d
+    g = torch.Generator().manual_seed(c * 7 + k + stride)
+    x = torch.randn(2, c, *hw, generator=g)
+    w = torch.randn(c, 1, k, k, generator=g) / k
+    top, left, bottom, right = pads
+    _grads_vs_fp64(lambda a, b: HipDepthwiseConv2d.apply(a, b, stride, pads, sim),
+                   lambda a, b: F.conv2d(F.pad(a, (left, right, top, bottom)), b, None, stride, 0, 1, c), [x, w], seed=k)
+
+
+def test_trunk_and_lift_head_on_the_training_graph_equal_the_torch_statement(sim):
+    """`TrainGraph.lift_head` - EfficientNet-b4 stem + blocks 0-21 (expansion, depthwise, squeeze-and-excite, projection,
+    drop-connect, skips), the x2 upsampling, the head's convolutions - on the HIP operators against `Encoder.lift_head`, the
+    torch statement of the same layers, both in train() mode from the same generator state: outputs, running statistics and
+    the gradient of every parameter of the encoder."""
+    from fiery_amd.config import get_preset_cfg
+    from fiery_amd.model import Fiery
+    from fiery_amd.train_graph import TrainGraph
+    cfg = get_preset_cfg('baseline.yml')
+    torch.manual_seed(0)
+    model = Fiery(cfg)
+    randomise_weights(model)
+    model._lib = sim
+    ref = Fiery(cfg)
+    ref.load_state_dict(model.state_dict())
+    model.train()
+    ref.train()
+    images = torch.randn(2, 3, 32, 64, generator=torch.Generator().manual_seed(1))
+    torch.manual_seed(5)
+    d_ref, f_ref = ref.encoder.lift_head(images)
+    torch.manual_seed(5)
+    d_got, f_got = TrainGraph(model, sim).lift_head(images)
+    assert _rel(d_got, d_ref) < 2e-4 and _rel(f_got, f_ref) < 2e-4, (_rel(d_got, d_ref), _rel(f_got, f_ref))
+    gen = torch.Generator().manual_seed(2)
+    gd, gf = torch.randn(d_ref.shape, generator=gen), torch.randn(f_ref.shape, generator=gen)
+    (d_ref * gd).sum().add((f_ref * gf).sum()).backward()
+    (d_got * gd).sum().add((f_got * gf).sum()).backward()
+    worst = 0.0
+    for (name, p), (_, q) in zip(model.encoder.named_parameters(), ref.encoder.named_parameters()):
+        assert p.grad is not None, name
+        # (the bias of a block's last BatchNorm feeds, through the skip chain, straight into the next batch-statistics
+        # BatchNorm: its true gradient is zero and both evaluations hold ~1e-4 of rounding noise there - hence the absolute term)
+        diff, scale = (p.grad - q.grad).norm().item(), q.grad.norm().item()
+        err = diff / max(scale, 1e-12)
+        worst = max(worst, min(err, diff / 1e-3))
+        assert diff <= 5e-3 * scale + 1e-3, (name, err, scale)
+    for (name, b), (_, c) in zip(model.encoder.named_buffers(), ref.encoder.named_buffers()):
+        assert torch.allclose(b.float(), c.float(), rtol=1e-4, atol=1e-5), name
+    assert worst > 0.0
+
+
 def test_batchnorm_act_all_gradients_vs_fp64(sim):
     """HipBatchNormAct in training mode with and without ReLU: y, dx, dgamma, dbeta (inputs kept away from the ReLU's kink: a
     gate within rounding of zero is the one thing fp32 and fp64 may legitimately disagree on)."""
@@ -354,6 +410,34 @@ def test_hip_conv2d_real_shapes_against_fp64(hip, cin, cout, k, stride, pad, hw)
                              (results['hip'][i] - results['torch32'][i]).abs().max().item(), scale, err_hip, err_t,
                              3 * err_t + 1e-5 * scale, 'reference = the fp32 operator of PyTorch-ROCm; bound is on the fp64 error')
         assert err_hip <= 3 * err_t + 1e-5 * scale, (what, err_hip, err_t, scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('c,k,stride,hw', [(144, 3, 2, (112, 240)), (192, 5, 2, (56, 120)), (336, 3, 1, (28, 60)), (960, 5, 1, (14, 30))])
+def test_depthwise_convolution_real_shapes_against_fp64(hip, c, k, stride, hw):
+    """`HipDepthwiseConv2d` at the image trunk's own layer shapes (EfficientNet-b4 at 224 x 480, six images) with the trunk's
+    'static same' padding: output, input gradient and weight gradient against float64 autograd on the host."""
+    from fiery_amd.train_graph import HipDepthwiseConv2d
+    from tests import parity_report
+    g = torch.Generator().manual_seed(c + k)
+    h, w = hw
+    pad_h = max((-(-h // stride) - 1) * stride + k - h, 0)
+    pad_w = max((-(-w // stride) - 1) * stride + k - w, 0)
+    pads = (pad_h // 2, pad_w // 2, pad_h - pad_h // 2, pad_w - pad_w // 2)            # top, left, bottom, right
+    x = torch.randn(6, c, h, w, generator=g)
+    wt = torch.randn(c, 1, k, k, generator=g) / k
+    xe, we = x.double().requires_grad_(), wt.double().requires_grad_()
+    ye = F.conv2d(F.pad(xe, (pads[1], pads[3], pads[0], pads[2])), we, None, stride, 0, 1, c)
+    gy = torch.randn(ye.shape, generator=g)
+    gxe, gwe = torch.autograd.grad(ye, (xe, we), gy.double())
+    xh, wh = x.cuda().requires_grad_(), wt.cuda().requires_grad_()
+    yh = HipDepthwiseConv2d.apply(xh, wh, stride, pads, hip)
+    gxh, gwh = torch.autograd.grad(yh, (xh, wh), gy.cuda())
+    for what, got, want in (('y', yh, ye), ('dx', gxh, gxe), ('dw', gwh, gwe)):
+        err = (got.detach().double().cpu() - want.detach()).abs().max().item()
+        scale = want.abs().max().item()
+        parity_report.record(f'hip_depthwise[{c} k{k} s{stride} {h}x{w}]', what, err, scale, err, None, 2e-5 * scale)
+        assert err <= 2e-5 * scale, (what, err, scale)
 
 
 @pytest.mark.gpu
