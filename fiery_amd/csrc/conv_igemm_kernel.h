@@ -37,6 +37,12 @@ namespace fiery {
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;    // k per LDS stage (4 units of 8 input channels)
+// A fourth workgroup per CU for the scalar-addressed 128 x 32 kernel (A/B switch): measured in round 3 after its registers
+// were trimmed to fit - faster for the plain and the chained launch (106 vs 112, 131 vs 138 us), slower for the Bottleneck
+// tail with its third stage, the launch the step issues most (162 vs 153 us): off.
+#ifndef FIERY_TAIL_FOUR_PER_CU
+#define FIERY_TAIL_FOUR_PER_CU 0
+#endif
 struct SrcP {
     const float* ptr;
     int ld, units;
@@ -125,12 +131,9 @@ __device__ __forceinline__ int fast_div(int g, unsigned m, int s) {
 // Workgroups of one tile shape that fit a CU, as its LDS (two A stages + two W stages) allows, capped where the tile's
 // registers would not follow: one wavefront per workgroup and SIMD, so this is also the waves-per-SIMD target that the
 // register allocation is held to (without it the compiler aims one notch too high for the 64 x 128 tile and spills).
-constexpr int conv_waves_per_simd(int bm, int bn) {
+constexpr int conv_waves_per_simd(int bm, int bn, bool aligned = false) {
     const int by_lds = 163840 / ((2 * bm * BK + 2 * BK * bn) * 4);
-    // (a fourth workgroup per CU for the scalar-addressed 128 x 32 kernel - it fits 128 registers since its set-up lost
-    // the 64-bit tap masks - was measured in round 3: the chained epilogue then spills 35 registers and the Bottleneck
-    // tail got slower, 177 vs 163 us)
-    const int cap = (bm == 64 && bn == 64) ? 4 : 3;
+    const int cap = ((bm == 64 && bn == 64) || (FIERY_TAIL_FOUR_PER_CU && bm == 128 && bn == 32 && aligned)) ? 4 : 3;
     return by_lds < cap ? by_lds : cap;
 }
 
@@ -140,7 +143,7 @@ constexpr int conv_waves_per_simd(int bm, int bn) {
 // v_cvt_pk_bf16_f32) on the way from LDS to the matrix core, the weights arrive already rounded and packed
 // [k / 8][cout][k % 8], products are exact and accumulate in fp32.  Scalar-addressed loop only.
 template <int BM, int BN, bool CLK = false, int PRIO = 0, bool SMALLCIN = false, bool ALIGNED = false, bool BF16 = false>
-__global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm(ConvP p) {
+__global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK && !BF16)) void k_conv_igemm(ConvP p) {
     static_assert(!BF16 || (ALIGNED && !SMALLCIN && !CLK), "the bf16 form exists for the scalar-addressed loop");
     unsigned long long clk_entry = 0;
     if constexpr (CLK) clk_entry = clock64();
@@ -759,18 +762,18 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
                 // are not known to be distinct, so loads written next to their stores stay behind the previous store).
                 const int c4 = tid & 15, prow0 = tid >> 4;
                 const int co = c4 * 4;
-                float4 resid[8];
-                long long out_off[8];                              // < 0: the row does not exist / the chunk is not stored
+                float4 resid[8];                                    // the residual rows, later the finished rows themselves
+                int out_off[8];                                    // floats from p.out.ptr (< 2^31: host check); < 0: not stored
                 {
                     int gp = pix0 + prow0;
                     int o = fast_div(gp, p.mg_hw, p.sh_hw), ppi = gp - o * HWout;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const bool live = gp < M && co < p.cout_store;
-                        const long long pp = ppi;
-                        out_off[i] = live ? o * p.out.istride + pp * p.out.ld + co : -1;
+                        out_off[i] = live ? static_cast<int>(o * p.out.istride + static_cast<long long>(ppi) * p.out.ld + co) : -1;
                         resid[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (live && p.res.ptr) resid[i] = *reinterpret_cast<const float4*>(p.res.ptr + o * p.res.istride + pp * p.res.ld + co);
+                        if (live && p.res.ptr)
+                            resid[i] = *reinterpret_cast<const float4*>(p.res.ptr + o * p.res.istride + static_cast<long long>(ppi) * p.res.ld + co);
                         gp += 16;
                         ppi += 16;
                         while (ppi >= HWout) {
@@ -781,8 +784,6 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
                 }
                 const float4 w3_lo = reinterpret_cast<const float4*>(p.heads.w)[tid];
                 const float4 w3_hi = reinterpret_cast<const float4*>(p.heads.w)[tid + 256];
-                const float4 sc2 = *reinterpret_cast<const float4*>(p.scale2 + co);
-                const float4 sh2 = *reinterpret_cast<const float4*>(p.shift2 + co);
                 __syncthreads();                                   // everyone is done reading the h and W tiles
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
@@ -792,31 +793,34 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN)) void k_conv_igemm
                         smem[pl * 64 + nt * 32 + m] = acc2[nt][r];
                     }
                 __syncthreads();
-                float4 y[8];
+                {
+                    const float4 sc2 = *reinterpret_cast<const float4*>(p.scale2 + co);
+                    const float4 sh2 = *reinterpret_cast<const float4*>(p.shift2 + co);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int pl = prow0 + 16 * i;
-                    float4 v = *reinterpret_cast<const float4*>(&smem[pl * 64 + co]);
-                    v.x = fmaf(v.x, sc2.x, sh2.x);  v.y = fmaf(v.y, sc2.y, sh2.y);  v.z = fmaf(v.z, sc2.z, sh2.z);  v.w = fmaf(v.w, sc2.w, sh2.w);
-                    if (p.act2 == FIERY_ACT_RELU) {
-                        v.x = fmaxf(v.x, 0.f);  v.y = fmaxf(v.y, 0.f);  v.z = fmaxf(v.z, 0.f);  v.w = fmaxf(v.w, 0.f);
-                    } else if (p.act2 == FIERY_ACT_SIGMOID) {
-                        v.x = sigmoidf(v.x);  v.y = sigmoidf(v.y);  v.z = sigmoidf(v.z);  v.w = sigmoidf(v.w);
+                    for (int i = 0; i < 8; ++i) {
+                        const int pl = prow0 + 16 * i;
+                        float4 v = *reinterpret_cast<const float4*>(&smem[pl * 64 + co]);
+                        v.x = fmaf(v.x, sc2.x, sh2.x);  v.y = fmaf(v.y, sc2.y, sh2.y);  v.z = fmaf(v.z, sc2.z, sh2.z);  v.w = fmaf(v.w, sc2.w, sh2.w);
+                        if (p.act2 == FIERY_ACT_RELU) {
+                            v.x = fmaxf(v.x, 0.f);  v.y = fmaxf(v.y, 0.f);  v.z = fmaxf(v.z, 0.f);  v.w = fmaxf(v.w, 0.f);
+                        } else if (p.act2 == FIERY_ACT_SIGMOID) {
+                            v.x = sigmoidf(v.x);  v.y = sigmoidf(v.y);  v.z = sigmoidf(v.z);  v.w = sigmoidf(v.w);
+                        }
+                        if (out_off[i] >= 0) {
+                            v.x += resid[i].x;  v.y += resid[i].y;  v.z += resid[i].z;  v.w += resid[i].w;
+                            *reinterpret_cast<float4*>(p.out.ptr + out_off[i]) = v;
+                        } else {
+                            v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+                        resid[i] = v;
                     }
-                    if (out_off[i] >= 0) {
-                        v.x += resid[i].x;  v.y += resid[i].y;  v.z += resid[i].z;  v.w += resid[i].w;
-                        *reinterpret_cast<float4*>(p.out.ptr + out_off[i]) = v;
-                    } else {
-                        v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
-                    y[i] = v;
                 }
                 __syncthreads();                                   // the staged tile has been read by everyone
                 // the finished tile as the A operand of the third GEMM: two K stages of [pixel][32 k], slot-swizzled
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int pl = prow0 + 16 * i;
-                    *reinterpret_cast<float4*>(&As[c4 >> 3][pl * BK + (((c4 & 7) ^ ((pl >> 1) & 7)) << 2)]) = y[i];
+                    *reinterpret_cast<float4*>(&As[c4 >> 3][pl * BK + (((c4 & 7) ^ ((pl >> 1) & 7)) << 2)]) = resid[i];
                 }
                 {
                     float* bdst = &Bs[0][0];                        // 2 stages x 32 x 32 floats = the packed 64 x 32 weights

@@ -174,7 +174,22 @@ template <int kRows>
 __global__ void k_rank_columns(const float* __restrict__ geometry, int n_fc, int D, int H, int W, GridParams p,
                                int tile_vox, int* __restrict__ rank, int4* __restrict__ coldesc,
                                int* __restrict__ colmask, int compact, unsigned char* __restrict__ occ, int n_cam,
-                               long long occ_stride, unsigned* __restrict__ live) {
+                               long long occ_stride, unsigned* __restrict__ live, float* __restrict__ clear,
+                               long long clear_floats) {
+    // `clear` (optional): output planes the pooling kernel will ADD to (the units of its last, partly filled round are cut
+    // into parts that meet in the output through atomics): zeroed here, a few 16-byte stores per thread, instead of by a
+    // memset dispatch of its own between the two kernels (round 3: ~6 us of the op with its launch gap).
+    if (clear) {
+        const long long n_thr = static_cast<long long>(gridDim.x) * blockDim.x;
+        const long long me = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+        if ((reinterpret_cast<uintptr_t>(clear) & 15) == 0) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (long long i = me * 4; i + 3 < clear_floats; i += n_thr * 4) *reinterpret_cast<float4*>(clear + i) = z;
+            if (me < (clear_floats & 3)) clear[(clear_floats & ~3ll) + me] = 0.f;
+        } else {
+            for (long long i = me; i < clear_floats; i += n_thr) clear[i] = 0.f;
+        }
+    }
     // `live` (optional, pre-zeroed): one word per (frame, camera, depth) slice, bit q set when quad q (columns 4q .. 4q+3)
     // has a point inside the grid - the compact-plane kernel does not request the rows of the others.  A workgroup's
     // columns span a few slices: their bits meet in LDS first, then one global atomic per slice and workgroup.
@@ -1572,6 +1587,32 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
     unsigned* live = reinterpret_cast<unsigned*>(ws + pl.off_live);
     if (compact_form && hipMemsetAsync(occ, 0, pl.off_occupied - pl.off_occ, s) != hipSuccess)     // occupancy bytes + live masks
         return fail(FIERY_ELAUNCH, "voxel_pool: cannot clear the occupancy map");
+    // compact form: the units of the last, partly filled round are cut into parts (below); the planes they add to are zeroed
+    // by the prepass
+    int cp_tail = 0, cp_parts = 1;
+    if (compact_form) {
+        const int n_units = C * frames;
+        int dev = 0, n_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+            n_cu = 256;
+        const int slots = n_cu * (cp_threads == 512 ? 2 : 1);
+        cp_tail = n_units % slots;
+        if (cp_tail > 0) cp_parts = slots / cp_tail;
+        if (n_units < slots) cp_parts = 1;                               // a single, partly filled round: nothing to balance
+        if (const char* forced = getenv("FIERY_POOL_TAIL_PARTS")) {                           // tuning / tests
+            cp_parts = atoi(forced);
+            if (cp_parts > 1 && cp_tail == 0) cp_tail = n_units < 3 ? n_units : 3;
+        }
+        if (cp_parts > 4 && !getenv("FIERY_POOL_TAIL_PARTS")) cp_parts = 4;   // (a part pays the bit-map set-up again: 4 measured best)
+        if (cp_parts > 8) cp_parts = 8;
+        if (cp_parts < 2) {
+            cp_parts = 1;
+            cp_tail = 0;
+        }
+    }
+    float* clear_ptr = cp_tail > 0 ? out + static_cast<long long>(C * frames - cp_tail) * pl.n_vox : nullptr;
+    const long long clear_floats = static_cast<long long>(cp_tail) * pl.n_vox;
     {
         int rows = 8;                                                    // rows of a column in flight in the prepass
         if (const char* forced = getenv("FIERY_POOL_PREPASS_ROWS")) rows = atoi(forced);         // tuning
@@ -1581,42 +1622,20 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
         const dim3 pgrid(ceil_div(n_cols_all, 256));
         if (rows >= 28)
             hipLaunchKernelGGL((k_rank_columns<28>), pgrid, dim3(256), 0, s, geometry, frames * n_cam, D, H, W, to_params(*grid),
-                               pl.tile, rank, coldesc, mask_arg, desc_mode, occ_arg, n_cam, occ_stride, compact_form ? live : nullptr);
+                               pl.tile, rank, coldesc, mask_arg, desc_mode, occ_arg, n_cam, occ_stride, compact_form ? live : nullptr, clear_ptr, clear_floats);
         else if (rows >= 14)
             hipLaunchKernelGGL((k_rank_columns<14>), pgrid, dim3(256), 0, s, geometry, frames * n_cam, D, H, W, to_params(*grid),
-                               pl.tile, rank, coldesc, mask_arg, desc_mode, occ_arg, n_cam, occ_stride, compact_form ? live : nullptr);
+                               pl.tile, rank, coldesc, mask_arg, desc_mode, occ_arg, n_cam, occ_stride, compact_form ? live : nullptr, clear_ptr, clear_floats);
         else
             hipLaunchKernelGGL((k_rank_columns<8>), pgrid, dim3(256), 0, s, geometry, frames * n_cam, D, H, W, to_params(*grid),
-                               pl.tile, rank, coldesc, mask_arg, desc_mode, occ_arg, n_cam, occ_stride, compact_form ? live : nullptr);
+                               pl.tile, rank, coldesc, mask_arg, desc_mode, occ_arg, n_cam, occ_stride, compact_form ? live : nullptr, clear_ptr, clear_floats);
     }
     rc = check_launch("rank_columns");
     if (rc) return rc;
     if (compact_form) {
-        // workgroups that fit the chip at once; the units of the last, partly filled round are cut into parts
-        const int n_units = C * frames;
-        int dev = 0, n_cu = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-            n_cu = 256;
         const int per_cu = cp_threads == 512 ? 2 : 1;
-        const int slots = n_cu * per_cu;
-        int tail = n_units % slots, parts = 1;
-        if (tail > 0) parts = slots / tail;
-        if (n_units < slots) parts = 1;                                  // a single, partly filled round: nothing to balance
-        if (const char* forced = getenv("FIERY_POOL_TAIL_PARTS")) {                           // tuning / tests
-            parts = atoi(forced);
-            if (parts > 1 && tail == 0) tail = n_units < 3 ? n_units : 3;
-        }
-        if (parts > 4 && !getenv("FIERY_POOL_TAIL_PARTS")) parts = 4;     // (a part pays the bit-map set-up again: 4 measured best)
-        if (parts > 8) parts = 8;
-        if (parts < 2) {
-            parts = 1;
-            tail = 0;
-        }
-        const int tail_first = n_units - tail;
-        if (tail > 0 && hipMemsetAsync(out + static_cast<long long>(tail_first) * pl.n_vox, 0,
-                                       static_cast<size_t>(tail) * pl.n_vox * sizeof(float), s) != hipSuccess)
-            return fail(FIERY_ELAUNCH, "voxel_pool: cannot clear the tail planes");
+        const int tail = cp_tail, parts = cp_parts;
+        const int tail_first = C * frames - tail;                        // (their planes were zeroed by the prepass)
         if (getenv("FIERY_POOL_VERBOSE"))
             fprintf(stderr, "voxel_pool compact: %d cells, %zu B LDS, %d threads, %d per CU, %d units + %d x %d parts\n", cp_cells,
                     cp_lds, cp_threads, per_cu, tail_first, tail, parts);
