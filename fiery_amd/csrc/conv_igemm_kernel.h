@@ -601,7 +601,9 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
         const int c4 = tid % c4n, prow0 = tid / c4n;
         const int co = cout0 + c4 * 4;
         const int half = p.cout_pad >> 1;
-        if (p.epi != FIERY_EPI_GRU_GATES && co >= p.cout_store) return;    // padding couts are never stored
+        const bool gates_upper = p.epi == FIERY_EPI_GRU_GATES && co >= half;
+        // padding couts are never stored (gate epilogue: cout_store channels of EACH half - the two gates)
+        if ((gates_upper ? co - half : co) >= p.cout_store) return;
         const float4 sc = *reinterpret_cast<const float4*>(scale + co);
         const float4 sh = *reinterpret_cast<const float4*>(shift + co);
         int gp = pix0 + prow0;
@@ -615,7 +617,6 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
             float4 a, b, bias;
         };
         const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        const bool gates_upper = p.epi == FIERY_EPI_GRU_GATES && co >= half;
         auto fetch = [&](int o_, int ppi_, bool live) {
             RowOperands r{zero4, zero4, zero4};
             if (!live) return r;
@@ -1040,6 +1041,7 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
                 p.out.ptr[o * p.out.istride + pp * p.out.ld + co] = v;
             } else if (p.epi == FIERY_EPI_GRU_GATES) {
                 const float g = sigmoidf(v);
+                if ((co < half ? co : co - half) >= p.cout_store) continue;
                 if (co < half) {
                     p.out.ptr[o * p.out.istride + pp * p.out.ld + co] = g;                       // update gate
                 } else {

@@ -337,6 +337,59 @@ def _border_tables(w_x):
     return torch.cat(rows, 0).float().contiguous()
 
 
+class _Bottleneck3D:
+    """fiery/layers/temporal.py:120-164 as it is used between two temporal blocks (temporal_model.py:33-36: kernel
+    (1, 3, 3)): the frames are independent, so the block runs on the frames that are still alive as a batch of images."""
+
+    def __init__(self, eng, mod):
+        lib, dev = eng.lib, eng.device
+        L = mod.layers
+        down, conv, up = L.conv_down_project, L.conv, L.conv_up_project
+        kt, kh, kw = conv.conv.weight.shape[2:]
+        if kt != 1:
+            raise NotImplementedError('Bottleneck3D with a temporal kernel extent is not part of any TemporalModel of the reference')
+        cin, mid, cout = down.conv.weight.shape[1], down.conv.weight.shape[0], up.conv.weight.shape[0]
+        self.cin, self.mid, self.cout = cin, mid, cout
+        sc, sh = fold_bn(down.norm, mid)
+        self.conv1 = ConvOp(lib, _w2d(down.conv).reshape(mid, cin, 1, 1), identity_chan_map(cin), (round_up(cin, 8) // 8, 0),
+                            sc, sh, dev, act=RELU)
+        w3 = conv.conv.weight.detach().float().reshape(mid, mid, kh, kw)
+        s2, b2 = fold_bn(conv.norm, mid)
+        s3, b3 = fold_bn(up.norm, cout)
+        w_up = _w2d(up.conv).reshape(cout, mid, 1, 1)
+        pad = ((kh - 1) // 2, (kw - 1) // 2)
+        self.fused_tail = self.conv2 = self.conv3 = None
+        if mid <= 32 and cout <= 64:
+            self.fused_tail = ConvOp(lib, w3, identity_chan_map(mid), (round_up(mid, 8) // 8, 0), s2, b2, dev, pad=pad,
+                                     act=RELU).chain_pointwise(w_up, s3, b3, RELU)
+        else:
+            self.conv2 = ConvOp(lib, w3, identity_chan_map(mid), (round_up(mid, 8) // 8, 0), s2, b2, dev, pad=pad, act=RELU)
+            self.conv3 = ConvOp(lib, w_up, identity_chan_map(mid), (round_up(mid, 8) // 8, 0), s3, b3, dev, act=RELU)
+        self.skip = None
+        if mod.projection is not None:
+            sc, sh = fold_bn(mod.projection[1], cout)
+            self.skip = ConvOp(lib, _w2d(mod.projection[0]).reshape(cout, cin, 1, 1), identity_chan_map(cin),
+                               (round_up(cin, 8) // 8, 0), sc, sh, dev)
+
+    def run(self, eng, x, tag, out=None):
+        n, H, W = x.n_img, x.H, x.W
+        if out is None:
+            out = eng.buf(tag + 'O', n, H, W, self.cout)
+        t1 = eng.buf(tag + 't1', n, H, W, self.mid)
+        self.conv1([x], t1)
+        res = x
+        if self.skip is not None:
+            res = eng.buf(tag + 'skip', n, H, W, self.cout)
+            self.skip([x], res)
+        if self.fused_tail is not None:
+            self.fused_tail([t1], out, res=res)
+        else:
+            t2 = eng.buf(tag + 't2', n, H, W, self.mid)
+            self.conv2([t1], t2)
+            self.conv3([t2], out, res=res)
+        return out
+
+
 class _Gru:
     """fiery/layers/temporal.py:10-62: update|reset as one N=2h GEMM, gate arithmetic in the epilogues.
 
@@ -347,10 +400,17 @@ class _Gru:
     def __init__(self, eng, g, const_x=False):
         lib, dev = eng.lib, eng.device
         cx, ch = g.input_size, g.hidden_size
-        assert ch % 16 == 0, 'hidden size must be a multiple of 16 for the fused gate GEMM'
         self.cx, self.ch = cx, ch
-        wg = torch.cat([g.conv_update.weight.detach(), g.conv_reset.weight.detach()], 0)
-        bg = torch.cat([g.conv_update.bias.detach(), g.conv_reset.bias.detach()], 0).float().cpu() + g.gru_bias_init
+        # each gate's rows start on a multiple of 16, so that the two halves of the padded GEMM are the two gates
+        # (hidden sizes such as 70 = 64 + the six ego-pose channels of an identity temporal model)
+        hp = round_up(ch, 16)
+
+        def halves(update, reset):
+            z = update.new_zeros((hp - ch,) + tuple(update.shape[1:]))
+            return torch.cat([update, z, reset, z], 0)
+        wg = halves(g.conv_update.weight.detach().float().cpu(), g.conv_reset.weight.detach().float().cpu())
+        bg = halves(g.conv_update.bias.detach().float().cpu() + g.gru_bias_init,
+                    g.conv_reset.bias.detach().float().cpu() + g.gru_bias_init)
         wt = g.conv_state_tilde.conv.weight.detach()
         sc, sh = fold_bn(g.conv_state_tilde.norm, ch)
         self.const_x = bool(const_x) and tuple(wg.shape[2:]) == (3, 3) and (2 * ch) % 32 == 0 and ch % 32 == 0
@@ -362,8 +422,8 @@ class _Gru:
         else:
             cxp = round_up(cx, 8)
             cmap = identity_chan_map(cx) + identity_chan_map(ch, offset=cxp)
-            units = (cxp // 8, ch // 8)
-        self.gates = ConvOp(lib, wg, cmap, units, torch.ones(2 * ch), bg, dev, epi=native.EPI_GRU_GATES)
+            units = (cxp // 8, round_up(ch, 8) // 8)
+        self.gates = ConvOp(lib, wg, cmap, units, torch.ones(2 * hp), bg, dev, epi=native.EPI_GRU_GATES)
         self.tilde = ConvOp(lib, wt, cmap, units, sc, sh, dev, act=RELU, epi=native.EPI_GRU_OUT)
 
 
@@ -400,15 +460,17 @@ class BevEngine:
     def _build(self):
         m, dev, lib = self.m, self.device, self.lib
         # temporal model
+        # temporal model: (kind, op, index of the temporal block) per stage of fiery/models/temporal_model.py:19-38
         self.temporal = []
         self.temporal_identity = not hasattr(m.temporal_model, 'model')
         if not self.temporal_identity:
-            if any(not hasattr(s, 'convolution_paths') for s in m.temporal_model.model):
-                raise NotImplementedError('MODEL.TEMPORAL_MODEL.INBETWEEN_LAYERS > 0 is not supported by the HIP engine yet')
-            for j, tb in enumerate(m.temporal_model.model):
-                self.temporal.append(_TemporalBlock(self, tb, 6 if (self.egopose and j == 0) else 0))
-        elif self.egopose:
-            raise NotImplementedError('identity temporal model with INPUT_EGOPOSE is not supported by the HIP engine yet')
+            j = 0
+            for stage in m.temporal_model.model:
+                if hasattr(stage, 'convolution_paths'):
+                    self.temporal.append(('block', _TemporalBlock(self, stage, 6 if (self.egopose and j == 0) else 0), j))
+                    j += 1
+                else:                                     # INBETWEEN_LAYERS > 0: Bottleneck3D (1, 3, 3) after block j - 1
+                    self.temporal.append(('spatial', _Bottleneck3D(self, stage), j))
         state_c = m.future_pred_in_channels
         self.state_c = state_c
         # distributions
@@ -464,8 +526,14 @@ class BevEngine:
         if d.predict_future_flow:
             heads.append(('instance_flow', d.instance_future_head))
         self.head_names = [n for n, _ in heads]
-        wh = torch.cat([h[0].weight.detach() for _, h in heads], 0)
-        scs, shs = zip(*[fold_bn(h[1], cin) for _, h in heads])
+        # every head's hidden channels start on a multiple of 8 of the combined GEMM's outputs (cin is 64 in every shipped
+        # configuration; 70 with an identity temporal model that carries the ego-pose channels)
+        cp = round_up(cin, 8)
+
+        def rows(t):
+            return torch.cat([t.detach().float().cpu(), t.new_zeros((cp - cin,) + tuple(t.shape[1:])).float().cpu()], 0)
+        wh = torch.cat([rows(h[0].weight) for _, h in heads], 0)
+        scs, shs = zip(*[[rows(v) for v in fold_bn(h[1], cin)] for _, h in heads])
         self.heads_conv = ConvOp(lib, wh, identity_chan_map(cin), (round_up(cin, 8) // 8, 0), torch.cat(scs), torch.cat(shs),
                                  dev, act=RELU)
         self.heads_final = []
@@ -473,7 +541,7 @@ class BevEngine:
             n_out = h[3].out_channels
             self.heads_final.append(dict(name=name, w=_w2d(h[3]).contiguous().to(dev),
                                          b=h[3].bias.detach().float().contiguous().to(dev), n_out=n_out,
-                                         sigmoid=len(h) > 4, c_off=i * cin))
+                                         sigmoid=len(h) > 4, c_off=i * cp))
         # With 64 hidden channels per head (the reference's shared_out_channels) the final 1x1s ride in the 3x3 GEMM's
         # epilogue: the (images, 200, 200, 256) hidden tensor is never written.
         n_rows = sum(hd['n_out'] for hd in self.heads_final)
@@ -712,7 +780,8 @@ class BevEngine:
         ego = future_egomotion.float().contiguous()
         theta_in = theta
         # -- ego-warp + layout change ---------------------------------------------------------------
-        x0 = self.buf('x0', B * S, H, W, C)
+        # (identity temporal model + INPUT_EGOPOSE: the state is the warped frame with the ego-pose channels behind it)
+        x0 = self.buf('x0', B * S, H, W, C + (6 if (self.temporal_identity and self.egopose) else 0))
         theta = self.vec('warp_theta', B * S, 6)
         ego_in = self.vec('ego_in', B * S, 6).view(B, S, 6) if self.egopose else None          # fiery.py:152-154
         lib.warp_params(ego, self.extent, theta=theta.view(B, S, 6), ego_shifted=ego_in)
@@ -728,15 +797,27 @@ class BevEngine:
             present_slot = dec_in.images(0, B, step=self.nf + 1)
         # -- temporal model --------------------------------------------------------------------------
         if self.temporal_identity:
+            # fiery/models/temporal_model.py:55-62: the last frame, ego-pose channels included when INPUT_EGOPOSE is set
+            # (fiery.py:147-154: frame t carries future_egomotion[t - 1], frame 0 zeros)
             present = x0.images(S - 1, B, step=S) if S > 1 else x0
-            if present_slot is not None:                  # (no shipped configuration: identity temporal model + future prediction)
+            if self.egopose:
+                rows = ego_in[:, S - 1].contiguous()
+                lib.broadcast(rows, 6, B, H * W, 6, present.slice(C, 8), present.ld, present.img_stride)
+            if present_slot is None and S > 1:            # the decoder reads its input as a dense batch of images
+                present_slot = self.buf('present_dense', B, H, W, self.state_c)
+            if present_slot is not None:                  # (no shipped configuration: identity temporal model over several frames)
                 present_slot.nhwc().copy_(present.nhwc())
                 present = present_slot
         else:
             x = x0
-            last = len(self.temporal) - 1
-            for j, blk in enumerate(self.temporal):
-                x = blk.run(self, x, j, ego_in, B, S, f't{j}', out=present_slot if (j == last and S - j - 1 == 1) else None)
+            n_stages = len(self.temporal)
+            for i, (kind, op, j) in enumerate(self.temporal):
+                final = i == n_stages - 1
+                if kind == 'block':
+                    x = op.run(self, x, j, ego_in, B, S, f't{j}',
+                               out=present_slot if (final and S - j - 1 == 1) else None)
+                else:
+                    x = op.run(self, x, f's{i}', out=present_slot if (final and x.n_img == B) else None)
             present = x                                   # (B images) = the last frame
         # -- distributions ---------------------------------------------------------------------------
         if self.nf > 0:

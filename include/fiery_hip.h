@@ -241,7 +241,8 @@ typedef struct {
     int32_t res_before_act;
     fiery_nhwc res;                    /* residual, ptr NULL = none (const in practice)                */
     fiery_nhwc out;
-    int32_t cout_store;                /* channels written to out (<= cout_pad)                         */
+    int32_t cout_store;                /* channels written to out (<= cout_pad); FIERY_EPI_GRU_GATES: channels of EACH
+                                        * half of the result (the update gate to out, (1 - reset) * state to out2)     */
     fiery_nhwc out2;                   /* second destination (GRU modes), ptr NULL = none               */
     fiery_nhwc aux0, aux1;             /* GRU operands                                                   */
     /* Optional chained 1x1 convolution on the result tile (the Bottleneck's up-projection,

@@ -138,3 +138,88 @@ def load_reference():
     ns.Fiery = ns.fiery_model.Fiery
     _REF = ns
     return ns
+
+
+class ScipyQuaternion:
+    """Stand-in for `pyquaternion.Quaternion` (absent offline) on top of scipy's `Rotation` - the three members the
+    reference's dataset code touches (fiery/data.py:173-200, fiery/utils/geometry.py:63), written independently of
+    `fiery_amd/poses.py`, which restates pyquaternion's own formulas.  (w, x, y, z) order, like the package."""
+
+    def __init__(self, array=None, scalar=None, vector=None):
+        import numpy as np
+        if array is None:
+            array = [scalar] + list(vector)
+        self.q = np.asarray(array, dtype=np.float64)
+
+    def _rotation(self):
+        from scipy.spatial.transform import Rotation
+        w, x, y, z = self.q
+        return Rotation.from_quat([x, y, z, w])              # scipy: scalar last; normalises
+
+    @property
+    def rotation_matrix(self):
+        return self._rotation().as_matrix()
+
+    @property
+    def inverse(self):
+        import numpy as np
+        w, x, y, z = self.q
+        return ScipyQuaternion(np.array([w, -x, -y, -z]) / float(np.dot(self.q, self.q)))
+
+    @property
+    def yaw_pitch_roll(self):
+        # the package documents R = R_x(roll) R_y(pitch) R_z(yaw): scipy's extrinsic z-y-x sequence
+        return tuple(self._rotation().as_euler('zyx'))
+
+
+_REF_DATA = None
+
+
+def load_reference_data():
+    """`fiery.data` of the reference, importable offline: cv2, the two dataset SDKs and torchvision's image transforms are
+    replaced by minimal stand-ins (none of them is reached by `get_input_data` / `get_future_egomotion` except the
+    transforms, whose documented semantics are two lines), `Quaternion` by `ScipyQuaternion`."""
+    global _REF_DATA
+    if _REF_DATA is not None:
+        return _REF_DATA
+    ns = load_reference()
+    import importlib
+    import numpy as np
+    import torch
+    for name in ('cv2', 'nuscenes', 'nuscenes.nuscenes', 'nuscenes.utils', 'nuscenes.utils.splits', 'nuscenes.utils.data_classes',
+                 'lyft_dataset_sdk', 'lyft_dataset_sdk.lyftdataset'):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules['nuscenes.nuscenes'].NuScenes = type('NuScenes', (), {})
+    sys.modules['nuscenes.utils.splits'].create_splits_scenes = lambda: {}
+    sys.modules['nuscenes.utils.data_classes'].Box = type('Box', (), {})
+    sys.modules['lyft_dataset_sdk.lyftdataset'].LyftDataset = type('LyftDataset', (), {})
+    transforms = sys.modules['torchvision.transforms']
+
+    class ToTensor:                       # PIL (H, W, C) uint8 -> (C, H, W) float in [0, 1]
+        def __call__(self, img):
+            return torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float().div(255)
+
+    class Compose:
+        def __init__(self, steps):
+            self.steps = steps
+
+        def __call__(self, x):
+            for step in self.steps:
+                x = step(x)
+            return x
+
+    def normalize_call(self, x):          # torchvision.transforms.Normalize: (x - mean) / std per channel
+        mean = torch.as_tensor(self.mean, dtype=x.dtype).view(-1, 1, 1)
+        std = torch.as_tensor(self.std, dtype=x.dtype).view(-1, 1, 1)
+        return (x - mean) / std
+
+    transforms.ToTensor, transforms.Compose = ToTensor, Compose
+    transforms.Normalize.forward = normalize_call
+    sys.modules['torchvision'].transforms = transforms
+    data = importlib.import_module('fiery.data')
+    data.Quaternion = ScipyQuaternion
+    ns.geometry.Quaternion = ScipyQuaternion
+    ns.data = data
+    _REF_DATA = ns
+    return ns

@@ -72,6 +72,32 @@ def test_static_single_frame_setting(sim):
     assert 'present_mu' not in got and got['instance_flow'] is None
 
 
+@pytest.mark.parametrize('inbetween,extra', [(1, 0), (2, 0), (1, 6)])
+def test_spatial_layers_between_the_temporal_blocks(sim, inbetween, extra):
+    """MODEL.TEMPORAL_MODEL.INBETWEEN_LAYERS > 0: Bottleneck3D (1, 3, 3) after every temporal block
+    (fiery/models/temporal_model.py:33-36, layers/temporal.py:120-164) - with EXTRA_IN_CHANNELS the second block widens and
+    its Bottleneck3D has 35 bottleneck channels (the unchained three-launch form)."""
+    cfg = tiny_cfg('baseline.yml', bev=8, **{'MODEL.TEMPORAL_MODEL.INBETWEEN_LAYERS': inbetween,
+                                             'MODEL.TEMPORAL_MODEL.EXTRA_IN_CHANNELS': extra,
+                                             'MODEL.FUTURE_PRED.N_GRU_BLOCKS': 1, 'MODEL.FUTURE_PRED.N_RES_LAYERS': 1,
+                                             'N_FUTURE_FRAMES': 1})
+    noise = torch.randn(1, 1, 32, generator=torch.Generator().manual_seed(3))
+    model, got, want, sd, _ = _run(cfg, sim, noise=noise)
+    _compare(got, want, KEYS)
+
+
+@pytest.mark.parametrize('n_future', [0, 2])
+def test_identity_temporal_model_with_ego_pose_channels(sim, n_future):
+    """TemporalModelIdentity with INPUT_EGOPOSE (fiery/models/temporal_model.py:55-62, fiery.py:147-154): the state is the
+    last warped frame with the six ego-motion values of the step before it as constant channels."""
+    over = {'MODEL.TEMPORAL_MODEL.NAME': 'identity', 'MODEL.TEMPORAL_MODEL.INPUT_EGOPOSE': True, 'N_FUTURE_FRAMES': n_future,
+            'MODEL.FUTURE_PRED.N_GRU_BLOCKS': 1, 'MODEL.FUTURE_PRED.N_RES_LAYERS': 1}
+    cfg = tiny_cfg('baseline.yml', bev=8, **over)
+    model, got, want, sd, _ = _run(cfg, sim, B=2)
+    keys = KEYS if n_future else ('segmentation', 'instance_center', 'instance_offset', 'instance_flow')
+    _compare(got, want, keys)
+
+
 def test_future_distribution_with_labels(sim):
     """evaluate.py passes the future labels in eval mode: the future distribution must be evaluated too
     (reference: evaluate.py:55-59, fiery.py:310-314)."""

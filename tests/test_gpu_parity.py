@@ -597,6 +597,33 @@ def test_other_reference_configs_against_the_live_oracle(hip, preset, n_cam):
     _check_against_oracle(host, want, f'live:{preset} n_cam={n}, host matrices + transforms', exact)
 
 
+@pytest.mark.parametrize('overrides', [
+    {'MODEL.TEMPORAL_MODEL.INBETWEEN_LAYERS': 1},
+    {'MODEL.TEMPORAL_MODEL.INBETWEEN_LAYERS': 1, 'MODEL.TEMPORAL_MODEL.EXTRA_IN_CHANNELS': 6},
+    {'MODEL.TEMPORAL_MODEL.NAME': 'identity', 'MODEL.TEMPORAL_MODEL.INPUT_EGOPOSE': True},
+], ids=['inbetween', 'inbetween_wider', 'identity_egopose'])
+def test_temporal_model_branches_no_yaml_uses_against_the_live_oracle(hip, overrides):
+    """`INBETWEEN_LAYERS > 0` (Bottleneck3D between the temporal blocks, temporal_model.py:33-36), `EXTRA_IN_CHANNELS`, and the
+    identity temporal model with ego-pose channels (a 70-channel state through the GRUs and the decoder), on baseline.yml's
+    200 x 200 grid with two cameras and a shortened future: every output element against the oracle."""
+    opts = []
+    for k, v in {**overrides, 'N_FUTURE_FRAMES': 2, 'MODEL.FUTURE_PRED.N_GRU_BLOCKS': 2, 'MODEL.FUTURE_PRED.N_RES_LAYERS': 2}.items():
+        opts += [k, str(v)]
+    cfg = get_preset_cfg('baseline.yml', opts)
+    model, sd = _model(cfg)
+    n, rf, D = 2, model.receptive_field, model.depth_channels
+    fh, fw = cfg.IMAGE.FINAL_DIM[0] // 8, cfg.IMAGE.FINAL_DIM[1] // 8
+    C = cfg.MODEL.ENCODER.OUT_CHANNELS
+    _, K, E, ego = make_inputs(2, rf + model.n_future, n, with_image=False, seed=5)
+    _, _, lifted = make_lifted_features(2 * rf * n, C, D, (fh, fw), seed=6)
+    lifted = lifted.view(2, rf, n, C, D, fh, fw)
+    with torch.no_grad():
+        want = bev_stack.bev_hot_path(sd, cfg, lifted, K, E, ego)
+        exact = bev_stack.bev_hot_path_exact(sd, cfg, lifted, K, E, ego)
+        got = _host_modes(model).bev_forward(lifted.to(DEV), K.to(DEV), E.to(DEV), ego.to(DEV))
+    _check_against_oracle(got, want, 'live:baseline.yml + ' + ','.join(f'{k.split(".")[-1]}={v}' for k, v in overrides.items()), exact)
+
+
 # ------------------------------------------------------------------------------------------------------
 # ego-warp in isolation (row a7): cumulative_warp_features, utils/geometry.py:225-253
 # ------------------------------------------------------------------------------------------------------

@@ -267,6 +267,17 @@ def as_close_to_exact_as_fp32_torch(hip, torch32, exact, test='train_step'):
                          2e-2, 'against the fp64 graph; yardstick = all-torch fp32 graph')
     parity_report.record(test, f'gradients: worst ({worst[2][-48:]}); {len(flipped)} past 2 %', worst[0], 1.0, worst[0], worst[1], 0.5)
     assert median <= 2e-2 and worst[0] <= 0.5 and len(flipped) <= len(rows) // 10, (median, worst, len(flipped))
+    # The 1 % question, per tensor: where fp32 arithmetic itself allows it - the all-torch fp32 graph is within 0.5 % of the
+    # fp64 one - the kernels' gradient is within 1 % (a flipped gate may again take a tenth of the tensors out); the tensors
+    # past 1 % are listed with the torch figure beside them, which is what says whether conditioning or a kernel is the cause.
+    past = sorted((r for r in rows if r[0] > 1e-2), reverse=True)
+    conditioned = [r for r in rows if r[1] <= 5e-3]
+    unexplained = [r for r in conditioned if r[0] > 1e-2]
+    parity_report.record(test, f'gradients: {len(rows) - len(past)} of {len(rows)} tensors within 1 % of fp64; of the {len(past)} past it '
+                         f'{sum(1 for r in past if r[1] > 5e-3)} have the torch fp32 graph past 0.5 % too', len(past) / len(rows), 1.0,
+                         past[0][0] if past else 0.0, past[0][1] if past else 0.0, 1e-2,
+                         'past 1 %: ' + '; '.join(f'{r[2][-40:]} {r[0]:.3f} (torch {r[1]:.3f})' for r in past[:6]))
+    assert len(unexplained) <= len(rows) // 10, unexplained[:8]
     return len(g_e)
 
 
