@@ -131,19 +131,35 @@ __device__ __forceinline__ int fast_div(int g, unsigned m, int s) {
 // Workgroups of one tile shape that fit a CU, as its LDS (two A stages + two W stages) allows, capped where the tile's
 // registers would not follow: one wavefront per workgroup and SIMD, so this is also the waves-per-SIMD target that the
 // register allocation is held to (without it the compiler aims one notch too high for the 64 x 128 tile and spills).
-constexpr int conv_waves_per_simd(int bm, int bn, bool aligned = false) {
-    const int by_lds = 163840 / ((2 * bm * BK + 2 * BK * bn) * 4);
-    const int cap = ((bm == 64 && bn == 64) || (FIERY_TAIL_FOUR_PER_CU && bm == 128 && bn == 32 && aligned)) ? 4 : 3;
+constexpr int conv_smem_floats(int bm, int bn, bool bf16) {
+    const int full = 2 * bm * BK + 2 * BK * bn;
+    if (!bf16 || (bm == 128 && bn == 32)) return full;
+    const int stages = full / 2;
+    const int epilogue = bm * bn + (bm == 64 && bn == 128 ? 256 : 0);       // staging tile (+ the decoder heads' 1x1 rows)
+    return stages > epilogue ? stages : epilogue;
+}
+#ifndef FIERY_BF16_WAVES
+#define FIERY_BF16_WAVES 4        // waves per SIMD the bf16 form's register allocation is held to (128 registers)
+#endif
+constexpr int conv_waves_per_simd(int bm, int bn, bool aligned = false, bool bf16 = false) {
+    const int by_lds = 163840 / (conv_smem_floats(bm, bn, bf16) * 4);
+    int cap = ((bm == 64 && bn == 64) || (FIERY_TAIL_FOUR_PER_CU && bm == 128 && bn == 32 && aligned)) ? 4 : 3;
+    if (bf16 && !(bm == 128 && bn == 32)) cap = FIERY_BF16_WAVES;         // (128 x 32: its chained epilogue needs 150)
     return by_lds < cap ? by_lds : cap;
 }
 
 // BF16: the matrix cores run v_mfma_f32_32x32x16_bf16 - sixteen k per instruction instead of two, an eighth of the
-// matrix-pipe time per stage.  Activations stay fp32 in HBM and in LDS (the gather, the LDS image of the A tile and
-// every epilogue are the fp32 kernel's); a lane rounds its eight k of an A row to bf16 (round to nearest even,
-// v_cvt_pk_bf16_f32) on the way from LDS to the matrix core, the weights arrive already rounded and packed
-// [k / 8][cout][k % 8], products are exact and accumulate in fp32.  Scalar-addressed loop only.
+// matrix-pipe time per stage.  Activations stay fp32 in HBM (the gather and every epilogue are the fp32 kernel's); a
+// thread rounds the four k it gathered to bf16 (round to nearest even, v_cvt_pk_bf16_f32) as it writes them to LDS,
+// so the A tile there is [pixel][32 k] bf16 - 64-byte rows of four 16-byte slots, slot s of row r stored at
+// s ^ ((r >> 2) & 3) (the 16 lanes of a ds_read_b128 group then touch 16 different slots of the 256-byte bank row) -
+// and a lane's operand of an MFMA is ONE 16-byte read.  (Until round 3 the tile stayed fp32 in LDS and was rounded at
+// operand-read time: twice the LDS bytes written, twice the reads, and every value converted once per wavefront that
+// used it - with bf16's short MFMAs the loop was bound by LDS traffic, 3 KB per MFMA against the 1 KB per MFMA the LDS
+// can deliver at full matrix rate.)  The weights arrive already rounded and packed [k / 8][cout][k % 8]; products are
+// exact and accumulate in fp32.  Scalar-addressed loop only.
 template <int BM, int BN, bool CLK = false, int PRIO = 0, bool SMALLCIN = false, bool ALIGNED = false, bool BF16 = false>
-__global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK && !BF16)) void k_conv_igemm(ConvP p) {
+__global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK && !BF16, BF16)) void k_conv_igemm(ConvP p) {
     static_assert(!BF16 || (ALIGNED && !SMALLCIN && !CLK), "the bf16 form exists for the scalar-addressed loop");
     unsigned long long clk_entry = 0;
     if constexpr (CLK) clk_entry = clock64();
@@ -164,11 +180,19 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
     constexpr int W_BYTES = BF16 ? 2 : 4;                      // bytes per packed weight
     constexpr int BLOADS = BF16 ? (BN >= 64 ? BN / 64 : 1) : (BK * BN / 4) / 256;      // 16-byte W loads per thread and stage
 
-    // one LDS block: two A stages, two W stages; the epilogue reuses it as a BM x BN staging tile
-    __shared__ __attribute__((aligned(16))) float smem[2 * BM * BK + 2 * BK * BN];
-    float (*As)[BM * BK] = reinterpret_cast<float (*)[BM * BK]>(smem);
+    // one LDS block: two A stages, two W stages; the epilogue reuses it as a BM x BN staging tile.  The bf16 form's stages
+    // are half the size (both operands are bf16 there), so its block is as large as the epilogue needs and no larger - the
+    // 128 x 32 tile excepted, whose chained epilogue lays fp32 operand tiles over the stages.
+    constexpr bool HALF_STAGES = BF16 && !(BM == 128 && BN == 32);
+    constexpr int A_STAGE = HALF_STAGES ? BM * (BK / 2) : BM * BK;        // floats between the two A stages
+    constexpr int W_STAGE = HALF_STAGES ? BK * BN / 2 : BK * BN;
+    constexpr int W_BASE = 2 * A_STAGE;
+    constexpr int SMEM_FLOATS = conv_smem_floats(BM, BN, BF16);
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    float (*As)[BM * BK] = reinterpret_cast<float (*)[BM * BK]>(smem);                       // (chained epilogue: fp32 stages)
     float (*Bs)[BK * BN] = reinterpret_cast<float (*)[BK * BN]>(smem + 2 * BM * BK);
-    static_assert(BM * BN <= 2 * BM * BK + 2 * BK * BN, "staging tile must fit");
+    static_assert(W_BASE + 2 * W_STAGE <= SMEM_FLOATS && BM * BN + (BM == 64 && BN == 128 ? 256 : 0) <= SMEM_FLOATS,
+                  "stages, staging tile and the heads' 1x1 rows must fit");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
@@ -428,29 +452,31 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
     };
     // LDS addresses: thread constants (floats from smem) + compile-time offsets
     const int a_st = prow * BK + ((f4 ^ ((prow >> 1) & 7)) << 2);                     // + 32 j BK + buf BM BK
-    const int b_st = 2 * BM * BK + tid * 4;                                            // + 1024 k + buf BK BN
+    const int b_st = W_BASE + tid * 4;                                                 // + 1024 k + buf W_STAGE
     const int a_row = wm * (32 * MT) + m;
     int a_rd[4];                                                                       // + 32 t BK + buf BM BK
 #pragma unroll
     for (int q = 0; q < 4; ++q) a_rd[q] = a_row * BK + (((2 * q + hi) ^ ((a_row >> 1) & 7)) << 2);
-    const int b_rd = 2 * BM * BK + (hi * BN + wn * (32 * NT) + m) * 4;                 // + (2 q BN + 32 nt) 4 + buf BK BN
-    // bf16: a lane's eight k of MFMA kh (k = 16 kh + 8 hi ..) are the two 16-byte slots 4 kh + 2 hi, + 1 of its A row
-    int a_rd16[2][2];
+    const int b_rd = W_BASE + (hi * BN + wn * (32 * NT) + m) * 4;                      // + (2 q BN + 32 nt) 4 + buf W_STAGE
+    // bf16: a lane's eight k of MFMA kh (k = 16 kh + 8 hi ..) are slot 2 kh + hi of its row of the bf16 image
+    int a_rd16[2];
 #pragma unroll
-    for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) a_rd16[kh][e] = a_row * BK + (((4 * kh + 2 * hi + e) ^ ((a_row >> 1) & 7)) << 2);
+    for (int kh = 0; kh < 2; ++kh) a_rd16[kh] = a_row * 16 + (((2 * kh + hi) ^ ((a_row >> 2) & 3)) << 2);     // + 32 t 16 + buf A_STAGE
+    // bf16 image of the A tile: 16 floats' worth of bytes per row; this thread's four k are half of slot f4 >> 1
+    const int a_st16 = prow * 16 + (((f4 >> 1) ^ ((prow >> 2) & 3)) << 2) + (f4 & 1) * 2;     // + 32 j 16 + buf A_STAGE
     auto store_a = [&](int buf, int j) {
-        *reinterpret_cast<float4*>(&smem[a_st + 32 * j * BK + buf * BM * BK]) = j == 0 ? areg0 : j == 1 ? areg1 : j == 2 ? areg2 : areg3;
+        const float4 v = j == 0 ? areg0 : j == 1 ? areg1 : j == 2 ? areg2 : areg3;
+        if constexpr (BF16) *reinterpret_cast<uint2*>(&smem[a_st16 + 32 * j * 16 + buf * A_STAGE]) = pack_bf16x4(v);
+        else *reinterpret_cast<float4*>(&smem[a_st + 32 * j * BK + buf * A_STAGE]) = v;
     };
     auto store_b = [&](int buf, int k) {
-        *reinterpret_cast<float4*>(&smem[b_st + 1024 * k + buf * BK * BN]) = k == 0 ? breg0 : k == 1 ? breg1 : k == 2 ? breg2 : breg3;
+        *reinterpret_cast<float4*>(&smem[b_st + 1024 * k + buf * W_STAGE]) = k == 0 ? breg0 : k == 1 ? breg1 : k == 2 ? breg2 : breg3;
     };
     auto lds_a = [&](int buf, int q, int t) {
-        return *reinterpret_cast<const float4*>(&smem[a_rd[q] + 32 * t * BK + buf * BM * BK]);
+        return *reinterpret_cast<const float4*>(&smem[a_rd[q] + 32 * t * BK + buf * A_STAGE]);
     };
     auto lds_b = [&](int buf, int q, int nt) {
-        return *reinterpret_cast<const float4*>(&smem[b_rd + (2 * q * BN + 32 * nt) * 4 + buf * BK * BN]);
+        return *reinterpret_cast<const float4*>(&smem[b_rd + (2 * q * BN + 32 * nt) * 4 + buf * W_STAGE]);
     };
     // piece i of a stage's side work, i = 0 .. N_PIECES-1; the stage running out of `buf` fills the other buffer
     auto side_piece = [&](int buf, int i) {
@@ -491,20 +517,16 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
     auto stage_body = [&](auto buf_c) {
         constexpr int buf = decltype(buf_c)::value;
         if constexpr (BF16) {
-            // two MFMAs of sixteen k per 32 x 32 block and stage; the W image is [k / 8][cout][k % 8] bf16, so a lane's
-            // operand is one 16-byte read; its A operand is two 16-byte reads of fp32 and four packed conversions
+            // two MFMAs of sixteen k per 32 x 32 block and stage; the W image is [k / 8][cout][k % 8] bf16 and the A image
+            // [pixel][k] bf16, so each operand of a lane is one 16-byte read
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh) {
                 bf16x8 a8[MT], b8[NT];
 #pragma unroll
-                for (int t = 0; t < MT; ++t) {
-                    const float4 lo = *reinterpret_cast<const float4*>(&smem[a_rd16[kh][0] + 32 * t * BK + buf * BM * BK]);
-                    const float4 hi4 = *reinterpret_cast<const float4*>(&smem[a_rd16[kh][1] + 32 * t * BK + buf * BM * BK]);
-                    a8[t] = pack_bf16x8(lo, hi4);
-                }
+                for (int t = 0; t < MT; ++t) a8[t] = load_bf16x8(&smem[a_rd16[kh] + 32 * t * 16 + buf * A_STAGE]);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    b8[nt] = load_bf16x8(&smem[2 * BM * BK + buf * BK * BN + ((2 * kh + hi) * BN + wn * (32 * NT) + nt * 32 + m) * 4]);
+                    b8[nt] = load_bf16x8(&smem[W_BASE + buf * W_STAGE + ((2 * kh + hi) * BN + wn * (32 * NT) + nt * 32 + m) * 4]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)

@@ -71,6 +71,15 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(float4 lo, float4 hi) {
     return v;
 }
 __device__ __forceinline__ bf16x8 load_bf16x8(const float* p) { return *reinterpret_cast<const bf16x8*>(p); }
+// four fp32 -> four bf16 (two v_cvt_pk_bf16_f32), as the eight bytes they occupy in memory
+__device__ __forceinline__ uint2 pack_bf16x4(float4 v) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    bf16x4 h;
+    h[0] = static_cast<__bf16>(v.x);  h[1] = static_cast<__bf16>(v.y);  h[2] = static_cast<__bf16>(v.z);  h[3] = static_cast<__bf16>(v.w);
+    uint2 r;
+    __builtin_memcpy(&r, &h, 8);
+    return r;
+}
 // D(32 x 32) += A(32 x 16) . B(16 x 32): lane l holds A[l & 31][8 (l >> 5) + j], B[8 (l >> 5) + j][l & 31], j < 8
 __device__ __forceinline__ fiery_v16f mfma_bf16_32x32x16(bf16x8 a, bf16x8 b, fiery_v16f c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);

@@ -44,6 +44,12 @@ inline bf16x8 pack_bf16x8(float4 lo, float4 hi) {
     return {{bf16_bits(lo.x), bf16_bits(lo.y), bf16_bits(lo.z), bf16_bits(lo.w), bf16_bits(hi.x), bf16_bits(hi.y), bf16_bits(hi.z),
              bf16_bits(hi.w)}};
 }
+inline uint2 pack_bf16x4(float4 v) {
+    const unsigned short h[4] = {bf16_bits(v.x), bf16_bits(v.y), bf16_bits(v.z), bf16_bits(v.w)};
+    uint2 r;
+    __builtin_memcpy(&r, h, 8);
+    return r;
+}
 inline bf16x8 load_bf16x8(const float* p) {
     bf16x8 r;
     __builtin_memcpy(&r, p, 16);

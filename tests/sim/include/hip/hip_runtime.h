@@ -40,6 +40,7 @@ struct int2 { int x, y; };
 inline int2 make_int2(int x, int y) { return {x, y}; }
 struct int4 { int x, y, z, w; };
 struct uint4 { unsigned x, y, z, w; };
+struct uint2 { unsigned x, y; };
 inline int4 make_int4(int x, int y, int z, int w) { return {x, y, z, w}; }
 inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
 
