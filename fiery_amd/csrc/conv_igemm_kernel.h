@@ -108,7 +108,7 @@ bool conv_launch_64x64(const ConvP& p, dim3 grid, hipStream_t stream, int varian
 bool conv_launch_64x128(const ConvP& p, dim3 grid, hipStream_t stream, int variant, unsigned long long* clk);
 // bf16 matrix-core form of the scalar-addressed kernel (weights packed by fiery_conv_pack_weights_bf16 in p.w); returns
 // false when (bm, bn) has no such kernel
-bool conv_launch_bf16(const ConvP& p, int bm, int bn, dim3 grid, hipStream_t stream);
+bool conv_launch_bf16(const ConvP& p, int bm, int bn, dim3 grid, hipStream_t stream, bool halo = false);
 
 #ifdef FIERY_CONV_KERNEL_TU
 namespace {
@@ -131,18 +131,20 @@ __device__ __forceinline__ int fast_div(int g, unsigned m, int s) {
 // Workgroups of one tile shape that fit a CU, as its LDS (two A stages + two W stages) allows, capped where the tile's
 // registers would not follow: one wavefront per workgroup and SIMD, so this is also the waves-per-SIMD target that the
 // register allocation is held to (without it the compiler aims one notch too high for the 64 x 128 tile and spills).
-constexpr int conv_smem_floats(int bm, int bn, bool bf16) {
+// (halo loop, 3 x 3: three runs of bm + 2 pixels + one zero entry, 80 bytes = 20 floats per entry, and two W stages)
+constexpr int HALO_RUN_EXTRA = 3, HALO_PITCH = 20;
+constexpr int conv_smem_floats(int bm, int bn, bool bf16, bool halo = false) {
     const int full = 2 * bm * BK + 2 * BK * bn;
     if (!bf16 || (bm == 128 && bn == 32)) return full;
-    const int stages = full / 2;
+    const int stages = halo ? 3 * (bm + HALO_RUN_EXTRA) * HALO_PITCH + BK * bn : full / 2;
     const int epilogue = bm * bn + (bm == 64 && bn == 128 ? 256 : 0);       // staging tile (+ the decoder heads' 1x1 rows)
     return stages > epilogue ? stages : epilogue;
 }
 #ifndef FIERY_BF16_WAVES
 #define FIERY_BF16_WAVES 4        // waves per SIMD the bf16 form's register allocation is held to (128 registers)
 #endif
-constexpr int conv_waves_per_simd(int bm, int bn, bool aligned = false, bool bf16 = false) {
-    const int by_lds = 163840 / (conv_smem_floats(bm, bn, bf16) * 4);
+constexpr int conv_waves_per_simd(int bm, int bn, bool aligned = false, bool bf16 = false, bool halo = false) {
+    const int by_lds = 163840 / (conv_smem_floats(bm, bn, bf16, halo) * 4);
     int cap = ((bm == 64 && bn == 64) || (FIERY_TAIL_FOUR_PER_CU && bm == 128 && bn == 32 && aligned)) ? 4 : 3;
     if (bf16 && !(bm == 128 && bn == 32)) cap = FIERY_BF16_WAVES;         // (128 x 32: its chained epilogue needs 150)
     return by_lds < cap ? by_lds : cap;
@@ -158,9 +160,10 @@ constexpr int conv_waves_per_simd(int bm, int bn, bool aligned = false, bool bf1
 // used it - with bf16's short MFMAs the loop was bound by LDS traffic, 3 KB per MFMA against the 1 KB per MFMA the LDS
 // can deliver at full matrix rate.)  The weights arrive already rounded and packed [k / 8][cout][k % 8]; products are
 // exact and accumulate in fp32.  Scalar-addressed loop only.
-template <int BM, int BN, bool CLK = false, int PRIO = 0, bool SMALLCIN = false, bool ALIGNED = false, bool BF16 = false>
-__global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK && !BF16, BF16)) void k_conv_igemm(ConvP p) {
+template <int BM, int BN, bool CLK = false, int PRIO = 0, bool SMALLCIN = false, bool ALIGNED = false, bool BF16 = false, bool HALO = false>
+__global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK && !BF16, BF16, HALO)) void k_conv_igemm(ConvP p) {
     static_assert(!BF16 || (ALIGNED && !SMALLCIN && !CLK), "the bf16 form exists for the scalar-addressed loop");
+    static_assert(!HALO || (BF16 && BM == 64 && BN >= 64), "the halo loop exists for the bf16 form's 64-pixel tiles");
     unsigned long long clk_entry = 0;
     if constexpr (CLK) clk_entry = clock64();
     if constexpr (PRIO == 1) {
@@ -187,11 +190,11 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
     constexpr int A_STAGE = HALF_STAGES ? BM * (BK / 2) : BM * BK;        // floats between the two A stages
     constexpr int W_STAGE = HALF_STAGES ? BK * BN / 2 : BK * BN;
     constexpr int W_BASE = 2 * A_STAGE;
-    constexpr int SMEM_FLOATS = conv_smem_floats(BM, BN, BF16);
+    constexpr int SMEM_FLOATS = conv_smem_floats(BM, BN, BF16, HALO);
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     float (*As)[BM * BK] = reinterpret_cast<float (*)[BM * BK]>(smem);                       // (chained epilogue: fp32 stages)
     float (*Bs)[BK * BN] = reinterpret_cast<float (*)[BK * BN]>(smem + 2 * BM * BK);
-    static_assert(W_BASE + 2 * W_STAGE <= SMEM_FLOATS && BM * BN + (BM == 64 && BN == 128 ? 256 : 0) <= SMEM_FLOATS,
+    static_assert((HALO || W_BASE + 2 * W_STAGE <= SMEM_FLOATS) && BM * BN + (BM == 64 && BN == 128 ? 256 : 0) <= SMEM_FLOATS,
                   "stages, staging tile and the heads' 1x1 rows must fit");
 
     const int tid = threadIdx.x;
@@ -489,11 +492,6 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
         else advance();
     };
 
-    v16f acc[MT * NT];
-#pragma unroll
-    for (int t = 0; t < MT * NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     unsigned long long clk_c0 = 0, clk_w0 = 0;
     if constexpr (CLK) {
@@ -502,6 +500,161 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
             clk_w0 = wall_clock64();
         }
     }
+    v16f acc[MT * NT];
+#pragma unroll
+    for (int t = 0; t < MT * NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if constexpr (HALO) {
+        // ---- halo loop: 3 x 3, stride 1, 'same' padding, bf16 operands ------------------------------------------------
+        // The scalar-addressed loop gathers the A tile once per (tap, 32-channel group): nine times the same pixels, shifted.
+        // With bf16's short MFMAs that traffic - 1 KB from L2 per MFMA - is what bounds the loop.  Here the loop runs
+        // channel group by channel group: the tile's 64 consecutive pixels and their neighbours are fetched ONCE per group
+        // as three runs of 66 pixels (the rows above, of, and below the tile's pixels: linear pixel index - W - 1 .., - 1 ..,
+        // + W - 1 ..), rounded to bf16 and laid out in LDS, and the nine taps are nine stages that read shifted windows of
+        // that block: tap (dy, dx) of tile pixel i is entry i + dx of run dy.  Only the weights change from stage to stage.
+        //   * rows outside the image: an entry of run 0 (2) whose pixel lies in the last (first) row of an image belongs to
+        //     no pixel of THIS image's window - it is fetched as zero (offset past the descriptor), like pixels outside the
+        //     tensor; that settles dy.
+        //   * columns: the left neighbour of a pixel with x = 0 is the previous row's last pixel in linear order; such a
+        //     lane reads the run's zero entry instead (one address select per lane, made once: rdL / rdR below).
+        //   * entries are 80 bytes apart (64 of data): 16 consecutive entries at one 16-byte slot then fall into 16
+        //     different slots of the 256-byte bank row for every lane group of ds_read_b128, and every tap's address is a
+        //     per-lane base plus an immediate.
+        constexpr int RUN = BM + HALO_RUN_EXTRA;                    // entries per run: BM + 2 pixels, then zeros
+        constexpr int PITCH = HALO_PITCH;
+        constexpr int HALO_W = 3 * RUN * PITCH;                     // the W stages start here (floats)
+        constexpr int W_STG = BK * BN / 2;
+        constexpr int NE = (3 * (BM + 2) + 31) / 32;                // halo elements (16 bytes of fp32) per thread and group
+        constexpr int BL = BN / 64;                                 // 16-byte W loads per thread and stage
+        static_assert(HALO_W % 4 == 0 && HALO_W + 2 * W_STG <= SMEM_FLOATS, "halo block and W stages must fit");
+        const int W_img = p.Wout, H_img = p.Hout;
+        const int groups = p.cin_units >> 2, groups0 = p.src[0].units >> 2;
+        const int f4h = tid & 7, prow_h = tid >> 3;
+        int hv0[NE], hv1[NE], hst[NE];
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int ent = prow_h + 32 * i;
+            const int r = ent >= 2 * (BM + 2) ? 2 : ent >= (BM + 2) ? 1 : 0;
+            const int idx = ent - r * (BM + 2);
+            const int q = pix0 + (r - 1) * W_img - 1 + idx;
+            const bool inside = ent < 3 * (BM + 2) && q >= 0 && q < M;
+            const int qq = inside ? q : 0;
+            const int o = fast_div(qq, p.mg_hw, p.sh_hw);
+            const int ppi = qq - o * HWout;
+            const int y = fast_div(ppi, p.mg_w, p.sh_w);
+            const int b = fast_div(o, p.mg_t, p.sh_t), tl = o - b * p.Tout;
+            const bool ok = inside && (r == 0 ? y <= H_img - 2 : r == 2 ? y >= 1 : true);
+            const int kofs = (f4h >> 1) * 8 + (f4h & 1) * 4;
+            const int e0 = 4 * (b * static_cast<int>(p.src[0].bstride) + (tl + p.tinadd) * static_cast<int>(p.src[0].tstride) + ppi * p.src[0].ld + kofs);
+            const int e1 = 4 * (b * static_cast<int>(p.src[1].bstride) + (tl + p.tinadd) * static_cast<int>(p.src[1].tstride) + ppi * p.src[1].ld + kofs);
+            hv0[i] = ok ? e0 : static_cast<int>(0x80000000u);
+            hv1[i] = ok ? e1 : static_cast<int>(0x80000000u);
+            hst[i] = (ent + r) * (PITCH / 2) + (f4h >> 1) * 2 + (f4h & 1);      // 8-byte units; ent + r = r RUN + idx
+        }
+        const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src[0].ptr), 0, p.src[0].ext_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src[1].ptr ? p.src[1].ptr : p.src[0].ptr), 0,
+                                                                               p.src[1].ptr ? p.src[1].ext_bytes : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(p.w) + static_cast<long long>(tile_n) * p.k_chunks * (BK * BN * 2)), 0,
+            p.k_chunks * (BK * BN * 2), 0x00020000);
+        float4 hreg[NE];
+        auto halo_load = [&](int g) {
+            const bool second = g >= groups0;
+            const int soff = 128 * (g - (second ? groups0 : 0));
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                float4 v;
+                if (second) v = to_float4(__builtin_amdgcn_raw_buffer_load_b128(rsrc1, hv1[i], soff, 0));
+                else v = to_float4(__builtin_amdgcn_raw_buffer_load_b128(rsrc0, hv0[i], soff, 0));
+                hreg[i] = v;
+            }
+        };
+        const bool last_live = prow_h + 32 * (NE - 1) < 3 * (BM + 2);     // (all but a thread's last element always exist)
+        uint2* const smem2 = reinterpret_cast<uint2*>(smem);
+        auto halo_store = [&]() {
+#pragma unroll
+            for (int i = 0; i < NE; ++i)
+                if (i < NE - 1 || last_live) smem2[hst[i]] = pack_bf16x4(hreg[i]);
+        };
+        float4 wreg[BL];
+        auto w_load = [&](int g, int t) {                       // stage (t, g) of the packed weights: chunk t groups + g
+            int chunk = t * groups + g;
+            chunk = chunk < p.k_chunks ? chunk : p.k_chunks - 1;                        // past the end: any chunk
+            const int soff = chunk * (BK * BN * 2);
+#pragma unroll
+            for (int k = 0; k < BL; ++k) wreg[k] = to_float4(__builtin_amdgcn_raw_buffer_load_b128(wrs, tid * 16, soff + k * 4096, 0));
+        };
+        // this lane's window: tile pixel pl, slot hi of each entry; the zero entry for the taps that would wrap around a row end
+        const int pl_h = wm * 32 + m;
+        int rdC = pl_h * PITCH + hi * 4, rdL, rdR;
+        {
+            const int gp = pix0 + pl_h;
+            const int g_ = gp < M ? gp : 0;
+            const int o = fast_div(g_, p.mg_hw, p.sh_hw);
+            const int ppi = g_ - o * HWout;
+            const int y = fast_div(ppi, p.mg_w, p.sh_w), x = ppi - y * W_img;
+            const int rdZ = (BM + 2) * PITCH + hi * 4;
+            rdL = x == 0 ? rdZ : rdC;
+            rdR = x == W_img - 1 ? rdZ - 2 * PITCH : rdC;
+        }
+        int w_rd_cur = HALO_W + (hi * BN + wn * (32 * NT) + m) * 4, w_rd_oth = w_rd_cur + W_STG;
+        float4* const smem4 = reinterpret_cast<float4*>(smem);
+        int w_st_cur = HALO_W / 4 + tid, w_st_oth = w_st_cur + W_STG / 4;        // in 16-byte units (keeps the stores ds_write_b128)
+        // prologue: zero entries, group 0's halo, stage 0's weights; group 1's halo and stage 1's weights stay in flight
+        if (tid < 3 * PITCH) smem[((tid / PITCH) * RUN + BM + 2) * PITCH + tid % PITCH] = 0.f;
+        halo_load(0);
+        w_load(0, 0);
+        halo_store();
+#pragma unroll
+        for (int k = 0; k < BL; ++k) smem4[w_st_cur + 256 * k] = wreg[k];
+        w_load(0, 1);
+        if (groups > 1) halo_load(1);
+        __syncthreads();
+        for (int g = 0; g < groups; ++g) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dy = t / 3, dx = t % 3;
+                const int rd = (dx == 0 ? rdL : dx == 2 ? rdR : rdC) + (dy * RUN + dx) * PITCH;
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh) {
+                    const bf16x8 a8 = load_bf16x8(&smem[rd + kh * 8]);
+                    bf16x8 b8[NT];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) b8[nt] = load_bf16x8(&smem[w_rd_cur + (2 * kh * BN + 32 * nt) * 4]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        acc[nt] = mfma_bf16_32x32x16(a8, b8[nt], acc[nt]);
+                        if (kh == 0 && nt == 0) {
+                            // the next stage's weights (in registers since the stage before this one) go to the idle buffer
+#pragma unroll
+                            for (int k = 0; k < BL; ++k) smem4[w_st_oth + 256 * k] = wreg[k];
+                        }
+                        if (kh == 1 && nt == 0) {
+                            // ... and the registers take the stage after that: (t + 2, g), wrapping into the next group
+                            if (t + 2 < 9) w_load(g, t + 2);
+                            else w_load(g + 1, t + 2 - 9);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                {
+                    const int a = w_rd_cur, b = w_st_cur;
+                    w_rd_cur = w_rd_oth;  w_rd_oth = a;
+                    w_st_cur = w_st_oth;  w_st_oth = b;
+                }
+                __syncthreads();
+            }
+            if (g + 1 < groups) {
+                // every wavefront has read its last window of this group: the next group's halo (requested a group ago) replaces it
+                halo_store();
+                __syncthreads();
+                if (g + 2 < groups) halo_load(g + 2);
+            }
+        }
+    } else {
     // ---- software pipeline ------------------------------------------------------------------------------------
     // While stage s is multiplied out of LDS buffer s&1, stage s+1 sits in registers (requested one iteration
     // earlier, so its latency is long gone) and is written to the other buffer, and stage s+2 is requested into
@@ -596,6 +749,7 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
         }
         if (chunk < c_k_chunks) stage_body(std::integral_constant<int, 0>{});
     }
+    }      // !HALO
     if constexpr (CLK) {
         // effective shader clock under this kernel's load = cycles / ticks * 100 MHz
         if (tid == 0 && (blockIdx.x & 15) == 0 && g_clk_probe) {
@@ -1102,6 +1256,10 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
 template <int BM, int BN>
 void conv_launch_tile_bf16(const ConvP& p, dim3 grid, hipStream_t hs) {
     hipLaunchKernelGGL((k_conv_igemm<BM, BN, false, 0, false, true, true>), grid, dim3(256), 0, hs, p);
+}
+template <int BM, int BN>
+void conv_launch_tile_bf16_halo(const ConvP& p, dim3 grid, hipStream_t hs) {
+    hipLaunchKernelGGL((k_conv_igemm<BM, BN, false, 0, false, true, true, true>), grid, dim3(256), 0, hs, p);
 }
 
 template <int BM, int BN, unsigned kMask>

@@ -398,6 +398,37 @@ def test_conv2d_bf16_form(sim, monkeypatch, cin, cout, k, stride, hw, tile_m):
     assert (got - full).abs().max() < 0.05 and (got - full).abs().max() > 1e-5       # it IS the rounded-operand result
 
 
+@pytest.mark.parametrize('cin,cout,hw,n', [
+    (32, 64, (9, 14), 2),        # one channel group, rows much shorter than a tile: a run covers several image rows
+    (64, 128, (7, 5), 3),        # two groups, 64 x 128 tile, a tile spans two images (35 pixels each)
+    (128, 64, (3, 70), 1),       # four groups, rows longer than a tile
+    (96, 128, (1, 9), 2),        # one-row images: no tap above or below
+    (32, 64, (66, 1), 1),        # one-column images: every left / right tap is outside
+])
+def test_conv2d_bf16_halo_loop(sim, monkeypatch, cin, cout, hw, n):
+    """3 x 3 / stride 1 layers on 64-pixel tiles take the halo loop (the tile and its neighbours fetched once per 32-channel
+    group, the nine taps as shifted windows of that block): against the rounded-operand convolution, and against the
+    scalar-addressed loop it replaces (same products, another order of the fp32 additions)."""
+    monkeypatch.setenv('FIERY_CONV_TILE_M', '64')
+    g = torch.Generator().manual_seed(cin + cout + hw[0])
+    x = torch.randn(n, cin, *hw, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    res = torch.randn(n, cout, *hw, generator=g)
+    src, rbuf = _to_buf(x), _to_buf(res)
+    op = ConvOp(sim, w, identity_chan_map(cin), (src.C // 8, 0), scale, shift, 'cpu', act=native.ACT_RELU, precision=native.PRECISION_BF16)
+    outs = {}
+    for halo in ('1', '0'):
+        monkeypatch.setenv('FIERY_CONV_HALO', halo)
+        out = Buf.alloc(n, *hw, cout, 'cpu')
+        op([src], out, res=rbuf)
+        outs[halo] = out.to_nchw()[:, :cout]
+    want = F.relu(F.conv2d(_bf16(x), _bf16(w), padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)) + res
+    assert torch.allclose(outs['1'], want, rtol=2e-5, atol=2e-5), (outs['1'] - want).abs().max()
+    assert torch.allclose(outs['1'], outs['0'], rtol=1e-5, atol=1e-5)
+    assert not torch.equal(outs['1'], outs['0']) or cin == 32        # (it really is the other loop: the sums round differently)
+
+
 def test_bf16_form_falls_back_to_fp32_where_it_does_not_apply(sim):
     """13 input channels cannot take the scalar-addressed loop: the launch runs the fp32 kernel and is exact again."""
     g = torch.Generator().manual_seed(77)
@@ -410,8 +441,12 @@ def test_bf16_form_falls_back_to_fp32_where_it_does_not_apply(sim):
     assert torch.allclose(out.to_nchw()[:, :32], F.conv2d(x, w, padding=1), **TOL)
 
 
-def test_gru_epilogues_and_chained_tail_on_the_bf16_form(sim):
-    """The epilogues are the fp32 kernel's: GRU gate GEMM (two sources) and a Bottleneck tail with its chained 1x1."""
+@pytest.mark.parametrize('tile_m', [None, '64'])
+def test_gru_epilogues_and_chained_tail_on_the_bf16_form(sim, monkeypatch, tile_m):
+    """The epilogues are the fp32 kernel's: GRU gate GEMM (two sources; on 64-pixel tiles the halo loop, whose channel
+    groups come from one source each) and a Bottleneck tail with its chained 1x1."""
+    if tile_m:
+        monkeypatch.setenv('FIERY_CONV_TILE_M', tile_m)
     g = torch.Generator().manual_seed(91)
     ch = 32
     x, h = torch.randn(1, ch, 8, 10, generator=g), torch.randn(1, ch, 8, 10, generator=g)
