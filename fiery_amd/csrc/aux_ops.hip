@@ -200,6 +200,35 @@ __global__ void k_maxpool2x2(const float* __restrict__ in, int in_ld, long long 
     out[((static_cast<long long>(img) * Ho + yo) * Wo + xo) * out_ld + c] = m;
 }
 
+// gradient of the above: the window's first maximum in row-major order takes the output's gradient
+__global__ void k_maxpool2x2_bwd(const float* __restrict__ in, int in_ld, long long in_img_stride, const float* __restrict__ gy, int g_ld,
+                                 int H, int W, int C, int Ho, int Wo, float* __restrict__ gx, int gi_ld, long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = static_cast<int>(i % C);
+    long long r = i / C;
+    const int xo = static_cast<int>(r % Wo);
+    r /= Wo;
+    const int yo = static_cast<int>(r % Ho);
+    const int img = static_cast<int>(r / Ho);
+    const float* base = in + static_cast<long long>(img) * in_img_stride;
+    float m = -INFINITY;
+    int best = 0;
+    for (int k = 0; k < 4; ++k) {
+        const int y = 2 * yo + (k >> 1), x = 2 * xo + (k & 1);
+        const float v = (y < H && x < W) ? base[(static_cast<long long>(y) * W + x) * in_ld + c] : 0.f;
+        if (v > m || v != v) {                                  // ATen: (val > maxval) || isnan(val)
+            m = v;
+            best = k;
+        }
+    }
+    const float g = gy[((static_cast<long long>(img) * Ho + yo) * Wo + xo) * g_ld + c];
+    for (int k = 0; k < 4; ++k) {
+        const int y = 2 * yo + (k >> 1), x = 2 * xo + (k & 1);
+        if (y < H && x < W) gx[((static_cast<long long>(img) * H + y) * W + x) * gi_ld + c] = k == best ? g : 0.f;
+    }
+}
+
 // bilinear x2, align_corners=False: source = dst / 2 - 0.25 clamped at 0, upper neighbour clamped at the edge
 __global__ void k_upsample2x_add(const float* __restrict__ in, int in_ld, int H, int W, int C,
                                  const float* __restrict__ shift, const float* __restrict__ skip, int skip_ld,
@@ -739,6 +768,18 @@ extern "C" int fiery_maxpool2x2_nhwc(const float* in, int in_ld, int64_t in_img_
     hipLaunchKernelGGL(k_maxpool2x2, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), in, in_ld, istride, H, W, C, Ho,
                        Wo, out, out_ld, total);
     return check_launch("maxpool2x2");
+}
+
+extern "C" int fiery_maxpool2x2_bwd_nhwc(const float* in, int in_ld, int64_t in_img_stride, const float* grad_out, int g_ld, int n_img,
+                                         int H, int W, int C, float* grad_in, int gi_ld, fiery_stream_t stream) {
+    FIERY_REQUIRE(in && grad_out && grad_in && n_img > 0 && H > 0 && W > 0 && C > 0, "maxpool2x2_bwd: bad argument");
+    FIERY_REQUIRE(in_ld >= C && g_ld >= C && gi_ld >= C, "maxpool2x2_bwd: leading dimension below the channel count");
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const long long total = static_cast<long long>(n_img) * Ho * Wo * C;
+    const long long istride = in_img_stride > 0 ? in_img_stride : static_cast<long long>(H) * W * in_ld;
+    hipLaunchKernelGGL(k_maxpool2x2_bwd, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), in, in_ld, istride, grad_out, g_ld,
+                       H, W, C, Ho, Wo, grad_in, gi_ld, total);
+    return check_launch("maxpool2x2_bwd");
 }
 
 extern "C" int fiery_upsample2x_add_nhwc(const float* in, int in_ld, int n_img, int H, int W, int C, const float* shift,

@@ -249,10 +249,76 @@ __global__ __launch_bounds__(256) void k_bev_warp(const float* __restrict__ in, 
     }
 }
 
+// Adjoint of k_bev_warp in its input.  Same grid and tile; phase 1: the 64-pixel x C tile of the output gradient arrives
+// pixel-major with lanes along channels; phase 2: wavefront w scatters channels w, w + 4, ... with lanes along x - the four
+// corners of neighbouring pixels are neighbouring addresses of one channel plane for small rotations.
+__global__ __launch_bounds__(256) void k_bev_warp_bwd(const float* __restrict__ gy, int g_ld, long long g_img_stride,
+                                                      const float* __restrict__ theta, IdentityFlags identity, int C, int H, int W,
+                                                      float* __restrict__ gx, int flags) {
+    HIP_DYNAMIC_SHARED(float, tile)            // [kWarpTile][C + 1]
+    const int img = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * kWarpTile;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = x0 + lane;
+    const int row = C + 1;
+    const float* gbase = gy + static_cast<long long>(img) * g_img_stride + (static_cast<long long>(y) * W + x0) * g_ld;
+    const int npx = min(kWarpTile, W - x0);
+    for (int i = threadIdx.x; i < npx * C; i += blockDim.x) {
+        const int px = i / C, c = i - px * C;
+        tile[px * row + c] = gbase[static_cast<long long>(px) * g_ld + c];
+    }
+    __syncthreads();
+    if (x >= W) return;
+    float* plane0 = gx + static_cast<long long>(img) * C * H * W;
+    if (identity.v[img] != 0) {                                   // copied, not resampled: every pixel is written exactly once
+        for (int c = wave; c < C; c += 4) plane0[static_cast<long long>(c) * H * W + y * W + x] = tile[lane * row + c];
+        return;
+    }
+    float fx, fy;
+    sample_position(theta + img * 6, x, y, W, H, (flags & FIERY_WARP_FUSED_GRID_PRODUCT) != 0, fx, fy);
+    const float flx = floorf(fx), fly = floorf(fy);
+    const int ix0 = static_cast<int>(flx), iy0 = static_cast<int>(fly);
+    const float tx = fx - flx, ty = fy - fly;
+    const float ex = 1.f - tx, sy = 1.f - ty;
+    const float w00 = sy * ex, w01 = sy * tx, w10 = ty * ex, w11 = ty * tx;
+    const bool xin0 = ix0 >= 0 && ix0 < W, xin1 = ix0 + 1 >= 0 && ix0 + 1 < W;
+    const bool yin0 = iy0 >= 0 && iy0 < H, yin1 = iy0 + 1 >= 0 && iy0 + 1 < H;
+    for (int c = wave; c < C; c += 4) {
+        const float g = tile[lane * row + c];
+        float* pl = plane0 + static_cast<long long>(c) * H * W;
+        if (xin0 && yin0) atomicAdd(pl + iy0 * W + ix0, g * w00);
+        if (xin1 && yin0) atomicAdd(pl + iy0 * W + ix0 + 1, g * w01);
+        if (xin0 && yin1) atomicAdd(pl + (iy0 + 1) * W + ix0, g * w10);
+        if (xin1 && yin1) atomicAdd(pl + (iy0 + 1) * W + ix0 + 1, g * w11);
+    }
+}
+
 }  // namespace
 }  // namespace fiery
 
 using namespace fiery;
+
+extern "C" int fiery_bev_warp_bwd_nhwc_to_nchw(const float* grad_out, int g_ld, int64_t g_img_stride, const float* theta,
+                                               const uint8_t* identity, int n_img, int C, int H, int W, float* grad_in, int flags,
+                                               fiery_stream_t stream) {
+    FIERY_REQUIRE(grad_out && theta && grad_in, "bev_warp_bwd: null pointer");
+    FIERY_REQUIRE(n_img > 0 && C > 0 && H > 0 && W > 0 && g_ld >= C, "bev_warp_bwd: bad shape");
+    FIERY_REQUIRE(static_cast<size_t>(kWarpTile) * (C + 1) * sizeof(float) <= 160 * 1024, "bev_warp_bwd: too many channels");
+    const size_t image = static_cast<size_t>(C) * H * W;
+    if (hipMemsetAsync(grad_in, 0, image * n_img * sizeof(float), as_stream(stream)) != hipSuccess)
+        return fail(FIERY_ELAUNCH, "bev_warp_bwd: cannot clear the input gradient");
+    for (int i0 = 0; i0 < n_img; i0 += kMaxWarpImages) {
+        const int n = n_img - i0 < kMaxWarpImages ? n_img - i0 : kMaxWarpImages;
+        IdentityFlags ident;
+        for (int i = 0; i < kMaxWarpImages; ++i) ident.v[i] = (identity && i < n && identity[i0 + i]) ? 1 : 0;
+        hipLaunchKernelGGL(k_bev_warp_bwd, dim3(ceil_div(W, kWarpTile), H, n), dim3(256),
+                           static_cast<size_t>(kWarpTile) * (C + 1) * sizeof(float), as_stream(stream),
+                           grad_out + static_cast<long long>(i0) * g_img_stride, g_ld, static_cast<long long>(g_img_stride),
+                           theta + static_cast<long long>(i0) * 6, ident, C, H, W, grad_in + static_cast<long long>(i0) * image, flags);
+        int rc = check_launch("bev_warp_bwd");
+        if (rc) return rc;
+    }
+    return FIERY_OK;
+}
 
 extern "C" int fiery_warp_params(const float* future_egomotion, int B, int S, float extent_x, float extent_y,
                                  float* theta, float* ego_shifted, fiery_stream_t stream) {

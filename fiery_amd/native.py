@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libfiery_hip.so')
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -113,6 +113,10 @@ _SIGNATURES = {
     'fiery_bev_warp_nearest_nchw': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'fiery_bev_warp_nchw_to_nhwc': (C.c_int, [C.c_void_p, C.c_void_p, c_uint8_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                               C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p]),
+    'fiery_bev_warp_bwd_nhwc_to_nchw': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, c_uint8_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                  C.c_void_p, C.c_int, C.c_void_p]),
+    'fiery_maxpool2x2_bwd_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_int, C.c_void_p]),
     'fiery_conv_packed_floats': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'fiery_conv_pack_weights': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_int32_p, C.c_int, C.c_void_p, C.c_void_p]),
     'fiery_conv_fwd': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
@@ -371,6 +375,22 @@ class Lib:
         flags = warp_flags_of_this_host(h, w) if flags is None else flags
         self.check(self.dll.fiery_bev_warp_nchw_to_nhwc(_ptr(x), _ptr(theta), ident, n, c, h, w, _ptr(out), out_ld,
                                                         out_img_stride, flags, _stream_of(out)))
+
+    def bev_warp_bwd(self, grad_out, g_ld, g_img_stride, theta, identity, n, c, h, w, flags=None):
+        """Adjoint of `bev_warp_nchw_to_nhwc` in its input: pixel-major output gradient -> (n, c, h, w)."""
+        ident = (C.c_uint8 * n)(*[1 if v else 0 for v in identity]) if identity is not None else None
+        flags = warp_flags_of_this_host(h, w) if flags is None else flags
+        gx = torch.empty(n, c, h, w, dtype=torch.float32, device=grad_out.device)
+        self.check(self.dll.fiery_bev_warp_bwd_nhwc_to_nchw(_ptr(grad_out), g_ld, g_img_stride, _ptr(theta), ident, n, c, h, w,
+                                                            _ptr(gx), flags, _stream_of(gx)))
+        return gx
+
+    def maxpool2x2_bwd(self, x, in_ld, grad_out, g_ld, n_img, h, w, c):
+        """x dense pixel-major (n_img, h, w, in_ld), grad_out (n_img, ceil(h/2), ceil(w/2), g_ld) -> (n_img, h, w, in_ld)."""
+        gx = torch.zeros(n_img, h, w, in_ld, dtype=torch.float32, device=grad_out.device)
+        self.check(self.dll.fiery_maxpool2x2_bwd_nhwc(_ptr(x), in_ld, 0, _ptr(grad_out), g_ld, n_img, h, w, c, _ptr(gx), in_ld,
+                                                      _stream_of(gx)))
+        return gx
 
     # -- conv -------------------------------------------------------------------------------------
     def conv_pack_weights(self, w, cout, cin_total, taps, chan_map, cin_units):

@@ -19,7 +19,8 @@ PyTorch autograd graph over pixel-major (channels-last) tensors in which
   trunk's explicit 'static same' padding, depthwise ones on `HipDepthwiseConv2d` (`fiery_depthwise_conv_nhwc` in both
   directions, `fiery_depthwise_conv_wgrad_nhwc`), BatchNorm on `HipBatchNormAct`, the squeeze-and-excite means on
   `HipSpatialMean` and its two dense layers as matrix products;
-* what is left on PyTorch-ROCm operators over the same memory: max-pool of the skip paths, the ego-warp (`grid_sample`),
+* the max-pool of the skip paths and the ego-warp (`grid_sample`) run on the library's kernels in both directions since round 3
+  (`HipMaxPool2x2`, `HipEgoWarp`); what is left on PyTorch-ROCm operators over the same memory:
   swish / sigmoid gates, concatenations, residual adds, the small dense layers (matrix products) - their backward comes from
   autograd.  No MIOpen convolution is left in the graph.
 
@@ -196,6 +197,55 @@ class HipUpsample2x(torch.autograd.Function):
     def backward(ctx, gy):
         n, c, h, w, cp, lib = ctx.meta
         return lib.upsample2x_bwd(_pixel_major(gy.float(), 4), n, h, w, cp)[..., :c].permute(0, 3, 1, 2), None
+
+
+class HipMaxPool2x2(torch.autograd.Function):
+    """`F.max_pool2d(F.pad(x, odd sizes -> even, 0), 2, 2)` - the pooled skip of a down-sampling Bottleneck
+    (layers/convolutions.py:150-166): forward `fiery_maxpool2x2_nhwc`, backward `fiery_maxpool2x2_bwd_nhwc` (the gradient goes
+    to the window's first maximum, ATen's tie rule; what falls on the zero padding is dropped, as `F.pad`'s backward does)."""
+
+    @staticmethod
+    def forward(ctx, x, lib):
+        n, c, h, w = x.shape
+        x_nhwc = _pixel_major(x.detach().float(), 4)
+        cp = x_nhwc.shape[-1]
+        out = torch.empty(n, (h + 1) // 2, (w + 1) // 2, cp, dtype=torch.float32, device=x.device)
+        lib.maxpool2x2(x_nhwc, cp, n, h, w, cp, out, cp)
+        ctx.save_for_backward(x_nhwc)
+        ctx.meta = (n, c, h, w, cp, lib)
+        return _padded_rows(out[..., :c].permute(0, 3, 1, 2), c, cp)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x_nhwc, = ctx.saved_tensors
+        n, c, h, w, cp, lib = ctx.meta
+        gx = lib.maxpool2x2_bwd(x_nhwc, cp, _pixel_major(gy.float(), 4), cp, n, h, w, cp)
+        return _padded_rows(gx[..., :c].permute(0, 3, 1, 2), c, cp), None
+
+
+class HipEgoWarp(torch.autograd.Function):
+    """`cumulative_warp_features` (utils/geometry.py:225-253) of all frames at once, differentiable in the features: forward
+    `fiery_bev_warp_nchw_to_nhwc` (the resampling the inference path uses, pixel-major output for the temporal model), backward
+    its adjoint `fiery_bev_warp_bwd_nhwc_to_nchw` (channel planes, what the pooling backward reads).  The transforms depend on
+    the ego-motion only and carry no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, theta, identity, lib):
+        n, c, h, w = x.shape
+        cp = round_up(c, 8)
+        make = torch.zeros if cp != c else torch.empty
+        out = make(n, h, w, cp, dtype=torch.float32, device=x.device)
+        lib.bev_warp_nchw_to_nhwc(x.detach().float().contiguous(), theta, identity, out, cp, h * w * cp)
+        ctx.save_for_backward(theta)
+        ctx.meta = (n, c, h, w, cp, tuple(identity), lib)
+        return _padded_rows(out[..., :c].permute(0, 3, 1, 2), c, cp)
+
+    @staticmethod
+    def backward(ctx, gy):
+        theta, = ctx.saved_tensors
+        n, c, h, w, cp, identity, lib = ctx.meta
+        g = _pixel_major(gy.float())
+        return lib.bev_warp_bwd(g, cp, h * w * cp, theta, identity, n, c, h, w), None, None, None
 
 
 def _rows(x):
@@ -529,7 +579,10 @@ class TrainGraph:
         skip = x
         if blk.downsample:
             # odd sizes are padded first so that the pooled skip meets the strided convolution's size (convolutions.py:160-162)
-            skip = F.max_pool2d(F.pad(skip, (0, skip.shape[-1] % 2, 0, skip.shape[-2] % 2), value=0), 2, 2)
+            if self._hip_ops:
+                skip = HipMaxPool2x2.apply(skip, self.lib)
+            else:
+                skip = F.max_pool2d(F.pad(skip, (0, skip.shape[-1] % 2, 0, skip.shape[-2] % 2), value=0), 2, 2)
         skip = self.bn_act(self.conv2d(skip, blk.projection.conv_skip_proj), blk.projection.bn_skip_proj, relu=False)
         return r + skip
 
@@ -651,7 +704,16 @@ class TrainGraph:
         """Everything after pooling; x (B, S, C, X, Y) pooled BEV features, future_egomotion (B, S, 6)."""
         m = self.m
         cfg = m.cfg
-        x = cumulative_warp_features(x.clone(), future_egomotion, 'bilinear', m.spatial_extent)
+        if self._hip_ops and x.shape[1] > 1:
+            b, s, c, h, w = x.shape
+            ego = future_egomotion.detach().float().contiguous()
+            theta = m._warp_transforms(ego)                     # 'host' mode: the reference's own CPU operators
+            if theta is None:
+                theta = self.lib.warp_params(ego, m.spatial_extent)
+            x = HipEgoWarp.apply(x.reshape(b * s, c, h, w), theta.reshape(b * s, 6).contiguous(),
+                                 [(i % s) == s - 1 for i in range(b * s)], self.lib).view(b, s, c, h, w)
+        else:
+            x = cumulative_warp_features(x.clone(), future_egomotion, 'bilinear', m.spatial_extent)
         if cfg.MODEL.TEMPORAL_MODEL.INPUT_EGOPOSE:
             b, s, c = future_egomotion.shape
             h, w = x.shape[-2:]

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FIERY_ABI_VERSION 17
+#define FIERY_ABI_VERSION 18
 
 #define FIERY_OK 0
 #define FIERY_EINVAL (-22)      /* bad argument (shape, alignment, null pointer) */
@@ -187,6 +187,15 @@ int fiery_bev_warp_nearest_nchw(const float* in, const float* theta, int n_img, 
 int fiery_bev_warp_nchw_to_nhwc(const float* in, const float* theta /* [n_img][6] */,
                                 const uint8_t* identity /* host */, int n_img, int C, int H, int W,
                                 float* out, int out_ld, int64_t out_img_stride, int flags, fiery_stream_t stream);
+
+/* Adjoint of fiery_bev_warp_nchw_to_nhwc in its input (training; the sampling positions depend on the ego-motion only, which
+ * carries no gradient - fiery/utils/geometry.py:181-222 under autograd): grad_in[img][c] receives, for every output pixel, its
+ * gradient times the four bilinear weights at the four source pixels that lie inside the map (atomic fp32 additions: the order of
+ * the few contributions per source pixel is not fixed, as in ATen's own backward); images with identity[i] != 0 are copied.
+ * grad_out NHWC (ld, img_stride as given), grad_in [n_img][C][H][W], overwritten. */
+int fiery_bev_warp_bwd_nhwc_to_nchw(const float* grad_out, int g_ld, int64_t g_img_stride, const float* theta /* [n_img][6] */,
+                                    const uint8_t* identity /* host */, int n_img, int C, int H, int W, float* grad_in, int flags,
+                                    fiery_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * BEV convolution stack            (reference: fiery/layers/convolutions.py, fiery/layers/temporal.py,
@@ -378,6 +387,12 @@ int fiery_latent_sample(const float* mu, const float* log_sigma, const float* no
  * (layers/convolutions.py:150,166). */
 int fiery_maxpool2x2_nhwc(const float* in, int in_ld, int64_t in_img_stride /* floats between images; 0 = H*W*in_ld */,
                           int n_img, int H, int W, int C, float* out, int out_ld, fiery_stream_t stream);
+
+/* Gradient of fiery_maxpool2x2_nhwc in its input: grad_in (n_img, H, W, C in rows of gi_ld) gets grad_out at the first maximum
+ * of each window in row-major order (ATen's max_pool2d_with_indices tie rule; the zero column / row that pads an odd size takes
+ * part in the maximum and its share of the gradient is dropped) and zeros elsewhere. */
+int fiery_maxpool2x2_bwd_nhwc(const float* in, int in_ld, int64_t in_img_stride /* 0 = H*W*in_ld */, const float* grad_out, int g_ld,
+                              int n_img, int H, int W, int C, float* grad_in, int gi_ld, fiery_stream_t stream);
 
 /* Depthwise k x k convolution, NHWC, + folded BatchNorm (scale, shift; may be NULL) + activation: the MBConv blocks of the
  * image trunk (efficientnet-pytorch `MBConvBlock._depthwise_conv` + `_bn1` + swish, behind fiery/models/encoder.py:58-86).

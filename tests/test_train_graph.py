@@ -76,6 +76,28 @@ def test_upsampling_plane_mean_and_strided_convolution_gradients_vs_fp64(sim):
         _grads_vs_fp64(lambda a, b: HipConv2d.apply(a, b, 2, pad, sim), lambda a, b: F.conv2d(a, b, None, 2, pad), [xx, ww], seed=cin + k)
 
 
+def test_maxpool_and_ego_warp_all_gradients_vs_fp64(sim):
+    """HipMaxPool2x2 (the pooled skip of a down-sampling Bottleneck, layers/convolutions.py:150-166: odd sizes padded with a
+    zero row / column that takes part in the maximum) and HipEgoWarp (`cumulative_warp_features`, utils/geometry.py:225-253:
+    bilinear `grid_sample` with zero padding; the present frame is copied) against the float64 autograd evaluation of their
+    torch statements - values and input gradients."""
+    from fiery_amd.train_graph import HipEgoWarp, HipMaxPool2x2, cumulative_warp_features
+    g = torch.Generator().manual_seed(8)
+    for shape in ((2, 12, 6, 8), (1, 7, 7, 9), (2, 64, 13, 13), (1, 4, 1, 5)):
+        x = torch.randn(*shape, generator=g)
+        x[..., -1] = -1.0 - x[..., -1].abs()                    # odd widths: the zero padding wins its window
+        x[:, :, 0, 0] = x[:, :, 0, 1]                           # a tie: the first element of the window takes the gradient
+        _grads_vs_fp64(lambda t: HipMaxPool2x2.apply(t, sim),
+                       lambda t: F.max_pool2d(F.pad(t, (0, t.shape[-1] % 2, 0, t.shape[-2] % 2), value=0), 2, 2), [x], seed=shape[1])
+    for (b, s, c, h, w), extent in (((2, 3, 8, 12, 10), (6.0, 5.0)), ((1, 2, 64, 16, 16), (8.0, 8.0)), ((1, 3, 5, 7, 70), (3.5, 35.0))):
+        x = torch.randn(b, s, c, h, w, generator=g)
+        ego = torch.randn(b, s, 6, generator=g) * torch.tensor([1.5, 1.5, 0.1, 0.02, 0.02, 0.2])
+        theta = sim.warp_params(ego.contiguous(), extent).reshape(b * s, 6)
+        identity = [(i % s) == s - 1 for i in range(b * s)]
+        _grads_vs_fp64(lambda t: HipEgoWarp.apply(t.reshape(b * s, c, h, w), theta, identity, sim).reshape(b, s, c, h, w),
+                       lambda t: cumulative_warp_features(t.clone(), ego.double(), 'bilinear', extent), [x], seed=c, tol=5e-5)
+
+
 @pytest.mark.parametrize('c,k,stride,pads,hw', [(8, 3, 1, (1, 1, 1, 1), (7, 9)), (12, 3, 2, (0, 0, 1, 1), (9, 12)), (8, 5, 1, (2, 2, 2, 2), (6, 7)),
                                                  (16, 5, 2, (1, 1, 2, 2), (11, 10)), (8, 5, 2, (2, 2, 2, 2), (8, 8)), (4, 3, 2, (0, 1, 1, 0), (5, 5))])
 def test_depthwise_convolution_all_gradients_vs_fp64(sim, c, k, stride, pads, hw):
@@ -266,7 +288,10 @@ def as_close_to_exact_as_fp32_torch(hip, torch32, exact, test='train_step'):
     parity_report.record(test, f'gradients: {len(rows)} tensors, relative L2, median', median, 1.0, median, sorted(r[1] for r in rows)[len(rows) // 2],
                          2e-2, 'against the fp64 graph; yardstick = all-torch fp32 graph')
     parity_report.record(test, f'gradients: worst ({worst[2][-48:]}); {len(flipped)} past 2 %', worst[0], 1.0, worst[0], worst[1], 0.5)
-    assert median <= 2e-2 and worst[0] <= 0.5 and len(flipped) <= len(rows) // 10, (median, worst, len(flipped))
+    # (the yardstick applies to the median too: on the tiny simulator configuration the all-torch fp32 graph's own median is
+    # 2.8 % - a 1e-7 change of a sampling position moves these gradients by percents; a fixed 2 % would measure the seed)
+    median_torch = sorted(r[1] for r in rows)[len(rows) // 2]
+    assert median <= max(2e-2, 1.25 * median_torch) and worst[0] <= 0.5 and len(flipped) <= len(rows) // 10, (median, median_torch, worst, len(flipped))
     # The 1 % question, per tensor: where fp32 arithmetic itself allows it - the all-torch fp32 graph is within 0.5 % of the
     # fp64 one - the kernels' gradient is within 1 % (a flipped gate may again take a tenth of the tensors out); the tensors
     # past 1 % are listed with the torch figure beside them, which is what says whether conditioning or a kernel is the cause.
@@ -421,6 +446,46 @@ def test_hip_conv2d_real_shapes_against_fp64(hip, cin, cout, k, stride, pad, hw)
                              (results['hip'][i] - results['torch32'][i]).abs().max().item(), scale, err_hip, err_t,
                              3 * err_t + 1e-5 * scale, 'reference = the fp32 operator of PyTorch-ROCm; bound is on the fp64 error')
         assert err_hip <= 3 * err_t + 1e-5 * scale, (what, err_hip, err_t, scale)
+
+
+@pytest.mark.gpu
+def test_maxpool_and_ego_warp_real_shapes_against_fp64(hip):
+    """`HipMaxPool2x2` at the distribution encoder's sizes (200 -> 100 -> 50 -> 25 -> 13: the last one odd) and `HipEgoWarp` at
+    baseline.yml's (2 samples x 3 frames x 64 channels x 200 x 200): values and input gradients against the float64 evaluation
+    of the torch statement on the host, with PyTorch-ROCm's fp32 operators on the same GPU as the yardstick."""
+    from fiery_amd.train_graph import HipEgoWarp, HipMaxPool2x2, cumulative_warp_features
+    from tests import parity_report
+    g = torch.Generator().manual_seed(21)
+
+    def check(name, run, x, gy=None):
+        results = {}
+        for kind, dev, dt in (('exact', 'cpu', torch.float64), ('torch32', 'cuda', torch.float32), ('hip', 'cuda', torch.float32)):
+            xx = x.to(device=dev, dtype=dt).requires_grad_()
+            y = run(xx, kind == 'hip')
+            if gy is None:
+                gy = torch.randn(y.shape, generator=g)
+            gx, = torch.autograd.grad(y, xx, gy.to(device=dev, dtype=dt))
+            results[kind] = [t.detach().double().cpu() for t in (y, gx)]
+        for i, what in enumerate(('y', 'dx')):
+            exact = results['exact'][i]
+            err_hip, err_t = (results['hip'][i] - exact).abs().max().item(), (results['torch32'][i] - exact).abs().max().item()
+            scale = exact.abs().max().item()
+            parity_report.record(name, what, (results['hip'][i] - results['torch32'][i]).abs().max().item(), scale, err_hip, err_t,
+                                 3 * err_t + 1e-5 * scale, 'reference = the fp32 operator of PyTorch-ROCm; bound is on the fp64 error')
+            assert err_hip <= 3 * err_t + 1e-5 * scale, (name, what, err_hip, err_t, scale)
+
+    for c, hw in ((70, (200, 200)), (64, (25, 25)), (128, (13, 13))):
+        x = torch.randn(2, c, *hw, generator=g)
+        check(f'hip_maxpool[{c} {hw[0]}]',
+              lambda t, ours: HipMaxPool2x2.apply(t, hip) if ours else F.max_pool2d(F.pad(t, (0, t.shape[-1] % 2, 0, t.shape[-2] % 2), value=0), 2, 2), x)
+    b, s, c, h, w, extent = 2, 3, 64, 200, 200, (50.0, 50.0)
+    x = torch.randn(b, s, c, h, w, generator=g)
+    ego = torch.randn(b, s, 6, generator=g) * torch.tensor([2.0, 2.0, 0.1, 0.01, 0.01, 0.1])
+    theta = hip.warp_params(ego.cuda().contiguous(), extent).reshape(b * s, 6)
+    identity = [(i % s) == s - 1 for i in range(b * s)]
+    check('hip_ego_warp[2x3x64x200x200]',
+          lambda t, ours: (HipEgoWarp.apply(t.reshape(b * s, c, h, w), theta, identity, hip).reshape(b, s, c, h, w) if ours else
+                           cumulative_warp_features(t.clone(), ego.to(device=t.device, dtype=t.dtype), 'bilinear', extent)), x)
 
 
 @pytest.mark.gpu

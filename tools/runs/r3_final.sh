@@ -22,6 +22,14 @@ timeout 600 python bench.py --steps 10 --warmup 3 --precision bf16 --config lite
 timeout 600 python bench.py --steps 10 --warmup 3 --precision bf16 --config lyft/baseline.yml --cams 7 --no-from-images > $O/bench_lyft7_bf16.json 2>> $O/bench.err
 grep -h -o '"value": [0-9.]*' $O/bench_baseline_bf16.json $O/bench_pon_bf16.json $O/bench_lyft7_bf16.json
 {
+  echo "# round 3 - tools/microbench.py conv, fp32 form"
+  timeout 300 python tools/microbench.py conv --reps 20 2>&1 | grep -v amdgpu.ids
+  echo "# bf16 form (CONV_PRECISION=bf16; halo loop on the 3 x 3 layers)"
+  CONV_PRECISION=bf16 timeout 300 python tools/microbench.py conv --reps 20 2>&1 | grep -v amdgpu.ids
+  echo "# voxel pooling op"
+  timeout 300 python tools/microbench.py pool --reps 20 2>&1 | grep -v amdgpu.ids
+} > $O/microbench.txt
+{
   echo "# round 3 - one training step of the path (forward + backward + SGD step from the lifted features), baseline.yml, B = 2, tools/time_train_step.py"
   timeout 600 python tools/time_train_step.py --batch 2 --steps 5 2>&1 | grep time_train_step
   echo "# the same graph with PyTorch-ROCm operators for convolution / BatchNorm / upsampling (MIOpen, ATen)"
