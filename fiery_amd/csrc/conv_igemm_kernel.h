@@ -136,7 +136,7 @@ constexpr int HALO_RUN_EXTRA = 3, HALO_PITCH = 20;
 constexpr int conv_smem_floats(int bm, int bn, bool bf16, bool halo = false) {
     const int full = 2 * bm * BK + 2 * BK * bn;
     if (!bf16 || (bm == 128 && bn == 32)) return full;
-    const int stages = halo ? 3 * (bm + HALO_RUN_EXTRA) * HALO_PITCH + BK * bn : full / 2;
+    const int stages = halo ? 3 * (bm + HALO_RUN_EXTRA) * HALO_PITCH : full / 2;
     const int epilogue = bm * bn + (bm == 64 && bn == 128 ? 256 : 0);       // staging tile (+ the decoder heads' 1x1 rows)
     return stages > epilogue ? stages : epilogue;
 }
@@ -176,7 +176,8 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
         }
     }
     constexpr int NA = BM / 32;            // A-gather loads (16 B each) per thread and stage
-    constexpr int WN = BN >= 64 ? 2 : 1;   // wavefronts along couts
+    // (halo loop: a wavefront fetches its own weights, so with 128 couts each wavefront takes 32 of them and all 64 pixels)
+    constexpr int WN = HALO ? (BN >= 128 ? 4 : 2) : (BN >= 64 ? 2 : 1);   // wavefronts along couts
     constexpr int WM = 4 / WN;             // wavefronts along pixels
     constexpr int MT = BM / (32 * WM);     // 32-pixel MFMA tiles per wavefront   (BN=32: 1, else 2)
     constexpr int NT = BN / (32 * WN);     // 32-cout MFMA tiles per wavefront    (BN=128: 2, else 1)
@@ -524,11 +525,8 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
         //     per-lane base plus an immediate.
         constexpr int RUN = BM + HALO_RUN_EXTRA;                    // entries per run: BM + 2 pixels, then zeros
         constexpr int PITCH = HALO_PITCH;
-        constexpr int HALO_W = 3 * RUN * PITCH;                     // the W stages start here (floats)
-        constexpr int W_STG = BK * BN / 2;
         constexpr int NE = (3 * (BM + 2) + 31) / 32;                // halo elements (16 bytes of fp32) per thread and group
-        constexpr int BL = BN / 64;                                 // 16-byte W loads per thread and stage
-        static_assert(HALO_W % 4 == 0 && HALO_W + 2 * W_STG <= SMEM_FLOATS, "halo block and W stages must fit");
+        static_assert(3 * RUN * PITCH <= SMEM_FLOATS && NT == 1, "halo block must fit; one cout tile per wavefront");
         const int W_img = p.Wout, H_img = p.Hout;
         const int groups = p.cin_units >> 2, groups0 = p.src[0].units >> 2;
         const int f4h = tid & 7, prow_h = tid >> 3;
@@ -578,82 +576,75 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
             for (int i = 0; i < NE; ++i)
                 if (i < NE - 1 || last_live) smem2[hst[i]] = pack_bf16x4(hreg[i]);
         };
-        float4 wreg[BL];
-        auto w_load = [&](int g, int t) {                       // stage (t, g) of the packed weights: chunk t groups + g
+        // The weights never touch LDS: a lane's B operand of an MFMA - eight k of one cout - is one 16-byte piece of the
+        // packed image [k / 8][cout][k % 8], and each wavefront multiplies its own 32 couts, so it requests exactly its
+        // operands (two 16-byte loads per lane and stage) straight into registers, two stages ahead, in a ring of three
+        // register sets (nine stages per group = three turns of the ring: the set of a stage is a compile-time index).
+        // No LDS writes, no W reads, and no barrier inside a channel group: the wavefronts only meet when the halo changes.
+        const int w_vo = (hi * BN + wn * 32 + m) * 16;
+        float4 wq[3][2];
+        auto w_load = [&](int set, int g, int t) {              // stage (t, g) of the packed weights: chunk t groups + g
             int chunk = t * groups + g;
             chunk = chunk < p.k_chunks ? chunk : p.k_chunks - 1;                        // past the end: any chunk
             const int soff = chunk * (BK * BN * 2);
-#pragma unroll
-            for (int k = 0; k < BL; ++k) wreg[k] = to_float4(__builtin_amdgcn_raw_buffer_load_b128(wrs, tid * 16, soff + k * 4096, 0));
+            wq[set][0] = to_float4(__builtin_amdgcn_raw_buffer_load_b128(wrs, w_vo, soff, 0));
+            wq[set][1] = to_float4(__builtin_amdgcn_raw_buffer_load_b128(wrs, w_vo, soff + 2 * BN * 16, 0));
         };
-        // this lane's window: tile pixel pl, slot hi of each entry; the zero entry for the taps that would wrap around a row end
-        const int pl_h = wm * 32 + m;
-        int rdC = pl_h * PITCH + hi * 4, rdL, rdR;
-        {
+        // this lane's windows: tile pixels pl (+ 32 for the second pixel tile), slot hi of each entry; the zero entry for the
+        // taps that would wrap around a row end
+        int rdC[MT], rdL[MT], rdR[MT];
+#pragma unroll
+        for (int tt = 0; tt < MT; ++tt) {
+            const int pl_h = wm * (32 * MT) + tt * 32 + m;
             const int gp = pix0 + pl_h;
             const int g_ = gp < M ? gp : 0;
             const int o = fast_div(g_, p.mg_hw, p.sh_hw);
             const int ppi = g_ - o * HWout;
             const int y = fast_div(ppi, p.mg_w, p.sh_w), x = ppi - y * W_img;
             const int rdZ = (BM + 2) * PITCH + hi * 4;
-            rdL = x == 0 ? rdZ : rdC;
-            rdR = x == W_img - 1 ? rdZ - 2 * PITCH : rdC;
+            rdC[tt] = pl_h * PITCH + hi * 4;
+            rdL[tt] = x == 0 ? rdZ : rdC[tt];
+            rdR[tt] = x == W_img - 1 ? rdZ - 2 * PITCH : rdC[tt];
         }
-        int w_rd_cur = HALO_W + (hi * BN + wn * (32 * NT) + m) * 4, w_rd_oth = w_rd_cur + W_STG;
-        float4* const smem4 = reinterpret_cast<float4*>(smem);
-        int w_st_cur = HALO_W / 4 + tid, w_st_oth = w_st_cur + W_STG / 4;        // in 16-byte units (keeps the stores ds_write_b128)
-        // prologue: zero entries, group 0's halo, stage 0's weights; group 1's halo and stage 1's weights stay in flight
+        // prologue: zero entries, group 0's halo; group 1's halo and the first two stages' weights stay in flight
         if (tid < 3 * PITCH) smem[((tid / PITCH) * RUN + BM + 2) * PITCH + tid % PITCH] = 0.f;
         halo_load(0);
-        w_load(0, 0);
         halo_store();
-#pragma unroll
-        for (int k = 0; k < BL; ++k) smem4[w_st_cur + 256 * k] = wreg[k];
-        w_load(0, 1);
+        w_load(0, 0, 0);
+        w_load(1, 0, 1);
         if (groups > 1) halo_load(1);
         __syncthreads();
         for (int g = 0; g < groups; ++g) {
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int dy = t / 3, dx = t % 3;
-                const int rd = (dx == 0 ? rdL : dx == 2 ? rdR : rdC) + (dy * RUN + dx) * PITCH;
+                bf16x8 a8[MT][2];
 #pragma unroll
-                for (int kh = 0; kh < 2; ++kh) {
-                    const bf16x8 a8 = load_bf16x8(&smem[rd + kh * 8]);
-                    bf16x8 b8[NT];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) b8[nt] = load_bf16x8(&smem[w_rd_cur + (2 * kh * BN + 32 * nt) * 4]);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        acc[nt] = mfma_bf16_32x32x16(a8, b8[nt], acc[nt]);
-                        if (kh == 0 && nt == 0) {
-                            // the next stage's weights (in registers since the stage before this one) go to the idle buffer
-#pragma unroll
-                            for (int k = 0; k < BL; ++k) smem4[w_st_oth + 256 * k] = wreg[k];
-                        }
-                        if (kh == 1 && nt == 0) {
-                            // ... and the registers take the stage after that: (t + 2, g), wrapping into the next group
-                            if (t + 2 < 9) w_load(g, t + 2);
-                            else w_load(g + 1, t + 2 - 9);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                for (int tt = 0; tt < MT; ++tt) {
+                    const int rd = (dx == 0 ? rdL[tt] : dx == 2 ? rdR[tt] : rdC[tt]) + (dy * RUN + dx) * PITCH;
+                    a8[tt][0] = load_bf16x8(&smem[rd]);
+                    a8[tt][1] = load_bf16x8(&smem[rd + 8]);
                 }
-                {
-                    const int a = w_rd_cur, b = w_st_cur;
-                    w_rd_cur = w_rd_oth;  w_rd_oth = a;
-                    w_st_cur = w_st_oth;  w_st_oth = b;
+                const bf16x8 b0 = bits_bf16x8(wq[t % 3][0]), b1 = bits_bf16x8(wq[t % 3][1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tt = 0; tt < MT; ++tt) {
+                    acc[tt] = mfma_bf16_32x32x16(a8[tt][0], b0, acc[tt]);
+                    acc[tt] = mfma_bf16_32x32x16(a8[tt][1], b1, acc[tt]);
                 }
-                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+                // the set this stage leaves takes the stage after next: (t + 2, g), wrapping into the next group
+                if (t + 2 < 9) w_load((t + 2) % 3, g, t + 2);
+                else w_load((t + 2) % 3, g + 1, t + 2 - 9);
             }
             if (g + 1 < groups) {
-                // every wavefront has read its last window of this group: the next group's halo (requested a group ago) replaces it
-                halo_store();
+                __syncthreads();                                   // every wavefront has read its last window of this group
+                halo_store();                                      // (the next group's halo was requested a group ago)
                 __syncthreads();
                 if (g + 2 < groups) halo_load(g + 2);
             }
         }
+        __syncthreads();                                           // the epilogue stages its tile over the halo
     } else {
     // ---- software pipeline ------------------------------------------------------------------------------------
     // While stage s is multiplied out of LDS buffer s&1, stage s+1 sits in registers (requested one iteration
@@ -1107,8 +1098,13 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
     if constexpr (BM == 64 && BN == 128) {
         if (p.epi == FIERY_EPI_HEADS) {
             float* w2 = smem + BM * BN;                              // [<= 4 outputs of this cout tile][64], behind the tile
-            stage_tile(acc[0], 0, 0, BN);
-            stage_tile(acc[1], 0, 1, BN);
+            if constexpr (NT == 2) {
+                stage_tile(acc[0], 0, 0, BN);
+                stage_tile(acc[1], 0, 1, BN);
+            } else {                                                 // (halo loop: two pixel tiles, one cout tile per wavefront)
+                stage_tile(acc[0], 0, 0, BN);
+                stage_tile(acc[1], 1, 0, BN);
+            }
             // the final 1x1 rows whose 64-channel group lies in this 128-cout tile (at most 4: one per wavefront)
             int my_out = -1;
             {

@@ -71,6 +71,12 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(float4 lo, float4 hi) {
     return v;
 }
 __device__ __forceinline__ bf16x8 load_bf16x8(const float* p) { return *reinterpret_cast<const bf16x8*>(p); }
+// sixteen bytes that already hold eight bf16 values (a piece of the packed weights fetched into registers)
+__device__ __forceinline__ bf16x8 bits_bf16x8(float4 v) {
+    bf16x8 r;
+    __builtin_memcpy(&r, &v, 16);
+    return r;
+}
 // four fp32 -> four bf16 (two v_cvt_pk_bf16_f32), as the eight bytes they occupy in memory
 __device__ __forceinline__ uint2 pack_bf16x4(float4 v) {
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));

@@ -50,6 +50,11 @@ inline uint2 pack_bf16x4(float4 v) {
     __builtin_memcpy(&r, h, 8);
     return r;
 }
+inline bf16x8 bits_bf16x8(float4 v) {
+    bf16x8 r;
+    __builtin_memcpy(&r, &v, 16);
+    return r;
+}
 inline bf16x8 load_bf16x8(const float* p) {
     bf16x8 r;
     __builtin_memcpy(&r, p, 16);

@@ -4,7 +4,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r3_h
+O=$R/gpurun_out/${RUN_TAG:-r3_h}
 mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "temporal_model_branches or bf16" > $O/pytest_subset.txt 2>&1; tail -3 $O/pytest_subset.txt
 for halo in 1 0; do
