@@ -374,7 +374,13 @@ int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, bool launch) {
         return check_launch("conv_fwd (bf16)");
     }
     bool launched;
-    if (half_tiles) launched = bn == 128 ? conv_launch_64x128(p, grid, hs, variant, clk) : conv_launch_64x64(p, grid, hs, variant, clk);
+    // fp32 halo loop (FIERY_CONV_HALO_F32=1; A/B switch while it is being measured): the same layers as the bf16 one
+    bool halo_f32 = false;
+    if (const char* on = getenv("FIERY_CONV_HALO_F32"))
+        halo_f32 = atoi(on) != 0 && variant == kConvAligned && bm == 64 && bn >= 64 && d->kT == 1 && d->kH == 3 && d->kW == 3 && d->stride == 1 &&
+                   d->padH == 1 && d->padW == 1 && d->Hin == d->Hout && d->Win == d->Wout && p.M + 2ll * d->Wout + 2 < (1ll << 31);
+    if (halo_f32) launched = conv_launch_f32_halo(p, bn, grid, hs);
+    else if (half_tiles) launched = bn == 128 ? conv_launch_64x128(p, grid, hs, variant, clk) : conv_launch_64x64(p, grid, hs, variant, clk);
     else if (bn == 128) launched = conv_launch_128x128(p, grid, hs, variant, clk);
     else if (bn == 64) launched = conv_launch_128x64(p, grid, hs, variant, clk);
     else launched = conv_launch_128x32(p, grid, hs, variant, clk);

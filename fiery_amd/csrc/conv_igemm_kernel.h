@@ -109,6 +109,8 @@ bool conv_launch_64x128(const ConvP& p, dim3 grid, hipStream_t stream, int varia
 // bf16 matrix-core form of the scalar-addressed kernel (weights packed by fiery_conv_pack_weights_bf16 in p.w); returns
 // false when (bm, bn) has no such kernel
 bool conv_launch_bf16(const ConvP& p, int bm, int bn, dim3 grid, hipStream_t stream, bool halo = false);
+// fp32 halo loop (3 x 3 / stride 1 layers on 64-pixel tiles; bn = 64 or 128)
+bool conv_launch_f32_halo(const ConvP& p, int bn, dim3 grid, hipStream_t stream);
 
 #ifdef FIERY_CONV_KERNEL_TU
 namespace {
@@ -131,12 +133,14 @@ __device__ __forceinline__ int fast_div(int g, unsigned m, int s) {
 // Workgroups of one tile shape that fit a CU, as its LDS (two A stages + two W stages) allows, capped where the tile's
 // registers would not follow: one wavefront per workgroup and SIMD, so this is also the waves-per-SIMD target that the
 // register allocation is held to (without it the compiler aims one notch too high for the 64 x 128 tile and spills).
-// (halo loop, 3 x 3: three runs of bm + 2 pixels + one zero entry, 80 bytes = 20 floats per entry, and two W stages)
-constexpr int HALO_RUN_EXTRA = 3, HALO_PITCH = 20;
+// (halo loop, 3 x 3: three runs of bm + 2 pixels + one zero entry; an entry is 32 channels - 64 bytes of bf16 or 128 of fp32 -
+// plus 16 bytes that keep ds_read_b128 conflict-free: 20 / 36 floats)
+constexpr int HALO_RUN_EXTRA = 3;
+constexpr int halo_pitch(bool bf16) { return bf16 ? 20 : 36; }
 constexpr int conv_smem_floats(int bm, int bn, bool bf16, bool halo = false) {
     const int full = 2 * bm * BK + 2 * BK * bn;
-    if (!bf16 || (bm == 128 && bn == 32)) return full;
-    const int stages = halo ? 3 * (bm + HALO_RUN_EXTRA) * HALO_PITCH : full / 2;
+    if (!halo && (!bf16 || (bm == 128 && bn == 32))) return full;
+    const int stages = halo ? 3 * (bm + HALO_RUN_EXTRA) * halo_pitch(bf16) : full / 2;
     const int epilogue = bm * bn + (bm == 64 && bn == 128 ? 256 : 0);       // staging tile (+ the decoder heads' 1x1 rows)
     return stages > epilogue ? stages : epilogue;
 }
@@ -147,6 +151,7 @@ constexpr int conv_waves_per_simd(int bm, int bn, bool aligned = false, bool bf1
     const int by_lds = 163840 / (conv_smem_floats(bm, bn, bf16, halo) * 4);
     int cap = ((bm == 64 && bn == 64) || (FIERY_TAIL_FOUR_PER_CU && bm == 128 && bn == 32 && aligned)) ? 4 : 3;
     if (bf16 && !(bm == 128 && bn == 32)) cap = FIERY_BF16_WAVES;         // (128 x 32: its chained epilogue needs 150)
+    if (halo && !bf16) cap = 3;
     return by_lds < cap ? by_lds : cap;
 }
 
@@ -163,7 +168,7 @@ constexpr int conv_waves_per_simd(int bm, int bn, bool aligned = false, bool bf1
 template <int BM, int BN, bool CLK = false, int PRIO = 0, bool SMALLCIN = false, bool ALIGNED = false, bool BF16 = false, bool HALO = false>
 __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK && !BF16, BF16, HALO)) void k_conv_igemm(ConvP p) {
     static_assert(!BF16 || (ALIGNED && !SMALLCIN && !CLK), "the bf16 form exists for the scalar-addressed loop");
-    static_assert(!HALO || (BF16 && BM == 64 && BN >= 64), "the halo loop exists for the bf16 form's 64-pixel tiles");
+    static_assert(!HALO || (ALIGNED && !SMALLCIN && !CLK && BM == 64 && BN >= 64), "the halo loop exists for the 64-pixel tiles");
     unsigned long long clk_entry = 0;
     if constexpr (CLK) clk_entry = clock64();
     if constexpr (PRIO == 1) {
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
     // one LDS block: two A stages, two W stages; the epilogue reuses it as a BM x BN staging tile.  The bf16 form's stages
     // are half the size (both operands are bf16 there), so its block is as large as the epilogue needs and no larger - the
     // 128 x 32 tile excepted, whose chained epilogue lays fp32 operand tiles over the stages.
-    constexpr bool HALF_STAGES = BF16 && !(BM == 128 && BN == 32);
+    constexpr bool HALF_STAGES = BF16 && !(BM == 128 && BN == 32) && !HALO;
     constexpr int A_STAGE = HALF_STAGES ? BM * (BK / 2) : BM * BK;        // floats between the two A stages
     constexpr int W_STAGE = HALF_STAGES ? BK * BN / 2 : BK * BN;
     constexpr int W_BASE = 2 * A_STAGE;
@@ -524,7 +529,9 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
         //     different slots of the 256-byte bank row for every lane group of ds_read_b128, and every tap's address is a
         //     per-lane base plus an immediate.
         constexpr int RUN = BM + HALO_RUN_EXTRA;                    // entries per run: BM + 2 pixels, then zeros
-        constexpr int PITCH = HALO_PITCH;
+        constexpr int PITCH = halo_pitch(BF16);                     // floats between entries
+        constexpr int NQ = BF16 ? 2 : 4;                            // 16-byte operand pieces per lane, entry / cout and stage
+        constexpr int W_CHUNK = BK * BN * (BF16 ? 2 : 4);           // bytes of one stage of the packed weights
         constexpr int NE = (3 * (BM + 2) + 31) / 32;                // halo elements (16 bytes of fp32) per thread and group
         static_assert(3 * RUN * PITCH <= SMEM_FLOATS && NT == 1, "halo block must fit; one cout tile per wavefront");
         const int W_img = p.Wout, H_img = p.Hout;
@@ -549,14 +556,15 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
             const int e1 = 4 * (b * static_cast<int>(p.src[1].bstride) + (tl + p.tinadd) * static_cast<int>(p.src[1].tstride) + ppi * p.src[1].ld + kofs);
             hv0[i] = ok ? e0 : static_cast<int>(0x80000000u);
             hv1[i] = ok ? e1 : static_cast<int>(0x80000000u);
-            hst[i] = (ent + r) * (PITCH / 2) + (f4h >> 1) * 2 + (f4h & 1);      // 8-byte units; ent + r = r RUN + idx
+            // where the element goes (ent + r = r RUN + idx): bf16 - 8-byte units, half of slot f4 >> 1; fp32 - 16-byte units, slot f4
+            hst[i] = BF16 ? (ent + r) * (PITCH / 2) + (f4h >> 1) * 2 + (f4h & 1) : (ent + r) * (PITCH / 4) + f4h;
         }
         const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src[0].ptr), 0, p.src[0].ext_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src[1].ptr ? p.src[1].ptr : p.src[0].ptr), 0,
                                                                                p.src[1].ptr ? p.src[1].ext_bytes : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<char*>(reinterpret_cast<const char*>(p.w) + static_cast<long long>(tile_n) * p.k_chunks * (BK * BN * 2)), 0,
-            p.k_chunks * (BK * BN * 2), 0x00020000);
+            const_cast<char*>(reinterpret_cast<const char*>(p.w) + static_cast<long long>(tile_n) * p.k_chunks * W_CHUNK), 0,
+            p.k_chunks * W_CHUNK, 0x00020000);
         float4 hreg[NE];
         auto halo_load = [&](int g) {
             const bool second = g >= groups0;
@@ -571,10 +579,14 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
         };
         const bool last_live = prow_h + 32 * (NE - 1) < 3 * (BM + 2);     // (all but a thread's last element always exist)
         uint2* const smem2 = reinterpret_cast<uint2*>(smem);
+        float4* const smem4 = reinterpret_cast<float4*>(smem);
         auto halo_store = [&]() {
 #pragma unroll
             for (int i = 0; i < NE; ++i)
-                if (i < NE - 1 || last_live) smem2[hst[i]] = pack_bf16x4(hreg[i]);
+                if (i < NE - 1 || last_live) {
+                    if constexpr (BF16) smem2[hst[i]] = pack_bf16x4(hreg[i]);
+                    else smem4[hst[i]] = hreg[i];
+                }
         };
         // The weights never touch LDS: a lane's B operand of an MFMA - eight k of one cout - is one 16-byte piece of the
         // packed image [k / 8][cout][k % 8], and each wavefront multiplies its own 32 couts, so it requests exactly its
@@ -582,13 +594,13 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
         // register sets (nine stages per group = three turns of the ring: the set of a stage is a compile-time index).
         // No LDS writes, no W reads, and no barrier inside a channel group: the wavefronts only meet when the halo changes.
         const int w_vo = (hi * BN + wn * 32 + m) * 16;
-        float4 wq[3][2];
+        float4 wq[3][NQ];
         auto w_load = [&](int set, int g, int t) {              // stage (t, g) of the packed weights: chunk t groups + g
             int chunk = t * groups + g;
             chunk = chunk < p.k_chunks ? chunk : p.k_chunks - 1;                        // past the end: any chunk
-            const int soff = chunk * (BK * BN * 2);
-            wq[set][0] = to_float4(__builtin_amdgcn_raw_buffer_load_b128(wrs, w_vo, soff, 0));
-            wq[set][1] = to_float4(__builtin_amdgcn_raw_buffer_load_b128(wrs, w_vo, soff + 2 * BN * 16, 0));
+            const int soff = chunk * W_CHUNK;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) wq[set][q] = to_float4(__builtin_amdgcn_raw_buffer_load_b128(wrs, w_vo, soff + q * (2 * BN * 16), 0));
         };
         // this lane's windows: tile pixels pl (+ 32 for the second pixel tile), slot hi of each entry; the zero entry for the
         // taps that would wrap around a row end
@@ -618,19 +630,51 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int dy = t / 3, dx = t % 3;
-                bf16x8 a8[MT][2];
+                int rd[MT];
 #pragma unroll
-                for (int tt = 0; tt < MT; ++tt) {
-                    const int rd = (dx == 0 ? rdL[tt] : dx == 2 ? rdR[tt] : rdC[tt]) + (dy * RUN + dx) * PITCH;
-                    a8[tt][0] = load_bf16x8(&smem[rd]);
-                    a8[tt][1] = load_bf16x8(&smem[rd + 8]);
-                }
-                const bf16x8 b0 = bits_bf16x8(wq[t % 3][0]), b1 = bits_bf16x8(wq[t % 3][1]);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int tt = 0; tt < MT; ++tt) rd[tt] = (dx == 0 ? rdL[tt] : dx == 2 ? rdR[tt] : rdC[tt]) + (dy * RUN + dx) * PITCH;
+                if constexpr (BF16) {
+                    bf16x8 a8[MT][2];
 #pragma unroll
-                for (int tt = 0; tt < MT; ++tt) {
-                    acc[tt] = mfma_bf16_32x32x16(a8[tt][0], b0, acc[tt]);
-                    acc[tt] = mfma_bf16_32x32x16(a8[tt][1], b1, acc[tt]);
+                    for (int tt = 0; tt < MT; ++tt) {
+                        a8[tt][0] = load_bf16x8(&smem[rd[tt]]);
+                        a8[tt][1] = load_bf16x8(&smem[rd[tt] + 8]);
+                    }
+                    const bf16x8 b0 = bits_bf16x8(wq[t % 3][0]), b1 = bits_bf16x8(wq[t % 3][1]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int tt = 0; tt < MT; ++tt) {
+                        acc[tt] = mfma_bf16_32x32x16(a8[tt][0], b0, acc[tt]);
+                        acc[tt] = mfma_bf16_32x32x16(a8[tt][1], b1, acc[tt]);
+                    }
+                } else {
+                    // fp32: a lane's piece q holds its row's (its cout's) k = 8 q + 4 hi + j, j < 4: four MFMA k-steps; piece
+                    // q + 1 is read from LDS while the MFMAs of piece q run
+                    float4 a_cur[MT], a_nxt[MT];
+#pragma unroll
+                    for (int tt = 0; tt < MT; ++tt) a_cur[tt] = *reinterpret_cast<const float4*>(&smem[rd[tt]]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (q < 3) {
+#pragma unroll
+                            for (int tt = 0; tt < MT; ++tt) a_nxt[tt] = *reinterpret_cast<const float4*>(&smem[rd[tt] + (q + 1) * 8]);
+                        }
+                        const float4 b4 = wq[t % 3][q];
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float bv = j == 0 ? b4.x : j == 1 ? b4.y : j == 2 ? b4.z : b4.w;
+#pragma unroll
+                            for (int tt = 0; tt < MT; ++tt) {
+                                const float av = j == 0 ? a_cur[tt].x : j == 1 ? a_cur[tt].y : j == 2 ? a_cur[tt].z : a_cur[tt].w;
+                                acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tt], 0, 0, 0);
+                            }
+                        }
+                        if (q < 3) {
+#pragma unroll
+                            for (int tt = 0; tt < MT; ++tt) a_cur[tt] = a_nxt[tt];
+                        }
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // the set this stage leaves takes the stage after next: (t + 2, g), wrapping into the next group
@@ -1252,6 +1296,10 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
 template <int BM, int BN>
 void conv_launch_tile_bf16(const ConvP& p, dim3 grid, hipStream_t hs) {
     hipLaunchKernelGGL((k_conv_igemm<BM, BN, false, 0, false, true, true>), grid, dim3(256), 0, hs, p);
+}
+template <int BM, int BN>
+void conv_launch_tile_f32_halo(const ConvP& p, dim3 grid, hipStream_t hs) {
+    hipLaunchKernelGGL((k_conv_igemm<BM, BN, false, 0, false, true, false, true>), grid, dim3(256), 0, hs, p);
 }
 template <int BM, int BN>
 void conv_launch_tile_bf16_halo(const ConvP& p, dim3 grid, hipStream_t hs) {

@@ -429,6 +429,50 @@ def test_conv2d_bf16_halo_loop(sim, monkeypatch, cin, cout, hw, n):
     assert not torch.equal(outs['1'], outs['0']) or cin == 32        # (it really is the other loop: the sums round differently)
 
 
+@pytest.mark.parametrize('cin,cout,hw,n', [(32, 64, (9, 14), 2), (64, 128, (7, 5), 3), (128, 64, (3, 70), 1), (96, 128, (1, 9), 2),
+                                           (32, 64, (66, 1), 1)])
+def test_conv2d_fp32_halo_loop(sim, monkeypatch, cin, cout, hw, n):
+    """The halo loop in fp32 (FIERY_CONV_HALO_F32=1): the same windows, fp32 entries of 144 bytes, weights from global memory
+    into each wavefront's MFMA operands - against the fp32 convolution and the scalar-addressed loop (another summation order)."""
+    monkeypatch.setenv('FIERY_CONV_TILE_M', '64')
+    g = torch.Generator().manual_seed(cin + cout + hw[0] + 1)
+    x = torch.randn(n, cin, *hw, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    res = torch.randn(n, cout, *hw, generator=g)
+    src, rbuf = _to_buf(x), _to_buf(res)
+    op = ConvOp(sim, w, identity_chan_map(cin), (src.C // 8, 0), scale, shift, 'cpu', act=native.ACT_RELU)
+    outs = {}
+    for halo in ('1', '0'):
+        monkeypatch.setenv('FIERY_CONV_HALO_F32', halo)
+        out = Buf.alloc(n, *hw, cout, 'cpu')
+        op([src], out, res=rbuf)
+        outs[halo] = out.to_nchw()[:, :cout]
+    want = F.relu(F.conv2d(x, w, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)) + res
+    assert torch.allclose(outs['1'], want, **TOL), (outs['1'] - want).abs().max()
+    assert torch.allclose(outs['1'], outs['0'], rtol=1e-5, atol=1e-5)
+    assert not torch.equal(outs['1'], outs['0']) or cin == 32
+
+
+def test_gru_epilogues_on_the_fp32_halo_loop(sim, monkeypatch):
+    """Two sources (the GRU's [x, h]) and both GRU epilogues through the fp32 halo loop."""
+    monkeypatch.setenv('FIERY_CONV_TILE_M', '64')
+    monkeypatch.setenv('FIERY_CONV_HALO_F32', '1')
+    g = torch.Generator().manual_seed(92)
+    ch = 32
+    x, h = torch.randn(2, ch, 8, 10, generator=g), torch.randn(2, ch, 8, 10, generator=g)
+    wg = torch.randn(2 * ch, 2 * ch, 3, 3, generator=g) / (2 * ch * 9) ** 0.5
+    bg = torch.randn(2 * ch, generator=g) * 0.1
+    xb, hb = _to_buf(x), _to_buf(h)
+    gates = ConvOp(sim, wg, identity_chan_map(ch) + identity_chan_map(ch, offset=ch), (ch // 8, ch // 8), torch.ones(2 * ch), bg,
+                   'cpu', epi=native.EPI_GRU_GATES)
+    U, RH = Buf.alloc(2, 8, 10, ch, 'cpu'), Buf.alloc(2, 8, 10, ch, 'cpu')
+    gates([xb, hb], U, out2=RH, aux0=hb)
+    pre = F.conv2d(torch.cat([x, h], 1), wg, padding=1) + bg.view(1, -1, 1, 1)
+    assert torch.allclose(U.to_nchw(), torch.sigmoid(pre[:, :ch]), **TOL)
+    assert torch.allclose(RH.to_nchw(), (1 - torch.sigmoid(pre[:, ch:])) * h, **TOL)
+
+
 def test_bf16_form_falls_back_to_fp32_where_it_does_not_apply(sim):
     """13 input channels cannot take the scalar-addressed loop: the launch runs the fp32 kernel and is exact again."""
     g = torch.Generator().manual_seed(77)
