@@ -366,8 +366,8 @@ int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, bool launch) {
     if (bf16) {
         FIERY_REQUIRE(aligned16(d->weights_bf16), "conv_fwd: bf16 weights must be 16-byte aligned");
         p.w = static_cast<const float*>(d->weights_bf16);
-        // 3 x 3 / stride 1 / 'same' layers on 64-pixel tiles take the halo loop (conv_igemm_kernel.h); FIERY_CONV_HALO=0: A/B runs
-        bool halo = bm == 64 && bn >= 64 && d->kT == 1 && d->kH == 3 && d->kW == 3 && d->stride == 1 && d->padH == 1 && d->padW == 1 &&
+        // 3 x 3 / stride 1 / 'same' layers with 64 couts or more take the halo loop (conv_igemm_kernel.h); FIERY_CONV_HALO=0: A/B runs
+        bool halo = bn >= 64 && !d->weights2 && d->kT == 1 && d->kH == 3 && d->kW == 3 && d->stride == 1 && d->padH == 1 && d->padW == 1 &&
                     d->Hin == d->Hout && d->Win == d->Wout && p.M + 2ll * d->Wout + 2 < (1ll << 31);
         if (const char* forced = getenv("FIERY_CONV_HALO")) halo = halo && atoi(forced) != 0;
         if (!conv_launch_bf16(p, bm, bn, grid, hs, halo)) return fail(FIERY_EINVAL, "conv_fwd: no bf16 kernel for the %d x %d tile", bm, bn);

@@ -152,6 +152,7 @@ constexpr int conv_waves_per_simd(int bm, int bn, bool aligned = false, bool bf1
     int cap = ((bm == 64 && bn == 64) || (FIERY_TAIL_FOUR_PER_CU && bm == 128 && bn == 32 && aligned)) ? 4 : 3;
     if (bf16 && !(bm == 128 && bn == 32)) cap = FIERY_BF16_WAVES;         // (128 x 32: its chained epilogue needs 150)
     if (halo && !bf16) cap = 3;
+    if (halo && bm == 128) cap = bn == 128 ? 2 : 3;                        // (13 halo elements per thread in flight)
     return by_lds < cap ? by_lds : cap;
 }
 
@@ -168,7 +169,7 @@ constexpr int conv_waves_per_simd(int bm, int bn, bool aligned = false, bool bf1
 template <int BM, int BN, bool CLK = false, int PRIO = 0, bool SMALLCIN = false, bool ALIGNED = false, bool BF16 = false, bool HALO = false>
 __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK && !BF16, BF16, HALO)) void k_conv_igemm(ConvP p) {
     static_assert(!BF16 || (ALIGNED && !SMALLCIN && !CLK), "the bf16 form exists for the scalar-addressed loop");
-    static_assert(!HALO || (ALIGNED && !SMALLCIN && !CLK && BM == 64 && BN >= 64), "the halo loop exists for the 64-pixel tiles");
+    static_assert(!HALO || (ALIGNED && !SMALLCIN && !CLK && BN >= 64 && (BM == 64 || BF16)), "the halo loop: 64-pixel tiles (bf16: 128 too), 64 couts or more");
     unsigned long long clk_entry = 0;
     if constexpr (CLK) clk_entry = clock64();
     if constexpr (PRIO == 1) {
@@ -533,7 +534,7 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
         constexpr int NQ = BF16 ? 2 : 4;                            // 16-byte operand pieces per lane, entry / cout and stage
         constexpr int W_CHUNK = BK * BN * (BF16 ? 2 : 4);           // bytes of one stage of the packed weights
         constexpr int NE = (3 * (BM + 2) + 31) / 32;                // halo elements (16 bytes of fp32) per thread and group
-        static_assert(3 * RUN * PITCH <= SMEM_FLOATS && NT == 1, "halo block must fit; one cout tile per wavefront");
+        static_assert(3 * RUN * PITCH <= SMEM_FLOATS && NT == 1 && (MT == 1 || MT == 2 || MT == 4), "halo block must fit; one cout tile per wavefront");
         const int W_img = p.Wout, H_img = p.Hout;
         const int groups = p.cin_units >> 2, groups0 = p.src[0].units >> 2;
         const int f4h = tid & 7, prow_h = tid >> 3;
@@ -1207,9 +1208,13 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
         // (the loop's last barrier has passed: the stages are free)
         stage_tile(acc[0], 0, 0, BN);
         if constexpr (NT == 2) stage_tile(acc[1], 0, 1, BN);
-        if constexpr (MT == 2) {
+        if constexpr (MT >= 2) {
             stage_tile(acc[NT], 1, 0, BN);
             if constexpr (NT == 2) stage_tile(acc[NT + 1], 1, 1, BN);
+        }
+        if constexpr (MT == 4) {                                   // (halo loop, 128 x 128: one wavefront holds all four pixel tiles)
+            stage_tile(acc[2 * NT], 2, 0, BN);
+            stage_tile(acc[3 * NT], 3, 0, BN);
         }
         __syncthreads();
         store_rows(BN, tile_n * BN, p.scale, p.shift, p.act, true);
@@ -1281,9 +1286,13 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
     // compile-time tile indices keep the accumulators in registers
     emit(acc[0], 0, 0);
     if constexpr (NT == 2) emit(acc[1], 0, 1);
-    if constexpr (MT == 2) {
+    if constexpr (MT >= 2) {
         emit(acc[NT], 1, 0);
         if constexpr (NT == 2) emit(acc[NT + 1], 1, 1);
+    }
+    if constexpr (MT == 4) {
+        emit(acc[2 * NT], 2, 0);
+        emit(acc[3 * NT], 3, 0);
     }
 }
 

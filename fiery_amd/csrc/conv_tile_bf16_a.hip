@@ -11,4 +11,10 @@ bool conv_launch_bf16_m128(const ConvP& p, int bn, dim3 grid, hipStream_t stream
     else return false;
     return true;
 }
+bool conv_launch_bf16_halo_m128(const ConvP& p, int bn, dim3 grid, hipStream_t stream) {
+    if (bn == 64) conv_launch_tile_bf16_halo<128, 64>(p, grid, stream);
+    else if (bn == 128) conv_launch_tile_bf16_halo<128, 128>(p, grid, stream);
+    else return false;
+    return true;
+}
 }  // namespace fiery

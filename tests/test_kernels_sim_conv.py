@@ -405,11 +405,12 @@ def test_conv2d_bf16_form(sim, monkeypatch, cin, cout, k, stride, hw, tile_m):
     (96, 128, (1, 9), 2),        # one-row images: no tap above or below
     (32, 64, (66, 1), 1),        # one-column images: every left / right tap is outside
 ])
-def test_conv2d_bf16_halo_loop(sim, monkeypatch, cin, cout, hw, n):
+@pytest.mark.parametrize('tile_m', ['64', '128'])
+def test_conv2d_bf16_halo_loop(sim, monkeypatch, cin, cout, hw, n, tile_m):
     """3 x 3 / stride 1 layers on 64-pixel tiles take the halo loop (the tile and its neighbours fetched once per 32-channel
     group, the nine taps as shifted windows of that block): against the rounded-operand convolution, and against the
     scalar-addressed loop it replaces (same products, another order of the fp32 additions)."""
-    monkeypatch.setenv('FIERY_CONV_TILE_M', '64')
+    monkeypatch.setenv('FIERY_CONV_TILE_M', tile_m)
     g = torch.Generator().manual_seed(cin + cout + hw[0])
     x = torch.randn(n, cin, *hw, generator=g)
     w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
@@ -485,7 +486,7 @@ def test_bf16_form_falls_back_to_fp32_where_it_does_not_apply(sim):
     assert torch.allclose(out.to_nchw()[:, :32], F.conv2d(x, w, padding=1), **TOL)
 
 
-@pytest.mark.parametrize('tile_m', [None, '64'])
+@pytest.mark.parametrize('tile_m', [None, '64', '128'])
 def test_gru_epilogues_and_chained_tail_on_the_bf16_form(sim, monkeypatch, tile_m):
     """The epilogues are the fp32 kernel's: GRU gate GEMM (two sources; on 64-pixel tiles the halo loop, whose channel
     groups come from one source each) and a Bottleneck tail with its chained 1x1."""
