@@ -947,23 +947,6 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
             const float* b2 = &Bs[0][0];
-            if constexpr (BF16) {
-                // the bf16 form rounds these operands too (h and the 1x1 weights, at operand-read time - two MFMAs per block
-                // instead of sixteen; the tile is small): lane (m, hi) of MFMA kh holds k = 16 kh + 8 hi + i = slots 4 kh + 2 hi, + 1
-                const int pl = wm * 32 + m, sw = (pl >> 1) & 7;
-#pragma unroll
-                for (int kh = 0; kh < 2; ++kh) {
-                    const int s0 = 4 * kh + 2 * hi;
-                    const bf16x8 a8 = pack_bf16x8(*reinterpret_cast<const float4*>(&As[0][pl * BK + ((s0 ^ sw) << 2)]),
-                                                  *reinterpret_cast<const float4*>(&As[0][pl * BK + (((s0 + 1) ^ sw) << 2)]));
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        const bf16x8 b8 = pack_bf16x8(*reinterpret_cast<const float4*>(&b2[(s0 * 64 + nt * 32 + m) * 4]),
-                                                      *reinterpret_cast<const float4*>(&b2[((s0 + 1) * 64 + nt * 32 + m) * 4]));
-                        acc2[nt] = mfma_bf16_32x32x16(a8, b8, acc2[nt]);
-                    }
-                }
-            } else
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int pl = wm * 32 + m;
@@ -1061,20 +1044,6 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
                 v16f acc3;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc3[r] = 0.f;
-                if constexpr (BF16) {
-                    const int pl = wm * 32 + m, sw = (pl >> 1) & 7;
-#pragma unroll
-                    for (int st = 0; st < 2; ++st)
-#pragma unroll
-                        for (int kh = 0; kh < 2; ++kh) {
-                            const int s0 = 4 * kh + 2 * hi;
-                            const bf16x8 a8 = pack_bf16x8(*reinterpret_cast<const float4*>(&As[st][pl * BK + ((s0 ^ sw) << 2)]),
-                                                          *reinterpret_cast<const float4*>(&As[st][pl * BK + (((s0 + 1) ^ sw) << 2)]));
-                            const bf16x8 b8 = pack_bf16x8(*reinterpret_cast<const float4*>(&Bs[st][(s0 * 32 + m) * 4]),
-                                                          *reinterpret_cast<const float4*>(&Bs[st][((s0 + 1) * 32 + m) * 4]));
-                            acc3 = mfma_bf16_32x32x16(a8, b8, acc3);
-                        }
-                } else
 #pragma unroll
                 for (int st = 0; st < 2; ++st)
 #pragma unroll
