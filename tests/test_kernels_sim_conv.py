@@ -517,6 +517,16 @@ def test_gru_epilogues_and_chained_tail_on_the_bf16_form(sim, monkeypatch, tile_
     mid = F.relu(F.conv2d(_bf16(t1), _bf16(w3), padding=1))
     want = F.relu(F.conv2d(mid, w1)) + res
     assert torch.allclose(out.to_nchw(), want, rtol=3e-5, atol=3e-5), (out.to_nchw() - want).abs().max()
+    # ... and with the next block's down-projection as a third stage (64 -> 32 on the finished tile, residual included; the chained
+    # GEMMs stay fp32 in the bf16 mode: on bf16 MFMAs they were measured no faster - 664.6 vs 671.7 samples/s, tools/runs/r3_l.sh)
+    w4 = torch.randn(32, 64, 1, 1, generator=g) / 8.0
+    s4, b4 = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g)
+    op3 = tail.chain_next(w4, s4, b4, native.ACT_RELU)
+    out3, nxt = Buf.alloc(1, 8, 10, 64, 'cpu'), Buf.alloc(1, 8, 10, 32, 'cpu')
+    op3([_to_buf(t1)], out3, res=_to_buf(res), out3=nxt)
+    assert torch.allclose(out3.to_nchw(), want, rtol=3e-5, atol=3e-5)
+    t = F.relu(F.conv2d(out3.to_nchw(), w4) * s4.view(1, -1, 1, 1) + b4.view(1, -1, 1, 1))
+    assert torch.allclose(nxt.to_nchw()[:, :32], t, rtol=5e-5, atol=5e-5), (nxt.to_nchw()[:, :32] - t).abs().max()
 
 
 # ---- training: weight gradient ------------------------------------------------------------------------------------------
