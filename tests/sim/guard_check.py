@@ -156,8 +156,9 @@ def main():
         randomise_weights(model)
         model.train()
         model._lib = lib
-        image, K, E, ego = make_inputs(2, model.receptive_field + model.n_future, 2, image_hw=tuple(cfg.IMAGE.FINAL_DIM), seed=3)
-        labels = torch.randn(2, 1 + model.n_future, 6, *model.bev_size, generator=g)
+        # (one sample, two cameras: four images through the trunk - the simulator pays per launch and per work-item)
+        image, K, E, ego = make_inputs(1, model.receptive_field + model.n_future, 2, image_hw=tuple(cfg.IMAGE.FINAL_DIM), seed=3)
+        labels = torch.randn(1, 1 + model.n_future, 6, *model.bev_size, generator=g)
         out = model(image, K, E, ego, labels)
         sum((v.float() ** 2).mean() for v in out.values() if v is not None).backward()
     else:
