@@ -144,6 +144,9 @@ constexpr int conv_smem_floats(int bm, int bn, bool bf16, bool halo = false) {
     const int epilogue = bm * bn + (bm == 64 && bn == 128 ? 256 : 0);       // staging tile (+ the decoder heads' 1x1 rows)
     return stages > epilogue ? stages : epilogue;
 }
+#ifndef FIERY_HALO_F32_WAVES
+#define FIERY_HALO_F32_WAVES 4    // fp32 halo loop: 1,024 instead of 768 workgroup slots (the 120,000-pixel maps: 1.83 rounds, not 2.44)
+#endif
 #ifndef FIERY_BF16_WAVES
 #define FIERY_BF16_WAVES 4        // waves per SIMD the bf16 form's register allocation is held to (128 registers)
 #endif
@@ -151,7 +154,7 @@ constexpr int conv_waves_per_simd(int bm, int bn, bool aligned = false, bool bf1
     const int by_lds = 163840 / (conv_smem_floats(bm, bn, bf16, halo) * 4);
     int cap = ((bm == 64 && bn == 64) || (FIERY_TAIL_FOUR_PER_CU && bm == 128 && bn == 32 && aligned)) ? 4 : 3;
     if (bf16 && !(bm == 128 && bn == 32)) cap = FIERY_BF16_WAVES;         // (128 x 32: its chained epilogue needs 150)
-    if (halo && !bf16) cap = 3;
+    if (halo && !bf16) cap = FIERY_HALO_F32_WAVES;
     if (halo && bm == 128) cap = bn == 128 ? 2 : 3;                        // (13 halo elements per thread in flight)
     return by_lds < cap ? by_lds : cap;
 }
@@ -585,8 +588,13 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
 #pragma unroll
             for (int i = 0; i < NE; ++i)
                 if (i < NE - 1 || last_live) {
-                    if constexpr (BF16) smem2[hst[i]] = pack_bf16x4(hreg[i]);
-                    else smem4[hst[i]] = hreg[i];
+                    if constexpr (BF16) {
+                        smem2[hst[i]] = pack_bf16x4(hreg[i]);
+                    } else {                                         // (recomputed: seven registers fewer held across the loop)
+                        const int ent = prow_h + 32 * i;
+                        const int r = ent >= 2 * (BM + 2) ? 2 : ent >= (BM + 2) ? 1 : 0;
+                        smem4[(ent + r) * (PITCH / 4) + f4h] = hreg[i];
+                    }
                 }
         };
         // The weights never touch LDS: a lane's B operand of an MFMA - eight k of one cout - is one 16-byte piece of the
@@ -595,6 +603,16 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
         // register sets (nine stages per group = three turns of the ring: the set of a stage is a compile-time index).
         // No LDS writes, no W reads, and no barrier inside a channel group: the wavefronts only meet when the halo changes.
         const int w_vo = (hi * BN + wn * 32 + m) * 16;
+        // (fp32: four pieces per stage would make the ring of three stages 48 registers; its pieces go through a ring of six
+        // instead, each requested five pieces - a stage and a quarter - before it is multiplied: 36 pieces per group = six turns)
+        constexpr int NP = 9 * NQ, RING = 6, AHEAD = 5;
+        float4 wp[RING];
+        auto w_piece = [&](int slot, int g, int pidx) {
+            const int gg = pidx >= NP ? g + 1 : g, pi = pidx >= NP ? pidx - NP : pidx;
+            int chunk = (pi / NQ) * groups + gg;
+            chunk = chunk < p.k_chunks ? chunk : p.k_chunks - 1;
+            wp[slot] = to_float4(__builtin_amdgcn_raw_buffer_load_b128(wrs, w_vo, chunk * W_CHUNK + (pi % NQ) * (2 * BN * 16), 0));
+        };
         float4 wq[3][NQ];
         auto w_load = [&](int set, int g, int t) {              // stage (t, g) of the packed weights: chunk t groups + g
             int chunk = t * groups + g;
@@ -623,8 +641,13 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
         if (tid < 3 * PITCH) smem[((tid / PITCH) * RUN + BM + 2) * PITCH + tid % PITCH] = 0.f;
         halo_load(0);
         halo_store();
-        w_load(0, 0, 0);
-        w_load(1, 0, 1);
+        if constexpr (BF16) {
+            w_load(0, 0, 0);
+            w_load(1, 0, 1);
+        } else {
+#pragma unroll
+            for (int pi = 0; pi < AHEAD; ++pi) w_piece(pi, 0, pi);
+        }
         if (groups > 1) halo_load(1);
         __syncthreads();
         for (int g = 0; g < groups; ++g) {
@@ -660,7 +683,7 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
 #pragma unroll
                             for (int tt = 0; tt < MT; ++tt) a_nxt[tt] = *reinterpret_cast<const float4*>(&smem[rd[tt] + (q + 1) * 8]);
                         }
-                        const float4 b4 = wq[t % 3][q];
+                        const float4 b4 = wp[(t * NQ + q) % RING];
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
@@ -675,12 +698,16 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
 #pragma unroll
                             for (int tt = 0; tt < MT; ++tt) a_cur[tt] = a_nxt[tt];
                         }
+                        __builtin_amdgcn_sched_barrier(0);
+                        w_piece((t * NQ + q + AHEAD) % RING, g, t * NQ + q + AHEAD);      // the slot the previous piece just left
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                // the set this stage leaves takes the stage after next: (t + 2, g), wrapping into the next group
-                if (t + 2 < 9) w_load((t + 2) % 3, g, t + 2);
-                else w_load((t + 2) % 3, g + 1, t + 2 - 9);
+                if constexpr (BF16) {
+                    // the set this stage leaves takes the stage after next: (t + 2, g), wrapping into the next group
+                    if (t + 2 < 9) w_load((t + 2) % 3, g, t + 2);
+                    else w_load((t + 2) % 3, g + 1, t + 2 - 9);
+                }
             }
             if (g + 1 < groups) {
                 __syncthreads();                                   // every wavefront has read its last window of this group
