@@ -145,7 +145,7 @@ constexpr int conv_smem_floats(int bm, int bn, bool bf16, bool halo = false) {
     return stages > epilogue ? stages : epilogue;
 }
 #ifndef FIERY_HALO_F32_WAVES
-#define FIERY_HALO_F32_WAVES 4    // fp32 halo loop: 1,024 instead of 768 workgroup slots (the 120,000-pixel maps: 1.83 rounds, not 2.44)
+#define FIERY_HALO_F32_WAVES 3    // fp32 halo loop (opt-in): 4 = 128 registers, 1,024 workgroup slots - measured equal (profiles/r3_conv_halo_f32_waves_ab.txt)
 #endif
 #ifndef FIERY_BF16_WAVES
 #define FIERY_BF16_WAVES 4        // waves per SIMD the bf16 form's register allocation is held to (128 registers)
