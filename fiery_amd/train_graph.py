@@ -82,6 +82,13 @@ def _unit_epilogue(cout, device):
     return _UNIT_EPILOGUE[key]
 
 
+# Matrix-core precision of the training graph's convolutions (forward and input gradient; the weight gradient stays fp32):
+# 'f32' - the reference's arithmetic - or 'bf16': operands rounded to bf16 on chip, fp32 accumulation, fp32 tensors in memory -
+# the library's counterpart of the reference's mixed-precision recipe (`PRECISION: 16`, fiery/configs/baseline.yml:6, trainer
+# flag `precision=16` in train.py:36).  `FIERY_TRAIN_PRECISION=bf16`, or set `train_graph.CONV_PRECISION` before the step.
+CONV_PRECISION = {'f32': native.PRECISION_F32, 'bf16': native.PRECISION_BF16}[os.environ.get('FIERY_TRAIN_PRECISION', 'f32')]
+
+
 def _launch_conv(lib, x_nhwc, weight, stride, pad):
     """Plain convolution (no bias, no activation) of a pixel-major tensor on the implicit-GEMM kernel.  The weights change
     every optimiser step, so they are packed per call (a device kernel) and no tile-height timing is done."""
@@ -90,7 +97,7 @@ def _launch_conv(lib, x_nhwc, weight, stride, pad):
     dev = x_nhwc.device
     scale, shift = _unit_epilogue(cout, dev)
     op = ConvOp(lib, weight, identity_chan_map(cin), (cp // 8, 0), scale, shift, dev, stride=stride, pad=(pad, pad),
-                precision=native.PRECISION_F32, tune=False)
+                precision=CONV_PRECISION, tune=False)
     ho, wo = op.out_hw(h, w)
     out = Buf.alloc(n, ho, wo, cout, dev, zero=False)
     op([Buf(x_nhwc, n, h, w, cp)], out)

@@ -76,6 +76,30 @@ def test_upsampling_plane_mean_and_strided_convolution_gradients_vs_fp64(sim):
         _grads_vs_fp64(lambda a, b: HipConv2d.apply(a, b, 2, pad, sim), lambda a, b: F.conv2d(a, b, None, 2, pad), [xx, ww], seed=cin + k)
 
 
+def test_bf16_operand_convolutions_in_the_training_graph(sim, monkeypatch):
+    """`train_graph.CONV_PRECISION = bf16` (the library's mixed-precision mode for training): forward and input gradient
+    are the convolutions of the bf16-ROUNDED operands with fp32 accumulation (exactly: compared at 3e-5 against torch on the
+    rounded operands), the weight gradient stays the fp32 one."""
+    from fiery_amd import native, train_graph as tg
+    monkeypatch.setattr(tg, 'CONV_PRECISION', native.PRECISION_BF16)
+    rb = lambda t: t.to(torch.bfloat16).float()
+    g = torch.Generator().manual_seed(12)
+    for cin, cout, k, stride, pad, hw in ((32, 64, 3, 1, 1, (9, 14)), (64, 128, 3, 1, 1, (7, 5)), (64, 32, 1, 1, 0, (6, 7)), (32, 64, 3, 2, 1, (9, 12))):
+        x = torch.randn(2, cin, *hw, generator=g)
+        w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+        xx, ww = x.clone().requires_grad_(), w.clone().requires_grad_()
+        y = tg.HipConv2d.apply(xx, ww, stride, pad, sim)
+        gy = torch.randn(y.shape, generator=g)
+        gx, gw = torch.autograd.grad(y, (xx, ww), gy)
+        want_y = F.conv2d(rb(x), rb(w), None, stride, pad)
+        assert torch.allclose(y, want_y, rtol=3e-5, atol=3e-5), (cin, cout, (y - want_y).abs().max())
+        want_gx = torch.nn.grad.conv2d_input(x.shape, rb(w), rb(gy), stride, pad)
+        assert torch.allclose(gx, want_gx, rtol=3e-5, atol=3e-5), (cin, cout, (gx - want_gx).abs().max())
+        want_gw = torch.nn.grad.conv2d_weight(x, w.shape, gy, stride, pad)
+        assert torch.allclose(gw, want_gw, rtol=1e-4, atol=1e-4), (cin, cout, (gw - want_gw).abs().max())
+        assert (y - F.conv2d(x, w, None, stride, pad)).abs().max() > 1e-4          # it IS the rounded-operand result
+
+
 def test_maxpool_and_ego_warp_all_gradients_vs_fp64(sim):
     """HipMaxPool2x2 (the pooled skip of a down-sampling Bottleneck, layers/convolutions.py:150-166: odd sizes padded with a
     zero row / column that takes part in the maximum) and HipEgoWarp (`cumulative_warp_features`, utils/geometry.py:225-253:
