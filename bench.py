@@ -63,6 +63,7 @@ def parse():
                          'configuration); bf16 = operands rounded at the matrix cores, fp32 accumulate (configs[3] / [4])')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-from-images', action='store_true', help='skip the secondary forward-from-images timing')
+    ap.add_argument('--no-bf16-mode', action='store_true', help='skip the secondary timing of the same step with bf16 matrix-core operands')
     ap.add_argument('--no-graph', action='store_true', help='enqueue every launch from the host each step instead of '
                                                             'replaying the captured hipGraph')
     ap.add_argument('--no-sample-streams', action='store_true', help='one stream for the whole batch instead of one '
@@ -331,6 +332,33 @@ def main():
                                   'ref_abs_max': round(v.abs().max().item(), 3),
                                   'within_1e-4': bool((got[k] - v).abs().max().item() <= 1e-4)}     # (the fp32 configuration's bar)
                               for k, v in want.items() if v is not None}
+        # secondary figure (BASELINE.json configs[3] / [4] are bf16 configurations): the same step with bf16 matrix-core
+        # operands, timed the same way after everything above - beside the headline, never as `value`; its outputs are
+        # compared with the fp32 step's of this run (the accuracy side of that mode: DESIGN.md section 4)
+        if world == 1 and args.precision == 'f32' and not args.no_bf16_mode and not frames_layout:
+            try:
+                with torch.no_grad():
+                    ref32 = {k: v.float().clone() for k, v in step().items() if v is not None}
+                    model.conv_precision = 'bf16'
+                    model.refresh_engine()
+                    bf_step = eager_step if (args.no_graph or graph_step is None) else graph_step
+                    for _ in range(max(args.warmup, 2)):
+                        got16 = bf_step()
+                    torch.cuda.synchronize()
+                    t16 = time.perf_counter()
+                    for _ in range(args.steps):
+                        got16 = bf_step()
+                    torch.cuda.synchronize()
+                    ms16 = (time.perf_counter() - t16) / args.steps * 1e3
+                    line['bf16_mode'] = {
+                        'value': round(B / ms16 * 1e3, 3), 'unit': 'samples/s', 'ms_per_step': round(ms16, 3),
+                        'dtype': 'bf16 matrix-core operands; fp32 accumulation, epilogues and tensors in HBM',
+                        'max_abs_diff_vs_fp32_step': {k: float(f'{(got16[k].float() - v).abs().max().item():.3e}') for k, v in ref32.items()},
+                        'what': f'the same workload and launch mode, {args.steps} steps after {max(args.warmup, 2)} warm-up'}
+            except Exception as e:                                   # noqa: BLE001  (the headline line must not depend on it)
+                line['bf16_mode'] = {'error': repr(e)[:200]}
+            finally:
+                model.conv_precision = 'f32'
         print(json.dumps(line), flush=True)
     if use_dist:
         import torch.distributed as dist

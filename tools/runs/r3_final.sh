@@ -40,19 +40,19 @@ cd /tmp
 for mode in one_stream sample_streams; do
   extra=""; [ $mode = one_stream ] && extra="--no-sample-streams"
   rm -rf /tmp/kt_$mode
-  timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/kt_$mode -o kt -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-from-images $extra > $O/kt_$mode.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/kt_$mode -o kt -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-from-images --no-bf16-mode $extra > $O/kt_$mode.log 2>&1
   db=$(find /tmp/kt_$mode -name "*.db" | head -1)
-  python $R/tools/rocprof_summary.py "$db" $O/kernel_stats_$mode.csv "round 3 ($mode): rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-from-images $extra"
+  python $R/tools/rocprof_summary.py "$db" $O/kernel_stats_$mode.csv "round 3 ($mode): rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-from-images --no-bf16-mode $extra"
   [ $mode = one_stream ] && python $R/tools/rocprof_sequence.py "$db" copyBuffer > $O/copybuffer_neighbours.txt 2>&1
 done
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$ctr
-  timeout 400 rocprofv3 --pmc $ctr --kernel-trace -d /tmp/pmc_$ctr -o pmc -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-from-images --no-graph --no-sample-streams > $O/pmc_$ctr.log 2>&1
+  timeout 400 rocprofv3 --pmc $ctr --kernel-trace -d /tmp/pmc_$ctr -o pmc -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-from-images --no-bf16-mode --no-graph --no-sample-streams > $O/pmc_$ctr.log 2>&1
   python $R/tools/pmc_dump.py "/tmp/pmc_$ctr/**/*.db" > $O/pmc_$ctr.txt 2>&1
 done
 python $R/tools/pmc_traffic.py $O/pmc_FETCH_SIZE.txt $O/pmc_WRITE_SIZE.txt $O/pmc_traffic.json
 rm -rf /tmp/pmc_mfma
-timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU --kernel-trace -d /tmp/pmc_mfma -o pmc -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-from-images --no-graph --no-sample-streams > $O/pmc_mfma.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU --kernel-trace -d /tmp/pmc_mfma -o pmc -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-from-images --no-bf16-mode --no-graph --no-sample-streams > $O/pmc_mfma.log 2>&1
 python $R/tools/pmc_dump.py "/tmp/pmc_mfma/**/*.db" > $O/pmc_mfma.txt 2>&1
 python $R/tools/pmc_mfma.py $O/pmc_mfma.txt > $O/mfma_util.txt 2>&1; tail -8 $O/mfma_util.txt
 head -10 $O/kernel_stats_one_stream.csv
