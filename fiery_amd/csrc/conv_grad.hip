@@ -14,6 +14,7 @@
 // a few hundred cycles of each other, and three of four requests are served by the CU's vector cache.
 // (The data gradient reuses the forward kernel with transposed, mirrored weights: fiery_amd/train_graph.py.)
 #include "common.h"
+#include <fiery_gfx950.h>
 
 #include <cstdlib>
 
@@ -147,9 +148,19 @@ struct Wgrad3P {
     int c_tiles, co_tiles, seg, n_seg, rows_per_wg, row_parts;
 };
 
+// BF16 (mixed-precision training, fiery_conv_wgrad_prec): the K dimension - output pixels - goes through
+// v_mfma_f32_32x32x16_bf16, sixteen pixels per instruction instead of two.  The operands stay fp32 in LDS in the same
+// [pixel][channel] image; a lane's eight pixels of one cout (channel) are eight ds_read_b32 of one bank column, rounded to
+// bf16 in registers (round to nearest even), and the ten input pixels a lane needs for the three horizontal taps are read
+// once: taps dx = 0 and dx = 2 share their bf16 pairs, dx = 1 pairs them the other way.  Per sixteen pixels and wavefront:
+// 38 LDS reads, 31 packed conversions, 9 MFMAs of 32 cycles where the fp32 form issues 72 of 64.  Products of bf16 values
+// are exact in fp32 and the accumulation is fp32: the result is the weight gradient of the ROUNDED dY and X.
+template <bool BF16>
 __global__ __launch_bounds__(256, 2) void k_conv_wgrad3x3(Wgrad3P p) {
-    __shared__ float s_g[kSegMax * 64];                       // dY segment [pixel][cout]
-    __shared__ float s_x[3][(kSegMax + 2) * 64];              // ring of X rows [pixel + 1][channel]; ring slot = input row % 3
+    constexpr int G_ROWS = BF16 ? 64 : kSegMax;               // (bf16: whole 16-pixel steps; rows past the segment hold zeros)
+    constexpr int X_ROWS = BF16 ? 66 : kSegMax + 2;
+    __shared__ float s_g[G_ROWS * 64];                        // dY segment [pixel][cout]
+    __shared__ float s_x[3][X_ROWS * 64];                     // ring of X rows [pixel + 1][channel]; ring slot = input row % 3
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 31, kk = lane >> 5;
     // which strip: blockIdx.x = ((co tile * c_tiles + c tile) * n_seg + segment), blockIdx.y = (image, row part)
@@ -169,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad3x3(Wgrad3P p) {
     const int q = tid & 15, prow = tid >> 4;                  // 16 pixel slots per pass, 16 passes cover 256 pixels
     const bool g_q_ok = co0 + 4 * q + 3 < p.g_ld, x_q_ok = c0 + 4 * q + 3 < p.x_ld;
     constexpr int kOutside = static_cast<int>(0x80000000u);
-    constexpr int G_SLOTS = (kSegMax + 15) / 16, X_SLOTS = (kSegMax + 2 + 15) / 16;
+    constexpr int G_SLOTS = (G_ROWS + 15) / 16, X_SLOTS = (X_ROWS + 15) / 16;
     float4 g_reg[G_SLOTS], x_reg[X_SLOTS];
     const float* g_img = p.g + img * p.g_istride;
     const float* x_img = p.x + img * p.x_istride;
@@ -203,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad3x3(Wgrad3P p) {
 #pragma unroll
         for (int i = 0; i < G_SLOTS; ++i) {
             const int px = prow + 16 * i;
-            if (px < kSegMax) *reinterpret_cast<float4*>(&s_g[px * 64 + 4 * q]) = g_reg[i];
+            if (px < G_ROWS) *reinterpret_cast<float4*>(&s_g[px * 64 + 4 * q]) = g_reg[i];
         }
     };
     auto store_x = [&](int iy) {
@@ -211,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad3x3(Wgrad3P p) {
 #pragma unroll
         for (int i = 0; i < X_SLOTS; ++i) {
             const int px = prow + 16 * i;
-            if (px < kSegMax + 2) *reinterpret_cast<float4*>(&dst[px * 64 + 4 * q]) = x_reg[i];
+            if (px < X_ROWS) *reinterpret_cast<float4*>(&dst[px * 64 + 4 * q]) = x_reg[i];
         }
     };
     v16f acc[9];
@@ -241,6 +252,29 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad3x3(Wgrad3P p) {
             const float* xr1 = s_x[y % 3];
             const float* xr2 = s_x[(y + 1) % 3];
             const int a_off = cow * 32 + m, b_off = cw * 32 + m;
+            if constexpr (BF16) {
+                const int k_steps16 = (p.seg + 15) >> 4;
+                for (int j = k_part; j < k_steps16; j += k_parts) {
+                    const int px = 16 * j + 8 * kk;                // this lane's eight output pixels: px .. px + 7
+                    float av[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) av[i] = s_g[(px + i) * 64 + a_off];
+                    const bf16x8 a8 = pack_bf16x8(make_float4(av[0], av[1], av[2], av[3]), make_float4(av[4], av[5], av[6], av[7]));
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const float* xr = r == 0 ? xr0 : r == 1 ? xr1 : xr2;
+                        float v[10];
+#pragma unroll
+                        for (int i = 0; i < 10; ++i) v[i] = xr[(px + i) * 64 + b_off];
+                        const bf16x8 b0 = pack_bf16x8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+                        const bf16x8 b1 = pack_bf16x8(make_float4(v[1], v[2], v[3], v[4]), make_float4(v[5], v[6], v[7], v[8]));
+                        const bf16x8 b2 = pack_bf16x8(make_float4(v[2], v[3], v[4], v[5]), make_float4(v[6], v[7], v[8], v[9]));
+                        acc[3 * r] = mfma_bf16_32x32x16(a8, b0, acc[3 * r]);
+                        acc[3 * r + 1] = mfma_bf16_32x32x16(a8, b1, acc[3 * r + 1]);
+                        acc[3 * r + 2] = mfma_bf16_32x32x16(a8, b2, acc[3 * r + 2]);
+                    }
+                }
+            } else
             for (int j = k_part; j < k_steps; j += k_parts) {
                 const int px = 2 * j + kk;                     // this lane's output pixel of the pair (segment-relative)
                 const float a = s_g[px * 64 + a_off];
@@ -345,6 +379,14 @@ using namespace fiery;
 extern "C" int fiery_conv_wgrad(const float* in, int in_ld, int64_t in_img_stride, int cin_units, const float* grad_out,
                                 int g_ld, int64_t g_img_stride, int cout, int n_img, int Hin, int Win, int Hout, int Wout, int kH,
                                 int kW, int stride, int padH, int padW, float* dw, fiery_stream_t stream) {
+    return fiery_conv_wgrad_prec(in, in_ld, in_img_stride, cin_units, grad_out, g_ld, g_img_stride, cout, n_img, Hin, Win, Hout, Wout,
+                                 kH, kW, stride, padH, padW, FIERY_PRECISION_F32, dw, stream);
+}
+
+extern "C" int fiery_conv_wgrad_prec(const float* in, int in_ld, int64_t in_img_stride, int cin_units, const float* grad_out,
+                                     int g_ld, int64_t g_img_stride, int cout, int n_img, int Hin, int Win, int Hout, int Wout, int kH,
+                                     int kW, int stride, int padH, int padW, int precision, float* dw, fiery_stream_t stream) {
+    FIERY_REQUIRE(precision == FIERY_PRECISION_F32 || precision == FIERY_PRECISION_BF16, "conv_wgrad: unknown precision %d", precision);
     FIERY_REQUIRE(in && grad_out && dw, "conv_wgrad: null pointer");
     FIERY_REQUIRE(cin_units > 0 && cout > 0 && n_img > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "conv_wgrad: bad shape");
     FIERY_REQUIRE(kH >= 1 && kW >= 1 && stride >= 1 && padH >= 0 && padW >= 0, "conv_wgrad: bad kernel geometry");
@@ -398,7 +440,9 @@ extern "C" int fiery_conv_wgrad(const float* in, int in_ld, int64_t in_img_strid
             q.rows_per_wg = ceil_div(Hout, parts);
             q.row_parts = ceil_div(Hout, q.rows_per_wg);
             FIERY_REQUIRE(static_cast<long long>(n_img) * q.row_parts < 65536, "conv_wgrad: grid too large");
-            hipLaunchKernelGGL(k_conv_wgrad3x3, dim3(q.co_tiles * q.c_tiles * q.n_seg, n_img * q.row_parts), dim3(256), 0, as_stream(stream), q);
+            const dim3 grid3(q.co_tiles * q.c_tiles * q.n_seg, n_img * q.row_parts);
+            if (precision == FIERY_PRECISION_BF16) hipLaunchKernelGGL(k_conv_wgrad3x3<true>, grid3, dim3(256), 0, as_stream(stream), q);
+            else hipLaunchKernelGGL(k_conv_wgrad3x3<false>, grid3, dim3(256), 0, as_stream(stream), q);
             return check_launch("conv_wgrad (3x3 staged)");
         }
     }

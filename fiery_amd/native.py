@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libfiery_hip.so')
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -124,6 +124,8 @@ _SIGNATURES = {
     'fiery_conv_precision_used': (C.c_int, [C.POINTER(ConvDesc)]),
     'fiery_conv_wgrad': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int64] + [C.c_int] * 11 +
                          [C.c_void_p, C.c_void_p]),
+    'fiery_conv_wgrad_prec': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int64] + [C.c_int] * 12 +
+                              [C.c_void_p, C.c_void_p]),
     'fiery_heads_1x1_nchw': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        c_int32_p, c_uint8_p, C.c_void_p, C.c_void_p]),
     'fiery_spatial_mean': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
@@ -415,17 +417,18 @@ class Lib:
             self.check(rc)
         return rc
 
-    def conv_wgrad(self, x, grad_out, cout, k, stride, pad):
+    def conv_wgrad(self, x, grad_out, cout, k, stride, pad, precision=PRECISION_F32):
         """x: pixel-major (n, Hin, Win, cin_pad) f32 (cin_pad a multiple of 8), grad_out: (n, Hout, Wout, >= cout) f32, both
-        with contiguous rows -> dw (cout, k*k, cin_pad) f32."""
+        with contiguous rows -> dw (cout, k*k, cin_pad) f32.  precision = PRECISION_BF16: operands rounded on chip where the
+        bf16 kernel applies (3 x 3 / stride 1), fp32 accumulation."""
         n, hin, win, cin_pad = x.shape
         _, hout, wout, g_ld = grad_out.shape
         # (strides of size-1 dimensions are arbitrary in torch: derive them from the shapes of the dense tensors)
         assert cin_pad % 8 == 0 and x.is_contiguous() and grad_out.is_contiguous()
         dw = torch.zeros(cout, k * k, cin_pad, dtype=torch.float32, device=x.device)
-        self.check(self.dll.fiery_conv_wgrad(_ptr(x), cin_pad, hin * win * cin_pad, cin_pad // 8, _ptr(grad_out), g_ld,
-                                             hout * wout * g_ld, cout, n, hin, win, hout, wout, k, k, stride, pad, pad, _ptr(dw),
-                                             _stream_of(dw)))
+        self.check(self.dll.fiery_conv_wgrad_prec(_ptr(x), cin_pad, hin * win * cin_pad, cin_pad // 8, _ptr(grad_out), g_ld,
+                                                  hout * wout * g_ld, cout, n, hin, win, hout, wout, k, k, stride, pad, pad, precision,
+                                                  _ptr(dw), _stream_of(dw)))
         return dw
 
     def conv_fwd(self, desc, stream_tensor):

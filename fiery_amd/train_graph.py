@@ -82,7 +82,7 @@ def _unit_epilogue(cout, device):
     return _UNIT_EPILOGUE[key]
 
 
-# Matrix-core precision of the training graph's convolutions (forward and input gradient; the weight gradient stays fp32):
+# Matrix-core precision of the training graph's convolutions (forward, input gradient, and the 3 x 3 layers' weight gradient):
 # 'f32' - the reference's arithmetic - or 'bf16': operands rounded to bf16 on chip, fp32 accumulation, fp32 tensors in memory -
 # the library's counterpart of the reference's mixed-precision recipe (`PRECISION: 16`, fiery/configs/baseline.yml:6, trainer
 # flag `precision=16` in train.py:36).  `FIERY_TRAIN_PRECISION=bf16`, or set `train_graph.CONV_PRECISION` before the step.
@@ -124,7 +124,7 @@ class HipConv2d(torch.autograd.Function):
         g = _pixel_major(gy.float())                                            # (n, ho, wo, round_up(cout, 8))
         gx = gw = None
         if ctx.needs_input_grad[1]:
-            dw = lib.conv_wgrad(x_nhwc, g, cout, k, stride, pad)                # (cout, taps, cp)
+            dw = lib.conv_wgrad(x_nhwc, g, cout, k, stride, pad, CONV_PRECISION)  # (cout, taps, cp)
             gw = dw[:, :, :c].permute(0, 2, 1).reshape(cout, c, k, k)
         if ctx.needs_input_grad[0]:
             # dL/dx = correlation of the (zero-stuffed, for stride > 1) output gradient with the transposed, mirrored

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FIERY_ABI_VERSION 18
+#define FIERY_ABI_VERSION 19
 
 #define FIERY_OK 0
 #define FIERY_EINVAL (-22)      /* bad argument (shape, alignment, null pointer) */
@@ -336,6 +336,13 @@ int fiery_conv_fwd(const fiery_conv_desc* desc /* host */, fiery_stream_t stream
 int fiery_conv_wgrad(const float* in, int in_ld, int64_t in_img_stride, int cin_units, const float* grad_out, int g_ld,
                      int64_t g_img_stride, int cout, int n_img, int Hin, int Win, int Hout, int Wout, int kH, int kW,
                      int stride, int padH, int padW, float* dw, fiery_stream_t stream);
+
+/* The same with a matrix-core precision: FIERY_PRECISION_BF16 rounds both operands (grad_out and in) to bf16 on chip and
+ * accumulates in fp32 - the weight gradient of mixed-precision training; layers its bf16 kernel does not cover (anything but
+ * 3 x 3 / stride 1 / pad 1 on 16-byte addressable rows) run the fp32 kernels. */
+int fiery_conv_wgrad_prec(const float* in, int in_ld, int64_t in_img_stride, int cin_units, const float* grad_out, int g_ld,
+                          int64_t g_img_stride, int cout, int n_img, int Hin, int Win, int Hout, int Wout, int kH, int kW,
+                          int stride, int padH, int padW, int precision, float* dw, fiery_stream_t stream);
 
 /* FIERY_PRECISION_F32 or FIERY_PRECISION_BF16: the matrix-core form fiery_conv_fwd runs this descriptor in (negative:
  * an error code - the descriptor is invalid). */

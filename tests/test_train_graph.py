@@ -79,25 +79,35 @@ def test_upsampling_plane_mean_and_strided_convolution_gradients_vs_fp64(sim):
 def test_bf16_operand_convolutions_in_the_training_graph(sim, monkeypatch):
     """`train_graph.CONV_PRECISION = bf16` (the library's mixed-precision mode for training): forward and input gradient
     are the convolutions of the bf16-ROUNDED operands with fp32 accumulation (exactly: compared at 3e-5 against torch on the
-    rounded operands), the weight gradient stays the fp32 one."""
+    rounded operands); the weight gradient of the 3 x 3 / stride 1 layers likewise, of the others in fp32."""
     from fiery_amd import native, train_graph as tg
     monkeypatch.setattr(tg, 'CONV_PRECISION', native.PRECISION_BF16)
     rb = lambda t: t.to(torch.bfloat16).float()
     g = torch.Generator().manual_seed(12)
-    for cin, cout, k, stride, pad, hw in ((32, 64, 3, 1, 1, (9, 14)), (64, 128, 3, 1, 1, (7, 5)), (64, 32, 1, 1, 0, (6, 7)), (32, 64, 3, 2, 1, (9, 12))):
+    for cin, cout, k, stride, pad, hw in ((32, 64, 3, 1, 1, (9, 14)), (64, 128, 3, 1, 1, (7, 5)), (64, 32, 1, 1, 0, (6, 7)), (32, 64, 3, 2, 1, (9, 12)),
+                                          (96, 40, 3, 1, 1, (5, 120)), (16, 32, 3, 1, 1, (1, 9))):
         x = torch.randn(2, cin, *hw, generator=g)
         w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
         xx, ww = x.clone().requires_grad_(), w.clone().requires_grad_()
         y = tg.HipConv2d.apply(xx, ww, stride, pad, sim)
         gy = torch.randn(y.shape, generator=g)
         gx, gw = torch.autograd.grad(y, (xx, ww), gy)
-        want_y = F.conv2d(rb(x), rb(w), None, stride, pad)
+        fwd_rounded = cin % 32 == 0                                # (whole 32-channel stages, as for the input gradient below)
+        want_y = F.conv2d(rb(x) if fwd_rounded else x, rb(w) if fwd_rounded else w, None, stride, pad)
         assert torch.allclose(y, want_y, rtol=3e-5, atol=3e-5), (cin, cout, (y - want_y).abs().max())
-        want_gx = torch.nn.grad.conv2d_input(x.shape, rb(w), rb(gy), stride, pad)
+        # (the input gradient is a convolution over the cout channels: the bf16 kernel takes it when those are whole
+        # 32-channel stages, otherwise that launch runs the fp32 kernel - `fiery_conv_precision_used`)
+        dgrad_rounded = cout % 32 == 0
+        want_gx = torch.nn.grad.conv2d_input(x.shape, rb(w) if dgrad_rounded else w, rb(gy) if dgrad_rounded else gy, stride, pad)
         assert torch.allclose(gx, want_gx, rtol=3e-5, atol=3e-5), (cin, cout, (gx - want_gx).abs().max())
-        want_gw = torch.nn.grad.conv2d_weight(x, w.shape, gy, stride, pad)
+        # weight gradient: the 3 x 3 / stride 1 layers' kernel has a bf16 form (operands rounded, sixteen pixels per MFMA);
+        # the other layers keep the fp32 kernels
+        rounded = k == 3 and stride == 1
+        want_gw = torch.nn.grad.conv2d_weight(rb(x) if rounded else x, w.shape, rb(gy) if rounded else gy, stride, pad)
         assert torch.allclose(gw, want_gw, rtol=1e-4, atol=1e-4), (cin, cout, (gw - want_gw).abs().max())
-        assert (y - F.conv2d(x, w, None, stride, pad)).abs().max() > 1e-4          # it IS the rounded-operand result
+        if rounded:
+            assert (gw - torch.nn.grad.conv2d_weight(x, w.shape, gy, stride, pad)).abs().max() > 1e-4
+        assert not fwd_rounded or (y - F.conv2d(x, w, None, stride, pad)).abs().max() > 1e-4          # it IS the rounded-operand result
 
 
 def test_maxpool_and_ego_warp_all_gradients_vs_fp64(sim):
