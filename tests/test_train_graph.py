@@ -434,7 +434,7 @@ def test_forward_from_images_in_training_mode_reaches_every_parameter(sim):
     randomise_weights(model)
     model.train()
     model._lib = sim
-    B, n = 2, 1
+    B, n = 1, 2                                  # (two cameras of one sample: half the images of a batch of two, both loops exercised)
     image, K, E, ego = make_inputs(B, model.receptive_field + model.n_future, n, image_hw=tuple(cfg.IMAGE.FINAL_DIM), seed=3)
     labels = torch.randn(B, 1 + model.n_future, 6, *model.bev_size, generator=torch.Generator().manual_seed(4))
     opt = torch.optim.SGD(model.parameters(), lr=1e-3)
