@@ -1004,11 +1004,14 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
                 const int co = c4 * 4;
                 float4 resid[8];                                    // the residual rows, later the finished rows themselves
                 int out_off[8];                                    // floats from p.out.ptr (< 2^31: host check); < 0: not stored
-                {
-                    int gp = pix0 + prow0;
-                    int o = fast_div(gp, p.mg_hw, p.sh_hw), ppi = gp - o * HWout;
+                // rows [i0, i1) of this thread: where they go, and their residual on its way.  FIERY_TAIL_FOUR_PER_CU: the
+                // first four rows are requested here, the last four once the accumulators of the second GEMM have left
+                // their registers (the residual rows can then live where those were: 128 registers without spills)
+                auto request_rows = [&](int i0, int i1) {
+                    int gp = pix0 + prow0 + 16 * i0;
+                    int o = fast_div(gp < M ? gp : 0, p.mg_hw, p.sh_hw), ppi = gp - o * HWout;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
+                    for (int i = i0; i < i1; ++i) {
                         const bool live = gp < M && co < p.cout_store;
                         out_off[i] = live ? static_cast<int>(o * p.out.istride + static_cast<long long>(ppi) * p.out.ld + co) : -1;
                         resid[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1021,7 +1024,9 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
                             ++o;
                         }
                     }
-                }
+                };
+                constexpr int ROWS_EARLY = FIERY_TAIL_FOUR_PER_CU ? 4 : 8;
+                request_rows(0, ROWS_EARLY);
                 const float4 w3_lo = reinterpret_cast<const float4*>(p.heads.w)[tid];
                 const float4 w3_hi = reinterpret_cast<const float4*>(p.heads.w)[tid + 256];
                 __syncthreads();                                   // everyone is done reading the h and W tiles
@@ -1032,6 +1037,7 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
                         const int pl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                         smem[pl * 64 + nt * 32 + m] = acc2[nt][r];
                     }
+                if constexpr (ROWS_EARLY < 8) request_rows(ROWS_EARLY, 8);
                 __syncthreads();
                 {
                     const float4 sc2 = *reinterpret_cast<const float4*>(p.scale2 + co);
