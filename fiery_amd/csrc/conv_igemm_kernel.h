@@ -39,7 +39,9 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 constexpr int BK = 32;    // k per LDS stage (4 units of 8 input channels)
 // A fourth workgroup per CU for the scalar-addressed 128 x 32 kernel (A/B switch): measured in round 3 after its registers
 // were trimmed to fit - faster for the plain and the chained launch (106 vs 112, 131 vs 138 us), slower for the Bottleneck
-// tail with its third stage, the launch the step issues most (162 vs 153 us): off.
+// tail with its third stage, the launch the step issues most (162 vs 153 us): off.  Measured again after that epilogue
+// stopped spilling at 128 registers (residual rows in two halves): 107 vs 115, 134 vs 139, 149 vs 158 - and 162 vs 155 for the
+// third-stage launch, 286.5 vs 289.1 samples/s (profiles/r3_tail_four_per_cu_ab.txt): still off.
 #ifndef FIERY_TAIL_FOUR_PER_CU
 #define FIERY_TAIL_FOUR_PER_CU 0
 #endif
