@@ -196,7 +196,10 @@ class _TemporalBlock:
         self.cin, self.cout, self.half = tb.in_channels, tb.out_channels, tb.half_channels
         self.ego = ego_channels
         self.cf = self.cin - ego_channels                     # channels that really vary in space
-        hp = self.hp = round_up(self.half, 8)
+        # each path's channels start on an 8-aligned column of the combined tensors; in the bf16 mode on a 32-aligned one, so that
+        # the causal convolutions read whole 32-channel stages (35 -> 64 channels of which 29 are zeros: 1.8x the products, but
+        # on the bf16 kernels instead of the fp32 fallback - those two layers were 7.5 % of the bf16 step)
+        hp = self.hp = round_up(self.half, 32 if eng.precision == native.PRECISION_BF16 else 8)
         cf_pad = round_up(self.cf, 8)
         paths = tb.convolution_paths
         firsts = [paths[0][0], paths[1][0], paths[2]]

@@ -98,6 +98,30 @@ def test_identity_temporal_model_with_ego_pose_channels(sim, n_future):
     _compare(got, want, keys)
 
 
+def test_bf16_mode_of_the_whole_engine(sim):
+    """`conv_precision = 'bf16'`: every convolution the bf16 kernels cover runs on them (halo loop on the 3 x 3 layers; the
+    temporal blocks' 35-channel paths padded to whole 32-channel stages so that their causal convolutions qualify) - against
+    the fp32 oracle within the rounding the mode brings (a layout mistake is an O(1) error)."""
+    cfg = tiny_cfg('baseline.yml', bev=8)
+    torch.manual_seed(0)
+    model = Fiery(cfg).eval()
+    model.conv_precision = 'bf16'
+    sd = randomise_weights(model)
+    model._lib = sim
+    rf, n = model.receptive_field, 2
+    _, K, E, ego = make_inputs(2, rf + model.n_future, n, with_image=False, seed=0)
+    fh, fw = cfg.IMAGE.FINAL_DIM[0] // 8, cfg.IMAGE.FINAL_DIM[1] // 8
+    _, _, lifted = make_lifted_features(2 * rf * n, 64, model.depth_channels, (fh, fw), seed=1)
+    lifted = lifted.view(2, rf, n, 64, model.depth_channels, fh, fw)
+    with torch.no_grad():
+        got = model.bev_forward(lifted, K, E, ego)
+        want = bev_stack.bev_hot_path(sd, cfg, lifted, K, E, ego)
+    assert model.engine().temporal[0][1].hp == 64
+    for k in KEYS:
+        err, scale = (got[k] - want[k]).abs().max().item(), max(1.0, want[k].abs().max().item())
+        assert 1e-5 < err <= 5e-2 * scale, (k, err, scale)
+
+
 def test_future_distribution_with_labels(sim):
     """evaluate.py passes the future labels in eval mode: the future distribution must be evaluated too
     (reference: evaluate.py:55-59, fiery.py:310-314)."""

@@ -11,3 +11,9 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')
 timeout 600 python bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err; cut -c1-260 $O/bench.json
 timeout 300 python bench.py --steps 20 --warmup 3 --precision bf16 --no-from-images --no-cpu-baseline > $O/bench_baseline_bf16.json 2>> $O/bench.err
 grep -h -o '"value": [0-9.]*' $O/bench_baseline_bf16.json | head -1
+timeout 300 python bench.py --steps 10 --warmup 3 --precision bf16 --config literature/pon_setting.yml --no-from-images --no-cpu-baseline > $O/bench_pon_bf16.json 2>> $O/bench.err
+timeout 300 python bench.py --steps 10 --warmup 3 --precision bf16 --config lyft/baseline.yml --cams 7 --no-from-images --no-cpu-baseline > $O/bench_lyft7_bf16.json 2>> $O/bench.err
+grep -h -o '"value": [0-9.]*' $O/bench_pon_bf16.json $O/bench_lyft7_bf16.json | grep -v '"value": 0\.'
+python -c "
+import json
+d=json.loads(open('$O/bench.json').read().strip().splitlines()[-1]); print('bf16_mode', d.get('bf16_mode'))"
