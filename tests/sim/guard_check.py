@@ -150,7 +150,7 @@ def main():
         from fiery_amd.synthetic import make_inputs, randomise_weights
         from tests.helpers import tiny_cfg
         cfg = tiny_cfg('baseline.yml', bev=8, **{'MODEL.FUTURE_PRED.N_GRU_BLOCKS': 1, 'MODEL.FUTURE_PRED.N_RES_LAYERS': 1, 'N_FUTURE_FRAMES': 1,
-                                                  'TIME_RECEPTIVE_FIELD': 2})
+                                                  'TIME_RECEPTIVE_FIELD': 2, 'MODEL.ENCODER.NAME': 'efficientnet-b0'})
         torch.manual_seed(0)
         model = Fiery(cfg)
         randomise_weights(model)

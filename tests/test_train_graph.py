@@ -427,8 +427,10 @@ def test_forward_from_images_in_training_mode_reaches_every_parameter(sim):
     from the old weights)."""
     from fiery_amd.model import Fiery
     from fiery_amd.synthetic import make_inputs
+    # (EfficientNet-b0, the reference's other trunk (encoder.py:40-56): a third of the b4 trunk's work on the simulator; the b4
+    # trunk under autograd is covered by test_trunk_and_lift_head_on_the_training_graph_equal_the_torch_statement)
     cfg = tiny_cfg('baseline.yml', bev=8, **{'MODEL.FUTURE_PRED.N_GRU_BLOCKS': 1, 'MODEL.FUTURE_PRED.N_RES_LAYERS': 1,
-                                             'N_FUTURE_FRAMES': 1, 'TIME_RECEPTIVE_FIELD': 2})
+                                             'N_FUTURE_FRAMES': 1, 'TIME_RECEPTIVE_FIELD': 2, 'MODEL.ENCODER.NAME': 'efficientnet-b0'})
     torch.manual_seed(0)
     model = Fiery(cfg)
     randomise_weights(model)
