@@ -141,6 +141,68 @@ class HipConv2d(torch.autograd.Function):
         return gx, gw, None, None, None
 
 
+class HipConv2dCat(torch.autograd.Function):
+    """conv2d(cat([x0, x1], 1), weight, 1, pad) without the concatenation: the kernel reads its input channels from two tensors
+    (the virtual concat of `fiery_conv_desc.src[0..1]` - the GRU's [x, h], layers/temporal.py:49-62).  Stride 1.  The weight
+    gradient is two launches, one per source, each filling its own channel range; the input gradient one launch over all
+    channels, handed back as two channel views."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, weight, pad, lib):
+        a, b = _pixel_major(x0.detach().float()), _pixel_major(x1.detach().float())
+        n, h, w, p0 = a.shape
+        p1 = b.shape[-1]
+        c0, c1 = x0.shape[1], x1.shape[1]
+        cout, cin, k, _ = weight.shape
+        assert cin == c0 + c1 and tuple(b.shape[:3]) == (n, h, w)
+        dev = a.device
+        scale, shift = _unit_epilogue(cout, dev)
+        op = ConvOp(lib, weight.detach().float(), identity_chan_map(c0) + identity_chan_map(c1, offset=p0), (p0 // 8, p1 // 8), scale, shift,
+                    dev, stride=1, pad=(pad, pad), precision=CONV_PRECISION, tune=False)
+        ho, wo = op.out_hw(h, w)
+        out = Buf.alloc(n, ho, wo, cout, dev, zero=False)
+        op([Buf(a, n, h, w, p0), Buf(b, n, h, w, p1)], out)
+        ctx.save_for_backward(a, b, weight)
+        ctx.meta = (c0, c1, h, w, pad, lib)
+        y = out.tensor
+        return _padded_rows(y[..., :cout].permute(0, 3, 1, 2), cout, y.shape[-1])
+
+    @staticmethod
+    def backward(ctx, gy):
+        a, b, weight = ctx.saved_tensors
+        c0, c1, h, w, pad, lib = ctx.meta
+        cout, _, k, _ = weight.shape
+        g = _pixel_major(gy.float())
+        gx0 = gx1 = gw = None
+        if ctx.needs_input_grad[2]:
+            d0 = lib.conv_wgrad(a, g, cout, k, 1, pad, CONV_PRECISION)[:, :, :c0]          # (cout, taps, c0)
+            d1 = lib.conv_wgrad(b, g, cout, k, 1, pad, CONV_PRECISION)[:, :, :c1]
+            gw = torch.cat([d0, d1], dim=2).permute(0, 2, 1).reshape(cout, c0 + c1, k, k)
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            w_t = weight.detach().float().transpose(0, 1).flip(2, 3).contiguous()
+            gx = _launch_conv(lib, g, w_t, 1, k - 1 - pad)                                  # (n, h, w, round_up(c0 + c1, 8))
+            gx0 = gx[..., :c0].permute(0, 3, 1, 2)
+            gx1 = gx[..., c0:c0 + c1].permute(0, 3, 1, 2)
+        return gx0, gx1, gw, None, None
+
+
+class HipSplitChannels(torch.autograd.Function):
+    """(N, 2C, H, W) -> two (N, C, H, W) channel views of it; the two gradients meet again in ONE pixel-major tensor (autograd's
+    own slice backward would zero-fill and add two full-size tensors)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        c = x.shape[1] // 2
+        ctx.c = c
+        return x[:, :c], x[:, c:2 * c]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        n, c, h, w = ga.shape
+        g = torch.cat([ga.permute(0, 2, 3, 1), gb.permute(0, 2, 3, 1)], dim=3)              # (n, h, w, 2c) dense rows
+        return g.permute(0, 3, 1, 2)
+
+
 class HipDepthwiseConv2d(torch.autograd.Function):
     """Depthwise k x k convolution with explicit (asymmetric) zero padding - `MBConvBlock._depthwise_conv` of the image trunk
     (efficientnet-pytorch, behind fiery/models/encoder.py:58-86): forward `fiery_depthwise_conv_nhwc` (no BatchNorm, no
@@ -595,16 +657,18 @@ class TrainGraph:
 
     def gru_cell(self, x, state, gru):
         """fiery/layers/temporal.py:49-62 (note (1 - reset) * state)."""
-        xs = torch.cat([x, state], dim=1)
         tilde = gru.conv_state_tilde
         hidden = state.shape[1]
-        if self._hip_ops and hidden % 4 == 0:
-            # the gate convolutions without their bias; bias + gru_bias_init and both sigmoids inside the element-wise kernels
-            pre_u = self._conv(xs, gru.conv_update.weight, 1, gru.conv_update.padding[0], self.lib)
-            pre_r = self._conv(xs, gru.conv_reset.weight, 1, gru.conv_reset.padding[0], self.lib)
+        if self._hip_ops and hidden % 8 == 0 and gru.conv_update.stride[0] == 1:
+            # update | reset as ONE convolution over the virtual concat [x, state] (the inference plan's form: an N = 2h GEMM, the
+            # input read once, no concatenated copy); bias + gru_bias_init and both sigmoids inside the element-wise kernels
+            pad = gru.conv_update.padding[0]
+            w_gates = torch.cat([gru.conv_update.weight, gru.conv_reset.weight], dim=0)
+            pre_u, pre_r = HipSplitChannels.apply(HipConv2dCat.apply(x, state, w_gates, pad, self.lib))
             rh = HipGruReset.apply(pre_r, gru.conv_reset.bias + gru.gru_bias_init, state, self.lib)
-            proposal = self.bn_act(self.conv2d(torch.cat([x, rh], dim=1), tilde.conv), tilde.norm, relu=True)
+            proposal = self.bn_act(HipConv2dCat.apply(x, rh, tilde.conv.weight, tilde.conv.padding[0], self.lib), tilde.norm, relu=True)
             return HipGruOut.apply(pre_u, gru.conv_update.bias + gru.gru_bias_init, state, proposal, self.lib)
+        xs = torch.cat([x, state], dim=1)
         update = torch.sigmoid(self.conv2d(xs, gru.conv_update) + gru.gru_bias_init)
         reset = torch.sigmoid(self.conv2d(xs, gru.conv_reset) + gru.gru_bias_init)
         proposal = self.bn_act(self.conv2d(torch.cat([x, (1.0 - reset) * state], dim=1), tilde.conv), tilde.norm, relu=True)

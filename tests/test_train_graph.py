@@ -110,6 +110,24 @@ def test_bf16_operand_convolutions_in_the_training_graph(sim, monkeypatch):
         assert not fwd_rounded or (y - F.conv2d(x, w, None, stride, pad)).abs().max() > 1e-4          # it IS the rounded-operand result
 
 
+def test_two_source_convolution_and_channel_split_gradients_vs_fp64(sim):
+    """HipConv2dCat (the GRU's convolutions over [x, h] without the concatenated copy: forward from two tensors, weight gradient
+    per source, one input-gradient launch split in two views) and HipSplitChannels (update | reset halves of the fused gate
+    convolution) against the float64 autograd evaluation of `conv2d(cat(...))` / `chunk`."""
+    from fiery_amd.train_graph import HipConv2dCat, HipSplitChannels
+    g = torch.Generator().manual_seed(17)
+    for c0, c1, cout, k, hw in ((32, 64, 128, 3, (7, 9)), (64, 64, 64, 3, (6, 5)), (35, 24, 40, 1, (5, 8)), (8, 64, 128, 3, (9, 4))):
+        x0, x1 = torch.randn(2, c0, *hw, generator=g), torch.randn(2, c1, *hw, generator=g)
+        w = torch.randn(cout, c0 + c1, k, k, generator=g) / ((c0 + c1) * k * k) ** 0.5
+        pad = (k - 1) // 2
+        _grads_vs_fp64(lambda a, b, ww: HipConv2dCat.apply(a, b, ww, pad, sim), lambda a, b, ww: F.conv2d(torch.cat([a, b], 1), ww, None, 1, pad),
+                       [x0, x1, w], seed=c0 + cout)
+    x = torch.randn(2, 128, 6, 7, generator=g)
+    w = torch.randn(3, generator=g)
+    _grads_vs_fp64(lambda t, s: (lambda a, b: a * s[0] + b * s[1] * a)(*HipSplitChannels.apply(t)),
+                   lambda t, s: (lambda a, b: a * s[0] + b * s[1] * a)(*t.chunk(2, dim=1)), [x, w], seed=3, tol=1e-6)
+
+
 def test_maxpool_and_ego_warp_all_gradients_vs_fp64(sim):
     """HipMaxPool2x2 (the pooled skip of a down-sampling Bottleneck, layers/convolutions.py:150-166: odd sizes padded with a
     zero row / column that takes part in the maximum) and HipEgoWarp (`cumulative_warp_features`, utils/geometry.py:225-253:
