@@ -354,6 +354,12 @@ def main():
                         'value': round(B / ms16 * 1e3, 3), 'unit': 'samples/s', 'ms_per_step': round(ms16, 3),
                         'dtype': 'bf16 matrix-core operands; fp32 accumulation, epilogues and tensors in HBM',
                         'max_abs_diff_vs_fp32_step': {k: float(f'{(got16[k].float() - v).abs().max().item():.3e}') for k, v in ref32.items()},
+                        # the step's convolution flops over the whole timed step (a lower bound on the kernels' own rate),
+                        # against the dense bf16 matrix peak of the guide (2.5 PFLOP/s)
+                        'step_tflops': (round(roofline['algorithmic_gflop_per_step'] / ms16, 1)
+                                        if roofline and roofline.get('algorithmic_gflop_per_step') else None),
+                        'frac_of_bf16_peak': (round(roofline['algorithmic_gflop_per_step'] / ms16 / 2500.0, 4)
+                                              if roofline and roofline.get('algorithmic_gflop_per_step') else None),
                         'what': f'the same workload and launch mode, {args.steps} steps after {max(args.warmup, 2)} warm-up'}
             except Exception as e:                                   # noqa: BLE001  (the headline line must not depend on it)
                 line['bf16_mode'] = {'error': repr(e)[:200]}
