@@ -285,6 +285,153 @@ __global__ void k_rank_columns(const float* __restrict__ geometry, int n_fc, int
     }
 }
 
+// The same prepass with FOUR lanes per column (lane 16 p + c of a wavefront takes rows [p kRpp, (p + 1) kRpp) of the
+// wavefront's column c): four times the wavefronts of k_rank_columns, each with a quarter of the loads and of the
+// quantisation arithmetic (three correctly rounded divisions per point), so the memory latency of one lane's rows is
+// covered by other wavefronts instead of standing in a row four times (one thread per column: 2.4 wavefronts per SIMD,
+// 25 us for 52 MB; this form: ~10 per SIMD).  The four lanes of a column meet through three wave exchanges: the last
+// rank of the part above (is my first row a new run?), the OR of the parts' run-start bits, and the ranks at the second
+// and third run start.  Everything it writes - ranks, descriptors / quad records, tile masks, occupancy bytes, live
+// masks, cleared tail planes - is what k_rank_columns writes, bit for bit.  H <= 4 kRpp <= 32.
+template <int kRpp>
+__global__ __launch_bounds__(256) void k_rank_columns4(const float* __restrict__ geometry, int n_fc, int D, int H, int W,
+                                                        GridParams p, int tile_vox, int* __restrict__ rank,
+                                                        int4* __restrict__ coldesc, int* __restrict__ colmask, int compact,
+                                                        unsigned char* __restrict__ occ, int n_cam, long long occ_stride,
+                                                        unsigned* __restrict__ live, float* __restrict__ clear,
+                                                        long long clear_floats) {
+    if (clear) {
+        const long long n_thr = static_cast<long long>(gridDim.x) * blockDim.x;
+        const long long me = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+        if ((reinterpret_cast<uintptr_t>(clear) & 15) == 0) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (long long i = me * 4; i + 3 < clear_floats; i += n_thr * 4) *reinterpret_cast<float4*>(clear + i) = z;
+            if (me < (clear_floats & 3)) clear[(clear_floats & ~3ll) + me] = 0.f;
+        } else {
+            for (long long i = me; i < clear_floats; i += n_thr) clear[i] = 0.f;
+        }
+    }
+    __shared__ unsigned live_lds[24];                                    // 64 columns of at least 4: at most 17 slices
+    const long long col_first = static_cast<long long>(blockIdx.x) * 64;
+    if (live) {
+        if (threadIdx.x < 24) live_lds[threadIdx.x] = 0u;
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63, part = lane >> 4;
+    const long long col = col_first + (threadIdx.x >> 6) * 16 + (lane & 15);
+    const long long n_cols = static_cast<long long>(n_fc) * D * W;
+    const bool has_col = col < n_cols;
+    const long long colc = has_col ? col : n_cols - 1;                  // (idle lanes shadow the last column: they take part in the exchanges)
+    const int w = static_cast<int>(colc % W);
+    const long long fd = colc / W;                                       // (frame*camera)*D + d
+    const long long base = fd * H * W + w;                               // point index of (.., h = 0, w)
+    const int h0 = part * kRpp;
+    int r[kRpp];
+    {
+        float gx[kRpp], gy[kRpp], gz[kRpp];
+#pragma unroll
+        for (int j = 0; j < kRpp; ++j) {
+            const int h = h0 + j < H ? h0 + j : H - 1;                   // clamp: rows past the end re-read the last one
+            const float* g = geometry + 3 * (base + static_cast<long long>(h) * W);
+            gx[j] = g[0];
+            gy[j] = g[1];
+            gz[j] = g[2];
+        }
+#pragma unroll
+        for (int j = 0; j < kRpp; ++j) {
+            r[j] = voxel_rank(gx[j], gy[j], gz[j], p, nullptr);
+            if (has_col && h0 + j < H) rank[base + static_cast<long long>(h0 + j) * W] = r[j];
+        }
+    }
+    // the rank of the row above my first one: the last row of the part above (parts 1 and 3 sit 16 lanes above parts 0 and
+    // 2, part 2 sits 16 lanes above part 1: lane ^ 16 and lane ^ 48)
+    const int last = r[kRpp - 1];
+    const int up16 = __shfl_xor(last, 16), up48 = __shfl_xor(last, 48);
+    int prev = (part & 1) ? up16 : up48;
+    unsigned char* occ_f = occ ? occ + (fd / (static_cast<long long>(n_cam) * D)) * occ_stride : nullptr;
+    unsigned starts = 0;                                                 // bit h: row h starts a run
+    int tiles = 0;
+    bool any_inside = false;
+#pragma unroll
+    for (int j = 0; j < kRpp; ++j) {
+        const int h = h0 + j;
+        if (h < H) {
+            if (h == 0 || r[j] != prev) {
+                starts |= 1u << h;
+                if (occ_f && has_col && r[j] >= 0) occ_f[r[j]] = 1;
+            }
+            if (r[j] >= 0) {
+                tiles |= 1 << (r[j] / tile_vox);
+                any_inside = true;
+            }
+        }
+        prev = r[j];
+    }
+    starts |= static_cast<unsigned>(__shfl_xor(static_cast<int>(starts), 16));
+    starts |= static_cast<unsigned>(__shfl_xor(static_cast<int>(starts), 32));
+    tiles |= __shfl_xor(tiles, 16);
+    tiles |= __shfl_xor(tiles, 32);
+    int inside = any_inside ? 1 : 0;
+    inside |= __shfl_xor(inside, 16);
+    inside |= __shfl_xor(inside, 32);
+    const int runs = __popc(starts);
+    const unsigned after_first = starts & (starts - 1u);                // (bit 0 is always set: row 0 starts the first run)
+    const int s1 = after_first ? __ffs(static_cast<int>(after_first)) - 1 : H;
+    const unsigned after_second = after_first & (after_first - 1u);
+    const int s2 = after_second ? __ffs(static_cast<int>(after_second)) - 1 : H;
+    // the ranks at rows 0, s1, s2: each is held by one of the four lanes, which offers rank + 1 (the others offer 0)
+    int offer_a = 0, offer_b = 0, offer_c = 0;
+#pragma unroll
+    for (int j = 0; j < kRpp; ++j) {
+        const int h = h0 + j;
+        if (h == 0) offer_a = r[j] + 1;
+        if (h == s1) offer_b = r[j] + 1;
+        if (h == s2) offer_c = r[j] + 1;
+    }
+    offer_a |= __shfl_xor(offer_a, 16);  offer_a |= __shfl_xor(offer_a, 32);
+    offer_b |= __shfl_xor(offer_b, 16);  offer_b |= __shfl_xor(offer_b, 32);
+    offer_c |= __shfl_xor(offer_c, 16);  offer_c |= __shfl_xor(offer_c, 32);
+    const int ra = offer_a - 1, rb = s1 < H ? offer_b - 1 : -1, rc = s2 < H ? offer_c - 1 : -1;
+    if (has_col && part == 0) {
+        const int general = (runs > 3 || H >= (1 << kSplitBits)) ? 1 : 0;
+        if (compact >= 2) {
+            const int quad_w = W >> 2;
+            const long long quad = fd * quad_w + (w >> 2);
+            const int k = w & 3;
+            const unsigned w16 = static_cast<unsigned>(s1) | (static_cast<unsigned>(s2) << 6) | (static_cast<unsigned>(general) << 12);
+            if (compact == 2) {
+                unsigned short* rec = reinterpret_cast<unsigned short*>(coldesc) + quad * 16;
+                auto r16 = [](int v) { return static_cast<unsigned short>(v < 0 ? kNoRank16 : static_cast<unsigned>(v)); };
+                rec[k] = static_cast<unsigned short>(w16);
+                rec[4 + k] = r16(ra);
+                rec[8 + k] = r16(rb);
+                rec[12 + k] = r16(rc);
+            } else {
+                char* rec = reinterpret_cast<char*>(coldesc) + quad * 64;
+                reinterpret_cast<unsigned short*>(rec)[k] = static_cast<unsigned short>(w16);
+                reinterpret_cast<int*>(rec + 16)[k] = ra;
+                reinterpret_cast<int*>(rec + 32)[k] = rb;
+                reinterpret_cast<int*>(rec + 48)[k] = rc;
+            }
+        } else if (compact) {
+            auto r16 = [](int v) { return v < 0 ? kNoRank16 : static_cast<unsigned>(v); };
+            const unsigned w16 = static_cast<unsigned>(s1) | (static_cast<unsigned>(s2) << 6) | (static_cast<unsigned>(general) << 12);
+            // (the one-thread form stores the ranks it met second and third even when a later run replaces nothing: same here)
+            reinterpret_cast<int2*>(coldesc)[col] = make_int2(static_cast<int>(r16(ra) | (r16(rb) << 16)), static_cast<int>(r16(rc) | (w16 << 16)));
+        } else {
+            coldesc[col] = make_int4(ra, rb, rc, s1 | (s2 << kSplitBits) | (general << (2 * kSplitBits)));
+            if (colmask) colmask[col] = tiles | (general ? static_cast<int>(0x80000000u) : 0);
+        }
+    }
+    if (live) {
+        const long long fd_first = col_first / W;                        // slice of the workgroup's first column
+        if (has_col && part == 0 && inside) atomicOr(&live_lds[static_cast<int>(fd - fd_first)], 1u << (w >> 2));
+        __syncthreads();
+        if (threadIdx.x < 24 && live_lds[threadIdx.x] != 0u && fd_first + threadIdx.x < static_cast<long long>(n_fc) * D)
+            atomicOr(&live[fd_first + threadIdx.x], live_lds[threadIdx.x]);
+    }
+}
+
 // Ordered (ascending id) list of the work-items that touch one tile of one frame; adjacent entries are adjacent
 // in memory, so the pooling kernel's wavefront loads stay unit-stride.  Items with a "general" column (more than
 // three runs) go to a second list that grows down from the end of the same array; counts = {front, back}.  A work-item is a column (group = 1) or
@@ -1073,13 +1220,17 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
     const float* __restrict__ x, PoolStrides xs, const int* __restrict__ rank, const void* __restrict__ quads,
     const unsigned char* __restrict__ occ, const unsigned* __restrict__ live, float* __restrict__ out,
     int* __restrict__ occupied, int n_cam, int D, int H, int W, int C, int n_vox, int n_words, int capacity, int tail_first,
-    int tail_parts) {
+    int tail_parts, int n_items, int* __restrict__ draw, long long* __restrict__ trace, int late_first, int late_prio,
+    int* __restrict__ counters, uint4* __restrict__ clean, int clean_vec) {
     using prefix_t = std::conditional_t<kWide, unsigned, unsigned short>;
     HIP_DYNAMIC_SHARED(unsigned char, cp_lds)
     const int n_w32 = 2 * n_words;
     unsigned* bits = reinterpret_cast<unsigned*>(cp_lds);                                    // [n_w32]
     prefix_t* prefix = reinterpret_cast<prefix_t*>(bits + n_w32);                            // [n_w32]
-    float* plane = reinterpret_cast<float*>(cp_lds + ((static_cast<size_t>(n_w32) * (4 + sizeof(prefix_t)) + 15) & ~size_t(15)));
+    // (16 bytes in front of the cells hold the item a workgroup has drawn: static LDS on top of the dynamic block would push
+    // two workgroups past a CU's 160 KB)
+    int* drawn = reinterpret_cast<int*>(cp_lds + ((static_cast<size_t>(n_w32) * (4 + sizeof(prefix_t)) + 15) & ~size_t(15)));
+    float* plane = reinterpret_cast<float*>(drawn + 4);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     // (told to the compiler in so many words: the wavefront index is the same in all lanes, so everything derived from it -
@@ -1087,7 +1238,33 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
     // treats tid >> 6 as divergent and wraps every buffer load in a loop over the "different" values)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int kWaves = kThreads / 64;
-    int unit = blockIdx.x, part = 0, parts = 1;
+    // Work items: [0, tail_first) are whole (channel, frame) units, the rest are the parts of the units of the last, partly
+    // filled round.  A workgroup takes items blockIdx.x, blockIdx.x + gridDim.x, ...: with a grid of one workgroup per slot
+    // of the chip (the default, `persistent`) every slot does its whole units and then a part of a tail unit WITHOUT a
+    // second dispatch, so the tail is cut as fine as there are slots and all of them stream to the end (576 units on 512
+    // slots: one unit + one eighth each); with a grid of one workgroup per item the loop runs once.
+    // `draw` (optional, zeroed by the caller): the parts of the tail units are not dealt by index but drawn from this
+    // counter, so a workgroup that was slower on its whole unit (the second workgroup of a CU runs ~12 % behind the first:
+    // the older wavefronts win the arbitration) takes fewer parts and all slots finish together.
+    // Two workgroups share a CU and the one dispatched first runs ~12 % ahead of the other all the way (the arbiter favours
+    // the older wavefronts): the later half of the first round of workgroups asks for a higher issue priority.
+    if (late_prio > 0 && static_cast<int>(blockIdx.x) >= late_first) {
+        if (late_prio == 1) __builtin_amdgcn_s_setprio(1);
+        else if (late_prio == 2) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(3);
+    }
+    int total = 0, f_have = -1;
+    for (int item = blockIdx.x;; item += gridDim.x) {
+    if (draw && item >= tail_first) {
+        if (tid == 0) *drawn = tail_first + atomicAdd(draw, 1);
+        __syncthreads();
+        item = *drawn;
+        __syncthreads();
+    }
+    if (item >= n_items) break;
+    // tuning aid (FIERY_POOL_TRACE = address of 4 * n_items int64): the 100 MHz wall clock at the item's phases
+    if (trace && tid == 0) trace[4 * item] = wall_clock64();
+    int unit = item, part = 0, parts = 1;
     if (unit >= tail_first) {
         const int t = unit - tail_first;
         unit = tail_first + t / tail_parts;
@@ -1098,8 +1275,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
     const int f = unit / C;
 
     // ---- occupancy bytes -> bit map + exclusive prefix of the words' popcounts --------------------------------
-    int total;
-    {
+    if (f != f_have) {                                                    // (kept from the previous item of the same frame)
+        f_have = f;
         const unsigned char* occ_f = occ + static_cast<long long>(f) * n_words * 64;
         const int wpt = (n_w32 + kThreads - 1) / kThreads;               // consecutive 32-voxel words per thread
         int local = 0;
@@ -1139,8 +1316,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
             before += __popc(bits[w]);
         }
         __syncthreads();                                                  // scratch read, bits / prefix written
-        if (occupied && c == 0 && part == 0 && tid == 0) occupied[f] = total;
     }
+    if (occupied && c == 0 && part == 0 && tid == 0) occupied[f] = total;
+    if (trace && tid == 0) trace[4 * item + 1] = wall_clock64();
     auto cell_of = [&](int r) {                                           // r: a voxel that is occupied
         return static_cast<int>(prefix[r >> 5]) + __popc(bits[r >> 5] & ((1u << (r & 31)) - 1u));
     };
@@ -1352,17 +1530,22 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
         };
         vf4 rows_in_flight[kCompactRows];
         Record record;
-        const int s_first = wave + part * kWaves, s_step = kWaves * parts;
+        // a part is a contiguous range of slices (neighbouring depths of one or two cameras: it touches a fraction of the
+        // plane's cells, so its atomic write-out is short, and its rows are one stretch of memory)
+        const int s_lo = static_cast<int>(static_cast<long long>(part) * n_slices / parts);
+        const int s_end = static_cast<int>(static_cast<long long>(part + 1) * n_slices / parts);
+        const int s_first = s_lo + wave, s_step = kWaves;
         {
-            const bool has = s_first < n_slices;
+            const bool has = s_first < s_end;
             fetch_record(record, s_first, has);
             const int off = has ? slice_offset(s_first) : 0;
             const unsigned alive = has ? live_f[s_first] : 0u;
 #pragma unroll
             for (int j = 0; j < kCompactRows; ++j) request_row(rows_in_flight[j], j, off, ((alive >> q) & 1u) ? row_voff : kOob);
         }
-        for (int s = s_first; s < n_slices; s += s_step) process(rows_in_flight, record, s, s + s_step);
+        for (int s = s_first; s < s_end; s += s_step) process(rows_in_flight, record, s, s + s_step < s_end ? s + s_step : n_slices);
         __syncthreads();
+        if (trace && tid == 0) trace[4 * item + 2] = wall_clock64();
         // ---- expand the window of cells into the dense plane --------------------------------------------------
         if (parts == 1 && n_pass == 1 && (n_vox & 3) == 0 && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
             // one pass, whole units: every voxel gets its cell's sum or a zero - four voxels (one nibble of a bit word) per
@@ -1377,6 +1560,23 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
                 if (nib & 4u) v.z = plane[cell++];
                 if (nib & 8u) v.w = plane[cell];
                 *reinterpret_cast<float4*>(o + v0) = v;
+            }
+        } else if (parts > 1 && n_pass == 1 && (n_vox & 3) == 0) {
+            // a part adds its cells to the (pre-zeroed) plane: the same walk, four voxels per thread and step - a step per voxel
+            // is a chain of three dependent LDS reads, 78 of them in a row (12 us per part against 3 us for this form)
+            for (int v0 = 4 * tid; v0 < n_vox; v0 += 4 * kThreads) {
+                const unsigned wbits = bits[v0 >> 5];
+                const unsigned nib = (wbits >> (v0 & 31)) & 15u;
+                if (nib == 0u) continue;
+                int cell = static_cast<int>(prefix[v0 >> 5]) + __popc(wbits & ((1u << (v0 & 31)) - 1u));
+                float val[4] = {0.f, 0.f, 0.f, 0.f};
+                if (nib & 1u) val[0] = plane[cell++];
+                if (nib & 2u) val[1] = plane[cell++];
+                if (nib & 4u) val[2] = plane[cell++];
+                if (nib & 8u) val[3] = plane[cell];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (val[k] != 0.f) atomicAdd(&o[v0 + k], val[k]);
             }
         } else
         for (int v0 = tid; v0 < n_vox; v0 += kThreads) {
@@ -1393,6 +1593,20 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
             }
         }
         __syncthreads();                                                  // the plane is cleared again by the next pass
+    }
+    if (trace && tid == 0) trace[4 * item + 3] = wall_clock64();
+    }   // items
+    // The workgroup that finishes last leaves the workspace's cleared region (occupancy bytes, live masks, counters) as this
+    // launch found it - all zero - so the next call on this workspace can skip its memset dispatch
+    // (FIERY_POOL_WORKSPACE_CLEAN).  Every other workgroup has read what it needed from the region before it counted itself.
+    if (counters) {
+        __syncthreads();
+        if (tid == 0) *drawn = atomicAdd(counters + 1, 1);
+        __syncthreads();
+        if (*drawn == static_cast<int>(gridDim.x) - 1) {
+            const uint4 z = {0u, 0u, 0u, 0u};
+            for (int i = tid; i < clean_vec; i += kThreads) clean[i] = z;
+        }
     }
 }
 
@@ -1470,7 +1684,8 @@ int plan_pool(int frames, int n_cam, int D, int H, int W, long long n_vox_ll, in
     pl->n_words = ceil_div(pl->n_vox, 64);
     pl->off_occ = align(pl->off_lists + cols * pl->n_tiles * sizeof(int));
     pl->off_live = align(pl->off_occ + static_cast<size_t>(frames) * pl->n_words * 64);     // (cleared together with the bytes)
-    pl->off_occupied = align(pl->off_live + static_cast<size_t>(frames) * n_cam * D * 4);
+    // (+ 256 B: the counter the compact form's workgroups draw the parts of the tail units from; cleared with the masks)
+    pl->off_occupied = align(pl->off_live + static_cast<size_t>(frames) * n_cam * D * 4 + 256);
     pl->total = align(pl->off_occupied + static_cast<size_t>(frames) * 4);
     return FIERY_OK;
 }
@@ -1506,7 +1721,7 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
                   "voxel_pool: bev_dimension[2] = %d; the reference only supports one z cell "
                   "(fiery/models/fiery.py:268-271)", grid->dim[2]);
     FIERY_REQUIRE(grid->dim[0] > 0 && grid->dim[1] > 0, "voxel_pool: empty grid");
-    FIERY_REQUIRE((flags & ~FIERY_POOL_DETERMINISTIC) == 0, "voxel_pool: unknown flags 0x%x", flags);
+    FIERY_REQUIRE((flags & ~(FIERY_POOL_DETERMINISTIC | FIERY_POOL_WORKSPACE_CLEAN)) == 0, "voxel_pool: unknown flags 0x%x", flags);
     const bool fixed = (flags & FIERY_POOL_DETERMINISTIC) != 0;
     PoolPlan pl;
     int rc = plan_pool(frames, n_cam, D, H, W, static_cast<long long>(grid->dim[0]) * grid->dim[1], tile_voxels, fixed, fused, &pl);
@@ -1565,7 +1780,7 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
     if (const char* forced = getenv("FIERY_POOL_COMPACT")) compact_form = compact_form && atoi(forced) != 0;   // tuning / A-B runs
     if (compact_form) {
         // LDS: bit map (4 B per 32 voxels) + cell prefixes (2 B, or 4 B for grids of 65,535 voxels or more), then the cells
-        const long long fixed_bytes = ((static_cast<long long>(pl.n_words) * 2 * (4 + (pl.n_vox >= 65535 ? 4 : 2))) + 15) / 16 * 16;
+        const long long fixed_bytes = ((static_cast<long long>(pl.n_words) * 2 * (4 + (pl.n_vox >= 65535 ? 4 : 2))) + 15) / 16 * 16 + 16;
         const long long cells_max = (163840 - fixed_bytes) / 4;
         const long long cells_two = (81920 - fixed_bytes) / 4;
         long long cells = tile_voxels > 0 ? tile_voxels : cells_two;
@@ -1585,11 +1800,18 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
     unsigned char* occ = reinterpret_cast<unsigned char*>(ws + pl.off_occ);
     int* occupied = reinterpret_cast<int*>(ws + pl.off_occupied);
     unsigned* live = reinterpret_cast<unsigned*>(ws + pl.off_live);
-    if (compact_form && hipMemsetAsync(occ, 0, pl.off_occupied - pl.off_occ, s) != hipSuccess)     // occupancy bytes + live masks
+    // occupancy bytes + live masks + counters: cleared here unless the caller vouches that the region is as the library
+    // left it (the compact form's last workgroup re-zeroes it) or as a zero-filled allocation
+    if (compact_form && !(flags & FIERY_POOL_WORKSPACE_CLEAN) && hipMemsetAsync(occ, 0, pl.off_occupied - pl.off_occ, s) != hipSuccess)
         return fail(FIERY_ELAUNCH, "voxel_pool: cannot clear the occupancy map");
     // compact form: the units of the last, partly filled round are cut into parts (below); the planes they add to are zeroed
     // by the prepass
-    int cp_tail = 0, cp_parts = 1;
+    int cp_tail = 0, cp_parts = 1, cp_slots = 0;
+    // FIERY_POOL_PERSISTENT=1: one workgroup per slot of the chip, each taking its items in turn (see the kernel)
+    // (measured, profiles/r4_pool_decomposition.txt: the per-item grid with the tail units cut in four is as fast or faster
+    // than persistent workgroups with drawn parts - a part's fixed costs outweigh the better balance - so this is opt-in)
+    bool persistent = false;
+    if (const char* forced = getenv("FIERY_POOL_PERSISTENT")) persistent = atoi(forced) != 0;   // tuning / A-B runs
     if (compact_form) {
         const int n_units = C * frames;
         int dev = 0, n_cu = 0;
@@ -1597,6 +1819,7 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
             hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
             n_cu = 256;
         const int slots = n_cu * (cp_threads == 512 ? 2 : 1);
+        cp_slots = slots;
         cp_tail = n_units % slots;
         if (cp_tail > 0) cp_parts = slots / cp_tail;
         if (n_units < slots) cp_parts = 1;                               // a single, partly filled round: nothing to balance
@@ -1604,8 +1827,17 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
             cp_parts = atoi(forced);
             if (cp_parts > 1 && cp_tail == 0) cp_tail = n_units < 3 ? n_units : 3;
         }
-        if (cp_parts > 4 && !getenv("FIERY_POOL_TAIL_PARTS")) cp_parts = 4;   // (a part pays the bit-map set-up again: 4 measured best)
-        if (cp_parts > 8) cp_parts = 8;
+        // (a part pays the bit-map set-up again: with a dispatch per part 4 measured best; a persistent workgroup goes on
+        // to its part straight from its unit, and there as many parts as fill every slot are best)
+        if (cp_parts > 4 && !persistent && !getenv("FIERY_POOL_TAIL_PARTS")) cp_parts = 4;
+        // persistent workgroups draw the parts from a counter: finer parts (about three slices per wavefront) even out the
+        // workgroups' different speeds
+        if (persistent && cp_tail > 0 && cp_parts > 1 && !getenv("FIERY_POOL_TAIL_PARTS")) {
+            const int per_part = 3 * (cp_threads / 64);
+            cp_parts = (n_cam * D + per_part - 1) / per_part;
+            if (cp_parts < 2) cp_parts = 2;
+        }
+        if (cp_parts > 16) cp_parts = 16;
         if (cp_parts < 2) {
             cp_parts = 1;
             cp_tail = 0;
@@ -1620,7 +1852,18 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
         const long long occ_stride = static_cast<long long>(pl.n_words) * 64;
         int* mask_arg = (plane_form || compact_form) ? nullptr : colmask;
         const dim3 pgrid(ceil_div(n_cols_all, 256));
-        if (rows >= 28)
+        // four lanes per column (see k_rank_columns4) whenever a column's rows fit four parts of 7 or 8 (its run-start bits
+        // are one 32-bit word)
+        bool four = H <= 32;
+        if (const char* forced = getenv("FIERY_POOL_PREPASS_LANES")) four = four && atoi(forced) == 4;   // tuning / A-B runs
+        const dim3 pgrid4(ceil_div(n_cols_all, 64));
+        if (four && H <= 28)
+            hipLaunchKernelGGL((k_rank_columns4<7>), pgrid4, dim3(256), 0, s, geometry, frames * n_cam, D, H, W, to_params(*grid),
+                               pl.tile, rank, coldesc, mask_arg, desc_mode, occ_arg, n_cam, occ_stride, compact_form ? live : nullptr, clear_ptr, clear_floats);
+        else if (four)
+            hipLaunchKernelGGL((k_rank_columns4<8>), pgrid4, dim3(256), 0, s, geometry, frames * n_cam, D, H, W, to_params(*grid),
+                               pl.tile, rank, coldesc, mask_arg, desc_mode, occ_arg, n_cam, occ_stride, compact_form ? live : nullptr, clear_ptr, clear_floats);
+        else if (rows >= 28)
             hipLaunchKernelGGL((k_rank_columns<28>), pgrid, dim3(256), 0, s, geometry, frames * n_cam, D, H, W, to_params(*grid),
                                pl.tile, rank, coldesc, mask_arg, desc_mode, occ_arg, n_cam, occ_stride, compact_form ? live : nullptr, clear_ptr, clear_floats);
         else if (rows >= 14)
@@ -1639,7 +1882,15 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
         if (getenv("FIERY_POOL_VERBOSE"))
             fprintf(stderr, "voxel_pool compact: %d cells, %zu B LDS, %d threads, %d per CU, %d units + %d x %d parts\n", cp_cells,
                     cp_lds, cp_threads, per_cu, tail_first, tail, parts);
-        dim3 units(static_cast<unsigned>(tail_first + tail * parts));
+        const int n_items = tail_first + tail * parts;
+        dim3 units(static_cast<unsigned>(persistent && n_items > cp_slots ? cp_slots : n_items));
+        // (the counter lies in the cleared region in front of `occupied`)
+        int* draw = (persistent && tail > 0 && !getenv("FIERY_POOL_NO_DRAW")) ? reinterpret_cast<int*>(ws + pl.off_occupied - 256) : nullptr;
+        int* counters = reinterpret_cast<int*>(ws + pl.off_occupied - 256);       // [0] parts drawn, [1] workgroups finished
+        int late_first = cp_slots / 2, late_prio = 0;
+        if (const char* forced = getenv("FIERY_POOL_LATE_PRIO")) late_prio = atoi(forced);      // tuning / A-B runs
+        long long* trace = nullptr;
+        if (const char* t = getenv("FIERY_POOL_TRACE")) trace = reinterpret_cast<long long*>(strtoull(t, nullptr, 0));   // tuning
         bool nt = true;                                                  // non-temporal row loads (see the kernel)
         if (const char* forced = getenv("FIERY_POOL_NT")) nt = atoi(forced) != 0;                // tuning / A-B runs
 #define FIERY_POOL_COMPACT_LAUNCH(THREADS, WIDE, EXACT, NT)                                                              \
@@ -1650,7 +1901,8 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
             return fail(FIERY_ELAUNCH, "voxel_pool: cannot reserve %zu B of LDS", cp_lds);                              \
         hipLaunchKernelGGL((k_voxel_pool_compact<THREADS, WIDE, EXACT, NT>), units, dim3(THREADS), cp_lds, s, x, st, rank, \
                            static_cast<const void*>(coldesc), occ, live, out, occupied, n_cam, D, H, W, C, pl.n_vox, pl.n_words, \
-                           cp_cells, tail_first, parts);                                                                 \
+                           cp_cells, tail_first, parts, n_items, draw, trace, late_first, late_prio, counters,           \
+                           reinterpret_cast<uint4*>(occ), static_cast<int>((pl.off_occupied - pl.off_occ) / 16));        \
     } while (0)
 #define FIERY_POOL_COMPACT_ROWS(THREADS, WIDE)                            \
     do {                                                                 \

@@ -715,8 +715,18 @@ class BevEngine:
         key = ('poolws', f, n, d, h, w, self.pool_tile, self.pool_flags)
         ws = self._bufs.get(key)
         if ws is None:
-            ws = self._bufs[key] = self.lib.pool_workspace(f, n, d, h, w, device, self.grid, self.pool_tile, self.pool_flags)
+            # zero-filled once and then only ever handed to the library's pooling calls, each of which leaves it clean: they
+            # run with POOL_WORKSPACE_CLEAN and skip their memset dispatch (a call that raises drops the workspace)
+            ws = self._bufs[key] = self.lib.pool_workspace(f, n, d, h, w, device, self.grid, self.pool_tile, self.pool_flags,
+                                                           zeroed=True)
         return ws
+
+    def _pool_call(self, key_dims, fn):
+        try:
+            return fn()
+        except Exception:
+            self._bufs.pop(('poolws',) + key_dims + (self.pool_tile, self.pool_flags), None)
+            raise
 
     def pool(self, x, geometry, out=None):
         """`projection_to_birds_eye_view`: x logical (F, n, D, h, w, C) of any strides -> (F, C, X, Y) (written into
@@ -730,9 +740,9 @@ class BevEngine:
         # in-grid points; the prepass leaves every point's voxel rank (-1 = outside) at the head of the workspace, so
         # the profiling consumer counts them after the run (`pool_algorithmic_bytes`) - no device read-back here.
         detail = dict(workspace=ws, points=f * n * d * h * w, channels=c, frames=f, voxels=self.X * self.Y)
-        return ops.profiled('voxel_pool', None, x, lambda: self.lib.voxel_pool(
+        return ops.profiled('voxel_pool', None, x, lambda: self._pool_call((f, n, d, h, w), lambda: self.lib.voxel_pool(
             x, x.stride(), geometry.contiguous(), f, n, d, h, w, c, self.grid, out=out, workspace=ws,
-            tile_voxels=self.pool_tile, flags=self.pool_flags), detail=detail)
+            tile_voxels=self.pool_tile, flags=self.pool_flags | native.POOL_WORKSPACE_CLEAN)), detail=detail)
 
     def pool_fused(self, depth_logits, features, geometry, out=None):
         """depth logits (F, n, D, h, w) + features (F, n, C, h, w) -> (F, C, X, Y) without the outer product."""
@@ -743,8 +753,9 @@ class BevEngine:
             return res if out is None else out.copy_(res)
         prob = self.lib.depth_softmax(depth_logits.reshape(f * n, d, h, w).contiguous())
         ws = self._pool_workspace(f, n, d, h, w, features.device)
-        return self.lib.lift_splat(prob, features.contiguous(), geometry.contiguous(), f, n, d, h, w, c, self.grid,
-                                   out=out, workspace=ws, tile_voxels=self.pool_tile, flags=self.pool_flags)
+        return self._pool_call((f, n, d, h, w), lambda: self.lib.lift_splat(
+            prob, features.contiguous(), geometry.contiguous(), f, n, d, h, w, c, self.grid, out=out, workspace=ws,
+            tile_voxels=self.pool_tile, flags=self.pool_flags | native.POOL_WORKSPACE_CLEAN))
 
     def _run_distribution(self, ops, srcs, tag, mu=None, log_sigma=None):
         lib = self.lib

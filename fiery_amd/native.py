@@ -24,6 +24,7 @@ ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SWISH = 0, 1, 2, 3
 PRECISION_F32, PRECISION_BF16 = 0, 1
 EPI_PLAIN, EPI_GRU_GATES, EPI_GRU_OUT, EPI_HEADS = 0, 1, 2, 3
 POOL_DETERMINISTIC = 1
+POOL_WORKSPACE_CLEAN = 2        # the workspace is a zero-filled allocation or was left by a successful pooling call
 WARP_FUSED_GRID_PRODUCT = 1
 
 
@@ -274,12 +275,14 @@ class Lib:
         self.check(self.dll.fiery_voxel_index(_ptr(geometry), n, C.byref(grid), _ptr(rank), _ptr(idx), _stream_of(rank)))
         return rank, idx
 
-    def pool_workspace(self, frames, n_cam, d, h, w, device, grid, tile_voxels=0, flags=0):
+    def pool_workspace(self, frames, n_cam, d, h, w, device, grid, tile_voxels=0, flags=0, zeroed=False):
+        """`zeroed`: a zero-filled allocation - what a caller that keeps the workspace across calls needs in order to pass
+        POOL_WORKSPACE_CLEAN (every successful call leaves the workspace clean again)."""
         nbytes = self.dll.fiery_voxel_pool_workspace_bytes(frames, n_cam, d, h, w, grid.dim[0] * grid.dim[1],
                                                            tile_voxels, flags)
         if nbytes == 0:
             raise NativeError('libfiery_hip: unusable pooling problem size (see fiery_voxel_pool_workspace_bytes)')
-        return torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=device)
+        return (torch.zeros if zeroed else torch.empty)((nbytes + 3) // 4, dtype=torch.int32, device=device)
 
     def pool_occupied(self, workspace, frames, n_cam, d, h, w, grid, tile_voxels=0, flags=0):
         """Occupied voxels per frame, as the last compact-plane pooling call on `workspace` counted them (int32 view of the

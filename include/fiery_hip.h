@@ -71,6 +71,10 @@ int fiery_voxel_index(const float* geometry, int64_t n_points, const fiery_bev_g
                       int32_t* rank, int32_t* idx /* [n_points][3] or NULL */, fiery_stream_t stream);
 
 #define FIERY_POOL_DETERMINISTIC 1u  /* flags: bit-reproducible sums (order-independent fixed point), slower */
+/* flags: the caller vouches that the workspace is either a zero-filled allocation or was last used by a pooling call of
+ * this library that returned FIERY_OK (every call leaves the region it clears as it found it): the call then skips its
+ * memset dispatch.  Without the flag any workspace contents are accepted. */
+#define FIERY_POOL_WORKSPACE_CLEAN 2u
 
 /* Scratch needed by fiery_voxel_pool_fwd / fiery_lift_splat_fwd for this problem (n_voxels = X*Y;
  * tile_voxels and flags as passed to the pooling call); 0 if the arguments are unusable. */

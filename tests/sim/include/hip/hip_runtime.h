@@ -253,6 +253,20 @@ inline float __shfl_xor(float v, int mask) {
     return got;
 }
 
+inline int __shfl_xor(int v, int mask) {
+    float f;
+    __builtin_memcpy(&f, &v, 4);
+    ::hipsim::Run& run = *::hipsim::run_ptr();
+    const ::hipsim::Tls& t = ::hipsim::tls();
+    int* slot = reinterpret_cast<int*>(run.wave_a[t.wave].data());
+    slot[t.lane] = v;
+    ::hipsim::barrier_wait(run.waves[t.wave]);
+    const int got = slot[(t.lane ^ mask) & 63];
+    ::hipsim::barrier_wait(run.waves[t.wave]);
+    return got;
+}
+inline int __ffs(int v) { return __builtin_ffs(v); }
+
 // f32 MFMA 32x32x2: D = A(32x2) . B(2x32) + C, one wave.
 typedef float hipsim_v16f __attribute__((vector_size(64)));
 #define HIP_SYMBOL(x) (&(x))

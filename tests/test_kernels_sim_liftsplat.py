@@ -553,3 +553,99 @@ def test_fused_and_reproducible_forms_random_shapes(sim, case):
     if flags:
         again = sim.lift_splat(prob, feats, torch.from_numpy(geo), frames, n_cam, D, H, W, C, grid, flags=flags)
         assert torch.equal(again, fused)
+
+
+@pytest.mark.parametrize('persistent,C,frames', [(1, 6, 2), (0, 6, 2), (1, 5, 3), (1, 9, 1)])
+def test_compact_plane_form_persistent_workgroups(sim, monkeypatch, persistent, C, frames):
+    """More (channel, frame) units than the (simulated 4-CU) device has workgroup slots: the default launch is one workgroup
+    per slot, each taking whole units and then a part of a tail unit in turn - a workgroup's items lie in different frames
+    (the bit map is rebuilt) or in the same one (it is kept).  Same results as one workgroup per item, as the dense form and
+    as the float64 pooling."""
+    frustum, intr, extr, lifted = _small_problem(61, n_cam=2, D=12, H=28, W=40, C=C, frames=frames)
+    frames, n_cam, C, D, H, W = lifted.shape
+    geo = ls.get_geometry(frustum, intr.numpy(), extr.numpy())
+    grid, (res, start, dim) = _grid([-14.0, 30.0, 0.5], [-24.0, 10.0, 0.5], [-10.0, 10.0, 20.0])
+    st = lifted.stride()
+    strides = (st[0], st[1], st[3], st[4], st[5], st[2])
+    monkeypatch.setenv('FIERY_POOL_PERSISTENT', str(persistent))
+    ws = sim.pool_workspace(frames, n_cam, D, H, W, lifted.device, grid)
+    ws.fill_(-3)
+    garbage = torch.full((frames, C, int(dim[0]), int(dim[1])), 7.0)
+    out = sim.voxel_pool(lifted, strides, torch.from_numpy(geo), frames, n_cam, D, H, W, C, grid, out=garbage, workspace=ws)
+    occupied = sim.pool_occupied(ws, frames, n_cam, D, H, W, grid).clone()
+    monkeypatch.setenv('FIERY_POOL_COMPACT', '0')
+    dense = sim.voxel_pool(lifted, strides, torch.from_numpy(geo), frames, n_cam, D, H, W, C, grid)
+    assert (out - dense).abs().max() < 2e-5
+    for f in range(frames):
+        pts = ls.lifted_to_points(lifted[f].numpy())
+        exact = ls.voxel_pool_exact(pts, geo[f].reshape(-1, 3), res, start, dim)
+        assert np.abs(out[f].numpy() - exact).max() < 2e-5
+        _, keep, rank_o = ls.voxel_indices(geo[f].reshape(-1, 3), res, start, dim)
+        assert int(occupied[f]) == len(np.unique(rank_o[keep]))
+
+
+@pytest.mark.parametrize('H,form', [(28, 'compact'), (27, 'compact'), (14, 'compact'), (28, 'plane'), (28, 'tiled'), (31, 'tiled')])
+def test_four_lane_prepass_writes_what_the_one_lane_prepass_writes(sim, monkeypatch, H, form):
+    """The prepass with four lanes per column (the default when a column has at most 32 rows) against the one-thread-per-column
+    form: ranks, column descriptors / quad records, tile masks, occupancy bytes and live masks - the workspace byte for byte
+    up to the counters - and the pooled output, for each descriptor form, with rolled and pitched cameras (many-run and
+    two- / three-run columns) and rows past the end of a part (H = 27, 14, 31)."""
+    frustum, intr, extr, lifted = _small_problem(62, n_cam=3, D=10, H=H, W=40, C=2, frames=2)
+    roll = torch.tensor([[0.0, -1.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0], [0.0, 0.0, 1.0, 0.0], [0.0, 0.0, 0.0, 1.0]])
+    a = 0.06
+    pitch = torch.tensor([[1.0, 0.0, 0.0, 0.0], [0.0, float(np.cos(a)), -float(np.sin(a)), 0.0],
+                          [0.0, float(np.sin(a)), float(np.cos(a)), 0.0], [0.0, 0.0, 0.0, 1.0]])
+    extr = extr.clone()
+    extr[:, 0] = extr[:, 0] @ roll
+    extr[:, 1] = extr[:, 1] @ pitch
+    frames, n_cam, C, D, H, W = lifted.shape
+    geo = ls.get_geometry(frustum, intr.numpy(), extr.numpy())
+    grid, (res, start, dim) = _grid([-14.0, 30.0, 0.5], [-24.0, 10.0, 0.5], [-10.0, 10.0, 20.0])
+    st = lifted.stride()
+    strides = (st[0], st[1], st[3], st[4], st[5], st[2])
+    if form != 'compact':
+        monkeypatch.setenv('FIERY_POOL_COMPACT', '0')
+    if form == 'tiled':
+        monkeypatch.setenv('FIERY_POOL_PLANE', '0')
+    outs, spaces = [], []
+    for lanes in ('1', '4'):
+        monkeypatch.setenv('FIERY_POOL_PREPASS_LANES', lanes)
+        ws = sim.pool_workspace(frames, n_cam, D, H, W, lifted.device, grid)
+        ws.zero_()                                                       # (regions a form does not write must compare equal)
+        outs.append(sim.voxel_pool(lifted, strides, torch.from_numpy(geo), frames, n_cam, D, H, W, C, grid, workspace=ws))
+        end = sim.dll.fiery_voxel_pool_occupied_offset(frames, n_cam, D, H, W, grid.dim[0] * grid.dim[1], 0, 0) // 4 - 64
+        spaces.append(ws[:end].clone())
+    assert torch.equal(spaces[0], spaces[1])
+    assert torch.equal(outs[0], outs[1])
+    for f in range(frames):
+        _, keep, rank_o = ls.voxel_indices(geo[f].reshape(-1, 3), res, start, dim)
+        got = spaces[1][:frames * n_cam * D * H * W].view(frames, -1)[f].numpy().astype(np.int64)
+        assert np.array_equal(got >= 0, keep) and np.array_equal(got[keep], rank_o[keep])
+
+
+@pytest.mark.parametrize('persistent', [0, 1])
+def test_pooling_leaves_its_workspace_clean(sim, monkeypatch, persistent):
+    """FIERY_POOL_WORKSPACE_CLEAN: on a zero-filled workspace the compact form skips its memset; its last workgroup re-zeroes
+    the occupancy bytes, live masks and counters, so the NEXT call (another rig: other voxels occupied, other quads live) may
+    skip it too.  Results equal the unflagged calls' on a garbage workspace."""
+    from fiery_amd import native
+    monkeypatch.setenv('FIERY_POOL_PERSISTENT', str(persistent))
+    grid, (res, start, dim) = _grid([-14.0, 30.0, 0.5], [-24.0, 10.0, 0.5], [-10.0, 10.0, 20.0])
+    ws = None
+    for seed in (63, 64, 65):
+        frustum, intr, extr, lifted = _small_problem(seed, n_cam=2, D=12, H=28, W=40, C=5, frames=2)
+        frames, n_cam, C, D, H, W = lifted.shape
+        geo = torch.from_numpy(ls.get_geometry(frustum, intr.numpy(), extr.numpy()))
+        st = lifted.stride()
+        strides = (st[0], st[1], st[3], st[4], st[5], st[2])
+        if ws is None:
+            ws = sim.pool_workspace(frames, n_cam, D, H, W, lifted.device, grid, zeroed=True)
+        got = sim.voxel_pool(lifted, strides, geo, frames, n_cam, D, H, W, C, grid, workspace=ws, flags=native.POOL_WORKSPACE_CLEAN)
+        dirty = sim.pool_workspace(frames, n_cam, D, H, W, lifted.device, grid)
+        dirty.fill_(-5)
+        want = sim.voxel_pool(lifted, strides, geo, frames, n_cam, D, H, W, C, grid, workspace=dirty)
+        assert torch.equal(got, want)
+        off = sim.dll.fiery_voxel_pool_occupied_offset(frames, n_cam, D, H, W, grid.dim[0] * grid.dim[1], 0, 0) // 4
+        assert torch.equal(sim.pool_occupied(ws, frames, n_cam, D, H, W, grid), sim.pool_occupied(dirty, frames, n_cam, D, H, W, grid))
+        n_occ_words = frames * ((grid.dim[0] * grid.dim[1] + 63) // 64) * 16 + frames * n_cam * D + 64
+        assert int(ws[off - n_occ_words:off].abs().sum()) == 0           # occupancy bytes, live masks, counters: all zero again
