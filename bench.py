@@ -31,16 +31,32 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X dense bf16 matrix peak (no sparsity)
 PEAK_HBM_GBS = 8000.0             # MI355X HBM3E spec bandwidth
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over
-    this bench command - baseline.yml, fp32, batch 3 - folded by tools/pmc_traffic.py with the gfx950 correction); None when
-    the summary is absent.  Callers report it for THAT workload only: any other configuration's line carries null.
-    Counters cannot be collected from inside the timed process, so this is the one roofline field not measured live."""
-    for name in ('r3_pmc_traffic.json', 'r2_pmc_traffic.json', 'r1_pmc_traffic.json'):
+def pmc_traffic(kernels):
+    """HBM bytes per launch of `kernels` (summed) from the COMMITTED PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over
+    this bench command - baseline.yml, fp32, batch 3 - folded by tools/pmc_traffic.py with the gfx950 correction), with the
+    file they come from and the commit that file was last changed in; None when the summary is absent.  Callers report it for
+    THAT workload only: any other configuration's line carries null.  Counters cannot be collected from inside the timed
+    process, so this is the one roofline field not measured live - hence its name in the line, `traffic_from_profiles`."""
+    import subprocess
+    for name in ('r4_pmc_traffic.json', 'r3_pmc_traffic.json', 'r2_pmc_traffic.json', 'r1_pmc_traffic.json'):
+        path = os.path.join(ROOT, 'profiles', name)
         try:
-            return json.load(open(os.path.join(ROOT, 'profiles', name)))[kernel]['traffic_bytes']
+            table = json.load(open(path))
+            per_kernel = {}
+            for k in kernels:
+                hits = [v['traffic_bytes'] for key, v in table.items() if isinstance(v, dict) and (key == k or key.startswith(k))]
+                if not hits:
+                    raise KeyError(k)
+                per_kernel[k] = hits[0]
         except (OSError, KeyError, ValueError):
             continue
+        try:
+            commit = subprocess.run(['git', '-C', ROOT, 'log', '-1', '--format=%h', '--', os.path.join('profiles', name)],
+                                    capture_output=True, text=True, timeout=10).stdout.strip() or None
+        except (OSError, subprocess.SubprocessError):
+            commit = None
+        return {'bytes_per_launch': sum(per_kernel.values()), 'per_kernel': per_kernel, 'file': 'profiles/' + name, 'commit': commit,
+                'what': '2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes over this command (not collected in this run)'}
     return None
 
 
@@ -62,6 +78,8 @@ def parse():
                     help='matrix-core precision of the convolutions: f32 = the reference\'s arithmetic (configs[1], the parity '
                          'configuration); bf16 = operands rounded at the matrix cores, fp32 accumulate (configs[3] / [4])')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary-configs', action='store_true',
+                    help='skip the secondary lines of BASELINE.json configs[3] / [4] (pon_setting.yml bf16; lyft/baseline.yml with 7 cameras, bf16, one GPU)')
     ap.add_argument('--no-from-images', action='store_true', help='skip the secondary forward-from-images timing')
     ap.add_argument('--no-bf16-mode', action='store_true', help='skip the secondary timing of the same step with bf16 matrix-core operands')
     ap.add_argument('--no-graph', action='store_true', help='enqueue every launch from the host each step instead of '
@@ -74,9 +92,10 @@ def parse():
 
 
 def cpu_baseline(cfg, sd, lifted, K, E, ego, runs=3):
-    """The oracle (a port of the reference's CPU path on the same ATen CPU kernels) on the host cores, on a
-    bounded sample: one batch element of the same workload.  Returns the baseline dict and the sample's outputs (the
-    parity check of the GPU result rides on them)."""
+    """The oracle (a port of the reference's CPU path on the same ATen CPU kernels) on the host cores, on a bounded sample of
+    the same workload: one batch element (median of `runs` after a warm-up) and, once, the whole batch of the headline
+    configuration (BASELINE.md's north-star row is quoted at that batch).  Returns the baseline dict and the first sample's
+    outputs (the parity check of the GPU result rides on them)."""
     from oracle import bev_stack
     cores = len(os.sched_getaffinity(0))
     try:                                               # a cgroup CPU quota caps the usable cores below the affinity mask
@@ -87,6 +106,7 @@ def cpu_baseline(cfg, sd, lifted, K, E, ego, runs=3):
         pass
     torch.set_num_threads(cores)
     one = [t[:1].cpu() for t in (lifted, K, E, ego)]
+    whole = [t.cpu() for t in (lifted, K, E, ego)]
     sd_cpu = {k: v.cpu() for k, v in sd.items()}
     times = []
     with torch.no_grad():
@@ -95,10 +115,16 @@ def cpu_baseline(cfg, sd, lifted, K, E, ego, runs=3):
             t0 = time.perf_counter()
             out = bev_stack.bev_hot_path(sd_cpu, cfg, *one)
             times.append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        bev_stack.bev_hot_path(sd_cpu, cfg, *whole)
+        t_batch = time.perf_counter() - t0
     dt = sorted(times)[len(times) // 2]
+    n_batch = whole[0].shape[0]
     return {'value': 1.0 / dt, 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
             'sample': f'1 sample (batch 1 of the same workload), median of {runs} runs after 1 warm-up '
-                      f'({", ".join(f"{t:.2f}" for t in times)} s)'}, out
+                      f'({", ".join(f"{t:.2f}" for t in times)} s)',
+            'at_batch': {'batch': n_batch, 'value': round(n_batch / t_batch, 4), 'unit': 'samples/s',
+                         'sample': f'the whole batch of {n_batch} once ({t_batch:.2f} s), same cores, after the runs above'}}, out
 
 
 def main():
@@ -255,7 +281,8 @@ def main():
                     'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                     'by_precision': {k_: {'launches': n_, 'ms_per_step': round(t_ * 1e3, 3), 'tflops': round(f_ / t_ / 1e12, 2)}
                                      for k_, (t_, f_, n_) in by_prec.items()},
-                    'traffic': pmc_traffic('k_conv_igemm (all tile shapes)') if args.precision == 'f32' and args.config == 'baseline.yml' and n_cam == 6 and B == 3 else None,
+                    'traffic': None,             # (no counters in a timed run; the committed passes' figure follows)
+                    'traffic_from_profiles': pmc_traffic(['k_conv_igemm (all tile shapes)']) if args.precision == 'f32' and args.config == 'baseline.yml' and n_cam == 6 and B == 3 else None,
                     'launches': n_dom, 'avg_launch_us': round(t_dom / n_dom * 1e6, 2),
                     'algorithmic_gflop_per_step': round(f_conv / 1e9, 1), 'kernel_ms_per_step': round(t_conv * 1e3, 3),
                     'measured': 'HIP events around every launch of one instrumented step after the timed region, whole '
@@ -272,7 +299,8 @@ def main():
             gbs = b_pool / t_pool / 1e9
             pooling = {'kernel': 'k_rank_columns + k_voxel_pool_compact (op boundary projection_to_birds_eye_view)', 'bound': 'hbm',
                        'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
-                       'traffic': pmc_traffic('k_voxel_pool') if args.config == 'baseline.yml' and n_cam == 6 and B == 3 else None,
+                       'traffic': None,          # (no counters in a timed run; the committed passes' figure - prepass included - follows)
+                       'traffic_from_profiles': pmc_traffic(['k_voxel_pool', 'fiery::k_rank_columns']) if args.config == 'baseline.yml' and n_cam == 6 and B == 3 else None,
                        'algorithmic_mb_per_step': round(b_pool / 1e6, 1),
                        'op_us_per_step': round(t_pool * 1e6, 1), 'kept_fraction': round(kept_frac, 4),
                        'bytes': '4*C*N_kept + 12*N + 4*C*X*Y per frame (SURVEY 8d), N_kept counted from the ranks the op left'}
@@ -303,6 +331,18 @@ def main():
                                f'EfficientNet trunk + lift head + the hot path, {how}, mean of 5'}
         del image
 
+    # who took part: every rank's device, as the process group sees it (a SCALE record then shows N ranks on N devices)
+    me = {'rank': rank, 'local_rank': local_rank, 'device': f'cuda:{torch.cuda.current_device()}',
+          'name': torch.cuda.get_device_name(), 'pid': os.getpid()}
+    try:
+        me['pci_bus_id'] = torch.cuda.get_device_properties(torch.cuda.current_device()).pci_bus_id
+    except AttributeError:
+        pass
+    ranks = [me]
+    if use_dist:
+        import torch.distributed as dist
+        ranks = [None] * dist.get_world_size()
+        dist.all_gather_object(ranks, me)
     if rank == 0:
         line = {
             'metric': f'BEV samples/s ({n_cam} cams x {rf} frames -> {model.bev_size[0]}x{model.bev_size[1]} BEV, hot path from '
@@ -320,6 +360,8 @@ def main():
                        'launch': launch_mode + (', one stream per sample' if model.sample_streams else '')},
             'roofline': roofline, 'roofline_pooling': pooling, 'host_enqueue_ms_per_step': round(host_ms, 3),
             'forward_from_images': from_images,
+            'ranks': {'world_size': world, 'backend': ('nccl (RCCL), world ' + str(torch.distributed.get_world_size())) if use_dist else 'none (one process)',
+                      'devices': ranks},
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'], want = cpu_baseline(cfg, sd, lifted, K, E, ego)
@@ -330,8 +372,13 @@ def main():
                 got = {k: (None if v is None else v[:1].float().cpu()) for k, v in step().items()}
             line['parity'] = {k: {'max_abs_err': float(f'{(got[k] - v).abs().max().item():.3e}'),
                                   'ref_abs_max': round(v.abs().max().item(), 3),
-                                  'within_1e-4': bool((got[k] - v).abs().max().item() <= 1e-4)}     # (the fp32 configuration's bar)
+                                  'within_1e-4': bool((got[k] - v).abs().max().item() <= 1e-4),     # (the fp32 configuration's bar)
+                                  # the literal bar element by element: how many of the output's values pass it
+                                  'elements_within_1e-4': int(((got[k] - v).abs() <= 1e-4).sum().item()), 'elements': v.numel()}
                               for k, v in want.items() if v is not None}
+            line['parity_literal_1e-4'] = {'outputs_passing': sum(1 for r in line['parity'].values() if r['within_1e-4']),
+                                           'outputs': len(line['parity']),
+                                           'what': 'sample 0 of this run against the oracle, max-abs <= 1e-4 with no scaling'}
         # secondary figure (BASELINE.json configs[3] / [4] are bf16 configurations): the same step with bf16 matrix-core
         # operands, timed the same way after everything above - beside the headline, never as `value`; its outputs are
         # compared with the fp32 step's of this run (the accuracy side of that mode: DESIGN.md section 4)
@@ -365,6 +412,24 @@ def main():
                 line['bf16_mode'] = {'error': repr(e)[:200]}
             finally:
                 model.conv_precision = 'f32'
+        # secondary lines (BASELINE.json configs[3] and configs[4] at one GPU): this script again, in a process of its own,
+        # for pon_setting.yml (400 x 200 BEV, the pooling stress) and lyft/baseline.yml with 7 cameras, both with bf16
+        # matrix-core operands - each with its own `roofline` / `roofline_pooling`; beside the headline, never as `value`
+        if (world == 1 and not args.no_secondary_configs and args.precision == 'f32' and args.config == 'baseline.yml'
+                and not frames_layout and not args.fused and not args.cams):
+            import subprocess
+            line['secondary_configs'] = {}
+            for key, extra in (('pon_setting_bf16', ['--config', 'literature/pon_setting.yml', '--precision', 'bf16']),
+                               ('lyft_baseline_7cams_bf16', ['--config', 'lyft/baseline.yml', '--cams', '7', '--precision', 'bf16'])):
+                cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(args.steps), '--warmup', str(args.warmup), '--batch', str(B),
+                       '--no-cpu-baseline', '--no-from-images', '--no-bf16-mode', '--no-secondary-configs'] + extra
+                try:
+                    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                    sub = json.loads(res.stdout.strip().splitlines()[-1])
+                    line['secondary_configs'][key] = {k: sub.get(k) for k in ('metric', 'value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline',
+                                                                             'roofline_pooling', 'host_enqueue_ms_per_step')}
+                except Exception as e:                               # noqa: BLE001  (the headline line must not depend on it)
+                    line['secondary_configs'][key] = {'error': repr(e)[:200]}
         print(json.dumps(line), flush=True)
     if use_dist:
         import torch.distributed as dist

@@ -57,6 +57,25 @@ class _SamePadConv(nn.Conv2d):
         return F.conv2d(self.static_padding(x), self.weight, self.bias, self.stride, 0, self.dilation, self.groups)
 
 
+def same_pads(conv):
+    """(left, right, top, bottom) of a 'static same padding' convolution, read the way efficientnet-pytorch 0.7 publishes it
+    (`conv.static_padding`: an `nn.ZeroPad2d` with a `.padding` 4-tuple, or an `nn.Identity`): works for the package's
+    modules and for any restatement that keeps the attribute."""
+    pads = getattr(getattr(conv, 'static_padding', None), 'padding', None)
+    return tuple(int(v) for v in pads) if pads is not None else (0, 0, 0, 0)
+
+
+def mbconv_geometry(blk):
+    """(stride, input channels, output channels) of an MBConv block, read from its LAYERS - the names the checkpoint fixes
+    (`_expand_conv`, `_depthwise_conv`, `_project_conv`) - not from bookkeeping attributes, which differ between the
+    efficientnet-pytorch package (`_block_args`) and restatements of it.  The block has the identity skip iff
+    stride == 1 and cin == cout (`id_skip` is set for every block of the published b0 / b4 schedules)."""
+    dw = blk._depthwise_conv
+    stride = dw.stride[0] if isinstance(dw.stride, (tuple, list)) else dw.stride
+    first = blk._expand_conv if hasattr(blk, '_expand_conv') else dw
+    return int(stride), int(first.in_channels), int(blk._project_conv.out_channels)
+
+
 class MBConvBlock(nn.Module):
     def __init__(self, kernel, stride, expand, cin, cout, image_size, se_ratio=0.25):
         super().__init__()

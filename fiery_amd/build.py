@@ -45,7 +45,14 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=True):
-    objdir = os.path.join(HERE, 'build')
+    # FIERY_BUILD_VARIANT=name (+ FIERY_BUILD_FLAGS="-D..."): a second library for A/B runs on one GPU box,
+    # tools/ab/libfiery_hip_<name>.so, selected with FIERY_HIP_LIB=...; the in-tree library is left alone
+    variant = os.environ.get('FIERY_BUILD_VARIANT')
+    global OUT
+    objdir = os.path.join(HERE, 'build' if not variant else 'build_' + variant)
+    if variant:
+        os.makedirs(os.path.join(os.path.dirname(HERE), 'tools', 'ab'), exist_ok=True)
+        OUT = os.path.join(os.path.dirname(HERE), 'tools', 'ab', f'libfiery_hip_{variant}.so')
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_igemm_kernel.h'),
                os.path.join(CSRC, 'fiery_gfx950.h'), os.path.join(INCLUDE, 'fiery_hip.h')]
@@ -55,7 +62,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(objdir, name + '.o')
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            cmd = [HIPCC] + COMMON + TUNING + extra + ['-c', src, '-o', obj]
+            cmd = [HIPCC] + COMMON + TUNING + os.environ.get('FIERY_BUILD_FLAGS', '').split() + extra + ['-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)
             jobs.append((name, subprocess.Popen(cmd)))       # translation units compile side by side

@@ -37,6 +37,9 @@ namespace fiery {
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;    // k per LDS stage (4 units of 8 input channels)
+#ifndef FIERY_CONV_EPILOGUE_PRIO
+#define FIERY_CONV_EPILOGUE_PRIO 0     // wave priority of the epilogue (0 = unchanged); see the end of the K loop
+#endif
 // A fourth workgroup per CU for the scalar-addressed 128 x 32 kernel (A/B switch): measured in round 3 after its registers
 // were trimmed to fit - faster for the plain and the chained launch (106 vs 112, 131 vs 138 us), slower for the Bottleneck
 // tail with its third stage, the launch the step issues most (162 vs 153 us): off.  Measured again after that epilogue
@@ -78,6 +81,7 @@ struct ConvP {
     TensP res, out, out2, aux0, aux1;
     int cout_store;
     long long M;
+    int tiles_m;          // pixel tiles of the launch (the grid's x extent may be smaller: persistent workgroups, see k_conv_igemm)
     // exact division of a 31-bit pixel index by Hout Wout, Wout and Tout as multiply + shift (set by the host, see
     // conv_magic): the kernel's set-up divides a dozen times per thread, and a run-time divisor costs ~25 vector
     // instructions per division on this ISA
@@ -171,16 +175,29 @@ constexpr int conv_waves_per_simd(int bm, int bn, bool aligned = false, bool bf1
 // used it - with bf16's short MFMAs the loop was bound by LDS traffic, 3 KB per MFMA against the 1 KB per MFMA the LDS
 // can deliver at full matrix rate.)  The weights arrive already rounded and packed [k / 8][cout][k % 8]; products are
 // exact and accumulate in fp32.  Scalar-addressed loop only.
-template <int BM, int BN, bool CLK = false, int PRIO = 0, bool SMALLCIN = false, bool ALIGNED = false, bool BF16 = false, bool HALO = false>
-__global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK && !BF16, BF16, HALO)) void k_conv_igemm(ConvP p) {
+// One output tile (pixel tile `bid_x` of `nblk_x` in dispatch order, cout tile blockIdx.y); the kernel below walks a
+// workgroup through its tiles.
+template <int BM, int BN, bool CLK, int PRIO, bool SMALLCIN, bool ALIGNED, bool BF16, bool HALO>
+__device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const int nblk_x) {
     static_assert(!BF16 || (ALIGNED && !SMALLCIN && !CLK), "the bf16 form exists for the scalar-addressed loop");
     static_assert(!HALO || (ALIGNED && !SMALLCIN && !CLK && BN >= 64 && (BM == 64 || BF16)), "the halo loop: 64-pixel tiles (bf16: 128 too), 64 couts or more");
     unsigned long long clk_entry = 0;
-    if constexpr (CLK) clk_entry = clock64();
+    // (tuning builds: slot 7 of the probe block may hold the address of a timeline buffer - eight 64-bit words per tile: the
+    // 100 MHz wall clock at entry / K loop start / K loop end / end of the tile, and the hardware id of wave 0's SIMD)
+    unsigned long long* clk_trace = nullptr;
+    if constexpr (CLK) {
+        clk_entry = clock64();
+        if (threadIdx.x == 0 && g_clk_probe && g_clk_probe[7]) {
+            clk_trace = reinterpret_cast<unsigned long long*>(g_clk_probe[7]) + 8ull * (bid_x + static_cast<unsigned>(blockIdx.y) * nblk_x);
+            clk_trace[0] = wall_clock64();
+            clk_trace[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));     // HW_REG_HW_ID
+            clk_trace[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));    // HW_REG_XCC_ID
+        }
+    }
     if constexpr (PRIO == 1) {
         // experiment: workgroups that share a CU (dispatch order puts b and b + 256 on one CU first) get different wave
         // priorities, so that they do not march through their MFMA and load/store phases in lockstep
-        switch ((blockIdx.x >> 8) % 3) {
+        switch ((bid_x >> 8) % 3) {
             case 1: __builtin_amdgcn_s_setprio(1); break;
             case 2: __builtin_amdgcn_s_setprio(2); break;
             default: break;
@@ -209,16 +226,24 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
     static_assert((HALO || W_BASE + 2 * W_STAGE <= SMEM_FLOATS) && BM * BN + (BM == 64 && BN == 128 ? 256 : 0) <= SMEM_FLOATS,
                   "stages, staging tile and the heads' 1x1 rows must fit");
 
-    const int tid = threadIdx.x;
+    // (taken afresh for every tile of the persistent loop: hoisted out of it, everything derived from the thread index -
+    // a few dozen registers that the set-up needs and the K loop does not - would stay live across the whole tile)
+#if FIERY_CONV_EPILOGUE_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    int tid_ = threadIdx.x, tile_n_ = blockIdx.y;
+    opaque_v(tid_);
+    opaque_s(tile_n_);
+    const int tid = tid_;
     const int lane = tid & 63, wv = tid >> 6;
     const int wm = wv % WM, wn = wv / WM;
     const int m = lane & 31, hi = lane >> 5;
-    const int tile_n = blockIdx.y;
+    const int tile_n = tile_n_;
     // XCD-aware tile order: workgroup b runs on XCD b % 8, so give every XCD a contiguous run of pixel
     // tiles - neighbouring tiles share their 3x3 halo rows through that XCD's L2 instead of re-fetching them
     int tile_m;
     {
-        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int nblk = nblk_x, bid = bid_x;
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
         tile_m = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
@@ -507,7 +532,8 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
 
     unsigned long long clk_c0 = 0, clk_w0 = 0;
     if constexpr (CLK) {
-        if (tid == 0 && (blockIdx.x & 15) == 0) {
+        if (clk_trace) clk_trace[1] = wall_clock64();
+        if (tid == 0 && (bid_x & 15) == 0) {
             clk_c0 = clock64();
             clk_w0 = wall_clock64();
         }
@@ -815,9 +841,15 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
         if (chunk < c_k_chunks) stage_body(std::integral_constant<int, 0>{});
     }
     }      // !HALO
+    // The epilogue's vector and memory instructions share the SIMD with the other workgroups' MFMAs and, at equal priority,
+    // are served in the gaps those leave: an epilogue of 5 us alone takes 27 us there (profiles/r4_conv_phases.txt), a time
+    // during which this wavefront feeds the matrix pipe nothing.  Raised priority gets it through and back to MFMAs.
+#if FIERY_CONV_EPILOGUE_PRIO
+    __builtin_amdgcn_s_setprio(FIERY_CONV_EPILOGUE_PRIO);
+#endif
     if constexpr (CLK) {
         // effective shader clock under this kernel's load = cycles / ticks * 100 MHz
-        if (tid == 0 && (blockIdx.x & 15) == 0 && g_clk_probe) {
+        if (tid == 0 && (bid_x & 15) == 0 && g_clk_probe) {
             atomicAdd(g_clk_probe, static_cast<unsigned long long>(clock64() - clk_c0));
             atomicAdd(g_clk_probe + 1, static_cast<unsigned long long>(wall_clock64() - clk_w0));
             atomicAdd(g_clk_probe + 2, static_cast<unsigned long long>(clk_c0 - clk_entry));       // prologue (set-up + first loads)
@@ -825,9 +857,13 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
         }
     }
     const unsigned long long clk_loop_end = CLK ? clock64() : 0ull;
+    if constexpr (CLK) {
+        if (clk_trace) clk_trace[2] = wall_clock64();
+    }
     auto clk_finish = [&]() {                                  // epilogue cycles of the sampled workgroups (staged paths)
         if constexpr (CLK) {
-            if (tid == 0 && (blockIdx.x & 15) == 0 && g_clk_probe)
+            if (clk_trace) clk_trace[3] = wall_clock64();
+            if (tid == 0 && (bid_x & 15) == 0 && g_clk_probe)
                 atomicAdd(g_clk_probe + 3, static_cast<unsigned long long>(clock64() - clk_loop_end));
         }
     };
@@ -836,6 +872,7 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
     // A lane holds one cout for 16 scattered pixel rows, so storing from registers means 4-byte accesses 128 B
     // at a time; going through LDS turns the tile into full rows: every residual load and output store is a
     // 16-byte, unit-stride access.  `store_rows(width, ...)` finishes a staged tile of `width` couts.
+    int res_pre_rows = p.res_pre;                              // (the argument block itself is read-only)
     auto store_rows = [&](int width, int cout0, const float* scale, const float* shift, int act, bool with_bias) {
         const int c4n = width >> 2;                                 // 16-byte chunks per pixel row
         const int rows_per_pass = 256 / c4n;
@@ -896,7 +933,7 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
             const long long pp = ppi;
             if (p.epi == FIERY_EPI_PLAIN) {
                 const float4 r = cur.a;
-                if (p.res_pre) { v.x += r.x;  v.y += r.y;  v.z += r.z;  v.w += r.w; }
+                if (res_pre_rows) { v.x += r.x;  v.y += r.y;  v.z += r.z;  v.w += r.w; }
                 if (act == FIERY_ACT_RELU) {
                     v.x = fmaxf(v.x, 0.f);  v.y = fmaxf(v.y, 0.f);  v.z = fmaxf(v.z, 0.f);  v.w = fmaxf(v.w, 0.f);
                 } else if (act == FIERY_ACT_SIGMOID) {
@@ -904,7 +941,7 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
                 } else if (act == FIERY_ACT_SWISH) {
                     v.x *= sigmoidf(v.x);  v.y *= sigmoidf(v.y);  v.z *= sigmoidf(v.z);  v.w *= sigmoidf(v.w);
                 }
-                if (!p.res_pre) { v.x += r.x;  v.y += r.y;  v.z += r.z;  v.w += r.w; }
+                if (!res_pre_rows) { v.x += r.x;  v.y += r.y;  v.z += r.z;  v.w += r.w; }
                 *reinterpret_cast<float4*>(p.out.ptr + o * p.out.istride + pp * p.out.ld + co) = v;
             } else if (p.epi == FIERY_EPI_GRU_GATES) {
                 float4 g = make_float4(sigmoidf(v.x), sigmoidf(v.y), sigmoidf(v.z), sigmoidf(v.w));
@@ -1139,10 +1176,8 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
                         smem[pl * 64 + nt * 32 + m] = acc2[nt][r];
                     }
                 __syncthreads();
-                const int keep_res_pre = p.res_pre;
-                p.res_pre = 0;                                     // the chained form adds the residual after the activation
+                res_pre_rows = 0;                                  // the chained form adds the residual after the activation
                 store_rows(64, 0, p.scale2, p.shift2, p.act2, false);
-                p.res_pre = keep_res_pre;
                 clk_finish();
                 return;
             }
@@ -1331,6 +1366,47 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
     }
 }
 
+// A workgroup takes the pixel tiles bid, bid + gridDim.x, ... one after another.  By default the grid has one workgroup per
+// tile and the loop runs once; FIERY_CONV_PERSISTENT=1 caps the grid at one workgroup per slot of the chip (round 4's
+// experiment: would workgroups that stay hide each other's epilogue and set-up under their K loops?  see conv_persistent_grid).
+template <int BM, int BN, bool CLK = false, int PRIO = 0, bool SMALLCIN = false, bool ALIGNED = false, bool BF16 = false, bool HALO = false>
+__global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK && !BF16, BF16, HALO)) void k_conv_igemm(ConvP p) {
+    const int n_tiles_m = p.tiles_m;
+    for (int bid = blockIdx.x; bid < n_tiles_m; bid += gridDim.x) {
+        // the argument block is read afresh for every tile (kernel_args_again: an offset the optimiser cannot see through):
+        // hoisted out of the loop its hundred scalars stay live across the tile and spill (168 registers + 496 B of scratch);
+        // read in place, never copied: the heads' members are indexed at run time and a copy would live in scratch
+        conv_tile<BM, BN, CLK, PRIO, SMALLCIN, ALIGNED, BF16, HALO>(kernel_args_again(p), bid, n_tiles_m);
+        if (bid + static_cast<int>(gridDim.x) < n_tiles_m) __syncthreads();      // the next tile's first stage overwrites the staging tile
+    }
+}
+
+// The grid of a launch: one workgroup per pixel tile and cout tile, capped at the workgroups the chip holds at once
+// (`per_cu` per CU - the kernel's launch bound; a multiple of 8 in x so that the tile order stays XCD-aware); the kernel's
+// workgroups then take several pixel tiles each.  FIERY_CONV_PERSISTENT=0: a workgroup per tile (A/B runs).
+inline dim3 conv_persistent_grid(ConvP& q, dim3 grid, int per_cu) {
+    q.tiles_m = static_cast<int>(grid.x);
+    int dev = 0, n_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+        n_cu = 256;
+    // Measured (profiles/r4_conv_phases.txt, r4_conv_persistent_ab.txt): NOT faster - 281 against 286 samples/s on baseline.yml;
+    // the workgroups of a CU are not in step to begin with (a tile's K loop takes 55-115 us depending on what its neighbours
+    // are doing), so there was no idle phase to fill, and a persistent workgroup's set-up meets two running K loops.  Opt-in.
+    const char* e = getenv("FIERY_CONV_PERSISTENT");
+    if (!e || atoi(e) == 0) return grid;
+    int cap = (n_cu * per_cu / static_cast<int>(grid.y > 0 ? grid.y : 1)) & ~7;
+    if (cap < 8) cap = 8;
+    if (static_cast<int>(grid.x) > cap) grid.x = static_cast<unsigned>(cap);
+    return grid;
+}
+#define FIERY_CONV_LAUNCH(BM_, BN_, CLK_, PRIO_, SMALL_, ALIGNED_, BF16_, HALO_)                                              \
+    do {                                                                                                                     \
+        ConvP q_ = p;                                                                                                        \
+        const dim3 g_ = conv_persistent_grid(q_, grid, conv_waves_per_simd(BM_, BN_, ALIGNED_ && !CLK_ && !BF16_, BF16_, HALO_)); \
+        hipLaunchKernelGGL((k_conv_igemm<BM_, BN_, CLK_, PRIO_, SMALL_, ALIGNED_, BF16_, HALO_>), g_, dim3(256), 0, hs, q_);   \
+    } while (0)
+
 // ---- weight packing ------------------------------------------------------------------------------
 // The variants of tile shape (BM, BN) that exist: generic and scalar-addressed for all five shapes, the small-cin
 // loop for the four shapes that use it, the probes only in tuning builds (FIERY_CONV_TUNING=1: they double the
@@ -1339,15 +1415,15 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
 // minutes each to compile, is spread over two units.
 template <int BM, int BN>
 void conv_launch_tile_bf16(const ConvP& p, dim3 grid, hipStream_t hs) {
-    hipLaunchKernelGGL((k_conv_igemm<BM, BN, false, 0, false, true, true>), grid, dim3(256), 0, hs, p);
+    FIERY_CONV_LAUNCH(BM, BN, false, 0, false, true, true, false);
 }
 template <int BM, int BN>
 void conv_launch_tile_f32_halo(const ConvP& p, dim3 grid, hipStream_t hs) {
-    hipLaunchKernelGGL((k_conv_igemm<BM, BN, false, 0, false, true, false, true>), grid, dim3(256), 0, hs, p);
+    FIERY_CONV_LAUNCH(BM, BN, false, 0, false, true, false, true);
 }
 template <int BM, int BN>
 void conv_launch_tile_bf16_halo(const ConvP& p, dim3 grid, hipStream_t hs) {
-    hipLaunchKernelGGL((k_conv_igemm<BM, BN, false, 0, false, true, true, true>), grid, dim3(256), 0, hs, p);
+    FIERY_CONV_LAUNCH(BM, BN, false, 0, false, true, true, true);
 }
 
 template <int BM, int BN, unsigned kMask>
@@ -1355,19 +1431,19 @@ bool conv_launch_tile(const ConvP& p, dim3 grid, hipStream_t hs, int variant, un
     (void)clk;
     if constexpr ((kMask >> kConvGeneric) & 1u) {
         if (variant == kConvGeneric) {
-            hipLaunchKernelGGL((k_conv_igemm<BM, BN>), grid, dim3(256), 0, hs, p);
+            FIERY_CONV_LAUNCH(BM, BN, false, 0, false, false, false, false);
             return true;
         }
     }
     if constexpr ((kMask >> kConvAligned) & 1u) {
         if (variant == kConvAligned) {
-            hipLaunchKernelGGL((k_conv_igemm<BM, BN, false, 0, false, true>), grid, dim3(256), 0, hs, p);
+            FIERY_CONV_LAUNCH(BM, BN, false, 0, false, true, false, false);
             return true;
         }
     }
     if constexpr ((kMask >> kConvSmallCin) & 1u) {
         if (variant == kConvSmallCin) {
-            hipLaunchKernelGGL((k_conv_igemm<BM, BN, false, 0, true>), grid, dim3(256), 0, hs, p);
+            FIERY_CONV_LAUNCH(BM, BN, false, 0, true, false, false, false);
             return true;
         }
     }
@@ -1376,12 +1452,12 @@ bool conv_launch_tile(const ConvP& p, dim3 grid, hipStream_t hs, int variant, un
         if (variant == kConvClock || variant == kConvClockAligned) {
             if (hipMemcpyToSymbolAsync(HIP_SYMBOL(g_clk_probe), &clk, sizeof(clk), 0, hipMemcpyHostToDevice, hs) != hipSuccess)
                 return false;
-            if (variant == kConvClockAligned) hipLaunchKernelGGL((k_conv_igemm<BM, BN, true, 0, false, true>), grid, dim3(256), 0, hs, p);
-            else hipLaunchKernelGGL((k_conv_igemm<BM, BN, true>), grid, dim3(256), 0, hs, p);
+            if (variant == kConvClockAligned) FIERY_CONV_LAUNCH(BM, BN, true, 0, false, true, false, false);
+            else FIERY_CONV_LAUNCH(BM, BN, true, 0, false, false, false, false);
             return true;
         }
         if (variant == kConvPrio) {
-            hipLaunchKernelGGL((k_conv_igemm<BM, BN, false, 1>), grid, dim3(256), 0, hs, p);
+            FIERY_CONV_LAUNCH(BM, BN, false, 1, false, false, false, false);
             return true;
         }
     }

@@ -103,4 +103,22 @@ __device__ __forceinline__ unsigned short bf16_bits(float v) {
 // three batches of rows in registers - or rather in scratch.)
 __device__ __forceinline__ void pk_pin(v2f& a, v2f& b, v2f& c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c) : : "memory"); }
 
+
+// A value the optimiser must take as it finds it at this point (per-lane / wave-uniform): what is derived from it inside a
+// loop body is recomputed there instead of being hoisted out and kept in registers across the body.
+__device__ __forceinline__ void opaque_v(int& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void opaque_s(int& v) { asm volatile("" : "+s"(v)); }
+
+// The kernel's argument block (its first and only explicit argument), re-read from the kernarg segment behind an offset the
+// optimiser cannot see through: inside a loop the loads stay inside the loop (scalar loads from constant memory, cached)
+// instead of being hoisted and kept live across the body.
+template <typename Args>
+__device__ __forceinline__ const Args& kernel_args_again(const Args&) {
+    int off = 0;
+    asm volatile("" : "+s"(off));
+    const __attribute__((address_space(4))) char* ka =
+        (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    return *(const Args*)(ka + off);
+}
+
 }  // namespace fiery

@@ -119,11 +119,7 @@ class _Bottleneck:
         tail(s2)
 
 
-def _same_pads(conv):
-    """(left, right, top, bottom) of an efficientnet-pytorch 'static same padding' convolution."""
-    pad = getattr(conv, 'static_padding', None)
-    pads = getattr(pad, 'padding', None)
-    return tuple(int(v) for v in pads) if pads is not None else (0, 0, 0, 0)
+from .backbone import mbconv_geometry, same_pads as _same_pads      # noqa: E402  (layer-derived: any EfficientNet with the package's names)
 
 
 def _out_size(size, k, stride, before, after):
@@ -138,7 +134,7 @@ class _MBConv:
 
     def __init__(self, eng, blk):
         lib, dev = eng.lib, eng.device
-        self.cin, self.cout, self.stride = blk.cin, blk.cout, blk.stride
+        self.stride, self.cin, self.cout = mbconv_geometry(blk)
         dw = blk._depthwise_conv
         self.mid = dw.in_channels
         self.k = dw.kernel_size[0]

@@ -103,6 +103,8 @@ def randomise_weights(model, seed=2):
             v = 0.5 + torch.rand(t.shape, generator=g)
         elif key.endswith('running_mean'):
             v = 0.2 * torch.randn(t.shape, generator=g)
+        elif t.dim() == 0:                                     # (the trainer's uncertainty weights, fiery/trainer.py:42-64)
+            v = 0.1 * torch.randn((), generator=g)
         elif t.dim() == 1 and key.endswith('weight'):          # BN / affine scale
             v = 0.75 + 0.5 * torch.rand(t.shape, generator=g)
         elif t.dim() == 1:

@@ -35,6 +35,7 @@ import torch
 import torch.nn.functional as F
 
 from . import native
+from .backbone import mbconv_geometry, same_pads
 from .ops import Buf, ConvOp, identity_chan_map, round_up
 
 
@@ -842,8 +843,7 @@ class TrainGraph:
     def _same_pad_conv(self, x, conv):
         """A convolution of the trunk with its 'static same' padding (fixed at construction, asymmetric: right / bottom get the
         odd pixel): dense ones on `HipConv2d` after an explicit pad, depthwise ones on `HipDepthwiseConv2d`."""
-        pad = getattr(conv, 'static_padding', None)
-        left, right, top, bottom = tuple(pad.padding) if isinstance(pad, torch.nn.ZeroPad2d) else (0, 0, 0, 0)
+        left, right, top, bottom = same_pads(conv)
         if conv.groups == 1:
             if left or right or top or bottom:
                 x = F.pad(x, (left, right, top, bottom))
@@ -862,7 +862,8 @@ class TrainGraph:
         The two dense layers of the squeeze-and-excite act on 1x1 maps: matrix products, not convolutions (section 9c)."""
         swish = lambda t: t * torch.sigmoid(t)
         x = inputs
-        if blk.expand != 1:
+        stride, cin, cout = mbconv_geometry(blk)
+        if hasattr(blk, '_expand_conv'):
             x = swish(self.bn_act(self._same_pad_conv(x, blk._expand_conv), blk._bn0, relu=False))
         x = swish(self.bn_act(self._same_pad_conv(x, blk._depthwise_conv), blk._bn1, relu=False))
         gate = (HipSpatialMean.apply(x, self.lib) if self._hip_ops else x.mean(dim=(2, 3)))
@@ -870,7 +871,7 @@ class TrainGraph:
         gate = F.linear(gate, blk._se_expand.weight.flatten(1), blk._se_expand.bias)
         x = torch.sigmoid(gate)[:, :, None, None] * x
         x = self.bn_act(self._same_pad_conv(x, blk._project_conv), blk._bn2, relu=False)
-        if blk.stride == 1 and blk.cin == blk.cout:
+        if stride == 1 and cin == cout:
             if drop_connect_rate and blk.training:
                 keep = 1.0 - drop_connect_rate
                 mask = torch.floor(keep + torch.rand(x.shape[0], 1, 1, 1, dtype=x.dtype, device=x.device))

@@ -94,6 +94,37 @@ def _install_shims():
                 return torch.sum(to_reduce)
             raise ValueError('Reduction parameter unknown.')
 
+        class _Recorder:
+            """What `self.logger.experiment` is asked to do, kept for the test to look at."""
+            def __init__(self):
+                self.scalars, self.videos = [], []
+
+            def add_scalar(self, key, value, global_step=None):
+                self.scalars.append((key, float(value), global_step))
+
+            def add_video(self, name, video, global_step=None, fps=None):
+                self.videos.append((name, global_step))
+
+        class LightningModule(nn.Module):
+            """pytorch-lightning 1.1's LightningModule as far as fiery/trainer.py and evaluate.py use it: an nn.Module with a
+            settable `hparams`, `log`, a `logger.experiment`, and `load_from_checkpoint` (a `torch.save`d dict with
+            'state_dict' and 'hyper_parameters', the two checkpoint keys the class reads)."""
+            def __init__(self):
+                super().__init__()
+                self.logged = {}
+                self.logger = types.SimpleNamespace(experiment=_Recorder())
+
+            def log(self, key, value, **kwargs):
+                self.logged[key] = value
+
+            @classmethod
+            def load_from_checkpoint(cls, checkpoint_path, strict=True, **kwargs):
+                ckpt = torch.load(checkpoint_path, map_location='cpu', weights_only=False)
+                module = cls(ckpt['hyper_parameters'])
+                module.load_state_dict(ckpt['state_dict'], strict=strict)
+                return module
+
+        pl.LightningModule = LightningModule
         metric_mod.Metric = Metric
         classification.stat_scores_multiple_classes = stat_scores_multiple_classes
         reduction_mod.reduce = reduce
@@ -101,6 +132,107 @@ def _install_shims():
                             'pytorch_lightning.metrics.metric': metric_mod, 'pytorch_lightning.metrics.functional': functional,
                             'pytorch_lightning.metrics.functional.classification': classification,
                             'pytorch_lightning.metrics.functional.reduction': reduction_mod})
+
+    if 'fvcore' not in sys.modules:
+        # fiery/config.py:2 builds its defaults on fvcore's CfgNode (yacs + `_BASE_` files): configuration plumbing, restated
+        # here as far as config.py:32-148 and trainer.py:21 use it
+        import copy
+        import yaml
+        fv = types.ModuleType('fvcore')
+        common = types.ModuleType('fvcore.common')
+        config = types.ModuleType('fvcore.common.config')
+
+        class CfgNode(dict):
+            def __init__(self, init_dict=None):
+                super().__init__()
+                for k, v in (init_dict or {}).items():
+                    self[k] = CfgNode(v) if isinstance(v, dict) and not isinstance(v, CfgNode) else v
+                self.__dict__['_frozen'] = False
+
+            def __getattr__(self, name):
+                try:
+                    return self[name]
+                except KeyError:
+                    raise AttributeError(name)
+
+            def __setattr__(self, name, value):
+                if self.__dict__.get('_frozen'):
+                    raise AttributeError(f'attempted to modify the frozen config key {name}')
+                self[name] = value
+
+            def clone(self):
+                return copy.deepcopy(self)
+
+            def __deepcopy__(self, memo):
+                new = type(self)()
+                for k, v in self.items():
+                    dict.__setitem__(new, k, copy.deepcopy(v, memo))
+                return new
+
+            def freeze(self):
+                self._set_frozen(True)
+
+            def defrost(self):
+                self._set_frozen(False)
+
+            def _set_frozen(self, flag):
+                self.__dict__['_frozen'] = flag
+                for v in self.values():
+                    if isinstance(v, CfgNode):
+                        v._set_frozen(flag)
+
+            def merge_from_other_cfg(self, other):
+                for k, v in other.items():
+                    if k not in self:
+                        raise KeyError(f'non-existent config key: {k}')
+                    if isinstance(v, dict) and isinstance(self[k], CfgNode):
+                        self[k].merge_from_other_cfg(v if isinstance(v, CfgNode) else CfgNode(v))
+                    else:
+                        cur = self[k]
+                        if isinstance(cur, tuple) and isinstance(v, list):
+                            v = tuple(v)
+                        elif isinstance(cur, list) and isinstance(v, tuple):
+                            v = list(v)
+                        dict.__setitem__(self, k, copy.deepcopy(v))
+
+            def merge_from_file(self, path):
+                def load(pth):
+                    with open(pth) as f:
+                        raw = yaml.safe_load(f) or {}
+                    base = raw.pop('_BASE_', None)
+                    if base is None:
+                        return raw
+                    if not os.path.isabs(base):
+                        base = os.path.join(os.path.dirname(pth), base)
+                    merged = load(base)
+
+                    def overlay(dst, src):
+                        for k, v in src.items():
+                            if isinstance(v, dict) and isinstance(dst.get(k), dict):
+                                overlay(dst[k], v)
+                            else:
+                                dst[k] = v
+                    overlay(merged, raw)
+                    return merged
+                self.merge_from_other_cfg(CfgNode(load(path)))
+
+            def merge_from_list(self, opts):
+                import ast
+                for key, value in zip(opts[0::2], opts[1::2]):
+                    node = self
+                    parts = key.split('.')
+                    for part in parts[:-1]:
+                        node = node[part]
+                    if isinstance(value, str):
+                        try:
+                            value = ast.literal_eval(value)
+                        except (ValueError, SyntaxError):
+                            pass
+                    node.merge_from_other_cfg(CfgNode({parts[-1]: value}))
+
+        config.CfgNode = CfgNode
+        fv.common, common.config = common, config
+        sys.modules.update({'fvcore': fv, 'fvcore.common': common, 'fvcore.common.config': config})
 
     if 'efficientnet_pytorch' not in sys.modules:
         eff = types.ModuleType('efficientnet_pytorch')
@@ -137,6 +269,23 @@ def load_reference():
     ns.fiery_model = importlib.import_module('fiery.models.fiery')
     ns.Fiery = ns.fiery_model.Fiery
     _REF = ns
+    return ns
+
+
+def load_reference_callers(batches=None):
+    """The reference's caller code, unmodified: `fiery.config`, `fiery.losses`, `fiery.trainer` (TrainingModule) and, when
+    `batches` is given, `evaluate` (repository root) with `fiery.data.prepare_dataloaders` standing in for the nuScenes /
+    Lyft loaders (absent packages, absent datasets): it returns `batches` as the validation loader.  Returns a namespace."""
+    import importlib
+    ns = load_reference()
+    ns.config = importlib.import_module('fiery.config')
+    ns.losses = importlib.import_module('fiery.losses')
+    ns.trainer = importlib.import_module('fiery.trainer')
+    if batches is not None:
+        data = types.ModuleType('fiery.data')
+        data.prepare_dataloaders = lambda cfg: (None, batches)
+        sys.modules['fiery.data'] = data
+        ns.evaluate_path = os.path.join(REFERENCE_ROOT, 'evaluate.py')
     return ns
 
 

@@ -319,6 +319,7 @@ inline unsigned long long wall_clock64() { return 0; }
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }      // only ever applied to wave-uniform values
 inline void __builtin_amdgcn_sched_barrier(int) {}
 inline void __builtin_amdgcn_s_setprio(int) {}
+inline unsigned __builtin_amdgcn_s_getreg(int) { return 0; }
 inline void __builtin_amdgcn_s_waitcnt(int) {}
 inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 

@@ -116,6 +116,27 @@ def test_frame_sharding_with_the_all_to_all_exchange_moves_each_frame_to_its_own
     assert covered == list(range(batch))
 
 
+@pytest.mark.parametrize('exchange', ['all_gather', 'all_to_all'])
+def test_baseline_config_2_bookkeeping_at_eight_ranks(exchange):
+    """BASELINE.json configs[2]: baseline.yml, global batch 24 over 8 ranks, frames sharded for lift-splat (72 frames, 9 per
+    rank), one exchange, then 3 samples per rank.  With block partitions of both frames and samples a rank pools exactly its
+    own samples' frames: the all-to-all-v moves nothing across ranks, the all-gather hands every rank all 72 maps."""
+    from fiery_amd.parallel import sample_owner_ranges
+    world, batch, S = 8, 24, 3
+    res = _run(world=world, batch=batch, S=S, layout='frames', exchange=exchange)
+    assert sorted(f for r in range(world) for lo, hi in res[r]['calls'] for f in range(lo, hi)) == list(range(72))
+    assert sample_owner_ranges(batch, world) == [(3 * r, 3 * r + 3) for r in range(world)]
+    for r in range(world):
+        assert res[r]['layout'] == 'frames'
+        assert res[r]['calls'] == [(9 * r, 9 * r + 9)]                          # one pooling call: this rank's nine frames
+        assert res[r]['out']['range'] == (3 * r, 3 * r + 3)
+        want = torch.stack([_frame_value(f) for f in range(9 * r, 9 * r + 9)])
+        assert torch.equal(res[r]['out']['bev'], want)
+        if exchange == 'all_to_all':
+            assert res[r]['moved'] == [0]                                        # every frame already sits with its sample's owner
+        assert torch.equal(res[r]['full'], torch.arange(5, dtype=torch.float32).view(-1, 1))
+
+
 # ---- the real entry point (`sharded_bev_forward`) on the CPU-simulated kernels, 2 ranks over gloo -------------------
 def _sim_worker(rank, world, port, batch, layout, results, exchange='all_gather'):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
