@@ -353,7 +353,9 @@ int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, bool launch) {
         const long long span = (n_batch - 1) * d->src[s].batch_stride +
                                (static_cast<long long>(d->T_out) + d->kT + d->t_in_add) * d->src[s].time_stride +
                                (static_cast<long long>(d->Hin) + d->kH) * (d->Win + d->kW) * d->src[s].ld;
-        aligned = d->src[s].batch_stride >= 0 && d->src[s].time_stride >= 0 && span < (1ll << 29);
+        // (the descriptor size of the scalar-addressed and halo loops is p.src[s].ext_bytes, computed above from the exact
+        // extents; 0 there means "out of range" and would make every load return zeros - tie the two conditions together)
+        aligned = d->src[s].batch_stride >= 0 && d->src[s].time_stride >= 0 && span < (1ll << 29) && p.src[s].ext_bytes > 0;
     }
     if (const char* forced = getenv("FIERY_CONV_ALIGNED")) aligned = aligned && atoi(forced) != 0;       // tuning / tests
     int variant = aligned ? kConvAligned : kConvGeneric;

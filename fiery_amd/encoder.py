@@ -2,10 +2,9 @@
 
 Interface and `state_dict` names follow the reference's `Encoder`
 (reference: fiery/models/encoder.py:7-104): `backbone.*`, `upsampling_layer.conv.{0,1,3,4}.*`,
-`depth_layer.*`.  The trunk is outside this round's hand-written-kernel scope (SURVEY.md section 8,
-row a4 / section 8f rank 1) and runs on stock PyTorch-ROCm operators.  The lift head behind it (x2 bilinear of the
-coarse level, concat, two 3x3 conv+BN+ReLU, the 1x1 depth layer) runs on the HIP engine when the model is on the GPU in
-inference (`engine.BevEngine.lift_head`); its two results - depth logits and context features - feed the fused HIP
+`depth_layer.*`.  On the GPU the trunk and the lift head behind it (x2 bilinear of the coarse
+level, concat, two 3x3 conv+BN+ReLU, the 1x1 depth layer) run on the HIP engine in inference (`engine.BevEngine`: `_MBConv`,
+`lift_head`) and on `train_graph`'s operators in training; the modules below hold the parameters under the reference's names; its two results - depth logits and context features - feed the fused HIP
 lift-splat kernel directly, so the (n, C, D, h, w) outer product never has to exist unless a caller asks for it via
 `forward()`.  The torch statement of the head below is what autograd and `encoder_forward` use.
 """

@@ -6,8 +6,8 @@ the reference class (reference: fiery/models/fiery.py:13-339), so `trainer.py` /
 
 * `model.eval()`: the image trunk, the lift head and everything from the lift head's outputs to the output dict run on
   the hand-written gfx950 kernels in libfiery_hip.so through `fiery_amd.engine.BevEngine` (folded inference plan);
-* `model.train()`: the autograd graph of `fiery_amd.train_graph` over the same kernels (the image trunk and the lift head
-  on PyTorch-ROCm operators, which have the backward the engine lacks for them).
+* `model.train()`: the autograd graph of `fiery_amd.train_graph` over the same kernels, image trunk and lift head included
+  (`hip_trunk`, the default; `FIERY_HIP_TRUNK=0` puts those two back on PyTorch-ROCm / MIOpen operators).
 No ATen fallback exists for the BEV path: if the library is missing or the model is on the CPU, the call raises.
 """
 import os

@@ -192,7 +192,9 @@ def require_usable_gpu_process(what):
     i.e. in DataLoader worker processes.  With the default `fork` start method such a worker inherits an initialised HIP
     context it cannot use; PyTorch reports that as 'Cannot re-initialize CUDA in forked subprocess' from somewhere deep in
     the first tensor move.  Say it here, with the remedies."""
-    if torch.cuda.is_initialized() and getattr(torch.cuda, '_is_in_bad_fork', lambda: False)():
+    # (torch.cuda.is_initialized() is False in a forked child BY DEFINITION - it is `_initialized and not _is_in_bad_fork()` -
+    # so the fork test stands alone)
+    if getattr(torch.cuda, '_is_in_bad_fork', lambda: False)():
         raise RuntimeError(
             f'{what} launches HIP kernels, but this process was forked from one that had already initialised the GPU '
             f'(a DataLoader worker with the fork start method).  Create the DataLoader with '
@@ -477,7 +479,11 @@ class Lib:
         key = (int(c), str(device), stream)
         cache = self.__dict__.setdefault('_bn_ws', {})
         if key not in cache:
+            while len(cache) >= 64:                      # short-lived streams (lanes rebuilt, thread replicas) must not pile up
+                cache.pop(next(iter(cache)))             # oldest first (insertion order); a live stream's entry is re-made on demand
             cache[key] = torch.empty(self.dll.fiery_bn_workspace_floats(int(c)), dtype=torch.float32, device=device)
+        else:
+            cache[key] = cache.pop(key)                  # most recently used last
         return cache[key]
 
     def bn_train_fwd(self, x, ld, n_pixels, c, gamma, beta, running_mean, running_var, batch_stats, momentum, eps, relu, c_store):

@@ -71,6 +71,16 @@ def _pixel_major(x, pad_to=8):
     return F.pad(t, (0, cp - c)).contiguous()
 
 
+def _detached(x):
+    """x.detach().float() that keeps the padded-rows mark (a Python attribute: `detach()` returns a new tensor object without
+    it, and with it gone `_pixel_major` pads by copy - every forward of a 35- / 70-channel or image-trunk layer did)."""
+    t = x.detach().float()
+    mark = getattr(x, '_fiery_padded_rows', 0)
+    if mark and t.data_ptr() == x.data_ptr():
+        t._fiery_padded_rows = mark
+    return t
+
+
 _UNIT_EPILOGUE = {}
 
 
@@ -110,7 +120,7 @@ class HipConv2d(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, stride, pad, lib):
-        x_nhwc = _pixel_major(x.detach().float())
+        x_nhwc = _pixel_major(_detached(x))
         cout = weight.shape[0]
         y = _launch_conv(lib, x_nhwc, weight.detach().float(), stride, pad)
         ctx.save_for_backward(x_nhwc, weight)
@@ -499,6 +509,9 @@ class TrainGraph:
         self._hip_ops = conv2d is None
         self.whole_plane_pooling_as_means = True      # False: avg_pool3d + interpolate, operator for operator as the reference
         self.hip_trunk = os.environ.get('FIERY_HIP_TRUNK', '1') != '0'      # False: the image trunk + lift head as `Encoder.lift_head` (PyTorch-ROCm / MIOpen)
+        if not self.hip_trunk:
+            from . import exclude_miopen_nhwc_bwd_solver
+            exclude_miopen_nhwc_bwd_solver()
         # (with a substituted convolution the graph may run in fp64 / on the host: resampling then stays on torch too)
         self._upsample2x = (lambda x: HipUpsample2x.apply(x, self.lib)) if conv2d is None else (
             lambda x: F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False))

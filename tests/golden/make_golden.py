@@ -234,7 +234,72 @@ def golden_training_model():
     np.savez_compressed(os.path.join(OUT, 'train_model_tiny.npz'), **res)
 
 
+def trainer_step_case():
+    """The configuration, batch and pinned randomness of `trainer_step_tiny.npz` (shared with the GPU test that replays it)."""
+    from tests.test_reference_callers import _batch, _hparams
+    hparams = _hparams()
+    cfg = get_preset_cfg('baseline.yml')                         # (only to rebuild the node the same way the trainer does)
+    from fiery_amd.config import get_cfg
+    cfg = get_cfg(cfg_dict=hparams)
+    batch = _batch(cfg, seed=3)
+    noise = torch.randn(batch['image'].shape[0], 1, cfg.MODEL.DISTRIBUTION.LATENT_DIM, generator=torch.Generator().manual_seed(21))
+    return hparams, cfg, batch, noise
+
+
+def attach_trainer_weights(model):
+    """What `TrainingModule.__init__` adds to the model (fiery/trainer.py:42-64): four scalar Parameters."""
+    for name in ('segmentation_weight', 'centerness_weight', 'offset_weight', 'flow_weight'):
+        setattr(model, name, torch.nn.Parameter(torch.tensor(0.0), requires_grad=True))
+
+
+def golden_trainer_step():
+    """`TrainingModule.shared_step(batch, is_train=True)` of the UNMODIFIED fiery/trainer.py around the reference's `Fiery`
+    (tiny configuration of tests/test_reference_callers.py, from camera images, B = 2), with the two sources of randomness
+    pinned so that another device can replay it: the trunk's drop-connect rate set to 0 and the latent's noise passed in.
+    Stored: what the trainer fed the model (`future_distribution_inputs`), the outputs, d loss / d output of the reference's
+    own losses, the loss terms, and per parameter tensor the gradient's norm and its projection on a seeded direction."""
+    from oracle.ref_shims import load_reference_callers
+    callers = load_reference_callers()
+    hparams, cfg, batch, noise = trainer_step_case()
+    torch.manual_seed(0)
+    module = callers.trainer.TrainingModule(hparams)
+    randomise_weights(module.model)
+    module.model.encoder.backbone._global_params.drop_connect_rate = 0.0
+    plain_forward = module.model.forward
+    seen = {}
+
+    def forward(image, intrinsics, extrinsics, future_egomotion, future_distribution_inputs=None):
+        seen['future_distribution_inputs'] = future_distribution_inputs.detach().clone()
+        out = plain_forward(image, intrinsics, extrinsics, future_egomotion, future_distribution_inputs, noise=noise)
+        for v in out.values():
+            if v is not None:
+                v.retain_grad()
+        return out
+    module.model.forward = forward
+    module.train()
+    output, labels, loss = module.shared_step({k: v.clone() for k, v in batch.items()}, True)
+    sum(loss.values()).backward()
+    res = {'future_distribution_inputs': seen['future_distribution_inputs'].numpy(), 'noise': noise.numpy()}
+    for k, v in output.items():
+        if v is not None:
+            res['out_' + k] = v.detach().numpy()
+            res['dout_' + k] = v.grad.numpy()
+    for k, v in loss.items():
+        res['loss_' + k] = np.float64(v.item())
+    g = torch.Generator().manual_seed(5)
+    for name, p in module.model.named_parameters():
+        if p.grad is None:
+            continue
+        direction = torch.randn(p.shape, generator=g)
+        res['g_' + name] = np.array([p.grad.norm().item(), (p.grad * direction).sum().item()], dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, 'trainer_step_tiny.npz'), **res)
+    return {k: float(v) for k, v in loss.items()}
+
+
 if __name__ == '__main__':
+    if 'trainer' in sys.argv[1:]:
+        print(golden_trainer_step())
+        sys.exit(0)
     golden_index_path()
     golden_pooling_small()
     golden_pooling_backward_small()
@@ -244,6 +309,7 @@ if __name__ == '__main__':
     print(golden_forward('static_lss_1cam', get_preset_cfg('literature/static_lss_setting.yml'), 1, 1, SUB))
     golden_training_blocks()
     golden_training_model()
+    print(golden_trainer_step())
     for f in sorted(os.listdir(OUT)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -70,3 +70,28 @@ def test_presets_equal_the_reference_yaml_files():
     for name in PRESETS:
         args = get_parser().parse_args(['--config-file', os.path.join(base, name)])
         assert get_cfg(args).convert_to_dict() == get_preset_cfg(name).convert_to_dict(), name
+
+
+def test_fork_guard_of_the_input_pipeline_entry_points(monkeypatch):
+    """`require_usable_gpu_process` (labels / image preparation inside a forked DataLoader worker): raises the message with
+    the remedies when torch reports a bad fork - and only then."""
+    import torch
+    from fiery_amd import native
+    monkeypatch.setattr(torch.cuda, '_is_in_bad_fork', lambda: False, raising=False)
+    native.require_usable_gpu_process('instance labels')
+    monkeypatch.setattr(torch.cuda, '_is_in_bad_fork', lambda: True, raising=False)
+    with pytest.raises(RuntimeError, match="multiprocessing_context='spawn'"):
+        native.require_usable_gpu_process('instance labels')
+
+
+def test_padded_rows_mark_survives_detach_in_the_training_graph():
+    """`_pixel_major` widens a channel slice of padded rows in place instead of copying; the mark that says so is a Python
+    attribute, which `detach()` drops - `_detached` carries it over."""
+    import torch
+    from fiery_amd import train_graph as tg
+    rows = torch.zeros(2, 5, 6, 40)
+    x = tg._padded_rows(rows[..., :35].permute(0, 3, 1, 2), 35, 40)
+    assert getattr(x, '_fiery_padded_rows', 0) == 40
+    assert getattr(x.detach(), '_fiery_padded_rows', 0) == 0
+    t = tg._pixel_major(tg._detached(x))
+    assert t.shape == (2, 5, 6, 40) and t.data_ptr() == rows.data_ptr()            # widened in place: no copy

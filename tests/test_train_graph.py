@@ -1,6 +1,8 @@
 """Training path: the differentiable convolution on the HIP kernels and the training-mode
 forward built from it, on the CPU-simulated kernels - against torch autograd and against the reference's own modules
 run in train() mode."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -344,6 +346,19 @@ def as_close_to_exact_as_fp32_torch(hip, torch32, exact, test='train_step'):
     # 2.8 % - a 1e-7 change of a sampling position moves these gradients by percents; a fixed 2 % would measure the seed)
     median_torch = sorted(r[1] for r in rows)[len(rows) // 2]
     assert median <= max(2e-2, 1.25 * median_torch) and worst[0] <= 0.5 and len(flipped) <= len(rows) // 10, (median, median_torch, worst, len(flipped))
+    # THE criterion, per tensor and without allowances: no gradient tensor of the kernels' step is further from the fp64
+    # evaluation than three times the all-torch fp32 evaluation of the same graph is (+ 1e-3 of the tensor's norm).  A kernel,
+    # layout or indexing mistake is an O(1) error in every tensor it touches and cannot hide behind that; what the bound
+    # does absorb is exactly what fp32 arithmetic itself does to this step (on the tiny configuration PyTorch's own fp32
+    # graph is 20 % from fp64 on some tensors and the kernels' 6 %).  The looser clauses above stay as a second net.
+    strict = sorted((r for r in rows if r[0] > 3 * r[1] + 1e-3), reverse=True)
+    parity_report.record(test, f'gradients: {len(rows) - len(strict)} of {len(rows)} tensors within 3x the torch fp32 graph\'s distance to fp64 (+1e-3)',
+                         strict[0][0] if strict else 0.0, 1.0, strict[0][0] if strict else 0.0, strict[0][1] if strict else 0.0, 0.0,
+                         '; '.join(f'{r[2][-40:]} {r[0]:.4f} (torch {r[1]:.4f})' for r in strict[:6]))
+    if os.environ.get('FIERY_TEST_VERBOSE'):
+        for r in sorted(rows, reverse=True)[:40]:
+            print(f'{r[2]:80s} hip {r[0]:9.2e} torch {r[1]:9.2e}')
+    assert not strict, strict[:8]
     # The 1 % question, per tensor: where fp32 arithmetic itself allows it - the all-torch fp32 graph is within 0.5 % of the
     # fp64 one - the kernels' gradient is within 1 % (a flipped gate may again take a tenth of the tensors out); the tensors
     # past 1 % are listed with the torch figure beside them, which is what says whether conditioning or a kernel is the cause.
@@ -760,6 +775,59 @@ def test_training_blocks_equal_the_reference_autograd_fixture_on_the_simulated_k
 @pytest.mark.gpu
 def test_training_blocks_equal_the_reference_autograd_fixture(hip):
     _replay_training_blocks(hip, 'cuda', 2e-4)
+
+
+@pytest.mark.gpu
+def test_trainer_step_from_images_equals_the_reference_trainer_fixture(hip):
+    """`TrainingModule.shared_step(batch, is_train=True)` of the reference's trainer around the reference's model, replayed on
+    the MI355X (fixture `trainer_step_tiny.npz`, made by tests/golden/make_golden.py from the unmodified fiery/trainer.py):
+    the same batch of camera images, the future labels the trainer fed the model, the pinned noise, drop-connect off; this
+    class in train() mode - trunk, lift head, fused lift-splat and the BEV stack on the training graph's kernels - must give
+    the reference's outputs, and, fed the reference losses' own d loss / d output, the reference's parameter gradients: every
+    tensor's norm and seeded projection within 1 % (of the norm, or of 1e-5 of the model's largest gradient for the biases in
+    front of a train-mode BatchNorm whose gradient is zero analytically)."""
+    import os
+    import numpy as np
+    from fiery_amd.model import Fiery
+    from tests import parity_report
+    from tests.golden.make_golden import attach_trainer_weights, trainer_step_case
+    gold = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'trainer_step_tiny.npz'))
+    hparams, cfg, batch, noise = trainer_step_case()
+    torch.manual_seed(0)
+    model = Fiery(cfg)
+    attach_trainer_weights(model)                                  # (so that the seeded weights get the trainer's key order)
+    randomise_weights(model)
+    model.encoder.backbone._global_params.drop_connect_rate = 0.0
+    model = model.cuda().train()
+    dev = lambda k: batch[k].cuda()
+    out = model(dev('image'), dev('intrinsics'), dev('extrinsics'), dev('future_egomotion'),
+                torch.from_numpy(gold['future_distribution_inputs']).cuda(), noise=torch.from_numpy(gold['noise']).cuda())
+    keys = [k for k in out if out[k] is not None]
+    assert set(keys) == {k[4:] for k in gold.files if k.startswith('out_')}
+    for k in keys:
+        want = torch.from_numpy(gold['out_' + k])
+        err, scale = (out[k].detach().cpu() - want).abs().max().item(), max(1.0, want.abs().max().item())
+        parity_report.record('trainer_step_tiny vs reference trainer fixture', k, err, scale, None, None, 2e-4 * scale)
+        assert err <= 2e-4 * scale, (k, err)
+    torch.autograd.backward([out[k] for k in keys], [torch.from_numpy(gold['dout_' + k]).cuda() for k in keys])
+    top = max(gold[f][0] for f in gold.files if f.startswith('g_'))
+    g = torch.Generator().manual_seed(5)
+    rows = []
+    for name, p in model.named_parameters():
+        if 'g_' + name not in gold.files:
+            assert p.grad is None, name
+            continue
+        direction = torch.randn(p.shape, generator=g)                   # (drawn for every fixture tensor, in the fixture's order)
+        if name in ('segmentation_weight', 'centerness_weight', 'offset_weight', 'flow_weight'):
+            continue                                                    # the uncertainty weights live in the losses, not in the model's graph
+        assert p.grad is not None, name
+        got = np.array([p.grad.norm().item(), (p.grad.cpu() * direction).sum().item()])
+        want = gold['g_' + name]
+        rows.append((np.abs(got - want).max() / max(want[0], 1e-5 * top), name))
+    rows.sort(reverse=True)
+    parity_report.record('trainer_step_tiny vs reference trainer fixture', f'gradient norm / projection of {len(rows)} tensors, worst ({rows[0][1][-40:]})',
+                         rows[0][0], 1.0, None, None, 1e-2)
+    assert len(rows) > 300 and rows[0][0] < 1e-2, rows[:6]
 
 
 @pytest.mark.gpu
