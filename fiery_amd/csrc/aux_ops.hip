@@ -611,13 +611,13 @@ __global__ __launch_bounds__(256) void k_se_gate(const float* __restrict__ mean,
                                                  const float* __restrict__ w1, const float* __restrict__ b1, int sq,
                                                  const float* __restrict__ w2, const float* __restrict__ b2,
                                                  float* __restrict__ gate, int gate_ld) {
-    __shared__ float part[256 * kSeMaxHidden];
+    // (round 4: the first dense layer used to keep 64 partial sums per thread and have `sq` threads add up 256 of them
+    // each from LDS - 41 us per call, 0.9 ms per pass of the trunk; now a wavefront owns a hidden unit at a time: its lanes
+    // stride over the channels and meet in a shuffle tree, every sum in a fixed order)
+    __shared__ float means[1024];
     __shared__ float hidden[kSeMaxHidden];
-    const int img = blockIdx.x, t = threadIdx.x;
+    const int img = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const float* m = mean + static_cast<long long>(img) * chunks * ld;
-    float acc[kSeMaxHidden];
-#pragma unroll
-    for (int s_ = 0; s_ < kSeMaxHidden; ++s_) acc[s_] = 0.f;
     for (int c = t; c < C; c += 256) {
         float mv = 0.f;
         for (int k0 = 0; k0 < chunks; k0 += 8) {               // eight partial rows in flight, summed in order
@@ -627,19 +627,16 @@ __global__ __launch_bounds__(256) void k_se_gate(const float* __restrict__ mean,
 #pragma unroll
             for (int j = 0; j < 8; ++j) mv += pv[j];
         }
-        mv *= inv_count;
-#pragma unroll
-        for (int s_ = 0; s_ < kSeMaxHidden; ++s_)
-            if (s_ < sq) acc[s_] = fmaf(w1[static_cast<long long>(s_) * C + c], mv, acc[s_]);
+        means[c] = mv * inv_count;
     }
-#pragma unroll
-    for (int s_ = 0; s_ < kSeMaxHidden; ++s_)
-        if (s_ < sq) part[t * kSeMaxHidden + s_] = acc[s_];
     __syncthreads();
-    if (t < sq) {
-        float sum = 0.f;
-        for (int u = 0; u < 256; ++u) sum += part[u * kSeMaxHidden + t];
-        hidden[t] = apply_act(sum + b1[t], FIERY_ACT_SWISH);
+    for (int s_ = wave; s_ < sq; s_ += 4) {
+        const float* wr = w1 + static_cast<long long>(s_) * C;
+        float a = 0.f;
+        for (int c = lane; c < C; c += 64) a = fmaf(wr[c], means[c], a);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d);
+        if (lane == 0) hidden[s_] = apply_act(a + b1[s_], FIERY_ACT_SWISH);
     }
     __syncthreads();
     for (int c = t; c < C; c += 256) {

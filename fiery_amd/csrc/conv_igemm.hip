@@ -293,6 +293,17 @@ int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, bool launch) {
                       (!d->weights2 || (aligned16(d->scale2) && aligned16(d->shift2))))
                          ? 1 : 0;
     if (const char* forced = getenv("FIERY_CONV_VEC_EPILOGUE")) p.vec_epilogue = p.vec_epilogue && atoi(forced) != 0;
+    // bit 1: every tensor of the epilogue is dense over its images and addressable with 31-bit byte offsets (the row epilogue
+    // then walks buffer descriptors with one 32-bit add per row, conv_igemm_kernel.h store_rows)
+    if (p.vec_epilogue) {
+        const long long hw = static_cast<long long>(d->Hout) * d->Wout;
+        auto dense = [&](const fiery_nhwc& t) {
+            return !t.ptr || (t.img_stride == hw * t.ld && p.M * t.ld * 4 < (1ll << 31));
+        };
+        bool all_dense = dense(d->out) && dense(d->res) && dense(d->out2) && dense(d->aux0) && dense(d->aux1) && !p.bias_border;
+        if (const char* forced = getenv("FIERY_CONV_DENSE_EPILOGUE")) all_dense = all_dense && atoi(forced) != 0;     // A/B runs
+        if (all_dense) p.vec_epilogue |= 2;
+    }
     p.w2 = d->weights2;
     p.scale2 = d->scale2;
     p.shift2 = d->shift2;
@@ -304,7 +315,7 @@ int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, bool launch) {
         FIERY_REQUIRE(!d->res.ptr || !d->res_before_act, "conv_fwd: chained 1x1 adds the residual after the activation");
     }
     if (d->weights3) {
-        FIERY_REQUIRE(d->weights2 && d->cout_store == 64 && p.vec_epilogue, "conv_fwd: the third stage needs the chained 1x1, 64 stored channels and 16-byte addressable tensors");
+        FIERY_REQUIRE(d->weights2 && d->cout_store == 64 && (p.vec_epilogue & 1), "conv_fwd: the third stage needs the chained 1x1, 64 stored channels and 16-byte addressable tensors");
         FIERY_REQUIRE(d->scale3 && d->shift3 && d->out3.ptr && aligned16(d->weights3) && aligned16(d->scale3) && aligned16(d->shift3) &&
                           aligned16(d->out3.ptr) && d->out3.ld % 4 == 0 && d->out3.img_stride % 4 == 0 && d->out3.ld >= 32,
                       "conv_fwd: third-stage operands missing or misaligned");

@@ -91,7 +91,7 @@ struct ConvP {
     const float* scale2;
     const float* shift2;
     int act2;
-    int vec_epilogue;     // destinations / residual / bias rows are 16-byte addressable
+    int vec_epilogue;     // bit 0: destinations / residual / bias rows are 16-byte addressable; bit 1: and dense (see store_rows)
     int bias_border;      // img_bias holds nine rows per image, chosen by the output pixel's border class
     HeadsP heads;         // FIERY_EPI_HEADS
 };
@@ -129,6 +129,12 @@ __device__ unsigned long long* g_clk_probe = nullptr;
 __device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};   // (not const: it must live in the global address space like the sources, or the select makes the loads flat)
 
 __device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(-v)); }
+// The GRU gates' sigmoid in the row epilogues: v_exp_f32 and v_rcp_f32 (1 ulp each) - five instructions where the correctly
+// rounded division and libm's expf take about eighteen; a gate launch's epilogue applies it to 32 values per lane, and epilogue
+// instructions are the expensive kind.  1e-7 on a gate in [0, 1].
+__device__ __forceinline__ float sigmoid_gate(float v) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
+}
 // g / d for 0 <= g < 2^31 with (m, s) = conv_magic(d): exact (Granlund-Montgomery, round-up form)
 __device__ __forceinline__ int fast_div(int g, unsigned m, int s) {
     return static_cast<int>((static_cast<unsigned long long>(static_cast<unsigned>(g)) * m) >> s);
@@ -884,6 +890,99 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
         if ((gates_upper ? co - half : co) >= p.cout_store) return;
         const float4 sc = *reinterpret_cast<const float4*>(scale + co);
         const float4 sh = *reinterpret_cast<const float4*>(shift + co);
+        if (p.vec_epilogue & 2) {
+            // DENSE TENSORS (round 4; the host sets the bit when every tensor the epilogue touches has its images back to back -
+            // img_stride == Hout Wout ld - and spans less than 2 GB): pixel gp of a tensor then sits gp * ld floats from its base
+            // whatever image it belongs to, so a row costs one 32-bit add per tensor on a buffer descriptor (whose range check also
+            // drops the rows past M) instead of an image / in-image split with its wrap-around loop and three 64-bit
+            // multiply-adds.  The epilogue's ~1,000 instructions per wavefront are served in the gaps other wavefronts' MFMAs
+            // leave: every instruction less is ~60 cycles sooner back in the K loop.
+            const int m_rows = M;
+            auto rsrc = [&](const float* ptr, int ld_) {
+                return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ptr), 0, ptr ? m_rows * ld_ * 4 : 0, 0x00020000);
+            };
+            auto load4 = [&](__amdgpu_buffer_rsrc_t r, int voff) {
+                const auto raw = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+                float4 f;
+                __builtin_memcpy(&f, &raw, 16);
+                return f;
+            };
+            auto store4 = [&](__amdgpu_buffer_rsrc_t r, int voff, const float4& f) {
+                decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0)) raw;
+                __builtin_memcpy(&raw, &f, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(raw, r, voff, 0, 0);
+            };
+            const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            int gp = pix0 + prow0;
+            const bool plain = p.epi == FIERY_EPI_PLAIN, gates = p.epi == FIERY_EPI_GRU_GATES;
+            // descriptors are wave-uniform (one per tensor); which of them a lane uses - a gate launch's lower channel half
+            // stores the update gate to `out`, its upper half reads the state and stores to `out2` - is a per-lane predicate
+            const bool upper = gates && gates_upper;
+            const TensP& t_a = plain ? p.res : p.aux0;
+            const int c_x = upper ? co - half : co;                          // channel inside out2 / aux0 for the upper half
+            const bool has_a = plain ? p.res.ptr != nullptr : (gates ? upper : true);
+            const bool has_b = !plain && !gates;                              // GRU_OUT: aux1 = state
+            const bool has_d1 = has_b && p.out2.ptr != nullptr;
+            const __amdgpu_buffer_rsrc_t r_out = rsrc(p.out.ptr, p.out.ld), r_out2 = rsrc(p.out2.ptr, p.out2.ld),
+                                         r_a = rsrc(t_a.ptr, t_a.ld), r_b = rsrc(has_b ? p.aux1.ptr : nullptr, p.aux1.ld);
+            int o_out = (gp * p.out.ld + co) * 4, o_out2 = (gp * p.out2.ld + c_x) * 4, o_a = (gp * t_a.ld + c_x) * 4,
+                o_b = (gp * p.aux1.ld + co) * 4;
+            const int s_out = rows_per_pass * p.out.ld * 4, s_out2 = rows_per_pass * p.out2.ld * 4, s_a = rows_per_pass * t_a.ld * 4,
+                      s_b = rows_per_pass * p.aux1.ld * 4;
+            const bool bias_rows = with_bias && p.img_bias;
+            auto bias_of = [&](int g) {
+                return *reinterpret_cast<const float4*>(p.img_bias + fast_div(g, p.mg_hw, p.sh_hw) * p.cout_pad + co);
+            };
+            float4 cur_a = has_a ? load4(r_a, o_a) : zero4, cur_b = has_b ? load4(r_b, o_b) : zero4;
+            float4 cur_bias = (bias_rows && gp < M) ? bias_of(gp) : zero4;
+            for (int pl = prow0; pl < BM; pl += rows_per_pass) {
+                if (gp >= M) break;
+                const int gp_n = gp + rows_per_pass;
+                const bool more = pl + rows_per_pass < BM && gp_n < M;
+                // the next row's operands are requested before this row is stored (an in-place residual is a different pixel)
+                const float4 nxt_a = (has_a && more) ? load4(r_a, o_a + s_a) : zero4;
+                const float4 nxt_b = (has_b && more) ? load4(r_b, o_b + s_b) : zero4;
+                const float4 nxt_bias = (bias_rows && more) ? bias_of(gp_n) : zero4;
+                float4 v = *reinterpret_cast<const float4*>(&smem[pl * width + c4 * 4]);
+                v.x += cur_bias.x;  v.y += cur_bias.y;  v.z += cur_bias.z;  v.w += cur_bias.w;
+                v.x = fmaf(v.x, sc.x, sh.x);  v.y = fmaf(v.y, sc.y, sh.y);  v.z = fmaf(v.z, sc.z, sh.z);  v.w = fmaf(v.w, sc.w, sh.w);
+                if (plain) {
+                    const float4 r = cur_a;
+                    if (res_pre_rows) { v.x += r.x;  v.y += r.y;  v.z += r.z;  v.w += r.w; }
+                    if (act == FIERY_ACT_RELU) {
+                        v.x = fmaxf(v.x, 0.f);  v.y = fmaxf(v.y, 0.f);  v.z = fmaxf(v.z, 0.f);  v.w = fmaxf(v.w, 0.f);
+                    } else if (act == FIERY_ACT_SIGMOID) {
+                        v.x = sigmoidf(v.x);  v.y = sigmoidf(v.y);  v.z = sigmoidf(v.z);  v.w = sigmoidf(v.w);
+                    } else if (act == FIERY_ACT_SWISH) {
+                        v.x *= sigmoidf(v.x);  v.y *= sigmoidf(v.y);  v.z *= sigmoidf(v.z);  v.w *= sigmoidf(v.w);
+                    }
+                    if (!res_pre_rows) { v.x += r.x;  v.y += r.y;  v.z += r.z;  v.w += r.w; }
+                    store4(r_out, o_out, v);
+                } else if (gates) {
+                    float4 g = make_float4(sigmoid_gate(v.x), sigmoid_gate(v.y), sigmoid_gate(v.z), sigmoid_gate(v.w));
+                    if (upper) {                                                                // (1 - reset) * state
+                        const float4 h = cur_a;
+                        g.x = (1.0f - g.x) * h.x;  g.y = (1.0f - g.y) * h.y;  g.z = (1.0f - g.z) * h.z;  g.w = (1.0f - g.w) * h.w;
+                        store4(r_out2, o_out2, g);
+                    } else {
+                        store4(r_out, o_out, g);                                                // update gate
+                    }
+                } else {                                                                        // FIERY_EPI_GRU_OUT
+                    const float4 u = cur_a, h = cur_b;
+                    float4 hn;
+                    { const float a = (1.0f - u.x) * h.x, b = u.x * fmaxf(v.x, 0.f); hn.x = a + b; }
+                    { const float a = (1.0f - u.y) * h.y, b = u.y * fmaxf(v.y, 0.f); hn.y = a + b; }
+                    { const float a = (1.0f - u.z) * h.z, b = u.z * fmaxf(v.z, 0.f); hn.z = a + b; }
+                    { const float a = (1.0f - u.w) * h.w, b = u.w * fmaxf(v.w, 0.f); hn.w = a + b; }
+                    store4(r_out, o_out, hn);
+                    if (has_d1) store4(r_out2, o_out2, hn);
+                }
+                cur_a = nxt_a;  cur_b = nxt_b;  cur_bias = nxt_bias;
+                gp = gp_n;
+                o_out += s_out;  o_out2 += s_out2;  o_a += s_a;  o_b += s_b;
+            }
+            return;
+        }
         int gp = pix0 + prow0;
         int o = fast_div(gp, p.mg_hw, p.sh_hw), ppi = gp - o * HWout;
         // The row's global operands - residual, or the GRU's state / update gate, and the per-image bias - are requested
@@ -944,7 +1043,7 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
                 if (!res_pre_rows) { v.x += r.x;  v.y += r.y;  v.z += r.z;  v.w += r.w; }
                 *reinterpret_cast<float4*>(p.out.ptr + o * p.out.istride + pp * p.out.ld + co) = v;
             } else if (p.epi == FIERY_EPI_GRU_GATES) {
-                float4 g = make_float4(sigmoidf(v.x), sigmoidf(v.y), sigmoidf(v.z), sigmoidf(v.w));
+                float4 g = make_float4(sigmoid_gate(v.x), sigmoid_gate(v.y), sigmoid_gate(v.z), sigmoid_gate(v.w));
                 if (!gates_upper) {                                                         // update gate
                     *reinterpret_cast<float4*>(p.out.ptr + o * p.out.istride + pp * p.out.ld + co) = g;
                 } else {                                                                    // (1 - reset) * state
@@ -977,7 +1076,7 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
             smem[pl * width + col] = a[r];
         }
     };
-    const bool rows16 = p.vec_epilogue != 0;
+    const bool rows16 = (p.vec_epilogue & 1) != 0;
 
     // ---- optional chained 1x1 convolution on the tile (Bottleneck up-projection) -----------------------------
     if constexpr (BN == 32 && BM == 128) {

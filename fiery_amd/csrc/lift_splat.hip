@@ -1265,6 +1265,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
     // tuning aid (FIERY_POOL_TRACE = address of 4 * n_items int64): the 100 MHz wall clock at the item's phases
     if (trace && tid == 0) trace[4 * item] = wall_clock64();
     int unit = item, part = 0, parts = 1;
+    if (late_prio < 0 && unit < tail_first) unit = tail_first - 1 - unit;      // tuning (FIERY_POOL_LATE_PRIO=-1): whole units in reverse order
     if (unit >= tail_first) {
         const int t = unit - tail_first;
         unit = tail_first + t / tail_parts;
@@ -1532,9 +1533,13 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
         Record record;
         // a part is a contiguous range of slices (neighbouring depths of one or two cameras: it touches a fraction of the
         // plane's cells, so its atomic write-out is short, and its rows are one stretch of memory)
-        const int s_lo = static_cast<int>(static_cast<long long>(part) * n_slices / parts);
-        const int s_end = static_cast<int>(static_cast<long long>(part + 1) * n_slices / parts);
-        const int s_first = s_lo + wave, s_step = kWaves;
+        // ... when the parts are drawn (persistent workgroups); the statically dealt parts of the default launch take the
+        // slices block-cyclically instead: contiguous ranges differ in how many of their quads are live (a part's row phase
+        // took 29-53 us against 28-37 us, and the slowest part ends the kernel)
+        const bool ranges = draw != nullptr;
+        const int s_lo = ranges ? static_cast<int>(static_cast<long long>(part) * n_slices / parts) : 0;
+        const int s_end = ranges ? static_cast<int>(static_cast<long long>(part + 1) * n_slices / parts) : n_slices;
+        const int s_first = ranges ? s_lo + wave : wave + part * kWaves, s_step = ranges ? kWaves : kWaves * parts;
         {
             const bool has = s_first < s_end;
             fetch_record(record, s_first, has);

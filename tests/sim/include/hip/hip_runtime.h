@@ -303,6 +303,14 @@ inline hipsim_v2u __builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rsrc_t r,
     hipsim_buffer_load<2>(r, voff, soff, d);
     return hipsim_v2u{d[0], d[1]};
 }
+inline void __builtin_amdgcn_raw_buffer_store_b128(hipsim_v4u v, __amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
+    const unsigned long long off = static_cast<unsigned long long>(static_cast<unsigned>(voff)) + static_cast<unsigned>(soff);
+    for (int i = 0; i < 4; ++i)
+        if (off + 4ull * i + 4ull <= r.num) {
+            const unsigned word = v[i];
+            __builtin_memcpy(const_cast<char*>(r.base) + off + 4 * i, &word, 4);
+        }
+}
 inline unsigned __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
     unsigned d[1];
     hipsim_buffer_load<1>(r, voff, soff, d);
@@ -320,6 +328,8 @@ inline int __builtin_amdgcn_readfirstlane(int v) { return v; }      // only ever
 inline void __builtin_amdgcn_sched_barrier(int) {}
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline unsigned __builtin_amdgcn_s_getreg(int) { return 0; }
+inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+inline float __builtin_amdgcn_exp2f(float x) { return __builtin_exp2f(x); }
 inline void __builtin_amdgcn_s_waitcnt(int) {}
 inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 

@@ -68,3 +68,23 @@ def test_resnet18_stages_agree_in_layout_and_initialisation():
     x = torch.randn(2, 64, 12, 10, generator=g)
     with torch.no_grad():
         assert torch.allclose(blk(x), _basic_block(x, Weights(blk.state_dict())), rtol=1e-5, atol=1e-6)
+
+
+def test_efficientnet_parameter_counts_are_the_published_ones_and_the_manifest_holds():
+    """Two external anchors for the absent `efficientnet-pytorch==0.7.0` (fiery/models/encoder.py:16): (1) the whole network's
+    parameter count - 5,288,548 for b0 and 19,341,616 for b4, the figures published with the package and the paper's tables -
+    which fixes stem / stage widths, repeats, kernel sizes, expansion and squeeze ratios, head and classifier together;
+    (2) `tests/golden/efficientnet_manifest.json`: every state_dict key with its shape (706 keys for b4), the list a released
+    FIERY checkpoint's `encoder.backbone.*` entries are checked against before loading.  Both restatements -
+    the product's and the checker's - must agree with both."""
+    import json
+    import os
+    from fiery_amd.backbone import EfficientNet as Product
+    from oracle.third_party import EfficientNet as Checker
+    manifest = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'efficientnet_manifest.json')))
+    published = {'efficientnet-b0': 5288548, 'efficientnet-b4': 19341616}
+    for name, count in published.items():
+        for cls in (Product, Checker):
+            net = cls.from_pretrained(name)
+            assert sum(p.numel() for p in net.parameters()) == count, (name, cls.__module__)
+            assert {k: list(v.shape) for k, v in net.state_dict().items()} == manifest[name], (name, cls.__module__)
