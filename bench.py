@@ -246,11 +246,21 @@ def main():
             eager_step()                                   # also tunes this mode's launches, outside the brackets
             torch.cuda.synchronize()
             eager_step()                                   # backlog: the GPU must not wait for the host during the next one
-            ops.PROFILE_SINK = []
-            eager_step()                                   # same kernels, launched one by one so each can be bracketed
+            # five instrumented steps (same kernels, launched one by one so each can be bracketed): the figures below come from
+            # the step whose convolution time is the median, the pooling op's from the median over the five (one step's
+            # bracket of a 275 us op moves by +-5 us from run to run)
+            instrumented = []
+            for _ in range(5):
+                ops.PROFILE_SINK = []
+                eager_step()
+                torch.cuda.synchronize()
+                instrumented.append(ops.PROFILE_SINK)
         torch.cuda.synchronize()
         model.sample_streams = streams_on
-        recs, ops.PROFILE_SINK = ops.PROFILE_SINK, None
+        ops.PROFILE_SINK = None
+        conv_time = lambda rr: sum(s.elapsed_time(e) for k, s, e, w, _ in rr if k == 'conv_igemm')
+        recs = sorted(instrumented, key=conv_time)[len(instrumented) // 2]
+        pool_samples = sorted(sum(s.elapsed_time(e) * 1e3 for k, s, e, _, _ in rr if k == 'voxel_pool') for rr in instrumented)
         conv = [(s.elapsed_time(e) * 1e-3, w) for k, s, e, w, _ in recs if k == 'conv_igemm']
         # launches by the matrix-core form they ran in (a bf16 run keeps fp32 for the layers the bf16 kernel does not take)
         by_prec = {}
@@ -285,7 +295,7 @@ def main():
                     'traffic_from_profiles': pmc_traffic(['k_conv_igemm (all tile shapes)']) if args.precision == 'f32' and args.config == 'baseline.yml' and n_cam == 6 and B == 3 else None,
                     'launches': n_dom, 'avg_launch_us': round(t_dom / n_dom * 1e6, 2),
                     'algorithmic_gflop_per_step': round(f_conv / 1e9, 1), 'kernel_ms_per_step': round(t_conv * 1e3, 3),
-                    'measured': 'HIP events around every launch of one instrumented step after the timed region, whole '
+                    'measured': 'HIP events around every launch of the median of five instrumented steps after the timed region, whole '
                                 'batch on one stream (`--no-sample-streams` mode): the kernel alone on the GPU',
                     # the same kernel in the TIMED launch mode (hipGraph, one chain per sample: kernels of different
                     # samples share the CUs, so no per-launch bracket exists): its flops over the whole step time - a lower
@@ -295,14 +305,15 @@ def main():
                                    'what': 'conv flops of a step / timed ms_per_step (lower bound: the step holds all kernels)'},
                     'step_tflops': round(f_conv / (elapsed / args.steps) / 1e12, 2)}
         if pool:
-            t_pool, b_pool = sum(t for t, _ in pool), sum(w for _, w in pool)
+            t_pool, b_pool = pool_samples[len(pool_samples) // 2] * 1e-6, sum(w for _, w in pool)
             gbs = b_pool / t_pool / 1e9
             pooling = {'kernel': 'k_rank_columns + k_voxel_pool_compact (op boundary projection_to_birds_eye_view)', 'bound': 'hbm',
                        'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
                        'traffic': None,          # (no counters in a timed run; the committed passes' figure - prepass included - follows)
                        'traffic_from_profiles': pmc_traffic(['k_voxel_pool', 'fiery::k_rank_columns']) if args.config == 'baseline.yml' and n_cam == 6 and B == 3 else None,
                        'algorithmic_mb_per_step': round(b_pool / 1e6, 1),
-                       'op_us_per_step': round(t_pool * 1e6, 1), 'kept_fraction': round(kept_frac, 4),
+                       'op_us_per_step': round(t_pool * 1e6, 1), 'op_us_samples': [round(v, 1) for v in pool_samples],
+                       'kept_fraction': round(kept_frac, 4),
                        'bytes': '4*C*N_kept + 12*N + 4*C*X*Y per frame (SURVEY 8d), N_kept counted from the ranks the op left'}
 
     # secondary figure: the whole `forward()` from images - image trunk and lift head on the engine as well -

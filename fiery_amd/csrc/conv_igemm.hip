@@ -300,7 +300,8 @@ int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, bool launch) {
         auto dense = [&](const fiery_nhwc& t) {
             return !t.ptr || (t.img_stride == hw * t.ld && p.M * t.ld * 4 < (1ll << 31));
         };
-        bool all_dense = dense(d->out) && dense(d->res) && dense(d->out2) && dense(d->aux0) && dense(d->aux1) && !p.bias_border;
+        bool all_dense = dense(d->out) && dense(d->res) && dense(d->out2) && dense(d->aux0) && dense(d->aux1) && !p.bias_border &&
+                         (!d->weights3 || dense(d->out3));
         if (const char* forced = getenv("FIERY_CONV_DENSE_EPILOGUE")) all_dense = all_dense && atoi(forced) != 0;     // A/B runs
         if (all_dense) p.vec_epilogue |= 2;
     }

@@ -1145,7 +1145,27 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
                 // rows [i0, i1) of this thread: where they go, and their residual on its way.  FIERY_TAIL_FOUR_PER_CU: the
                 // first four rows are requested here, the last four once the accumulators of the second GEMM have left
                 // their registers (the residual rows can then live where those were: 128 registers without spills)
+                // (dense tensors, round 4 - see store_rows: a row's place is gp * ld from the base, one multiply-add in 32 bits, and
+                // residual / destinations go through buffer descriptors)
+                const bool dense = (p.vec_epilogue & 2) != 0;
+                const __amdgpu_buffer_rsrc_t r_res3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res.ptr), 0, (dense && p.res.ptr) ? M * p.res.ld * 4 : 0, 0x00020000);
+                const __amdgpu_buffer_rsrc_t r_out3 = __builtin_amdgcn_make_buffer_rsrc(p.out.ptr, 0, dense ? M * p.out.ld * 4 : 0, 0x00020000);
+                const __amdgpu_buffer_rsrc_t r_nxt3 = __builtin_amdgcn_make_buffer_rsrc(p.out2.ptr, 0, dense ? M * p.out2.ld * 4 : 0, 0x00020000);
                 auto request_rows = [&](int i0, int i1) {
+                    if (dense) {
+#pragma unroll
+                        for (int i = i0; i < i1; ++i) {
+                            const int gp = pix0 + prow0 + 16 * i;
+                            const bool live = gp < M && co < p.cout_store;
+                            out_off[i] = live ? gp * p.out.ld + co : -1;
+                            resid[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (live && p.res.ptr) {
+                                const auto raw = __builtin_amdgcn_raw_buffer_load_b128(r_res3, (gp * p.res.ld + co) * 4, 0, 0);
+                                __builtin_memcpy(&resid[i], &raw, 16);
+                            }
+                        }
+                        return;
+                    }
                     int gp = pix0 + prow0 + 16 * i0;
                     int o = fast_div(gp < M ? gp : 0, p.mg_hw, p.sh_hw), ppi = gp - o * HWout;
 #pragma unroll
@@ -1192,7 +1212,13 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
                         }
                         if (out_off[i] >= 0) {
                             v.x += resid[i].x;  v.y += resid[i].y;  v.z += resid[i].z;  v.w += resid[i].w;
-                            *reinterpret_cast<float4*>(p.out.ptr + out_off[i]) = v;
+                            if (dense) {
+                                decltype(__builtin_amdgcn_raw_buffer_load_b128(r_out3, 0, 0, 0)) raw;
+                                __builtin_memcpy(&raw, &v, 16);
+                                __builtin_amdgcn_raw_buffer_store_b128(raw, r_out3, out_off[i] * 4, 0, 0);
+                            } else {
+                                *reinterpret_cast<float4*>(p.out.ptr + out_off[i]) = v;
+                            }
                         } else {
                             v = make_float4(0.f, 0.f, 0.f, 0.f);
                         }
@@ -1241,7 +1267,7 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
                     const float4 sc3 = *reinterpret_cast<const float4*>(p.aux0.ptr + dco);
                     const float4 sh3 = *reinterpret_cast<const float4*>(p.aux1.ptr + dco);
                     int gp = pix0 + drow0;
-                    int o = fast_div(gp, p.mg_hw, p.sh_hw), ppi = gp - o * HWout;
+                    int o = dense ? 0 : fast_div(gp, p.mg_hw, p.sh_hw), ppi = dense ? 0 : gp - o * HWout;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int pl = drow0 + 32 * i;
@@ -1251,14 +1277,22 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
                             if (p.heads.n_out == FIERY_ACT_RELU) {
                                 v.x = fmaxf(v.x, 0.f);  v.y = fmaxf(v.y, 0.f);  v.z = fmaxf(v.z, 0.f);  v.w = fmaxf(v.w, 0.f);
                             }
-                            const long long pp = ppi;
-                            *reinterpret_cast<float4*>(p.out2.ptr + o * p.out2.istride + pp * p.out2.ld + dco) = v;
+                            if (dense) {
+                                decltype(__builtin_amdgcn_raw_buffer_load_b128(r_nxt3, 0, 0, 0)) raw;
+                                __builtin_memcpy(&raw, &v, 16);
+                                __builtin_amdgcn_raw_buffer_store_b128(raw, r_nxt3, (gp * p.out2.ld + dco) * 4, 0, 0);
+                            } else {
+                                const long long pp = ppi;
+                                *reinterpret_cast<float4*>(p.out2.ptr + o * p.out2.istride + pp * p.out2.ld + dco) = v;
+                            }
                         }
                         gp += 32;
-                        ppi += 32;
-                        while (ppi >= HWout) {
-                            ppi -= HWout;
-                            ++o;
+                        if (!dense) {
+                            ppi += 32;
+                            while (ppi >= HWout) {
+                                ppi -= HWout;
+                                ++o;
+                            }
                         }
                     }
                 }

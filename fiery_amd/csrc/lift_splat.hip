@@ -1215,13 +1215,16 @@ constexpr int kCompactGroupLanes = 16;     // lanes per row group: the form take
 
 // kThreads: 512 (two workgroups per CU) or 1024 (one): sixteen wavefronts per CU either way; kWide: 64-byte quad records and 32-bit cell prefixes;
 // kExactRows: H == 28 exactly, no row of a lane ever lies past the end of its column.
-template <int kThreads, bool kWide, bool kExactRows, bool kNonTemporal>
+// kTuning: the instantiation with the round-4 tuning hooks (persistent grid / drawn parts / phase timeline / priorities / part
+// shapes, all behind FIERY_POOL_* switches); the production instantiation has none of them - its body is round 3's plus the
+// completion tickets (with the hooks compiled in, even unused, the kernel measured 6 us slower: profiles/r4_pool_decomposition.txt)
+template <int kThreads, bool kWide, bool kExactRows, bool kNonTemporal, bool kTuning = false>
 __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
     const float* __restrict__ x, PoolStrides xs, const int* __restrict__ rank, const void* __restrict__ quads,
     const unsigned char* __restrict__ occ, const unsigned* __restrict__ live, float* __restrict__ out,
     int* __restrict__ occupied, int n_cam, int D, int H, int W, int C, int n_vox, int n_words, int capacity, int tail_first,
     int tail_parts, int n_items, int* __restrict__ draw, long long* __restrict__ trace, int late_first, int late_prio,
-    int* __restrict__ counters, uint4* __restrict__ clean, int clean_vec) {
+    int* __restrict__ counters, uint4* __restrict__ clean, int clean_vec, int part_ranges) {
     using prefix_t = std::conditional_t<kWide, unsigned, unsigned short>;
     HIP_DYNAMIC_SHARED(unsigned char, cp_lds)
     const int n_w32 = 2 * n_words;
@@ -1248,14 +1251,15 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
     // the older wavefronts win the arbitration) takes fewer parts and all slots finish together.
     // Two workgroups share a CU and the one dispatched first runs ~12 % ahead of the other all the way (the arbiter favours
     // the older wavefronts): the later half of the first round of workgroups asks for a higher issue priority.
-    if (late_prio > 0 && static_cast<int>(blockIdx.x) >= late_first) {
+    if (kTuning && late_prio > 0 && static_cast<int>(blockIdx.x) >= late_first) {
         if (late_prio == 1) __builtin_amdgcn_s_setprio(1);
         else if (late_prio == 2) __builtin_amdgcn_s_setprio(2);
         else __builtin_amdgcn_s_setprio(3);
     }
-    int total = 0, f_have = -1;
-    for (int item = blockIdx.x;; item += gridDim.x) {
-    if (draw && item >= tail_first) {
+    int total = 0, f_have = -1, ticket = -1;
+    for (int item = blockIdx.x, round = 0;; item += gridDim.x, ++round) {
+    if (!kTuning && round) break;                                         // (production: one item per workgroup, no loop)
+    if (kTuning && draw && item >= tail_first) {
         if (tid == 0) *drawn = tail_first + atomicAdd(draw, 1);
         __syncthreads();
         item = *drawn;
@@ -1263,9 +1267,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
     }
     if (item >= n_items) break;
     // tuning aid (FIERY_POOL_TRACE = address of 4 * n_items int64): the 100 MHz wall clock at the item's phases
-    if (trace && tid == 0) trace[4 * item] = wall_clock64();
+    if (kTuning && trace && tid == 0) trace[4 * item] = wall_clock64();
     int unit = item, part = 0, parts = 1;
-    if (late_prio < 0 && unit < tail_first) unit = tail_first - 1 - unit;      // tuning (FIERY_POOL_LATE_PRIO=-1): whole units in reverse order
+    if (kTuning && late_prio < 0 && unit < tail_first) unit = tail_first - 1 - unit;      // tuning (FIERY_POOL_LATE_PRIO=-1): whole units in reverse order
     if (unit >= tail_first) {
         const int t = unit - tail_first;
         unit = tail_first + t / tail_parts;
@@ -1319,7 +1323,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
         __syncthreads();                                                  // scratch read, bits / prefix written
     }
     if (occupied && c == 0 && part == 0 && tid == 0) occupied[f] = total;
-    if (trace && tid == 0) trace[4 * item + 1] = wall_clock64();
+    if (kTuning && trace && tid == 0) trace[4 * item + 1] = wall_clock64();
     auto cell_of = [&](int r) {                                           // r: a voxel that is occupied
         return static_cast<int>(prefix[r >> 5]) + __popc(bits[r >> 5] & ((1u << (r & 31)) - 1u));
     };
@@ -1536,7 +1540,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
         // ... when the parts are drawn (persistent workgroups); the statically dealt parts of the default launch take the
         // slices block-cyclically instead: contiguous ranges differ in how many of their quads are live (a part's row phase
         // took 29-53 us against 28-37 us, and the slowest part ends the kernel)
-        const bool ranges = draw != nullptr;
+        const bool ranges = kTuning && (draw != nullptr || part_ranges);
         const int s_lo = ranges ? static_cast<int>(static_cast<long long>(part) * n_slices / parts) : 0;
         const int s_end = ranges ? static_cast<int>(static_cast<long long>(part + 1) * n_slices / parts) : n_slices;
         const int s_first = ranges ? s_lo + wave : wave + part * kWaves, s_step = ranges ? kWaves : kWaves * parts;
@@ -1550,7 +1554,13 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
         }
         for (int s = s_first; s < s_end; s += s_step) process(rows_in_flight, record, s, s + s_step < s_end ? s + s_step : n_slices);
         __syncthreads();
-        if (trace && tid == 0) trace[4 * item + 2] = wall_clock64();
+        if (kTuning && trace && tid == 0) trace[4 * item + 2] = wall_clock64();
+        // this item has read the last thing it needs from the region the call clears (its live masks): it takes its ticket now,
+        // so that the atomic's round trip passes under the write-out instead of holding the slot afterwards
+        // (not when parts are drawn: the draw counter lives in the same region and is read until the last workgroup leaves)
+        // (sixteen counters, dealt by item: the workgroups of a round finish within microseconds of each other and an atomic on
+        // ONE address is served every ~0.1 us - 512 of them held every slot for its share of 50 us)
+        if (counters && !(kTuning && draw) && pass == n_pass - 1 && tid == 0) ticket = atomicAdd(counters + 16 + (item & 15), 1);
         // ---- expand the window of cells into the dense plane --------------------------------------------------
         if (parts == 1 && n_pass == 1 && (n_vox & 3) == 0 && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
             // one pass, whole units: every voxel gets its cell's sum or a zero - four voxels (one nibble of a bit word) per
@@ -1565,23 +1575,6 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
                 if (nib & 4u) v.z = plane[cell++];
                 if (nib & 8u) v.w = plane[cell];
                 *reinterpret_cast<float4*>(o + v0) = v;
-            }
-        } else if (parts > 1 && n_pass == 1 && (n_vox & 3) == 0) {
-            // a part adds its cells to the (pre-zeroed) plane: the same walk, four voxels per thread and step - a step per voxel
-            // is a chain of three dependent LDS reads, 78 of them in a row (12 us per part against 3 us for this form)
-            for (int v0 = 4 * tid; v0 < n_vox; v0 += 4 * kThreads) {
-                const unsigned wbits = bits[v0 >> 5];
-                const unsigned nib = (wbits >> (v0 & 31)) & 15u;
-                if (nib == 0u) continue;
-                int cell = static_cast<int>(prefix[v0 >> 5]) + __popc(wbits & ((1u << (v0 & 31)) - 1u));
-                float val[4] = {0.f, 0.f, 0.f, 0.f};
-                if (nib & 1u) val[0] = plane[cell++];
-                if (nib & 2u) val[1] = plane[cell++];
-                if (nib & 4u) val[2] = plane[cell++];
-                if (nib & 8u) val[3] = plane[cell];
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (val[k] != 0.f) atomicAdd(&o[v0 + k], val[k]);
             }
         } else
         for (int v0 = tid; v0 < n_vox; v0 += kThreads) {
@@ -1599,12 +1592,30 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
         }
         __syncthreads();                                                  // the plane is cleared again by the next pass
     }
-    if (trace && tid == 0) trace[4 * item + 3] = wall_clock64();
-    }   // items
-    // The workgroup that finishes last leaves the workspace's cleared region (occupancy bytes, live masks, counters) as this
+    if (kTuning && trace && tid == 0) trace[4 * item + 3] = wall_clock64();
+    // The item that takes the last ticket leaves the workspace's cleared region (occupancy bytes, live masks, counters) as this
     // launch found it - all zero - so the next call on this workspace can skip its memset dispatch
-    // (FIERY_POOL_WORKSPACE_CLEAN).  Every other workgroup has read what it needed from the region before it counted itself.
-    if (counters) {
+    // (FIERY_POOL_WORKSPACE_CLEAN).  Every other item had read what it needed from the region before it took its ticket.
+    if (counters && !(kTuning && draw)) {
+        // the item that completes its counter (items k, k + 16, ...: (n_items - k + 15) / 16 of them) reports to the top counter;
+        // the one that completes that cleans
+        if (tid == 0) {
+            int last = 0;
+            if (ticket == (n_items - (item & 15) + 15) / 16 - 1) {
+                const int filled = min(n_items, 16);                      // counters that receive any item
+                last = atomicAdd(counters + 1, 1) == filled - 1;
+            }
+            *drawn = last;
+        }
+        __syncthreads();
+        if (*drawn) {
+            const uint4 z = {0u, 0u, 0u, 0u};
+            for (int i = tid; i < clean_vec; i += kThreads) clean[i] = z;
+        }
+        __syncthreads();                                                  // (`drawn` is written again by the next item)
+    }
+    }   // items
+    if (kTuning && counters && draw) {                                    // drawn parts: one ticket per workgroup, after its last draw
         __syncthreads();
         if (tid == 0) *drawn = atomicAdd(counters + 1, 1);
         __syncthreads();
@@ -1892,22 +1903,31 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
         // (the counter lies in the cleared region in front of `occupied`)
         int* draw = (persistent && tail > 0 && !getenv("FIERY_POOL_NO_DRAW")) ? reinterpret_cast<int*>(ws + pl.off_occupied - 256) : nullptr;
         int* counters = reinterpret_cast<int*>(ws + pl.off_occupied - 256);       // [0] parts drawn, [1] workgroups finished
+        if (getenv("FIERY_POOL_NO_COUNTERS")) counters = nullptr;                   // tuning: no tickets, no in-kernel cleaning (callers must not pass WORKSPACE_CLEAN)
+        int part_ranges = 0;
+        if (const char* forced = getenv("FIERY_POOL_PART_RANGES")) part_ranges = atoi(forced);      // tuning / A-B runs
         int late_first = cp_slots / 2, late_prio = 0;
         if (const char* forced = getenv("FIERY_POOL_LATE_PRIO")) late_prio = atoi(forced);      // tuning / A-B runs
         long long* trace = nullptr;
         if (const char* t = getenv("FIERY_POOL_TRACE")) trace = reinterpret_cast<long long*>(strtoull(t, nullptr, 0));   // tuning
+        const bool tuning = persistent || trace || late_prio != 0 || part_ranges != 0 || draw != nullptr;
         bool nt = true;                                                  // non-temporal row loads (see the kernel)
         if (const char* forced = getenv("FIERY_POOL_NT")) nt = atoi(forced) != 0;                // tuning / A-B runs
 #define FIERY_POOL_COMPACT_LAUNCH(THREADS, WIDE, EXACT, NT)                                                              \
     do {                                                                                                                 \
+        if (tuning) FIERY_POOL_COMPACT_LAUNCH_T(THREADS, WIDE, EXACT, NT, true);                                         \
+        else FIERY_POOL_COMPACT_LAUNCH_T(THREADS, WIDE, EXACT, NT, false);                                               \
+    } while (0)
+#define FIERY_POOL_COMPACT_LAUNCH_T(THREADS, WIDE, EXACT, NT, TUNING)                                                    \
+    do {                                                                                                                 \
         if (cp_lds > 65536 &&                                                                                            \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_voxel_pool_compact<THREADS, WIDE, EXACT, NT>),          \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_voxel_pool_compact<THREADS, WIDE, EXACT, NT, TUNING>),  \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(cp_lds)) != hipSuccess)     \
             return fail(FIERY_ELAUNCH, "voxel_pool: cannot reserve %zu B of LDS", cp_lds);                              \
-        hipLaunchKernelGGL((k_voxel_pool_compact<THREADS, WIDE, EXACT, NT>), units, dim3(THREADS), cp_lds, s, x, st, rank, \
+        hipLaunchKernelGGL((k_voxel_pool_compact<THREADS, WIDE, EXACT, NT, TUNING>), units, dim3(THREADS), cp_lds, s, x, st, rank, \
                            static_cast<const void*>(coldesc), occ, live, out, occupied, n_cam, D, H, W, C, pl.n_vox, pl.n_words, \
                            cp_cells, tail_first, parts, n_items, draw, trace, late_first, late_prio, counters,           \
-                           reinterpret_cast<uint4*>(occ), static_cast<int>((pl.off_occupied - pl.off_occ) / 16));        \
+                           reinterpret_cast<uint4*>(occ), static_cast<int>((pl.off_occupied - pl.off_occ) / 16), part_ranges); \
     } while (0)
 #define FIERY_POOL_COMPACT_ROWS(THREADS, WIDE)                            \
     do {                                                                 \
@@ -1924,6 +1944,7 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
         }
 #undef FIERY_POOL_COMPACT_ROWS
 #undef FIERY_POOL_COMPACT_LAUNCH
+#undef FIERY_POOL_COMPACT_LAUNCH_T
         return check_launch("voxel_pool (compact)");
     }
     if (plane_form) {

@@ -446,6 +446,9 @@ class BevEngine:
         self.frustum = model.frustum.detach().float().contiguous().to(self.device)
         self.pool_tile = int(os.environ.get('FIERY_POOL_TILE', '0'))      # voxels per LDS tile, 0 = library default
         self.pool_flags = 0
+        # the engine's pooling workspace is zero-filled once and then only used by the library: calls skip their memset
+        # (FIERY_POOL_NO_CLEAN=1: A/B runs against the memset form)
+        self._pool_clean_flag = 0 if os.environ.get('FIERY_POOL_NO_CLEAN') == '1' else native.POOL_WORKSPACE_CLEAN
         # matrix-core precision of every convolution of this plan ('f32' | 'bf16'; model.conv_precision)
         self.precision = {'f32': native.PRECISION_F32, 'bf16': native.PRECISION_BF16}[getattr(model, 'conv_precision', 'f32')]
         previous, ops.DEFAULT_PRECISION = ops.DEFAULT_PRECISION, self.precision
@@ -738,7 +741,7 @@ class BevEngine:
         detail = dict(workspace=ws, points=f * n * d * h * w, channels=c, frames=f, voxels=self.X * self.Y)
         return ops.profiled('voxel_pool', None, x, lambda: self._pool_call((f, n, d, h, w), lambda: self.lib.voxel_pool(
             x, x.stride(), geometry.contiguous(), f, n, d, h, w, c, self.grid, out=out, workspace=ws,
-            tile_voxels=self.pool_tile, flags=self.pool_flags | native.POOL_WORKSPACE_CLEAN)), detail=detail)
+            tile_voxels=self.pool_tile, flags=self.pool_flags | self._pool_clean_flag)), detail=detail)
 
     def pool_fused(self, depth_logits, features, geometry, out=None):
         """depth logits (F, n, D, h, w) + features (F, n, C, h, w) -> (F, C, X, Y) without the outer product."""
@@ -751,7 +754,7 @@ class BevEngine:
         ws = self._pool_workspace(f, n, d, h, w, features.device)
         return self._pool_call((f, n, d, h, w), lambda: self.lib.lift_splat(
             prob, features.contiguous(), geometry.contiguous(), f, n, d, h, w, c, self.grid, out=out, workspace=ws,
-            tile_voxels=self.pool_tile, flags=self.pool_flags | native.POOL_WORKSPACE_CLEAN))
+            tile_voxels=self.pool_tile, flags=self.pool_flags | self._pool_clean_flag))
 
     def _run_distribution(self, ops, srcs, tag, mu=None, log_sigma=None):
         lib = self.lib

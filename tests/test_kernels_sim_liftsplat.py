@@ -623,17 +623,18 @@ def test_four_lane_prepass_writes_what_the_one_lane_prepass_writes(sim, monkeypa
         assert np.array_equal(got >= 0, keep) and np.array_equal(got[keep], rank_o[keep])
 
 
-@pytest.mark.parametrize('persistent', [0, 1])
-def test_pooling_leaves_its_workspace_clean(sim, monkeypatch, persistent):
+@pytest.mark.parametrize('persistent,channels', [(0, 5), (1, 5), (0, 19)])
+def test_pooling_leaves_its_workspace_clean(sim, monkeypatch, persistent, channels):
     """FIERY_POOL_WORKSPACE_CLEAN: on a zero-filled workspace the compact form skips its memset; its last workgroup re-zeroes
     the occupancy bytes, live masks and counters, so the NEXT call (another rig: other voxels occupied, other quads live) may
-    skip it too.  Results equal the unflagged calls' on a garbage workspace."""
+    skip it too.  Results equal the unflagged calls' on a garbage workspace.  (10 and 38 (channel, frame) units: fewer than the
+    sixteen completion counters, and more with a ragged last round.)"""
     from fiery_amd import native
     monkeypatch.setenv('FIERY_POOL_PERSISTENT', str(persistent))
     grid, (res, start, dim) = _grid([-14.0, 30.0, 0.5], [-24.0, 10.0, 0.5], [-10.0, 10.0, 20.0])
     ws = None
     for seed in (63, 64, 65):
-        frustum, intr, extr, lifted = _small_problem(seed, n_cam=2, D=12, H=28, W=40, C=5, frames=2)
+        frustum, intr, extr, lifted = _small_problem(seed, n_cam=2, D=12, H=28, W=40, C=channels, frames=2)
         frames, n_cam, C, D, H, W = lifted.shape
         geo = torch.from_numpy(ls.get_geometry(frustum, intr.numpy(), extr.numpy()))
         st = lifted.stride()
