@@ -77,12 +77,7 @@ __device__ __forceinline__ int voxel_rank(float gx, float gy, float gz, const Gr
 // ------------------------------------------------------------------------------------------------
 // camera matrices: M = R . K^-1, t
 // ------------------------------------------------------------------------------------------------
-__global__ void k_camera_matrices(const float* __restrict__ intrinsics, const float* __restrict__ extrinsics,
-                                  int n, float* __restrict__ cam) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float* K = intrinsics + i * 9;
-    const float* E = extrinsics + i * 16;
+__device__ __forceinline__ void camera_matrix(const float* __restrict__ K, const float* __restrict__ E, float* __restrict__ out) {
     float inv[9];
     const float fx = K[0], fy = K[4], cx = K[2], cy = K[5];
     const bool canonical = K[1] == 0.f && K[3] == 0.f && K[6] == 0.f && K[7] == 0.f && K[8] == 1.f &&
@@ -105,7 +100,6 @@ __global__ void k_camera_matrices(const float* __restrict__ intrinsics, const fl
         inv[3] = B * r;  inv[4] = (a * k - c * g) * r;   inv[5] = -(a * f - c * d) * r;
         inv[6] = C * r;  inv[7] = -(a * h - b * g) * r;  inv[8] = (a * e - b * d) * r;
     }
-    float* out = cam + i * 12;
     for (int r = 0; r < 3; ++r) {
         for (int c = 0; c < 3; ++c) {
             // ATen's small-matmul CPU kernel: products and sums rounded one by one, k ascending
@@ -115,6 +109,74 @@ __global__ void k_camera_matrices(const float* __restrict__ intrinsics, const fl
             out[r * 3 + c] = acc;
         }
         out[9 + r] = E[r * 4 + 3];
+    }
+}
+
+
+__global__ void k_camera_matrices(const float* __restrict__ intrinsics, const float* __restrict__ extrinsics,
+                                  int n, float* __restrict__ cam) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    camera_matrix(intrinsics + i * 9, extrinsics + i * 16, cam + i * 12);
+}
+
+// ------------------------------------------------------------------------------------------------
+// camera matrices through the calibration table (fiery_amd/calibration.py): the HOST inverts (LAPACK, as the reference's
+// CPU path does), keyed on the 21 words of K and [R | t] that enter the computation; the device looks the words up.
+// One workgroup: a step has 54 cameras, and a launch-private miss count needs no clearing.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned calibration_hash(const unsigned* key) {
+    unsigned h = 2166136261u;                                              // FNV-1a over the words, one final fold
+    for (int i = 0; i < FIERY_CALIB_KEY_WORDS; ++i) h = (h ^ key[i]) * 16777619u;
+    return h ^ (h >> 15);
+}
+
+__global__ __launch_bounds__(64) void k_camera_matrices_cached(const float* __restrict__ intrinsics,
+                                                                const float* __restrict__ extrinsics, int n,
+                                                                const unsigned* __restrict__ table, int slots,
+                                                                unsigned* __restrict__ misses, int miss_capacity,
+                                                                float* __restrict__ cam) {
+    __shared__ int n_miss;
+    if (threadIdx.x == 0) n_miss = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        unsigned key[FIERY_CALIB_KEY_WORDS];
+        const unsigned* k_words = reinterpret_cast<const unsigned*>(intrinsics) + i * 9;
+        const unsigned* e_words = reinterpret_cast<const unsigned*>(extrinsics) + i * 16;
+        for (int w = 0; w < 9; ++w) key[w] = k_words[w];
+        for (int w = 0; w < 12; ++w) key[9 + w] = e_words[w];                // the rows of [R | t]
+        const unsigned h = calibration_hash(key);
+        const unsigned* hit = nullptr;
+        for (int probe = 0; probe < FIERY_CALIB_PROBES && !hit; ++probe) {
+            const unsigned* e = table + static_cast<size_t>((h + probe) & (slots - 1)) * FIERY_CALIB_ENTRY_WORDS;
+            if (e[0] == 0u) break;                                          // entries are never removed: an empty slot ends the chain
+            bool same = true;
+            for (int w = 0; w < FIERY_CALIB_KEY_WORDS; ++w) same = same && e[1 + w] == key[w];
+            if (same) hit = e;
+        }
+        float* out = cam + i * 12;
+        if (hit) {
+            unsigned* out_words = reinterpret_cast<unsigned*>(out);
+            for (int w = 0; w < 12; ++w) out_words[w] = hit[1 + FIERY_CALIB_KEY_WORDS + w];
+        } else {
+            camera_matrix(intrinsics + i * 9, extrinsics + i * 16, out);
+            const int m = atomicAdd(&n_miss, 1);
+            if (m < miss_capacity) {
+                unsigned* row = misses + FIERY_CALIB_MISS_HEADER + m * FIERY_CALIB_MISS_WORDS;
+                for (int w = 0; w < FIERY_CALIB_KEY_WORDS; ++w) row[w] = key[w];
+                row[FIERY_CALIB_KEY_WORDS] = static_cast<unsigned>(i);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // the list is rewritten by every launch; the launch number, in front of and behind the entries, tells the host
+        // which launch a copy of the list belongs to and whether the copy was complete
+        const unsigned launch = misses[2] + 1u;
+        misses[0] = static_cast<unsigned>(min(n_miss, miss_capacity));
+        misses[1] = static_cast<unsigned>(n_miss);
+        misses[2] = launch;
+        misses[FIERY_CALIB_MISS_HEADER + miss_capacity * FIERY_CALIB_MISS_WORDS] = launch;
     }
 }
 
@@ -1637,6 +1699,18 @@ extern "C" int fiery_camera_matrices(const float* intrinsics, const float* extri
     hipLaunchKernelGGL(k_camera_matrices, dim3(ceil_div(n_cameras, 64)), dim3(64), 0, as_stream(stream),
                        intrinsics, extrinsics, n_cameras, cam);
     return check_launch("camera_matrices");
+}
+
+extern "C" int fiery_camera_matrices_cached(const float* intrinsics, const float* extrinsics, int n_cameras,
+                                            const uint32_t* table, int table_slots, uint32_t* misses, int miss_capacity,
+                                            float* cam, fiery_stream_t stream) {
+    FIERY_REQUIRE(intrinsics && extrinsics && cam && table && misses && n_cameras > 0,
+                  "camera_matrices_cached: null pointer or n <= 0");
+    FIERY_REQUIRE(table_slots >= 64 && (table_slots & (table_slots - 1)) == 0 && miss_capacity > 0,
+                  "camera_matrices_cached: the table needs a power-of-two number of slots >= 64 and a miss list");
+    hipLaunchKernelGGL(k_camera_matrices_cached, dim3(1), dim3(64), 0, as_stream(stream), intrinsics, extrinsics, n_cameras,
+                       table, table_slots, misses, miss_capacity, cam);
+    return check_launch("camera_matrices_cached");
 }
 
 extern "C" int fiery_lift_geometry(const float* frustum, const float* cam, int n_cameras, int D, int H, int W,

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libfiery_hip.so')
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -96,6 +96,8 @@ _SIGNATURES = {
     'fiery_abi_version': (C.c_int, []),
     'fiery_last_error': (C.c_char_p, []),
     'fiery_camera_matrices': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'fiery_camera_matrices_cached': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                               C.c_void_p, C.c_void_p]),
     'fiery_lift_geometry': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'fiery_voxel_index': (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(BevGrid), C.c_void_p, C.c_void_p, C.c_void_p]),
     'fiery_voxel_pool_workspace_bytes': (C.c_size_t, [C.c_int] * 7 + [C.c_uint32]),
@@ -260,6 +262,15 @@ class Lib:
         n = intrinsics.numel() // 9
         cam = torch.empty(n, 12, dtype=torch.float32, device=intrinsics.device)
         self.check(self.dll.fiery_camera_matrices(_ptr(intrinsics), _ptr(extrinsics), n, _ptr(cam), _stream_of(cam)))
+        return cam
+
+    def camera_matrices_cached(self, intrinsics, extrinsics, table, slots, misses, miss_capacity):
+        """Camera matrices through a calibration table (fiery_amd/calibration.py owns `table` and `misses`)."""
+        n = intrinsics.numel() // 9
+        assert extrinsics.numel() == n * 16 and table.numel() == slots * 36 and table.dtype == torch.int32
+        cam = torch.empty(n, 12, dtype=torch.float32, device=intrinsics.device)
+        self.check(self.dll.fiery_camera_matrices_cached(_ptr(intrinsics), _ptr(extrinsics), n, _ptr(table), slots, _ptr(misses),
+                                                         miss_capacity, _ptr(cam), _stream_of(cam)))
         return cam
 
     def lift_geometry(self, frustum, cam):

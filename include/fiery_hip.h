@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FIERY_ABI_VERSION 20
+#define FIERY_ABI_VERSION 21
 
 #define FIERY_OK 0
 #define FIERY_EINVAL (-22)      /* bad argument (shape, alignment, null pointer) */
@@ -46,6 +46,27 @@ const char* fiery_last_error(void);
  * intrinsics [n][3][3], extrinsics [n][4][4] (camera->ego). */
 int fiery_camera_matrices(const float* intrinsics, const float* extrinsics, int n_cameras,
                           float* cam, fiery_stream_t stream);
+
+/* The same matrices served from a calibration table (round 4, ABI 21): `torch.inverse` in the reference's CPU path is LAPACK;
+ * the closed form above equals it bit for bit for zero-skew pinhole intrinsics only.  The caller computes cam[12] for the
+ * calibrations of its rig ON THE HOST with the reference's own operators and files them in `table` under the 21 words that enter
+ * the computation (K's nine, then the three rows of [R | t]); this entry point looks every camera's words up (open addressing,
+ * FNV-1a over the words folded once: h ^= h >> 15; at most FIERY_CALIB_PROBES slots from h & (table_slots - 1), an empty slot
+ * ends the search) and copies the twelve numbers on a hit.  A miss evaluates the device form (as fiery_camera_matrices) and
+ * appends the camera's words to `misses`, which every call rewrites:
+ *   misses[0] entries written (<= miss_capacity), [1] misses of the call, [2] call number, [3] unused,
+ *   then miss_capacity rows of FIERY_CALIB_MISS_WORDS words {21 key words, camera index, 2 unused}, then the call number again
+ *   (a host that copies the list asynchronously compares the two call numbers to see that its copy is whole).
+ * table: table_slots (a power of two >= 64) rows of FIERY_CALIB_ENTRY_WORDS words {occupied, 21 key words, 12 value words, 2 unused}.
+ * No host interaction: capturable in a hipGraph.  The host side is fiery_amd/calibration.py. */
+#define FIERY_CALIB_KEY_WORDS 21
+#define FIERY_CALIB_ENTRY_WORDS 36
+#define FIERY_CALIB_MISS_WORDS 24
+#define FIERY_CALIB_MISS_HEADER 4
+#define FIERY_CALIB_PROBES 16
+int fiery_camera_matrices_cached(const float* intrinsics, const float* extrinsics, int n_cameras,
+                                 const uint32_t* table, int table_slots, uint32_t* misses, int miss_capacity,
+                                 float* cam, fiery_stream_t stream);
 
 /* geometry[n][D][H][W][3] = M_n . (u*d, v*d, d) + t_n for every frustum point.
  * Replaces fiery.py:199-205.  frustum [D][H][W][3] = (u, v, depth) (fiery.py:109-128). */

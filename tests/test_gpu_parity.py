@@ -66,19 +66,25 @@ def test_geometry_and_indices_bit_exact_full_size(hip, name, preset, n_cam, jitt
     assert np.array_equal(rank[::97].astype(np.int32), gold[key + '_rank_sample'])
 
 
-def test_host_camera_matrices_bit_exact_for_skewed_intrinsics(hip):
-    """`camera_matrix_mode = 'host'`: geometry and voxel ranks equal the oracle's (LAPACK inverse, as the reference's CPU
-    path) bit for bit for intrinsics the device closed form does not cover - full-size baseline grid, 6 cameras."""
+@pytest.mark.parametrize('mode', ['host', 'table'])
+def test_host_camera_matrices_bit_exact_for_skewed_intrinsics(hip, mode):
+    """`camera_matrix_mode = 'host'` (the reference's operators every call) and the default `'table'` (the same matrices filed
+    once per calibration, looked up on the device; tests/test_calibration_table.py replays it inside a hipGraph): geometry and
+    voxel ranks equal the oracle's (LAPACK inverse, as the reference's CPU path) bit for bit for intrinsics the device closed
+    form does not cover - full-size baseline grid, 6 cameras."""
     cfg = get_preset_cfg('baseline.yml')
     grid, (res, start, dim) = _grid_of(cfg)
     model, _ = _model(cfg)
-    model.camera_matrix_mode = 'host'
+    assert model.camera_matrix_mode == 'table'
+    model.camera_matrix_mode = mode
     _, K, E, _ = make_inputs(1, 1, 6, with_image=False)
     gen = torch.Generator().manual_seed(9)
     K = K.clone()
     K[..., 0, 1] = 1.5 * torch.randn(K.shape[:3], generator=gen)
     K[..., 1, 0] = 0.2 * torch.randn(K.shape[:3], generator=gen)
     K[..., 2, 2] = 1.0 + 0.01 * torch.randn(K.shape[:3], generator=gen)
+    if mode == 'table':
+        model.prime_calibrations(K, E)
     geo = model.get_geometry(K[:, 0].to(DEV), E[:, 0].to(DEV))
     want = ls.get_geometry(_frustum(cfg), K[:, 0].numpy(), E[:, 0].numpy())
     assert np.array_equal(geo.cpu().numpy(), want)
