@@ -36,6 +36,9 @@ namespace fiery {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 
+#ifndef FIERY_CONV_EARLY_LOADS
+#define FIERY_CONV_EARLY_LOADS 1
+#endif
 constexpr int BK = 32;    // k per LDS stage (4 units of 8 input channels)
 #ifndef FIERY_CONV_EPILOGUE_PRIO
 #define FIERY_CONV_EPILOGUE_PRIO 0     // wave priority of the epilogue (0 = unchanged); see the end of the K loop
@@ -526,6 +529,19 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
     };
     // piece i of a stage's side work, i = 0 .. N_PIECES-1; the stage running out of `buf` fills the other buffer
     auto side_piece = [&](int buf, int i) {
+#if FIERY_CONV_EARLY_LOADS
+        // every register is requested again right after the store that frees it: a request then has the whole stage to land
+        // (with all stores first and all requests after them it had the second half of one stage and the first MFMAs of the next)
+        if (i < 3) load_setup(i);
+        else if (i < 3 + 2 * NA) {
+            if ((i - 3) & 1) load_a((i - 3) >> 1);
+            else store_a(buf ^ 1, (i - 3) >> 1);
+        } else if (i < 3 + 2 * NA + 2 * BLOADS) {
+            if ((i - 3 - 2 * NA) & 1) load_b((i - 3 - 2 * NA) >> 1);
+            else store_b(buf ^ 1, (i - 3 - 2 * NA) >> 1);
+        } else advance();
+        return;
+#endif
         constexpr int S0 = NA + BLOADS;            // first setup piece
         if (i < NA) store_a(buf ^ 1, i);
         else if (i < S0) store_b(buf ^ 1, i - NA);
@@ -758,7 +774,12 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
     // the registers that frees.  The pieces are dealt out evenly between the MFMAs of the running stage.
     // prologue: stage 0 -> LDS buffer 0, stage 1 -> registers (it stays in flight across the barrier)
 #pragma unroll
-    for (int i = NA + BLOADS; i < N_PIECES; ++i) side_piece(1, i);
+    for (int k = 0; k < 3; ++k) load_setup(k);
+#pragma unroll
+    for (int j = 0; j < NA; ++j) load_a(j);
+#pragma unroll
+    for (int k = 0; k < BLOADS; ++k) load_b(k);
+    advance();
 #pragma unroll
     for (int i = 0; i < N_PIECES; ++i) side_piece(1, i);
     __syncthreads();
@@ -879,7 +900,8 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
     // at a time; going through LDS turns the tile into full rows: every residual load and output store is a
     // 16-byte, unit-stride access.  `store_rows(width, ...)` finishes a staged tile of `width` couts.
     int res_pre_rows = p.res_pre;                              // (the argument block itself is read-only)
-    auto store_rows = [&](int width, int cout0, const float* scale, const float* shift, int act, bool with_bias) {
+    auto store_rows = [&](int width, int cout0, const float* scale, const float* shift, int act, bool with_bias,
+                          const float4* fetched = nullptr) {
         const int c4n = width >> 2;                                 // 16-byte chunks per pixel row
         const int rows_per_pass = 256 / c4n;
         const int c4 = tid % c4n, prow0 = tid / c4n;
@@ -888,8 +910,13 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
         const bool gates_upper = p.epi == FIERY_EPI_GRU_GATES && co >= half;
         // padding couts are never stored (gate epilogue: cout_store channels of EACH half - the two gates)
         if ((gates_upper ? co - half : co) >= p.cout_store) return;
-        const float4 sc = *reinterpret_cast<const float4*>(scale + co);
-        const float4 sh = *reinterpret_cast<const float4*>(shift + co);
+        // (`fetched`: the caller requested this thread's scale / shift before it staged the tile - one memory round trip less
+        // between the K loop's end and the first row)
+        const float4 sc = fetched ? fetched[0] : *reinterpret_cast<const float4*>(scale + co);
+        const float4 sh = fetched ? fetched[1] : *reinterpret_cast<const float4*>(shift + co);
+        if constexpr (CLK) {                                              // scale / shift have arrived
+            if (clk_trace) clk_trace[7] = wall_clock64() + (__builtin_bit_cast(int, sc.x) & __builtin_bit_cast(int, sh.x) & 0);
+        }
         if (p.vec_epilogue & 2) {
             // DENSE TENSORS (round 4; the host sets the bit when every tensor the epilogue touches has its images back to back -
             // img_stride == Hout Wout ld - and spans less than 2 GB): pixel gp of a tensor then sits gp * ld floats from its base
@@ -912,74 +939,108 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
                 __builtin_memcpy(&raw, &f, 16);
                 __builtin_amdgcn_raw_buffer_store_b128(raw, r, voff, 0, 0);
             };
-            const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            int gp = pix0 + prow0;
-            const bool plain = p.epi == FIERY_EPI_PLAIN, gates = p.epi == FIERY_EPI_GRU_GATES;
-            // descriptors are wave-uniform (one per tensor); which of them a lane uses - a gate launch's lower channel half
-            // stores the update gate to `out`, its upper half reads the state and stores to `out2` - is a per-lane predicate
-            const bool upper = gates && gates_upper;
-            const TensP& t_a = plain ? p.res : p.aux0;
-            const int c_x = upper ? co - half : co;                          // channel inside out2 / aux0 for the upper half
-            const bool has_a = plain ? p.res.ptr != nullptr : (gates ? upper : true);
-            const bool has_b = !plain && !gates;                              // GRU_OUT: aux1 = state
-            const bool has_d1 = has_b && p.out2.ptr != nullptr;
-            const __amdgpu_buffer_rsrc_t r_out = rsrc(p.out.ptr, p.out.ld), r_out2 = rsrc(p.out2.ptr, p.out2.ld),
-                                         r_a = rsrc(t_a.ptr, t_a.ld), r_b = rsrc(has_b ? p.aux1.ptr : nullptr, p.aux1.ld);
-            int o_out = (gp * p.out.ld + co) * 4, o_out2 = (gp * p.out2.ld + c_x) * 4, o_a = (gp * t_a.ld + c_x) * 4,
-                o_b = (gp * p.aux1.ld + co) * 4;
-            const int s_out = rows_per_pass * p.out.ld * 4, s_out2 = rows_per_pass * p.out2.ld * 4, s_a = rows_per_pass * t_a.ld * 4,
-                      s_b = rows_per_pass * p.aux1.ld * 4;
-            const bool bias_rows = with_bias && p.img_bias;
-            auto bias_of = [&](int g) {
-                return *reinterpret_cast<const float4*>(p.img_bias + fast_div(g, p.mg_hw, p.sh_hw) * p.cout_pad + co);
-            };
-            float4 cur_a = has_a ? load4(r_a, o_a) : zero4, cur_b = has_b ? load4(r_b, o_b) : zero4;
-            float4 cur_bias = (bias_rows && gp < M) ? bias_of(gp) : zero4;
-            for (int pl = prow0; pl < BM; pl += rows_per_pass) {
-                if (gp >= M) break;
-                const int gp_n = gp + rows_per_pass;
-                const bool more = pl + rows_per_pass < BM && gp_n < M;
-                // the next row's operands are requested before this row is stored (an in-place residual is a different pixel)
-                const float4 nxt_a = (has_a && more) ? load4(r_a, o_a + s_a) : zero4;
-                const float4 nxt_b = (has_b && more) ? load4(r_b, o_b + s_b) : zero4;
-                const float4 nxt_bias = (bias_rows && more) ? bias_of(gp_n) : zero4;
-                float4 v = *reinterpret_cast<const float4*>(&smem[pl * width + c4 * 4]);
-                v.x += cur_bias.x;  v.y += cur_bias.y;  v.z += cur_bias.z;  v.w += cur_bias.w;
-                v.x = fmaf(v.x, sc.x, sh.x);  v.y = fmaf(v.y, sc.y, sh.y);  v.z = fmaf(v.z, sc.z, sh.z);  v.w = fmaf(v.w, sc.w, sh.w);
-                if (plain) {
-                    const float4 r = cur_a;
-                    if (res_pre_rows) { v.x += r.x;  v.y += r.y;  v.z += r.z;  v.w += r.w; }
-                    if (act == FIERY_ACT_RELU) {
-                        v.x = fmaxf(v.x, 0.f);  v.y = fmaxf(v.y, 0.f);  v.z = fmaxf(v.z, 0.f);  v.w = fmaxf(v.w, 0.f);
-                    } else if (act == FIERY_ACT_SIGMOID) {
-                        v.x = sigmoidf(v.x);  v.y = sigmoidf(v.y);  v.z = sigmoidf(v.z);  v.w = sigmoidf(v.w);
-                    } else if (act == FIERY_ACT_SWISH) {
-                        v.x *= sigmoidf(v.x);  v.y *= sigmoidf(v.y);  v.z *= sigmoidf(v.z);  v.w *= sigmoidf(v.w);
+            // The row loop is instantiated per kind of epilogue (round 4): with the kind read at run time every row paid for
+            // all of them - two packed adds of a bias that is mostly absent, the residual added before AND after the
+            // activation with four selects each, a NaN-quieting max in front of the ReLU, scalar branches on the activation -
+            // ~30 vector instructions where BatchNorm + ReLU needs six; and a vector instruction of an epilogue costs ~60
+            // cycles next to other workgroups' MFMAs (above).  -1 = read at run time (the general loop, everything else).
+            auto rows = [&](auto epi_c, auto act_c, auto res_c, auto bias_c) {
+                constexpr int kEpi = decltype(epi_c)::value, kAct = decltype(act_c)::value;
+                constexpr int kRes = decltype(res_c)::value;               // 0 none, 1 before the activation, 2 after it
+                constexpr int kBias = decltype(bias_c)::value;             // 0 none, 1 per-image bias rows
+                const int epi_ = kEpi < 0 ? p.epi : kEpi;
+                const int act_ = kAct < 0 ? act : kAct;
+                const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                int gp = pix0 + prow0;
+                const bool plain = epi_ == FIERY_EPI_PLAIN, gates = epi_ == FIERY_EPI_GRU_GATES;
+                // descriptors are wave-uniform (one per tensor); which of them a lane uses - a gate launch's lower channel half
+                // stores the update gate to `out`, its upper half reads the state and stores to `out2` - is a per-lane predicate
+                const bool upper = gates && gates_upper;
+                const TensP& t_a = plain ? p.res : p.aux0;
+                const int c_x = upper ? co - half : co;                          // channel inside out2 / aux0 for the upper half
+                const bool has_a = plain ? (kRes < 0 ? p.res.ptr != nullptr : kRes != 0) : (gates ? upper : true);
+                const bool res_first = kRes < 0 ? res_pre_rows != 0 : kRes == 1;
+                const bool has_b = !plain && !gates;                              // GRU_OUT: aux1 = state
+                const bool has_d1 = has_b && p.out2.ptr != nullptr;
+                const __amdgpu_buffer_rsrc_t r_out = rsrc(p.out.ptr, p.out.ld), r_out2 = rsrc(p.out2.ptr, p.out2.ld),
+                                             r_a = rsrc(t_a.ptr, t_a.ld), r_b = rsrc(has_b ? p.aux1.ptr : nullptr, p.aux1.ld);
+                int o_out = (gp * p.out.ld + co) * 4, o_out2 = (gp * p.out2.ld + c_x) * 4, o_a = (gp * t_a.ld + c_x) * 4,
+                    o_b = (gp * p.aux1.ld + co) * 4;
+                const int s_out = rows_per_pass * p.out.ld * 4, s_out2 = rows_per_pass * p.out2.ld * 4, s_a = rows_per_pass * t_a.ld * 4,
+                          s_b = rows_per_pass * p.aux1.ld * 4;
+                const bool bias_rows = kBias < 0 ? (with_bias && p.img_bias) : kBias != 0;
+                auto bias_of = [&](int g) {
+                    return *reinterpret_cast<const float4*>(p.img_bias + fast_div(g, p.mg_hw, p.sh_hw) * p.cout_pad + co);
+                };
+                float4 cur_a = has_a ? load4(r_a, o_a) : zero4, cur_b = has_b ? load4(r_b, o_b) : zero4;
+                float4 cur_bias = (bias_rows && gp < M) ? bias_of(gp) : zero4;
+                for (int pl = prow0; pl < BM; pl += rows_per_pass) {
+                    if (gp >= M) break;
+                    const int gp_n = gp + rows_per_pass;
+                    const bool more = pl + rows_per_pass < BM && gp_n < M;
+                    // the next row's operands are requested before this row is stored (an in-place residual is a different pixel)
+                    const float4 nxt_a = (has_a && more) ? load4(r_a, o_a + s_a) : zero4;
+                    const float4 nxt_b = (has_b && more) ? load4(r_b, o_b + s_b) : zero4;
+                    const float4 nxt_bias = (bias_rows && more) ? bias_of(gp_n) : zero4;
+                    float4 v = *reinterpret_cast<const float4*>(&smem[pl * width + c4 * 4]);
+                    if (kBias != 0) { v.x += cur_bias.x;  v.y += cur_bias.y;  v.z += cur_bias.z;  v.w += cur_bias.w; }
+                    v.x = fmaf(v.x, sc.x, sh.x);  v.y = fmaf(v.y, sc.y, sh.y);  v.z = fmaf(v.z, sc.z, sh.z);  v.w = fmaf(v.w, sc.w, sh.w);
+                    if (plain) {
+                        const float4 r = cur_a;
+                        if (kRes != 0 && kRes != 2 && res_first) { v.x += r.x;  v.y += r.y;  v.z += r.z;  v.w += r.w; }
+                        if (act_ == FIERY_ACT_RELU) {
+                            v.x = fmaxf(v.x, 0.f);  v.y = fmaxf(v.y, 0.f);  v.z = fmaxf(v.z, 0.f);  v.w = fmaxf(v.w, 0.f);
+                        } else if (act_ == FIERY_ACT_SIGMOID) {
+                            v.x = sigmoidf(v.x);  v.y = sigmoidf(v.y);  v.z = sigmoidf(v.z);  v.w = sigmoidf(v.w);
+                        } else if (act_ == FIERY_ACT_SWISH) {
+                            v.x *= sigmoidf(v.x);  v.y *= sigmoidf(v.y);  v.z *= sigmoidf(v.z);  v.w *= sigmoidf(v.w);
+                        }
+                        if (kRes != 0 && kRes != 1 && !res_first) { v.x += r.x;  v.y += r.y;  v.z += r.z;  v.w += r.w; }
+                        store4(r_out, o_out, v);
+                    } else if (gates) {
+                        float4 g = make_float4(sigmoid_gate(v.x), sigmoid_gate(v.y), sigmoid_gate(v.z), sigmoid_gate(v.w));
+                        if (upper) {                                                                // (1 - reset) * state
+                            const float4 h = cur_a;
+                            g.x = (1.0f - g.x) * h.x;  g.y = (1.0f - g.y) * h.y;  g.z = (1.0f - g.z) * h.z;  g.w = (1.0f - g.w) * h.w;
+                            store4(r_out2, o_out2, g);
+                        } else {
+                            store4(r_out, o_out, g);                                                // update gate
+                        }
+                    } else {                                                                        // FIERY_EPI_GRU_OUT
+                        const float4 u = cur_a, h = cur_b;
+                        float4 hn;
+                        { const float a = (1.0f - u.x) * h.x, b = u.x * fmaxf(v.x, 0.f); hn.x = a + b; }
+                        { const float a = (1.0f - u.y) * h.y, b = u.y * fmaxf(v.y, 0.f); hn.y = a + b; }
+                        { const float a = (1.0f - u.z) * h.z, b = u.z * fmaxf(v.z, 0.f); hn.z = a + b; }
+                        { const float a = (1.0f - u.w) * h.w, b = u.w * fmaxf(v.w, 0.f); hn.w = a + b; }
+                        store4(r_out, o_out, hn);
+                        if (has_d1) store4(r_out2, o_out2, hn);
                     }
-                    if (!res_pre_rows) { v.x += r.x;  v.y += r.y;  v.z += r.z;  v.w += r.w; }
-                    store4(r_out, o_out, v);
-                } else if (gates) {
-                    float4 g = make_float4(sigmoid_gate(v.x), sigmoid_gate(v.y), sigmoid_gate(v.z), sigmoid_gate(v.w));
-                    if (upper) {                                                                // (1 - reset) * state
-                        const float4 h = cur_a;
-                        g.x = (1.0f - g.x) * h.x;  g.y = (1.0f - g.y) * h.y;  g.z = (1.0f - g.z) * h.z;  g.w = (1.0f - g.w) * h.w;
-                        store4(r_out2, o_out2, g);
-                    } else {
-                        store4(r_out, o_out, g);                                                // update gate
-                    }
-                } else {                                                                        // FIERY_EPI_GRU_OUT
-                    const float4 u = cur_a, h = cur_b;
-                    float4 hn;
-                    { const float a = (1.0f - u.x) * h.x, b = u.x * fmaxf(v.x, 0.f); hn.x = a + b; }
-                    { const float a = (1.0f - u.y) * h.y, b = u.y * fmaxf(v.y, 0.f); hn.y = a + b; }
-                    { const float a = (1.0f - u.z) * h.z, b = u.z * fmaxf(v.z, 0.f); hn.z = a + b; }
-                    { const float a = (1.0f - u.w) * h.w, b = u.w * fmaxf(v.w, 0.f); hn.w = a + b; }
-                    store4(r_out, o_out, hn);
-                    if (has_d1) store4(r_out2, o_out2, hn);
+                    cur_a = nxt_a;  cur_b = nxt_b;  cur_bias = nxt_bias;
+                    gp = gp_n;
+                    o_out += s_out;  o_out2 += s_out2;  o_a += s_a;  o_b += s_b;
                 }
-                cur_a = nxt_a;  cur_b = nxt_b;  cur_bias = nxt_bias;
-                gp = gp_n;
-                o_out += s_out;  o_out2 += s_out2;  o_a += s_a;  o_b += s_b;
+            };
+            using std::integral_constant;
+            constexpr integral_constant<int, -1> any{};
+            constexpr integral_constant<int, 0> c0{};
+            constexpr integral_constant<int, 1> c1{};
+            constexpr integral_constant<int, 2> c2{};
+            const bool no_bias = !(with_bias && p.img_bias);
+            if (no_bias && p.epi == FIERY_EPI_PLAIN && act == FIERY_ACT_RELU) {
+                constexpr integral_constant<int, FIERY_EPI_PLAIN> e{};
+                constexpr integral_constant<int, FIERY_ACT_RELU> a{};
+                if (!p.res.ptr) rows(e, a, c0, c0);
+                else if (res_pre_rows) rows(e, a, c1, c0);
+                else rows(e, a, c2, c0);
+            } else if (no_bias && p.epi == FIERY_EPI_PLAIN && act == FIERY_ACT_NONE && !p.res.ptr) {
+                rows(integral_constant<int, FIERY_EPI_PLAIN>{}, integral_constant<int, FIERY_ACT_NONE>{}, c0, c0);
+            } else if (no_bias && p.epi == FIERY_EPI_GRU_GATES) {
+                rows(integral_constant<int, FIERY_EPI_GRU_GATES>{}, any, c0, c0);
+            } else if (no_bias && p.epi == FIERY_EPI_GRU_OUT) {
+                rows(integral_constant<int, FIERY_EPI_GRU_OUT>{}, any, c0, c0);
+            } else {
+                rows(any, any, any, any);
             }
             return;
         }
@@ -1409,6 +1470,13 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
 
     if (rows16) {
         // (the loop's last barrier has passed: the stages are free)
+        float4 fetched[2];
+        {
+            const int co = tile_n * BN + (tid % (BN >> 2)) * 4;
+            const bool live = co < p.cout_pad;
+            fetched[0] = live ? *reinterpret_cast<const float4*>(p.scale + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+            fetched[1] = live ? *reinterpret_cast<const float4*>(p.shift + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         stage_tile(acc[0], 0, 0, BN);
         if constexpr (NT == 2) stage_tile(acc[1], 0, 1, BN);
         if constexpr (MT >= 2) {
@@ -1420,7 +1488,10 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
             stage_tile(acc[3 * NT], 3, 0, BN);
         }
         __syncthreads();
-        store_rows(BN, tile_n * BN, p.scale, p.shift, p.act, true);
+        if constexpr (CLK) {
+            if (clk_trace) clk_trace[6] = wall_clock64();                  // tile staged, every wavefront through the barrier
+        }
+        store_rows(BN, tile_n * BN, p.scale, p.shift, p.act, true, fetched);
         clk_finish();
         return;
     }

@@ -24,7 +24,7 @@ for k, stride, cin, cout, n, H, W in CASES:
     for _ in range(3):
         op([x], out)
     torch.cuda.synchronize()
-    for persistent in ('0', '1'):
+    for persistent in os.environ.get('TRACE_PERSISTENT', '0,1').split(','):
         os.environ['FIERY_CONV_PERSISTENT'] = persistent
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
@@ -60,6 +60,9 @@ for k, stride, cin, cout, n, H, W in CASES:
               f'{len(us)} tiles on {len(np.unique(place))} CUs', flush=True)
         print(f'    entry {q(us[:, 0])} | set-up {q(us[:, 1] - us[:, 0])} | K loop {q(us[:, 2] - us[:, 1])} | epilogue {q(us[:, 3] - us[:, 2])} | '
               f'end {q(us[:, 3])}   (us: min / p10 / median / p90 / max)', flush=True)
+        if (t[:, 6] > 0).all():                                  # (epilogue stamps: staged + barrier, scale / shift arrived)
+            e6, e7 = (t[:, 6] - t0) / 100.0, (t[:, 7] - t0) / 100.0
+            print(f'    epilogue parts: stage + barrier {q(e6 - us[:, 2])} | scale / shift arrive {q(e7 - e6)} | rows {q(us[:, 3] - e7)}', flush=True)
         per_cu = np.array([np.sum(place == c) for c in np.unique(place)])
         busy = np.array([(us[place == c, 3].max() - us[place == c, 0].min()) for c in np.unique(place)])
         print(f'    tiles per CU {per_cu.min()}..{per_cu.max()} (mean {per_cu.mean():.2f}); a CU is busy {q(busy)} us; '
