@@ -55,7 +55,10 @@ def pmc_traffic(kernels):
                                     capture_output=True, text=True, timeout=10).stdout.strip() or None
         except (OSError, subprocess.SubprocessError):
             commit = None
+        # (a GPU box's snapshot has no .git: the summary itself names the commit its passes ran at)
+        commit = commit or table.get('_measured_at_commit')
         return {'bytes_per_launch': sum(per_kernel.values()), 'per_kernel': per_kernel, 'file': 'profiles/' + name, 'commit': commit,
+                'measured_at_commit': table.get('_measured_at_commit'),
                 'what': '2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes over this command (not collected in this run)'}
     return None
 
