@@ -66,10 +66,19 @@ struct Geometry {
     int cout_pad, bn, n_tiles, k_chunks, n_units;
 };
 
+// cout tile width of a layer: the widest of 128 / 64 / 32 that divides its padded couts.  (FIERY_CONV_BN128_AS_64=1, an
+// experiment switch read by packing and launch alike: exactly-128-cout layers as two 64-wide tiles - 3,750 tiles of 64 x 64 on
+// 1,024 slots instead of 1,875 of 64 x 128 on 768 for a 120,000-pixel map.)
+int conv_bn(int cout_pad) {
+    static const bool narrow128 = getenv("FIERY_CONV_BN128_AS_64") != nullptr;
+    if (cout_pad == 128 && narrow128) return 64;
+    return (cout_pad % 128 == 0) ? 128 : (cout_pad % 64 == 0) ? 64 : 32;
+}
+
 Geometry conv_geometry(int cout, int cin_units, int taps) {
     Geometry g;
     g.cout_pad = (cout + 31) / 32 * 32;
-    g.bn = (g.cout_pad % 128 == 0) ? 128 : (g.cout_pad % 64 == 0) ? 64 : 32;
+    g.bn = conv_bn(g.cout_pad);
     g.n_tiles = g.cout_pad / g.bn;
     g.n_units = cin_units * taps;
     g.k_chunks = (g.n_units + 3) / 4;
@@ -329,7 +338,8 @@ int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, bool launch) {
         p.aux1.ptr = const_cast<float*>(d->shift3);
         p.out2 = TensP{d->out3.ptr, d->out3.ld, d->out3.img_stride};
     }
-    const int bn = (d->cout_pad % 128 == 0) ? 128 : (d->cout_pad % 64 == 0) ? 64 : 32;
+    const int bn = conv_bn(d->cout_pad);
+    FIERY_REQUIRE(d->epi != FIERY_EPI_HEADS || bn == 128, "conv_fwd: the heads epilogue needs 128-wide cout tiles");
     const int n_tiles = d->cout_pad / bn;
     // Tile height: workgroups run in rounds of (256 CUs x resident workgroups per CU); the default picks the height
     // whose last round is better filled.  How a partly filled round really behaves depends on the launch (a lone
