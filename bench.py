@@ -248,12 +248,15 @@ def main():
         with torch.no_grad():
             eager_step()                                   # also tunes this mode's launches, outside the brackets
             torch.cuda.synchronize()
-            eager_step()                                   # backlog: the GPU must not wait for the host during the next one
             # five instrumented steps (same kernels, launched one by one so each can be bracketed): the figures below come from
             # the step whose convolution time is the median, the pooling op's from the median over the five (one step's
-            # bracket of a 275 us op moves by +-5 us from run to run)
+            # bracket of a 275 us op moves by +-5 us from run to run).  Each is enqueued BEHIND an unrecorded step: the GPU must
+            # not wait for the host inside a bracket, and pooling is the first thing a step launches - behind a synchronise its
+            # bracket would hold the host's time to issue the two kernels (~15 us; until round 4 four of the five did).
             instrumented = []
             for _ in range(5):
+                ops.PROFILE_SINK = None
+                eager_step()                               # backlog (10 ms of GPU work; the host issues a step faster than that)
                 ops.PROFILE_SINK = []
                 eager_step()
                 torch.cuda.synchronize()
