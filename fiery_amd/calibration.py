@@ -78,6 +78,12 @@ class CalibrationTable:
                 fresh.append(i)
         if not fresh:
             return 0
+        room = self.slots // 2 - len(self.known)
+        if len(fresh) > room:                                       # (no host work for entries that cannot be filed)
+            self.stats['rejected'] += len(fresh) - max(room, 0)
+            fresh = fresh[:max(room, 0)]
+            if not fresh:
+                return 0
         try:
             values = host_camera_matrices(K[fresh], E[fresh]).numpy().view(np.uint32)
             usable = [True] * len(fresh)
@@ -116,6 +122,8 @@ class CalibrationTable:
 
     def absorb_miss_lists(self):
         """Entries for the calibrations earlier lookups missed, from whatever miss list has landed in pinned memory."""
+        if len(self.known) >= self.slots // 2:                      # full (calibrations that never repeat, e.g. a randomised
+            return 0                                                # K): everything new stays on the device form, at no host cost
         landed = self.landed.numpy().view(np.uint32)
         launch, count = int(landed[2]), int(landed[0])
         if launch == self.seen_launch or launch != int(landed[-1]):   # nothing new, or a copy in flight

@@ -109,6 +109,23 @@ def test_full_table_and_singular_matrices_stay_on_the_device_form(sim):
     assert fresh.prime(torch.cat([K[:2], singular]), torch.cat([E[:2], E[:1]])) == 2 and fresh.stats['rejected'] == 1
 
 
+def test_a_full_table_costs_the_host_nothing(sim, monkeypatch):
+    """Calibrations that never repeat (a randomised K per sample) fill the table once; from then on every miss is served by
+    the device form and the host neither inverts nor uploads anything."""
+    from fiery_amd import model as model_module
+    K, E = _skewed(40, 12)
+    table = CalibrationTable(sim, 'cpu', slots=64)
+    table.prime(K[:32], E[:32])
+    assert len(table.known) == 32
+    calls = []
+    monkeypatch.setattr(model_module, 'host_camera_matrices', lambda *a: calls.append(1))
+    for _ in range(3):
+        cam = table.lookup(K, E)                                     # eight misses every time
+    assert not calls and table.stats['from_miss_lists'] == 0
+    assert torch.equal(cam[32:], sim.camera_matrices(K[32:].contiguous(), E[32:].contiguous()))
+    assert table.prime(K[32:], E[32:]) == 0 and not calls
+
+
 def test_pinhole_rigs_get_the_same_matrices_from_table_and_closed_form(sim):
     _, K, E, _ = make_inputs(1, 3, 6, with_image=False)
     K, E = K.reshape(-1, 3, 3), E.reshape(-1, 4, 4)
