@@ -504,14 +504,14 @@ class Fiery(nn.Module):
                     future_distribution_inputs=future_distribution_inputs, noise=noise, depth_logits=depth_logits,
                     features=features)
         eng = self.engine()
-        key = (self._engine_generation, self.sample_streams) + tuple(
+        key = (self._engine_generation, self.sample_streams, self.camera_matrix_mode, self.warp_transform_mode) + tuple(
             (k,) if v is None else (k, v.data_ptr(), tuple(v.shape), tuple(v.stride()), v.dtype) for k, v in args.items())
         entry = self._graphs.get(key)
         if self.camera_matrix_mode == 'table':
             if entry is None:
                 self.prime_calibrations(intrinsics, extrinsics)    # (capturing synchronises anyway)
             else:
-                self._calibrations.absorb_miss_lists()             # what earlier replays missed: no wait
+                self.calibration_table().absorb_miss_lists()       # what earlier replays missed: no wait
         if entry is None:
             self.bev_forward(**args)                  # eager once: engine buffers and workspaces get allocated
             torch.cuda.synchronize()
@@ -532,14 +532,14 @@ class Fiery(nn.Module):
         args = dict(image=image, intrinsics=intrinsics, extrinsics=extrinsics, future_egomotion=future_egomotion,
                     future_distribution_inputs=future_distribution_inputs, noise=noise)
         eng = self.engine()
-        key = ('images', self._engine_generation, self.sample_streams, self.hip_trunk) + tuple(
+        key = ('images', self._engine_generation, self.sample_streams, self.hip_trunk, self.camera_matrix_mode, self.warp_transform_mode) + tuple(
             (k,) if v is None else (k, v.data_ptr(), tuple(v.shape), tuple(v.stride()), v.dtype) for k, v in args.items())
         entry = self._graphs.get(key)
         if self.camera_matrix_mode == 'table':
             if entry is None:
                 self.prime_calibrations(intrinsics, extrinsics)
             else:
-                self._calibrations.absorb_miss_lists()
+                self.calibration_table().absorb_miss_lists()
         if entry is None:
             with torch.no_grad():
                 self.forward(**args)                  # eager once: plans, buffers, workspaces, tile choices
