@@ -238,7 +238,8 @@ def main():
     # HIP events around every launch of the dominant kernel on the stream it is launched on
     roofline = pooling = None
     host_ms = None
-    if rank == 0:
+    # (rank 0's figures; in the frames layout every step holds a collective, so there all ranks walk through the same steps)
+    if rank == 0 or (frames_layout and use_dist and world > 1):
         torch.cuda.synchronize()
         t_host = time.perf_counter()
         with torch.no_grad():
@@ -285,7 +286,7 @@ def main():
                 pool.append((s_.elapsed_time(e_) * 1e-3, nbytes))
                 kept_frac = n_kept / d['points']
         dump = os.environ.get('FIERY_BENCH_DUMP')
-        if dump:                                           # per-launch table for kernel tuning
+        if dump and rank == 0:                                           # per-launch table for kernel tuning
             rows = [dict(kind=k, us=round(s.elapsed_time(e) * 1e3, 2), work=w, detail=d if k == 'conv_igemm' else None)
                     for k, s, e, w, d in recs]
             json.dump(rows, open(dump, 'w'))
