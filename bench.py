@@ -446,7 +446,9 @@ def main():
                 cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(args.steps), '--warmup', str(args.warmup), '--batch', str(B),
                        '--no-cpu-baseline', '--no-from-images', '--no-bf16-mode', '--no-secondary-configs'] + extra
                 try:
-                    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                    # (without FIERY_BENCH_DUMP: the per-launch table belongs to the headline step, not to the last secondary run)
+                    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+                                         env={k: v for k, v in os.environ.items() if k != 'FIERY_BENCH_DUMP'})
                     sub = json.loads(res.stdout.strip().splitlines()[-1])
                     line['secondary_configs'][key] = {k: sub.get(k) for k in ('metric', 'value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline',
                                                                              'roofline_pooling', 'host_enqueue_ms_per_step')}
