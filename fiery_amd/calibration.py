@@ -60,7 +60,14 @@ class CalibrationTable:
         pin = self.device.type == 'cuda'
         self.landed = torch.zeros(n_miss, dtype=torch.int32, pin_memory=pin)
         self.seen_launch = 0
-        self.stats = dict(entries=0, primed=0, from_miss_lists=0, rejected=0, miss_lists=0)
+        # keys a miss list has shown ONCE (bounded; see absorb_miss_lists): a key is filed when it comes back
+        self.candidates = set()
+        self.max_candidates = 4 * slots
+        # changed rows travel through a pinned staging buffer, `upload_rows` rows at a time, without blocking the host
+        self.upload_rows = 256
+        self.staging = torch.zeros(self.upload_rows * ENTRY_WORDS, dtype=torch.int32, pin_memory=pin)
+        self.staging_event = None
+        self.stats = dict(entries=0, primed=0, from_miss_lists=0, rejected=0, miss_lists=0, seen_once=0)
 
     # -- host side --------------------------------------------------------------------------------------
     def prime(self, intrinsics, extrinsics):
@@ -97,6 +104,7 @@ class CalibrationTable:
                     usable.append(False)                          # (the reference raises on it too)
         hashes = hash_words(words[fresh])
         added = 0
+        changed = []
         for j, i in enumerate(fresh):
             slot = self._free_slot(int(hashes[j])) if usable[j] else -1
             if slot < 0 or len(self.known) >= self.slots // 2:
@@ -106,12 +114,33 @@ class CalibrationTable:
             self.host[slot, 1:1 + KEY_WORDS] = words[i]
             self.host[slot, 1 + KEY_WORDS:1 + KEY_WORDS + 12] = values[j]
             self.known[words[i].tobytes()] = slot
+            changed.append(slot)
             added += 1
         if added:
-            # the whole table (slots x 144 B): ordered on the current stream in front of the next lookup
-            self.table.copy_(torch.from_numpy(self.host.view(np.int32).reshape(-1)), non_blocking=False)
+            self._upload(sorted(changed))
             self.stats['entries'] = len(self.known)
         return added
+
+    def _upload(self, slots):
+        """The changed rows only (144 B each), ordered on the current stream in front of the next lookup.  On the GPU they
+        go through the pinned staging buffer with a non-blocking copy per run of consecutive slots; the host waits only if
+        the previous batch of rows has not left the staging buffer yet."""
+        table = self.table.view(self.slots, ENTRY_WORDS)
+        host = self.host.view(np.int32)
+        if self.device.type != 'cuda':
+            idx = torch.as_tensor(slots, dtype=torch.long)
+            table[idx] = torch.from_numpy(host[slots])
+            return
+        staging = self.staging.view(self.upload_rows, ENTRY_WORDS)
+        for lo in range(0, len(slots), self.upload_rows):
+            part = slots[lo:lo + self.upload_rows]
+            if self.staging_event is not None:
+                self.staging_event.synchronize()                    # (the previous batch has long left: set-up time, or a step ago)
+            staging[:len(part)] = torch.from_numpy(host[part])
+            idx = torch.as_tensor(part, dtype=torch.long).pin_memory().to(self.device, non_blocking=True)
+            table.index_copy_(0, idx, staging[:len(part)].to(self.device, non_blocking=True))
+            self.staging_event = torch.cuda.Event()
+            self.staging_event.record()
 
     def _free_slot(self, h):
         for probe in range(PROBES):
@@ -139,7 +168,26 @@ class CalibrationTable:
         E[:, :3, :] = torch.from_numpy(f[:, 9:21].reshape(count, 3, 4).copy())
         E[:, 3, 3] = 1.0
         self.stats['miss_lists'] += 1
-        added = self.prime(K, E)
+        # A calibration is filed when a miss list shows it for the SECOND time: what repeats is a rig's calibration; the
+        # reference's loader (fiery/data.py:172-209) builds sensor_to_lidar from each sample's own ego poses, so its
+        # extrinsics never repeat - filing those would cost host LAPACK + an upload per step and fill the table with
+        # one-off keys (and make a step's output depend on the calls before it).  One-off keys stay on the device form.
+        again = []
+        for i in range(count):
+            kb = rows[i].tobytes()
+            if kb in self.known:
+                continue
+            if kb in self.candidates:
+                self.candidates.discard(kb)
+                again.append(i)
+            else:
+                if len(self.candidates) >= self.max_candidates:
+                    self.candidates.clear()                         # bounded memory; a repeating key comes back soon enough
+                self.candidates.add(kb)
+                self.stats['seen_once'] += 1
+        if not again:
+            return 0
+        added = self.prime(K[again], E[again])
         self.stats['from_miss_lists'] += added
         return added
 

@@ -164,16 +164,18 @@ class Fiery(nn.Module):
                                       predict_future_flow=cfg.INSTANCE_FLOW.ENABLED)
         set_bn_momentum(self, cfg.MODEL.BN_MOMENTUM)
 
-        # 'table' (default since round 4): R.K^-1 computed on the host by the reference's own CPU operators ONCE per distinct
-        # calibration, filed under the calibration's bit pattern and looked up on the device every step
-        # (`fiery_amd/calibration.py`): bit-exact indices for any K, no read-back, graph-capturable.  A calibration the table
-        # has not seen is served by the 'device' form until its miss list has landed on the host (`prime_calibrations`
-        # files a rig's calibrations up front; capturing a graph primes from its arguments).
-        # 'device': K^-1 and R.K^-1 on the GPU (closed form for zero-skew pinhole intrinsics: bit-equal to LAPACK on
-        # every calibration of that form tried but 1 ulp off on ~0.005 % of random ones; adjugate otherwise).
+        # 'device' (default): K^-1 and R.K^-1 on the GPU (closed form for zero-skew pinhole intrinsics: bit-equal to LAPACK
+        # on every calibration of that form tried but 1 ulp off on ~0.005 % of random ones; adjugate otherwise).  The same
+        # input always gives the same output, whatever was called before.
+        # 'table' (opt-in; was the default in round 4): R.K^-1 computed on the host by the reference's own CPU operators ONCE
+        # per distinct calibration, filed under the calibration's bit pattern and looked up on the device every step
+        # (`fiery_amd/calibration.py`): bit-exact indices for any K, no read-back, graph-capturable - for rigs whose
+        # (K, [R | t]) pairs REPEAT (a fixed rig in the ego frame).  The reference's nuScenes loader builds the extrinsics
+        # from each sample's own ego poses (fiery/data.py:172-209), so there they never repeat: the table then serves the
+        # device form (it files a key only when it has missed twice, or through `prime_calibrations`).
         # 'host': `host_camera_matrices` every call, then the device product: bit-exact for any K at the price of a
         # device-to-host read of the calibration per call (not graph-capturable).
-        self.camera_matrix_mode = os.environ.get('FIERY_CAMERA_MATRICES', 'table')
+        self.camera_matrix_mode = os.environ.get('FIERY_CAMERA_MATRICES', 'device')
         self._calibrations = None
         # 'device': the pose algebra of the ego-warp in `fiery_warp_params` (cos / sin / atan2 rounded once from double
         # precision: equal to the CPU libraries' values for ~95 % of arguments, one ulp off otherwise).

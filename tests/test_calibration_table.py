@@ -76,10 +76,34 @@ def test_a_missed_calibration_is_served_by_the_device_form_then_exactly(sim):
     assert landed[0] == 5 and landed[1] == 5
     rows = landed[calibration.MISS_HEADER:calibration.MISS_HEADER + 5 * calibration.MISS_WORDS].reshape(5, -1)
     assert sorted(rows[:, calibration.KEY_WORDS].tolist()) == [4, 5, 6, 7, 8]
-    second = table.lookup(K, E)                                      # absorbs the list that landed, then looks up
-    assert np.array_equal(second.numpy(), want)
+    second = table.lookup(K, E)                                      # first sighting of the five: candidates, not entries
+    assert torch.equal(second, first) and table.stats['seen_once'] == 5 and table.stats['entries'] == 4
+    third = table.lookup(K, E)                                       # they came back: filed from the list that landed
+    assert np.array_equal(third.numpy(), want)
     assert table.stats['from_miss_lists'] == 5 and table.stats['entries'] == 9
     assert table.landed.numpy()[0] == 0
+
+
+def test_calibrations_that_never_repeat_are_never_filed(sim, monkeypatch):
+    """The reference's loader builds the extrinsics from each sample's own ego poses (fiery/data.py:172-209): every step
+    brings new (K, [R | t]) pairs.  The table must not spend host LAPACK or uploads on them, must not fill up with one-off
+    keys, and the output for a given input must not depend on the calls before it."""
+    table = CalibrationTable(sim, 'cpu', slots=64)
+    calls = []
+    import fiery_amd.model as fm
+    real = fm.host_camera_matrices
+    monkeypatch.setattr(fm, 'host_camera_matrices', lambda *a: (calls.append(1), real(*a))[1])
+    for step in range(12):
+        K, E = _skewed(6, 100 + step)
+        cam = table.lookup(K, E)
+        assert torch.equal(cam, sim.camera_matrices(K, E))
+    assert not calls and table.stats['entries'] == 0 and table.stats['from_miss_lists'] == 0
+    assert len(table.candidates) <= table.max_candidates
+    # a rig that DOES repeat is still filed, after the one-off keys, and served exactly
+    K, E = _skewed(6, 7)
+    for _ in range(3):
+        cam = table.lookup(K, E)
+    assert np.array_equal(cam.numpy(), _oracle(K, E)) and table.stats['entries'] == 6
 
 
 def test_miss_list_overflow_and_duplicates(sim):
@@ -90,7 +114,7 @@ def test_miss_list_overflow_and_duplicates(sim):
     table = CalibrationTable(sim, 'cpu', miss_capacity=8)
     table.lookup(K, E)
     assert table.landed.numpy()[0] == 8 and table.landed.numpy()[1] == 24
-    for _ in range(4):
+    for _ in range(6):
         cam = table.lookup(K, E)
     assert np.array_equal(cam.numpy(), _oracle(K, E)) and table.stats['entries'] == 6
 
@@ -134,13 +158,15 @@ def test_pinhole_rigs_get_the_same_matrices_from_table_and_closed_form(sim):
     assert torch.equal(table.lookup(K, E), sim.camera_matrices(K, E))
 
 
-def test_model_default_mode_serves_get_geometry_exactly(sim):
-    """`Fiery.get_geometry` in the default mode: primed rigs exact; `prime_calibrations` is the set-up call."""
+def test_model_table_mode_serves_get_geometry_exactly(sim):
+    """`Fiery.get_geometry` in the 'table' mode: primed rigs exact; `prime_calibrations` is the set-up call.  The default is
+    'device' (the same input gives the same output whatever was called before)."""
     from tests.helpers import tiny_cfg
     cfg = tiny_cfg('baseline.yml', bev=8)
     model = Fiery(cfg).eval()
     model._lib = sim
-    assert model.camera_matrix_mode == 'table'
+    assert model.camera_matrix_mode == 'device'
+    model.camera_matrix_mode = 'table'
     K, E = _skewed(2, 6)
     K, E = K.view(1, 2, 3, 3), E.view(1, 2, 4, 4)
     assert model.prime_calibrations(K, E) == 2
@@ -156,7 +182,7 @@ def test_model_default_mode_serves_get_geometry_exactly(sim):
 # ----------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 def test_lookup_inside_a_captured_graph_is_bit_exact_for_skewed_intrinsics(hip):
-    """The default mode under a hipGraph: replays are bit-exact for every primed calibration written into the captured
+    """The 'table' mode under a hipGraph: replays are bit-exact for every primed calibration written into the captured
     buffers; a calibration the table has never seen is served by the device form for the replays until its miss list has
     landed (here: one synchronise), then exactly - with no read-back on the replay path."""
     dev = torch.device('cuda:0')
@@ -182,15 +208,19 @@ def test_lookup_inside_a_captured_graph_is_bit_exact_for_skewed_intrinsics(hip):
     torch.cuda.synchronize()
     assert torch.equal(cam, hip.camera_matrices(Kd, Ed))             # the device form, and a miss list on the host
     assert table.landed[0].item() == 54 and table.landed[1].item() == 54
-    assert table.absorb_miss_lists() == 54
+    assert table.absorb_miss_lists() == 0 and table.stats['seen_once'] == 54    # first sighting: candidates only
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(cam, hip.camera_matrices(Kd, Ed))
+    assert table.absorb_miss_lists() == 54                                      # they came back: filed
     graph.replay()
     torch.cuda.synchronize()
     assert np.array_equal(cam.cpu().numpy(), _oracle(K3, E3))
 
 
 @pytest.mark.gpu
-def test_bev_forward_graph_default_mode_equals_host_mode_for_skewed_intrinsics(hip):
-    """`bev_forward_graph` in the default mode against the eager pass with `camera_matrix_mode = 'host'` (the reference's
+def test_bev_forward_graph_table_mode_equals_host_mode_for_skewed_intrinsics(hip):
+    """`bev_forward_graph` in the 'table' mode against the eager pass with `camera_matrix_mode = 'host'` (the reference's
     operators every call): same voxel ranks, same outputs - deterministic pooling, so bit for bit."""
     from fiery_amd.config import get_preset_cfg
     from fiery_amd.synthetic import make_lifted_features
@@ -214,7 +244,7 @@ def test_bev_forward_graph_default_mode_equals_host_mode_for_skewed_intrinsics(h
     lifted = lifted.view(1, rf, n, 64, model.depth_channels, fh, fw).to(dev)
     noise = torch.zeros(1, 1, model.latent_dim, device=dev)
     Kd, Ed, egod = K.to(dev), E.to(dev), ego.to(dev)
-    assert model.camera_matrix_mode == 'table'
+    model.camera_matrix_mode = 'table'
     with torch.no_grad():
         got = {k: v.clone() for k, v in model.bev_forward_graph(lifted, Kd, Ed, egod, None, noise).items() if v is not None}
         got = {k: v.clone() for k, v in model.bev_forward_graph(lifted, Kd, Ed, egod, None, noise).items() if v is not None}

@@ -68,14 +68,14 @@ def test_geometry_and_indices_bit_exact_full_size(hip, name, preset, n_cam, jitt
 
 @pytest.mark.parametrize('mode', ['host', 'table'])
 def test_host_camera_matrices_bit_exact_for_skewed_intrinsics(hip, mode):
-    """`camera_matrix_mode = 'host'` (the reference's operators every call) and the default `'table'` (the same matrices filed
+    """`camera_matrix_mode = 'host'` (the reference's operators every call) and `'table'` (the same matrices filed
     once per calibration, looked up on the device; tests/test_calibration_table.py replays it inside a hipGraph): geometry and
     voxel ranks equal the oracle's (LAPACK inverse, as the reference's CPU path) bit for bit for intrinsics the device closed
     form does not cover - full-size baseline grid, 6 cameras."""
     cfg = get_preset_cfg('baseline.yml')
     grid, (res, start, dim) = _grid_of(cfg)
     model, _ = _model(cfg)
-    assert model.camera_matrix_mode == 'table'
+    assert model.camera_matrix_mode == 'device'
     model.camera_matrix_mode = mode
     _, K, E, _ = make_inputs(1, 1, 6, with_image=False)
     gen = torch.Generator().manual_seed(9)
