@@ -94,11 +94,29 @@ def parse():
     return ap.parse_args()
 
 
+def parity_rows(got, want):
+    """Per output: the max-abs error over ALL samples and per sample, the literal 1e-4 bar and the scaled bar of the tests."""
+    rows = {}
+    for k, v in want.items():
+        if v is None:
+            continue
+        err = (got[k] - v).abs()
+        per_sample = err.reshape(err.shape[0], -1).max(dim=1).values
+        worst, ref_max = per_sample.max().item(), v.abs().max().item()
+        rows[k] = {'max_abs_err': float(f'{worst:.3e}'), 'max_abs_err_per_sample': [float(f'{e:.3e}') for e in per_sample.tolist()],
+                   'ref_abs_max': round(ref_max, 3),
+                   'within_1e-4': bool(worst <= 1e-4),                                  # (the fp32 configuration's literal bar)
+                   'within_scaled': bool(worst <= 1e-4 * max(1.0, ref_max)),          # (the bar tests/test_gpu_parity.py asserts)
+                   # the literal bar element by element: how many of the output's values pass it
+                   'elements_within_1e-4': int((err <= 1e-4).sum().item()), 'elements': v.numel()}
+    return rows
+
+
 def cpu_baseline(cfg, sd, lifted, K, E, ego, runs=3):
     """The oracle (a port of the reference's CPU path on the same ATen CPU kernels) on the host cores, on a bounded sample of
     the same workload: one batch element (median of `runs` after a warm-up) and, once, the whole batch of the headline
-    configuration (BASELINE.md's north-star row is quoted at that batch).  Returns the baseline dict and the first sample's
-    outputs (the parity check of the GPU result rides on them)."""
+    configuration (BASELINE.md's north-star row is quoted at that batch).  Returns the baseline dict and the WHOLE batch's
+    outputs (the parity check of the GPU result rides on them: every sample, not the first)."""
     from oracle import bev_stack
     cores = len(os.sched_getaffinity(0))
     try:                                               # a cgroup CPU quota caps the usable cores below the affinity mask
@@ -119,7 +137,7 @@ def cpu_baseline(cfg, sd, lifted, K, E, ego, runs=3):
             out = bev_stack.bev_hot_path(sd_cpu, cfg, *one)
             times.append(time.perf_counter() - t0)
         t0 = time.perf_counter()
-        bev_stack.bev_hot_path(sd_cpu, cfg, *whole)
+        out = bev_stack.bev_hot_path(sd_cpu, cfg, *whole)       # (its outputs: every sample of the batch, for the parity check)
         t_batch = time.perf_counter() - t0
     dt = sorted(times)[len(times) // 2]
     n_batch = whole[0].shape[0]
@@ -388,19 +406,21 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'], want = cpu_baseline(cfg, sd, lifted, K, E, ego)
             line['speedup_vs_cpu_baseline'] = round(line['value'] / line['cpu_baseline']['value'], 1)
-            # parity of this run: sample 0 of the GPU step against the oracle's outputs for the same sample - achieved
-            # max-abs error per output, next to the literal 1e-4 of the north star and the scale the relative bound uses
+            # parity of this run: EVERY sample of the GPU step against the oracle's outputs for the same batch - achieved
+            # max-abs error per output over the whole batch, with both bars side by side: the literal 1e-4 of the north star
+            # (`within_1e-4`) and the scaled bound the parity tests assert, 1e-4 * max(1, |ref|_inf) (`within_scaled`)
             with torch.no_grad():
-                got = {k: (None if v is None else v[:1].float().cpu()) for k, v in step().items()}
-            line['parity'] = {k: {'max_abs_err': float(f'{(got[k] - v).abs().max().item():.3e}'),
-                                  'ref_abs_max': round(v.abs().max().item(), 3),
-                                  'within_1e-4': bool((got[k] - v).abs().max().item() <= 1e-4),     # (the fp32 configuration's bar)
-                                  # the literal bar element by element: how many of the output's values pass it
-                                  'elements_within_1e-4': int(((got[k] - v).abs() <= 1e-4).sum().item()), 'elements': v.numel()}
-                              for k, v in want.items() if v is not None}
+                got = {k: (None if v is None else v.float().cpu()) for k, v in step().items()}
+            line['parity'] = parity_rows(got, want)
             line['parity_literal_1e-4'] = {'outputs_passing': sum(1 for r in line['parity'].values() if r['within_1e-4']),
                                            'outputs': len(line['parity']),
-                                           'what': 'sample 0 of this run against the oracle, max-abs <= 1e-4 with no scaling'}
+                                           'outputs_passing_scaled': sum(1 for r in line['parity'].values() if r['within_scaled']),
+                                           'samples_compared': int(next(v for v in want.values() if v is not None).shape[0]),
+                                           'what': f'all {B} samples of this run against the oracle (whole batch on the host cores); '
+                                                   'literal: max-abs <= 1e-4; scaled: max-abs <= 1e-4 * max(1, |ref|_inf)'}
+            # BASELINE.md's own probe of the unmodified reference on CPU (this configuration, other host): context for `cpu_baseline`
+            line['cpu_baseline']['baseline_md_reference_probe'] = {'value': 0.369, 'unit': 'samples/s', 'cores': 8, 'batch': 3,
+                                                                   'what': 'BASELINE.md: the reference itself, batch 3, 8 cores of the survey container'}
         # secondary figure (BASELINE.json configs[3] / [4] are bf16 configurations): the same step with bf16 matrix-core
         # operands, timed the same way after everything above - beside the headline, never as `value`; its outputs are
         # compared with the fp32 step's of this run (the accuracy side of that mode: DESIGN.md section 4)

@@ -710,8 +710,10 @@ class BevEngine:
         o_logits, o_feats = out if out is not None else (None, None)
         return (planar(0, D, o_logits) if D else None), planar(D, C, o_feats)
 
-    def _pool_workspace(self, f, n, d, h, w, device):
-        key = ('poolws', f, n, d, h, w, self.pool_tile, self.pool_flags)
+    def _pool_workspace(self, f, n, d, h, w, device, form='compact'):
+        # (one workspace per FORM: the fused lift-splat lays its tile lists out with a different plan than the compact
+        # pooling, and POOL_WORKSPACE_CLEAN is a promise about the plan that used the workspace last)
+        key = ('poolws', form, f, n, d, h, w, self.pool_tile, self.pool_flags)
         ws = self._bufs.get(key)
         if ws is None:
             # zero-filled once and then only ever handed to the library's pooling calls, each of which leaves it clean: they
@@ -720,11 +722,11 @@ class BevEngine:
                                                            zeroed=True)
         return ws
 
-    def _pool_call(self, key_dims, fn):
+    def _pool_call(self, key_dims, fn, form='compact'):
         try:
             return fn()
         except Exception:
-            self._bufs.pop(('poolws',) + key_dims + (self.pool_tile, self.pool_flags), None)
+            self._bufs.pop(('poolws', form) + key_dims + (self.pool_tile, self.pool_flags), None)
             raise
 
     def pool(self, x, geometry, out=None):
@@ -751,10 +753,10 @@ class BevEngine:
             res = ops.LiftSplat.apply(depth_logits, features, geometry, self)
             return res if out is None else out.copy_(res)
         prob = self.lib.depth_softmax(depth_logits.reshape(f * n, d, h, w).contiguous())
-        ws = self._pool_workspace(f, n, d, h, w, features.device)
+        ws = self._pool_workspace(f, n, d, h, w, features.device, form='fused')
         return self._pool_call((f, n, d, h, w), lambda: self.lib.lift_splat(
             prob, features.contiguous(), geometry.contiguous(), f, n, d, h, w, c, self.grid, out=out, workspace=ws,
-            tile_voxels=self.pool_tile, flags=self.pool_flags | self._pool_clean_flag))
+            tile_voxels=self.pool_tile, flags=self.pool_flags | self._pool_clean_flag), form='fused')
 
     def _run_distribution(self, ops, srcs, tag, mu=None, log_sigma=None):
         lib = self.lib

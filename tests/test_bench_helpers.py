@@ -35,3 +35,20 @@ def test_default_arguments_are_the_contract(monkeypatch):
     args = bench.parse()
     assert args.gpus == 1 and args.steps == 10 and args.warmup == 3 and args.batch == 3 and args.config == 'baseline.yml'
     assert args.precision == 'f32' and args.layout == 'batch'
+
+
+def test_parity_rows_compare_every_sample_and_print_both_bars():
+    """The driver line's parity block: the max over ALL samples (round 4's compared sample 0 only), with the literal 1e-4 bar and
+    the scaled bar side by side - an output can pass the second and miss the first, and the line must say so."""
+    import torch
+    bench = _bench()
+    want = {'segmentation': torch.zeros(3, 2, 4, 4), 'flow': 8.0 * torch.ones(3, 2, 4, 4), 'absent': None}
+    got = {'segmentation': want['segmentation'].clone(), 'flow': want['flow'].clone(), 'absent': None}
+    got['segmentation'][2, 0, 1, 1] = 1.06e-4            # only the LAST sample misses the literal bar
+    got['flow'][1, 1, 0, 0] += 3e-4                      # inside 1e-4 * |ref|_inf = 8e-4, outside the literal bar
+    rows = bench.parity_rows(got, want)
+    assert set(rows) == {'segmentation', 'flow'}
+    seg, flow = rows['segmentation'], rows['flow']
+    assert not seg['within_1e-4'] and not seg['within_scaled'] and seg['max_abs_err_per_sample'][:2] == [0.0, 0.0]
+    assert seg['elements_within_1e-4'] == seg['elements'] - 1
+    assert not flow['within_1e-4'] and flow['within_scaled'] and flow['ref_abs_max'] == 8.0
