@@ -152,11 +152,14 @@ __device__ __forceinline__ int fast_div(int g, unsigned m, int s) {
 // plus 16 bytes that keep ds_read_b128 conflict-free: 20 / 36 floats)
 constexpr int HALO_RUN_EXTRA = 3;
 constexpr int halo_pitch(bool bf16) { return bf16 ? 20 : 36; }
-constexpr int conv_smem_floats(int bm, int bn, bool bf16, bool halo = false) {
+// (chained tails, round 5: each wavefront has an exchange tile of its own - 32 pixel rows of 64 couts, 68 floats apart - in
+// which accumulators in the lane-per-pixel layout become full rows and back; no staging tile)
+constexpr int CHAIN_PITCH = 68;
+constexpr int conv_smem_floats(int bm, int bn, bool bf16, bool halo = false, bool chain = false) {
     const int full = 2 * bm * BK + 2 * BK * bn;
-    if (!halo && (!bf16 || (bm == 128 && bn == 32))) return full;
+    if (!halo && !bf16) return full;
     const int stages = halo ? 3 * (bm + HALO_RUN_EXTRA) * halo_pitch(bf16) : full / 2;
-    const int epilogue = bm * bn + (bm == 64 && bn == 128 ? 256 : 0);       // staging tile (+ the decoder heads' 1x1 rows)
+    const int epilogue = chain ? 4 * 32 * CHAIN_PITCH : bm * bn + (bm == 64 && bn == 128 ? 256 : 0);       // staging tile (+ the decoder heads' 1x1 rows)
     return stages > epilogue ? stages : epilogue;
 }
 #ifndef FIERY_HALO_F32_WAVES
@@ -165,8 +168,8 @@ constexpr int conv_smem_floats(int bm, int bn, bool bf16, bool halo = false) {
 #ifndef FIERY_BF16_WAVES
 #define FIERY_BF16_WAVES 4        // waves per SIMD the bf16 form's register allocation is held to (128 registers)
 #endif
-constexpr int conv_waves_per_simd(int bm, int bn, bool aligned = false, bool bf16 = false, bool halo = false) {
-    const int by_lds = 163840 / (conv_smem_floats(bm, bn, bf16, halo) * 4);
+constexpr int conv_waves_per_simd(int bm, int bn, bool aligned = false, bool bf16 = false, bool halo = false, bool chain = false) {
+    const int by_lds = 163840 / (conv_smem_floats(bm, bn, bf16, halo, chain) * 4);
     int cap = ((bm == 64 && bn == 64) || (FIERY_TAIL_FOUR_PER_CU && bm == 128 && bn == 32 && aligned)) ? 4 : 3;
     if (bf16 && !(bm == 128 && bn == 32)) cap = FIERY_BF16_WAVES;         // (128 x 32: its chained epilogue needs 150)
     if (halo && !bf16) cap = FIERY_HALO_F32_WAVES;
@@ -186,8 +189,9 @@ constexpr int conv_waves_per_simd(int bm, int bn, bool aligned = false, bool bf1
 // exact and accumulate in fp32.  Scalar-addressed loop only.
 // One output tile (pixel tile `bid_x` of `nblk_x` in dispatch order, cout tile blockIdx.y); the kernel below walks a
 // workgroup through its tiles.
-template <int BM, int BN, bool CLK, int PRIO, bool SMALLCIN, bool ALIGNED, bool BF16, bool HALO>
+template <int BM, int BN, bool CLK, int PRIO, bool SMALLCIN, bool ALIGNED, bool BF16, bool HALO, bool CHAIN>
 __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const int nblk_x) {
+    static_assert(!CHAIN || (BM == 128 && BN == 32 && !HALO), "the chained tails run on the 128 x 32 tile");
     static_assert(!BF16 || (ALIGNED && !SMALLCIN && !CLK), "the bf16 form exists for the scalar-addressed loop");
     static_assert(!HALO || (ALIGNED && !SMALLCIN && !CLK && BN >= 64 && (BM == 64 || BF16)), "the halo loop: 64-pixel tiles (bf16: 128 too), 64 couts or more");
     unsigned long long clk_entry = 0;
@@ -218,22 +222,27 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
     constexpr int WM = 4 / WN;             // wavefronts along pixels
     constexpr int MT = BM / (32 * WM);     // 32-pixel MFMA tiles per wavefront   (BN=32: 1, else 2)
     constexpr int NT = BN / (32 * WN);     // 32-cout MFMA tiles per wavefront    (BN=128: 2, else 1)
+    // PIXLANE (the chained tails' kernel - CHAIN - on the 128 x 32 tile, round 5): the MFMAs take the WEIGHTS as their A operand and the pixels as B, so the
+    // accumulator block is the tile TRANSPOSED - lane l holds pixel l & 31 of its wavefront's 32, register r holds cout
+    // c(r, hi) = 8 (r / 4) + 4 hi + r % 4.  That is (a) the operand layout of a following 32-k MFMA step (lane = pixel, lane
+    // half = k), so the Bottleneck tails' chained 1 x 1 products read their input straight from the accumulator registers -
+    // no LDS round trip, no barrier, wavefronts finish on their own - and (b) four consecutive couts in four consecutive
+    // registers, so a lane finishes 16-byte pieces of its own pixel row without a staging tile (tools/probe/
+    // chained_gemm_swapped.hip, profiles/r5_chained_gemm_swapped_gpu.txt: the layout algebra on real MFMA lanes).
+    constexpr bool PIXLANE = CHAIN;
     constexpr int W_BYTES = BF16 ? 2 : 4;                      // bytes per packed weight
     constexpr int BLOADS = BF16 ? (BN >= 64 ? BN / 64 : 1) : (BK * BN / 4) / 256;      // 16-byte W loads per thread and stage
 
     // one LDS block: two A stages, two W stages; the epilogue reuses it as a BM x BN staging tile.  The bf16 form's stages
-    // are half the size (both operands are bf16 there), so its block is as large as the epilogue needs and no larger - the
-    // 128 x 32 tile excepted, whose chained epilogue lays fp32 operand tiles over the stages.
-    constexpr bool HALF_STAGES = BF16 && !(BM == 128 && BN == 32) && !HALO;
+    // are half the size (both operands are bf16 there), so its block is as large as the epilogue needs and no larger.
+    constexpr bool HALF_STAGES = BF16 && !HALO;
     constexpr int A_STAGE = HALF_STAGES ? BM * (BK / 2) : BM * BK;        // floats between the two A stages
     constexpr int W_STAGE = HALF_STAGES ? BK * BN / 2 : BK * BN;
     constexpr int W_BASE = 2 * A_STAGE;
-    constexpr int SMEM_FLOATS = conv_smem_floats(BM, BN, BF16, HALO);
+    constexpr int SMEM_FLOATS = conv_smem_floats(BM, BN, BF16, HALO, CHAIN);
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
-    float (*As)[BM * BK] = reinterpret_cast<float (*)[BM * BK]>(smem);                       // (chained epilogue: fp32 stages)
-    float (*Bs)[BK * BN] = reinterpret_cast<float (*)[BK * BN]>(smem + 2 * BM * BK);
-    static_assert((HALO || W_BASE + 2 * W_STAGE <= SMEM_FLOATS) && BM * BN + (BM == 64 && BN == 128 ? 256 : 0) <= SMEM_FLOATS,
-                  "stages, staging tile and the heads' 1x1 rows must fit");
+    static_assert((HALO || W_BASE + 2 * W_STAGE <= SMEM_FLOATS) && (CHAIN ? 4 * 32 * CHAIN_PITCH : BM * BN + (BM == 64 && BN == 128 ? 256 : 0)) <= SMEM_FLOATS,
+                  "stages, staging tile (chained tails: the wavefronts' exchange tiles) and the heads' 1x1 rows must fit");
 
     // (taken afresh for every tile of the persistent loop: hoisted out of it, everything derived from the thread index -
     // a few dozen registers that the set-up needs and the K loop does not - would stay live across the whole tile)
@@ -519,6 +528,8 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
         else *reinterpret_cast<float4*>(&smem[a_st + 32 * j * BK + buf * A_STAGE]) = v;
     };
     auto store_b = [&](int buf, int k) {
+        // (bf16, BN = 32: a stage's weights are 2 KiB - the upper half of the threads fetched nothing and has no slot)
+        if (BF16 && BN == 32 && tid >= 128) return;
         *reinterpret_cast<float4*>(&smem[b_st + 1024 * k + buf * W_STAGE]) = k == 0 ? breg0 : k == 1 ? breg1 : k == 2 ? breg2 : breg3;
     };
     auto lds_a = [&](int buf, int q, int t) {
@@ -803,7 +814,8 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int t = 0; t < MT; ++t) {
-                        acc[t * NT + nt] = mfma_bf16_32x32x16(a8[t], b8[nt], acc[t * NT + nt]);
+                        if constexpr (PIXLANE) acc[t * NT + nt] = mfma_bf16_32x32x16(b8[nt], a8[t], acc[t * NT + nt]);
+                        else acc[t * NT + nt] = mfma_bf16_32x32x16(a8[t], b8[nt], acc[t * NT + nt]);
                         const int s = (kh * NT + nt) * MT + t;
 #pragma unroll
                         for (int i = 0; i < N_PIECES; ++i)
@@ -840,7 +852,8 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
 #pragma unroll
                     for (int t = 0; t < MT; ++t) {
                         const float av = j == 0 ? a_cur[t].x : j == 1 ? a_cur[t].y : j == 2 ? a_cur[t].z : a_cur[t].w;
-                        acc[t * NT + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t * NT + nt], 0, 0, 0);
+                        if constexpr (PIXLANE) acc[t * NT + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, acc[t * NT + nt], 0, 0, 0);
+                        else acc[t * NT + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t * NT + nt], 0, 0, 0);
                         // MFMA slot s of the stage is followed by the side-work pieces dealt to it (spread evenly)
                         const int s = ((q * 4 + j) * NT + nt) * MT + t;
 #pragma unroll
@@ -1139,268 +1152,178 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
     };
     const bool rows16 = (p.vec_epilogue & 1) != 0;
 
-    // ---- optional chained 1x1 convolution on the tile (Bottleneck up-projection) -----------------------------
-    if constexpr (BN == 32 && BM == 128) {
-        if (p.w2) {
-            // (0) the second GEMM's weights are requested first: their latency passes under (1)
-            const float4 w2_lo = reinterpret_cast<const float4*>(p.w2)[tid];
-            const float4 w2_hi = reinterpret_cast<const float4*>(p.w2)[tid + 256];
-            // (1) h = act(acc*scale + shift) back into LDS as the A operand of a second GEMM: [pixel][32 k], same
-            //     slot swizzle as the main loop.  Every wave passed the loop's last barrier, so stage 0 is free.
-            {
-                const int co = m;                                   // tile_n == 0, wn == 0 for BN = 32
-                const float sc = p.scale[co], sh = p.shift[co];
+    // ---- Bottleneck tail (CHAIN kernels): 3 x 3 -> BN + act -> 1 x 1 (32 -> 64) -> BN + act + residual [-> 1 x 1 (64 -> 32) -> BN + act]
+    // (layers/convolutions.py:110-168 of the reference).  Lane = pixel, registers = couts (PIXLANE above): the chained products
+    // take their input straight from the accumulator registers, and a wavefront finishes its own 32 pixels without meeting the
+    // other three - no workgroup barrier after the K loop.  Global rows are still moved as FULL rows (a lane's own 16-byte
+    // pieces of its pixel row would be 32-byte fragments of 32 different cache lines per instruction - measured 16 % slower
+    // than the staged rows, profiles/r5_tail_ab.txt): the accumulators pass through an exchange tile in LDS that belongs to
+    // the wavefront alone, ordered by `wave_sync` (the LDS runs one wavefront's instructions in order).
+    if constexpr (PIXLANE) {
+        auto comp = [](const float4& f, int j) { return j == 0 ? f.x : j == 1 ? f.y : j == 2 ? f.z : f.w; };
+        auto activate = [](float v, int act) {
+            if (act == FIERY_ACT_RELU) return fmaxf(v, 0.f);
+            if (act == FIERY_ACT_SIGMOID) return sigmoidf(v);
+            if (act == FIERY_ACT_SWISH) return v * sigmoidf(v);
+            return v;
+        };
+        auto ld4 = [&](const float* q, bool vec) {                   // four consecutive floats; 16-byte access when allowed
+            if (vec) return *reinterpret_cast<const float4*>(q);
+            return make_float4(q[0], q[1], q[2], q[3]);
+        };
+        // the second product's weights are requested first - the packed image [k / 4][cout][k % 4] IS the order the accumulator
+        // registers hold their couts in: k = c(4 g + j, hi) sits at piece 2 g + hi, element j
+        float4 w2r[8];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int pl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    float v = fmaf(acc[0][r], sc, sh);
-                    if (p.act == FIERY_ACT_RELU) v = fmaxf(v, 0.f);
-                    else if (p.act == FIERY_ACT_SIGMOID) v = sigmoidf(v);
-                    As[0][pl * BK + (((co >> 2) ^ ((pl >> 1) & 7)) << 2) + (co & 3)] = v;
-                }
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) w2r[g * 2 + nt] = reinterpret_cast<const float4*>(p.w2)[(2 * g + hi) * 64 + nt * 32 + m];
+        const int wpix0 = pix0 + wm * 32;                            // this wavefront's 32 pixels
+        // where a pixel's row starts in a tensor (floats from its base): dense tensors - images back to back - need one multiply
+        const bool dense = (p.vec_epilogue & 2) != 0;
+        auto row_at = [&](const TensP& t, int gp) -> long long {
+            if (dense) return static_cast<long long>(gp) * t.ld;
+            const int o = fast_div(gp, p.mg_hw, p.sh_hw);
+            return o * t.istride + static_cast<long long>(gp - o * HWout) * t.ld;
+        };
+        // row layout of the 64-cout rows: sixteen 16-byte chunks per row, four rows per pass, eight passes
+        const int c16 = lane & 15, r16 = lane >> 4;
+        float4 resid[8];
+        if (rows16) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int gp = wpix0 + 4 * i + r16;
+                resid[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.res.ptr && gp < M && 4 * c16 < p.cout_store) resid[i] = *reinterpret_cast<const float4*>(p.res.ptr + row_at(p.res, gp) + 4 * c16);
             }
-            // (2) the 32 x 64 weight tile, already in its LDS image, into the (now idle) W stages
-            {
-                float* bdst = &Bs[0][0];                            // 2 stages x 32 x 32 floats = 32 x 64
-                *reinterpret_cast<float4*>(bdst + tid * 4) = w2_lo;
-                *reinterpret_cast<float4*>(bdst + (tid + 256) * 4) = w2_hi;
+        }
+        // (1) h = act(acc * scale + shift): register r of this lane half is cout c(r, hi)
+        float h[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 sc = ld4(p.scale + 8 * g + 4 * hi, rows16), sh = ld4(p.shift + 8 * g + 4 * hi, rows16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h[4 * g + j] = activate(fmaf(acc[0][4 * g + j], comp(sc, j), comp(sh, j)), p.act);
+        }
+        // (2) out2[cout2][pixel] += W2[k][cout2] h[pixel][k]: weights as A (row = cout2), h as B (column = pixel) - the result is
+        //     lane = pixel, registers = couts again
+        v16f acc2[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[nt][r] = 0.f;
+        if constexpr (BF16) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bf16x8 hb = pack_bf16x8(make_float4(h[8 * i], h[8 * i + 1], h[8 * i + 2], h[8 * i + 3]),
+                                              make_float4(h[8 * i + 4], h[8 * i + 5], h[8 * i + 6], h[8 * i + 7]));
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc2[nt] = mfma_bf16_32x32x16(pack_bf16x8(w2r[(2 * i) * 2 + nt], w2r[(2 * i + 1) * 2 + nt]), hb, acc2[nt]);
             }
-            __syncthreads();
-            // (3) 128 x 64 = (128 x 32) . (32 x 64): each wavefront 32 pixels x 64 couts
-            v16f acc2[2];
+        } else {
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int r = 0; r < 16; ++r)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
-            const float* b2 = &Bs[0][0];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int pl = wm * 32 + m;
-                const int slot = (2 * q + hi) ^ ((pl >> 1) & 7);
-                const float4 a4 = *reinterpret_cast<const float4*>(&As[0][pl * BK + slot * 4]);
-                const float av2[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const float4 b4 = *reinterpret_cast<const float4*>(&b2[((2 * q + hi) * 64 + nt * 32 + m) * 4]);
-                    const float bv2[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av2[j], bv2[j], acc2[nt], 0, 0, 0);
-                }
-            }
-            // (4) second epilogue: folded BN, activation, residual, store
-            if (rows16 && p.heads.w) {
-                // (4') ... and a THIRD convolution on the finished tile: the next Bottleneck's 1x1 down-projection
-                // (64 -> 32, + BN + ReLU; layers/convolutions.py:110-116 of the following block).  On its own that layer
-                // is a memory-bound launch that re-reads what this kernel has just written; here its input is the tile in
-                // hand.  Operands ride in members the chained mode does not use: heads.w = packed 64 x 32 weights,
-                // aux0.ptr / aux1.ptr = scale3 / shift3 [32], heads.n_out = act3, out2 = destination.
-                // rows of the 128 x 64 tile: 16 chunks of four channels per row, 16 rows per pass, 8 passes per thread.
-                // Their residual rows and the third GEMM's weights are requested NOW, all of them, before the tile is even
-                // staged: one memory round trip for the whole epilogue instead of one per row (destination and residual
-                // are not known to be distinct, so loads written next to their stores stay behind the previous store).
-                const int c4 = tid & 15, prow0 = tid >> 4;
-                const int co = c4 * 4;
-                float4 resid[8];                                    // the residual rows, later the finished rows themselves
-                int out_off[8];                                    // floats from p.out.ptr (< 2^31: host check); < 0: not stored
-                // rows [i0, i1) of this thread: where they go, and their residual on its way.  FIERY_TAIL_FOUR_PER_CU: the
-                // first four rows are requested here, the last four once the accumulators of the second GEMM have left
-                // their registers (the residual rows can then live where those were: 128 registers without spills)
-                // (dense tensors, round 4 - see store_rows: a row's place is gp * ld from the base, one multiply-add in 32 bits, and
-                // residual / destinations go through buffer descriptors)
-                const bool dense = (p.vec_epilogue & 2) != 0;
-                const __amdgpu_buffer_rsrc_t r_res3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res.ptr), 0, (dense && p.res.ptr) ? M * p.res.ld * 4 : 0, 0x00020000);
-                const __amdgpu_buffer_rsrc_t r_out3 = __builtin_amdgcn_make_buffer_rsrc(p.out.ptr, 0, dense ? M * p.out.ld * 4 : 0, 0x00020000);
-                const __amdgpu_buffer_rsrc_t r_nxt3 = __builtin_amdgcn_make_buffer_rsrc(p.out2.ptr, 0, dense ? M * p.out2.ld * 4 : 0, 0x00020000);
-                auto request_rows = [&](int i0, int i1) {
-                    if (dense) {
-#pragma unroll
-                        for (int i = i0; i < i1; ++i) {
-                            const int gp = pix0 + prow0 + 16 * i;
-                            const bool live = gp < M && co < p.cout_store;
-                            out_off[i] = live ? gp * p.out.ld + co : -1;
-                            resid[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (live && p.res.ptr) {
-                                const auto raw = __builtin_amdgcn_raw_buffer_load_b128(r_res3, (gp * p.res.ld + co) * 4, 0, 0);
-                                __builtin_memcpy(&resid[i], &raw, 16);
-                            }
-                        }
-                        return;
-                    }
-                    int gp = pix0 + prow0 + 16 * i0;
-                    int o = fast_div(gp < M ? gp : 0, p.mg_hw, p.sh_hw), ppi = gp - o * HWout;
-#pragma unroll
-                    for (int i = i0; i < i1; ++i) {
-                        const bool live = gp < M && co < p.cout_store;
-                        out_off[i] = live ? static_cast<int>(o * p.out.istride + static_cast<long long>(ppi) * p.out.ld + co) : -1;
-                        resid[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (live && p.res.ptr)
-                            resid[i] = *reinterpret_cast<const float4*>(p.res.ptr + o * p.res.istride + static_cast<long long>(ppi) * p.res.ld + co);
-                        gp += 16;
-                        ppi += 16;
-                        while (ppi >= HWout) {
-                            ppi -= HWout;
-                            ++o;
-                        }
-                    }
-                };
-                constexpr int ROWS_EARLY = FIERY_TAIL_FOUR_PER_CU ? 4 : 8;
-                request_rows(0, ROWS_EARLY);
-                const float4 w3_lo = reinterpret_cast<const float4*>(p.heads.w)[tid];
-                const float4 w3_hi = reinterpret_cast<const float4*>(p.heads.w)[tid + 256];
-                __syncthreads();                                   // everyone is done reading the h and W tiles
+                for (int nt = 0; nt < 2; ++nt)
+                    acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(w2r[(r >> 2) * 2 + nt], r & 3), h[r], acc2[nt], 0, 0, 0);
+        }
+        if (!rows16) {
+            // unaligned destinations: this lane's pixel, channel by channel, straight from the registers (no third stage here)
+            const int gp = wpix0 + m;
+            if (gp < M) {
+                const long long at_out = row_at(p.out, gp), at_res = p.res.ptr ? row_at(p.res, gp) : 0;
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int pl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        smem[pl * 64 + nt * 32 + m] = acc2[nt][r];
+                        const int co = nt * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
+                        if (co >= p.cout_store) continue;
+                        float v = activate(fmaf(acc2[nt][r], p.scale2[co], p.shift2[co]), p.act2);
+                        if (p.res.ptr) v += p.res.ptr[at_res + co];
+                        p.out.ptr[at_out + co] = v;
                     }
-                if constexpr (ROWS_EARLY < 8) request_rows(ROWS_EARLY, 8);
-                __syncthreads();
-                {
-                    const float4 sc2 = *reinterpret_cast<const float4*>(p.scale2 + co);
-                    const float4 sh2 = *reinterpret_cast<const float4*>(p.shift2 + co);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int pl = prow0 + 16 * i;
-                        float4 v = *reinterpret_cast<const float4*>(&smem[pl * 64 + co]);
-                        v.x = fmaf(v.x, sc2.x, sh2.x);  v.y = fmaf(v.y, sc2.y, sh2.y);  v.z = fmaf(v.z, sc2.z, sh2.z);  v.w = fmaf(v.w, sc2.w, sh2.w);
-                        if (p.act2 == FIERY_ACT_RELU) {
-                            v.x = fmaxf(v.x, 0.f);  v.y = fmaxf(v.y, 0.f);  v.z = fmaxf(v.z, 0.f);  v.w = fmaxf(v.w, 0.f);
-                        } else if (p.act2 == FIERY_ACT_SIGMOID) {
-                            v.x = sigmoidf(v.x);  v.y = sigmoidf(v.y);  v.z = sigmoidf(v.z);  v.w = sigmoidf(v.w);
-                        }
-                        if (out_off[i] >= 0) {
-                            v.x += resid[i].x;  v.y += resid[i].y;  v.z += resid[i].z;  v.w += resid[i].w;
-                            if (dense) {
-                                decltype(__builtin_amdgcn_raw_buffer_load_b128(r_out3, 0, 0, 0)) raw;
-                                __builtin_memcpy(&raw, &v, 16);
-                                __builtin_amdgcn_raw_buffer_store_b128(raw, r_out3, out_off[i] * 4, 0, 0);
-                            } else {
-                                *reinterpret_cast<float4*>(p.out.ptr + out_off[i]) = v;
-                            }
-                        } else {
-                            v = make_float4(0.f, 0.f, 0.f, 0.f);
-                        }
-                        resid[i] = v;
-                    }
-                }
-                __syncthreads();                                   // the staged tile has been read by everyone
-                // the finished tile as the A operand of the third GEMM: two K stages of [pixel][32 k], slot-swizzled
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int pl = prow0 + 16 * i;
-                    *reinterpret_cast<float4*>(&As[c4 >> 3][pl * BK + (((c4 & 7) ^ ((pl >> 1) & 7)) << 2)]) = resid[i];
-                }
-                {
-                    float* bdst = &Bs[0][0];                        // 2 stages x 32 x 32 floats = the packed 64 x 32 weights
-                    *reinterpret_cast<float4*>(bdst + tid * 4) = w3_lo;
-                    *reinterpret_cast<float4*>(bdst + (tid + 256) * 4) = w3_hi;
-                }
-                __syncthreads();
-                v16f acc3;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc3[r] = 0.f;
-#pragma unroll
-                for (int st = 0; st < 2; ++st)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int pl = wm * 32 + m;
-                        const int slot = (2 * q + hi) ^ ((pl >> 1) & 7);
-                        const float4 a4 = *reinterpret_cast<const float4*>(&As[st][pl * BK + slot * 4]);
-                        const float4 b4 = *reinterpret_cast<const float4*>(&Bs[st][((2 * q + hi) * 32 + m) * 4]);
-                        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc3, 0, 0, 0);
-                        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc3, 0, 0, 0);
-                        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc3, 0, 0, 0);
-                        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc3, 0, 0, 0);
-                    }
-                __syncthreads();                                   // A and W tiles consumed; the staging tile aliases them
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int pl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    smem[pl * 32 + m] = acc3[r];
-                }
-                __syncthreads();
-                {
-                    const int d4 = tid & 7, drow0 = tid >> 3;       // 8 chunks per row of 32, 32 rows per pass, 4 passes
-                    const int dco = d4 * 4;
-                    const float4 sc3 = *reinterpret_cast<const float4*>(p.aux0.ptr + dco);
-                    const float4 sh3 = *reinterpret_cast<const float4*>(p.aux1.ptr + dco);
-                    int gp = pix0 + drow0;
-                    int o = dense ? 0 : fast_div(gp, p.mg_hw, p.sh_hw), ppi = dense ? 0 : gp - o * HWout;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int pl = drow0 + 32 * i;
-                        if (gp < M) {
-                            float4 v = *reinterpret_cast<const float4*>(&smem[pl * 32 + dco]);
-                            v.x = fmaf(v.x, sc3.x, sh3.x);  v.y = fmaf(v.y, sc3.y, sh3.y);  v.z = fmaf(v.z, sc3.z, sh3.z);  v.w = fmaf(v.w, sc3.w, sh3.w);
-                            if (p.heads.n_out == FIERY_ACT_RELU) {
-                                v.x = fmaxf(v.x, 0.f);  v.y = fmaxf(v.y, 0.f);  v.z = fmaxf(v.z, 0.f);  v.w = fmaxf(v.w, 0.f);
-                            }
-                            if (dense) {
-                                decltype(__builtin_amdgcn_raw_buffer_load_b128(r_nxt3, 0, 0, 0)) raw;
-                                __builtin_memcpy(&raw, &v, 16);
-                                __builtin_amdgcn_raw_buffer_store_b128(raw, r_nxt3, (gp * p.out2.ld + dco) * 4, 0, 0);
-                            } else {
-                                const long long pp = ppi;
-                                *reinterpret_cast<float4*>(p.out2.ptr + o * p.out2.istride + pp * p.out2.ld + dco) = v;
-                            }
-                        }
-                        gp += 32;
-                        if (!dense) {
-                            ppi += 32;
-                            while (ppi >= HWout) {
-                                ppi -= HWout;
-                                ++o;
-                            }
-                        }
-                    }
-                }
-                clk_finish();
-                return;
             }
-            if (rows16) {
-                __syncthreads();                                   // everyone is done reading the h and W tiles
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int pl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        smem[pl * 64 + nt * 32 + m] = acc2[nt][r];
-                    }
-                __syncthreads();
-                res_pre_rows = 0;                                  // the chained form adds the residual after the activation
-                store_rows(64, 0, p.scale2, p.shift2, p.act2, false);
-                clk_finish();
-                return;
-            }
-            const int gp_base = pix0 + wm * 32 + 4 * hi;
-            const int o_base = fast_div(gp_base, p.mg_hw, p.sh_hw);
-            const int pp_base = gp_base - o_base * HWout;
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int co = nt * 32 + m;
-                const float sc = p.scale2[co], sh = p.shift2[co];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int off = (r & 3) + 8 * (r >> 2);
-                    if (gp_base + off >= M || co >= p.cout_store) continue;
-                    int o = o_base, ppi = pp_base + off;
-                    while (ppi >= HWout) {
-                        ppi -= HWout;
-                        ++o;
-                    }
-                    const long long pp = ppi;
-                    float v = fmaf(acc2[nt][r], sc, sh);
-                    if (p.act2 == FIERY_ACT_RELU) v = fmaxf(v, 0.f);
-                    else if (p.act2 == FIERY_ACT_SIGMOID) v = sigmoidf(v);
-                    if (p.res.ptr) v += p.res.ptr[o * p.res.istride + pp * p.res.ld + co];
-                    p.out.ptr[o * p.out.istride + pp * p.out.ld + co] = v;
-                }
-            }
+            clk_finish();
             return;
         }
+        // the third product's weights (the NEXT block's 1 x 1 down-projection, 64 -> 32): packed [k / 32][k % 32 / 4][cout][k % 4]
+        const bool third = p.heads.w != nullptr;
+        float4 w3r[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            w3r[i] = third ? reinterpret_cast<const float4*>(p.heads.w)[(i >> 2) * 256 + (2 * (i & 3) + hi) * 32 + m] : make_float4(0.f, 0.f, 0.f, 0.f);
+        // (3) the accumulators through the wavefront's exchange tile into rows: BN + activation + residual (after the
+        //     activation) on full rows - a lane's four channels are the same for all its rows, so scale / shift are two loads
+        float4* const xt = reinterpret_cast<float4*>(smem + wv * (32 * CHAIN_PITCH));       // [32 rows][17 x 16 bytes]
+        constexpr int XP = CHAIN_PITCH / 4;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                xt[m * XP + nt * 8 + 2 * g + hi] = make_float4(acc2[nt][4 * g], acc2[nt][4 * g + 1], acc2[nt][4 * g + 2], acc2[nt][4 * g + 3]);
+        wave_sync();
+        {
+            const int co = 4 * c16;
+            const float4 sc = *reinterpret_cast<const float4*>(p.scale2 + co), sh = *reinterpret_cast<const float4*>(p.shift2 + co);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = 4 * i + r16, gp = wpix0 + row;
+                float4 v = xt[row * XP + c16];
+                v.x = activate(fmaf(v.x, sc.x, sh.x), p.act2) + resid[i].x;
+                v.y = activate(fmaf(v.y, sc.y, sh.y), p.act2) + resid[i].y;
+                v.z = activate(fmaf(v.z, sc.z, sh.z), p.act2) + resid[i].z;
+                v.w = activate(fmaf(v.w, sc.w, sh.w), p.act2) + resid[i].w;
+                const bool keep = gp < M && co < p.cout_store;
+                if (keep) *reinterpret_cast<float4*>(p.out.ptr + row_at(p.out, gp) + co) = v;
+                if (third) xt[row * XP + c16] = keep ? v : make_float4(0.f, 0.f, 0.f, 0.f);     // (rows that do not exist: zeros)
+            }
+        }
+        if (third) {
+            // (4) ... and the next Bottleneck's 1 x 1 down-projection (64 -> 32, + BN + ReLU) on the finished rows.  On its own that
+            //     layer is a memory-bound launch that re-reads what this kernel has just written.  Operands ride in members the
+            //     chained mode does not use: heads.w = packed 64 x 32 weights, aux0.ptr / aux1.ptr = scale3 / shift3 [32],
+            //     heads.n_out = act3, out2 = destination.
+            wave_sync();
+            v16f acc3;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc3[r] = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                float4 y4[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) y4[g] = xt[m * XP + nt * 8 + 2 * g + hi];
+                if constexpr (BF16) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        acc3 = mfma_bf16_32x32x16(pack_bf16x8(w3r[nt * 4 + 2 * i], w3r[nt * 4 + 2 * i + 1]), pack_bf16x8(y4[2 * i], y4[2 * i + 1]), acc3);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(w3r[nt * 4 + (r >> 2)], r & 3), comp(y4[r >> 2], r & 3), acc3, 0, 0, 0);
+                }
+            }
+            wave_sync();                                           // every lane has read its operands: the tile takes the result
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xt[m * XP + 2 * g + hi] = make_float4(acc3[4 * g], acc3[4 * g + 1], acc3[4 * g + 2], acc3[4 * g + 3]);
+            wave_sync();
+            // rows of 32 couts: eight 16-byte chunks per row, eight rows per pass, four passes
+            const int c8 = lane & 7, r8 = lane >> 3;
+            const int dco = 4 * c8;
+            const float4 sc = *reinterpret_cast<const float4*>(p.aux0.ptr + dco), sh = *reinterpret_cast<const float4*>(p.aux1.ptr + dco);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 8 * i + r8, gp = wpix0 + row;
+                float4 v = xt[row * XP + c8];
+                v.x = fmaf(v.x, sc.x, sh.x);  v.y = fmaf(v.y, sc.y, sh.y);  v.z = fmaf(v.z, sc.z, sh.z);  v.w = fmaf(v.w, sc.w, sh.w);
+                if (p.heads.n_out == FIERY_ACT_RELU) {
+                    v.x = fmaxf(v.x, 0.f);  v.y = fmaxf(v.y, 0.f);  v.z = fmaxf(v.z, 0.f);  v.w = fmaxf(v.w, 0.f);
+                }
+                if (gp < M) *reinterpret_cast<float4*>(p.out2.ptr + row_at(p.out2, gp) + dco) = v;
+            }
+        }
+        clk_finish();
+        return;
     }
 
     // ---- decoder heads: the hidden tile stays in LDS, only the heads' final 1x1 outputs are stored -------------
@@ -1573,14 +1496,15 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
 // A workgroup takes the pixel tiles bid, bid + gridDim.x, ... one after another.  By default the grid has one workgroup per
 // tile and the loop runs once; FIERY_CONV_PERSISTENT=1 caps the grid at one workgroup per slot of the chip (round 4's
 // experiment: would workgroups that stay hide each other's epilogue and set-up under their K loops?  see conv_persistent_grid).
-template <int BM, int BN, bool CLK = false, int PRIO = 0, bool SMALLCIN = false, bool ALIGNED = false, bool BF16 = false, bool HALO = false>
-__global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK && !BF16, BF16, HALO)) void k_conv_igemm(ConvP p) {
+template <int BM, int BN, bool CLK = false, int PRIO = 0, bool SMALLCIN = false, bool ALIGNED = false, bool BF16 = false, bool HALO = false,
+          bool CHAIN = false>
+__global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK && !BF16, BF16, HALO, CHAIN)) void k_conv_igemm(ConvP p) {
     const int n_tiles_m = p.tiles_m;
     for (int bid = blockIdx.x; bid < n_tiles_m; bid += gridDim.x) {
         // the argument block is read afresh for every tile (kernel_args_again: an offset the optimiser cannot see through):
         // hoisted out of the loop its hundred scalars stay live across the tile and spill (168 registers + 496 B of scratch);
         // read in place, never copied: the heads' members are indexed at run time and a copy would live in scratch
-        conv_tile<BM, BN, CLK, PRIO, SMALLCIN, ALIGNED, BF16, HALO>(kernel_args_again(p), bid, n_tiles_m);
+        conv_tile<BM, BN, CLK, PRIO, SMALLCIN, ALIGNED, BF16, HALO, CHAIN>(kernel_args_again(p), bid, n_tiles_m);
         if (bid + static_cast<int>(gridDim.x) < n_tiles_m) __syncthreads();      // the next tile's first stage overwrites the staging tile
     }
 }
@@ -1590,26 +1514,33 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
 // workgroups then take several pixel tiles each.  FIERY_CONV_PERSISTENT=0: a workgroup per tile (A/B runs).
 inline dim3 conv_persistent_grid(ConvP& q, dim3 grid, int per_cu) {
     q.tiles_m = static_cast<int>(grid.x);
-    int dev = 0, n_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-        n_cu = 256;
+    // (the switch is read once per process and the launch returns at once when it is off: this runs for every launch)
+    static const bool persistent = [] {
+        const char* e = getenv("FIERY_CONV_PERSISTENT");
+        return e && atoi(e) != 0;
+    }();
+    if (!persistent) return grid;
+    static const int n_cu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
     // Measured (profiles/r4_conv_phases.txt, r4_conv_persistent_ab.txt): NOT faster - 281 against 286 samples/s on baseline.yml;
     // the workgroups of a CU are not in step to begin with (a tile's K loop takes 55-115 us depending on what its neighbours
     // are doing), so there was no idle phase to fill, and a persistent workgroup's set-up meets two running K loops.  Opt-in.
-    const char* e = getenv("FIERY_CONV_PERSISTENT");
-    if (!e || atoi(e) == 0) return grid;
     int cap = (n_cu * per_cu / static_cast<int>(grid.y > 0 ? grid.y : 1)) & ~7;
     if (cap < 8) cap = 8;
     if (static_cast<int>(grid.x) > cap) grid.x = static_cast<unsigned>(cap);
     return grid;
 }
-#define FIERY_CONV_LAUNCH(BM_, BN_, CLK_, PRIO_, SMALL_, ALIGNED_, BF16_, HALO_)                                              \
+#define FIERY_CONV_LAUNCH_C(BM_, BN_, CLK_, PRIO_, SMALL_, ALIGNED_, BF16_, HALO_, CHAIN_)                                    \
     do {                                                                                                                     \
         ConvP q_ = p;                                                                                                        \
-        const dim3 g_ = conv_persistent_grid(q_, grid, conv_waves_per_simd(BM_, BN_, ALIGNED_ && !CLK_ && !BF16_, BF16_, HALO_)); \
-        hipLaunchKernelGGL((k_conv_igemm<BM_, BN_, CLK_, PRIO_, SMALL_, ALIGNED_, BF16_, HALO_>), g_, dim3(256), 0, hs, q_);   \
+        const dim3 g_ = conv_persistent_grid(q_, grid, conv_waves_per_simd(BM_, BN_, ALIGNED_ && !CLK_ && !BF16_, BF16_, HALO_, CHAIN_)); \
+        hipLaunchKernelGGL((k_conv_igemm<BM_, BN_, CLK_, PRIO_, SMALL_, ALIGNED_, BF16_, HALO_, CHAIN_>), g_, dim3(256), 0, hs, q_); \
     } while (0)
+#define FIERY_CONV_LAUNCH(BM_, BN_, CLK_, PRIO_, SMALL_, ALIGNED_, BF16_, HALO_)                                              \
+    FIERY_CONV_LAUNCH_C(BM_, BN_, CLK_, PRIO_, SMALL_, ALIGNED_, BF16_, HALO_, false)
 
 // ---- weight packing ------------------------------------------------------------------------------
 // The variants of tile shape (BM, BN) that exist: generic and scalar-addressed for all five shapes, the small-cin
@@ -1619,6 +1550,12 @@ inline dim3 conv_persistent_grid(ConvP& q, dim3 grid, int per_cu) {
 // minutes each to compile, is spread over two units.
 template <int BM, int BN>
 void conv_launch_tile_bf16(const ConvP& p, dim3 grid, hipStream_t hs) {
+    if constexpr (BM == 128 && BN == 32) {
+        if (p.w2) {                                          // Bottleneck tail: the register-chained kernel
+            FIERY_CONV_LAUNCH_C(BM, BN, false, 0, false, true, true, false, true);
+            return;
+        }
+    }
     FIERY_CONV_LAUNCH(BM, BN, false, 0, false, true, true, false);
 }
 template <int BM, int BN>
@@ -1633,6 +1570,15 @@ void conv_launch_tile_bf16_halo(const ConvP& p, dim3 grid, hipStream_t hs) {
 template <int BM, int BN, unsigned kMask>
 bool conv_launch_tile(const ConvP& p, dim3 grid, hipStream_t hs, int variant, unsigned long long* clk) {
     (void)clk;
+    if constexpr (BM == 128 && BN == 32) {
+        // Bottleneck tails (a chained 1 x 1): the register-chained kernels - every loop variant has one, the probes none
+        if (p.w2) {
+            if (variant == kConvAligned || variant == kConvClockAligned) FIERY_CONV_LAUNCH_C(BM, BN, false, 0, false, true, false, false, true);
+            else if (variant == kConvSmallCin) FIERY_CONV_LAUNCH_C(BM, BN, false, 0, true, false, false, false, true);
+            else FIERY_CONV_LAUNCH_C(BM, BN, false, 0, false, false, false, false, true);
+            return true;
+        }
+    }
     if constexpr ((kMask >> kConvGeneric) & 1u) {
         if (variant == kConvGeneric) {
             FIERY_CONV_LAUNCH(BM, BN, false, 0, false, false, false, false);

@@ -104,6 +104,15 @@ __device__ __forceinline__ unsigned short bf16_bits(float v) {
 __device__ __forceinline__ void pk_pin(v2f& a, v2f& b, v2f& c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c) : : "memory"); }
 
 
+// Wavefront-level rendezvous for data handed from lane to lane through LDS inside ONE wavefront: the LDS executes a
+// wavefront's instructions in order, so no s_barrier is needed - only that the compiler keeps the accesses in program order
+// (fence at wavefront scope) and the wavefront's lanes are treated as having arrived (wave_barrier: no instruction).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // A value the optimiser must take as it finds it at this point (per-lane / wave-uniform): what is derived from it inside a
 // loop body is recomputed there instead of being hoisted out and kept in registers across the body.
 __device__ __forceinline__ void opaque_v(int& v) { asm volatile("" : "+v"(v)); }

@@ -256,10 +256,17 @@ def test_heads_1x1_nchw(sim):
         assert torch.allclose(out[:, o], want, **TOL)
 
 
+@pytest.mark.parametrize('epilogue', ['rows', 'rows, images apart', 'unaligned'])
 @pytest.mark.parametrize('mid,cout,stride', [(32, 64, 1), (20, 40, 2)])
-def test_chained_pointwise_conv_with_residual(sim, mid, cout, stride):
+def test_chained_pointwise_conv_with_residual(sim, monkeypatch, mid, cout, stride, epilogue):
     """3x3 conv + BN + ReLU -> 1x1 conv + BN + ReLU + residual as ONE kernel (the Bottleneck's tail,
-    fiery/layers/convolutions.py:123-168): the intermediate tile stays on chip."""
+    fiery/layers/convolutions.py:123-168): the intermediate values stay on chip (round 5: in the accumulator registers).  The
+    three ways its rows leave: full 16-byte rows of dense tensors, of tensors whose images are apart (per-row image / pixel
+    split), and channel by channel from the registers when the destinations are not 16-byte addressable."""
+    if epilogue == 'unaligned':
+        monkeypatch.setenv('FIERY_CONV_VEC_EPILOGUE', '0')
+    elif epilogue != 'rows':
+        monkeypatch.setenv('FIERY_CONV_DENSE_EPILOGUE', '0')
     g = torch.Generator().manual_seed(mid + cout)
     x = torch.randn(2, mid, 9, 14, generator=g)
     w2 = torch.randn(mid, mid, 3, 3, generator=g) * 0.15
@@ -505,7 +512,8 @@ def test_gru_epilogues_and_chained_tail_on_the_bf16_form(sim, monkeypatch, tile_
     pre = F.conv2d(torch.cat([_bf16(x), _bf16(h)], 1), _bf16(wg), padding=1) + bg.view(1, -1, 1, 1)
     assert torch.allclose(U.to_nchw(), torch.sigmoid(pre[:, :ch]), rtol=2e-5, atol=2e-5)
     assert torch.allclose(RH.to_nchw(), (1 - torch.sigmoid(pre[:, ch:])) * h, rtol=2e-5, atol=2e-5)
-    # Bottleneck tail: 3x3 32 -> 32 (+BN+ReLU) in bf16, chained 1x1 32 -> 64 (+BN+ReLU, + residual) in fp32 on chip
+    # Bottleneck tail: 3x3 32 -> 32 (+BN+ReLU) in bf16, chained 1x1 32 -> 64 (+BN+ReLU, + residual) on chip - since round 5 on
+    # bf16 MFMAs too, its input taken from the accumulator registers and rounded there (fp32 accumulate, fp32 epilogue)
     t1 = torch.randn(1, 32, 8, 10, generator=g)
     w3 = torch.randn(32, 32, 3, 3, generator=g) / (32 * 9) ** 0.5
     w1 = torch.randn(64, 32, 1, 1, generator=g) / 32 ** 0.5
@@ -515,17 +523,16 @@ def test_gru_epilogues_and_chained_tail_on_the_bf16_form(sim, monkeypatch, tile_
     out = Buf.alloc(1, 8, 10, 64, 'cpu')
     tail([_to_buf(t1)], out, res=_to_buf(res))
     mid = F.relu(F.conv2d(_bf16(t1), _bf16(w3), padding=1))
-    want = F.relu(F.conv2d(mid, w1)) + res
+    want = F.relu(F.conv2d(_bf16(mid), _bf16(w1))) + res
     assert torch.allclose(out.to_nchw(), want, rtol=3e-5, atol=3e-5), (out.to_nchw() - want).abs().max()
-    # ... and with the next block's down-projection as a third stage (64 -> 32 on the finished tile, residual included; the chained
-    # GEMMs stay fp32 in the bf16 mode: on bf16 MFMAs they were measured no faster - 664.6 vs 671.7 samples/s, tools/runs/r3_l.sh)
+    # ... and with the next block's down-projection as a third stage (64 -> 32 on the finished values, residual included)
     w4 = torch.randn(32, 64, 1, 1, generator=g) / 8.0
     s4, b4 = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g)
     op3 = tail.chain_next(w4, s4, b4, native.ACT_RELU)
     out3, nxt = Buf.alloc(1, 8, 10, 64, 'cpu'), Buf.alloc(1, 8, 10, 32, 'cpu')
     op3([_to_buf(t1)], out3, res=_to_buf(res), out3=nxt)
     assert torch.allclose(out3.to_nchw(), want, rtol=3e-5, atol=3e-5)
-    t = F.relu(F.conv2d(out3.to_nchw(), w4) * s4.view(1, -1, 1, 1) + b4.view(1, -1, 1, 1))
+    t = F.relu(F.conv2d(_bf16(out3.to_nchw()), _bf16(w4)) * s4.view(1, -1, 1, 1) + b4.view(1, -1, 1, 1))
     assert torch.allclose(nxt.to_nchw()[:, :32], t, rtol=5e-5, atol=5e-5), (nxt.to_nchw()[:, :32] - t).abs().max()
 
 

@@ -355,23 +355,21 @@ def as_close_to_exact_as_fp32_torch(hip, torch32, exact, test='train_step'):
     # train-mode BatchNorm over B x T pooled values - three at B = 1 - whose backward subtracts nearly equal numbers; there two
     # fp32 evaluations differ by percents whatever computes them (MI355X, 104 x 104, B = 1: 1.7e-2 here, 5e-4 for ATen's
     # order of operations, 0 violations at B = 2).  They get 5 %.)
-    # (The factor: the YARDSTICK is not reproducible on the MI355X.  The kernels' own columns of the ledger are the same to every
-    # digit in five runs (median 7.559e-3, worst 1.655e-2), the all-torch fp32 graph's move by 10-20 % from run to run (ATen's
-    # reductions), and a tensor's torch distance with them.  Three times the torch distance held in four full runs of round 4 and
-    # failed in one by a tenth - decoder.layer2.1.bn2.bias at 1.0e-2 against 3 x 2.7e-3 + 1e-3, a draw of the yardstick.  The
-    # ASSERTED factor is therefore ten - still an order of magnitude below what a kernel mistake does to a tensor - and the
-    # count inside three times stays in the ledger, where a drift would show.)
+    # (The factor is THREE, and the yardstick deterministic.  Round 4 widened it to ten after one GPU run in five failed "by a
+    # tenth": the kernels' own columns of the ledger were the same to every digit in five runs (median 7.559e-3, worst
+    # 1.655e-2), but the all-torch fp32 graph evaluated on the GPU moved by 10-20 % from run to run (ATen's GPU reductions) and
+    # a tensor's bound with it.  Since round 5 the GPU test evaluates the yardstick graph on the host with a fixed thread count
+    # - same numbers every run - so the bound no longer needs room for a draw of the yardstick.)
     bound = lambda r, factor: max(factor * r[1] + 1e-3, 5e-2 if 'pyramid_pooling' in r[2] else 0.0)
     past3 = sorted((r for r in rows if r[0] > bound(r, 3)), reverse=True)
-    strict = sorted((r for r in rows if r[0] > bound(r, 10)), reverse=True)
-    parity_report.record(test, f'gradients: {len(rows) - len(past3)} of {len(rows)} tensors within 3x the torch fp32 graph\'s distance to fp64 (+1e-3); asserted: all within 10x',
+    strict = past3
+    parity_report.record(test, f'gradients: {len(rows) - len(past3)} of {len(rows)} tensors within 3x the torch fp32 graph\'s distance to fp64 (+1e-3); asserted: all',
                          past3[0][0] if past3 else 0.0, 1.0, past3[0][0] if past3 else 0.0, past3[0][1] if past3 else 0.0, 0.0,
                          '; '.join(f'{r[2][-40:]} {r[0]:.4f} (torch {r[1]:.4f})' for r in past3[:6]))
     if os.environ.get('FIERY_TEST_VERBOSE'):
         for r in sorted(rows, reverse=True)[:40]:
             print(f'{r[2]:80s} hip {r[0]:9.2e} torch {r[1]:9.2e}')
     assert not strict, strict[:8]
-    assert len(past3) <= max(1, len(rows) // 100), past3[:8]               # (3x: at most one tensor in a hundred may sit past it)
     # The 1 % question, per tensor: where fp32 arithmetic itself allows it - the all-torch fp32 graph is within 0.5 % of the
     # fp64 one - the kernels' gradient is within 1 % (a flipped gate may again take a tenth of the tensors out); the tensors
     # past 1 % are listed with the torch figure beside them, which is what says whether conditioning or a kernel is the cause.
@@ -612,7 +610,15 @@ def test_training_step_on_the_gpu_is_as_close_to_exact_as_fp32_torch(hip):
     inputs = forward_case(cfg, model.receptive_field, model.n_future, model.depth_channels, model.bev_size, 1, 6, with_labels=True,
                           with_noise=True)
     exact = graph_step(cfg, state, hip, _torch_conv, torch.float64, *inputs, device='cuda')
-    torch32 = graph_step(cfg, state, hip, _torch_conv, torch.float32, *inputs, device='cuda')
+    # The yardstick - the all-torch fp32 evaluation of the same graph - runs on the HOST with a fixed thread count (pooling on the
+    # kernels, like the other two): ATen's CPU reductions are deterministic for a given thread count, its GPU reductions are not
+    # (round 4: the same tensor's torch distance moved by 10-20 % from run to run, and with it a bound of 3x that distance).
+    threads = torch.get_num_threads()
+    torch.set_num_threads(8)
+    try:
+        torch32 = graph_step(cfg, state, hip, _torch_conv, torch.float32, *inputs, device='cpu', pool_device='cuda')
+    finally:
+        torch.set_num_threads(threads)
     got = graph_step(cfg, state, hip, None, torch.float32, *inputs, device='cuda')
     assert as_close_to_exact_as_fp32_torch(got, torch32, exact, 'train_step[baseline 104x104 B1]') > 100
 
@@ -839,10 +845,10 @@ def test_trainer_step_from_images_equals_the_reference_trainer_fixture(hip):
         rows.append((np.abs(got - want).max() / max(want[0], 1e-5 * top), name))
     rows.sort(reverse=True)
     parity_report.record('trainer_step_tiny vs reference trainer fixture', f'gradient norm / projection of {len(rows)} tensors, worst ({rows[0][1][-40:]})',
-                         rows[0][0], 1.0, None, None, 1e-2)
+                         rows[0][0], 1.0, None, None, 2e-2)
     # (the worst tensor sat at 5.9e-3, 3.2e-3 and 2.6e-3 in three runs of round 4 on the MI355X - this step, from images at
-    # B = 2, has atomics in the pooling tail and the weight gradients, its summation order is not reproducible - so the asserted
-    # bound is 2 %, twice the 1 % the ledger row is written against)
+    # B = 2, has atomics in the pooling tail and the weight gradients, its summation order is not reproducible - so the bound,
+    # asserted and in the ledger row alike, is 2 %)
     assert len(rows) > 300 and rows[0][0] < 2e-2, rows[:6]
 
 
