@@ -25,6 +25,7 @@ SOURCES = [
     ('conv_tile_bf16_a.hip', []),
     ('conv_tile_bf16_b.hip', []),
     ('conv_tile_halo_f32.hip', []),
+    ('conv_tile_stream_k.hip', []),
     ('aux_ops.hip', []),
     ('conv_grad.hip', []),
     ('bn_train.hip', []),

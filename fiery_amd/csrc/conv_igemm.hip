@@ -178,16 +178,34 @@ bool conv_takes_bf16(const fiery_conv_desc* d, bool aligned, int bm, int bn, int
     if (getenv("FIERY_CONV_CLKPROBE") || getenv("FIERY_CONV_PRIO")) return false;
     return (bm == 128 && (bn == 32 || bn == 64 || bn == 128)) || (bm == 64 && (bn == 64 || bn == 128));
 }
-int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, bool launch);
+struct StreamKPlan {
+    long long workspace_bytes = 0;
+    int n_counters = 0, n_workgroups = 0;
+};
+enum ConvRunMode { kRunLaunch, kRunPrecision, kRunStreamKPlan };
+int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, ConvRunMode mode, StreamKPlan* plan = nullptr);
 }  // namespace
 
-extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) { return conv_run(d, stream, true); }
+extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) { return conv_run(d, stream, kRunLaunch); }
 
-extern "C" int fiery_conv_precision_used(const fiery_conv_desc* d) { return conv_run(d, nullptr, false); }
+extern "C" int fiery_conv_precision_used(const fiery_conv_desc* d) { return conv_run(d, nullptr, kRunPrecision); }
+
+extern "C" int fiery_conv_stream_k_plan(const fiery_conv_desc* d, int64_t* workspace_bytes, int32_t* n_counters, int32_t* n_workgroups) {
+    FIERY_REQUIRE(workspace_bytes && n_counters && n_workgroups, "conv_stream_k_plan: null pointer");
+    StreamKPlan plan;
+    const int rc = conv_run(d, nullptr, kRunStreamKPlan, &plan);
+    if (rc != FIERY_OK) return rc;
+    *workspace_bytes = plan.workspace_bytes;
+    *n_counters = plan.n_counters;
+    *n_workgroups = plan.n_workgroups;
+    return FIERY_OK;
+}
 
 namespace {
-// validates the descriptor, plans the launch; `launch` = false: returns the precision the launch would run in
-int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, bool launch) {
+// validates the descriptor, plans the launch; kRunPrecision: returns the precision the launch would run in; kRunStreamKPlan:
+// fills *plan with what the stream-K form of the launch needs (n_workgroups = 0: not covered)
+int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, ConvRunMode mode, StreamKPlan* plan) {
+    const bool launch = mode == kRunLaunch;
     FIERY_REQUIRE(d, "conv_fwd: null descriptor");
     FIERY_REQUIRE(d->src[0].ptr && d->src[0].units > 0, "conv_fwd: source 0 missing");
     FIERY_REQUIRE(d->src[1].units == 0 || d->src[1].ptr, "conv_fwd: source 1 missing");
@@ -228,6 +246,9 @@ int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, bool launch) {
     }
     const int taps = d->kT * d->kH * d->kW;
     ConvP p;
+    p.sk_tiles = 0;
+    p.sk_ws = nullptr;
+    p.sk_cnt = nullptr;
     for (int s = 0; s < 2; ++s) {
         // bytes from ptr to the end of the last row the launch may read: last batch element, last frame (output frame
         // T_out - 1 reads source frame T_out - 1 + t_in_add at its latest tap), last pixel, the source's channel units.
@@ -384,9 +405,51 @@ int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, bool launch) {
     if (cin_units < 4) variant = kConvSmallCin;       // the loop whose unit advance may carry several times per stage
     else if (clk) variant = aligned ? kConvClockAligned : kConvClock;
     else if (prio) variant = kConvPrio;
-    const int bm = half_tiles ? 64 : 128;
-    const bool bf16 = conv_takes_bf16(d, aligned, bm, bn, cin_units);
+    int bm = half_tiles ? 64 : 128;
+    // Stream-K form (conv_igemm_kernel.h, k_conv_igemm<SK>): fp32, scalar-addressed loop, 128-pixel tiles of 64 or 128 couts, no
+    // chained 1x1, no heads; one round of workgroups - as many as the chip holds - each with at least eight chunks of work
+    StreamKPlan sk;
+    if (variant == kConvAligned && (bn == 64 || bn == 128) && !d->weights2 && d->epi != FIERY_EPI_HEADS &&
+        !(d->precision == FIERY_PRECISION_BF16 && conv_takes_bf16(d, aligned, 128, bn, cin_units))) {
+        static const int n_cu = [] {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+            return n;
+        }();
+        const long long tiles = static_cast<long long>(ceil_div(p.M, 128)) * n_tiles;
+        const long long total = tiles * p.k_chunks;
+        long long nwg = static_cast<long long>(n_cu) * conv_stream_k_per_cu(bn);
+        if (const char* forced = getenv("FIERY_CONV_SK_WGS")) nwg = atoll(forced);                  // tuning / tests
+        if (nwg > total / 8) nwg = total / 8;
+        nwg &= ~7ll;
+        if (nwg >= 8 && tiles < (1ll << 30)) {
+            sk.n_workgroups = static_cast<int>(nwg);
+            sk.n_counters = static_cast<int>(tiles);
+            sk.workspace_bytes = nwg * 2 * 128 * bn * 4;
+        }
+    }
+    if (mode == kRunStreamKPlan) {
+        *plan = sk;
+        return FIERY_OK;
+    }
+    bool stream_k = d->stream_k != 0 && sk.n_workgroups > 0;
+    if (const char* forced = getenv("FIERY_CONV_STREAM_K")) stream_k = sk.n_workgroups > 0 && atoi(forced) != 0 && d->sk_workspace != nullptr;   // tuning / tests
+    if (stream_k) {
+        FIERY_REQUIRE(d->sk_workspace && d->sk_counters && d->sk_workspace_bytes >= sk.workspace_bytes && d->sk_counters_len >= sk.n_counters &&
+                          aligned16(d->sk_workspace),
+                      "conv_fwd: stream-K needs %lld workspace bytes and %d counters (fiery_conv_stream_k_plan)", sk.workspace_bytes, sk.n_counters);
+        bm = 128;
+    }
+    const bool bf16 = !stream_k && conv_takes_bf16(d, aligned, bm, bn, cin_units);
     if (!launch) return bf16 ? FIERY_PRECISION_BF16 : FIERY_PRECISION_F32;
+    if (stream_k) {
+        p.sk_tiles = sk.n_counters;
+        p.sk_ws = static_cast<float*>(d->sk_workspace);
+        p.sk_cnt = d->sk_counters;
+        p.tiles_m = 0;
+        if (!conv_launch_stream_k(p, bn, dim3(sk.n_workgroups), hs)) return fail(FIERY_EINVAL, "conv_fwd: no stream-K kernel for %d-wide cout tiles", bn);
+        return check_launch("conv_fwd (stream-K)");
+    }
     if (bf16) {
         FIERY_REQUIRE(aligned16(d->weights_bf16), "conv_fwd: bf16 weights must be 16-byte aligned");
         p.w = static_cast<const float*>(d->weights_bf16);

@@ -97,6 +97,11 @@ struct ConvP {
     int vec_epilogue;     // bit 0: destinations / residual / bias rows are 16-byte addressable; bit 1: and dense (see store_rows)
     int bias_border;      // img_bias holds nine rows per image, chosen by the output pixel's border class
     HeadsP heads;         // FIERY_EPI_HEADS
+    // stream-K launches (SK kernels): output tiles of the launch (pixel tiles x cout tiles), partial tiles' workspace
+    // (two slots of BM x BN floats per workgroup), one ticket counter per output tile (zero between launches)
+    int sk_tiles;
+    float* sk_ws;
+    int* sk_cnt;
 };
 
 // kernel variants of one tile shape
@@ -118,6 +123,10 @@ bool conv_launch_64x128(const ConvP& p, dim3 grid, hipStream_t stream, int varia
 // bf16 matrix-core form of the scalar-addressed kernel (weights packed by fiery_conv_pack_weights_bf16 in p.w); returns
 // false when (bm, bn) has no such kernel
 bool conv_launch_bf16(const ConvP& p, int bm, int bn, dim3 grid, hipStream_t stream, bool halo = false);
+// stream-K form of the scalar-addressed fp32 kernel on 128-pixel tiles (bn = 64 or 128); returns false when bn has none
+bool conv_launch_stream_k(const ConvP& p, int bn, dim3 grid, hipStream_t stream);
+// workgroups the stream-K kernel of cout tile width bn keeps resident per CU
+int conv_stream_k_per_cu(int bn);
 // fp32 halo loop (3 x 3 / stride 1 layers on 64-pixel tiles; bn = 64 or 128)
 bool conv_launch_f32_halo(const ConvP& p, int bn, dim3 grid, hipStream_t stream);
 
@@ -189,9 +198,13 @@ constexpr int conv_waves_per_simd(int bm, int bn, bool aligned = false, bool bf1
 // exact and accumulate in fp32.  Scalar-addressed loop only.
 // One output tile (pixel tile `bid_x` of `nblk_x` in dispatch order, cout tile blockIdx.y); the kernel below walks a
 // workgroup through its tiles.
-template <int BM, int BN, bool CLK, int PRIO, bool SMALLCIN, bool ALIGNED, bool BF16, bool HALO, bool CHAIN>
-__device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const int nblk_x) {
+// (SK - stream-K, round 5: the workgroup multiplies chunks [sk_kb, sk_ke) of output tile sk_tile; sk_j = its place in the
+// launch's even split of all (tile, chunk) units; see k_conv_igemm)
+template <int BM, int BN, bool CLK, int PRIO, bool SMALLCIN, bool ALIGNED, bool BF16, bool HALO, bool CHAIN, bool SK = false>
+__device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const int nblk_x, const int sk_tile = 0, const int sk_kb = 0,
+                                          const int sk_ke = 0, const int sk_j = 0, const int sk_nwg = 0) {
     static_assert(!CHAIN || (BM == 128 && BN == 32 && !HALO), "the chained tails run on the 128 x 32 tile");
+    static_assert(!SK || (ALIGNED && !BF16 && !HALO && !CHAIN && !CLK && !SMALLCIN), "stream-K: the scalar-addressed fp32 loop");
     static_assert(!BF16 || (ALIGNED && !SMALLCIN && !CLK), "the bf16 form exists for the scalar-addressed loop");
     static_assert(!HALO || (ALIGNED && !SMALLCIN && !CLK && BN >= 64 && (BM == 64 || BF16)), "the halo loop: 64-pixel tiles (bf16: 128 too), 64 couts or more");
     unsigned long long clk_entry = 0;
@@ -249,7 +262,8 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
 #if FIERY_CONV_EPILOGUE_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
-    int tid_ = threadIdx.x, tile_n_ = blockIdx.y;
+    const int sk_ntiles = SK ? p.cout_pad / BN : 1;
+    int tid_ = threadIdx.x, tile_n_ = SK ? sk_tile % sk_ntiles : blockIdx.y;
     opaque_v(tid_);
     opaque_s(tile_n_);
     const int tid = tid_;
@@ -260,7 +274,9 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
     // XCD-aware tile order: workgroup b runs on XCD b % 8, so give every XCD a contiguous run of pixel
     // tiles - neighbouring tiles share their 3x3 halo rows through that XCD's L2 instead of re-fetching them
     int tile_m;
-    {
+    if constexpr (SK) {
+        tile_m = sk_tile / sk_ntiles;                 // (the split itself is XCD-aware: k_conv_igemm)
+    } else {
         const int nblk = nblk_x, bid = bid_x;
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
         tile_m = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -340,6 +356,17 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
     bool s_second = false;
     __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src0_ptr), 0, 0, 0x00020000);
     const int s_groups = c_cin_units >> 2, s_groups0 = src0_units >> 2;
+    if constexpr (SK) {
+        // the pipeline's state is a function of the chunk it starts from: chunk = tap * groups + g, tap = (dt kH + dy) kW + dx
+        ld_stage = sk_kb;
+        s_tap = sk_kb / s_groups;
+        s_g = sk_kb - s_tap * s_groups;
+        const int khw = c_kH * c_kW;
+        s_dt = s_tap / khw;
+        const int r = s_tap - s_dt * khw;
+        s_dy = r / c_kW;
+        s_dx = r - s_dy * c_kW;
+    }
     if constexpr (ALIGNED) {
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
@@ -873,14 +900,75 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
         __syncthreads();
     };
     {
+        const int n_chunks = SK ? sk_ke - sk_kb : c_k_chunks;
         int chunk = 0;
-        for (; chunk + 1 < c_k_chunks; chunk += 2) {
+        for (; chunk + 1 < n_chunks; chunk += 2) {
             stage_body(std::integral_constant<int, 0>{});
             stage_body(std::integral_constant<int, 1>{});
         }
-        if (chunk < c_k_chunks) stage_body(std::integral_constant<int, 0>{});
+        if (chunk < n_chunks) stage_body(std::integral_constant<int, 0>{});
     }
     }      // !HALO
+    if constexpr (SK) {
+        // ---- stream-K: a tile whose chunks are shared between workgroups ----------------------------------------------------
+        // Every holder of a part writes its accumulators to its workspace slot - in accumulator order, 16 bytes per lane and
+        // piece, so the stores are unit-stride and nothing is staged - and takes a ticket on the tile's counter; the LAST arrival
+        // reads all parts back IN PART ORDER (its own too: the sum must not depend on who came last), and runs the epilogue on
+        // the sum.  The parts may sit on different XCDs, whose L2s are not coherent with each other: partial stores and loads
+        // carry sc0 sc1 (system scope: written through / fetched past the L2s; tools/probe/xcd_partials_probe.hip measured
+        // them at the plain accesses' speed, where agent-scope fences cost 4x - profiles/r5_xcd_partials_probe.txt), and the
+        // ticket is a memory-side atomic.
+        if (!(sk_kb == 0 && sk_ke == c_k_chunks)) {
+            const long long total = static_cast<long long>(p.sk_tiles) * c_k_chunks;
+            const int nwg = sk_nwg;
+            auto owner = [&](long long u) { return static_cast<int>(((u + 1) * nwg - 1) / total); };       // the workgroup holding unit u
+            const long long t0 = static_cast<long long>(sk_tile) * c_k_chunks;
+            const int j0 = owner(t0), j1 = owner(t0 + c_k_chunks - 1);
+            // a workgroup holds at most two partial tiles: its first (slot 0) and its last (slot 1)
+            auto slot_of = [&](int j) {
+                const long long b = static_cast<long long>(j) * total / nwg;
+                return 2 * j + (static_cast<int>(b / c_k_chunks) == sk_tile ? 0 : 1);
+            };
+            auto part_rsrc = [&](int j) {
+                return __builtin_amdgcn_make_buffer_rsrc(p.sk_ws + static_cast<long long>(slot_of(j)) * (BM * BN), 0, BM * BN * 4, 0x00020000);
+            };
+            {
+                const __amdgpu_buffer_rsrc_t mine = part_rsrc(sk_j);
+#pragma unroll
+                for (int i = 0; i < MT * NT; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 v = make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
+                        decltype(__builtin_amdgcn_raw_buffer_load_b128(mine, 0, 0, 0)) raw;
+                        __builtin_memcpy(&raw, &v, 16);
+                        __builtin_amdgcn_raw_buffer_store_b128(raw, mine, ((i * 4 + g) * 256 + tid) * 16, 0, 17);      // sc0 | sc1
+                    }
+            }
+            vmem_done();                                              // this wavefront's stores are out before the barrier lets the ticket go
+            __syncthreads();
+            int* const flag = reinterpret_cast<int*>(smem);           // (the stages are free: the loop's last barrier has passed)
+            if (tid == 0) *flag = atomicAdd(p.sk_cnt + sk_tile, 1);
+            __syncthreads();
+            const int ticket = *flag;
+            __syncthreads();                                          // (read by everyone before the epilogue stages its tile there)
+            if (ticket != j1 - j0) return;                            // not the last arrival: this part is done
+#pragma unroll
+            for (int i = 0; i < MT * NT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            for (int j = j0; j <= j1; ++j) {
+                const __amdgpu_buffer_rsrc_t part = part_rsrc(j);
+#pragma unroll
+                for (int i = 0; i < MT * NT; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 v = to_float4(__builtin_amdgcn_raw_buffer_load_b128(part, ((i * 4 + g) * 256 + tid) * 16, 0, 17));
+                        acc[i][4 * g] += v.x;  acc[i][4 * g + 1] += v.y;  acc[i][4 * g + 2] += v.z;  acc[i][4 * g + 3] += v.w;
+                    }
+            }
+            if (tid == 0) atomicExch(p.sk_cnt + sk_tile, 0);          // ready for the next launch
+        }
+    }
     // The epilogue's vector and memory instructions share the SIMD with the other workgroups' MFMAs and, at equal priority,
     // are served in the gaps those leave: an epilogue of 5 us alone takes 27 us there (profiles/r4_conv_phases.txt), a time
     // during which this wavefront feeds the matrix pipe nothing.  Raised priority gets it through and back to MFMAs.
@@ -1497,8 +1585,37 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
 // tile and the loop runs once; FIERY_CONV_PERSISTENT=1 caps the grid at one workgroup per slot of the chip (round 4's
 // experiment: would workgroups that stay hide each other's epilogue and set-up under their K loops?  see conv_persistent_grid).
 template <int BM, int BN, bool CLK = false, int PRIO = 0, bool SMALLCIN = false, bool ALIGNED = false, bool BF16 = false, bool HALO = false,
-          bool CHAIN = false>
+          bool CHAIN = false, bool SK = false>
 __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK && !BF16, BF16, HALO, CHAIN)) void k_conv_igemm(ConvP p) {
+    if constexpr (SK) {
+        // STREAM-K (round 5): the launch's work - every (output tile, K chunk) unit - is dealt out EVENLY to exactly as many
+        // workgroups as the chip holds at once; a workgroup walks its contiguous run of units tile by tile, so a tile's chunks
+        // may be shared by two or more workgroups (conv_tile: partial tiles).  No partly filled last round of workgroups: that
+        // quantisation, not the loop, was what held the big layers at 0.72-0.76 of the matrix peak (938 tiles on 512 slots).
+        // Workgroup b runs on XCD b % 8: the runs are dealt so that each XCD gets a contiguous eighth of the unit space and
+        // neighbouring tiles share their halo rows through that XCD's L2.
+        const int nwg = static_cast<int>(gridDim.x), b = static_cast<int>(blockIdx.x);
+        const int j = (b & 7) * (nwg >> 3) + (b >> 3);
+        long long u0, u1;
+        {
+            const ConvP& q = kernel_args_again(p);
+            const long long total = static_cast<long long>(q.sk_tiles) * q.k_chunks;
+            u0 = j * total / nwg;
+            u1 = (j + 1) * total / nwg;
+        }
+        while (u0 < u1) {
+            const ConvP& q = kernel_args_again(p);
+            const int kc = q.k_chunks;
+            const int tile = static_cast<int>(u0 / kc);
+            const int kb = static_cast<int>(u0 - static_cast<long long>(tile) * kc);
+            const long long left = u1 - u0;
+            const int ke = left < kc - kb ? kb + static_cast<int>(left) : kc;
+            conv_tile<BM, BN, CLK, PRIO, SMALLCIN, ALIGNED, BF16, HALO, CHAIN, true>(q, 0, 0, tile, kb, ke, j, nwg);
+            u0 += ke - kb;
+            if (u0 < u1) __syncthreads();                      // the next tile's first stage overwrites the staging tile
+        }
+        return;
+    }
     const int n_tiles_m = p.tiles_m;
     for (int bid = blockIdx.x; bid < n_tiles_m; bid += gridDim.x) {
         // the argument block is read afresh for every tile (kernel_args_again: an offset the optimiser cannot see through):
@@ -1557,6 +1674,10 @@ void conv_launch_tile_bf16(const ConvP& p, dim3 grid, hipStream_t hs) {
         }
     }
     FIERY_CONV_LAUNCH(BM, BN, false, 0, false, true, true, false);
+}
+template <int BM, int BN>
+void conv_launch_tile_stream_k(const ConvP& p, dim3 grid, hipStream_t hs) {
+    hipLaunchKernelGGL((k_conv_igemm<BM, BN, false, 0, false, true, false, false, false, true>), grid, dim3(256), 0, hs, p);
 }
 template <int BM, int BN>
 void conv_launch_tile_f32_halo(const ConvP& p, dim3 grid, hipStream_t hs) {

@@ -113,6 +113,10 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Every vector-memory access this wavefront has issued has completed (loads returned, stores acknowledged): in front of the
+// barrier + ticket that hands sc0 sc1 (written-through) partial results to another workgroup.
+__device__ __forceinline__ void vmem_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // A value the optimiser must take as it finds it at this point (per-lane / wave-uniform): what is derived from it inside a
 // loop body is recomputed there instead of being hoisted out and kept in registers across the body.
 __device__ __forceinline__ void opaque_v(int& v) { asm volatile("" : "+v"(v)); }

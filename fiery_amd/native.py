@@ -66,6 +66,8 @@ class ConvDesc(C.Structure):
         ('weights3', C.c_void_p), ('scale3', C.c_void_p), ('shift3', C.c_void_p), ('act3', C.c_int32), ('out3', Nhwc),
         ('tile_m', C.c_int32), ('img_bias_border', C.c_int32), ('heads', ConvHeads),
         ('weights_bf16', C.c_void_p), ('precision', C.c_int32),
+        ('stream_k', C.c_int32), ('sk_workspace', C.c_void_p), ('sk_workspace_bytes', C.c_int64),
+        ('sk_counters', C.c_void_p), ('sk_counters_len', C.c_int32),
     ]
 
 
@@ -125,6 +127,7 @@ _SIGNATURES = {
     'fiery_conv_fwd': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     'fiery_conv_pack_weights_bf16': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_int32_p, C.c_int, C.c_void_p, C.c_void_p]),
     'fiery_conv_precision_used': (C.c_int, [C.POINTER(ConvDesc)]),
+    'fiery_conv_stream_k_plan': (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     'fiery_conv_wgrad': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int64] + [C.c_int] * 11 +
                          [C.c_void_p, C.c_void_p]),
     'fiery_conv_wgrad_prec': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int64] + [C.c_int] * 12 +
@@ -432,6 +435,12 @@ class Lib:
         if rc < 0:
             self.check(rc)
         return rc
+
+    def conv_stream_k_plan(self, desc):
+        """(workspace bytes, counters, workgroups) of the stream-K form of this launch; workgroups = 0: not covered."""
+        nbytes, n_cnt, n_wg = C.c_int64(0), C.c_int32(0), C.c_int32(0)
+        self.check(self.dll.fiery_conv_stream_k_plan(C.byref(desc), C.byref(nbytes), C.byref(n_cnt), C.byref(n_wg)))
+        return nbytes.value, n_cnt.value, n_wg.value
 
     def conv_wgrad(self, x, grad_out, cout, k, stride, pad, precision=PRECISION_F32):
         """x: pixel-major (n, Hin, Win, cin_pad) f32 (cin_pad a multiple of 8), grad_out: (n, Hout, Wout, >= cout) f32, both

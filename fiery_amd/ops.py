@@ -161,7 +161,8 @@ class ConvOp:
         self.chain = None
         self.chain3 = None
         self.heads = None
-        self._tile_m = {}            # (n_img, H, W) of the output -> measured best tile height
+        self._tile_m = {}            # (n_img, H, W) of the output -> measured best form (64 / 128 pixel tiles, 'sk')
+        self.force_form = None       # tests / A-B runs: 64, 128 or 'sk' instead of the measured choice
 
     def chain_pointwise(self, weight, scale, shift, act):
         """Fuse a following 1x1 convolution (Cin <= 32 = this op's padded outputs, Cout <= 64) into this kernel:
@@ -217,22 +218,39 @@ class ConvOp:
     def out_hw(self, H, W):
         return ((H + 2 * self.padH - self.kH) // self.stride + 1, (W + 2 * self.padW - self.kW) // self.stride + 1)
 
+    def _set_form(self, d, form, sk=None):
+        d.tile_m, d.stream_k = (128, 1) if form == 'sk' else (form, 0)
+        if form == 'sk':
+            d.sk_workspace, d.sk_workspace_bytes = sk['ws'].data_ptr(), sk['ws'].numel() * 4
+            d.sk_counters, d.sk_counters_len = sk['cnt'].data_ptr(), sk['cnt'].numel()
+        else:
+            d.sk_workspace = d.sk_counters = None
+            d.sk_workspace_bytes = d.sk_counters_len = 0
+
     def _pick_tile(self, d, out):
-        """Tile height for this launch.  The same launches repeat every step, so the first time a shape is seen on
-        the GPU both heights are timed (HIP events, on the launch stream) and the faster one is kept - the partly
-        filled last round of workgroups makes the better choice shape-dependent.  The
-        convolution is a pure function of its inputs, so the extra launches leave the same result behind."""
+        """The form of this launch: a tile height (64 / 128 output pixels per workgroup, one workgroup per tile), or
+        stream-K (the launch's work dealt evenly to one round of workgroups, shared tiles summed through a workspace -
+        `fiery_conv_desc.stream_k`).  The same launches repeat every step, so the first time a shape is seen on the GPU the
+        candidates are timed (HIP events, on the launch stream) and the fastest is kept - the partly filled last round of
+        workgroups makes the better choice shape-dependent.  The convolution is a pure function of its
+        inputs, so the extra launches leave the same result behind (up to the last bits between stream-K and the tile
+        forms: another summation split)."""
+        self._set_form(d, 0)
         if self.cout_pad % 64 != 0 or self.chain is not None or self.heads is not None or not self.tune:
-            return 0                                   # one tile shape only (or: library heuristic)
+            return                                     # one tile shape only (or: library heuristic)
         key = (out.n_img, out.H, out.W)
-        choice = self._tile_m.get(key)
+        choice = self._tile_m.get(key) if self.force_form is None else self.force_form
+        if choice is None and FORCE_FORM:
+            choice = 'sk' if FORCE_FORM == 'sk' else int(FORCE_FORM)
+        sk = _stream_k_workspace(self.lib, d, out.tensor) if (choice == 'sk' or choice is None) else None
         if choice is None:
             if not _autotune_enabled(out.tensor):
-                return 0                               # library heuristic (and nothing cached: tune when possible)
-            times = {64: float('inf'), 128: float('inf')}
+                return                                 # library heuristic (and nothing cached: tune when possible)
+            forms = [64, 128] + (['sk'] if sk is not None else [])
+            times = {f: float('inf') for f in forms}
             for _trial in range(2):                    # alternate the candidates, keep each one's best trial
-                for tile in (64, 128):
-                    d.tile_m = tile
+                for form in forms:
+                    self._set_form(d, form, sk)
                     self.lib.conv_fwd(d, out.tensor)   # warm
                     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     start.record()
@@ -240,9 +258,11 @@ class ConvOp:
                         self.lib.conv_fwd(d, out.tensor)
                     end.record()
                     end.synchronize()
-                    times[tile] = min(times[tile], start.elapsed_time(end))
+                    times[form] = min(times[form], start.elapsed_time(end))
             choice = self._tile_m[key] = min(times, key=times.get)
-        return choice
+        if choice == 'sk' and sk is None:
+            choice = 0                                 # (no workspace for this stream, e.g. first met inside a capture)
+        self._set_form(d, choice, sk)
 
     def __call__(self, srcs, out, res=None, img_bias=None, out2=None, aux0=None, aux1=None,
                  T_out=1, t_out0=0, t_in_add=0, cout_store=None, img_bias_border=False, head_planes=None, out3=None):
@@ -302,7 +322,7 @@ class ConvOp:
         self._keep = (srcs, out, res, img_bias, out2, aux0, aux1, out3)
         d.weights_bf16 = self.packed_bf16.data_ptr() if self.packed_bf16 is not None else None
         d.precision = self.precision if self.packed_bf16 is not None else native.PRECISION_F32
-        d.tile_m = self._pick_tile(d, out)
+        self._pick_tile(d, out)
         flops = 2.0 * out.n_img * out.H * out.W * self.cin_total * self.kT * self.kH * self.kW * self.cout
         if self.chain is not None:
             flops += 2.0 * out.n_img * out.H * out.W * self.cout * self.chain['cout']
@@ -313,6 +333,34 @@ class ConvOp:
             used = 'bf16' if self.lib.conv_precision_used(d) == native.PRECISION_BF16 else 'f32'
         profiled('conv_igemm', flops, out.tensor, lambda: self.lib.conv_fwd(d, out.tensor),
                  detail=(self.kT, self.kH, self.kW, self.stride, self.cin_total, self.cout, out.n_img, out.H, out.W, used))
+
+
+# Stream-K workspaces: one per (device, stream) - launches on different streams may be in flight together -, allocated once at
+# a fixed size (captured graphs keep their addresses) and never freed.  Partial tiles: 64 MiB covers one round of workgroups
+# of either stream-K kernel (512 x 2 x 128 x 128 or 768 x 2 x 128 x 64 floats); the ticket counters start at zero and every
+# launch leaves them at zero.
+_SK_WORKSPACES = {}
+SK_WORKSPACE_BYTES = 64 << 20
+SK_COUNTERS = 1 << 17
+STREAM_K = os.environ.get('FIERY_STREAM_K', '1') != '0'
+FORCE_FORM = os.environ.get('FIERY_CONV_FORM')      # A/B runs: '64', '128' or 'sk' for every launch that has the form, no timing
+
+
+def _stream_k_workspace(lib, d, t):
+    """The stream-K workspace of the current stream if this launch has a stream-K form that fits it, else None."""
+    if not STREAM_K:
+        return None
+    nbytes, n_cnt, n_wg = lib.conv_stream_k_plan(d)
+    if n_wg == 0 or nbytes > SK_WORKSPACE_BYTES or n_cnt > SK_COUNTERS:
+        return None
+    key = (t.device.type, t.device.index, torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0)
+    ws = _SK_WORKSPACES.get(key)
+    if ws is None:
+        if t.is_cuda and torch.cuda.is_current_stream_capturing():
+            return None                                # (allocated outside captures only: the eager pass in front of one)
+        ws = _SK_WORKSPACES[key] = dict(ws=torch.empty(SK_WORKSPACE_BYTES // 4, dtype=torch.float32, device=t.device),
+                                        cnt=torch.zeros(SK_COUNTERS, dtype=torch.int32, device=t.device))
+    return ws
 
 
 class HeadsOut:

@@ -329,6 +329,20 @@ typedef struct {
      * with `weights`, which therefore must always be set; fiery_conv_precision_used tells which form a descriptor gets. */
     const void* weights_bf16;          /* packed by fiery_conv_pack_weights_bf16, or NULL                  */
     int32_t precision;                 /* FIERY_PRECISION_F32 (0) or FIERY_PRECISION_BF16                  */
+    /* STREAM-K (round 5).  The tile forms above run one workgroup per output tile, in rounds of as many workgroups as the chip
+     * holds; a launch whose last round is partly filled pays for a full one (938 tiles of 128 x 128 on 512 slots: 8 % idle;
+     * 294 tiles on 768 slots: 62 %).  stream_k != 0 asks for the form that deals the launch's (tile, K chunk) units out evenly
+     * to exactly one round of workgroups instead; tiles whose chunks end up shared are summed through `sk_workspace` (partial
+     * accumulators, written and read past the L2s, which are not coherent across XCDs) by the last holder to arrive, in part
+     * order - results are deterministic for a given device, and differ from the tile forms' in the last bits (another
+     * summation split).  Taken only by launches the form covers (fiery_conv_stream_k_plan says which, and what they need:
+     * fp32, scalar-addressed loop, 64- or 128-wide cout tiles, no chained 1x1, no heads); others ignore the request.
+     * sk_counters: zero before the first launch; every launch leaves them zero.  One workspace per stream in flight. */
+    int32_t stream_k;
+    void* sk_workspace;
+    int64_t sk_workspace_bytes;
+    int32_t* sk_counters;
+    int32_t sk_counters_len;
 } fiery_conv_desc;
 
 #define FIERY_PRECISION_F32 0
@@ -372,6 +386,13 @@ int fiery_conv_wgrad_prec(const float* in, int in_ld, int64_t in_img_stride, int
 /* FIERY_PRECISION_F32 or FIERY_PRECISION_BF16: the matrix-core form fiery_conv_fwd runs this descriptor in (negative:
  * an error code - the descriptor is invalid). */
 int fiery_conv_precision_used(const fiery_conv_desc* desc /* host */);
+
+/* What the stream-K form of this descriptor needs (the descriptor's own stream_k / sk_* members are not looked at):
+ * *n_workgroups = 0 when the form does not cover the launch, else its grid, with *workspace_bytes (partial tiles) and
+ * *n_counters (int32, zero-initialised) the caller must provide in sk_workspace / sk_counters.  Returns 0, or an error code
+ * for an invalid descriptor. */
+int fiery_conv_stream_k_plan(const fiery_conv_desc* desc /* host */, int64_t* workspace_bytes, int32_t* n_counters,
+                             int32_t* n_workgroups);
 
 /* Final 1x1 heads: out_nchw[img][o][y][x] = act_o(bias[o] + sum_{c<head_c} w[o][c] * in[img][y][x][c_off[o] + c])
  * (fiery/models/decoder.py:30-51, the last conv (+ Sigmoid) of each head), NCHW result.

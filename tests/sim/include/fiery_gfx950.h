@@ -116,6 +116,8 @@ inline float rows_sum4(float v) {
 // wavefront-level rendezvous (lane-to-lane hand-over through LDS inside one wavefront)
 inline void wave_sync() { ::hipsim::barrier_wait(::hipsim::run_ptr()->waves[::hipsim::tls().wave]); }
 
+inline void vmem_done() {}
+
 inline void opaque_v(int&) {}
 inline void opaque_s(int&) {}
 // (simulator: the argument block is the argument)

@@ -220,6 +220,12 @@ inline unsigned long long atomicAdd(unsigned long long* addr, unsigned long long
     return old;
 }
 
+inline int atomicExch(int* addr, int v) {
+    const int old = *addr;
+    *addr = v;
+    return old;
+}
+
 inline unsigned atomicOr(unsigned* addr, unsigned v) {
     const unsigned old = *addr;
     *addr = old | v;

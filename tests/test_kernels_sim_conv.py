@@ -562,3 +562,69 @@ def test_conv_wgrad_matches_autograd(sim, cin, cout, k, stride, hw):
     got = dw[:, :, :cin].permute(0, 2, 1).reshape(cout, cin, k, k)
     assert torch.allclose(got, w.grad, rtol=1e-4, atol=1e-4), (got - w.grad).abs().max()
     assert dw[:, :, cin:].abs().max() == 0 if cin_pad > cin else True      # padded channels see zero inputs
+
+
+@pytest.mark.parametrize('wgs', ['8', '16', '40'])
+@pytest.mark.parametrize('case', ['3x3 64->128', '3x3 two sources -> 64, GRU out', '1x1 96->256 residual', '(2,3,3) 32->64 temporal'])
+def test_stream_k_form_equals_the_tile_form(sim, monkeypatch, case, wgs):
+    """Stream-K (`fiery_conv_desc.stream_k`, round 5): the launch's (tile, K chunk) units dealt evenly to a fixed number of
+    workgroups, shared tiles summed through the workspace by the last arrival.  Against the tile form of the same launch and
+    against torch: with 8 / 16 / 40 workgroups the same tiles are whole, split in two, and split in three or more parts; ragged
+    pixel counts, several cout tiles, every epilogue kind the form covers.  (Visibility of the partials across XCDs is a GPU
+    matter - tests/test_gpu_parity.py; here: indexing, part order, counters left at zero.)"""
+    from fiery_amd import ops
+    monkeypatch.setenv('FIERY_CONV_SK_WGS', wgs)
+    g = torch.Generator().manual_seed(len(case) + int(wgs))
+    if case == '3x3 64->128':
+        x = torch.randn(2, 64, 13, 17, generator=g)
+        w = torch.randn(128, 64, 3, 3, generator=g) / 24
+        sc, sh = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g)
+        op = ConvOp(sim, w, identity_chan_map(64), (8, 0), sc, sh, 'cpu', act=native.ACT_RELU, tune=True)
+        run = lambda o, out: o([_to_buf(x)], out)
+        want = F.relu(F.conv2d(x, w, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+        shape = (2, 13, 17, 128)
+    elif case == '3x3 two sources -> 64, GRU out':
+        x, h = torch.randn(1, 32, 12, 15, generator=g), torch.randn(1, 64, 12, 15, generator=g)
+        u = torch.rand(1, 64, 12, 15, generator=g)
+        w = torch.randn(64, 96, 3, 3, generator=g) / 30
+        sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+        op = ConvOp(sim, w, identity_chan_map(32) + identity_chan_map(64, offset=32), (4, 8), sc, sh, 'cpu', act=native.ACT_RELU,
+                    epi=native.EPI_GRU_OUT, tune=True)
+        xb, hb, ub = _to_buf(x), _to_buf(h), _to_buf(u)
+        run = lambda o, out: o([xb, hb], out, aux0=ub, aux1=hb)
+        tilde = F.relu(F.conv2d(torch.cat([x, h], 1), w, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+        want = (1 - u) * h + u * tilde
+        shape = (1, 12, 15, 64)
+    elif case == '1x1 96->256 residual':
+        x = torch.randn(3, 96, 9, 11, generator=g)
+        w = torch.randn(256, 96, 1, 1, generator=g) / 10
+        res = torch.randn(3, 256, 9, 11, generator=g)
+        op = ConvOp(sim, w, identity_chan_map(96), (12, 0), torch.ones(256), torch.zeros(256), 'cpu', act=native.ACT_RELU, tune=True)
+        rb = _to_buf(res)
+        run = lambda o, out: o([_to_buf(x)], out, res=rb)
+        want = F.relu(F.conv2d(x, w)) + res
+        shape = (3, 9, 11, 256)
+    else:
+        B, T = 2, 3
+        x = torch.randn(B * T, 32, 10, 9, generator=g)                       # frames of B sequences, t minor
+        w = torch.randn(64, 32, 2, 3, 3, generator=g) / 24
+        op = ConvOp(sim, w, identity_chan_map(32), (4, 0), torch.ones(64), torch.zeros(64), 'cpu', tune=True)
+        xb = _to_buf(x)
+        run = lambda o, out: o([(xb, T * xb.img_stride, xb.img_stride)], out, T_out=T)
+        xs = x.view(B, T, 32, 10, 9).permute(0, 2, 1, 3, 4)
+        want = F.conv3d(F.pad(xs, (1, 1, 1, 1, 1, 0)), w).permute(0, 2, 1, 3, 4).reshape(B * T, 64, 10, 9)
+        shape = (B * T, 10, 9, 64)
+    outs = {}
+    for form in (128, 'sk'):
+        op.force_form = form
+        out = Buf.alloc(*shape, 'cpu')
+        run(op, out)
+        outs[form] = out.to_nchw()
+    ws = ops._SK_WORKSPACES[('cpu', None, 0)]
+    assert int(ws['cnt'].abs().sum()) == 0, 'every launch leaves the ticket counters at zero'
+    assert torch.allclose(outs['sk'], want, **TOL), (outs['sk'] - want).abs().max()
+    assert torch.allclose(outs["sk"], outs[128], rtol=1e-5, atol=3e-6)        # (the same sums, split at other chunks)
+    # a second launch through the same workspace (stale partials in every slot) gives the same bits
+    out2 = Buf.alloc(*shape, 'cpu')
+    run(op, out2)
+    assert torch.equal(out2.to_nchw(), outs['sk'])
