@@ -204,8 +204,10 @@ def main():
         lifted_d = torch.empty((B * world,) + tuple(lifted.shape[1:]), device=dev)
         assert block_range(B * world * rf, world, rank) == (rank * B * rf, (rank + 1) * B * rf)     # this rank pools its own samples' frames
         lifted_d[rank * B:(rank + 1) * B].copy_(lifted)
+        from fiery_amd.parallel import sharded_bev_forward_graph
         eager_step = lambda: sharded_bev_forward(model, K_d, E_d, ego_d, lifted=lifted_d, layout='frames', exchange=args.exchange)[0]
-        graph_step = None                                  # the collective is enqueued by torch.distributed: eager launches
+        # (round 5: the exchange - enqueued by torch.distributed on the capturing stream - is a node of the captured graph)
+        graph_step = lambda: sharded_bev_forward_graph(model, K_d, E_d, ego_d, lifted=lifted_d, layout='frames', exchange=args.exchange)[0]
     elif args.fused:
         dl_d = dl.view(B, rf, n_cam, D, fh, fw).to(dev)
         ft_d = ft.view(B, rf, n_cam, C, fh, fw).to(dev)
@@ -290,12 +292,22 @@ def main():
         recs = sorted(instrumented, key=conv_time)[len(instrumented) // 2]
         pool_samples = sorted(sum(s.elapsed_time(e) * 1e3 for k, s, e, _, _ in rr if k == 'voxel_pool') for rr in instrumented)
         conv = [(s.elapsed_time(e) * 1e-3, w) for k, s, e, w, _ in recs if k == 'conv_igemm']
-        # launches by the matrix-core form they ran in (a bf16 run keeps fp32 for the layers the bf16 kernel does not take)
-        by_prec = {}
+        # launches by the matrix-core form they ran in (a bf16 run keeps fp32 for the layers the bf16 kernel does not take).  A
+        # Winograd F(2x2, 3x3) launch EXECUTES 16 / 36 of the direct form's matrix flops: the MFMA roofline below is on executed
+        # flops; the direct-form-equivalent ("algorithmic") flops of those launches and the speed-up they stand for are reported
+        # separately, never against the matrix peak.
+        WINO = 16.0 / 36.0
+        executed_of = lambda w, d: w * WINO if 'winograd' in str(d[-1]) else w
+        by_form = {}
         for k, s_, e_, w, d in recs:
             if k == 'conv_igemm':
-                t_, f_, n_ = by_prec.get(d[-1], (0.0, 0.0, 0))
-                by_prec[d[-1]] = (t_ + s_.elapsed_time(e_) * 1e-3, f_ + w, n_ + 1)
+                t_, f_, x_, n_ = by_form.get(d[-1], (0.0, 0.0, 0.0, 0))
+                by_form[d[-1]] = (t_ + s_.elapsed_time(e_) * 1e-3, f_ + w, x_ + executed_of(w, d), n_ + 1)
+        by_prec = {}                                                   # 'f32' (all fp32 forms) / 'bf16': time, executed flops, launches
+        for form, (t_, f_, x_, n_) in by_form.items():
+            key = 'bf16' if form == 'bf16' else 'f32'
+            a = by_prec.get(key, (0.0, 0.0, 0))
+            by_prec[key] = (a[0] + t_, a[1] + x_, a[2] + n_)
         # pooling: algorithmic bytes with N_kept, counted from the voxel ranks the op left in its workspace
         pool, kept_frac = [], None
         for k, s_, e_, _, d in recs:
@@ -309,6 +321,7 @@ def main():
                     for k, s, e, w, d in recs]
             json.dump(rows, open(dump, 'w'))
         t_conv, f_conv = sum(t for t, _ in conv), sum(w for _, w in conv)
+        x_conv = sum(x_ for _, _, x_, _ in by_form.values())             # executed matrix flops of the step's convolutions
         # the dominant kernel = the form that holds most of the time; its flops against ITS peak
         dom = max(by_prec, key=lambda k_: by_prec[k_][0])
         peak = PEAK_BF16_MFMA_TFLOPS if dom == 'bf16' else PEAK_F32_MFMA_TFLOPS
@@ -319,6 +332,17 @@ def main():
                     'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                     'by_precision': {k_: {'launches': n_, 'ms_per_step': round(t_ * 1e3, 3), 'tflops': round(f_ / t_ / 1e12, 2)}
                                      for k_, (t_, f_, n_) in by_prec.items()},
+                    # the forms the launches ran in: direct tiles ('f32'), stream-K, Winograd F(2x2, 3x3); executed = matrix flops
+                    # the MFMAs really did, algorithmic = the direct form's flops for the same layers (SURVEY 8d's count)
+                    'by_form': {str(k_): {'launches': n_, 'ms_per_step': round(t_ * 1e3, 3), 'executed_tflops': round(x_ / t_ / 1e12, 2),
+                                          'executed_frac_of_peak': round(x_ / t_ / 1e12 / (PEAK_BF16_MFMA_TFLOPS if k_ == 'bf16' else PEAK_F32_MFMA_TFLOPS), 4),
+                                          'algorithmic_gflop': round(f_ / 1e9, 1), 'executed_gflop': round(x_ / 1e9, 1)}
+                                for k_, (t_, f_, x_, n_) in by_form.items()},
+                    'executed_gflop_per_step': round(x_conv / 1e9, 1),
+                    'algorithmic_speedup': {'value': round(f_conv / x_conv, 3),
+                                            'what': 'direct-form flops of the step / matrix flops executed (Winograd F(2x2,3x3) layers execute 16/36); '
+                                                    'a separate figure - `achieved` / `frac` are on EXECUTED flops'},
+                    'direct_form_equivalent_tflops': round(f_conv / t_conv / 1e12, 2),
                     'traffic': None,             # (no counters in a timed run; the committed passes' figure follows)
                     'traffic_from_profiles': pmc_traffic(['k_conv_igemm (all tile shapes)']) if args.precision == 'f32' and args.config == 'baseline.yml' and n_cam == 6 and B == 3 else None,
                     'launches': n_dom, 'avg_launch_us': round(t_dom / n_dom * 1e6, 2),
@@ -328,10 +352,10 @@ def main():
                     # the same kernel in the TIMED launch mode (hipGraph, one chain per sample: kernels of different
                     # samples share the CUs, so no per-launch bracket exists): its flops over the whole step time - a lower
                     # bound of what it reaches there, because the step also holds every other kernel
-                    'timed_mode': {'achieved': round(f_conv / (elapsed / args.steps) / 1e12, 2), 'unit': 'TFLOP/s',
-                                   'frac': round(f_conv / (elapsed / args.steps) / 1e12 / peak, 4),
-                                   'what': 'conv flops of a step / timed ms_per_step (lower bound: the step holds all kernels)'},
-                    'step_tflops': round(f_conv / (elapsed / args.steps) / 1e12, 2)}
+                    'timed_mode': {'achieved': round(x_conv / (elapsed / args.steps) / 1e12, 2), 'unit': 'TFLOP/s',
+                                   'frac': round(x_conv / (elapsed / args.steps) / 1e12 / peak, 4),
+                                   'what': 'executed conv flops of a step / timed ms_per_step (lower bound: the step holds all kernels)'},
+                    'step_tflops': round(x_conv / (elapsed / args.steps) / 1e12, 2)}
         if pool:
             t_pool, b_pool = pool_samples[len(pool_samples) // 2] * 1e-6, sum(w for _, w in pool)
             gbs = b_pool / t_pool / 1e9
@@ -370,9 +394,27 @@ def main():
                                f'EfficientNet trunk + lift head + the hot path, {how}, mean of 5'}
         del image
 
+    # the frames layout's exchange on its own: HIP events around the collective of a few eager steps, on every rank (each step holds
+    # the collective, so all ranks walk through the same steps), and the bytes this rank receives from the others
+    exchange = None
+    if frames_layout:
+        from fiery_amd import parallel
+        parallel.EXCHANGE_SINK = []
+        with torch.no_grad():
+            for _ in range(5):
+                eager_step()
+        torch.cuda.synchronize()
+        ms = sorted(s_.elapsed_time(e_) for s_, e_, _ in parallel.EXCHANGE_SINK)
+        exchange = {'exchange_ms': round(ms[len(ms) // 2], 4) if ms else 0.0,
+                    'bytes_received': int(parallel.EXCHANGE_SINK[0][2]) if parallel.EXCHANGE_SINK else 0,
+                    'kind': args.exchange + (' (no collective issued: one rank keeps its own frames)' if not ms else '')}
+        parallel.EXCHANGE_SINK = None
+
     # who took part: every rank's device, as the process group sees it (a SCALE record then shows N ranks on N devices)
     me = {'rank': rank, 'local_rank': local_rank, 'device': f'cuda:{torch.cuda.current_device()}',
           'name': torch.cuda.get_device_name(), 'pid': os.getpid()}
+    if exchange is not None:
+        me.update(exchange)
     try:
         me['pci_bus_id'] = torch.cuda.get_device_properties(torch.cuda.current_device()).pci_bus_id
     except AttributeError:

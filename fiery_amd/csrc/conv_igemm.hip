@@ -7,11 +7,6 @@ namespace {
 
 __device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(-v)); }
 
-constexpr int kMaxPackUnits = 128;      // 8-channel input units per convolution: 1024 channels (the trunk's 960-wide projections)
-struct ChanInverse {
-    short ci[kMaxPackUnits * 8];   // padded channel position -> logical input channel, -1 = padding (2 KB of kernel arguments)
-};
-
 __global__ void k_pack_weights(const float* __restrict__ w, int cout, int cin_total, int taps, ChanInverse inv,
                                int cin_units, int bn, int k_chunks, long long total, float* __restrict__ packed) {
     const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -169,6 +164,28 @@ extern "C" int fiery_conv_pack_weights_bf16(const float* w, int cout, int cin_to
     hipLaunchKernelGGL(k_pack_weights_bf16, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w, cout, cin_total,
                        taps, inv, cin_units, g.bn, g.k_chunks, total, static_cast<unsigned short*>(packed));
     return check_launch("conv_pack_weights_bf16");
+}
+
+extern "C" size_t fiery_conv_winograd_packed_floats(int cout, int cin_units) {
+    if (cout <= 0 || cin_units <= 0) return 0;
+    return conv_winograd_packed_floats(cout, cin_units);
+}
+
+extern "C" int fiery_conv_pack_weights_winograd(const float* w, int cout, int cin_total, const int32_t* chan_map, int cin_units,
+                                                float* packed, fiery_stream_t stream) {
+    FIERY_REQUIRE(w && chan_map && packed, "conv_pack_weights_winograd: null pointer");
+    FIERY_REQUIRE(cout > 0 && cin_total > 0 && cin_units > 0 && cin_units % 2 == 0, "conv_pack_weights_winograd: bad shape (whole 16-channel stages)");
+    FIERY_REQUIRE(cin_units <= kMaxPackUnits, "conv_pack_weights_winograd: at most %d input channels", kMaxPackUnits * 8);
+    ChanInverse inv;
+    for (int i = 0; i < kMaxPackUnits * 8; ++i) inv.ci[i] = -1;
+    for (int ci = 0; ci < cin_total; ++ci) {
+        const int pos = chan_map[ci];
+        FIERY_REQUIRE(pos >= 0 && pos < cin_units * 8, "conv_pack_weights_winograd: chan_map[%d] = %d out of range", ci, pos);
+        FIERY_REQUIRE(inv.ci[pos] < 0, "conv_pack_weights_winograd: chan_map maps two channels to position %d", pos);
+        inv.ci[pos] = static_cast<short>(ci);
+    }
+    if (conv_winograd_pack(w, cout, cin_total, inv, cin_units, packed, as_stream(stream)) != 0) return fail(FIERY_EINVAL, "conv_pack_weights_winograd: launch failed");
+    return check_launch("conv_pack_weights_winograd");
 }
 
 namespace {
@@ -440,8 +457,21 @@ int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, ConvRunMode mode, 
                       "conv_fwd: stream-K needs %lld workspace bytes and %d counters (fiery_conv_stream_k_plan)", sk.workspace_bytes, sk.n_counters);
         bm = 128;
     }
-    const bool bf16 = !stream_k && conv_takes_bf16(d, aligned, bm, bn, cin_units);
+    // Winograd F(2x2, 3x3) form (conv_winograd.hip): the caller packed the transformed weights and asks for it; taken by fp32
+    // launches of 3 x 3 / stride 1 / 'same' layers with whole 16-channel stages per source, 64-cout tiles, 16-byte addressable
+    // tensors, the plain or GRU epilogues - everything else ignores the request
+    const bool winograd = d->winograd != 0 && d->weights_winograd && variant == kConvAligned && d->kT == 1 && d->kH == 3 && d->kW == 3 &&
+                          d->stride == 1 && d->padH == 1 && d->padW == 1 && d->Hin == d->Hout && d->Win == d->Wout && d->cout_pad % 64 == 0 &&
+                          cin_units % 2 == 0 && d->src[0].units % 2 == 0 && !d->weights2 && d->epi != FIERY_EPI_HEADS && (p.vec_epilogue & 1) &&
+                          d->precision != FIERY_PRECISION_BF16 && aligned16(d->weights_winograd) &&
+                          static_cast<long long>(d->n_img_out) * ((d->Hout + 1) / 2) * ((d->Wout + 1) / 2) < (1ll << 30);
+    const bool bf16 = !stream_k && !winograd && conv_takes_bf16(d, aligned, bm, bn, cin_units);
     if (!launch) return bf16 ? FIERY_PRECISION_BF16 : FIERY_PRECISION_F32;
+    if (winograd) {
+        p.w = d->weights_winograd;
+        if (!conv_launch_winograd(p, hs)) return fail(FIERY_EINVAL, "conv_fwd: Winograd launch failed");
+        return check_launch("conv_fwd (Winograd)");
+    }
     if (stream_k) {
         p.sk_tiles = sk.n_counters;
         p.sk_ws = static_cast<float*>(d->sk_workspace);

@@ -123,6 +123,15 @@ bool conv_launch_64x128(const ConvP& p, dim3 grid, hipStream_t stream, int varia
 // bf16 matrix-core form of the scalar-addressed kernel (weights packed by fiery_conv_pack_weights_bf16 in p.w); returns
 // false when (bm, bn) has no such kernel
 bool conv_launch_bf16(const ConvP& p, int bm, int bn, dim3 grid, hipStream_t stream, bool halo = false);
+// weight packers' argument: padded channel position -> logical input channel, -1 = padding (2 KB of kernel arguments)
+constexpr int kMaxPackUnits = 128;      // 8-channel input units per convolution: 1024 channels (the trunk's 960-wide projections)
+struct ChanInverse {
+    short ci[kMaxPackUnits * 8];
+};
+// Winograd F(2x2, 3x3) form (conv_winograd.hip): 3 x 3 / stride 1 / 'same' layers, 64-cout tiles, 16-channel stages
+size_t conv_winograd_packed_floats(int cout, int cin_units);
+int conv_winograd_pack(const float* w, int cout, int cin_total, const ChanInverse& inv, int cin_units, float* packed, hipStream_t stream);
+bool conv_launch_winograd(const ConvP& p, hipStream_t stream);
 // stream-K form of the scalar-addressed fp32 kernel on 128-pixel tiles (bn = 64 or 128); returns false when bn has none
 bool conv_launch_stream_k(const ConvP& p, int bn, dim3 grid, hipStream_t stream);
 // workgroups the stream-K kernel of cout tile width bn keeps resident per CU

@@ -1,0 +1,370 @@
+// Winograd F(2x2, 3x3) form of the 3 x 3 / stride 1 / 'same' convolutions of the BEV stack, fp32 on the gfx950 matrix cores
+// (round 5).  Reference layers: fiery/layers/convolutions.py:9-60 (ConvBlock), fiery/layers/temporal.py:36-62 (SpatialGRU's
+// gate and candidate convolutions), fiery/models/decoder.py:53-91 (BasicBlock / upsampling stages) - everything `conv2d(k = 3,
+// stride = 1, padding = 1)` with 64 couts or more.
+//
+// WHY.  The fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at the vector ALU's multiplier rate, 157.3 TFLOP/s; four rounds of tuning
+// left the direct implicit GEMM at 0.65-0.75 of it on these layers, which hold ~85 % of the step's convolution time.  What is
+// left is doing fewer multiplies: F(2x2, 3x3) computes a 2 x 2 output block from a 4 x 4 input block with 16 multiplies per
+// (cin, cout) pair instead of 36 - 2.25x fewer - at the price of add-only transforms of the input (32 adds per block and
+// channel, shared by all couts) and of the output (24 adds per block and cout, shared by all cins).
+//   Y = A^T [ sum_c (G g_c G^T) . (B^T d_c B) ] A
+// Numerics were gated first (tests/experiments/winograd_numerics.py, profiles/r5_winograd_numerics.txt): the oracle's hot
+// path with every such convolution through an fp32 emulation of this form lands 7.9e-6 from the direct fp32 evaluation on
+// the worst output (the bar is 1e-4) and at the same distance from the fp64 evaluation (7.00e-4 vs 6.98e-4).
+//
+// HOW.  16 independent GEMMs, one per transform point p: M_p[tile][cout] = sum_c V_p[tile][c] U_p[c][cout].
+//   * workgroup = 4 wavefronts, 32 tiles (= 128 output pixels) x 64 couts; wavefront w owns the transform points 4 w .. 4 w + 3
+//     for all 32 tiles and both 32-cout blocks: 8 accumulator blocks = 128 registers, so two workgroups fit a CU and one's
+//     transforms / epilogue run under the other's MFMAs.
+//   * K advances 16 channels per stage.  Every thread owns one (tile, channel pair) of the stage: it fetches the tile's 4 x 4
+//     input block for its two channels straight from the pixel-major activations (16 eight-byte buffer loads, border taps
+//     masked to the descriptor's out-of-range zero), transforms it in registers with packed adds and writes the sixteen
+//     V_p values to LDS ([p][tile][16 k], 16-byte slots XOR-swizzled so the operand reads are conflict-free).  The loads of
+//     stage s + 1 are in flight while stage s is multiplied; LDS is double-buffered, one barrier per stage.
+//   * the transformed weights U (host-side: G g G^T evaluated in fp64, rounded once - fiery_conv_pack_weights_winograd) never
+//     touch LDS: a lane's operand of four MFMA k-steps is one 16-byte piece of the packed image [p][k / 4][cout][k % 4], and
+//     each wavefront requests exactly the pieces of its own transform points into a register ring, several pieces ahead.
+//   * MFMA operands are swapped (weights as A, tiles as B), so an accumulator block is lane = tile, registers = couts: four
+//     consecutive couts sit in four consecutive registers and go to LDS as 16-byte pieces.
+//   * epilogue: per 32-cout block the sixteen M_p blocks meet in LDS ([p][tile][cout], the K loop's buffers reused); a thread
+//     takes (tile, four couts), applies A^T . A, then bias / folded BatchNorm / activation / residual or the GRU gate
+//     arithmetic of the direct kernel's epilogues, and stores 16 bytes to each of the block's four pixels.
+// Executed matrix flops are 16 / 36 of the direct form's; bench.py reports the algorithmic (direct-form) flops of these
+// launches and the executed-MFMA fraction side by side, never an "algorithmic TFLOP/s" against the matrix peak.
+#define FIERY_CONV_KERNEL_TU 1
+#include "conv_igemm_kernel.h"
+
+namespace fiery {
+namespace {
+
+constexpr int WT = 32;            // tiles (2 x 2 output blocks) per workgroup
+constexpr int WBN = 64;           // couts per workgroup
+constexpr int WKC = 16;           // channels per stage
+constexpr int W_V_FLOATS = 16 * WT * WKC;              // one stage of V
+constexpr int W_M_PITCH = 36;                          // floats between tiles of the epilogue's exchange block (32 couts + 4)
+constexpr int W_SMEM_FLOATS = 16 * WT * W_M_PITCH;     // 73,728 bytes: the exchange block; the two V stages (65,536) lie inside
+static_assert(2 * W_V_FLOATS <= W_SMEM_FLOATS, "the V stages must fit the block");
+
+// floats of the transformed, packed weights: [cout tile][p][cin_pad / 4][64][4]
+__host__ __device__ inline long long wino_packed_floats(int cout_pad64, int cin_pad) { return 16ll * cout_pad64 * cin_pad; }
+
+// U = G g G^T in fp64, rounded once; packed[(((tn * 16 + p) * Q + k / 4) * 64 + n % 64) * 4 + k % 4], k = padded channel position
+__global__ void k_pack_winograd(const float* __restrict__ w, int cout, int cin_total, ChanInverse inv, int cin_units, long long total,
+                                float* __restrict__ packed) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int Q = cin_units * 2;
+    const int kk = static_cast<int>(i & 3);
+    long long r = i >> 2;
+    const int nn = static_cast<int>(r % 64);
+    r /= 64;
+    const int quad = static_cast<int>(r % Q);
+    r /= Q;
+    const int p = static_cast<int>(r % 16);
+    const int tn = static_cast<int>(r / 16);
+    const int n = tn * 64 + nn, k = quad * 4 + kk;
+    float v = 0.f;
+    if (n < cout) {
+        const int ci = inv.ci[k];
+        if (ci >= 0) {
+            const float* g = w + (static_cast<long long>(n) * cin_total + ci) * 9;
+            const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+            const int pi = p >> 2, pj = p & 3;
+            double s = 0.0;
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) s += G[pi][a] * static_cast<double>(g[a * 3 + b]) * G[pj][b];
+            v = static_cast<float>(s);
+        }
+    }
+    packed[i] = v;
+}
+
+__global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
+    __shared__ __attribute__((aligned(16))) float smem[W_SMEM_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31, hi = lane >> 5;
+    const int tile_n = blockIdx.y;
+    const int H = p.Hout, W = p.Wout;
+    const int TH = (H + 1) >> 1, TW = (W + 1) >> 1;
+    const int tiles_img = TH * TW;
+    const int n_tiles = p.n_img * tiles_img;
+    // XCD-aware order of the workgroups' tile blocks (workgroup b runs on XCD b % 8: a contiguous run of blocks per XCD)
+    int blk;
+    {
+        const int nblk = static_cast<int>(gridDim.x), bid = static_cast<int>(blockIdx.x);
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile0 = blk * WT;
+
+    // ---- this thread's input block: tile tt, channels 2 cp, 2 cp + 1 of the stage ------------------------------------------
+    const int tt = tid >> 3, cp = tid & 7;
+    int voff0, voff1;               // byte offsets of the block's top-left tap (y0 - 1 + 1 lead row ...) in the two sources
+    unsigned tapmask = 0;           // bit 4 i + j: tap (i, j) lies inside the image
+    {
+        const int T = tile0 + tt;
+        const bool live = T < n_tiles;
+        const int Tq = live ? T : 0;
+        const int o = Tq / tiles_img, rem = Tq - o * tiles_img;
+        const int ty = rem / TW, tx = rem - ty * TW;
+        const int b = fast_div(o, p.mg_t, p.sh_t), tl = o - b * p.Tout;
+        const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+        if (live)
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j)
+                    if (static_cast<unsigned>(y0 + i) < static_cast<unsigned>(H) && static_cast<unsigned>(x0 + j) < static_cast<unsigned>(W))
+                        tapmask |= 1u << (4 * i + j);
+        // (the descriptors start one row and one pixel before the tensors: the top-left tap's offset is never negative)
+        const int pos = (y0 + 1) * W + (x0 + 1);
+        voff0 = 4 * (b * static_cast<int>(p.src[0].bstride) + (tl + p.tinadd) * static_cast<int>(p.src[0].tstride) + pos * p.src[0].ld + 2 * cp);
+        voff1 = 4 * (b * static_cast<int>(p.src[1].bstride) + (tl + p.tinadd) * static_cast<int>(p.src[1].tstride) + pos * p.src[1].ld + 2 * cp);
+    }
+    const int lead0 = (W + 1) * p.src[0].ld, lead1 = (W + 1) * p.src[1].ld;
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src[0].ptr - lead0), 0, 4 * lead0 + p.src[0].ext_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.src[1].ptr ? p.src[1].ptr - lead1 : p.src[0].ptr), 0, p.src[1].ptr ? 4 * lead1 + p.src[1].ext_bytes : 0, 0x00020000);
+    const int stages = p.cin_units >> 1, stages0 = p.src[0].units >> 1;
+    const int rowb0 = W * p.src[0].ld * 4, pixb0 = p.src[0].ld * 4, rowb1 = W * p.src[1].ld * 4, pixb1 = p.src[1].ld * 4;
+
+    v2f d[16];                      // the 4 x 4 block (two channels per element), transformed in place
+    auto request = [&](int s) {
+        const bool second = s >= stages0;
+        const int ch = 64 * (s - (second ? stages0 : 0));                  // bytes: 16 channels per stage
+        const int rowb = second ? rowb1 : rowb0, pixb = second ? pixb1 : pixb0;
+        const int vo = second ? voff1 : voff0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int v = (tapmask >> (4 * i + j)) & 1u ? vo : static_cast<int>(0x80000000u);     // outside: reads as zero
+                const auto raw = second ? __builtin_amdgcn_raw_buffer_load_b64(rs1, v, ch + i * rowb + j * pixb, 0)
+                                        : __builtin_amdgcn_raw_buffer_load_b64(rs0, v, ch + i * rowb + j * pixb, 0);
+                __builtin_memcpy(&d[4 * i + j], &raw, 8);
+            }
+    };
+    // B^T d B in place (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]): columns, then rows - 32 packed adds
+    auto transform = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const v2f d0 = d[j], d1 = d[4 + j], d2 = d[8 + j], d3 = d[12 + j];
+            d[j] = d0 - d2;
+            d[4 + j] = d1 + d2;
+            d[8 + j] = d2 - d1;
+            d[12 + j] = d1 - d3;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const v2f t0 = d[4 * i], t1 = d[4 * i + 1], t2 = d[4 * i + 2], t3 = d[4 * i + 3];
+            d[4 * i] = t0 - t2;
+            d[4 * i + 1] = t1 + t2;
+            d[4 * i + 2] = t2 - t1;
+            d[4 * i + 3] = t1 - t3;
+        }
+    };
+    // V stage in LDS: [p][tile][16 k]; 16-byte slot q of a tile's row sits at q ^ ((tile >> 2) & 3)
+    const int v_st = (tt * WKC + 4 * ((cp >> 1) ^ ((tt >> 2) & 3)) + 2 * (cp & 1));              // + p * WT * WKC + buf * W_V_FLOATS
+    auto store_v = [&](int buf) {
+#pragma unroll
+        for (int pp = 0; pp < 16; ++pp) *reinterpret_cast<v2f*>(&smem[buf * W_V_FLOATS + pp * (WT * WKC) + v_st]) = d[pp];
+    };
+    // operand reads: lane (m, hi) of k-group q reads slot 2 q + hi of tile m's row
+    int v_rd[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) v_rd[q] = m * WKC + 4 * ((2 * q + hi) ^ ((m >> 2) & 3));          // + p * WT * WKC + buf * W_V_FLOATS
+
+    // ---- transformed weights: this wavefront's pieces, straight into a register ring -----------------------------------------
+    // piece index within a stage: ((q * 4 + pl) * 2 + nb), pl = local transform point; 16 pieces per stage
+    const int Q = p.cin_units * 2;                                      // 16-byte k-quads of the whole K
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.w) + static_cast<long long>(tile_n) * 16 * Q * 256, 0, 16 * Q * 1024, 0x00020000);
+    const int w_vo = (hi * 64 + m) * 16;
+    constexpr int RING = 8, AHEAD = 6;
+    float4 wr[RING];
+    auto to_f4 = [](auto raw) {
+        float4 f;
+        __builtin_memcpy(&f, &raw, 16);
+        return f;
+    };
+    auto w_request = [&](int slot, int s, int piece) {                  // piece of stage s (past the end: any piece of the last stage)
+        const int ss = s < stages ? s : stages - 1;
+        const int q = piece >> 3, pl = (piece >> 1) & 3, nb = piece & 1;
+        const int soff = (((4 * wv + pl) * Q + 4 * ss + 2 * q) * 64 + nb * 32) * 16;
+        wr[slot] = to_f4(__builtin_amdgcn_raw_buffer_load_b128(wrs, w_vo, soff, 0));
+    };
+
+    v16f acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][nb][r] = 0.f;
+
+    // ---- prologue: stage 0 into LDS, stage 1's block and the first weight pieces in flight ----------------------------------
+    request(0);
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i) w_request(i, 0, i);
+    transform();
+    store_v(0);
+    if (stages > 1) request(1);
+    __syncthreads();
+
+    auto comp = [](const float4& f, int j) { return j == 0 ? f.x : j == 1 ? f.y : j == 2 ? f.z : f.w; };
+    for (int s = 0; s < stages; ++s) {
+        const int buf = s & 1;
+        const float* vb = smem + buf * W_V_FLOATS + (4 * wv) * (WT * WKC);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int pl = 0; pl < 4; ++pl) {
+                const float4 a4 = *reinterpret_cast<const float4*>(vb + pl * (WT * WKC) + v_rd[q]);
+                const int piece = (q * 4 + pl) * 2;
+                const float4 b0 = wr[piece % RING], b1 = wr[(piece + 1) % RING];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[pl][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(b0, j), comp(a4, j), acc[pl][0], 0, 0, 0);
+                    acc[pl][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(b1, j), comp(a4, j), acc[pl][1], 0, 0, 0);
+                }
+                // the two slots this point leaves take the pieces AHEAD further on (wrapping into the next stage)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int nxt = piece + e + AHEAD;
+                    if (nxt < 16) w_request(nxt % RING, s, nxt);
+                    else w_request(nxt % RING, s + 1, nxt - 16);
+                }
+                // the next stage's block is transformed and stored half-way through this one (its loads were requested a
+                // stage ago), and the block after it requested at once
+                if (q == 0 && pl == 3 && s + 1 < stages) {
+                    transform();
+                    store_v(buf ^ 1);
+                    if (s + 2 < stages) request(s + 2);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: per 32-cout block, M_p -> LDS [p][tile][cout], then A^T M A and the direct kernel's epilogue arithmetic -------
+    const int et = tid >> 3, cq = tid & 7;                                  // this thread's tile and four couts of the block
+    int e_o = 0, e_y = 0, e_x = 0;
+    bool e_live;
+    {
+        const int T = tile0 + et;
+        e_live = T < n_tiles;
+        const int Tq = e_live ? T : 0;
+        e_o = Tq / tiles_img;
+        const int rem = Tq - e_o * tiles_img;
+        const int ty = rem / TW;
+        e_y = 2 * ty;
+        e_x = 2 * (rem - ty * TW);
+    }
+    const int half = p.cout_pad >> 1;
+    auto activate = [](float v, int act) {
+        if (act == FIERY_ACT_RELU) return fmaxf(v, 0.f);
+        if (act == FIERY_ACT_SIGMOID) return sigmoidf(v);
+        if (act == FIERY_ACT_SWISH) return v * sigmoidf(v);
+        return v;
+    };
+    auto epilogue_block = [&](auto nb_c) {
+        constexpr int nb = decltype(nb_c)::value;
+        // (the K loop's last barrier has passed: the V stages are free)
+#pragma unroll
+        for (int pl = 0; pl < 4; ++pl)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const v16f& a = acc[pl][nb];
+                *reinterpret_cast<float4*>(&smem[((4 * wv + pl) * WT + m) * W_M_PITCH + 8 * g + 4 * hi]) =
+                    make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+            }
+        __syncthreads();
+        const int co = tile_n * WBN + nb * 32 + 4 * cq;
+        const bool upper = p.epi == FIERY_EPI_GRU_GATES && co >= half;
+        const int c_x = upper ? co - half : co;
+        if (e_live && c_x < p.cout_store) {
+            float4 mm[16];
+#pragma unroll
+            for (int pp = 0; pp < 16; ++pp) mm[pp] = *reinterpret_cast<const float4*>(&smem[(pp * WT + et) * W_M_PITCH + 4 * cq]);
+            // A^T M A, A^T = [1 1 1 0; 0 1 -1 -1]
+            float4 t[2][4];
+            auto add3 = [](const float4& a, const float4& b, const float4& c) { return make_float4(a.x + b.x + c.x, a.y + b.y + c.y, a.z + b.z + c.z, a.w + b.w + c.w); };
+            auto sub3 = [](const float4& a, const float4& b, const float4& c) { return make_float4(a.x - b.x - c.x, a.y - b.y - c.y, a.z - b.z - c.z, a.w - b.w - c.w); };
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t[0][j] = add3(mm[j], mm[4 + j], mm[8 + j]);
+                t[1][j] = sub3(mm[4 + j], mm[8 + j], mm[12 + j]);
+            }
+            const float4 sc = *reinterpret_cast<const float4*>(p.scale + co), sh = *reinterpret_cast<const float4*>(p.shift + co);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int y = e_y + a, x = e_x + b;
+                    if (y >= H || x >= W) continue;                     // (odd image sizes: the last row / column of blocks is half outside)
+                    float4 v = b == 0 ? add3(t[a][0], t[a][1], t[a][2]) : sub3(t[a][1], t[a][2], t[a][3]);
+                    const long long pix = static_cast<long long>(y) * W + x;
+                    if (p.img_bias) {
+                        long long brow = e_o;
+                        if (p.bias_border) brow = brow * 9 + (y == 0 ? 0 : y == H - 1 ? 2 : 1) * 3 + (x == 0 ? 0 : x == W - 1 ? 2 : 1);
+                        const float4 bz = *reinterpret_cast<const float4*>(p.img_bias + brow * p.cout_pad + co);
+                        v.x += bz.x;  v.y += bz.y;  v.z += bz.z;  v.w += bz.w;
+                    }
+                    v.x = fmaf(v.x, sc.x, sh.x);  v.y = fmaf(v.y, sc.y, sh.y);  v.z = fmaf(v.z, sc.z, sh.z);  v.w = fmaf(v.w, sc.w, sh.w);
+                    if (p.epi == FIERY_EPI_PLAIN) {
+                        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (p.res.ptr) r = *reinterpret_cast<const float4*>(p.res.ptr + e_o * p.res.istride + pix * p.res.ld + co);
+                        if (p.res_pre) { v.x += r.x;  v.y += r.y;  v.z += r.z;  v.w += r.w; }
+                        v.x = activate(v.x, p.act);  v.y = activate(v.y, p.act);  v.z = activate(v.z, p.act);  v.w = activate(v.w, p.act);
+                        if (!p.res_pre) { v.x += r.x;  v.y += r.y;  v.z += r.z;  v.w += r.w; }
+                        *reinterpret_cast<float4*>(p.out.ptr + e_o * p.out.istride + pix * p.out.ld + co) = v;
+                    } else if (p.epi == FIERY_EPI_GRU_GATES) {
+                        float4 g = make_float4(sigmoid_gate(v.x), sigmoid_gate(v.y), sigmoid_gate(v.z), sigmoid_gate(v.w));
+                        if (!upper) {
+                            *reinterpret_cast<float4*>(p.out.ptr + e_o * p.out.istride + pix * p.out.ld + co) = g;                   // update gate
+                        } else {                                                                                                      // (1 - reset) * state
+                            const float4 h = *reinterpret_cast<const float4*>(p.aux0.ptr + e_o * p.aux0.istride + pix * p.aux0.ld + c_x);
+                            g.x = (1.0f - g.x) * h.x;  g.y = (1.0f - g.y) * h.y;  g.z = (1.0f - g.z) * h.z;  g.w = (1.0f - g.w) * h.w;
+                            *reinterpret_cast<float4*>(p.out2.ptr + e_o * p.out2.istride + pix * p.out2.ld + c_x) = g;
+                        }
+                    } else {                                                                                                          // FIERY_EPI_GRU_OUT
+                        const float4 u = *reinterpret_cast<const float4*>(p.aux0.ptr + e_o * p.aux0.istride + pix * p.aux0.ld + co);
+                        const float4 h = *reinterpret_cast<const float4*>(p.aux1.ptr + e_o * p.aux1.istride + pix * p.aux1.ld + co);
+                        float4 hn;
+                        { const float a1 = (1.0f - u.x) * h.x, b1 = u.x * fmaxf(v.x, 0.f); hn.x = a1 + b1; }
+                        { const float a1 = (1.0f - u.y) * h.y, b1 = u.y * fmaxf(v.y, 0.f); hn.y = a1 + b1; }
+                        { const float a1 = (1.0f - u.z) * h.z, b1 = u.z * fmaxf(v.z, 0.f); hn.z = a1 + b1; }
+                        { const float a1 = (1.0f - u.w) * h.w, b1 = u.w * fmaxf(v.w, 0.f); hn.w = a1 + b1; }
+                        *reinterpret_cast<float4*>(p.out.ptr + e_o * p.out.istride + pix * p.out.ld + co) = hn;
+                        if (p.out2.ptr) *reinterpret_cast<float4*>(p.out2.ptr + e_o * p.out2.istride + pix * p.out2.ld + co) = hn;
+                    }
+                }
+        }
+    };
+    epilogue_block(std::integral_constant<int, 0>{});
+    __syncthreads();                                                // everyone has read the first block before the second overwrites it
+    epilogue_block(std::integral_constant<int, 1>{});
+}
+
+}  // namespace
+
+size_t conv_winograd_packed_floats(int cout, int cin_units) {
+    return static_cast<size_t>(wino_packed_floats((cout + 63) / 64 * 64, cin_units * 8));
+}
+
+int conv_winograd_pack(const float* w, int cout, int cin_total, const ChanInverse& inv, int cin_units, float* packed, hipStream_t stream) {
+    const long long total = wino_packed_floats((cout + 63) / 64 * 64, cin_units * 8);
+    hipLaunchKernelGGL(k_pack_winograd, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, stream, w, cout, cin_total, inv, cin_units,
+                       total, packed);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// p.w = the Winograd-packed weights; p.M etc. as for the direct form
+bool conv_launch_winograd(const ConvP& p, hipStream_t stream) {
+    const int TH = (p.Hout + 1) / 2, TW = (p.Wout + 1) / 2;
+    const long long tiles = static_cast<long long>(p.n_img) * TH * TW;
+    const dim3 grid(static_cast<unsigned>((tiles + WT - 1) / WT), static_cast<unsigned>(p.cout_pad / WBN));
+    hipLaunchKernelGGL(k_conv_winograd, grid, dim3(256), 0, stream, p);
+    return true;
+}
+
+}  // namespace fiery

@@ -66,6 +66,7 @@ class ConvDesc(C.Structure):
         ('weights3', C.c_void_p), ('scale3', C.c_void_p), ('shift3', C.c_void_p), ('act3', C.c_int32), ('out3', Nhwc),
         ('tile_m', C.c_int32), ('img_bias_border', C.c_int32), ('heads', ConvHeads),
         ('weights_bf16', C.c_void_p), ('precision', C.c_int32),
+        ('weights_winograd', C.c_void_p), ('winograd', C.c_int32),
         ('stream_k', C.c_int32), ('sk_workspace', C.c_void_p), ('sk_workspace_bytes', C.c_int64),
         ('sk_counters', C.c_void_p), ('sk_counters_len', C.c_int32),
     ]
@@ -127,6 +128,8 @@ _SIGNATURES = {
     'fiery_conv_fwd': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     'fiery_conv_pack_weights_bf16': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_int32_p, C.c_int, C.c_void_p, C.c_void_p]),
     'fiery_conv_precision_used': (C.c_int, [C.POINTER(ConvDesc)]),
+    'fiery_conv_winograd_packed_floats': (C.c_size_t, [C.c_int, C.c_int]),
+    'fiery_conv_pack_weights_winograd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_void_p]),
     'fiery_conv_stream_k_plan': (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     'fiery_conv_wgrad': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int64] + [C.c_int] * 11 +
                          [C.c_void_p, C.c_void_p]),
@@ -428,6 +431,14 @@ class Lib:
         cmap = (C.c_int32 * cin_total)(*chan_map)
         self.check(self.dll.fiery_conv_pack_weights_bf16(_ptr(w), cout, cin_total, taps, cmap, cin_units, _ptr(packed),
                                                          _stream_of(packed)))
+        return packed
+
+    def conv_pack_weights_winograd(self, w, cout, cin_total, chan_map, cin_units):
+        """w (cout, cin_total, 9) f32 -> the Winograd F(2x2, 3x3) image of the weights (G g G^T in fp64, rounded once)."""
+        n = self.dll.fiery_conv_winograd_packed_floats(cout, cin_units)
+        packed = torch.empty(n, dtype=torch.float32, device=w.device)
+        cmap = (C.c_int32 * cin_total)(*chan_map)
+        self.check(self.dll.fiery_conv_pack_weights_winograd(_ptr(w), cout, cin_total, cmap, cin_units, _ptr(packed), _stream_of(packed)))
         return packed
 
     def conv_precision_used(self, desc):

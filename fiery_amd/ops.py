@@ -148,6 +148,13 @@ class ConvOp:
             self.packed_bf16 = lib.conv_pack_weights_bf16(w.view(self.cout, self.cin_total, taps), self.cout, self.cin_total,
                                                           taps, list(chan_map), cin_units)
         self.cout_pad = round_up(self.cout, 32)
+        # Winograd F(2x2, 3x3) image of the weights for the layers that form covers (3 x 3 / stride 1 / 'same', whole 16-channel
+        # stages per source, 64-cout tiles; fp32 only): a candidate form of `_pick_tile`
+        self.packed_winograd = None
+        if (WINOGRAD and self.precision == native.PRECISION_F32 and (self.kT, self.kH, self.kW) == (1, 3, 3) and stride == 1 and
+                (self.padH, self.padW) == (1, 1) and self.cout_pad % 64 == 0 and all(u % 2 == 0 for u in self.units)):
+            self.packed_winograd = lib.conv_pack_weights_winograd(w.view(self.cout, self.cin_total, taps), self.cout, self.cin_total,
+                                                                  list(chan_map), cin_units)
         if torch.is_tensor(scale) and scale.device == w.device and scale.numel() == self.cout_pad:
             self.scale, self.shift = scale, shift          # already padded, already resident
         else:
@@ -219,6 +226,10 @@ class ConvOp:
         return ((H + 2 * self.padH - self.kH) // self.stride + 1, (W + 2 * self.padW - self.kW) // self.stride + 1)
 
     def _set_form(self, d, form, sk=None):
+        d.winograd = int(form == 'wino')
+        d.weights_winograd = self.packed_winograd.data_ptr() if form == 'wino' else None
+        if form == 'wino':
+            form = 0
         d.tile_m, d.stream_k = (128, 1) if form == 'sk' else (form, 0)
         if form == 'sk':
             d.sk_workspace, d.sk_workspace_bytes = sk['ws'].data_ptr(), sk['ws'].numel() * 4
@@ -241,12 +252,14 @@ class ConvOp:
         key = (out.n_img, out.H, out.W)
         choice = self._tile_m.get(key) if self.force_form is None else self.force_form
         if choice is None and FORCE_FORM:
-            choice = 'sk' if FORCE_FORM == 'sk' else int(FORCE_FORM)
+            choice = FORCE_FORM if FORCE_FORM in ('sk', 'wino') else int(FORCE_FORM)
+        if choice == 'wino' and self.packed_winograd is None:
+            choice = 0
         sk = _stream_k_workspace(self.lib, d, out.tensor) if (choice == 'sk' or choice is None) else None
         if choice is None:
             if not _autotune_enabled(out.tensor):
                 return                                 # library heuristic (and nothing cached: tune when possible)
-            forms = [64, 128] + (['sk'] if sk is not None else [])
+            forms = [64, 128] + (['sk'] if sk is not None else []) + (['wino'] if self.packed_winograd is not None else [])
             times = {f: float('inf') for f in forms}
             for _trial in range(2):                    # alternate the candidates, keep each one's best trial
                 for form in forms:
@@ -331,6 +344,10 @@ class ConvOp:
         used = 'f32'
         if PROFILE_SINK is not None and d.precision == native.PRECISION_BF16:
             used = 'bf16' if self.lib.conv_precision_used(d) == native.PRECISION_BF16 else 'f32'
+        if d.winograd:
+            used = 'f32 winograd'
+        elif d.stream_k:
+            used = 'f32 stream-K'
         profiled('conv_igemm', flops, out.tensor, lambda: self.lib.conv_fwd(d, out.tensor),
                  detail=(self.kT, self.kH, self.kW, self.stride, self.cin_total, self.cout, out.n_img, out.H, out.W, used))
 
@@ -343,7 +360,8 @@ _SK_WORKSPACES = {}
 SK_WORKSPACE_BYTES = 64 << 20
 SK_COUNTERS = 1 << 17
 STREAM_K = os.environ.get('FIERY_STREAM_K', '1') != '0'
-FORCE_FORM = os.environ.get('FIERY_CONV_FORM')      # A/B runs: '64', '128' or 'sk' for every launch that has the form, no timing
+FORCE_FORM = os.environ.get('FIERY_CONV_FORM')      # A/B runs: '64', '128', 'sk' or 'wino' for every launch that has the form, no timing
+WINOGRAD = os.environ.get('FIERY_CONV_WINOGRAD', '1') != '0'
 
 
 def _stream_k_workspace(lib, d, t):

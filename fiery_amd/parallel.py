@@ -19,6 +19,22 @@ import torch
 import torch.distributed as dist
 
 
+# When a list is installed here (bench.py does, for its instrumented steps), every exchange appends (start_event, end_event,
+# bytes_received) recorded on the stream the collective is enqueued on.
+EXCHANGE_SINK = None
+
+
+def _timed_exchange(fn, bytes_received, device):
+    if EXCHANGE_SINK is None or torch.device(device).type != 'cuda':
+        return fn()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    out = fn()
+    end.record()
+    EXCHANGE_SINK.append((start, end, bytes_received))
+    return out
+
+
 def block_range(n_items, world, rank):
     """Balanced contiguous partition: [lo, hi) of `n_items` owned by `rank`; every rank gets floor or ceil of
     n_items / world items (9 samples on 8 ranks: one rank takes two, nobody idles while another holds a double share)."""
@@ -51,6 +67,8 @@ class FrameExchange:
             rows.append(r * self.per + (i - block_range(n_items, self.world, r)[0]))
         self.row_of = rows
         self._index = {}
+        row_bytes = self.send[0].numel() * self.send.element_size()
+        self.bytes_received = (n_items - (self.hi - self.lo)) * row_bytes      # rows of the other ranks (padding not counted)
 
     def local_out(self):
         """Where this rank's items go (rows [0, hi - lo) of the send buffer): hand it to the producer as `out=`."""
@@ -60,7 +78,7 @@ class FrameExchange:
         if self.world == 1 and not dist.is_initialized():
             self.recv.copy_(self.send)
         else:
-            dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+            _timed_exchange(lambda: dist.all_gather_into_tensor(self.recv, self.send, group=self.group), self.bytes_received, self.recv.device)
         return self.recv
 
     def rows(self, lo, hi):
@@ -120,7 +138,8 @@ class FrameScatter:
         n_out = sum(self.out_splits)
         if self.world == 1:
             return self.send[:n_out]                                       # everything stays where the kernel wrote it
-        dist.all_to_all_single(self.recv[:n_out], self.send[:self.hi - self.lo], self.out_splits, self.in_splits, group=self.group)
+        _timed_exchange(lambda: dist.all_to_all_single(self.recv[:n_out], self.send[:self.hi - self.lo], self.out_splits, self.in_splits,
+                                                       group=self.group), self.bytes_received, self.recv.device)
         return self.recv[:n_out]
 
 
@@ -250,3 +269,34 @@ def sharded_bev_forward(model, K, E, ego, lifted=None, depth_logits=None, featur
         sharder = model._sharder = ShardedBevPath(group, layout, exchange)
     out = sharder.run(B, rf, pool_frames, stack, frame_shape=frame_shape, device=K.device)
     return out, owned.get('range')
+
+
+def sharded_bev_forward_graph(model, K, E, ego, lifted=None, depth_logits=None, features=None, group=None, noise=None,
+                              layout='auto', exchange='all_gather'):
+    """`sharded_bev_forward` replayed from a captured hipGraph: the exchange of the 'frames' layout - the RCCL all-gather /
+    all-to-all-v, enqueued by torch.distributed on the capturing stream - is a node of the graph between the pooling kernel
+    and the BEV stack, so a step is ONE graph launch per rank like the batch layout's (round 4 measured the eager form of this
+    layout 14 % behind the replayed batch layout at one rank: host enqueue of ~130 launches).  Every rank captures and replays
+    in step (the collective is part of each rank's graph).  Keyed on the argument buffers like `Fiery.bev_forward_graph`; the
+    returned tensors belong to the graph.  reference call site: /root/reference/train.py:34-43 (DDP over the batch)."""
+    model._require_eval()
+    args = dict(K=K, E=E, ego=ego, lifted=lifted, depth_logits=depth_logits, features=features, noise=noise)
+    key = ('sharded', layout, exchange, id(group), model._engine_generation, model.sample_streams, model.camera_matrix_mode,
+           model.warp_transform_mode) + tuple((k,) if v is None else (k, v.data_ptr(), tuple(v.shape), tuple(v.stride()), v.dtype)
+                                              for k, v in args.items())
+    entry = model._graphs.get(key)
+    if entry is None:
+        call = lambda: sharded_bev_forward(model, K, E, ego, lifted=lifted, depth_logits=depth_logits, features=features, group=group,
+                                           noise=noise, layout=layout, exchange=exchange)
+        with torch.no_grad():
+            call()                                    # eager once: buffers, workspaces, tile choices, the communicator
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            # (thread-local capture mode: the process group's watchdog thread may query events while this thread captures)
+            with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                out, owned = call()
+        while len(model._graphs) >= 4:
+            model._graphs.pop(next(iter(model._graphs)))
+        entry = model._graphs[key] = (graph, out, owned, args)
+    entry[0].replay()
+    return entry[1], entry[2]

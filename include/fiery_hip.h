@@ -338,6 +338,13 @@ typedef struct {
      * summation split).  Taken only by launches the form covers (fiery_conv_stream_k_plan says which, and what they need:
      * fp32, scalar-addressed loop, 64- or 128-wide cout tiles, no chained 1x1, no heads); others ignore the request.
      * sk_counters: zero before the first launch; every launch leaves them zero.  One workspace per stream in flight. */
+    /* WINOGRAD F(2x2, 3x3) (round 5): winograd != 0 with weights_winograd (fiery_conv_pack_weights_winograd) asks for the form
+     * that computes every 2 x 2 output block from a 4 x 4 input block with 16 multiplies per (cin, cout) instead of 36; taken
+     * by fp32 launches of 3 x 3 / stride 1 / 'same' layers (kT = 1) with whole 16-channel stages per source, cout_pad % 64 == 0,
+     * 16-byte addressable tensors, the plain or GRU epilogues, no chained 1x1 - others ignore the request.  Results differ
+     * from the direct form by fp32 rounding (another order of additions; measured 8e-6 on the hot path's outputs). */
+    const float* weights_winograd;
+    int32_t winograd;
     int32_t stream_k;
     void* sk_workspace;
     int64_t sk_workspace_bytes;
@@ -361,6 +368,12 @@ int fiery_conv_pack_weights(const float* w, int cout, int cin_total, int taps,
 int fiery_conv_pack_weights_bf16(const float* w, int cout, int cin_total, int taps,
                                  const int32_t* chan_map /* host */, int cin_units,
                                  void* packed, fiery_stream_t stream);
+
+/* The Winograd F(2x2, 3x3) image of a 3 x 3 convolution's weights W[cout][cin_total][9]: U = G g G^T per (cout, cin) in fp64,
+ * rounded once, packed [cout / 64][16 transform points][cin_pad / 4][64][4]; fiery_conv_winograd_packed_floats(...) floats. */
+size_t fiery_conv_winograd_packed_floats(int cout, int cin_units);
+int fiery_conv_pack_weights_winograd(const float* w, int cout, int cin_total, const int32_t* chan_map /* host */, int cin_units,
+                                     float* packed, fiery_stream_t stream);
 
 int fiery_conv_fwd(const fiery_conv_desc* desc /* host */, fiery_stream_t stream);
 

@@ -628,3 +628,95 @@ def test_stream_k_form_equals_the_tile_form(sim, monkeypatch, case, wgs):
     out2 = Buf.alloc(*shape, 'cpu')
     run(op, out2)
     assert torch.equal(out2.to_nchw(), outs['sk'])
+
+
+@pytest.mark.parametrize('case', ['64->128 relu + residual, odd size', 'two sources -> gates', 'two sources -> GRU out', '32->64 border-class bias',
+                                  '16->256 sequence views', '48->64 cout 40 stored'])
+def test_winograd_form_equals_torch(sim, case):
+    """Winograd F(2x2, 3x3) (`fiery_conv_desc.winograd`, csrc/conv_winograd.hip, round 5) against torch's direct convolution:
+    odd image sizes (half-outside blocks), tiles that straddle images and end ragged, two sources, every epilogue kind the
+    form covers, the border-class bias, several cout tiles, strided image views.  Tolerance: the transforms reorder the sums
+    (fp32), so 2e-5 relative instead of the direct form's 1e-5."""
+    g = torch.Generator().manual_seed(len(case))
+    WTOL = dict(rtol=2e-5, atol=2e-5)
+
+    def check(op, run, want, shape, cout):
+        assert op.packed_winograd is not None
+        outs = {}
+        for form in (128, 'wino'):
+            op.force_form = form
+            out = Buf.alloc(*shape, 'cpu')
+            run(op, out)
+            outs[form] = out.to_nchw()[:, :cout]
+        assert torch.allclose(outs[128], want, **TOL)
+        assert torch.allclose(outs['wino'], want, **WTOL), (outs['wino'] - want).abs().max()
+        return outs
+
+    if case == '64->128 relu + residual, odd size':
+        x = torch.randn(3, 64, 13, 25, generator=g)
+        w = torch.randn(128, 64, 3, 3, generator=g) / 24
+        sc, sh = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g)
+        res = torch.randn(3, 128, 13, 25, generator=g)
+        for pre in (False, True):
+            op = ConvOp(sim, w, identity_chan_map(64), (8, 0), sc, sh, 'cpu', act=native.ACT_RELU, res_before_act=pre, tune=True)
+            rb = _to_buf(res)
+            y = F.conv2d(x, w, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+            want = F.relu(y + res) if pre else F.relu(y) + res
+            check(op, lambda o, out: o([_to_buf(x)], out, res=rb), want, (3, 13, 25, 128), 128)
+    elif case == 'two sources -> gates':
+        ch = 32
+        x, h = torch.randn(2, 64, 10, 12, generator=g), torch.randn(2, ch, 10, 12, generator=g)
+        wg = torch.randn(2 * ch, 64 + ch, 3, 3, generator=g) / 30
+        bg = torch.randn(2 * ch, generator=g) * 0.1
+        op = ConvOp(sim, wg, identity_chan_map(64) + identity_chan_map(ch, offset=64), (8, ch // 8), torch.ones(2 * ch), bg, 'cpu',
+                    epi=native.EPI_GRU_GATES, tune=True)
+        xb, hb = _to_buf(x), _to_buf(h)
+        pre = F.conv2d(torch.cat([x, h], 1), wg, padding=1) + bg.view(1, -1, 1, 1)
+        op.force_form = 'wino'
+        U, RH = Buf.alloc(2, 10, 12, ch, 'cpu'), Buf.alloc(2, 10, 12, ch, 'cpu')
+        op([xb, hb], U, out2=RH, aux0=hb)
+        assert torch.allclose(U.to_nchw(), torch.sigmoid(pre[:, :ch]), **WTOL)
+        assert torch.allclose(RH.to_nchw(), (1 - torch.sigmoid(pre[:, ch:])) * h, **WTOL)
+    elif case == 'two sources -> GRU out':
+        x, h = torch.randn(1, 32, 12, 15, generator=g), torch.randn(1, 64, 12, 15, generator=g)
+        u = torch.rand(1, 64, 12, 15, generator=g)
+        w = torch.randn(64, 96, 3, 3, generator=g) / 30
+        sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+        op = ConvOp(sim, w, identity_chan_map(32) + identity_chan_map(64, offset=32), (4, 8), sc, sh, 'cpu', act=native.ACT_RELU,
+                    epi=native.EPI_GRU_OUT, tune=True)
+        xb, hb, ub = _to_buf(x), _to_buf(h), _to_buf(u)
+        tilde = F.relu(F.conv2d(torch.cat([x, h], 1), w, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+        outs = check(op, lambda o, out: o([xb, hb], out, aux0=ub, aux1=hb), (1 - u) * h + u * tilde, (1, 12, 15, 64), 64)
+    elif case == '32->64 border-class bias':
+        n, H, W = 2, 9, 8
+        x = torch.randn(n, 32, H, W, generator=g)
+        w = torch.randn(64, 32, 3, 3, generator=g) / 17
+        bias = torch.randn(n, 9, 64, generator=g)
+        op = ConvOp(sim, w, identity_chan_map(32), (4, 0), torch.ones(64), torch.zeros(64), 'cpu', act=native.ACT_RELU, tune=True)
+        cls = lambda v, size: torch.where(v == 0, 0, torch.where(v == size - 1, 2, 1))
+        rows = cls(torch.arange(H), H).view(H, 1) * 3 + cls(torch.arange(W), W).view(1, W)
+        want = F.relu(F.conv2d(x, w, padding=1) + bias[:, rows].permute(0, 3, 1, 2))
+        check(op, lambda o, out: o([_to_buf(x)], out, img_bias=bias.contiguous(), img_bias_border=True), want, (n, H, W, 64), 64)
+    elif case == '16->256 sequence views':
+        B, T, H, W = 2, 3, 6, 7
+        seq = torch.randn(B * T, H, W, 16, generator=g)
+        sbuf = Buf(seq, B * T, H, W, 16)
+        w = torch.randn(256, 16, 3, 3, generator=g) * 0.1
+        op = ConvOp(sim, w, identity_chan_map(16), (2, 0), torch.ones(256), torch.zeros(256), 'cpu', tune=True)
+        dst = Buf.alloc(B * T, H, W, 256, 'cpu')
+        op.force_form = 'wino'
+        op([sbuf.images(1, B, step=T)], dst.images(1, B, step=T))
+        x_t = seq.view(B, T, H, W, 16)[:, 1].permute(0, 3, 1, 2)
+        got = dst.nhwc().view(B, T, H, W, 256)[:, 1].permute(0, 3, 1, 2)
+        assert torch.allclose(got, F.conv2d(x_t, w, padding=1), **WTOL)
+        assert dst.nhwc().view(B, T, H, W, 256)[:, 0].abs().max() == 0
+    else:
+        x = torch.randn(2, 48, 7, 9, generator=g)
+        w = torch.randn(40, 48, 3, 3, generator=g) / 20
+        op = ConvOp(sim, w, identity_chan_map(48), (6, 0), torch.ones(40), torch.zeros(40), 'cpu', tune=True)
+        out = Buf.alloc(2, 7, 9, 64, 'cpu')
+        out.tensor.fill_(7.0)
+        op.force_form = 'wino'
+        op([_to_buf(x)], out)
+        assert torch.allclose(out.to_nchw()[:, :40], F.conv2d(x, w, padding=1), **WTOL)
+        assert (out.to_nchw()[:, 40:] == 7.0).all(), 'padding couts are never stored'
