@@ -266,6 +266,8 @@ int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, ConvRunMode mode, 
     p.sk_tiles = 0;
     p.sk_ws = nullptr;
     p.sk_cnt = nullptr;
+    p.wmg_img = p.wmg_tw = 0;
+    p.wsh_img = p.wsh_tw = 0;
     for (int s = 0; s < 2; ++s) {
         // bytes from ptr to the end of the last row the launch may read: last batch element, last frame (output frame
         // T_out - 1 reads source frame T_out - 1 + t_in_add at its latest tap), last pixel, the source's channel units.
@@ -347,10 +349,10 @@ int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, ConvRunMode mode, 
         auto dense = [&](const fiery_nhwc& t) {
             return !t.ptr || (t.img_stride == hw * t.ld && p.M * t.ld * 4 < (1ll << 31));
         };
-        bool all_dense = dense(d->out) && dense(d->res) && dense(d->out2) && dense(d->aux0) && dense(d->aux1) && !p.bias_border &&
-                         (!d->weights3 || dense(d->out3));
-        if (const char* forced = getenv("FIERY_CONV_DENSE_EPILOGUE")) all_dense = all_dense && atoi(forced) != 0;     // A/B runs
-        if (all_dense) p.vec_epilogue |= 2;
+        bool tensors_dense = dense(d->out) && dense(d->res) && dense(d->out2) && dense(d->aux0) && dense(d->aux1) && (!d->weights3 || dense(d->out3));
+        if (const char* forced = getenv("FIERY_CONV_DENSE_EPILOGUE")) tensors_dense = tensors_dense && atoi(forced) != 0;     // A/B runs
+        if (tensors_dense && !p.bias_border) p.vec_epilogue |= 2;
+        if (tensors_dense) p.vec_epilogue |= 4;             // (bit 2: dense tensors whatever the bias form - the Winograd kernel's lean epilogue)
     }
     p.w2 = d->weights2;
     p.scale2 = d->scale2;
@@ -459,15 +461,26 @@ int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, ConvRunMode mode, 
     }
     // Winograd F(2x2, 3x3) form (conv_winograd.hip): the caller packed the transformed weights and asks for it; taken by fp32
     // launches of 3 x 3 / stride 1 / 'same' layers with whole 16-channel stages per source, 64-cout tiles, 16-byte addressable
-    // tensors, the plain or GRU epilogues - everything else ignores the request
+    // tensors, the plain, GRU or heads epilogues - everything else ignores the request
     const bool winograd = d->winograd != 0 && d->weights_winograd && variant == kConvAligned && d->kT == 1 && d->kH == 3 && d->kW == 3 &&
                           d->stride == 1 && d->padH == 1 && d->padW == 1 && d->Hin == d->Hout && d->Win == d->Wout && d->cout_pad % 64 == 0 &&
-                          cin_units % 2 == 0 && d->src[0].units % 2 == 0 && !d->weights2 && d->epi != FIERY_EPI_HEADS && (p.vec_epilogue & 1) &&
+                          cin_units % 2 == 0 && d->src[0].units % 2 == 0 && !d->weights2 && (p.vec_epilogue & 1) &&
                           d->precision != FIERY_PRECISION_BF16 && aligned16(d->weights_winograd) &&
                           static_cast<long long>(d->n_img_out) * ((d->Hout + 1) / 2) * ((d->Wout + 1) / 2) < (1ll << 30);
     const bool bf16 = !stream_k && !winograd && conv_takes_bf16(d, aligned, bm, bn, cin_units);
     if (!launch) return bf16 ? FIERY_PRECISION_BF16 : FIERY_PRECISION_F32;
     if (winograd) {
+        {
+            auto magic = [](long long div, unsigned* m, int* sh) {       // (as conv_magic above: exact for 0 <= g < 2^31)
+                int l = 0;
+                while ((1ll << l) < div) ++l;
+                *m = static_cast<unsigned>((1ull << (31 + l)) / static_cast<unsigned long long>(div) + 1ull);
+                *sh = 31 + l;
+            };
+            const int TH = (d->Hout + 1) / 2, TW = (d->Wout + 1) / 2;
+            magic(static_cast<long long>(TH) * TW, &p.wmg_img, &p.wsh_img);
+            magic(TW, &p.wmg_tw, &p.wsh_tw);
+        }
         p.w = d->weights_winograd;
         if (!conv_launch_winograd(p, hs)) return fail(FIERY_EINVAL, "conv_fwd: Winograd launch failed");
         return check_launch("conv_fwd (Winograd)");

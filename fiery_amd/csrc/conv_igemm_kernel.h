@@ -94,7 +94,8 @@ struct ConvP {
     const float* scale2;
     const float* shift2;
     int act2;
-    int vec_epilogue;     // bit 0: destinations / residual / bias rows are 16-byte addressable; bit 1: and dense (see store_rows)
+    int vec_epilogue;     // bit 0: destinations / residual / bias rows are 16-byte addressable; bit 1: and dense (see store_rows);
+                          // bit 2: dense tensors whether or not the bias has border classes (conv_winograd.hip)
     int bias_border;      // img_bias holds nine rows per image, chosen by the output pixel's border class
     HeadsP heads;         // FIERY_EPI_HEADS
     // stream-K launches (SK kernels): output tiles of the launch (pixel tiles x cout tiles), partial tiles' workspace
@@ -102,6 +103,9 @@ struct ConvP {
     int sk_tiles;
     float* sk_ws;
     int* sk_cnt;
+    // Winograd launches: exact division of a block index by the blocks per image / per block row (multiply + shift, as mg_hw)
+    unsigned wmg_img, wmg_tw;
+    int wsh_img, wsh_tw;
 };
 
 // kernel variants of one tile shape

@@ -38,6 +38,15 @@
 namespace fiery {
 namespace {
 
+#ifndef W_RING
+#define W_RING 16                 // register ring of weight pieces (8 or 16: it must divide the 16 pieces of a stage)
+#endif
+#ifndef W_INTERLEAVE
+#define W_INTERLEAVE 1            // the next stage's input transform dealt out between this stage's MFMA blocks (0: in one piece)
+#endif
+#ifndef W_EXP
+#define W_EXP 0                   // timing experiments (wrong results): 1 weights from one hot piece, 2 no input loads in the loop,
+#endif                            // 3 no transform / V stores in the loop, 4 no epilogue
 constexpr int WT = 32;            // tiles (2 x 2 output blocks) per workgroup
 constexpr int WBN = 64;           // couts per workgroup
 constexpr int WKC = 16;           // channels per stage
@@ -80,7 +89,13 @@ __global__ void k_pack_winograd(const float* __restrict__ w, int cout, int cin_t
     packed[i] = v;
 }
 
+// KIND: which epilogue the kernel carries - with all of them behind run-time switches the code after the K loop was 18,000
+// instructions with scalar registers spilled to vector lanes, and an epilogue's vector instructions are served one per MFMA of the
+// CU's other workgroup (~64 cycles each): 0 plain, act none / ReLU, no residual, no bias; 1 plain, anything; 2 GRU gates; 3 GRU
+// output (0-3: every tensor dense over its images - the lean path); 4 decoder heads; -1 everything, general addressing (fallback)
+template <int KIND>
 __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
+    constexpr bool LEAN = KIND >= 0 && KIND <= 4;
     __shared__ __attribute__((aligned(16))) float smem[W_SMEM_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 31, hi = lane >> 5;
@@ -100,21 +115,32 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
 
     // ---- this thread's input block: tile tt, channels 2 cp, 2 cp + 1 of the stage ------------------------------------------
     const int tt = tid >> 3, cp = tid & 7;
+    int e_o, e_y, e_x;              // the tile's image and top-left output pixel (kept for the epilogue)
+    bool e_live;
     int voff0, voff1;               // byte offsets of the block's top-left tap (y0 - 1 + 1 lead row ...) in the two sources
     unsigned tapmask = 0;           // bit 4 i + j: tap (i, j) lies inside the image
     {
         const int T = tile0 + tt;
         const bool live = T < n_tiles;
         const int Tq = live ? T : 0;
-        const int o = Tq / tiles_img, rem = Tq - o * tiles_img;
-        const int ty = rem / TW, tx = rem - ty * TW;
+        const int o = fast_div(Tq, p.wmg_img, p.wsh_img), rem = Tq - o * tiles_img;
+        const int ty = fast_div(rem, p.wmg_tw, p.wsh_tw), tx = rem - ty * TW;
         const int b = fast_div(o, p.mg_t, p.sh_t), tl = o - b * p.Tout;
         const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
-        if (live)
-            for (int i = 0; i < 4; ++i)
-                for (int j = 0; j < 4; ++j)
-                    if (static_cast<unsigned>(y0 + i) < static_cast<unsigned>(H) && static_cast<unsigned>(x0 + j) < static_cast<unsigned>(W))
-                        tapmask |= 1u << (4 * i + j);
+        e_live = live;                                     // (the epilogue's thread-to-tile mapping is this one)
+        e_o = o;
+        e_y = 2 * ty;
+        e_x = 2 * tx;
+        if (live) {                                        // valid rows x valid columns (ranges, no loop over the sixteen taps)
+            unsigned colm = 0, rowm = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                colm |= static_cast<unsigned>(x0 + j) < static_cast<unsigned>(W) ? 1u << j : 0u;
+                rowm |= static_cast<unsigned>(y0 + j) < static_cast<unsigned>(H) ? 1u << j : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tapmask |= (rowm >> i) & 1u ? colm << (4 * i) : 0u;
+        }
         // (the descriptors start one row and one pixel before the tensors: the top-left tap's offset is never negative)
         const int pos = (y0 + 1) * W + (x0 + 1);
         voff0 = 4 * (b * static_cast<int>(p.src[0].bstride) + (tl + p.tinadd) * static_cast<int>(p.src[0].tstride) + pos * p.src[0].ld + 2 * cp);
@@ -128,6 +154,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
     const int rowb0 = W * p.src[0].ld * 4, pixb0 = p.src[0].ld * 4, rowb1 = W * p.src[1].ld * 4, pixb1 = p.src[1].ld * 4;
 
     v2f d[16];                      // the 4 x 4 block (two channels per element), transformed in place
+    // (a wavefront whose eight tiles all lie inside the image - almost all do - needs no per-tap select: 16 vector instructions
+    // per stage less, and vector instructions are what the K loop pays for)
+    const bool interior = __ballot(tapmask != 0xFFFFu) == 0ull;
     auto request = [&](int s) {
         const bool second = s >= stages0;
         const int ch = 64 * (s - (second ? stages0 : 0));                  // bytes: 16 channels per stage
@@ -137,37 +166,45 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int v = (tapmask >> (4 * i + j)) & 1u ? vo : static_cast<int>(0x80000000u);     // outside: reads as zero
+                const int v = (interior || ((tapmask >> (4 * i + j)) & 1u)) ? vo : static_cast<int>(0x80000000u);     // outside: reads as zero
                 const auto raw = second ? __builtin_amdgcn_raw_buffer_load_b64(rs1, v, ch + i * rowb + j * pixb, 0)
                                         : __builtin_amdgcn_raw_buffer_load_b64(rs0, v, ch + i * rowb + j * pixb, 0);
                 __builtin_memcpy(&d[4 * i + j], &raw, 8);
             }
     };
-    // B^T d B in place (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]): columns, then rows - 32 packed adds
+    // B^T d B in place (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]): columns, then rows - 32 packed adds, in four parts
+    auto transform_part = [&](int part) {
+        if (part < 2) {
+#pragma unroll
+            for (int j = 2 * part; j < 2 * part + 2; ++j) {
+                const v2f d0 = d[j], d1 = d[4 + j], d2 = d[8 + j], d3 = d[12 + j];
+                d[j] = d0 - d2;
+                d[4 + j] = d1 + d2;
+                d[8 + j] = d2 - d1;
+                d[12 + j] = d1 - d3;
+            }
+        } else {
+#pragma unroll
+            for (int i = 2 * (part - 2); i < 2 * (part - 2) + 2; ++i) {
+                const v2f t0 = d[4 * i], t1 = d[4 * i + 1], t2 = d[4 * i + 2], t3 = d[4 * i + 3];
+                d[4 * i] = t0 - t2;
+                d[4 * i + 1] = t1 + t2;
+                d[4 * i + 2] = t2 - t1;
+                d[4 * i + 3] = t1 - t3;
+            }
+        }
+    };
     auto transform = [&]() {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const v2f d0 = d[j], d1 = d[4 + j], d2 = d[8 + j], d3 = d[12 + j];
-            d[j] = d0 - d2;
-            d[4 + j] = d1 + d2;
-            d[8 + j] = d2 - d1;
-            d[12 + j] = d1 - d3;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const v2f t0 = d[4 * i], t1 = d[4 * i + 1], t2 = d[4 * i + 2], t3 = d[4 * i + 3];
-            d[4 * i] = t0 - t2;
-            d[4 * i + 1] = t1 + t2;
-            d[4 * i + 2] = t2 - t1;
-            d[4 * i + 3] = t1 - t3;
-        }
+        for (int part = 0; part < 4; ++part) transform_part(part);
     };
     // V stage in LDS: [p][tile][16 k]; 16-byte slot q of a tile's row sits at q ^ ((tile >> 2) & 3)
     const int v_st = (tt * WKC + 4 * ((cp >> 1) ^ ((tt >> 2) & 3)) + 2 * (cp & 1));              // + p * WT * WKC + buf * W_V_FLOATS
-    auto store_v = [&](int buf) {
+    auto store_v_rows = [&](int buf, int i0, int i1) {                   // rows [i0, i1) of the transformed block: points 4 i .. 4 i + 3
 #pragma unroll
-        for (int pp = 0; pp < 16; ++pp) *reinterpret_cast<v2f*>(&smem[buf * W_V_FLOATS + pp * (WT * WKC) + v_st]) = d[pp];
+        for (int pp = 4 * i0; pp < 4 * i1; ++pp) *reinterpret_cast<v2f*>(&smem[buf * W_V_FLOATS + pp * (WT * WKC) + v_st]) = d[pp];
     };
+    auto store_v = [&](int buf) { store_v_rows(buf, 0, 4); };
     // operand reads: lane (m, hi) of k-group q reads slot 2 q + hi of tile m's row
     int v_rd[2];
 #pragma unroll
@@ -179,7 +216,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.w) + static_cast<long long>(tile_n) * 16 * Q * 256, 0, 16 * Q * 1024, 0x00020000);
     const int w_vo = (hi * 64 + m) * 16;
-    constexpr int RING = 8, AHEAD = 6;
+    // (the ring is deep: vmcnt counts loads in issue order, so a weight piece requested behind the next stage's 16 input loads
+    // cannot be waited for without waiting for those too - pieces are requested almost a stage before they are multiplied, by
+    // which time the input loads in front of them have long landed)
+    constexpr int RING = W_RING, AHEAD = W_RING - 2;
     float4 wr[RING];
     auto to_f4 = [](auto raw) {
         float4 f;
@@ -189,18 +229,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
     auto w_request = [&](int slot, int s, int piece) {                  // piece of stage s (past the end: any piece of the last stage)
         const int ss = s < stages ? s : stages - 1;
         const int q = piece >> 3, pl = (piece >> 1) & 3, nb = piece & 1;
-        const int soff = (((4 * wv + pl) * Q + 4 * ss + 2 * q) * 64 + nb * 32) * 16;
+        const int soff = W_EXP == 1 ? 0 : (((4 * wv + pl) * Q + 4 * ss + 2 * q) * 64 + nb * 32) * 16;
         wr[slot] = to_f4(__builtin_amdgcn_raw_buffer_load_b128(wrs, w_vo, soff, 0));
     };
 
+    // (no zero fill: the first MFMA of every accumulator block takes the constant 0 as its addend - 128 vector moves less in the
+    // prologue, which runs at one instruction per MFMA of the CU's other workgroup)
     v16f acc[4][2];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][nb][r] = 0.f;
-
     // ---- prologue: stage 0 into LDS, stage 1's block and the first weight pieces in flight ----------------------------------
     request(0);
 #pragma unroll
@@ -211,7 +246,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
     __syncthreads();
 
     auto comp = [](const float4& f, int j) { return j == 0 ? f.x : j == 1 ? f.y : j == 2 ? f.z : f.w; };
-    for (int s = 0; s < stages; ++s) {
+    v16f zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+    auto stage = [&](int s, auto first_c) {
+        constexpr bool FIRST = decltype(first_c)::value;
         const int buf = s & 1;
         const float* vb = smem + buf * W_V_FLOATS + (4 * wv) * (WT * WKC);
 #pragma unroll
@@ -223,8 +262,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
                 const float4 b0 = wr[piece % RING], b1 = wr[(piece + 1) % RING];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    acc[pl][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(b0, j), comp(a4, j), acc[pl][0], 0, 0, 0);
-                    acc[pl][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(b1, j), comp(a4, j), acc[pl][1], 0, 0, 0);
+                    const bool fresh = FIRST && q == 0 && j == 0;
+                    acc[pl][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(b0, j), comp(a4, j), fresh ? zero16 : acc[pl][0], 0, 0, 0);
+                    acc[pl][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(b1, j), comp(a4, j), fresh ? zero16 : acc[pl][1], 0, 0, 0);
                 }
                 // the two slots this point leaves take the pieces AHEAD further on (wrapping into the next stage)
 #pragma unroll
@@ -233,32 +273,36 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
                     if (nxt < 16) w_request(nxt % RING, s, nxt);
                     else w_request(nxt % RING, s + 1, nxt - 16);
                 }
-                // the next stage's block is transformed and stored half-way through this one (its loads were requested a
-                // stage ago), and the block after it requested at once
-                if (q == 0 && pl == 3 && s + 1 < stages) {
-                    transform();
-                    store_v(buf ^ 1);
-                    if (s + 2 < stages) request(s + 2);
+                // the next stage's block is transformed and stored in the first half of this one (its loads were requested half a
+                // stage ago), and the block after it requested as soon as the registers are free
+                if (s + 1 < stages) {
+#if W_INTERLEAVE
+                    if (q == 0) {
+                        if (W_EXP != 3) transform_part(pl);          // columns 0-1, 2-3, rows 0-1, 2-3
+                        if (pl == 2 && W_EXP != 3) store_v_rows(buf ^ 1, 0, 2);
+                        if (pl == 3) {
+                            if (W_EXP != 3) store_v_rows(buf ^ 1, 2, 4);
+                            if (s + 2 < stages && W_EXP != 2) request(s + 2);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#else
+                    if (q == 0 && pl == 3) {
+                        transform();
+                        store_v(buf ^ 1);
+                        if (s + 2 < stages) request(s + 2);
+                    }
+#endif
                 }
             }
         }
         __syncthreads();
-    }
+    };
+    stage(0, std::true_type{});
+    for (int s = 1; s < stages; ++s) stage(s, std::false_type{});
 
     // ---- epilogue: per 32-cout block, M_p -> LDS [p][tile][cout], then A^T M A and the direct kernel's epilogue arithmetic -------
-    const int et = tid >> 3, cq = tid & 7;                                  // this thread's tile and four couts of the block
-    int e_o = 0, e_y = 0, e_x = 0;
-    bool e_live;
-    {
-        const int T = tile0 + et;
-        e_live = T < n_tiles;
-        const int Tq = e_live ? T : 0;
-        e_o = Tq / tiles_img;
-        const int rem = Tq - e_o * tiles_img;
-        const int ty = rem / TW;
-        e_y = 2 * ty;
-        e_x = 2 * (rem - ty * TW);
-    }
+    const int et = tt, cq = cp;                                             // this thread's tile and four couts of the block
     const int half = p.cout_pad >> 1;
     auto activate = [](float v, int act) {
         if (act == FIERY_ACT_RELU) return fmaxf(v, 0.f);
@@ -266,6 +310,17 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
         if (act == FIERY_ACT_SWISH) return v * sigmoidf(v);
         return v;
     };
+    // FIERY_EPI_HEADS (models/decoder.py:30-51: Conv3x3 -> BN -> ReLU -> Conv1x1 (+ bias) [-> Sigmoid]): a workgroup's 64 couts are
+    // one head's hidden channels, which never leave the chip - a thread keeps, for its block's four pixels, the partial dot
+    // products of its hidden channels with the rows of the final 1x1 that read this group; the eight threads of a tile add them
+    // up at the end and one of them stores the rows' values to their pixel-contiguous planes
+    const bool heads = KIND == 4 || (KIND < 0 && p.epi == FIERY_EPI_HEADS);
+    const int epi = KIND == 0 || KIND == 1 ? FIERY_EPI_PLAIN : KIND == 2 ? FIERY_EPI_GRU_GATES : KIND == 3 ? FIERY_EPI_GRU_OUT : p.epi;
+    float hp[FIERY_MAX_HEAD_OUTPUTS][4];
+#pragma unroll
+    for (int o = 0; o < FIERY_MAX_HEAD_OUTPUTS; ++o)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hp[o][q] = 0.f;
     auto epilogue_block = [&](auto nb_c) {
         constexpr int nb = decltype(nb_c)::value;
         // (the K loop's last barrier has passed: the V stages are free)
@@ -279,9 +334,184 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
             }
         __syncthreads();
         const int co = tile_n * WBN + nb * 32 + 4 * cq;
-        const bool upper = p.epi == FIERY_EPI_GRU_GATES && co >= half;
+        const bool upper = epi == FIERY_EPI_GRU_GATES && co >= half;
         const int c_x = upper ? co - half : co;
-        if (e_live && c_x < p.cout_store) {
+        if constexpr (LEAN) {
+            // ---- the lean path (every tensor dense over its images, 16-byte rows): the epilogue's vector instructions are
+            // served one per MFMA of the CU's other workgroup (~64 cycles each), so their NUMBER is what
+            // the launch pays for - packed adds for the transform (48 per 16 outputs), one buffer offset per tensor with the
+            // block's four pixels as scalar offsets, no per-pixel address arithmetic.
+            const bool ch_ok = e_live && (KIND == 4 || c_x < p.cout_store);
+            v2f mlo[16], mhi[16];
+#pragma unroll
+            for (int pp = 0; pp < 16; ++pp) {
+                const float4 f = *reinterpret_cast<const float4*>(&smem[(pp * WT + et) * W_M_PITCH + 4 * cq]);
+                mlo[pp] = v2f{f.x, f.y};
+                mhi[pp] = v2f{f.z, f.w};
+            }
+            // A^T M A with A^T = [1 1 1 0; 0 1 -1 -1]: s = m1 + m2, d = m1 - m2, (m0 + s, d - m3) - columns, then rows
+            v2f ylo[4], yhi[4];
+            auto out_transform = [](const v2f (&mm)[16], v2f (&y)[4]) {
+                v2f t0[4], t1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const v2f sm = mm[4 + j] + mm[8 + j], df = mm[4 + j] - mm[8 + j];
+                    t0[j] = mm[j] + sm;
+                    t1[j] = df - mm[12 + j];
+                }
+                { const v2f sm = t0[1] + t0[2], df = t0[1] - t0[2]; y[0] = t0[0] + sm; y[1] = df - t0[3]; }
+                { const v2f sm = t1[1] + t1[2], df = t1[1] - t1[2]; y[2] = t1[0] + sm; y[3] = df - t1[3]; }
+            };
+            out_transform(mlo, ylo);
+            out_transform(mhi, yhi);
+            const float4 sc = *reinterpret_cast<const float4*>(p.scale + co), sh = *reinterpret_cast<const float4*>(p.shift + co);
+            const v2f sclo = v2f{sc.x, sc.y}, schi = v2f{sc.z, sc.w}, shlo = v2f{sh.x, sh.y}, shhi = v2f{sh.z, sh.w};
+            // this thread's byte offset of pixel (e_y, e_x) in a dense tensor of row length ld, channel c; the block's other
+            // pixels are scalar offsets away; pixels outside an odd-sized image (and tiles past the end) are pointed out of range
+            const int gp00 = (e_o * H + e_y) * W + e_x;
+            const bool v01 = e_x + 1 < W, v10 = e_y + 1 < H;
+            const bool whole = __ballot(!(v01 && v10)) == 0ull;          // (even image sizes: every block of the wavefront is whole)
+            auto rsrc_of = [&](const float* ptr, int ld_) {
+                return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ptr), 0, ptr ? static_cast<int>(p.M) * ld_ * 4 : 0, 0x00020000);
+            };
+            auto off_of = [&](int ld_, int c) { return ch_ok ? (gp00 * ld_ + c) * 4 : static_cast<int>(0x80000000u); };
+            auto ld4 = [&](__amdgpu_buffer_rsrc_t r, int vo, int q, int ld_) {
+                const bool ok = whole || q == 0 || (q == 1 ? v01 : q == 2 ? v10 : (v01 && v10));
+                return to_f4(__builtin_amdgcn_raw_buffer_load_b128(r, ok ? vo : static_cast<int>(0x80000000u), (q >> 1) * W * ld_ * 4 + (q & 1) * ld_ * 4, 0));
+            };
+            auto st4 = [&](__amdgpu_buffer_rsrc_t r, int vo, int q, int ld_, const float4& f) {
+                const bool ok = whole || q == 0 || (q == 1 ? v01 : q == 2 ? v10 : (v01 && v10));
+                decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0)) raw;
+                __builtin_memcpy(&raw, &f, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(raw, r, ok ? vo : static_cast<int>(0x80000000u), (q >> 1) * W * ld_ * 4 + (q & 1) * ld_ * 4, 0);
+                store_data_settle();                                // (the next pixel's packed arithmetic lands in the same registers)
+            };
+            const __amdgpu_buffer_rsrc_t r_out = rsrc_of(p.out.ptr, p.out.ld);
+            const int o_out = off_of(p.out.ld, co);
+            // per-image bias rows (the first SpatialGRU's folded constant input: plain AND gate / output epilogues carry it), with
+            // the nine border classes of a zero-padded 3 x 3 when asked for: added in front of the folded BatchNorm
+            if constexpr (KIND != 0) {
+                if (p.img_bias) {
+                    const float* bias_base = p.img_bias + (p.bias_border ? 9ll : 1ll) * e_o * p.cout_pad + co;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        int cls = 0;
+                        if (p.bias_border) {
+                            const int y = e_y + (q >> 1), x = e_x + (q & 1);
+                            cls = (y == 0 ? 0 : y >= H - 1 ? 2 : 1) * 3 + (x == 0 ? 0 : x >= W - 1 ? 2 : 1);
+                        }
+                        const float4 bz = *reinterpret_cast<const float4*>(bias_base + cls * p.cout_pad);
+                        ylo[q] = ylo[q] + v2f{bz.x, bz.y};
+                        yhi[q] = yhi[q] + v2f{bz.z, bz.w};
+                    }
+                }
+            }
+            // BatchNorm + (ReLU | nothing): max with 0 or with -inf - one instruction either way, no branch
+            const float floor_ = p.act == FIERY_ACT_RELU ? 0.f : -__builtin_inff();
+            if constexpr (KIND == 4) {
+                // decoder heads: hidden = act(BN(conv)) stays in registers; partial dot products with the rows of the final 1x1
+                // that read this 64-channel group
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const v2f lo = pk_fma(ylo[q], sclo, shlo), hi2 = pk_fma(yhi[q], schi, shhi);
+                    const float vx = fmaxf(pk_lo(lo), floor_), vy = fmaxf(pk_hi(lo), floor_), vz = fmaxf(pk_lo(hi2), floor_), vw = fmaxf(pk_hi(hi2), floor_);
+#pragma unroll
+                    for (int o = 0; o < FIERY_MAX_HEAD_OUTPUTS; ++o)
+                        if (o < p.heads.n_out && p.heads.group[o] == tile_n) {
+                            const float4 w4 = *reinterpret_cast<const float4*>(p.heads.w + o * 64 + nb * 32 + 4 * cq);
+                            hp[o][q] = fmaf(vw, w4.w, fmaf(vz, w4.z, fmaf(vy, w4.y, fmaf(vx, w4.x, hp[o][q]))));
+                        }
+                }
+                if (!ch_ok) {
+#pragma unroll
+                    for (int o = 0; o < FIERY_MAX_HEAD_OUTPUTS; ++o)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) hp[o][q] = 0.f;
+                }
+            } else if constexpr (KIND == 0) {
+                // (all four pixels are finished before the first store: see store_data_settle)
+                float4 fin[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const v2f lo = pk_fma(ylo[q], sclo, shlo), hi2 = pk_fma(yhi[q], schi, shhi);
+                    fin[q] = make_float4(fmaxf(pk_lo(lo), floor_), fmaxf(pk_hi(lo), floor_), fmaxf(pk_lo(hi2), floor_), fmaxf(pk_hi(hi2), floor_));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) st4(r_out, o_out, q, p.out.ld, fin[q]);
+            } else if constexpr (KIND == 1) {
+                const __amdgpu_buffer_rsrc_t r_res = rsrc_of(p.res.ptr, p.res.ld);
+                const int o_res = off_of(p.res.ld, co);
+                float4 r4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) r4[q] = p.res.ptr ? ld4(r_res, o_res, q, p.res.ld) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v2f lo = ylo[q], hi2 = yhi[q];
+                    lo = pk_fma(lo, sclo, shlo);
+                    hi2 = pk_fma(hi2, schi, shhi);
+                    const v2f rlo = v2f{r4[q].x, r4[q].y}, rhi = v2f{r4[q].z, r4[q].w};
+                    if (p.res_pre) { lo = lo + rlo;  hi2 = hi2 + rhi; }
+                    float4 v = make_float4(fmaxf(pk_lo(lo), floor_), fmaxf(pk_hi(lo), floor_), fmaxf(pk_lo(hi2), floor_), fmaxf(pk_hi(hi2), floor_));
+                    if (!p.res_pre && p.res.ptr) { v.x += r4[q].x;  v.y += r4[q].y;  v.z += r4[q].z;  v.w += r4[q].w; }
+                    r4[q] = v;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) st4(r_out, o_out, q, p.out.ld, r4[q]);
+            } else if constexpr (KIND == 2) {
+                const __amdgpu_buffer_rsrc_t r_h = rsrc_of(p.aux0.ptr, p.aux0.ld), r_o2 = rsrc_of(p.out2.ptr, p.out2.ld);
+                const int o_h = off_of(p.aux0.ld, c_x), o_o2 = off_of(p.out2.ld, c_x);
+                float4 h4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) h4[q] = upper ? ld4(r_h, o_h, q, p.aux0.ld) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const v2f lo = pk_fma(ylo[q], sclo, shlo), hi2 = pk_fma(yhi[q], schi, shhi);
+                    float4 g = make_float4(sigmoid_gate(pk_lo(lo)), sigmoid_gate(pk_hi(lo)), sigmoid_gate(pk_lo(hi2)), sigmoid_gate(pk_hi(hi2)));
+                    if (upper) {                                                                                                      // (1 - reset) * state
+                        g.x = (1.0f - g.x) * h4[q].x;  g.y = (1.0f - g.y) * h4[q].y;  g.z = (1.0f - g.z) * h4[q].z;  g.w = (1.0f - g.w) * h4[q].w;
+                    }
+                    h4[q] = g;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (upper) st4(r_o2, o_o2, q, p.out2.ld, h4[q]);
+                    else st4(r_out, o_out, q, p.out.ld, h4[q]);                                                                       // update gate
+                }
+            } else {                                                                                                                  // FIERY_EPI_GRU_OUT
+                const __amdgpu_buffer_rsrc_t r_u = rsrc_of(p.aux0.ptr, p.aux0.ld), r_h = rsrc_of(p.aux1.ptr, p.aux1.ld), r_o2 = rsrc_of(p.out2.ptr, p.out2.ld);
+                const int o_u = off_of(p.aux0.ld, co), o_h = off_of(p.aux1.ld, co), o_o2 = off_of(p.out2.ld, co);
+                float4 u4[4], h4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    u4[q] = ld4(r_u, o_u, q, p.aux0.ld);
+                    h4[q] = ld4(r_h, o_h, q, p.aux1.ld);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const v2f lo = pk_fma(ylo[q], sclo, shlo), hi2 = pk_fma(yhi[q], schi, shhi);
+                    const float4 v = make_float4(pk_lo(lo), pk_hi(lo), pk_lo(hi2), pk_hi(hi2));
+                    const float4 u = u4[q], h = h4[q];
+                    float4 hn;
+                    { const float a1 = (1.0f - u.x) * h.x, b1 = u.x * fmaxf(v.x, 0.f); hn.x = a1 + b1; }
+                    { const float a1 = (1.0f - u.y) * h.y, b1 = u.y * fmaxf(v.y, 0.f); hn.y = a1 + b1; }
+                    { const float a1 = (1.0f - u.z) * h.z, b1 = u.z * fmaxf(v.z, 0.f); hn.z = a1 + b1; }
+                    { const float a1 = (1.0f - u.w) * h.w, b1 = u.w * fmaxf(v.w, 0.f); hn.w = a1 + b1; }
+                    h4[q] = hn;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    st4(r_out, o_out, q, p.out.ld, h4[q]);
+                    if (p.out2.ptr) st4(r_o2, o_o2, q, p.out2.ld, h4[q]);
+                }
+            }
+            return;
+        }
+        if constexpr (!LEAN) {
+        if (e_live && (heads || c_x < p.cout_store)) {
             float4 mm[16];
 #pragma unroll
             for (int pp = 0; pp < 16; ++pp) mm[pp] = *reinterpret_cast<const float4*>(&smem[(pp * WT + et) * W_M_PITCH + 4 * cq]);
@@ -310,21 +540,32 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
                         v.x += bz.x;  v.y += bz.y;  v.z += bz.z;  v.w += bz.w;
                     }
                     v.x = fmaf(v.x, sc.x, sh.x);  v.y = fmaf(v.y, sc.y, sh.y);  v.z = fmaf(v.z, sc.z, sh.z);  v.w = fmaf(v.w, sc.w, sh.w);
-                    if (p.epi == FIERY_EPI_PLAIN) {
+                    if (heads) {
+                        v.x = activate(v.x, p.act);  v.y = activate(v.y, p.act);  v.z = activate(v.z, p.act);  v.w = activate(v.w, p.act);
+#pragma unroll
+                        for (int o = 0; o < FIERY_MAX_HEAD_OUTPUTS; ++o)
+                            if (o < p.heads.n_out && p.heads.group[o] == tile_n) {
+                                const float4 w4 = *reinterpret_cast<const float4*>(p.heads.w + o * 64 + nb * 32 + 4 * cq);
+                                hp[o][2 * a + b] = fmaf(v.w, w4.w, fmaf(v.z, w4.z, fmaf(v.y, w4.y, fmaf(v.x, w4.x, hp[o][2 * a + b]))));
+                            }
+                    } else if (epi == FIERY_EPI_PLAIN) {
                         float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (p.res.ptr) r = *reinterpret_cast<const float4*>(p.res.ptr + e_o * p.res.istride + pix * p.res.ld + co);
                         if (p.res_pre) { v.x += r.x;  v.y += r.y;  v.z += r.z;  v.w += r.w; }
                         v.x = activate(v.x, p.act);  v.y = activate(v.y, p.act);  v.z = activate(v.z, p.act);  v.w = activate(v.w, p.act);
                         if (!p.res_pre) { v.x += r.x;  v.y += r.y;  v.z += r.z;  v.w += r.w; }
                         *reinterpret_cast<float4*>(p.out.ptr + e_o * p.out.istride + pix * p.out.ld + co) = v;
-                    } else if (p.epi == FIERY_EPI_GRU_GATES) {
+                        store_data_settle();
+                    } else if (epi == FIERY_EPI_GRU_GATES) {
                         float4 g = make_float4(sigmoid_gate(v.x), sigmoid_gate(v.y), sigmoid_gate(v.z), sigmoid_gate(v.w));
                         if (!upper) {
                             *reinterpret_cast<float4*>(p.out.ptr + e_o * p.out.istride + pix * p.out.ld + co) = g;                   // update gate
+                            store_data_settle();
                         } else {                                                                                                      // (1 - reset) * state
                             const float4 h = *reinterpret_cast<const float4*>(p.aux0.ptr + e_o * p.aux0.istride + pix * p.aux0.ld + c_x);
                             g.x = (1.0f - g.x) * h.x;  g.y = (1.0f - g.y) * h.y;  g.z = (1.0f - g.z) * h.z;  g.w = (1.0f - g.w) * h.w;
                             *reinterpret_cast<float4*>(p.out2.ptr + e_o * p.out2.istride + pix * p.out2.ld + c_x) = g;
+                            store_data_settle();
                         }
                     } else {                                                                                                          // FIERY_EPI_GRU_OUT
                         const float4 u = *reinterpret_cast<const float4*>(p.aux0.ptr + e_o * p.aux0.istride + pix * p.aux0.ld + co);
@@ -335,14 +576,40 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
                         { const float a1 = (1.0f - u.z) * h.z, b1 = u.z * fmaxf(v.z, 0.f); hn.z = a1 + b1; }
                         { const float a1 = (1.0f - u.w) * h.w, b1 = u.w * fmaxf(v.w, 0.f); hn.w = a1 + b1; }
                         *reinterpret_cast<float4*>(p.out.ptr + e_o * p.out.istride + pix * p.out.ld + co) = hn;
+                        store_data_settle();
                         if (p.out2.ptr) *reinterpret_cast<float4*>(p.out2.ptr + e_o * p.out2.istride + pix * p.out2.ld + co) = hn;
+                        store_data_settle();
                     }
                 }
         }
+        }
     };
+    if (W_EXP == 4) {
+        if (acc[0][0][0] + acc[1][1][3] + acc[2][0][5] + acc[3][1][7] == 1.234e-30f) p.out.ptr[tid] = 0.f;
+        return;
+    }
     epilogue_block(std::integral_constant<int, 0>{});
     __syncthreads();                                                // everyone has read the first block before the second overwrites it
     epilogue_block(std::integral_constant<int, 1>{});
+    if (heads) {
+#pragma unroll
+        for (int o = 0; o < FIERY_MAX_HEAD_OUTPUTS; ++o)
+            if (o < p.heads.n_out && p.heads.group[o] == tile_n) {                 // (wave-uniform: every lane takes part in the exchange)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v = hp[o][q];
+                    v += __shfl_xor(v, 1);
+                    v += __shfl_xor(v, 2);
+                    v += __shfl_xor(v, 4);
+                    const int y = e_y + (q >> 1), x = e_x + (q & 1);
+                    if (cq == 0 && e_live && y < H && x < W) {
+                        v += p.heads.bias[o];
+                        if (p.heads.sigmoid[o]) v = sigmoidf(v);
+                        p.heads.out[o][e_o * p.heads.istride[o] + static_cast<long long>(y) * W + x] = v;
+                    }
+                }
+            }
+    }
 }
 
 }  // namespace
@@ -363,7 +630,22 @@ bool conv_launch_winograd(const ConvP& p, hipStream_t stream) {
     const int TH = (p.Hout + 1) / 2, TW = (p.Wout + 1) / 2;
     const long long tiles = static_cast<long long>(p.n_img) * TH * TW;
     const dim3 grid(static_cast<unsigned>((tiles + WT - 1) / WT), static_cast<unsigned>(p.cout_pad / WBN));
-    hipLaunchKernelGGL(k_conv_winograd, grid, dim3(256), 0, stream, p);
+    const bool dense = (p.vec_epilogue & 4) != 0;          // images back to back, < 2 GB per tensor, 16-byte rows (conv_run)
+    int kind = -1;
+    if (p.epi == FIERY_EPI_HEADS) kind = (p.act == FIERY_ACT_NONE || p.act == FIERY_ACT_RELU) ? 4 : -1;
+    else if (dense && p.epi == FIERY_EPI_PLAIN && (p.act == FIERY_ACT_NONE || p.act == FIERY_ACT_RELU))
+        kind = (!p.res.ptr && !p.img_bias) ? 0 : 1;
+    else if (dense && p.epi == FIERY_EPI_GRU_GATES) kind = 2;
+    else if (dense && p.epi == FIERY_EPI_GRU_OUT) kind = 3;
+    if (const char* forced = getenv("FIERY_WINOGRAD_GENERAL_EPILOGUE")) if (atoi(forced) != 0) kind = -1;      // tests
+    switch (kind) {
+        case 0: hipLaunchKernelGGL(k_conv_winograd<0>, grid, dim3(256), 0, stream, p); break;
+        case 1: hipLaunchKernelGGL(k_conv_winograd<1>, grid, dim3(256), 0, stream, p); break;
+        case 2: hipLaunchKernelGGL(k_conv_winograd<2>, grid, dim3(256), 0, stream, p); break;
+        case 3: hipLaunchKernelGGL(k_conv_winograd<3>, grid, dim3(256), 0, stream, p); break;
+        case 4: hipLaunchKernelGGL(k_conv_winograd<4>, grid, dim3(256), 0, stream, p); break;
+        default: hipLaunchKernelGGL(k_conv_winograd<-1>, grid, dim3(256), 0, stream, p); break;
+    }
     return true;
 }
 

@@ -117,6 +117,17 @@ __device__ __forceinline__ void wave_sync() {
 // barrier + ticket that hands sc0 sc1 (written-through) partial results to another workgroup.
 __device__ __forceinline__ void vmem_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// After a 16-byte buffer store whose data registers the next vector instruction overwrites: the store reads its data some
+// cycles after issue, and a packed-fp32 write (v_pk_fma_f32) of those registers right behind it was seen to reach memory in
+// their place (round 5, conv_winograd.hip: the second and third pixel of a block swapped in some lanes) - the compiler's
+// hazard recogniser does not cover this pair, so the stores are followed by explicit wait states.
+// (sched_barrier on both sides: an asm statement alone does not keep vector arithmetic from being scheduled across it)
+__device__ __forceinline__ void store_data_settle() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 3" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // A value the optimiser must take as it finds it at this point (per-lane / wave-uniform): what is derived from it inside a
 // loop body is recomputed there instead of being hoisted out and kept in registers across the body.
 __device__ __forceinline__ void opaque_v(int& v) { asm volatile("" : "+v"(v)); }

@@ -247,19 +247,23 @@ class ConvOp:
         inputs, so the extra launches leave the same result behind (up to the last bits between stream-K and the tile
         forms: another summation split)."""
         self._set_form(d, 0)
-        if self.cout_pad % 64 != 0 or self.chain is not None or self.heads is not None or not self.tune:
+        if self.cout_pad % 64 != 0 or self.chain is not None or not self.tune:
             return                                     # one tile shape only (or: library heuristic)
+        if self.heads is not None and self.packed_winograd is None:
+            return                                     # (the heads' direct form has one tile shape)
         key = (out.n_img, out.H, out.W)
         choice = self._tile_m.get(key) if self.force_form is None else self.force_form
         if choice is None and FORCE_FORM:
             choice = FORCE_FORM if FORCE_FORM in ('sk', 'wino') else int(FORCE_FORM)
         if choice == 'wino' and self.packed_winograd is None:
             choice = 0
-        sk = _stream_k_workspace(self.lib, d, out.tensor) if (choice == 'sk' or choice is None) else None
+        sk = _stream_k_workspace(self.lib, d, out.tensor) if (choice == 'sk' or choice is None) and self.heads is None else None
         if choice is None:
             if not _autotune_enabled(out.tensor):
                 return                                 # library heuristic (and nothing cached: tune when possible)
             forms = [64, 128] + (['sk'] if sk is not None else []) + (['wino'] if self.packed_winograd is not None else [])
+            if self.heads is not None:
+                forms = [0, 'wino']                    # heads epilogue: the direct form's one tile shape, or Winograd
             times = {f: float('inf') for f in forms}
             for _trial in range(2):                    # alternate the candidates, keep each one's best trial
                 for form in forms:

@@ -341,7 +341,7 @@ typedef struct {
     /* WINOGRAD F(2x2, 3x3) (round 5): winograd != 0 with weights_winograd (fiery_conv_pack_weights_winograd) asks for the form
      * that computes every 2 x 2 output block from a 4 x 4 input block with 16 multiplies per (cin, cout) instead of 36; taken
      * by fp32 launches of 3 x 3 / stride 1 / 'same' layers (kT = 1) with whole 16-channel stages per source, cout_pad % 64 == 0,
-     * 16-byte addressable tensors, the plain or GRU epilogues, no chained 1x1 - others ignore the request.  Results differ
+     * 16-byte addressable tensors, the plain, GRU or heads epilogues, no chained 1x1 - others ignore the request.  Results differ
      * from the direct form by fp32 rounding (another order of additions; measured 8e-6 on the hot path's outputs). */
     const float* weights_winograd;
     int32_t winograd;

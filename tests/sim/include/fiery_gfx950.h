@@ -117,6 +117,7 @@ inline float rows_sum4(float v) {
 inline void wave_sync() { ::hipsim::barrier_wait(::hipsim::run_ptr()->waves[::hipsim::tls().wave]); }
 
 inline void vmem_done() {}
+inline void store_data_settle() {}
 
 inline void opaque_v(int&) {}
 inline void opaque_s(int&) {}

@@ -431,6 +431,90 @@ def test_conv_igemm_real_shapes(hip, cin, cout, k, stride):
     assert (out.to_nchw().cpu() - want).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize('form', ['sk', 'wino'])
+@pytest.mark.parametrize('case', ['128->128 relu', '64->128 relu + residual', 'gates 64+64 -> 2 x 64', 'GRU out 64+64 -> 64',
+                                  '64->64 border-class bias', '256->256 25x25 (odd size)'])
+def test_conv_forms_stream_k_and_winograd_real_shapes(hip, form, case):
+    """The two forms round 5 added beside the tile forms, on the step's real shapes, against torch fp32 on the host AND against
+    the 128-pixel tile form of the same launch, twice through the same workspace / buffers:
+      * 'sk'   stream-K (`fiery_conv_desc.stream_k`): partial tiles handed between workgroups on different XCDs through the
+               workspace - the thing the CPU simulator cannot see; the repeat runs over stale partials;
+      * 'wino' Winograd F(2x2, 3x3) (`fiery_conv_desc.winograd`, csrc/conv_winograd.hip): every epilogue kind it is instantiated
+               for (plain with / without residual, GRU gates, GRU output, border-class bias), odd image sizes.
+    Bounds: 2e-5 against torch for the direct sums (stream-K), 4e-5 for Winograd (the transforms reorder the sums)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(len(case) * 7 + len(form))
+    bound = 2e-5 if form == 'sk' else 4e-5
+    nhwc = lambda t: Buf(t.permute(0, 2, 3, 1).contiguous().to(DEV), t.shape[0], t.shape[2], t.shape[3], t.shape[1])
+    n, H, W = (15, 25, 25) if '25x25' in case else (3, 200, 200)
+    if case in ('128->128 relu', '256->256 25x25 (odd size)', '64->128 relu + residual', '64->64 border-class bias'):
+        cin, cout = {'128->128 relu': (128, 128), '256->256 25x25 (odd size)': (256, 256), '64->128 relu + residual': (64, 128),
+                     '64->64 border-class bias': (64, 64)}[case]
+        x = torch.randn(n, cin, H, W, generator=g)
+        w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+        sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+        op = ConvOp(hip, w, identity_chan_map(cin), (cin // 8, 0), sc, sh, DEV, act=native.ACT_RELU, tune=True)
+        y = F.conv2d(x, w, padding=1)
+        kw = {}
+        if 'residual' in case:
+            res = torch.randn(n, cout, H, W, generator=g)
+            kw['res'] = nhwc(res)
+        if 'bias' in case:
+            bias = torch.randn(n, 9, cout, generator=g)
+            cls = lambda v, size: torch.where(v == 0, 0, torch.where(v == size - 1, 2, 1))
+            rows = cls(torch.arange(H), H).view(H, 1) * 3 + cls(torch.arange(W), W).view(1, W)
+            y = y + bias[:, rows].permute(0, 3, 1, 2)
+            kw.update(img_bias=bias.contiguous().to(DEV), img_bias_border=True)
+        want = F.relu(y * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+        if 'residual' in case:
+            want = want + res
+        xb = nhwc(x)
+        run = lambda out: op([xb], out, **kw)
+        outs_of = lambda out: [out.to_nchw().cpu()]
+        wants = [want]
+        alloc = lambda: Buf.alloc(n, H, W, cout, DEV)
+    else:
+        ch = 64
+        x, h = torch.randn(n, ch, H, W, generator=g), torch.randn(n, ch, H, W, generator=g)
+        cmap = identity_chan_map(ch) + identity_chan_map(ch, offset=ch)
+        xb, hb = nhwc(x), nhwc(h)
+        if case.startswith('gates'):
+            wg = torch.randn(2 * ch, 2 * ch, 3, 3, generator=g) / (2 * ch * 9) ** 0.5
+            bg = torch.randn(2 * ch, generator=g) * 0.1
+            op = ConvOp(hip, wg, cmap, (ch // 8, ch // 8), torch.ones(2 * ch), bg, DEV, epi=native.EPI_GRU_GATES, tune=True)
+            pre = F.conv2d(torch.cat([x, h], 1), wg, padding=1) + bg.view(1, -1, 1, 1)
+            wants = [torch.sigmoid(pre[:, :ch]), (1 - torch.sigmoid(pre[:, ch:])) * h]
+            alloc = lambda: (Buf.alloc(n, H, W, ch, DEV), Buf.alloc(n, H, W, ch, DEV))
+            run = lambda out: op([xb, hb], out[0], out2=out[1], aux0=hb)
+            outs_of = lambda out: [out[0].to_nchw().cpu(), out[1].to_nchw().cpu()]
+        else:
+            u = torch.rand(n, ch, H, W, generator=g)
+            wt = torch.randn(ch, 2 * ch, 3, 3, generator=g) / (2 * ch * 9) ** 0.5
+            sc, sh = torch.rand(ch, generator=g) + 0.5, torch.randn(ch, generator=g)
+            op = ConvOp(hip, wt, cmap, (ch // 8, ch // 8), sc, sh, DEV, act=native.ACT_RELU, epi=native.EPI_GRU_OUT, tune=True)
+            ub = nhwc(u)
+            tilde = F.relu(F.conv2d(torch.cat([x, h], 1), wt, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+            wants = [(1 - u) * h + u * tilde]
+            alloc = lambda: Buf.alloc(n, H, W, ch, DEV)
+            run = lambda out: op([xb, hb], out, aux0=ub, aux1=hb)
+            outs_of = lambda out: [out.to_nchw().cpu()]
+    op.force_form = 128
+    tile_out = alloc()
+    run(tile_out)
+    tile = outs_of(tile_out)
+    op.force_form = form
+    for rep in range(2):
+        out = alloc()
+        run(out)
+        got = outs_of(out)
+        for i, (a, t, wnt) in enumerate(zip(got, tile, wants)):
+            err = (a - wnt).abs().max().item()
+            parity_report.record(f'conv form {form}: {case}' + (f' [{i}]' if len(got) > 1 else ''), 'vs torch fp32 (host)', (a - t).abs().max().item(),
+                                 wnt.abs().max().item(), err, (t - wnt).abs().max().item(), bound * max(1.0, wnt.abs().max().item()),
+                                 note='first column: against the 128-pixel tile form of the same launch')
+            assert err <= bound * max(1.0, wnt.abs().max().item()), (case, form, rep, i, err)
+
+
 @pytest.mark.parametrize('cin,cout,k,stride', [(64, 64, 3, 1), (128, 128, 3, 1), (64, 256, 3, 1), (64, 64, 7, 2), (32, 32, 3, 1)])
 def test_conv_igemm_bf16_form_real_shapes(hip, cin, cout, k, stride):
     """v_mfma_f32_32x32x16_bf16 on the real shapes: against the fp32 convolution of the bf16-rounded operands (what the

@@ -128,9 +128,11 @@ def test_constant_channels_folded_into_border_class_bias(sim, monkeypatch, unali
     assert torch.allclose(out.to_nchw(), want, **TOL), (out.to_nchw() - want).abs().max()
 
 
-def test_decoder_heads_epilogue_keeps_the_hidden_tensor_on_chip(sim):
+@pytest.mark.parametrize('form', [None, 'wino'])
+def test_decoder_heads_epilogue_keeps_the_hidden_tensor_on_chip(sim, form):
     """Four heads (Conv3x3 -> BN -> ReLU -> Conv1x1 + bias [-> Sigmoid], models/decoder.py:30-51) as one 256-cout GEMM
-    whose epilogue stores only the seven final rows, as NCHW planes of four separate tensors."""
+    whose epilogue stores only the seven final rows, as NCHW planes of four separate tensors.  form = 'wino': the same through
+    the Winograd F(2x2, 3x3) kernel, whose 64-cout workgroup tile is one head's hidden channels (round 5)."""
     g = torch.Generator().manual_seed(5)
     n, cin, hw = 2, 16, (9, 11)                       # 99 pixels per image: tiles straddle the image boundary
     n_outs, sig = [2, 1, 2, 2], [False, True, False, False]
@@ -143,6 +145,8 @@ def test_decoder_heads_epilogue_keeps_the_hidden_tensor_on_chip(sim):
     op = ConvOp(sim, w3, identity_chan_map(cin), (cin // 8, 0), scale, shift, 'cpu', act=native.ACT_RELU)
     groups = [h for h, k in enumerate(n_outs) for _ in range(k)]
     op.attach_heads(torch.cat(w1), torch.cat(b1), groups, [sig[h] for h in groups])
+    op.force_form = form
+    tol = TOL if form is None else dict(rtol=2e-5, atol=2e-5)
     outs = [torch.full((n, k, *hw), float('nan')) for k in n_outs]
     hwp = hw[0] * hw[1]
     planes = [(outs[h].data_ptr() + 4 * j * hwp, n_outs[h] * hwp) for h in range(4) for j in range(n_outs[h])]
@@ -152,7 +156,7 @@ def test_decoder_heads_epilogue_keeps_the_hidden_tensor_on_chip(sim):
         want = F.conv2d(hidden[:, 64 * h:64 * h + 64], w1[h].view(-1, 64, 1, 1), b1[h])
         if sig[h]:
             want = torch.sigmoid(want)
-        assert torch.allclose(outs[h], want, **TOL), (h, (outs[h] - want).abs().max())
+        assert torch.allclose(outs[h], want, **tol), (h, (outs[h] - want).abs().max())
 
 
 def test_channel_slices_of_wider_buffers(sim):
@@ -630,13 +634,18 @@ def test_stream_k_form_equals_the_tile_form(sim, monkeypatch, case, wgs):
     assert torch.equal(out2.to_nchw(), outs['sk'])
 
 
+@pytest.mark.parametrize('epilogue', ['per kind', 'general'])
 @pytest.mark.parametrize('case', ['64->128 relu + residual, odd size', 'two sources -> gates', 'two sources -> GRU out', '32->64 border-class bias',
                                   '16->256 sequence views', '48->64 cout 40 stored'])
-def test_winograd_form_equals_torch(sim, case):
+def test_winograd_form_equals_torch(sim, monkeypatch, case, epilogue):
     """Winograd F(2x2, 3x3) (`fiery_conv_desc.winograd`, csrc/conv_winograd.hip, round 5) against torch's direct convolution:
     odd image sizes (half-outside blocks), tiles that straddle images and end ragged, two sources, every epilogue kind the
     form covers, the border-class bias, several cout tiles, strided image views.  Tolerance: the transforms reorder the sums
-    (fp32), so 2e-5 relative instead of the direct form's 1e-5."""
+    (fp32), so 2e-5 relative instead of the direct form's 1e-5.  epilogue = 'per kind': the kernels instantiated per epilogue
+    kind (dense tensors: packed arithmetic, one buffer offset per tensor); 'general': the one kernel with everything behind
+    run-time switches and per-pixel addressing that serves what those do not (here forced for every case)."""
+    if epilogue == 'general':
+        monkeypatch.setenv('FIERY_WINOGRAD_GENERAL_EPILOGUE', '1')
     g = torch.Generator().manual_seed(len(case))
     WTOL = dict(rtol=2e-5, atol=2e-5)
 
@@ -677,6 +686,15 @@ def test_winograd_form_equals_torch(sim, case):
         op([xb, hb], U, out2=RH, aux0=hb)
         assert torch.allclose(U.to_nchw(), torch.sigmoid(pre[:, :ch]), **WTOL)
         assert torch.allclose(RH.to_nchw(), (1 - torch.sigmoid(pre[:, ch:])) * h, **WTOL)
+        # ... and with per-image bias rows in border classes (the first SpatialGRU's folded constant input rides on the GATE
+        # and OUTPUT epilogues too - round 5's first per-kind kernels forgot it there, and only the whole model noticed)
+        bias = torch.randn(2, 9, 2 * ch, generator=g)
+        cls = lambda v, size: torch.where(v == 0, 0, torch.where(v == size - 1, 2, 1))
+        rows = cls(torch.arange(10), 10).view(10, 1) * 3 + cls(torch.arange(12), 12).view(1, 12)
+        pre_b = pre + bias[:, rows].permute(0, 3, 1, 2)
+        op([xb, hb], U, out2=RH, aux0=hb, img_bias=bias.contiguous(), img_bias_border=True)
+        assert torch.allclose(U.to_nchw(), torch.sigmoid(pre_b[:, :ch]), **WTOL)
+        assert torch.allclose(RH.to_nchw(), (1 - torch.sigmoid(pre_b[:, ch:])) * h, **WTOL)
     elif case == 'two sources -> GRU out':
         x, h = torch.randn(1, 32, 12, 15, generator=g), torch.randn(1, 64, 12, 15, generator=g)
         u = torch.rand(1, 64, 12, 15, generator=g)
@@ -687,6 +705,9 @@ def test_winograd_form_equals_torch(sim, case):
         xb, hb, ub = _to_buf(x), _to_buf(h), _to_buf(u)
         tilde = F.relu(F.conv2d(torch.cat([x, h], 1), w, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
         outs = check(op, lambda o, out: o([xb, hb], out, aux0=ub, aux1=hb), (1 - u) * h + u * tilde, (1, 12, 15, 64), 64)
+        bias = torch.randn(1, 64, generator=g)                                # per-image bias rows (no border classes)
+        tilde_b = F.relu((F.conv2d(torch.cat([x, h], 1), w, padding=1) + bias.view(1, -1, 1, 1)) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+        check(op, lambda o, out: o([xb, hb], out, aux0=ub, aux1=hb, img_bias=bias.contiguous()), (1 - u) * h + u * tilde_b, (1, 12, 15, 64), 64)
     elif case == '32->64 border-class bias':
         n, H, W = 2, 9, 8
         x = torch.randn(n, 32, H, W, generator=g)
