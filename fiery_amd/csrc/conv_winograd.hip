@@ -42,7 +42,10 @@ namespace {
 #define W_RING 16                 // register ring of weight pieces (8 or 16: it must divide the 16 pieces of a stage)
 #endif
 #ifndef W_INTERLEAVE
-#define W_INTERLEAVE 1            // the next stage's input transform dealt out between this stage's MFMA blocks (0: in one piece)
+#define W_INTERLEAVE 0            // the next stage's input transform in one piece after the first half of the MFMAs (1: dealt out between the blocks - measured 1-2 % slower, profiles/r5_winograd_variants.txt)
+#endif
+#ifndef W_PIPE
+#define W_PIPE 1                  // pin the MFMA order of a transform point's block (A/B switch)
 #endif
 #ifndef W_EXP
 #define W_EXP 0                   // timing experiments (wrong results): 1 weights from one hot piece, 2 no input loads in the loop,
@@ -253,18 +256,28 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
         constexpr bool FIRST = decltype(first_c)::value;
         const int buf = s & 1;
         const float* vb = smem + buf * W_V_FLOATS + (4 * wv) * (WT * WKC);
+        // (the block operand of point pl + 1 is read from LDS while the MFMAs of point pl run; with W_PIPE the MFMA order is pinned
+        // as written - two accumulator blocks alternating - instead of the four-long dependent chains the scheduler prefers)
+        float4 a_nxt = *reinterpret_cast<const float4*>(vb + v_rd[0]);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
 #pragma unroll
             for (int pl = 0; pl < 4; ++pl) {
-                const float4 a4 = *reinterpret_cast<const float4*>(vb + pl * (WT * WKC) + v_rd[q]);
+                const float4 a4 = a_nxt;
+                if (q * 4 + pl < 7) a_nxt = *reinterpret_cast<const float4*>(vb + ((pl + 1) & 3) * (WT * WKC) + v_rd[pl == 3 ? q + 1 : q]);
                 const int piece = (q * 4 + pl) * 2;
                 const float4 b0 = wr[piece % RING], b1 = wr[(piece + 1) % RING];
+#if W_PIPE
+                __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const bool fresh = FIRST && q == 0 && j == 0;
                     acc[pl][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(b0, j), comp(a4, j), fresh ? zero16 : acc[pl][0], 0, 0, 0);
                     acc[pl][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(b1, j), comp(a4, j), fresh ? zero16 : acc[pl][1], 0, 0, 0);
+#if W_PIPE
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
                 }
                 // the two slots this point leaves take the pieces AHEAD further on (wrapping into the next stage)
 #pragma unroll
@@ -585,7 +598,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
         }
     };
     if (W_EXP == 4) {
-        if (acc[0][0][0] + acc[1][1][3] + acc[2][0][5] + acc[3][1][7] == 1.234e-30f) p.out.ptr[tid] = 0.f;
+        float live_ = 0.f;                                         // (every accumulator block stays alive: no MFMA may be optimised away)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) live_ += acc[a][b][r];
+        if (live_ == 1.234e-30f) p.out.ptr[tid] = 0.f;
         return;
     }
     epilogue_block(std::integral_constant<int, 0>{});

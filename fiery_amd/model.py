@@ -518,7 +518,8 @@ class Fiery(nn.Module):
             self.bev_forward(**args)                  # eager once: engine buffers and workspaces get allocated
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            from . import ops
+            with torch.cuda.graph(graph, stream=ops.prepare_capture(intrinsics.device)):
                 out = self.bev_forward(**args)
             while len(self._graphs) >= 4:
                 self._graphs.pop(next(iter(self._graphs)))
@@ -547,7 +548,8 @@ class Fiery(nn.Module):
                 self.forward(**args)                  # eager once: plans, buffers, workspaces, tile choices
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                from . import ops
+                with torch.cuda.graph(graph, stream=ops.prepare_capture(intrinsics.device)):
                     out = self.forward(**args)
             while len(self._graphs) >= 4:
                 self._graphs.pop(next(iter(self._graphs)))

@@ -368,6 +368,30 @@ FORCE_FORM = os.environ.get('FIERY_CONV_FORM')      # A/B runs: '64', '128', 'sk
 WINOGRAD = os.environ.get('FIERY_CONV_WINOGRAD', '1') != '0'
 
 
+def capture_stream(device):
+    """The stream this library captures its hipGraphs on: one per device, made once - so that what is keyed on the stream (the
+    stream-K workspaces) exists before a capture starts (`prepare_capture`) and the captured launches use the same forms as the
+    eager pass in front of them."""
+    key = ('capture', torch.device(device).index)
+    st = _SK_WORKSPACES.get(key)
+    if st is None:
+        st = _SK_WORKSPACES[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+def prepare_capture(device):
+    """Call before `torch.cuda.graph(graph, stream=capture_stream(device))`: allocates the capture stream's stream-K workspace
+    outside the capture."""
+    st = capture_stream(device)
+    if STREAM_K:
+        dev = torch.device(device)
+        key = (dev.type, dev.index, st.cuda_stream)
+        if key not in _SK_WORKSPACES:
+            _SK_WORKSPACES[key] = dict(ws=torch.empty(SK_WORKSPACE_BYTES // 4, dtype=torch.float32, device=dev),
+                                       cnt=torch.zeros(SK_COUNTERS, dtype=torch.int32, device=dev))
+    return st
+
+
 def _stream_k_workspace(lib, d, t):
     """The stream-K workspace of the current stream if this launch has a stream-K form that fits it, else None."""
     if not STREAM_K:

@@ -293,7 +293,8 @@ def sharded_bev_forward_graph(model, K, E, ego, lifted=None, depth_logits=None, 
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             # (thread-local capture mode: the process group's watchdog thread may query events while this thread captures)
-            with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+            from . import ops
+            with torch.cuda.graph(graph, stream=ops.prepare_capture(K.device), capture_error_mode='thread_local'):
                 out, owned = call()
         while len(model._graphs) >= 4:
             model._graphs.pop(next(iter(model._graphs)))

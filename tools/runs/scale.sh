@@ -27,7 +27,7 @@ for n in 1 2 4 8; do
     python - <<PY
 import json
 try:
-    d = json.loads(open('$O/$tag.json').read().strip().splitlines()[-1])
+    d = json.loads([l for l in open('$O/$tag.json').read().strip().splitlines() if l.startswith('{')][-1])     # (RCCL prints its versions behind the line)
     ex = [(r.get('exchange_ms'), r.get('bytes_received')) for r in d['ranks']['devices']]
     print('%-28s %8.1f samples/s  %7.3f ms/step  launch: %s  exchange (ms, bytes received) per rank: %s' % ('$tag', d['value'], d['ms_per_step'], d['config']['launch'][:40], ex))
 except Exception as e:
