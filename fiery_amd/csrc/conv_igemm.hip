@@ -352,7 +352,12 @@ int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, ConvRunMode mode, 
         bool tensors_dense = dense(d->out) && dense(d->res) && dense(d->out2) && dense(d->aux0) && dense(d->aux1) && (!d->weights3 || dense(d->out3));
         if (const char* forced = getenv("FIERY_CONV_DENSE_EPILOGUE")) tensors_dense = tensors_dense && atoi(forced) != 0;     // A/B runs
         if (tensors_dense && !p.bias_border) p.vec_epilogue |= 2;
-        if (tensors_dense) p.vec_epilogue |= 4;             // (bit 2: dense tensors whatever the bias form - the Winograd kernel's lean epilogue)
+        // bit 2 (the Winograd kernels' lean epilogue): every tensor addressable with ONE 31-bit byte offset per thread -
+        // image * img_stride + pixel * ld, images at any non-negative stride (the SpatialGRU's time-step views of sequence buffers)
+        auto small = [&](const fiery_nhwc& t) {
+            return !t.ptr || (t.img_stride >= 0 && ((static_cast<long long>(d->n_img_out) - 1) * t.img_stride + hw * t.ld) * 4 < (1ll << 31));
+        };
+        if (small(d->out) && small(d->res) && small(d->out2) && small(d->aux0) && small(d->aux1)) p.vec_epilogue |= 4;
     }
     p.w2 = d->weights2;
     p.scale2 = d->scale2;

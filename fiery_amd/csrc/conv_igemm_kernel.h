@@ -95,7 +95,7 @@ struct ConvP {
     const float* shift2;
     int act2;
     int vec_epilogue;     // bit 0: destinations / residual / bias rows are 16-byte addressable; bit 1: and dense (see store_rows);
-                          // bit 2: dense tensors whether or not the bias has border classes (conv_winograd.hip)
+                          // bit 2: every tensor spans < 2 GB from its base at a non-negative image stride (conv_winograd.hip)
     int bias_border;      // img_bias holds nine rows per image, chosen by the output pixel's border class
     HeadsP heads;         // FIERY_EPI_HEADS
     // stream-K launches (SK kernels): output tiles of the launch (pixel tiles x cout tiles), partial tiles' workspace

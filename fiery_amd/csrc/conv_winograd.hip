@@ -41,6 +41,12 @@ namespace {
 #ifndef W_RING
 #define W_RING 16                 // register ring of weight pieces (8 or 16: it must divide the 16 pieces of a stage)
 #endif
+#ifndef W_DEFAULT_WAVES
+#define W_DEFAULT_WAVES 4         // wavefronts per workgroup unless FIERY_WINOGRAD_WAVES says otherwise (4 or 8)
+#endif
+#ifndef W_RING8
+#define W_RING8 4                 // the ring of the eight-wavefront form (8 pieces per stage and wavefront; 8 spills at 128 registers)
+#endif
 #ifndef W_INTERLEAVE
 #define W_INTERLEAVE 0            // the next stage's input transform in one piece after the first half of the MFMAs (1: dealt out between the blocks - measured 1-2 % slower, profiles/r5_winograd_variants.txt)
 #endif
@@ -96,8 +102,14 @@ __global__ void k_pack_winograd(const float* __restrict__ w, int cout, int cin_t
 // instructions with scalar registers spilled to vector lanes, and an epilogue's vector instructions are served one per MFMA of the
 // CU's other workgroup (~64 cycles each): 0 plain, act none / ReLU, no residual, no bias; 1 plain, anything; 2 GRU gates; 3 GRU
 // output (0-3: every tensor dense over its images - the lean path); 4 decoder heads; -1 everything, general addressing (fallback)
-template <int KIND>
-__global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
+// NW: wavefronts per workgroup.  4: a wavefront owns four transform points (128 accumulator registers, two wavefronts per SIMD).
+// 8 (round 5, second form): two points per wavefront - 64 accumulator registers, the kernel held to 128 registers, FOUR
+// wavefronts per SIMD: twice as many MFMA streams to fill the gaps a stream leaves at its barriers and operand waits; a thread
+// then transforms one channel of a block (4-byte pieces) instead of two, and the first four wavefronts run the epilogue's rows.
+template <int KIND, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_conv_winograd(ConvP p) {
+    static_assert(NW == 4 || NW == 8, "four or eight wavefronts");
+    constexpr int PP = 16 / NW;                        // transform points per wavefront
     constexpr bool LEAN = KIND >= 0 && KIND <= 4;
     __shared__ __attribute__((aligned(16))) float smem[W_SMEM_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -117,7 +129,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
     const int tile0 = blk * WT;
 
     // ---- this thread's input block: tile tt, channels 2 cp, 2 cp + 1 of the stage ------------------------------------------
-    const int tt = tid >> 3, cp = tid & 7;
+    // (NW = 4: tile tt, channel PAIR cp of the stage, 8-byte pieces; NW = 8: tile tt, ONE channel cp, 4-byte pieces)
+    using DT = std::conditional_t<NW == 4, v2f, float>;
+    constexpr int CPT = NW == 4 ? 2 : 1;               // channels per thread
+    const int tt = NW == 4 ? tid >> 3 : tid >> 4, cp = NW == 4 ? tid & 7 : tid & 15;
     int e_o, e_y, e_x;              // the tile's image and top-left output pixel (kept for the epilogue)
     bool e_live;
     int voff0, voff1;               // byte offsets of the block's top-left tap (y0 - 1 + 1 lead row ...) in the two sources
@@ -146,8 +161,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
         }
         // (the descriptors start one row and one pixel before the tensors: the top-left tap's offset is never negative)
         const int pos = (y0 + 1) * W + (x0 + 1);
-        voff0 = 4 * (b * static_cast<int>(p.src[0].bstride) + (tl + p.tinadd) * static_cast<int>(p.src[0].tstride) + pos * p.src[0].ld + 2 * cp);
-        voff1 = 4 * (b * static_cast<int>(p.src[1].bstride) + (tl + p.tinadd) * static_cast<int>(p.src[1].tstride) + pos * p.src[1].ld + 2 * cp);
+        voff0 = 4 * (b * static_cast<int>(p.src[0].bstride) + (tl + p.tinadd) * static_cast<int>(p.src[0].tstride) + pos * p.src[0].ld + CPT * cp);
+        voff1 = 4 * (b * static_cast<int>(p.src[1].bstride) + (tl + p.tinadd) * static_cast<int>(p.src[1].tstride) + pos * p.src[1].ld + CPT * cp);
     }
     const int lead0 = (W + 1) * p.src[0].ld, lead1 = (W + 1) * p.src[1].ld;
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src[0].ptr - lead0), 0, 4 * lead0 + p.src[0].ext_bytes, 0x00020000);
@@ -156,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
     const int stages = p.cin_units >> 1, stages0 = p.src[0].units >> 1;
     const int rowb0 = W * p.src[0].ld * 4, pixb0 = p.src[0].ld * 4, rowb1 = W * p.src[1].ld * 4, pixb1 = p.src[1].ld * 4;
 
-    v2f d[16];                      // the 4 x 4 block (two channels per element), transformed in place
+    DT d[16];                       // the 4 x 4 block (one or two channels per element), transformed in place
     // (a wavefront whose eight tiles all lie inside the image - almost all do - needs no per-tap select: 16 vector instructions
     // per stage less, and vector instructions are what the K loop pays for)
     const bool interior = __ballot(tapmask != 0xFFFFu) == 0ull;
@@ -170,9 +185,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int v = (interior || ((tapmask >> (4 * i + j)) & 1u)) ? vo : static_cast<int>(0x80000000u);     // outside: reads as zero
-                const auto raw = second ? __builtin_amdgcn_raw_buffer_load_b64(rs1, v, ch + i * rowb + j * pixb, 0)
-                                        : __builtin_amdgcn_raw_buffer_load_b64(rs0, v, ch + i * rowb + j * pixb, 0);
-                __builtin_memcpy(&d[4 * i + j], &raw, 8);
+                if constexpr (NW == 4) {
+                    const auto raw = second ? __builtin_amdgcn_raw_buffer_load_b64(rs1, v, ch + i * rowb + j * pixb, 0)
+                                            : __builtin_amdgcn_raw_buffer_load_b64(rs0, v, ch + i * rowb + j * pixb, 0);
+                    __builtin_memcpy(&d[4 * i + j], &raw, 8);
+                } else {
+                    const unsigned raw = second ? __builtin_amdgcn_raw_buffer_load_b32(rs1, v, ch + i * rowb + j * pixb, 0)
+                                                : __builtin_amdgcn_raw_buffer_load_b32(rs0, v, ch + i * rowb + j * pixb, 0);
+                    __builtin_memcpy(&d[4 * i + j], &raw, 4);
+                }
             }
     };
     // B^T d B in place (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]): columns, then rows - 32 packed adds, in four parts
@@ -180,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
         if (part < 2) {
 #pragma unroll
             for (int j = 2 * part; j < 2 * part + 2; ++j) {
-                const v2f d0 = d[j], d1 = d[4 + j], d2 = d[8 + j], d3 = d[12 + j];
+                const DT d0 = d[j], d1 = d[4 + j], d2 = d[8 + j], d3 = d[12 + j];
                 d[j] = d0 - d2;
                 d[4 + j] = d1 + d2;
                 d[8 + j] = d2 - d1;
@@ -189,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
         } else {
 #pragma unroll
             for (int i = 2 * (part - 2); i < 2 * (part - 2) + 2; ++i) {
-                const v2f t0 = d[4 * i], t1 = d[4 * i + 1], t2 = d[4 * i + 2], t3 = d[4 * i + 3];
+                const DT t0 = d[4 * i], t1 = d[4 * i + 1], t2 = d[4 * i + 2], t3 = d[4 * i + 3];
                 d[4 * i] = t0 - t2;
                 d[4 * i + 1] = t1 + t2;
                 d[4 * i + 2] = t2 - t1;
@@ -202,10 +223,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
         for (int part = 0; part < 4; ++part) transform_part(part);
     };
     // V stage in LDS: [p][tile][16 k]; 16-byte slot q of a tile's row sits at q ^ ((tile >> 2) & 3)
-    const int v_st = (tt * WKC + 4 * ((cp >> 1) ^ ((tt >> 2) & 3)) + 2 * (cp & 1));              // + p * WT * WKC + buf * W_V_FLOATS
+    const int v_st = NW == 4 ? (tt * WKC + 4 * ((cp >> 1) ^ ((tt >> 2) & 3)) + 2 * (cp & 1))
+                             : (tt * WKC + 4 * ((cp >> 2) ^ ((tt >> 2) & 3)) + (cp & 3));                // + p * WT * WKC + buf * W_V_FLOATS
     auto store_v_rows = [&](int buf, int i0, int i1) {                   // rows [i0, i1) of the transformed block: points 4 i .. 4 i + 3
 #pragma unroll
-        for (int pp = 4 * i0; pp < 4 * i1; ++pp) *reinterpret_cast<v2f*>(&smem[buf * W_V_FLOATS + pp * (WT * WKC) + v_st]) = d[pp];
+        for (int pp = 4 * i0; pp < 4 * i1; ++pp) *reinterpret_cast<DT*>(&smem[buf * W_V_FLOATS + pp * (WT * WKC) + v_st]) = d[pp];
     };
     auto store_v = [&](int buf) { store_v_rows(buf, 0, 4); };
     // operand reads: lane (m, hi) of k-group q reads slot 2 q + hi of tile m's row
@@ -222,7 +244,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
     // (the ring is deep: vmcnt counts loads in issue order, so a weight piece requested behind the next stage's 16 input loads
     // cannot be waited for without waiting for those too - pieces are requested almost a stage before they are multiplied, by
     // which time the input loads in front of them have long landed)
-    constexpr int RING = W_RING, AHEAD = W_RING - 2;
+    constexpr int PIECES = 4 * PP;                                     // per stage: two k-groups x PP points x two cout halves
+    constexpr int RING = NW == 4 ? W_RING : W_RING8, AHEAD = RING - 2;
+    static_assert(PIECES % RING == 0, "the ring must divide a stage's pieces");
     float4 wr[RING];
     auto to_f4 = [](auto raw) {
         float4 f;
@@ -231,18 +255,18 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
     };
     auto w_request = [&](int slot, int s, int piece) {                  // piece of stage s (past the end: any piece of the last stage)
         const int ss = s < stages ? s : stages - 1;
-        const int q = piece >> 3, pl = (piece >> 1) & 3, nb = piece & 1;
-        const int soff = W_EXP == 1 ? 0 : (((4 * wv + pl) * Q + 4 * ss + 2 * q) * 64 + nb * 32) * 16;
+        const int q = piece / (2 * PP), pl = (piece >> 1) % PP, nb = piece & 1;
+        const int soff = W_EXP == 1 ? 0 : (((PP * wv + pl) * Q + 4 * ss + 2 * q) * 64 + nb * 32) * 16;
         wr[slot] = to_f4(__builtin_amdgcn_raw_buffer_load_b128(wrs, w_vo, soff, 0));
     };
 
     // (no zero fill: the first MFMA of every accumulator block takes the constant 0 as its addend - 128 vector moves less in the
     // prologue, which runs at one instruction per MFMA of the CU's other workgroup)
-    v16f acc[4][2];
+    v16f acc[PP][2];
     // ---- prologue: stage 0 into LDS, stage 1's block and the first weight pieces in flight ----------------------------------
     request(0);
 #pragma unroll
-    for (int i = 0; i < AHEAD; ++i) w_request(i, 0, i);
+    for (int i = 0; i < AHEAD; ++i) w_request(i % RING, i < PIECES ? 0 : 1, i < PIECES ? i : i - PIECES);
     transform();
     store_v(0);
     if (stages > 1) request(1);
@@ -255,17 +279,17 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
     auto stage = [&](int s, auto first_c) {
         constexpr bool FIRST = decltype(first_c)::value;
         const int buf = s & 1;
-        const float* vb = smem + buf * W_V_FLOATS + (4 * wv) * (WT * WKC);
+        const float* vb = smem + buf * W_V_FLOATS + (PP * wv) * (WT * WKC);
         // (the block operand of point pl + 1 is read from LDS while the MFMAs of point pl run; with W_PIPE the MFMA order is pinned
         // as written - two accumulator blocks alternating - instead of the four-long dependent chains the scheduler prefers)
         float4 a_nxt = *reinterpret_cast<const float4*>(vb + v_rd[0]);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
 #pragma unroll
-            for (int pl = 0; pl < 4; ++pl) {
+            for (int pl = 0; pl < PP; ++pl) {
                 const float4 a4 = a_nxt;
-                if (q * 4 + pl < 7) a_nxt = *reinterpret_cast<const float4*>(vb + ((pl + 1) & 3) * (WT * WKC) + v_rd[pl == 3 ? q + 1 : q]);
-                const int piece = (q * 4 + pl) * 2;
+                if (q * PP + pl < 2 * PP - 1) a_nxt = *reinterpret_cast<const float4*>(vb + ((pl + 1) % PP) * (WT * WKC) + v_rd[pl == PP - 1 ? q + 1 : q]);
+                const int piece = (q * PP + pl) * 2;
                 const float4 b0 = wr[piece % RING], b1 = wr[(piece + 1) % RING];
 #if W_PIPE
                 __builtin_amdgcn_sched_barrier(0);
@@ -283,13 +307,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int nxt = piece + e + AHEAD;
-                    if (nxt < 16) w_request(nxt % RING, s, nxt);
-                    else w_request(nxt % RING, s + 1, nxt - 16);
+                    if (nxt < PIECES) w_request(nxt % RING, s, nxt);
+                    else w_request(nxt % RING, s + 1, nxt - PIECES);
                 }
                 // the next stage's block is transformed and stored in the first half of this one (its loads were requested half a
                 // stage ago), and the block after it requested as soon as the registers are free
                 if (s + 1 < stages) {
 #if W_INTERLEAVE
+                    static_assert(PP == 4, "the interleaved transform is dealt over four points");
                     if (q == 0) {
                         if (W_EXP != 3) transform_part(pl);          // columns 0-1, 2-3, rows 0-1, 2-3
                         if (pl == 2 && W_EXP != 3) store_v_rows(buf ^ 1, 0, 2);
@@ -300,10 +325,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #else
-                    if (q == 0 && pl == 3) {
-                        transform();
-                        store_v(buf ^ 1);
-                        if (s + 2 < stages) request(s + 2);
+                    if (q == 0 && pl == PP - 1) {
+                        if (W_EXP != 3) transform();
+                        if (W_EXP != 3) store_v(buf ^ 1);
+                        if (s + 2 < stages && W_EXP != 2) request(s + 2);
                     }
 #endif
                 }
@@ -315,7 +340,20 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
     for (int s = 1; s < stages; ++s) stage(s, std::false_type{});
 
     // ---- epilogue: per 32-cout block, M_p -> LDS [p][tile][cout], then A^T M A and the direct kernel's epilogue arithmetic -------
-    const int et = tt, cq = cp;                                             // this thread's tile and four couts of the block
+    // this thread's tile and four couts of the block: 256 (tile, cout quad) tasks - all threads of the four-wavefront form (the
+    // transform's own mapping), the first four wavefronts of the eight-wavefront form (the others are done after the exchange)
+    const int et = NW == 4 ? tt : (tid >> 3) & 31, cq = tid & 7;
+    const bool e_worker = NW == 4 || wv < 4;
+    if constexpr (NW == 8) {
+        const int T = tile0 + et;
+        e_live = T < n_tiles && e_worker;
+        const int Tq = T < n_tiles ? T : 0;
+        e_o = fast_div(Tq, p.wmg_img, p.wsh_img);
+        const int rem = Tq - e_o * tiles_img;
+        const int ty = fast_div(rem, p.wmg_tw, p.wsh_tw);
+        e_y = 2 * ty;
+        e_x = 2 * (rem - ty * TW);
+    }
     const int half = p.cout_pad >> 1;
     auto activate = [](float v, int act) {
         if (act == FIERY_ACT_RELU) return fmaxf(v, 0.f);
@@ -338,14 +376,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
         constexpr int nb = decltype(nb_c)::value;
         // (the K loop's last barrier has passed: the V stages are free)
 #pragma unroll
-        for (int pl = 0; pl < 4; ++pl)
+        for (int pl = 0; pl < PP; ++pl)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const v16f& a = acc[pl][nb];
-                *reinterpret_cast<float4*>(&smem[((4 * wv + pl) * WT + m) * W_M_PITCH + 8 * g + 4 * hi]) =
+                *reinterpret_cast<float4*>(&smem[((PP * wv + pl) * WT + m) * W_M_PITCH + 8 * g + 4 * hi]) =
                     make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
             }
         __syncthreads();
+        if (!e_worker) return;                                      // (eight-wavefront form: the first four take the rows)
         const int co = tile_n * WBN + nb * 32 + 4 * cq;
         const bool upper = epi == FIERY_EPI_GRU_GATES && co >= half;
         const int c_x = upper ? co - half : co;
@@ -379,15 +418,19 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
             out_transform(mhi, yhi);
             const float4 sc = *reinterpret_cast<const float4*>(p.scale + co), sh = *reinterpret_cast<const float4*>(p.shift + co);
             const v2f sclo = v2f{sc.x, sc.y}, schi = v2f{sc.z, sc.w}, shlo = v2f{sh.x, sh.y}, shhi = v2f{sh.z, sh.w};
-            // this thread's byte offset of pixel (e_y, e_x) in a dense tensor of row length ld, channel c; the block's other
-            // pixels are scalar offsets away; pixels outside an odd-sized image (and tiles past the end) are pointed out of range
-            const int gp00 = (e_o * H + e_y) * W + e_x;
+            // this thread's byte offset of pixel (e_y, e_x) of image e_o in a tensor (image stride, row length ld), channel c - 31 bits
+            // (conv_run checked the spans); the block's other pixels are scalar offsets away; pixels outside an odd-sized image
+            // (and tiles past the end) are pointed out of range
+            const int pix00 = e_y * W + e_x;
             const bool v01 = e_x + 1 < W, v10 = e_y + 1 < H;
             const bool whole = __ballot(!(v01 && v10)) == 0ull;          // (even image sizes: every block of the wavefront is whole)
-            auto rsrc_of = [&](const float* ptr, int ld_) {
-                return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ptr), 0, ptr ? static_cast<int>(p.M) * ld_ * 4 : 0, 0x00020000);
+            auto rsrc_of = [&](const TensP& t) {
+                const int bytes = t.ptr ? ((p.n_img - 1) * static_cast<int>(t.istride) + H * W * t.ld) * 4 : 0;
+                return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(t.ptr), 0, bytes, 0x00020000);
             };
-            auto off_of = [&](int ld_, int c) { return ch_ok ? (gp00 * ld_ + c) * 4 : static_cast<int>(0x80000000u); };
+            auto off_of = [&](const TensP& t, int c) {
+                return ch_ok ? (e_o * static_cast<int>(t.istride) + pix00 * t.ld + c) * 4 : static_cast<int>(0x80000000u);
+            };
             auto ld4 = [&](__amdgpu_buffer_rsrc_t r, int vo, int q, int ld_) {
                 const bool ok = whole || q == 0 || (q == 1 ? v01 : q == 2 ? v10 : (v01 && v10));
                 return to_f4(__builtin_amdgcn_raw_buffer_load_b128(r, ok ? vo : static_cast<int>(0x80000000u), (q >> 1) * W * ld_ * 4 + (q & 1) * ld_ * 4, 0));
@@ -399,8 +442,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
                 __builtin_amdgcn_raw_buffer_store_b128(raw, r, ok ? vo : static_cast<int>(0x80000000u), (q >> 1) * W * ld_ * 4 + (q & 1) * ld_ * 4, 0);
                 store_data_settle();                                // (the next pixel's packed arithmetic lands in the same registers)
             };
-            const __amdgpu_buffer_rsrc_t r_out = rsrc_of(p.out.ptr, p.out.ld);
-            const int o_out = off_of(p.out.ld, co);
+            const __amdgpu_buffer_rsrc_t r_out = rsrc_of(p.out);
+            const int o_out = off_of(p.out, co);
             // per-image bias rows (the first SpatialGRU's folded constant input: plain AND gate / output epilogues carry it), with
             // the nine border classes of a zero-padded 3 x 3 when asked for: added in front of the folded BatchNorm
             if constexpr (KIND != 0) {
@@ -453,8 +496,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) st4(r_out, o_out, q, p.out.ld, fin[q]);
             } else if constexpr (KIND == 1) {
-                const __amdgpu_buffer_rsrc_t r_res = rsrc_of(p.res.ptr, p.res.ld);
-                const int o_res = off_of(p.res.ld, co);
+                const __amdgpu_buffer_rsrc_t r_res = rsrc_of(p.res);
+                const int o_res = off_of(p.res, co);
                 float4 r4[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) r4[q] = p.res.ptr ? ld4(r_res, o_res, q, p.res.ld) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -473,8 +516,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) st4(r_out, o_out, q, p.out.ld, r4[q]);
             } else if constexpr (KIND == 2) {
-                const __amdgpu_buffer_rsrc_t r_h = rsrc_of(p.aux0.ptr, p.aux0.ld), r_o2 = rsrc_of(p.out2.ptr, p.out2.ld);
-                const int o_h = off_of(p.aux0.ld, c_x), o_o2 = off_of(p.out2.ld, c_x);
+                const __amdgpu_buffer_rsrc_t r_h = rsrc_of(p.aux0), r_o2 = rsrc_of(p.out2);
+                const int o_h = off_of(p.aux0, c_x), o_o2 = off_of(p.out2, c_x);
                 float4 h4[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) h4[q] = upper ? ld4(r_h, o_h, q, p.aux0.ld) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -494,8 +537,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
                     else st4(r_out, o_out, q, p.out.ld, h4[q]);                                                                       // update gate
                 }
             } else {                                                                                                                  // FIERY_EPI_GRU_OUT
-                const __amdgpu_buffer_rsrc_t r_u = rsrc_of(p.aux0.ptr, p.aux0.ld), r_h = rsrc_of(p.aux1.ptr, p.aux1.ld), r_o2 = rsrc_of(p.out2.ptr, p.out2.ld);
-                const int o_u = off_of(p.aux0.ld, co), o_h = off_of(p.aux1.ld, co), o_o2 = off_of(p.out2.ld, co);
+                const __amdgpu_buffer_rsrc_t r_u = rsrc_of(p.aux0), r_h = rsrc_of(p.aux1), r_o2 = rsrc_of(p.out2);
+                const int o_u = off_of(p.aux0, co), o_h = off_of(p.aux1, co), o_o2 = off_of(p.out2, co);
                 float4 u4[4], h4[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -600,7 +643,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
     if (W_EXP == 4) {
         float live_ = 0.f;                                         // (every accumulator block stays alive: no MFMA may be optimised away)
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < PP; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -611,7 +654,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_winograd(ConvP p) {
     epilogue_block(std::integral_constant<int, 0>{});
     __syncthreads();                                                // everyone has read the first block before the second overwrites it
     epilogue_block(std::integral_constant<int, 1>{});
-    if (heads) {
+    if (heads && e_worker) {
 #pragma unroll
         for (int o = 0; o < FIERY_MAX_HEAD_OUTPUTS; ++o)
             if (o < p.heads.n_out && p.heads.group[o] == tile_n) {                 // (wave-uniform: every lane takes part in the exchange)
@@ -650,7 +693,7 @@ bool conv_launch_winograd(const ConvP& p, hipStream_t stream) {
     const int TH = (p.Hout + 1) / 2, TW = (p.Wout + 1) / 2;
     const long long tiles = static_cast<long long>(p.n_img) * TH * TW;
     const dim3 grid(static_cast<unsigned>((tiles + WT - 1) / WT), static_cast<unsigned>(p.cout_pad / WBN));
-    const bool dense = (p.vec_epilogue & 4) != 0;          // images back to back, < 2 GB per tensor, 16-byte rows (conv_run)
+    const bool dense = (p.vec_epilogue & 4) != 0;          // every tensor within 31-bit byte offsets of its base, 16-byte rows (conv_run)
     int kind = -1;
     if (p.epi == FIERY_EPI_HEADS) kind = (p.act == FIERY_ACT_NONE || p.act == FIERY_ACT_RELU) ? 4 : -1;
     else if (dense && p.epi == FIERY_EPI_PLAIN && (p.act == FIERY_ACT_NONE || p.act == FIERY_ACT_RELU))
@@ -658,14 +701,23 @@ bool conv_launch_winograd(const ConvP& p, hipStream_t stream) {
     else if (dense && p.epi == FIERY_EPI_GRU_GATES) kind = 2;
     else if (dense && p.epi == FIERY_EPI_GRU_OUT) kind = 3;
     if (const char* forced = getenv("FIERY_WINOGRAD_GENERAL_EPILOGUE")) if (atoi(forced) != 0) kind = -1;      // tests
+    int waves = W_DEFAULT_WAVES;                            // (read per launch: tests and A/B runs switch it)
+    if (const char* e = getenv("FIERY_WINOGRAD_WAVES")) waves = atoi(e) == 8 ? 8 : atoi(e) == 4 ? 4 : waves;
+    if (kind < 0) waves = 4;                                // (the general fallback does not fit 128 registers)
+#define FIERY_WINO_LAUNCH(K_)                                                                                  \
+    do {                                                                                                       \
+        if (waves == 8) hipLaunchKernelGGL((k_conv_winograd<K_, 8>), grid, dim3(512), 0, stream, p);            \
+        else hipLaunchKernelGGL((k_conv_winograd<K_, 4>), grid, dim3(256), 0, stream, p);                       \
+    } while (0)
     switch (kind) {
-        case 0: hipLaunchKernelGGL(k_conv_winograd<0>, grid, dim3(256), 0, stream, p); break;
-        case 1: hipLaunchKernelGGL(k_conv_winograd<1>, grid, dim3(256), 0, stream, p); break;
-        case 2: hipLaunchKernelGGL(k_conv_winograd<2>, grid, dim3(256), 0, stream, p); break;
-        case 3: hipLaunchKernelGGL(k_conv_winograd<3>, grid, dim3(256), 0, stream, p); break;
-        case 4: hipLaunchKernelGGL(k_conv_winograd<4>, grid, dim3(256), 0, stream, p); break;
-        default: hipLaunchKernelGGL(k_conv_winograd<-1>, grid, dim3(256), 0, stream, p); break;
+        case 0: FIERY_WINO_LAUNCH(0); break;
+        case 1: FIERY_WINO_LAUNCH(1); break;
+        case 2: FIERY_WINO_LAUNCH(2); break;
+        case 3: FIERY_WINO_LAUNCH(3); break;
+        case 4: FIERY_WINO_LAUNCH(4); break;
+        default: FIERY_WINO_LAUNCH(-1); break;
     }
+#undef FIERY_WINO_LAUNCH
     return true;
 }
 

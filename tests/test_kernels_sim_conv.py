@@ -128,8 +128,8 @@ def test_constant_channels_folded_into_border_class_bias(sim, monkeypatch, unali
     assert torch.allclose(out.to_nchw(), want, **TOL), (out.to_nchw() - want).abs().max()
 
 
-@pytest.mark.parametrize('form', [None, 'wino'])
-def test_decoder_heads_epilogue_keeps_the_hidden_tensor_on_chip(sim, form):
+@pytest.mark.parametrize('form', [None, 'wino', 'wino8'])
+def test_decoder_heads_epilogue_keeps_the_hidden_tensor_on_chip(sim, monkeypatch, form):
     """Four heads (Conv3x3 -> BN -> ReLU -> Conv1x1 + bias [-> Sigmoid], models/decoder.py:30-51) as one 256-cout GEMM
     whose epilogue stores only the seven final rows, as NCHW planes of four separate tensors.  form = 'wino': the same through
     the Winograd F(2x2, 3x3) kernel, whose 64-cout workgroup tile is one head's hidden channels (round 5)."""
@@ -145,7 +145,8 @@ def test_decoder_heads_epilogue_keeps_the_hidden_tensor_on_chip(sim, form):
     op = ConvOp(sim, w3, identity_chan_map(cin), (cin // 8, 0), scale, shift, 'cpu', act=native.ACT_RELU)
     groups = [h for h, k in enumerate(n_outs) for _ in range(k)]
     op.attach_heads(torch.cat(w1), torch.cat(b1), groups, [sig[h] for h in groups])
-    op.force_form = form
+    monkeypatch.setenv('FIERY_WINOGRAD_WAVES', '8' if form == 'wino8' else '4')
+    op.force_form = 'wino' if form == 'wino8' else form
     tol = TOL if form is None else dict(rtol=2e-5, atol=2e-5)
     outs = [torch.full((n, k, *hw), float('nan')) for k in n_outs]
     hwp = hw[0] * hw[1]
@@ -634,7 +635,7 @@ def test_stream_k_form_equals_the_tile_form(sim, monkeypatch, case, wgs):
     assert torch.equal(out2.to_nchw(), outs['sk'])
 
 
-@pytest.mark.parametrize('epilogue', ['per kind', 'general'])
+@pytest.mark.parametrize('epilogue', ['per kind', 'general', 'per kind, 8 wavefronts'])
 @pytest.mark.parametrize('case', ['64->128 relu + residual, odd size', 'two sources -> gates', 'two sources -> GRU out', '32->64 border-class bias',
                                   '16->256 sequence views', '48->64 cout 40 stored'])
 def test_winograd_form_equals_torch(sim, monkeypatch, case, epilogue):
@@ -646,6 +647,7 @@ def test_winograd_form_equals_torch(sim, monkeypatch, case, epilogue):
     run-time switches and per-pixel addressing that serves what those do not (here forced for every case)."""
     if epilogue == 'general':
         monkeypatch.setenv('FIERY_WINOGRAD_GENERAL_EPILOGUE', '1')
+    monkeypatch.setenv('FIERY_WINOGRAD_WAVES', '8' if '8 wavefronts' in epilogue else '4')
     g = torch.Generator().manual_seed(len(case))
     WTOL = dict(rtol=2e-5, atol=2e-5)
 
