@@ -31,14 +31,17 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X dense bf16 matrix peak (no sparsity)
 PEAK_HBM_GBS = 8000.0             # MI355X HBM3E spec bandwidth
 
 
-def pmc_traffic(kernels):
+def pmc_traffic(kernels, mode='f32'):
     """HBM bytes per launch of `kernels` (summed) from the COMMITTED PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over
     this bench command - baseline.yml, fp32, batch 3 - folded by tools/pmc_traffic.py with the gfx950 correction), with the
     file they come from and the commit that file was last changed in; None when the summary is absent.  Callers report it for
     THAT workload only: any other configuration's line carries null.  Counters cannot be collected from inside the timed
     process, so this is the one roofline field not measured live - hence its name in the line, `traffic_from_profiles`."""
     import subprocess
-    for name in ('r4_pmc_traffic.json', 'r3_pmc_traffic.json', 'r2_pmc_traffic.json', 'r1_pmc_traffic.json'):
+    names = ('r5_pmc_traffic.json', 'r4_pmc_traffic.json', 'r3_pmc_traffic.json', 'r2_pmc_traffic.json', 'r1_pmc_traffic.json')
+    if mode == 'bf16':                                   # (round 5: the same two passes over `bench.py --precision bf16`)
+        names = ('r5_pmc_traffic_bf16.json',)
+    for name in names:
         path = os.path.join(ROOT, 'profiles', name)
         try:
             table = json.load(open(path))
@@ -347,7 +350,26 @@ def main():
             rows = [dict(kind=k, us=round(s.elapsed_time(e) * 1e3, 2), work=w, detail=d if k == 'conv_igemm' else None)
                     for k, s, e, w, d in recs]
             json.dump(rows, open(dump, 'w'))
+        # per-layer bound (see `bound_per_layer` below): detail = (kT, kH, kW, stride, cin, cout, images, Hout, Wout, form)
+        ideal_s, mfma_bound_s, hbm_bound_s, hbm_bound_launches = 0.0, 0.0, 0.0, 0
+        for k, s_, e_, w, d in recs:
+            if k != 'conv_igemm':
+                continue
+            kT, kH, kW, stride, cin, cout, n_img, Ho, Wo, form = d
+            peak_l = (PEAK_BF16_MFMA_TFLOPS if form == 'bf16' else PEAK_F32_MFMA_TFLOPS) * 1e12
+            px_out = n_img * Ho * Wo
+            nbytes = 4.0 * (px_out * stride * stride * cin + px_out * cout + cin * cout * kT * kH * kW)
+            t_m, t_h = executed_of(w, d) / peak_l, nbytes / (PEAK_HBM_GBS * 1e9)
+            ideal_s += max(t_m, t_h)
+            mfma_bound_s += t_m
+            hbm_bound_s += t_h
+            hbm_bound_launches += t_h > t_m
         t_conv, f_conv = sum(t for t, _ in conv), sum(w for _, w in conv)
+        layerwise = {'ideal_ms_per_step': round(ideal_s * 1e3, 3), 'frac': round(ideal_s / t_conv, 4) if t_conv else None,
+                     'mfma_only_ms': round(mfma_bound_s * 1e3, 3), 'hbm_only_ms': round(hbm_bound_s * 1e3, 3),
+                     'launches_hbm_bound': int(hbm_bound_launches), 'launches': len(conv),
+                     'what': 'sum over launches of max(executed flops / matrix peak of the form, algorithmic bytes / 8 TB/s) '
+                             'divided by the measured convolution time of the step (one stream, HIP events)'}
         x_conv = sum(x_ for _, _, x_, _ in by_form.values())             # executed matrix flops of the step's convolutions
         # the dominant kernel = the form that holds most of the time; its flops against ITS peak
         dom = max(by_prec, key=lambda k_: by_prec[k_][0])
@@ -371,7 +393,12 @@ def main():
                                                     'a separate figure - `achieved` / `frac` are on EXECUTED flops'},
                     'direct_form_equivalent_tflops': round(f_conv / t_conv / 1e12, 2),
                     'traffic': None,             # (no counters in a timed run; the committed passes' figure follows)
-                    'traffic_from_profiles': pmc_traffic(['k_conv_igemm (all tile shapes)']) if args.precision == 'f32' and args.config == 'baseline.yml' and n_cam == 6 and B == 3 else None,
+                    'traffic_from_profiles': (pmc_traffic(['k_conv_igemm (all tile shapes)'], args.precision)
+                                              if args.config == 'baseline.yml' and n_cam == 6 and B == 3 else None),
+                    # per-layer roofline: a layer is bound by the matrix pipe OR by HBM - min over the two of what each allows;
+                    # the step's ideal time is the sum over its launches of max(executed flops / matrix peak, algorithmic bytes /
+                    # 8 TB/s) (bytes: the layer's input and output pixels x channels x 4 B + its weights, read / written once)
+                    'bound_per_layer': layerwise,
                     'launches': n_dom, 'avg_launch_us': round(t_dom / n_dom * 1e6, 2),
                     'algorithmic_gflop_per_step': round(f_conv / 1e9, 1), 'kernel_ms_per_step': round(t_conv * 1e3, 3),
                     'measured': 'HIP events around every launch of the median of five instrumented steps after the timed region, whole '
@@ -389,7 +416,8 @@ def main():
             pooling = {'kernel': 'k_rank_columns + k_voxel_pool_compact (op boundary projection_to_birds_eye_view)', 'bound': 'hbm',
                        'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
                        'traffic': None,          # (no counters in a timed run; the committed passes' figure - prepass included - follows)
-                       'traffic_from_profiles': pmc_traffic(['k_voxel_pool', 'fiery::k_rank_columns']) if args.config == 'baseline.yml' and n_cam == 6 and B == 3 else None,
+                       'traffic_from_profiles': (pmc_traffic(['k_voxel_pool', 'fiery::k_rank_columns'], args.precision)
+                                                 if args.config == 'baseline.yml' and n_cam == 6 and B == 3 else None),
                        'algorithmic_mb_per_step': round(b_pool / 1e6, 1),
                        'op_us_per_step': round(t_pool * 1e6, 1), 'op_us_samples': [round(v, 1) for v in pool_samples],
                        'kept_fraction': round(kept_frac, 4),
