@@ -487,6 +487,7 @@ int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, ConvRunMode mode, 
             magic(TW, &p.wmg_tw, &p.wsh_tw);
         }
         p.w = d->weights_winograd;
+        if (const char* t = getenv("FIERY_WINOGRAD_TRACE")) p.sk_ws = reinterpret_cast<float*>(strtoull(t, nullptr, 0));      // tuning builds (W_TRACE)
         if (!conv_launch_winograd(p, hs)) return fail(FIERY_EINVAL, "conv_fwd: Winograd launch failed");
         return check_launch("conv_fwd (Winograd)");
     }

@@ -50,6 +50,9 @@ namespace {
 #ifndef W_INTERLEAVE
 #define W_INTERLEAVE 0            // the next stage's input transform in one piece after the first half of the MFMAs (1: dealt out between the blocks - measured 1-2 % slower, profiles/r5_winograd_variants.txt)
 #endif
+#ifndef W_TRACE
+#define W_TRACE 0                 // tuning builds: per-workgroup timeline (100 MHz wall clock at entry / first barrier / end of the K
+#endif                            // loop / end, + the CU's hardware id) into the buffer whose address rides in p.sk_ws
 #ifndef W_PIPE
 #define W_PIPE 1                  // pin the MFMA order of a transform point's block (A/B switch)
 #endif
@@ -127,6 +130,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_conv_winograd(Conv
         blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int tile0 = blk * WT;
+#if W_TRACE
+    unsigned long long* trace = nullptr;
+    if (p.sk_ws && tid == 0) {
+        trace = reinterpret_cast<unsigned long long*>(p.sk_ws) + 8ull * (blockIdx.x + static_cast<unsigned long long>(blockIdx.y) * gridDim.x);
+        trace[0] = wall_clock64();
+        trace[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
+        trace[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));     // HW_REG_XCC_ID
+    }
+#endif
 
     // ---- this thread's input block: tile tt, channels 2 cp, 2 cp + 1 of the stage ------------------------------------------
     // (NW = 4: tile tt, channel PAIR cp of the stage, 8-byte pieces; NW = 8: tile tt, ONE channel cp, 4-byte pieces)
@@ -253,7 +265,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_conv_winograd(Conv
         __builtin_memcpy(&f, &raw, 16);
         return f;
     };
+    bool w_live = true;                                                 // (W_EXP == 6: no weight loads after the prologue)
     auto w_request = [&](int slot, int s, int piece) {                  // piece of stage s (past the end: any piece of the last stage)
+        if (W_EXP == 6 && !w_live) return;
         const int ss = s < stages ? s : stages - 1;
         const int q = piece / (2 * PP), pl = (piece >> 1) % PP, nb = piece & 1;
         const int soff = W_EXP == 1 ? 0 : (((PP * wv + pl) * Q + 4 * ss + 2 * q) * 64 + nb * 32) * 16;
@@ -271,6 +285,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_conv_winograd(Conv
     store_v(0);
     if (stages > 1) request(1);
     __syncthreads();
+#if W_TRACE
+    if (trace) trace[1] = wall_clock64();
+#endif
 
     auto comp = [](const float4& f, int j) { return j == 0 ? f.x : j == 1 ? f.y : j == 2 ? f.z : f.w; };
     v16f zero16;
@@ -336,8 +353,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_conv_winograd(Conv
         }
         __syncthreads();
     };
+    if (W_EXP == 6) w_live = false;
     stage(0, std::true_type{});
     for (int s = 1; s < stages; ++s) stage(s, std::false_type{});
+#if W_TRACE
+    if (trace) trace[2] = wall_clock64();
+#endif
 
     // ---- epilogue: per 32-cout block, M_p -> LDS [p][tile][cout], then A^T M A and the direct kernel's epilogue arithmetic -------
     // this thread's tile and four couts of the block: 256 (tile, cout quad) tasks - all threads of the four-wavefront form (the
@@ -654,6 +675,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_conv_winograd(Conv
     epilogue_block(std::integral_constant<int, 0>{});
     __syncthreads();                                                // everyone has read the first block before the second overwrites it
     epilogue_block(std::integral_constant<int, 1>{});
+#if W_TRACE
+    if (trace) trace[3] = wall_clock64();
+#endif
     if (heads && e_worker) {
 #pragma unroll
         for (int o = 0; o < FIERY_MAX_HEAD_OUTPUTS; ++o)
