@@ -343,6 +343,9 @@ class ConvOp:
         flops = 2.0 * out.n_img * out.H * out.W * self.cin_total * self.kT * self.kH * self.kW * self.cout
         if self.chain is not None:
             flops += 2.0 * out.n_img * out.H * out.W * self.cout * self.chain['cout']
+        if self.chain3 is not None and out3 is not None:
+            # (the third stage IS the next block's 1x1 down-projection, whose own launch is skipped: its flops are executed here)
+            flops += 2.0 * out.n_img * out.H * out.W * 64 * self.chain3['cout']
         if self.heads is not None:
             flops += 2.0 * out.n_img * out.H * out.W * 64 * self.heads['n_out']
         used = 'f32'
