@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FIERY_ABI_VERSION 21
+#define FIERY_ABI_VERSION 22      /* 22 (round 5): fiery_conv_desc grew (weights_winograd, winograd, stream_k, sk_*); fiery_conv_pack_weights_winograd, fiery_conv_winograd_packed_floats, fiery_conv_stream_k_plan */
 
 #define FIERY_OK 0
 #define FIERY_EINVAL (-22)      /* bad argument (shape, alignment, null pointer) */
