@@ -247,8 +247,8 @@ class ConvOp:
         inputs, so the extra launches leave the same result behind (up to the last bits between stream-K and the tile
         forms: another summation split)."""
         self._set_form(d, 0)
-        if self.cout_pad % 64 != 0 or self.chain is not None or not self.tune:
-            return                                     # one tile shape only (or: library heuristic)
+        if self.cout_pad % 64 != 0 or self.chain is not None or (not self.tune and self.force_form is None):
+            return                                     # one tile shape only (or: library heuristic; a forced form is honoured)
         if self.heads is not None and self.packed_winograd is None:
             return                                     # (the heads' direct form has one tile shape)
         key = (out.n_img, out.H, out.W)

@@ -98,6 +98,17 @@ def _unit_epilogue(cout, device):
 # the library's counterpart of the reference's mixed-precision recipe (`PRECISION: 16`, fiery/configs/baseline.yml:6, trainer
 # flag `precision=16` in train.py:36).  `FIERY_TRAIN_PRECISION=bf16`, or set `train_graph.CONV_PRECISION` before the step.
 CONV_PRECISION = {'f32': native.PRECISION_F32, 'bf16': native.PRECISION_BF16}[os.environ.get('FIERY_TRAIN_PRECISION', 'f32')]
+# Round 5: the fp32 training graph's 3 x 3 / stride-1 convolutions with 64 couts or more - forward AND input gradient (the same
+# launch with transposed, mirrored weights) - run as Winograd F(2x2, 3x3) like the inference path's (csrc/conv_winograd.hip; the
+# weights change every step, so their G g G^T image is packed per call: ~1 MB, a few microseconds beside a 100-200 us launch).
+# No per-shape timing here (one-shot ops): the form is taken wherever it applies.  `FIERY_TRAIN_WINOGRAD=0` switches it off.
+TRAIN_WINOGRAD = os.environ.get('FIERY_TRAIN_WINOGRAD', '1') != '0'
+
+
+def _train_form(op):
+    if TRAIN_WINOGRAD and op.packed_winograd is not None:
+        op.force_form = 'wino'
+    return op
 
 
 def _launch_conv(lib, x_nhwc, weight, stride, pad):
@@ -107,8 +118,8 @@ def _launch_conv(lib, x_nhwc, weight, stride, pad):
     cout, cin, k, _ = weight.shape
     dev = x_nhwc.device
     scale, shift = _unit_epilogue(cout, dev)
-    op = ConvOp(lib, weight, identity_chan_map(cin), (cp // 8, 0), scale, shift, dev, stride=stride, pad=(pad, pad),
-                precision=CONV_PRECISION, tune=False)
+    op = _train_form(ConvOp(lib, weight, identity_chan_map(cin), (cp // 8, 0), scale, shift, dev, stride=stride, pad=(pad, pad),
+                            precision=CONV_PRECISION, tune=False))
     ho, wo = op.out_hw(h, w)
     out = Buf.alloc(n, ho, wo, cout, dev, zero=False)
     op([Buf(x_nhwc, n, h, w, cp)], out)
@@ -168,8 +179,8 @@ class HipConv2dCat(torch.autograd.Function):
         assert cin == c0 + c1 and tuple(b.shape[:3]) == (n, h, w)
         dev = a.device
         scale, shift = _unit_epilogue(cout, dev)
-        op = ConvOp(lib, weight.detach().float(), identity_chan_map(c0) + identity_chan_map(c1, offset=p0), (p0 // 8, p1 // 8), scale, shift,
-                    dev, stride=1, pad=(pad, pad), precision=CONV_PRECISION, tune=False)
+        op = _train_form(ConvOp(lib, weight.detach().float(), identity_chan_map(c0) + identity_chan_map(c1, offset=p0), (p0 // 8, p1 // 8),
+                                scale, shift, dev, stride=1, pad=(pad, pad), precision=CONV_PRECISION, tune=False))
         ho, wo = op.out_hw(h, w)
         out = Buf.alloc(n, ho, wo, cout, dev, zero=False)
         op([Buf(a, n, h, w, p0), Buf(b, n, h, w, p1)], out)
