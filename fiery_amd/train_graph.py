@@ -505,6 +505,30 @@ def _stack_frames(frames):
     return torch.stack([f.permute(0, 2, 3, 1) for f in frames], dim=1).permute(0, 1, 4, 2, 3)
 
 
+class _Frames(torch.autograd.Function):
+    """(B, T, C, H, W) -> its T frames (views).  Indexing does the same; the difference is the backward: ONE pixel-major stack of
+    the frame gradients instead of T zero-filled (B, T, C, H, W) tensors in NCHW order, a copy into each and T - 1 additions -
+    and, downstream of those, every operator converting NCHW gradients back to pixel-major rows."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.frame = (x.shape[0], *x.shape[2:])
+        return tuple(x[:, t] for t in range(x.shape[1]))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        like = next(g for g in grads if g is not None)
+        return _stack_frames([like.new_zeros(ctx.frame) if g is None else g for g in grads])
+
+
+def _frames_view(y, b, t):
+    """(B T, C, H, W) channels-last images -> (B, T, C, H, W), the reshape written in memory order: when autograd has to
+    materialise the gradient of this view (a slice of it went on: no (B T) merge of its strides), the copy comes out
+    pixel-major.  `y.view(b, t, c, h, w)` materialises NCHW, and every backward kernel below it then converts."""
+    n, c, h, w = y.shape
+    return y.permute(0, 2, 3, 1).reshape(b, t, h, w, c).permute(0, 1, 4, 2, 3)
+
+
 def _cat_frames(parts):
     """The same for (B, t_i, C, H, W) pieces along the frame axis."""
     return torch.cat([p.permute(0, 1, 3, 4, 2) for p in parts], dim=1).permute(0, 1, 4, 2, 3)
@@ -660,7 +684,7 @@ class TrainGraph:
         y = x.reshape(b * t, c, h, w).contiguous(memory_format=torch.channels_last)
         for stage in tm.model:
             y = self.temporal_block(y, stage, b, t) if hasattr(stage, 'convolution_paths') else self.bottleneck3d(y, stage, b, t)
-        return y.view(b, t, -1, h, w)[:, (tm.receptive_field - 1):]
+        return _frames_view(y, b, t)[:, (tm.receptive_field - 1):]
 
     def bottleneck(self, x, blk):
         """fiery/layers/convolutions.py:64-168 (Dropout2d(p=0) is the identity)."""
@@ -704,15 +728,17 @@ class TrainGraph:
         fp = self.m.future_prediction
         for gru, blocks in zip(fp.spatial_grus, fp.res_blocks):
             state, outs = hidden, []
-            for t in range(x.shape[1]):
-                state = self.gru_cell(x[:, t], state, gru)
+            # (the first block's input is the latent sample expanded over the future frames: one tensor used T times)
+            frames = [x[:, 0]] * x.shape[1] if x.stride(1) == 0 else _Frames.apply(x)
+            for frame in frames:
+                state = self.gru_cell(frame, state, gru)
                 outs.append(state)
             x = _stack_frames(outs)                                # (B, T, C, H, W) over pixel-major memory
             b, n, c, h, w = x.shape
             y = x.reshape(b * n, c, h, w)                          # a view: channels-last images, frames of a sample consecutive
             for blk in blocks:
                 y = self.bottleneck(y, blk)
-            x = y.reshape(b, n, c, h, w)
+            x = _frames_view(y, b, n)
         return x
 
     def distribution(self, s_t, dm):

@@ -105,7 +105,13 @@ def main():
                 continue
             frames = [f for f in (ev.stack or []) if 'fiery_amd' in f]
             shapes = str(ev.input_shapes)[:60] if ev.input_shapes else ''
-            key = (ev.name, frames[0].split('fiery_amd/')[-1][:60] if frames else '(autograd engine / other)', shapes)
+            node, up = '', ev.cpu_parent
+            while up is not None:                 # backward: the autograd node the engine was evaluating (or accumulating after)
+                if up.name.startswith('autograd::engine::evaluate_function: '):
+                    node = up.name.split(': ', 1)[1]
+                    break
+                up = up.cpu_parent
+            key = (ev.name, frames[0].split('fiery_amd/')[-1][:60] if frames else f'(backward of {node})' if node else '(other)', shapes)
             sites[key][0] += dev_us
             sites[key][1] += 1
         total = sum(v[0] for v in sites.values())
