@@ -453,6 +453,31 @@ class Lib:
         self.check(self.dll.fiery_conv_stream_k_plan(C.byref(desc), C.byref(nbytes), C.byref(n_cnt), C.byref(n_wg)))
         return nbytes.value, n_cnt.value, n_wg.value
 
+    ZERO_CHUNK_FLOATS = 4 << 20
+
+    def zeros_f32(self, shape, device):
+        """A zeroed fp32 tensor for a kernel that accumulates into its output (the weight gradients' split-K atomics): a slice of
+        a 16 MB chunk zeroed in ONE fill when it was allocated, instead of a fill launch per tensor (150 per training step).
+        Chunks are never re-zeroed or handed out twice - the views keep theirs alive, the caching allocator takes it back after
+        the last one - so a view held by autograd (a shared weight's first contribution, a retained graph) stays valid.  One
+        chunk per (device, stream): the fill is ordered with its users.  Inside a stream capture: a plain `torch.zeros`
+        (a replay has to zero again)."""
+        n = 1
+        for v in shape:
+            n *= int(v)
+        step = (n + 63) // 64 * 64                                                          # 256-byte aligned slices
+        if device.type != 'cuda' or step * 4 > self.ZERO_CHUNK_FLOATS or torch.cuda.is_current_stream_capturing():
+            return torch.zeros(shape, dtype=torch.float32, device=device)
+        if not hasattr(self, '_zero_chunks'):
+            self._zero_chunks = {}
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        chunk = self._zero_chunks.get(key)
+        if chunk is None or chunk[1] + step > chunk[0].numel():
+            chunk = self._zero_chunks[key] = [torch.zeros(self.ZERO_CHUNK_FLOATS, dtype=torch.float32, device=device), 0]
+        view = chunk[0][chunk[1]:chunk[1] + n].view(shape)
+        chunk[1] += step
+        return view
+
     def conv_wgrad(self, x, grad_out, cout, k, stride, pad, precision=PRECISION_F32):
         """x: pixel-major (n, Hin, Win, cin_pad) f32 (cin_pad a multiple of 8), grad_out: (n, Hout, Wout, >= cout) f32, both
         with contiguous rows -> dw (cout, k*k, cin_pad) f32.  precision = PRECISION_BF16: operands rounded on chip where the
@@ -461,7 +486,7 @@ class Lib:
         _, hout, wout, g_ld = grad_out.shape
         # (strides of size-1 dimensions are arbitrary in torch: derive them from the shapes of the dense tensors)
         assert cin_pad % 8 == 0 and x.is_contiguous() and grad_out.is_contiguous()
-        dw = torch.zeros(cout, k * k, cin_pad, dtype=torch.float32, device=x.device)
+        dw = self.zeros_f32((cout, k * k, cin_pad), x.device)
         self.check(self.dll.fiery_conv_wgrad_prec(_ptr(x), cin_pad, hin * win * cin_pad, cin_pad // 8, _ptr(grad_out), g_ld,
                                                   hout * wout * g_ld, cout, n, hin, win, hout, wout, k, k, stride, pad, pad, precision,
                                                   _ptr(dw), _stream_of(dw)))
@@ -630,7 +655,7 @@ class Lib:
 
     def depthwise_conv_wgrad(self, x, in_ld, n_img, h, w, c, grad_out, g_ld, ho, wo, k, stride, pad_top, pad_left):
         """-> dw [k*k][c] (tap-major, like the forward's weights)."""
-        dw = torch.zeros(k * k, c, dtype=torch.float32, device=x.device)
+        dw = self.zeros_f32((k * k, c), x.device)
         self.check(self.dll.fiery_depthwise_conv_wgrad_nhwc(_ptr(x), in_ld, n_img, h, w, c, _ptr(grad_out), g_ld, ho, wo, k, stride,
                                                             pad_top, pad_left, _ptr(dw), c, _stream_of(dw)))
         return dw

@@ -521,17 +521,39 @@ class _Frames(torch.autograd.Function):
         return _stack_frames([like.new_zeros(ctx.frame) if g is None else g for g in grads])
 
 
-def _frames_view(y, b, t):
-    """(B T, C, H, W) channels-last images -> (B, T, C, H, W), the reshape written in memory order: when autograd has to
-    materialise the gradient of this view (a slice of it went on: no (B T) merge of its strides), the copy comes out
-    pixel-major.  `y.view(b, t, c, h, w)` materialises NCHW, and every backward kernel below it then converts."""
+def _frames_view(y, b, t, first=0):
+    """(B T, C, H, W) channels-last images -> (B, T - first, C, H, W) from frame `first` on, reshape and slice written in
+    memory order: when autograd has to materialise the gradient of this view (the zero-filled gradient of the slice; a slice
+    of it that went on, with no (B T) merge of its strides), the tensor comes out pixel-major.  `y.view(b, t, c, h, w)[:, first:]`
+    materialises NCHW, and every backward kernel below it then converts."""
     n, c, h, w = y.shape
-    return y.permute(0, 2, 3, 1).reshape(b, t, h, w, c).permute(0, 1, 4, 2, 3)
+    frames = y.permute(0, 2, 3, 1).reshape(b, t, h, w, c)
+    return (frames[:, first:] if first else frames).permute(0, 1, 4, 2, 3)
 
 
 def _cat_frames(parts):
     """The same for (B, t_i, C, H, W) pieces along the frame axis."""
     return torch.cat([p.permute(0, 1, 3, 4, 2) for p in parts], dim=1).permute(0, 1, 4, 2, 3)
+
+
+def _counts_batches_once(method):
+    """While a whole-path entry point runs, the BatchNorm layers' `num_batches_tracked += 1` are collected and applied in one
+    multi-tensor launch at the end (108 one-element kernels per step otherwise).  Block-level methods called on their own
+    count at once, as before."""
+    import functools
+
+    @functools.wraps(method)
+    def entry(self, *args, **kwargs):
+        if self._counters is not None:                 # nested entry (forward -> bev_forward -> bev_stack): the outermost flushes
+            return method(self, *args, **kwargs)
+        self._counters = {}
+        try:
+            return method(self, *args, **kwargs)
+        finally:
+            pending, self._counters = self._counters, None
+            if pending:
+                torch._foreach_add_([t for t, _ in pending.values()], [k for _, k in pending.values()])
+    return entry
 
 
 class TrainGraph:
@@ -542,6 +564,7 @@ class TrainGraph:
         self.lib = lib or model._lib or native.get()
         self._conv = conv2d or HipConv2d.apply
         self._hip_ops = conv2d is None
+        self._counters = None                         # {id: (num_batches_tracked, pending increments)} inside an entry point
         self.whole_plane_pooling_as_means = True      # False: avg_pool3d + interpolate, operator for operator as the reference
         self.hip_trunk = os.environ.get('FIERY_HIP_TRUNK', '1') != '0'      # False: the image trunk + lift head as `Encoder.lift_head` (PyTorch-ROCm / MIOpen)
         if not self.hip_trunk:
@@ -584,9 +607,14 @@ class TrainGraph:
         factor = 0.0 if norm.momentum is None else norm.momentum
         tracking = norm.track_running_stats and norm.running_mean is not None
         if norm.training and tracking and norm.num_batches_tracked is not None:
-            norm.num_batches_tracked.add_(1)
-            if norm.momentum is None:
-                factor = 1.0 / float(norm.num_batches_tracked)
+            counter = norm.num_batches_tracked
+            if norm.momentum is None:                 # cumulative average: the factor needs the count now (a host read)
+                counter.add_(1)
+                factor = 1.0 / float(counter)
+            elif self._counters is None:
+                counter.add_(1)
+            else:
+                self._counters[id(counter)] = (counter, self._counters.get(id(counter), (counter, 0))[1] + 1)
         batch_stats = norm.training or not tracking
         update = norm.training and tracking
         if isinstance(norm, torch.nn.SyncBatchNorm) and norm.training:
@@ -684,7 +712,7 @@ class TrainGraph:
         y = x.reshape(b * t, c, h, w).contiguous(memory_format=torch.channels_last)
         for stage in tm.model:
             y = self.temporal_block(y, stage, b, t) if hasattr(stage, 'convolution_paths') else self.bottleneck3d(y, stage, b, t)
-        return _frames_view(y, b, t)[:, (tm.receptive_field - 1):]
+        return _frames_view(y, b, t, tm.receptive_field - 1)
 
     def bottleneck(self, x, blk):
         """fiery/layers/convolutions.py:64-168 (Dropout2d(p=0) is the identity)."""
@@ -822,6 +850,7 @@ class TrainGraph:
         return {k: (None if v is None else v.contiguous().view(b, s, *v.shape[1:])) for k, v in out.items()}
 
     # -- the path -----------------------------------------------------------------------------------------------------
+    @_counts_batches_once
     def bev_stack(self, x, future_egomotion, future_distribution_inputs=None, noise=None):
         """Everything after pooling; x (B, S, C, X, Y) pooled BEV features, future_egomotion (B, S, 6)."""
         m = self.m
@@ -846,7 +875,7 @@ class TrainGraph:
         output = {}
         if m.n_future > 0:
             # one dense pixel-major copy of the present state: it is read by both distributions, every GRU block and the decoder
-            hidden = states[:, 0].contiguous(memory_format=torch.channels_last)
+            hidden = _Frames.apply(states)[0].contiguous(memory_format=torch.channels_last)
             present = hidden.unsqueeze(1)
             b, _, _, h, w = present.shape
             if cfg.PROBABILISTIC.ENABLED:
@@ -879,6 +908,7 @@ class TrainGraph:
                                  features.reshape(b * s, n, *features.shape[3:]), geometry)
         return bev.view(b, s, *bev.shape[1:])
 
+    @_counts_batches_once
     def bev_forward(self, lifted, intrinsics, extrinsics, future_egomotion, future_distribution_inputs=None, noise=None,
                     depth_logits=None, features=None):
         """The hot path from the encoder's outputs (`Fiery.bev_forward`'s arguments), differentiable in them and in the
@@ -929,6 +959,7 @@ class TrainGraph:
             x = x + inputs
         return x
 
+    @_counts_batches_once
     def trunk_endpoints(self, x):
         """`Encoder.trunk_endpoints` (fiery/models/encoder.py:58-86) on this graph's operators: (deep, shallow) levels."""
         enc = self.m.encoder
@@ -952,6 +983,7 @@ class TrainGraph:
         endpoints.append(x)
         return (endpoints[4], endpoints[3]) if enc.downsample == 16 else (endpoints[3], endpoints[2])
 
+    @_counts_batches_once
     def lift_head(self, images):
         """`Encoder.lift_head` (encoder.py:58-100) under autograd: -> (depth logits or None, context features)."""
         enc = self.m.encoder
@@ -965,6 +997,7 @@ class TrainGraph:
             return x[:, :enc.D], x[:, enc.D:(enc.D + enc.C)]
         return None, x
 
+    @_counts_batches_once
     def forward(self, image, intrinsics, extrinsics, future_egomotion, future_distribution_inputs=None, noise=None):
         """`Fiery.forward` (fiery.py:130-191) with autograd.  The image trunk and the lift head run on this graph's operators
         too (`lift_head`: every convolution - dense and depthwise -, BatchNorm, the plane means and the x2 upsampling on the

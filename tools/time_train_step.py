@@ -116,7 +116,7 @@ def main():
             sites[key][1] += 1
         total = sum(v[0] for v in sites.values())
         print(f'ATen kernels of one step by call site: {total / 1e3:.2f} ms of device time', file=sys.stderr)
-        for (name, site, shapes), (us, n_) in sorted(sites.items(), key=lambda kv: -kv[1][0])[:45]:
+        for (name, site, shapes), (us, n_) in sorted(sites.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get("FIERY_SITES", "45"))]:
             print(f'  {us / 1e3:7.3f} ms {n_:4d}x  {name:28s} {site:62s} {shapes}', file=sys.stderr)
     print(json.dumps(line))
 
