@@ -452,6 +452,48 @@ def test_training_step_on_the_kernels_is_as_close_to_exact_as_fp32_torch(sim, pr
     torch32 = graph_step(cfg, state, sim, _torch_conv, torch.float32, *inputs)
     hip = graph_step(cfg, state, sim, None, torch.float32, *inputs)
     assert as_close_to_exact_as_fp32_torch(hip, torch32, exact, 'train_step[sim tiny]') > 50
+    # BatchNorm's side effects on the HIP operators: running statistics as the torch statement's, and every layer's batch counter
+    # (collected over the pass and applied in one launch, train_graph._counts_batches_once) up by its number of calls - the GRU's
+    # norm runs once per future frame
+    want = dict(torch32[0].named_buffers())
+    counters = 0
+    for name, b in hip[0].named_buffers():
+        if name.endswith('num_batches_tracked') and not name.startswith('encoder.'):
+            assert int(b) == int(want[name]), name
+            counters += int(b) > 0
+        elif name.endswith(('running_mean', 'running_var')) and not name.startswith('encoder.'):
+            assert torch.allclose(b, want[name], rtol=1e-3, atol=1e-5), name
+    assert counters > 20 and max(int(b) for n, b in hip[0].named_buffers() if n.endswith('num_batches_tracked')) == hip[0].n_future
+
+
+@pytest.mark.gpu
+def test_zeroed_chunks_hand_out_disjoint_zero_slices(hip):
+    """`Lib.zeros_f32`: the weight gradients' accumulate-into outputs as slices of chunks zeroed in one fill - zero, 256-byte
+    aligned, disjoint, never handed out twice (a held view keeps its values when the chunk runs out), per stream; too large or
+    under capture: a plain allocation."""
+    dev = torch.device('cuda:0')
+    a = hip.zeros_f32((64, 9, 64), dev)
+    b = hip.zeros_f32((3, 5), dev)
+    assert a.is_contiguous() and a.shape == (64, 9, 64) and a.data_ptr() % 256 == 0 and b.data_ptr() % 256 == 0
+    assert float(a.abs().sum()) == 0.0 and float(b.abs().sum()) == 0.0
+    a.fill_(1.0)
+    assert float(b.abs().sum()) == 0.0 and b.data_ptr() >= a.data_ptr() + a.numel() * 4
+    seen = {a.data_ptr(), b.data_ptr()}
+    for _ in range(3 * hip.ZERO_CHUNK_FLOATS // (64 * 9 * 64)):                 # through several chunks
+        v = hip.zeros_f32((64, 9, 64), dev)
+        assert v.data_ptr() not in seen
+        seen.add(v.data_ptr())
+    assert float(v.abs().sum()) == 0.0 and float(a.sum()) == a.numel() and float(b.abs().sum()) == 0.0
+    big = hip.zeros_f32((hip.ZERO_CHUNK_FLOATS,), dev)
+    assert float(big.abs().sum()) == 0.0 and big.numel() == hip.ZERO_CHUNK_FLOATS
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        c = hip.zeros_f32((8, 8), dev)
+        c.add_(2.0)
+    side.synchronize()
+    d = hip.zeros_f32((8, 8), dev)
+    assert float(c.sum()) == 128.0 and float(d.abs().sum()) == 0.0
+    assert hip.zeros_f32((4, 4), torch.device('cpu')).device.type == 'cpu'
 
 
 def test_training_mode_needs_the_future_labels(sim):
