@@ -478,12 +478,11 @@ def test_zeroed_chunks_hand_out_disjoint_zero_slices(hip):
     assert float(a.abs().sum()) == 0.0 and float(b.abs().sum()) == 0.0
     a.fill_(1.0)
     assert float(b.abs().sum()) == 0.0 and b.data_ptr() >= a.data_ptr() + a.numel() * 4
-    seen = {a.data_ptr(), b.data_ptr()}
+    held = [a, b]                                         # (held: a chunk whose views are all gone goes back to the allocator)
     for _ in range(3 * hip.ZERO_CHUNK_FLOATS // (64 * 9 * 64)):                 # through several chunks
-        v = hip.zeros_f32((64, 9, 64), dev)
-        assert v.data_ptr() not in seen
-        seen.add(v.data_ptr())
-    assert float(v.abs().sum()) == 0.0 and float(a.sum()) == a.numel() and float(b.abs().sum()) == 0.0
+        held.append(hip.zeros_f32((64, 9, 64), dev))
+    assert len({v.data_ptr() for v in held}) == len(held)
+    assert float(torch.stack(held[2:]).abs().sum()) == 0.0 and float(a.sum()) == a.numel() and float(b.abs().sum()) == 0.0
     big = hip.zeros_f32((hip.ZERO_CHUNK_FLOATS,), dev)
     assert float(big.abs().sum()) == 0.0 and big.numel() == hip.ZERO_CHUNK_FLOATS
     side = torch.cuda.Stream(device=dev)
