@@ -940,7 +940,9 @@ class TrainGraph:
         """efficientnet-pytorch `MBConvBlock.forward` (the package's published block: expansion 1x1 + BN + swish, depthwise
         k x k + BN + swish, squeeze-and-excite, projection 1x1 + BN, drop-connect + identity skip) on this graph's operators.
         The two dense layers of the squeeze-and-excite act on 1x1 maps: matrix products, not convolutions (section 9c)."""
-        swish = lambda t: t * torch.sigmoid(t)
+        # x * sigmoid(x) as ONE operator each way (`F.silu`: the same function; its backward is one kernel reading x and the
+        # gradient, where the product form ran sigmoid_backward, two multiplications and an addition and kept sigmoid(x) too)
+        swish = F.silu
         x = inputs
         stride, cin, cout = mbconv_geometry(blk)
         if hasattr(blk, '_expand_conv'):
@@ -965,8 +967,7 @@ class TrainGraph:
         enc = self.m.encoder
         trunk = enc.backbone
         endpoints = []
-        x = self.bn_act(self._same_pad_conv(x, trunk._conv_stem), trunk._bn0, relu=False)
-        x = x * torch.sigmoid(x)
+        x = F.silu(self.bn_act(self._same_pad_conv(x, trunk._conv_stem), trunk._bn0, relu=False))
         previous = x
         n_blocks = len(trunk._blocks)
         from .encoder import _LAST_BLOCK_DS8
