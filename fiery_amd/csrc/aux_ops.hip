@@ -340,7 +340,55 @@ __global__ __launch_bounds__(256) void k_depthwise_wgrad(const float* __restrict
     float4 acc[K * K];
 #pragma unroll
     for (int t = 0; t < K * K; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live) {
+    if (live && stride == 1 && (K == 3 || K == 5)) {
+        // (round 5) stride 1: a thread walking along a row needs ONE new input column per step - the other K - 1 it read on the
+        // steps before.  The K x K window lives in registers; the walk is unrolled K times so that the slot of column ix,
+        // (ix + pad_left) mod K, is a compile-time index: 1 + K sixteen-byte loads per pixel instead of 1 + K * K (the
+        // launches were load-issue bound: 320 us against ~95 us for their bytes).  Columns and rows outside the image are
+        // zeros in the window - the sums see the same addends in the same order as the loop below.
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (long long row = static_cast<long long>(blockIdx.y) * 16 + r; row < n_rows; row += 16ll * gridDim.y) {
+            const int img = static_cast<int>(row / Ho), y = static_cast<int>(row - static_cast<long long>(img) * Ho);
+            const float* grow = g + (static_cast<long long>(img) * Ho + y) * Wo * g_ld + c;
+            const float* ximg = in + static_cast<long long>(img) * H * W * in_ld + c;
+            const float* xrow[K];
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+                const int iy = y - pad_top + ky;
+                xrow[ky] = (iy >= 0 && iy < H) ? ximg + static_cast<long long>(iy) * W * in_ld : nullptr;
+            }
+            float4 win[K][K];
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+                for (int j = 0; j < K - 1; ++j) {                                          // columns -pad_left .. K - 2 - pad_left
+                    const int ix = j - pad_left;
+                    win[ky][j] = (xrow[ky] && ix >= 0 && ix < W) ? *reinterpret_cast<const float4*>(xrow[ky] + static_cast<long long>(ix) * in_ld) : zero4;
+                }
+            for (int x0 = 0; x0 < Wo; x0 += K) {
+#pragma unroll
+                for (int u = 0; u < K; ++u) {
+                    const int x = x0 + u;
+                    if (x < Wo) {
+                        const float4 gv = *reinterpret_cast<const float4*>(grow + static_cast<long long>(x) * g_ld);
+                        const int ix_new = x + K - 1 - pad_left;
+#pragma unroll
+                        for (int ky = 0; ky < K; ++ky)
+                            win[ky][(u + K - 1) % K] = (xrow[ky] && ix_new >= 0 && ix_new < W)
+                                ? *reinterpret_cast<const float4*>(xrow[ky] + static_cast<long long>(ix_new) * in_ld) : zero4;
+#pragma unroll
+                        for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < K; ++kx) {
+                                const float4 xv = win[ky][(u + kx) % K];
+                                float4& a = acc[ky * K + kx];
+                                a.x = fmaf(gv.x, xv.x, a.x);  a.y = fmaf(gv.y, xv.y, a.y);  a.z = fmaf(gv.z, xv.z, a.z);  a.w = fmaf(gv.w, xv.w, a.w);
+                            }
+                    }
+                }
+            }
+        }
+    } else if (live) {
         for (long long row = static_cast<long long>(blockIdx.y) * 16 + r; row < n_rows; row += 16ll * gridDim.y) {
             const int img = static_cast<int>(row / Ho), y = static_cast<int>(row - static_cast<long long>(img) * Ho);
             const float* grow = g + (static_cast<long long>(img) * Ho + y) * Wo * g_ld + c;

@@ -153,7 +153,9 @@ def test_maxpool_and_ego_warp_all_gradients_vs_fp64(sim):
 
 
 @pytest.mark.parametrize('c,k,stride,pads,hw', [(8, 3, 1, (1, 1, 1, 1), (7, 9)), (12, 3, 2, (0, 0, 1, 1), (9, 12)), (8, 5, 1, (2, 2, 2, 2), (6, 7)),
-                                                 (16, 5, 2, (1, 1, 2, 2), (11, 10)), (8, 5, 2, (2, 2, 2, 2), (8, 8)), (4, 3, 2, (0, 1, 1, 0), (5, 5))])
+                                                 (16, 5, 2, (1, 1, 2, 2), (11, 10)), (8, 5, 2, (2, 2, 2, 2), (8, 8)), (4, 3, 2, (0, 1, 1, 0), (5, 5)),
+                                                 # stride 1, lopsided pads, widths that are not multiples of k (the register-window walk of the weight gradient)
+                                                 (8, 3, 1, (0, 2, 2, 0), (5, 8)), (12, 5, 1, (1, 3, 3, 1), (7, 11)), (4, 5, 1, (4, 0, 0, 4), (3, 4))])
 def test_depthwise_convolution_all_gradients_vs_fp64(sim, c, k, stride, pads, hw):
     """`HipDepthwiseConv2d` (the image trunk's MBConv depthwise layers, 'static same' padding - asymmetric): output, input
     gradient (stride 2: zero-stuffed gradient, mirrored taps; rows no window reaches get zeros) and weight gradient
