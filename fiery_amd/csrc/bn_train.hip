@@ -165,34 +165,69 @@ __global__ void k_bn_running_stats(const float* __restrict__ running_mean, const
     invstd[c] = 1.f / sqrtf(running_var[c] + eps);
 }
 
+// The element-wise passes' thread layout (round 5): c4 = t % groups (a float4 of the STORED channels), r = t / groups (pixel lane),
+// `rows` = kBnThreads / groups pixel lanes per block; a block covers kBnElemPixels * rows consecutive pixels, a lane walks
+// pixels p0 + r, p0 + r + rows, ...  The per-channel parameters are loaded once per thread (they used to be loaded per float4:
+// 16-20 parameter loads beside one or three payload loads, and a 64-bit division - the launches ran at 2.1 TB/s), the payload
+// loads of four pixels are issued together.
+constexpr int kBnElemPixels = 8;
+struct BnElemShape {
+    int groups, rows;
+    unsigned blocks;
+};
+inline BnElemShape bn_elem_shape(long long P, int C_store) {
+    BnElemShape s;
+    s.groups = (C_store + 3) / 4;
+    s.rows = kBnThreads / s.groups;
+    if (s.rows < 1) s.rows = 1;
+    s.blocks = static_cast<unsigned>(ceil_div(P, static_cast<long long>(s.rows) * kBnElemPixels));
+    return s;
+}
+
 // pass 3: y = act((x - mean) * invstd * gamma + beta); channels C .. C_store of y are written as zeros (row padding the
 // next convolution reads)
 __global__ __launch_bounds__(kBnThreads) void k_bn_apply(const float* __restrict__ x, int ld, long long P, int C, int vec,
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
-                                                         float* __restrict__ y, int y_ld, int C_store, int y_vec, int groups) {
-    const long long i = static_cast<long long>(blockIdx.x) * kBnThreads + threadIdx.x;
-    const long long p = i / groups;
-    const int c = static_cast<int>(i - p * groups) * 4;
-    if (p >= P) return;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < C) {
-        const float4 xv = load4(x + p * ld, c, C, vec);
-        const float in[4] = {xv.x, xv.y, xv.z, xv.w};
-        float out[4];
+                                                         float* __restrict__ y, int y_ld, int C_store, int y_vec, int groups, int rows) {
+    const int t = threadIdx.x, c4 = t % groups, r = t / groups, c = c4 * 4;
+    if (r >= rows) return;
+    const long long p0 = static_cast<long long>(blockIdx.x) * rows * kBnElemPixels;
+    float m[4], is[4], ga[4], be[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float r = 0.f;
-            if (c + j < C) {
-                const float g = gamma ? gamma[c + j] : 1.f, b = beta ? beta[c + j] : 0.f;
-                r = (in[j] - mean[c + j]) * invstd[c + j] * g + b;
-                if (relu) r = fmaxf(r, 0.f);
-            }
-            out[j] = r;
-        }
-        v = make_float4(out[0], out[1], out[2], out[3]);
+    for (int j = 0; j < 4; ++j) {
+        const bool in = c + j < C;
+        m[j] = in ? mean[c + j] : 0.f;
+        is[j] = in ? invstd[c + j] : 0.f;
+        ga[j] = in ? (gamma ? gamma[c + j] : 1.f) : 0.f;
+        be[j] = in ? (beta ? beta[c + j] : 0.f) : 0.f;
     }
-    store4(y + p * y_ld, c, C_store, y_vec, v);
+#pragma unroll
+    for (int k0 = 0; k0 < kBnElemPixels; k0 += 4) {
+        float4 xv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long long p = p0 + static_cast<long long>(k0 + k) * rows + r;
+            xv[k] = (p < P && c < C) ? load4(x + p * ld, c, C, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long long p = p0 + static_cast<long long>(k0 + k) * rows + r;
+            if (p >= P) continue;
+            const float in[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w};
+            float out[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = 0.f;
+                if (c + j < C) {
+                    v = (in[j] - m[j]) * is[j] * ga[j] + be[j];
+                    if (relu) v = fmaxf(v, 0.f);
+                }
+                out[j] = v;
+            }
+            store4(y + p * y_ld, c, C_store, y_vec, make_float4(out[0], out[1], out[2], out[3]));
+        }
+    }
 }
 
 // backward pass 1: partial[block][0][c] = sum g', partial[block][1][c] = sum g' * xhat    (g' = g where y > 0)
@@ -252,40 +287,59 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finish(const float* __restrict__
 }
 
 // backward pass 2: dx = gamma * invstd * (g' - [batch] (dbeta + xhat * dgamma) / P); channels C .. C_store as zeros
+// (thread layout and walk: see k_bn_apply)
 __global__ __launch_bounds__(kBnThreads) void k_bn_bwd_dx(const float* __restrict__ g, int g_ld, int g_vec, const float* __restrict__ x,
                                                           int ld, int vec, const float* __restrict__ y, int y_ld, int y_vec,
                                                           long long P, int C, const float* __restrict__ mean,
                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                           const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                                           int batch_stats, long long P_total, float* __restrict__ dx, int dx_ld,
-                                                          int C_store, int dx_vec, int groups) {
-    const long long i = static_cast<long long>(blockIdx.x) * kBnThreads + threadIdx.x;
-    const long long p = i / groups;
-    const int c = static_cast<int>(i - p * groups) * 4;
-    if (p >= P) return;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < C) {
-        const float4 gv4 = load4(g + p * g_ld, c, C, g_vec);
-        const float4 xv4 = load4(x + p * ld, c, C, vec);
-        float4 yv4 = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (y) yv4 = load4(y + p * y_ld, c, C, y_vec);
-        const float gv[4] = {gv4.x, gv4.y, gv4.z, gv4.w}, xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w}, yv[4] = {yv4.x, yv4.y, yv4.z, yv4.w};
-        const float inv_p = 1.f / static_cast<float>(P_total);       // the statistics' pixel count (all processes' for SyncBatchNorm)
-        float out[4];
+                                                          int C_store, int dx_vec, int groups, int rows) {
+    const int t = threadIdx.x, c4 = t % groups, r = t / groups, c = c4 * 4;
+    if (r >= rows) return;
+    const long long p0 = static_cast<long long>(blockIdx.x) * rows * kBnElemPixels;
+    const float inv_p = 1.f / static_cast<float>(P_total);           // the statistics' pixel count (all processes' for SyncBatchNorm)
+    float m[4], is[4], ga[4], dg[4], db[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float r = 0.f;
-            if (c + j < C) {
-                const float gg = yv[j] > 0.f ? gv[j] : 0.f;
-                const float is = invstd[c + j], ga = gamma ? gamma[c + j] : 1.f;
-                const float xhat = (xv[j] - mean[c + j]) * is;
-                r = batch_stats ? ga * is * (gg - (dbeta[c + j] + xhat * dgamma[c + j]) * inv_p) : ga * is * gg;
-            }
-            out[j] = r;
-        }
-        v = make_float4(out[0], out[1], out[2], out[3]);
+    for (int j = 0; j < 4; ++j) {
+        const bool in = c + j < C;
+        m[j] = in ? mean[c + j] : 0.f;
+        is[j] = in ? invstd[c + j] : 0.f;
+        ga[j] = in ? (gamma ? gamma[c + j] : 1.f) : 0.f;
+        dg[j] = in && batch_stats ? dgamma[c + j] : 0.f;
+        db[j] = in && batch_stats ? dbeta[c + j] : 0.f;
     }
-    store4(dx + p * dx_ld, c, C_store, dx_vec, v);
+#pragma unroll
+    for (int k0 = 0; k0 < kBnElemPixels; k0 += 4) {
+        float4 gq[4], xq[4], yq[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long long p = p0 + static_cast<long long>(k0 + k) * rows + r;
+            const bool on = p < P && c < C;
+            gq[k] = on ? load4(g + p * g_ld, c, C, g_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xq[k] = on ? load4(x + p * ld, c, C, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+            yq[k] = (on && y) ? load4(y + p * y_ld, c, C, y_vec) : make_float4(1.f, 1.f, 1.f, 1.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long long p = p0 + static_cast<long long>(k0 + k) * rows + r;
+            if (p >= P) continue;
+            const float gv[4] = {gq[k].x, gq[k].y, gq[k].z, gq[k].w}, xv[4] = {xq[k].x, xq[k].y, xq[k].z, xq[k].w},
+                        yv[4] = {yq[k].x, yq[k].y, yq[k].z, yq[k].w};
+            float out[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = 0.f;
+                if (c + j < C) {
+                    const float gg = yv[j] > 0.f ? gv[j] : 0.f;
+                    const float xhat = (xv[j] - m[j]) * is[j];
+                    v = batch_stats ? ga[j] * is[j] * (gg - (db[j] + xhat * dg[j]) * inv_p) : ga[j] * is[j] * gg;
+                }
+                out[j] = v;
+            }
+            store4(dx + p * dx_ld, c, C_store, dx_vec, make_float4(out[0], out[1], out[2], out[3]));
+        }
+    }
 }
 
 inline bool rows_vec(const float* p, int ld, int C) { return C % 4 == 0 && ld % 4 == 0 && aligned16(p); }
@@ -320,11 +374,10 @@ extern "C" int fiery_bn_train_fwd(const float* x, int ld, int64_t n_pixels, int 
     } else {
         hipLaunchKernelGGL(k_bn_running_stats, dim3(ceil_div(C, 64)), dim3(64), 0, hs, running_mean, running_var, C, eps, mean, invstd);
     }
-    const int groups_out = (C_store + 3) / 4;
+    const BnElemShape es = bn_elem_shape(n_pixels, C_store);
     const int y_vec = (C_store % 4 == 0 && y_ld % 4 == 0 && aligned16(y)) ? 1 : 0;
-    const long long total = static_cast<long long>(n_pixels) * groups_out;
-    hipLaunchKernelGGL(k_bn_apply, dim3(ceil_div(total, kBnThreads)), dim3(kBnThreads), 0, hs, x, ld, static_cast<long long>(n_pixels), C,
-                       vec, mean, invstd, gamma, beta, relu, y, y_ld, C_store, y_vec, groups_out);
+    hipLaunchKernelGGL(k_bn_apply, dim3(es.blocks), dim3(kBnThreads), 0, hs, x, ld, static_cast<long long>(n_pixels), C,
+                       vec, mean, invstd, gamma, beta, relu, y, y_ld, C_store, y_vec, es.groups, es.rows);
     return check_launch("bn_train_fwd");
 }
 
@@ -344,12 +397,11 @@ int bn_bwd_dx(const float* grad_out, int g_ld, const float* x, int ld, const flo
               const float* gamma, const float* mean, const float* invstd, const float* dgamma, const float* dbeta, int batch_stats,
               int64_t total_pixels, float* grad_in, int gi_ld, int C_store, hipStream_t hs) {
     const int vec = rows_vec(x, ld, C) ? 1 : 0, g_vec = rows_vec(grad_out, g_ld, C) ? 1 : 0, y_vec = (y && rows_vec(y, y_ld, C)) ? 1 : 0;
-    const int groups_out = (C_store + 3) / 4;
+    const BnElemShape es = bn_elem_shape(n_pixels, C_store);
     const int dx_vec = (C_store % 4 == 0 && gi_ld % 4 == 0 && aligned16(grad_in)) ? 1 : 0;
-    const long long total = static_cast<long long>(n_pixels) * groups_out;
-    hipLaunchKernelGGL(k_bn_bwd_dx, dim3(ceil_div(total, kBnThreads)), dim3(kBnThreads), 0, hs, grad_out, g_ld, g_vec, x, ld, vec, y, y_ld,
+    hipLaunchKernelGGL(k_bn_bwd_dx, dim3(es.blocks), dim3(kBnThreads), 0, hs, grad_out, g_ld, g_vec, x, ld, vec, y, y_ld,
                        y_vec, static_cast<long long>(n_pixels), C, mean, invstd, gamma, dgamma, dbeta, batch_stats,
-                       static_cast<long long>(total_pixels), grad_in, gi_ld, C_store, dx_vec, groups_out);
+                       static_cast<long long>(total_pixels), grad_in, gi_ld, C_store, dx_vec, es.groups, es.rows);
     return check_launch("bn_train_bwd (dx)");
 }
 }  // namespace
@@ -386,12 +438,12 @@ extern "C" int fiery_bn_apply(const float* x, int ld, int64_t n_pixels, int C, c
                               const float* beta, int relu, float* y, int y_ld, int C_store, fiery_stream_t stream) {
     FIERY_REQUIRE(x && y && mean && invstd, "bn_apply: null pointer");
     FIERY_REQUIRE(n_pixels > 0 && C > 0 && ld >= C && C_store >= C && y_ld >= C_store, "bn_apply: bad shape");
-    const int groups_out = (C_store + 3) / 4;
+    FIERY_REQUIRE(C_store <= 4 * kBnThreads, "bn_apply: at most %d channels", 4 * kBnThreads);
+    const BnElemShape es = bn_elem_shape(n_pixels, C_store);
     const int y_vec = (C_store % 4 == 0 && y_ld % 4 == 0 && aligned16(y)) ? 1 : 0;
-    const long long total = static_cast<long long>(n_pixels) * groups_out;
-    hipLaunchKernelGGL(k_bn_apply, dim3(ceil_div(total, kBnThreads)), dim3(kBnThreads), 0, as_stream(stream), x, ld,
+    hipLaunchKernelGGL(k_bn_apply, dim3(es.blocks), dim3(kBnThreads), 0, as_stream(stream), x, ld,
                        static_cast<long long>(n_pixels), C, rows_vec(x, ld, C) ? 1 : 0, mean, invstd, gamma, beta, relu, y, y_ld, C_store, y_vec,
-                       groups_out);
+                       es.groups, es.rows);
     return check_launch("bn_apply");
 }
 
