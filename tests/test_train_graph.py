@@ -497,6 +497,40 @@ def test_zeroed_chunks_hand_out_disjoint_zero_slices(hip):
     assert hip.zeros_f32((4, 4), torch.device('cpu')).device.type == 'cpu'
 
 
+def test_frame_views_and_splits_hand_back_pixel_major_gradients():
+    """`train_graph._frames_view` / `_Frames`: the same values as `view(b, t, ...)[:, k:]` / `x[:, t]`, but the gradient autograd
+    materialises for them is laid out as pixel-major rows like the activations - an NCHW gradient there made every accumulation
+    below it a transposing add and every BatchNorm backward start with a copy (round 5: 4.7 ms of a 55 ms step)."""
+    from fiery_amd.train_graph import _Frames, _frames_view, _stack_frames
+    g = torch.Generator().manual_seed(5)
+    leaf = torch.randn(6, 8, 5, 7, generator=g).contiguous(memory_format=torch.channels_last).requires_grad_()
+    weight = torch.randn(2, 2, 8, 5, 7, generator=g)
+    seen = {}
+    for name, view in (('ours', lambda z: _frames_view(z, 2, 3, 1)), ('plain', lambda z: z.view(2, 3, 8, 5, 7)[:, 1:])):
+        z = leaf * 1.0
+        assert z.is_contiguous(memory_format=torch.channels_last)
+        z.register_hook(lambda grad, name=name: seen.__setitem__(name, grad))
+        v = view(z)
+        assert v.shape == (2, 2, 8, 5, 7) and torch.equal(v, leaf.detach().view(2, 3, 8, 5, 7)[:, 1:])
+        (v * weight).sum().backward()
+    assert torch.equal(seen['ours'], seen['plain'])
+    assert seen['ours'].is_contiguous(memory_format=torch.channels_last) and not seen['plain'].is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(_frames_view(leaf, 2, 3), leaf.view(2, 3, 8, 5, 7))
+    # frame splits: one pixel-major stack of the frame gradients, zeros for a frame nobody used
+    frames5 = _stack_frames([torch.randn(2, 8, 5, 7, generator=g) for _ in range(3)]).requires_grad_()
+    x = frames5 * 1.0
+    x.register_hook(lambda grad: seen.__setitem__('split', grad))
+    parts = _Frames.apply(x)
+    assert len(parts) == 3 and all(torch.equal(parts[t], frames5.detach()[:, t]) for t in range(3))
+    (parts[0] * 2.0).sum().backward(retain_graph=True)
+    want = torch.zeros(2, 3, 8, 5, 7)
+    want[:, 0] = 2.0
+    assert torch.equal(seen['split'], want) and seen['split'].permute(0, 1, 3, 4, 2).is_contiguous()
+    (parts[0] * 2.0 + parts[2] * parts[2]).sum().backward()
+    want[:, 2] = 2.0 * frames5.detach()[:, 2]
+    assert torch.allclose(seen['split'], want)
+
+
 def test_training_mode_needs_the_future_labels(sim):
     from fiery_amd.model import Fiery
     cfg = _train_cfg()
