@@ -17,6 +17,7 @@
 #include "common.h"
 #include <fiery_gfx950.h>
 
+#include <cmath>
 #include <cstdio>
 #include <type_traits>
 
@@ -39,11 +40,65 @@ struct GridParams {
     float ox, oy, oz;
     float rx, ry, rz;
     int nx, ny, nz;
+    // Division-free forms of the quantisation, chosen per axis on the host (to_params) and bit-identical to the
+    // reference's `(g - origin) / resolution` (three correctly rounded divisions per point are ~30 of the prepass's ~50
+    // vector instructions per point):
+    //   mode 1: the resolution is a power of two - (g - o) * (1 / r) IS the correctly rounded quotient;
+    //   mode 2: a single cell along the axis (z in every shipped configuration) - the point is kept iff
+    //           lo < g - o < hi, lo / hi being the largest / smallest numerators whose correctly rounded quotient is
+    //           <= -1 / >= 1 (division is monotonic; found on the host by stepping through the neighbouring floats);
+    //   mode 0: divide.
+    int mx, my, mz;
+    float ax, ay, az;      // mode 1: 1 / r        mode 2: lo
+    float bx, by, bz;      //                      mode 2: hi
 };
 
+void quantise_mode(float r, int n, int* mode, float* a, float* b) {
+    *mode = 0;
+    *a = *b = 0.f;
+    if (!(r > 0.f) || !std::isfinite(r)) return;
+    int e = 0;
+    if (std::frexp(r, &e) == 0.5f && std::isnormal(1.0f / r)) {
+        *mode = 1;
+        *a = 1.0f / r;
+        return;
+    }
+    if (n == 1) {
+        volatile float q;                                         // (volatile: the quotient is rounded to fp32 here and now)
+        float lo = -r, hi = r;
+        q = lo / r;
+        if (q != -1.0f) return;
+        for (int i = 0; i < 16; ++i) {
+            const float next = std::nextafter(lo, INFINITY);
+            q = next / r;
+            if (!(q <= -1.0f)) break;
+            lo = next;
+            if (i == 15) return;
+        }
+        q = hi / r;
+        if (q != 1.0f) return;
+        for (int i = 0; i < 16; ++i) {
+            const float next = std::nextafter(hi, -INFINITY);
+            q = next / r;
+            if (!(q >= 1.0f)) break;
+            hi = next;
+            if (i == 15) return;
+        }
+        *mode = 2;
+        *a = lo;
+        *b = hi;
+    }
+}
+
 GridParams to_params(const fiery_bev_grid& g) {
-    return {g.origin[0], g.origin[1], g.origin[2], g.resolution[0], g.resolution[1], g.resolution[2],
-            g.dim[0], g.dim[1], g.dim[2]};
+    GridParams p{g.origin[0], g.origin[1], g.origin[2], g.resolution[0], g.resolution[1], g.resolution[2],
+                 g.dim[0], g.dim[1], g.dim[2], 0, 0, 0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (!getenv("FIERY_POOL_DIVIDE")) {                            // tests / A-B runs: the divisions everywhere
+        quantise_mode(p.rx, p.nx, &p.mx, &p.ax, &p.bx);
+        quantise_mode(p.ry, p.ny, &p.my, &p.ay, &p.by);
+        quantise_mode(p.rz, p.nz, &p.mz, &p.az, &p.bz);
+    }
+    return p;
 }
 
 // ((g - origin) / resolution).long() with the reference's bounds mask (fiery.py:236-247): `.long()`
@@ -61,16 +116,33 @@ __device__ __forceinline__ bool quantise(float g, float origin, float res, int n
     return false;
 }
 
+// The same decision and cell through the axis' division-free form (`mode`, uniform: a scalar branch); only for callers
+// that do not need the cell of a point outside the grid.
+__device__ __forceinline__ bool quantise_kept(float g, float origin, float res, int n, int mode, float a, float b, int& cell) {
+    const float d = g - origin;
+    if (mode == 2) {
+        cell = 0;
+        return d > a && d < b;
+    }
+    const float s = mode == 1 ? d * a : d / res;
+    cell = static_cast<int>(s);
+    return s > -1.0f && s < static_cast<float>(n);
+}
+
 __device__ __forceinline__ int voxel_rank(float gx, float gy, float gz, const GridParams& p, int* idx3) {
     int ix, iy, iz;
+    if (!idx3) {
+        const bool kx = quantise_kept(gx, p.ox, p.rx, p.nx, p.mx, p.ax, p.bx, ix);
+        const bool ky = quantise_kept(gy, p.oy, p.ry, p.ny, p.my, p.ay, p.by, iy);
+        const bool kz = quantise_kept(gz, p.oz, p.rz, p.nz, p.mz, p.az, p.bz, iz);
+        return (kx && ky && kz) ? (ix * (p.ny * p.nz) + iy * p.nz + iz) : -1;
+    }
     const bool kx = quantise(gx, p.ox, p.rx, p.nx, ix);
     const bool ky = quantise(gy, p.oy, p.ry, p.ny, iy);
     const bool kz = quantise(gz, p.oz, p.rz, p.nz, iz);
-    if (idx3) {
-        idx3[0] = ix;
-        idx3[1] = iy;
-        idx3[2] = iz;
-    }
+    idx3[0] = ix;
+    idx3[1] = iy;
+    idx3[2] = iz;
     return (kx && ky && kz) ? (ix * (p.ny * p.nz) + iy * p.nz + iz) : -1;
 }
 
@@ -361,7 +433,7 @@ __global__ __launch_bounds__(256) void k_rank_columns4(const float* __restrict__
                                                         int4* __restrict__ coldesc, int* __restrict__ colmask, int compact,
                                                         unsigned char* __restrict__ occ, int n_cam, long long occ_stride,
                                                         unsigned* __restrict__ live, float* __restrict__ clear,
-                                                        long long clear_floats) {
+                                                        long long clear_floats, int rank_sparse) {
     if (clear) {
         const long long n_thr = static_cast<long long>(gridDim.x) * blockDim.x;
         const long long me = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -402,7 +474,7 @@ __global__ __launch_bounds__(256) void k_rank_columns4(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < kRpp; ++j) {
             r[j] = voxel_rank(gx[j], gy[j], gz[j], p, nullptr);
-            if (has_col && h0 + j < H) rank[base + static_cast<long long>(h0 + j) * W] = r[j];
+            if (!rank_sparse && has_col && h0 + j < H) rank[base + static_cast<long long>(h0 + j) * W] = r[j];
         }
     }
     // the rank of the row above my first one: the last row of the part above (parts 1 and 3 sit 16 lanes above parts 0 and
@@ -454,6 +526,18 @@ __global__ __launch_bounds__(256) void k_rank_columns4(const float* __restrict__
     offer_b |= __shfl_xor(offer_b, 16);  offer_b |= __shfl_xor(offer_b, 32);
     offer_c |= __shfl_xor(offer_c, 16);  offer_c |= __shfl_xor(offer_c, 32);
     const int ra = offer_a - 1, rb = s1 < H ? offer_b - 1 : -1, rc = s2 < H ? offer_c - 1 : -1;
+    if (rank_sparse) {
+        // FIERY_POOL_NO_RANKS: the ranks of the quads with a many-run column only - the compact-plane kernel walks those
+        // row by row with their ranks (a quad = four neighbouring lanes of a part: lane ^ 1, lane ^ 2)
+        int many = (has_col && (runs > 3 || H >= (1 << kSplitBits))) ? 1 : 0;
+        many |= __shfl_xor(many, 1);
+        many |= __shfl_xor(many, 2);
+        if (many && has_col) {
+#pragma unroll
+            for (int j = 0; j < kRpp; ++j)
+                if (h0 + j < H) rank[base + static_cast<long long>(h0 + j) * W] = r[j];
+        }
+    }
     if (has_col && part == 0) {
         const int general = (runs > 3 || H >= (1 << kSplitBits)) ? 1 : 0;
         if (compact >= 2) {
@@ -1273,6 +1357,27 @@ __global__ __launch_bounds__(1024) void k_voxel_pool_plane(const float* __restri
 //   wide, 64 B:                                u16 split[4] | 8 B pad | i32 A[4] | i32 B[4] | i32 C[4]   (-1 = none)
 //   split = s1 | s2 << 6 | many_runs << 12   (rows [0, s1) are run A, [s1, s2) run B, [s2, H) run C)
 constexpr int kCompactRows = 7;            // rows per lane: the form takes H <= 4 * 7
+
+// What the last workgroup of a compact-form launch zeroes again (so that the next call on the workspace needs no memset):
+// the occupancy bytes and live masks of the launch's frames, and the launch's own counters - tickets [16 + 16 g, 32 + 16 g)
+// and the top counter [1 + g] of the 64-int counter block, g = the launch's group (a call split into frame groups runs one
+// launch per group, side by side on two streams; group 0 also owns [0], the tuning builds' draw counter).
+struct PoolClean {
+    uint4* occ;
+    int occ_vec;                            // 16-byte words
+    unsigned* live;
+    int live_words;
+    int group;
+};
+template <int kThreads>
+__device__ __forceinline__ void pool_clean(const PoolClean& cl, int* counters, int tid) {
+    const uint4 z = {0u, 0u, 0u, 0u};
+    for (int i = tid; i < cl.occ_vec; i += kThreads) cl.occ[i] = z;
+    for (int i = tid; i < cl.live_words; i += kThreads) cl.live[i] = 0u;
+    if (tid < 16) counters[16 + 16 * cl.group + tid] = 0;
+    if (tid == 16) counters[1 + cl.group] = 0;
+    if (tid == 17 && cl.group == 0) counters[0] = 0;
+}
 constexpr int kCompactGroupLanes = 16;     // lanes per row group: the form takes W / 4 <= 16
 
 // kThreads: 512 (two workgroups per CU) or 1024 (one): sixteen wavefronts per CU either way; kWide: 64-byte quad records and 32-bit cell prefixes;
@@ -1286,7 +1391,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
     const unsigned char* __restrict__ occ, const unsigned* __restrict__ live, float* __restrict__ out,
     int* __restrict__ occupied, int n_cam, int D, int H, int W, int C, int n_vox, int n_words, int capacity, int tail_first,
     int tail_parts, int n_items, int* __restrict__ draw, long long* __restrict__ trace, int late_first, int late_prio,
-    int* __restrict__ counters, uint4* __restrict__ clean, int clean_vec, int part_ranges) {
+    int* __restrict__ counters, PoolClean cl, int part_ranges) {
     using prefix_t = std::conditional_t<kWide, unsigned, unsigned short>;
     HIP_DYNAMIC_SHARED(unsigned char, cp_lds)
     const int n_w32 = 2 * n_words;
@@ -1341,55 +1446,6 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
     const int c = unit % C;
     const int f = unit / C;
 
-    // ---- occupancy bytes -> bit map + exclusive prefix of the words' popcounts --------------------------------
-    if (f != f_have) {                                                    // (kept from the previous item of the same frame)
-        f_have = f;
-        const unsigned char* occ_f = occ + static_cast<long long>(f) * n_words * 64;
-        const int wpt = (n_w32 + kThreads - 1) / kThreads;               // consecutive 32-voxel words per thread
-        int local = 0;
-        for (int k = 0; k < wpt; ++k) {
-            const int w = tid * wpt + k;
-            if (w >= n_w32) break;
-            const uint4* src = reinterpret_cast<const uint4*>(occ_f + static_cast<long long>(w) * 32);
-            const uint4 lo4 = src[0], hi4 = src[1];
-            // four bytes (0 or 1) -> four bits: the products' partial terms fall on distinct bits, so nothing carries
-            auto nib = [](unsigned m) { return ((m & 0x01010101u) * 0x10204080u) >> 28; };
-            const unsigned b = nib(lo4.x) | nib(lo4.y) << 4 | nib(lo4.z) << 8 | nib(lo4.w) << 12 | nib(hi4.x) << 16 |
-                               nib(hi4.y) << 20 | nib(hi4.z) << 24 | nib(hi4.w) << 28;
-            bits[w] = b;
-            local += __popc(b);
-        }
-        int* tsum = reinterpret_cast<int*>(plane);                       // scratch: the plane is cleared afterwards
-        int* wsum = tsum + kThreads;
-        tsum[tid] = local;
-        __syncthreads();
-        if (tid < kWaves) {
-            int a = 0;
-            for (int l = 0; l < 64; ++l) a += tsum[tid * 64 + l];
-            wsum[tid] = a;
-        }
-        __syncthreads();
-        int before = 0;
-        total = 0;
-        for (int w = 0; w < kWaves; ++w) {
-            before += w < wave ? wsum[w] : 0;
-            total += wsum[w];
-        }
-        for (int l = 0; l < lane; ++l) before += tsum[wave * 64 + l];
-        for (int k = 0; k < wpt; ++k) {
-            const int w = tid * wpt + k;
-            if (w >= n_w32) break;
-            prefix[w] = static_cast<prefix_t>(before);
-            before += __popc(bits[w]);
-        }
-        __syncthreads();                                                  // scratch read, bits / prefix written
-    }
-    if (occupied && c == 0 && part == 0 && tid == 0) occupied[f] = total;
-    if (kTuning && trace && tid == 0) trace[4 * item + 1] = wall_clock64();
-    auto cell_of = [&](int r) {                                           // r: a voxel that is occupied
-        return static_cast<int>(prefix[r >> 5]) + __popc(bits[r >> 5] & ((1u << (r & 31)) - 1u));
-    };
-
     const int g = lane / kCompactGroupLanes, q = lane % kCompactGroupLanes;
     const float gf = static_cast<float>(g);
     const int Wq = W >> 2;
@@ -1397,8 +1453,6 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
     const int n_slices = n_cam * D;
     const int HW = H * W;
     float* o = out + (static_cast<long long>(f) * C + c) * n_vox;
-    const int n_pass = total > 0 ? (total + capacity - 1) / capacity : 1;
-
     // Row and record loads are buffer loads: descriptor (wave-uniform base of this workgroup's (frame, channel) rows / of
     // the frame's quad records) + one loop-invariant 32-bit lane offset + a scalar offset that the scalar unit advances
     // per slice and row - no 64-bit address arithmetic on the vector ALU.  A lane without work points past the
@@ -1424,42 +1478,111 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
     };
     const unsigned* live_f = live + static_cast<long long>(f) * n_slices;
 
+    // A lane's seven rows of the running slice and the record of its four columns; both are re-requested for the
+    // wavefront's next slice as soon as they have been moved aside (requests are never conditional - a slot that is
+    // conditionally reloaded becomes two registers and a copy; when there is no next slice the lane offset points past
+    // the descriptor, which costs no memory access).
+    struct Record {
+        unsigned split_lo = 0, split_hi = 0;
+        int rk0 = 0, rk1 = 0, rk2 = 0, rk3 = 0;
+    };
+    auto request_row = [&](vf4& slot, int j, int slice_off, int lane_off) {
+        const int voff = (kExactRows || 4 * j + g < H) ? lane_off : kOob;
+        const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rows, voff, slice_off + j * row4_bytes, kNonTemporal ? 2 : 0);
+        __builtin_memcpy(&slot, &raw, 16);
+    };
+    // the split words of the lane's four columns and the voxels of "its" run
+    auto fetch_record = [&](Record& rec, int s, bool real) {
+        const int soff = real ? s * Wq * kRecBytes : 0;
+        const int split_off = real ? split_voff : kOob, rank_off = real ? rank_voff : kOob;
+        const auto sp = __builtin_amdgcn_raw_buffer_load_b64(recs, split_off, soff, 0);
+        rec.split_lo = sp[0];
+        rec.split_hi = sp[1];
+        if constexpr (kWide) {
+            const auto rr = __builtin_amdgcn_raw_buffer_load_b128(recs, rank_off, soff, 0);
+            rec.rk0 = static_cast<int>(rr[0]);  rec.rk1 = static_cast<int>(rr[1]);
+            rec.rk2 = static_cast<int>(rr[2]);  rec.rk3 = static_cast<int>(rr[3]);
+        } else {
+            const auto rr = __builtin_amdgcn_raw_buffer_load_b64(recs, rank_off, soff, 0);
+            rec.rk0 = static_cast<int>(rr[0]);                            // two 16-bit ranks per word
+            rec.rk1 = static_cast<int>(rr[1]);
+        }
+    };
+
+    // The first slice's rows and record are requested BEFORE the bit map is built: they depend on nothing the set-up
+    // computes, and the ~5 us of set-up (occupancy bytes -> bit map -> prefix -> cleared plane) then pass under their flight -
+    // at the start of the launch every workgroup of the chip sets up at the same time and nothing streamed for that long.
+    vf4 rows_in_flight[kCompactRows];
+    Record record;
+    const bool prefetch = !(kTuning && (draw != nullptr || part_ranges));
+    bool prefetched = false;
+    if (prefetch) {
+        const int s0 = wave + part * kWaves;
+        const bool has = s0 < n_slices;
+        fetch_record(record, s0, has);
+        const int off = has ? slice_offset(s0) : 0;
+        const unsigned alive = has ? live_f[s0] : 0u;
+#pragma unroll
+        for (int j = 0; j < kCompactRows; ++j) request_row(rows_in_flight[j], j, off, ((alive >> q) & 1u) ? row_voff : kOob);
+        prefetched = true;
+    }
+
+    // ---- occupancy bytes -> bit map + exclusive prefix of the words' popcounts --------------------------------
+    if (f != f_have) {                                                    // (kept from the previous item of the same frame)
+        f_have = f;
+        const unsigned char* occ_f = occ + static_cast<long long>(f) * n_words * 64;
+        const int wpt = (n_w32 + kThreads - 1) / kThreads;               // consecutive 32-voxel words per thread
+        int local = 0;
+        for (int k = 0; k < wpt; ++k) {
+            const int w = tid * wpt + k;
+            if (w >= n_w32) break;
+            const uint4* src = reinterpret_cast<const uint4*>(occ_f + static_cast<long long>(w) * 32);
+            const uint4 lo4 = src[0], hi4 = src[1];
+            // four bytes (0 or 1) -> four bits: the products' partial terms fall on distinct bits, so nothing carries
+            auto nib = [](unsigned m) { return ((m & 0x01010101u) * 0x10204080u) >> 28; };
+            const unsigned b = nib(lo4.x) | nib(lo4.y) << 4 | nib(lo4.z) << 8 | nib(lo4.w) << 12 | nib(hi4.x) << 16 |
+                               nib(hi4.y) << 20 | nib(hi4.z) << 24 | nib(hi4.w) << 28;
+            bits[w] = b;
+            local += __popc(b);
+        }
+        // exclusive prefix over the threads: a shuffle scan inside the wavefront, the wavefronts' totals through the LDS
+        int incl = local;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        int* wsum = reinterpret_cast<int*>(plane);                       // scratch: the plane is cleared afterwards
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int before = incl - local;
+        total = 0;
+        for (int w = 0; w < kWaves; ++w) {
+            before += w < wave ? wsum[w] : 0;
+            total += wsum[w];
+        }
+        for (int k = 0; k < wpt; ++k) {
+            const int w = tid * wpt + k;
+            if (w >= n_w32) break;
+            prefix[w] = static_cast<prefix_t>(before);
+            before += __popc(bits[w]);
+        }
+        __syncthreads();                                                  // scratch read, bits / prefix written
+    }
+    if (occupied && c == 0 && part == 0 && tid == 0) occupied[f] = total;
+    if (kTuning && trace && tid == 0) trace[4 * item + 1] = wall_clock64();
+    auto cell_of = [&](int r) {                                           // r: a voxel that is occupied
+        return static_cast<int>(prefix[r >> 5]) + __popc(bits[r >> 5] & ((1u << (r & 31)) - 1u));
+    };
+
+
+    const int n_pass = total > 0 ? (total + capacity - 1) / capacity : 1;
     for (int pass = 0; pass < n_pass; ++pass) {
         const int lo = pass * capacity;
         const int span = min(capacity, total - lo);
-        for (int i = tid; i < span; i += kThreads) plane[i] = 0.f;
+        for (int i = 4 * tid; i < span; i += 4 * kThreads) *reinterpret_cast<float4*>(plane + i) = make_float4(0.f, 0.f, 0.f, 0.f);   // (up to `capacity`, a multiple of four)
         __syncthreads();
 
-        // A lane's seven rows of the running slice and the record of its four columns; both are re-requested for the
-        // wavefront's next slice as soon as they have been moved aside (requests are never conditional - a slot that is
-        // conditionally reloaded becomes two registers and a copy; when there is no next slice the lane offset points past
-        // the descriptor, which costs no memory access).
-        struct Record {
-            unsigned split_lo = 0, split_hi = 0;
-            int rk0 = 0, rk1 = 0, rk2 = 0, rk3 = 0;
-        };
-        auto request_row = [&](vf4& slot, int j, int slice_off, int lane_off) {
-            const int voff = (kExactRows || 4 * j + g < H) ? lane_off : kOob;
-            const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rows, voff, slice_off + j * row4_bytes, kNonTemporal ? 2 : 0);
-            __builtin_memcpy(&slot, &raw, 16);
-        };
-        // the split words of the lane's four columns and the voxels of "its" run
-        auto fetch_record = [&](Record& rec, int s, bool real) {
-            const int soff = real ? s * Wq * kRecBytes : 0;
-            const int split_off = real ? split_voff : kOob, rank_off = real ? rank_voff : kOob;
-            const auto sp = __builtin_amdgcn_raw_buffer_load_b64(recs, split_off, soff, 0);
-            rec.split_lo = sp[0];
-            rec.split_hi = sp[1];
-            if constexpr (kWide) {
-                const auto rr = __builtin_amdgcn_raw_buffer_load_b128(recs, rank_off, soff, 0);
-                rec.rk0 = static_cast<int>(rr[0]);  rec.rk1 = static_cast<int>(rr[1]);
-                rec.rk2 = static_cast<int>(rr[2]);  rec.rk3 = static_cast<int>(rr[3]);
-            } else {
-                const auto rr = __builtin_amdgcn_raw_buffer_load_b64(recs, rank_off, soff, 0);
-                rec.rk0 = static_cast<int>(rr[0]);                            // two 16-bit ranks per word
-                rec.rk1 = static_cast<int>(rr[1]);
-            }
-        };
         // one slice: `set` / `rec` hold its rows and record; they are refilled with those of slice `s_refill`
         auto process = [&](vf4 (&set)[kCompactRows], Record& rec_io, int s, int s_refill) {
             // The slice's rows have arrived: move them aside and ask for the refill slice's rows at once, all seven back
@@ -1576,7 +1699,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
                 // a column with four or more runs in this quad (a rolled camera; 1.5 % of the quads of the jittered
                 // baseline rig): this lane fetches its rows again, with their ranks, and every element goes to the voxel
                 // its own rank names
-                const int* rk = rank + (static_cast<long long>(f) * n_slices + s) * HW + q * 4;
+                // (under FIERY_POOL_NO_RANKS the prepass has written the ranks of exactly these quads)
+                const long long pt = (static_cast<long long>(f) * n_slices + s) * HW + q * 4;
                 const int off = slice_offset(s);
 #pragma unroll 1
                 for (int j = 0; j < kCompactRows; ++j) {
@@ -1584,7 +1708,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
                     const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rows, row_voff, off + j * row4_bytes, 0);
                     vf4 row;
                     __builtin_memcpy(&row, &raw, 16);
-                    const int4 r = *reinterpret_cast<const int4*>(rk + (4 * j + g) * W);
+                    const int4 r = *reinterpret_cast<const int4*>(rank + pt + (4 * j + g) * W);
                     const int rr[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -1595,18 +1719,18 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
                 }
             }
         };
-        vf4 rows_in_flight[kCompactRows];
-        Record record;
         // a part is a contiguous range of slices (neighbouring depths of one or two cameras: it touches a fraction of the
         // plane's cells, so its atomic write-out is short, and its rows are one stretch of memory)
         // ... when the parts are drawn (persistent workgroups); the statically dealt parts of the default launch take the
         // slices block-cyclically instead: contiguous ranges differ in how many of their quads are live (a part's row phase
         // took 29-53 us against 28-37 us, and the slowest part ends the kernel)
+        // (round 6: contiguous ranges cut to EQUAL NUMBERS OF LIVE QUADS, with a third of the atomics per part, measured 12 us
+        // slower still: 270.4 against 258.6 us per op, profiles/r6_pool_steps.txt)
         const bool ranges = kTuning && (draw != nullptr || part_ranges);
         const int s_lo = ranges ? static_cast<int>(static_cast<long long>(part) * n_slices / parts) : 0;
         const int s_end = ranges ? static_cast<int>(static_cast<long long>(part + 1) * n_slices / parts) : n_slices;
         const int s_first = ranges ? s_lo + wave : wave + part * kWaves, s_step = ranges ? kWaves : kWaves * parts;
-        {
+        if (!prefetched) {
             const bool has = s_first < s_end;
             fetch_record(record, s_first, has);
             const int off = has ? slice_offset(s_first) : 0;
@@ -1614,6 +1738,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
 #pragma unroll
             for (int j = 0; j < kCompactRows; ++j) request_row(rows_in_flight[j], j, off, ((alive >> q) & 1u) ? row_voff : kOob);
         }
+        prefetched = false;
         for (int s = s_first; s < s_end; s += s_step) process(rows_in_flight, record, s, s + s_step < s_end ? s + s_step : n_slices);
         __syncthreads();
         if (kTuning && trace && tid == 0) trace[4 * item + 2] = wall_clock64();
@@ -1622,7 +1747,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
         // (not when parts are drawn: the draw counter lives in the same region and is read until the last workgroup leaves)
         // (sixteen counters, dealt by item: the workgroups of a round finish within microseconds of each other and an atomic on
         // ONE address is served every ~0.1 us - 512 of them held every slot for its share of 50 us)
-        if (counters && !(kTuning && draw) && pass == n_pass - 1 && tid == 0) ticket = atomicAdd(counters + 16 + (item & 15), 1);
+        if (counters && !(kTuning && draw) && pass == n_pass - 1 && tid == 0) ticket = atomicAdd(counters + 16 + 16 * cl.group + (item & 15), 1);
         // ---- expand the window of cells into the dense plane --------------------------------------------------
         if (parts == 1 && n_pass == 1 && (n_vox & 3) == 0 && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
             // one pass, whole units: every voxel gets its cell's sum or a zero - four voxels (one nibble of a bit word) per
@@ -1665,26 +1790,20 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
             int last = 0;
             if (ticket == (n_items - (item & 15) + 15) / 16 - 1) {
                 const int filled = min(n_items, 16);                      // counters that receive any item
-                last = atomicAdd(counters + 1, 1) == filled - 1;
+                last = atomicAdd(counters + 1 + cl.group, 1) == filled - 1;
             }
             *drawn = last;
         }
         __syncthreads();
-        if (*drawn) {
-            const uint4 z = {0u, 0u, 0u, 0u};
-            for (int i = tid; i < clean_vec; i += kThreads) clean[i] = z;
-        }
+        if (*drawn) pool_clean<kThreads>(cl, counters, tid);
         __syncthreads();                                                  // (`drawn` is written again by the next item)
     }
     }   // items
     if (kTuning && counters && draw) {                                    // drawn parts: one ticket per workgroup, after its last draw
         __syncthreads();
-        if (tid == 0) *drawn = atomicAdd(counters + 1, 1);
+        if (tid == 0) *drawn = atomicAdd(counters + 1 + cl.group, 1);
         __syncthreads();
-        if (*drawn == static_cast<int>(gridDim.x) - 1) {
-            const uint4 z = {0u, 0u, 0u, 0u};
-            for (int i = tid; i < clean_vec; i += kThreads) clean[i] = z;
-        }
+        if (*drawn == static_cast<int>(gridDim.x) - 1) pool_clean<kThreads>(cl, counters, tid);
     }
 }
 
@@ -1774,7 +1893,7 @@ int plan_pool(int frames, int n_cam, int D, int H, int W, long long n_vox_ll, in
     pl->n_words = ceil_div(pl->n_vox, 64);
     pl->off_occ = align(pl->off_lists + cols * pl->n_tiles * sizeof(int));
     pl->off_live = align(pl->off_occ + static_cast<size_t>(frames) * pl->n_words * 64);     // (cleared together with the bytes)
-    // (+ 256 B: the counter the compact form's workgroups draw the parts of the tail units from; cleared with the masks)
+    // (+ 256 B: the completion tickets / the counter the tuning builds draw the parts of the tail units from; cleared with the masks)
     pl->off_occupied = align(pl->off_live + static_cast<size_t>(frames) * n_cam * D * 4 + 256);
     pl->total = align(pl->off_occupied + static_cast<size_t>(frames) * 4);
     return FIERY_OK;
@@ -1811,7 +1930,7 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
                   "voxel_pool: bev_dimension[2] = %d; the reference only supports one z cell "
                   "(fiery/models/fiery.py:268-271)", grid->dim[2]);
     FIERY_REQUIRE(grid->dim[0] > 0 && grid->dim[1] > 0, "voxel_pool: empty grid");
-    FIERY_REQUIRE((flags & ~(FIERY_POOL_DETERMINISTIC | FIERY_POOL_WORKSPACE_CLEAN)) == 0, "voxel_pool: unknown flags 0x%x", flags);
+    FIERY_REQUIRE((flags & ~(FIERY_POOL_DETERMINISTIC | FIERY_POOL_WORKSPACE_CLEAN | FIERY_POOL_NO_RANKS)) == 0, "voxel_pool: unknown flags 0x%x", flags);
     const bool fixed = (flags & FIERY_POOL_DETERMINISTIC) != 0;
     PoolPlan pl;
     int rc = plan_pool(frames, n_cam, D, H, W, static_cast<long long>(grid->dim[0]) * grid->dim[1], tile_voxels, fixed, fused, &pl);
@@ -1884,12 +2003,17 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
         cp_threads = 2 * cp_lds <= 163840 ? 512 : 1024;                  // two workgroups per CU, or one: 16 wavefronts either way
     }
     if (compact_form) plane_form = false;
+    bool four_lanes = H <= 32;                // four lanes per column in the prepass (see k_rank_columns4)
+    if (const char* forced = getenv("FIERY_POOL_PREPASS_LANES")) four_lanes = four_lanes && atoi(forced) == 4;   // tuning / A-B runs
+    const bool no_ranks = compact_form && four_lanes && (flags & FIERY_POOL_NO_RANKS) != 0;
     const bool compact_desc = plane_form;
     const bool wide_records = pl.n_vox >= 65535;
     const int desc_mode = compact_form ? (wide_records ? 3 : 2) : (plane_form ? 1 : 0);
+    const long long occ_stride = static_cast<long long>(pl.n_words) * 64;
     unsigned char* occ = reinterpret_cast<unsigned char*>(ws + pl.off_occ);
     int* occupied = reinterpret_cast<int*>(ws + pl.off_occupied);
     unsigned* live = reinterpret_cast<unsigned*>(ws + pl.off_live);
+    int* counter_block = reinterpret_cast<int*>(ws + pl.off_occupied - 256);    // 64 ints: [0] parts drawn (tuning), [1] top counter, [16, 32) completion tickets
     // occupancy bytes + live masks + counters: cleared here unless the caller vouches that the region is as the library
     // left it (the compact form's last workgroup re-zeroes it) or as a zero-filled allocation
     if (compact_form && !(flags & FIERY_POOL_WORKSPACE_CLEAN) && hipMemsetAsync(occ, 0, pl.off_occupied - pl.off_occ, s) != hipSuccess)
@@ -1939,20 +2063,18 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
         int rows = 8;                                                    // rows of a column in flight in the prepass
         if (const char* forced = getenv("FIERY_POOL_PREPASS_ROWS")) rows = atoi(forced);         // tuning
         unsigned char* occ_arg = compact_form ? occ : nullptr;
-        const long long occ_stride = static_cast<long long>(pl.n_words) * 64;
         int* mask_arg = (plane_form || compact_form) ? nullptr : colmask;
         const dim3 pgrid(ceil_div(n_cols_all, 256));
         // four lanes per column (see k_rank_columns4) whenever a column's rows fit four parts of 7 or 8 (its run-start bits
         // are one 32-bit word)
-        bool four = H <= 32;
-        if (const char* forced = getenv("FIERY_POOL_PREPASS_LANES")) four = four && atoi(forced) == 4;   // tuning / A-B runs
+        const bool four = four_lanes;
         const dim3 pgrid4(ceil_div(n_cols_all, 64));
         if (four && H <= 28)
             hipLaunchKernelGGL((k_rank_columns4<7>), pgrid4, dim3(256), 0, s, geometry, frames * n_cam, D, H, W, to_params(*grid),
-                               pl.tile, rank, coldesc, mask_arg, desc_mode, occ_arg, n_cam, occ_stride, compact_form ? live : nullptr, clear_ptr, clear_floats);
+                               pl.tile, rank, coldesc, mask_arg, desc_mode, occ_arg, n_cam, occ_stride, compact_form ? live : nullptr, clear_ptr, clear_floats, no_ranks ? 1 : 0);
         else if (four)
             hipLaunchKernelGGL((k_rank_columns4<8>), pgrid4, dim3(256), 0, s, geometry, frames * n_cam, D, H, W, to_params(*grid),
-                               pl.tile, rank, coldesc, mask_arg, desc_mode, occ_arg, n_cam, occ_stride, compact_form ? live : nullptr, clear_ptr, clear_floats);
+                               pl.tile, rank, coldesc, mask_arg, desc_mode, occ_arg, n_cam, occ_stride, compact_form ? live : nullptr, clear_ptr, clear_floats, no_ranks ? 1 : 0);
         else if (rows >= 28)
             hipLaunchKernelGGL((k_rank_columns<28>), pgrid, dim3(256), 0, s, geometry, frames * n_cam, D, H, W, to_params(*grid),
                                pl.tile, rank, coldesc, mask_arg, desc_mode, occ_arg, n_cam, occ_stride, compact_form ? live : nullptr, clear_ptr, clear_floats);
@@ -1968,15 +2090,16 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
     if (compact_form) {
         const int per_cu = cp_threads == 512 ? 2 : 1;
         const int tail = cp_tail, parts = cp_parts;
-        const int tail_first = C * frames - tail;                        // (their planes were zeroed by the prepass)
+        const int tail_first = C * frames - tail;                        // (the first of the tail units)
         if (getenv("FIERY_POOL_VERBOSE"))
             fprintf(stderr, "voxel_pool compact: %d cells, %zu B LDS, %d threads, %d per CU, %d units + %d x %d parts\n", cp_cells,
                     cp_lds, cp_threads, per_cu, tail_first, tail, parts);
         const int n_items = tail_first + tail * parts;
         dim3 units(static_cast<unsigned>(persistent && n_items > cp_slots ? cp_slots : n_items));
         // (the counter lies in the cleared region in front of `occupied`)
-        int* draw = (persistent && tail > 0 && !getenv("FIERY_POOL_NO_DRAW")) ? reinterpret_cast<int*>(ws + pl.off_occupied - 256) : nullptr;
-        int* counters = reinterpret_cast<int*>(ws + pl.off_occupied - 256);       // [0] parts drawn, [1] workgroups finished
+        int* draw = (persistent && tail > 0 && !getenv("FIERY_POOL_NO_DRAW")) ? counter_block : nullptr;
+        int* counters = counter_block;
+        const PoolClean cl{reinterpret_cast<uint4*>(occ), static_cast<int>(frames * occ_stride / 16), live, frames * n_cam * D, 0};
         if (getenv("FIERY_POOL_NO_COUNTERS")) counters = nullptr;                   // tuning: no tickets, no in-kernel cleaning (callers must not pass WORKSPACE_CLEAN)
         int part_ranges = 0;
         if (const char* forced = getenv("FIERY_POOL_PART_RANGES")) part_ranges = atoi(forced);      // tuning / A-B runs
@@ -2000,8 +2123,8 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
             return fail(FIERY_ELAUNCH, "voxel_pool: cannot reserve %zu B of LDS", cp_lds);                              \
         hipLaunchKernelGGL((k_voxel_pool_compact<THREADS, WIDE, EXACT, NT, TUNING>), units, dim3(THREADS), cp_lds, s, x, st, rank, \
                            static_cast<const void*>(coldesc), occ, live, out, occupied, n_cam, D, H, W, C, pl.n_vox, pl.n_words, \
-                           cp_cells, tail_first, parts, n_items, draw, trace, late_first, late_prio, counters,           \
-                           reinterpret_cast<uint4*>(occ), static_cast<int>((pl.off_occupied - pl.off_occ) / 16), part_ranges); \
+                           cp_cells, tail_first, parts, n_items, draw, trace, late_first, late_prio, counters, cl,       \
+                           part_ranges);                                                                                \
     } while (0)
 #define FIERY_POOL_COMPACT_ROWS(THREADS, WIDE)                            \
     do {                                                                 \

@@ -449,6 +449,7 @@ class BevEngine:
         # the engine's pooling workspace is zero-filled once and then only used by the library: calls skip their memset
         # (FIERY_POOL_NO_CLEAN=1: A/B runs against the memset form)
         self._pool_clean_flag = 0 if os.environ.get('FIERY_POOL_NO_CLEAN') == '1' else native.POOL_WORKSPACE_CLEAN
+        self._pool_rank_flag = 0 if os.environ.get('FIERY_POOL_KEEP_RANKS') == '1' else native.POOL_NO_RANKS
         # matrix-core precision of every convolution of this plan ('f32' | 'bf16'; model.conv_precision)
         self.precision = {'f32': native.PRECISION_F32, 'bf16': native.PRECISION_BF16}[getattr(model, 'conv_precision', 'f32')]
         previous, ops.DEFAULT_PRECISION = ops.DEFAULT_PRECISION, self.precision
@@ -738,12 +739,14 @@ class BevEngine:
             return res if out is None else out.copy_(res)
         ws = self._pool_workspace(f, n, d, h, w, x.device)
         # The op's algorithmic bytes (4.C.N_kept + 12.N + 4.C.X.Y per frame) need N_kept, the number of
-        # in-grid points; the prepass leaves every point's voxel rank (-1 = outside) at the head of the workspace, so
-        # the profiling consumer counts them after the run (`pool_algorithmic_bytes`) - no device read-back here.
-        detail = dict(workspace=ws, points=f * n * d * h * w, channels=c, frames=f, voxels=self.X * self.Y)
+        # in-grid points: the profiling consumer counts them from the geometry after the run (`pool_algorithmic_bytes`).
+        # No backward follows this call, so it leaves no voxel ranks behind (POOL_NO_RANKS: 17 MB of stores less).
+        geometry = geometry.contiguous()
+        detail = dict(lib=self.lib, geometry=geometry, grid=self.grid, points=f * n * d * h * w, channels=c, frames=f,
+                      voxels=self.X * self.Y) if ops.PROFILE_SINK is not None else None
         return ops.profiled('voxel_pool', None, x, lambda: self._pool_call((f, n, d, h, w), lambda: self.lib.voxel_pool(
-            x, x.stride(), geometry.contiguous(), f, n, d, h, w, c, self.grid, out=out, workspace=ws,
-            tile_voxels=self.pool_tile, flags=self.pool_flags | self._pool_clean_flag)), detail=detail)
+            x, x.stride(), geometry, f, n, d, h, w, c, self.grid, out=out, workspace=ws,
+            tile_voxels=self.pool_tile, flags=self.pool_flags | self._pool_clean_flag | self._pool_rank_flag)), detail=detail)
 
     def pool_fused(self, depth_logits, features, geometry, out=None):
         """depth logits (F, n, D, h, w) + features (F, n, C, h, w) -> (F, C, X, Y) without the outer product."""

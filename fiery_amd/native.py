@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libfiery_hip.so')
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -25,6 +25,7 @@ PRECISION_F32, PRECISION_BF16 = 0, 1
 EPI_PLAIN, EPI_GRU_GATES, EPI_GRU_OUT, EPI_HEADS = 0, 1, 2, 3
 POOL_DETERMINISTIC = 1
 POOL_WORKSPACE_CLEAN = 2        # the workspace is a zero-filled allocation or was left by a successful pooling call
+POOL_NO_RANKS = 4               # inference: the call leaves no voxel ranks in its workspace (nobody runs backward)
 WARP_FUSED_GRID_PRODUCT = 1
 
 

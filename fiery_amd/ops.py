@@ -34,10 +34,12 @@ def profiled(kind, work, stream_tensor, fn, detail=None):
 
 def pool_algorithmic_bytes(detail):
     """Algorithmic HBM bytes of one pooling call recorded by `profiled('voxel_pool', ...)`:
-    every in-grid point's C features once, every point's geometry once, the dense output once.  Call after the
-    launch has completed: N_kept is counted from the voxel ranks the prepass left in the workspace."""
+    every in-grid point's C features once, every point's geometry once, the dense output once.  N_kept is counted with
+    `fiery_voxel_index` on the geometry the call read (inference calls leave no voxel ranks in their workspace since round 6:
+    FIERY_POOL_NO_RANKS) - call it after the step, outside any timed region."""
     n_points = detail['points']
-    n_kept = int((detail['workspace'][:n_points] >= 0).sum().item())
+    rank, _ = detail['lib'].voxel_index(detail['geometry'], detail['grid'], want_idx=False)
+    n_kept = int((rank >= 0).sum().item())
     c = detail['channels']
     return 4.0 * c * n_kept + 12.0 * n_points + 4.0 * c * detail['voxels'] * detail['frames'], n_kept
 

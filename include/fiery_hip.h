@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FIERY_ABI_VERSION 22      /* 22 (round 5): fiery_conv_desc grew (weights_winograd, winograd, stream_k, sk_*); fiery_conv_pack_weights_winograd, fiery_conv_winograd_packed_floats, fiery_conv_stream_k_plan */
+#define FIERY_ABI_VERSION 23      /* 23 (round 6): FIERY_POOL_NO_RANKS, the prepass quantises without divisions where that is exact; 22 (round 5): fiery_conv_desc grew (weights_winograd, winograd, stream_k, sk_*); fiery_conv_pack_weights_winograd, fiery_conv_winograd_packed_floats, fiery_conv_stream_k_plan */
 
 #define FIERY_OK 0
 #define FIERY_EINVAL (-22)      /* bad argument (shape, alignment, null pointer) */
@@ -96,6 +96,11 @@ int fiery_voxel_index(const float* geometry, int64_t n_points, const fiery_bev_g
  * this library that returned FIERY_OK (every call leaves the region it clears as it found it): the call then skips its
  * memset dispatch.  Without the flag any workspace contents are accepted. */
 #define FIERY_POOL_WORKSPACE_CLEAN 2u
+/* flags: the caller does not need the voxel ranks (int32 [frames][n_cameras][D][H][W], -1 = outside the grid) that a
+ * pooling call otherwise leaves at the head of its workspace for fiery_voxel_pool_bwd: an inference call in the
+ * compact-plane form then does not write them (17 MB of the prepass's 27 MB of stores at baseline.yml; the other
+ * forms read the ranks themselves and ignore the flag).  Results are unchanged. */
+#define FIERY_POOL_NO_RANKS 4u
 
 /* Scratch needed by fiery_voxel_pool_fwd / fiery_lift_splat_fwd for this problem (n_voxels = X*Y;
  * tile_voxels and flags as passed to the pooling call); 0 if the arguments are unusable. */

@@ -271,6 +271,17 @@ inline int __shfl_xor(int v, int mask) {
     ::hipsim::barrier_wait(run.waves[t.wave]);
     return got;
 }
+// lane l receives lane (l - delta)'s value; lanes below `delta` keep their own (HIP's __shfl_up)
+inline int __shfl_up(int v, unsigned delta) {
+    ::hipsim::Run& run = *::hipsim::run_ptr();
+    const ::hipsim::Tls& t = ::hipsim::tls();
+    int* slot = reinterpret_cast<int*>(run.wave_a[t.wave].data());
+    slot[t.lane] = v;
+    ::hipsim::barrier_wait(run.waves[t.wave]);
+    const int got = t.lane >= static_cast<int>(delta) ? slot[t.lane - static_cast<int>(delta)] : v;
+    ::hipsim::barrier_wait(run.waves[t.wave]);
+    return got;
+}
 inline int __ffs(int v) { return __builtin_ffs(v); }
 
 // f32 MFMA 32x32x2: D = A(32x2) . B(2x32) + C, one wave.

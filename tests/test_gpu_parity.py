@@ -113,7 +113,7 @@ def _native_strides(x):
 
 @pytest.mark.parametrize('preset,n_cam', [('literature/static_lss_setting.yml', 1), ('baseline.yml', 6),
                                           ('literature/pon_setting.yml', 6)])
-@pytest.mark.parametrize('flags', [0, native.POOL_DETERMINISTIC])
+@pytest.mark.parametrize('flags', [0, native.POOL_DETERMINISTIC, native.POOL_NO_RANKS])
 def test_voxel_pool_vs_oracle(hip, preset, n_cam, flags):
     cfg = get_preset_cfg(preset)
     grid, (res, start, dim) = _grid_of(cfg)
@@ -127,9 +127,20 @@ def test_voxel_pool_vs_oracle(hip, preset, n_cam, flags):
     got = out[0].cpu().numpy()
     assert np.abs(got - exact).max() < 2e-5          # a plain fp32 segmented sum sits ~1e-6 from the truth
     assert np.abs(got - ref).max() < TOL             # the reference's prefix-sum trick is the noisy one
-    if flags:
+    if flags == native.POOL_DETERMINISTIC:
         again = hip.voxel_pool(x, _native_strides(x), torch.from_numpy(geo).to(DEV), f, n, D, h, w, C, grid, flags=flags)
         assert torch.equal(again, out)               # bit-reproducible mode
+    if flags == native.POOL_NO_RANKS:
+        # the inference flag: no voxel ranks left in the workspace except those of the many-run quads; the plane of every
+        # whole (channel, frame) unit has the bits of the call that writes them all (a single frame: no tail units)
+        ws = hip.pool_workspace(f, n, D, h, w, x.device, grid)
+        ws.fill_(-77)
+        again = hip.voxel_pool(x, _native_strides(x), torch.from_numpy(geo).to(DEV), f, n, D, h, w, C, grid, workspace=ws, flags=flags)
+        assert np.abs(again[0].cpu().numpy() - exact).max() < 2e-5
+        left = ws[:f * n * D * h * w]
+        rank, _ = hip.voxel_index(torch.from_numpy(geo).to(DEV), grid, want_idx=False)
+        written = left != -77
+        assert int(written.sum()) < left.numel() // 4 and torch.equal(left[written], rank.view(-1)[written])
 
 
 def test_voxel_pool_full_baseline_size_properties(hip):

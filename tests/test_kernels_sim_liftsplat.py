@@ -650,3 +650,32 @@ def test_pooling_leaves_its_workspace_clean(sim, monkeypatch, persistent, channe
         assert torch.equal(sim.pool_occupied(ws, frames, n_cam, D, H, W, grid), sim.pool_occupied(dirty, frames, n_cam, D, H, W, grid))
         n_occ_words = frames * ((grid.dim[0] * grid.dim[1] + 63) // 64) * 16 + frames * n_cam * D + 64
         assert int(ws[off - n_occ_words:off].abs().sum()) == 0           # occupancy bytes, live masks, counters: all zero again
+
+
+@pytest.mark.parametrize('H', [28, 27])
+def test_no_ranks_flag_leaves_the_result_unchanged(sim, H):
+    """FIERY_POOL_NO_RANKS: the prepass writes the voxel ranks of the many-run quads only (the compact kernel walks those
+    row by row); planes are bit-identical to the call that leaves all ranks behind, on a rig with a rolled camera (many-run
+    quads) and points outside the grid, on a workspace whose rank area holds garbage."""
+    from fiery_amd import native
+    frustum, intr, extr, lifted = _small_problem(81, n_cam=3, D=16, H=H, W=40, C=2, frames=2)
+    roll = torch.tensor([[0.0, -1.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0], [0.0, 0.0, 1.0, 0.0], [0.0, 0.0, 0.0, 1.0]])
+    extr = extr.clone()
+    extr[:, 0] = extr[:, 0] @ roll
+    frames, n_cam, C, D, H, W = lifted.shape
+    geo = torch.from_numpy(ls.get_geometry(frustum, intr.numpy(), extr.numpy()))
+    grid, _ = _grid([-14.0, 30.0, 0.5], [-24.0, 10.0, 0.5], [-10.0, 10.0, 20.0])
+    st = lifted.stride()
+    strides = (st[0], st[1], st[3], st[4], st[5], st[2])
+    ws = sim.pool_workspace(frames, n_cam, D, H, W, lifted.device, grid)
+    ws.fill_(-11)
+    want = sim.voxel_pool(lifted, strides, geo, frames, n_cam, D, H, W, C, grid, workspace=ws)
+    n_pts = frames * n_cam * D * H * W
+    ranks = ws[:n_pts].clone()
+    ws2 = sim.pool_workspace(frames, n_cam, D, H, W, lifted.device, grid)
+    ws2.fill_(123456)                                             # a rank that would index far outside the bit map
+    got = sim.voxel_pool(lifted, strides, geo, frames, n_cam, D, H, W, C, grid, workspace=ws2, flags=native.POOL_NO_RANKS)
+    assert torch.equal(got, want)
+    written = ws2[:n_pts] != 123456
+    assert 0 < int(written.sum()) < n_pts // 4                    # some quads are many-run quads, most are not
+    assert torch.equal(ws2[:n_pts][written], ranks[written])
