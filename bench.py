@@ -244,6 +244,13 @@ def main():
     # The timed step replays the whole path (every kernel, same work) from one captured hipGraph; the first call
     # captures it and is checked against the eager path.
     step, launch_mode = eager_step, 'host enqueue per launch'
+    if use_dist:
+        # every rank runs rank 0's convolution forms (they differ in fp32 rounding; each rank's own timings could pick differently)
+        from fiery_amd.parallel import share_conv_forms
+        with torch.no_grad():
+            eager_step()                                   # (tunes this rank's launches)
+        torch.cuda.synchronize()
+        share_conv_forms(freeze=False)                 # (later modes - the one-stream instrumented steps - may still tune their shapes)
     if not args.no_graph and graph_step is not None:
         try:
             with torch.no_grad():

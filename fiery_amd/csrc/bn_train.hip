@@ -360,7 +360,7 @@ extern "C" int fiery_bn_train_fwd(const float* x, int ld, int64_t n_pixels, int 
     FIERY_REQUIRE(x && y && mean && invstd && workspace, "bn_train_fwd: null pointer");
     FIERY_REQUIRE(n_pixels > 0 && C > 0 && ld >= C && C_store >= C && y_ld >= C_store, "bn_train_fwd: bad shape");
     FIERY_REQUIRE(batch_stats || (running_mean && running_var), "bn_train_fwd: eval mode needs the running statistics");
-    FIERY_REQUIRE(C <= 4 * kBnThreads, "bn_train_fwd: at most %d channels", 4 * kBnThreads);
+    FIERY_REQUIRE(C_store <= 4 * kBnThreads, "bn_train_fwd: at most %d stored channels", 4 * kBnThreads);     // (the apply pass deals channel quads to a workgroup's threads)
     hipStream_t hs = as_stream(stream);
     const BnShape s = bn_shape(n_pixels, C);
     const int Cp = (C + 3) / 4 * 4;
@@ -412,7 +412,7 @@ extern "C" int fiery_bn_train_bwd(const float* grad_out, int g_ld, const float* 
     FIERY_REQUIRE(grad_out && x && mean && invstd && grad_in && dgamma && dbeta && workspace, "bn_train_bwd: null pointer");
     FIERY_REQUIRE(n_pixels > 0 && C > 0 && ld >= C && g_ld >= C && (!y || y_ld >= C) && C_store >= C && gi_ld >= C_store,
                   "bn_train_bwd: bad shape");
-    FIERY_REQUIRE(C <= 4 * kBnThreads, "bn_train_bwd: at most %d channels", 4 * kBnThreads);
+    FIERY_REQUIRE(C_store <= 4 * kBnThreads, "bn_train_bwd: at most %d stored channels", 4 * kBnThreads);
     const int rc = bn_bwd_reduce(grad_out, g_ld, x, ld, y, y_ld, n_pixels, C, mean, invstd, dgamma, dbeta, workspace, as_stream(stream));
     if (rc) return rc;
     return bn_bwd_dx(grad_out, g_ld, x, ld, y, y_ld, n_pixels, C, gamma, mean, invstd, dgamma, dbeta, batch_stats, n_pixels, grad_in, gi_ld,
@@ -462,6 +462,7 @@ extern "C" int fiery_bn_train_bwd_dx(const float* grad_out, int g_ld, const floa
     FIERY_REQUIRE(grad_out && x && mean && invstd && dgamma && dbeta && grad_in, "bn_train_bwd_dx: null pointer");
     FIERY_REQUIRE(n_pixels > 0 && total_pixels >= n_pixels && C > 0 && ld >= C && g_ld >= C && (!y || y_ld >= C) && C_store >= C &&
                       gi_ld >= C_store, "bn_train_bwd_dx: bad shape");
+    FIERY_REQUIRE(C_store <= 4 * kBnThreads, "bn_train_bwd_dx: at most %d stored channels", 4 * kBnThreads);
     return bn_bwd_dx(grad_out, g_ld, x, ld, y, y_ld, n_pixels, C, gamma, mean, invstd, dgamma, dbeta, 1, total_pixels, grad_in, gi_ld, C_store,
                      as_stream(stream));
 }

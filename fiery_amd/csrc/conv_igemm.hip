@@ -199,13 +199,15 @@ struct StreamKPlan {
     long long workspace_bytes = 0;
     int n_counters = 0, n_workgroups = 0;
 };
-enum ConvRunMode { kRunLaunch, kRunPrecision, kRunStreamKPlan };
+enum ConvRunMode { kRunLaunch, kRunPrecision, kRunStreamKPlan, kRunForm };
 int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, ConvRunMode mode, StreamKPlan* plan = nullptr);
 }  // namespace
 
 extern "C" int fiery_conv_fwd(const fiery_conv_desc* d, fiery_stream_t stream) { return conv_run(d, stream, kRunLaunch); }
 
 extern "C" int fiery_conv_precision_used(const fiery_conv_desc* d) { return conv_run(d, nullptr, kRunPrecision); }
+
+extern "C" int fiery_conv_form_used(const fiery_conv_desc* d) { return conv_run(d, nullptr, kRunForm); }
 
 extern "C" int fiery_conv_stream_k_plan(const fiery_conv_desc* d, int64_t* workspace_bytes, int32_t* n_counters, int32_t* n_workgroups) {
     FIERY_REQUIRE(workspace_bytes && n_counters && n_workgroups, "conv_stream_k_plan: null pointer");
@@ -473,6 +475,7 @@ int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, ConvRunMode mode, 
                           d->precision != FIERY_PRECISION_BF16 && aligned16(d->weights_winograd) &&
                           static_cast<long long>(d->n_img_out) * ((d->Hout + 1) / 2) * ((d->Wout + 1) / 2) < (1ll << 30);
     const bool bf16 = !stream_k && !winograd && conv_takes_bf16(d, aligned, bm, bn, cin_units);
+    if (mode == kRunForm) return winograd ? FIERY_CONV_FORM_WINOGRAD : (stream_k ? FIERY_CONV_FORM_STREAM_K : FIERY_CONV_FORM_TILE);
     if (!launch) return bf16 ? FIERY_PRECISION_BF16 : FIERY_PRECISION_F32;
     if (winograd) {
         {

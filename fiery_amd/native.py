@@ -23,6 +23,7 @@ c_uint8_p = C.POINTER(C.c_uint8)
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SWISH = 0, 1, 2, 3
 PRECISION_F32, PRECISION_BF16 = 0, 1
 EPI_PLAIN, EPI_GRU_GATES, EPI_GRU_OUT, EPI_HEADS = 0, 1, 2, 3
+CONV_FORM_TILE, CONV_FORM_STREAM_K, CONV_FORM_WINOGRAD = 0, 1, 2
 POOL_DETERMINISTIC = 1
 POOL_WORKSPACE_CLEAN = 2        # the workspace is a zero-filled allocation or was left by a successful pooling call
 POOL_NO_RANKS = 4               # inference: the call leaves no voxel ranks in its workspace (nobody runs backward)
@@ -129,6 +130,7 @@ _SIGNATURES = {
     'fiery_conv_fwd': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     'fiery_conv_pack_weights_bf16': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_int32_p, C.c_int, C.c_void_p, C.c_void_p]),
     'fiery_conv_precision_used': (C.c_int, [C.POINTER(ConvDesc)]),
+    'fiery_conv_form_used': (C.c_int, [C.POINTER(ConvDesc)]),
     'fiery_conv_winograd_packed_floats': (C.c_size_t, [C.c_int, C.c_int]),
     'fiery_conv_pack_weights_winograd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_void_p]),
     'fiery_conv_stream_k_plan': (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -448,6 +450,14 @@ class Lib:
             self.check(rc)
         return rc
 
+    def conv_form_used(self, desc):
+        """CONV_FORM_TILE / _STREAM_K / _WINOGRAD: the form `conv_fwd` runs this descriptor in (requests the form does not
+        cover fall back to the tile form)."""
+        rc = self.dll.fiery_conv_form_used(C.byref(desc))
+        if rc < 0:
+            self.check(rc)
+        return rc
+
     def conv_stream_k_plan(self, desc):
         """(workspace bytes, counters, workgroups) of the stream-K form of this launch; workgroups = 0: not covered."""
         nbytes, n_cnt, n_wg = C.c_int64(0), C.c_int32(0), C.c_int32(0)
@@ -467,7 +477,7 @@ class Lib:
         for v in shape:
             n *= int(v)
         step = (n + 63) // 64 * 64                                                          # 256-byte aligned slices
-        if device.type != 'cuda' or step * 4 > self.ZERO_CHUNK_FLOATS or torch.cuda.is_current_stream_capturing():
+        if device.type != 'cuda' or step > self.ZERO_CHUNK_FLOATS or torch.cuda.is_current_stream_capturing():
             return torch.zeros(shape, dtype=torch.float32, device=device)
         if not hasattr(self, '_zero_chunks'):
             self._zero_chunks = {}

@@ -154,7 +154,10 @@ class ConvOp:
         # stages per source, 64-cout tiles; fp32 only): a candidate form of `_pick_tile`
         self.packed_winograd = None
         if (WINOGRAD and self.precision == native.PRECISION_F32 and (self.kT, self.kH, self.kW) == (1, 3, 3) and stride == 1 and
-                (self.padH, self.padW) == (1, 1) and self.cout_pad % 64 == 0 and all(u % 2 == 0 for u in self.units)):
+                (self.padH, self.padW) == (1, 1) and self.cout_pad % 64 == 0 and all(u % 2 == 0 for u in self.units) and
+                # (what the library's scalar-addressed loop - the only one with a Winograd form - asks of the channel layout:
+                # whole 32-channel stages per tap and in source 0; a launch can still fall back on extents, see `_winograd_taken`)
+                cin_units % 4 == 0 and self.units[0] % 4 == 0 and cin_units >= 4):
             self.packed_winograd = lib.conv_pack_weights_winograd(w.view(self.cout, self.cin_total, taps), self.cout, self.cin_total,
                                                                   list(chan_map), cin_units)
         if torch.is_tensor(scale) and scale.device == w.device and scale.numel() == self.cout_pad:
@@ -170,8 +173,8 @@ class ConvOp:
         self.chain = None
         self.chain3 = None
         self.heads = None
-        self._tile_m = {}            # (n_img, H, W) of the output -> measured best form (64 / 128 pixel tiles, 'sk')
         self.force_form = None       # tests / A-B runs: 64, 128 or 'sk' instead of the measured choice
+
 
     def chain_pointwise(self, weight, scale, shift, act):
         """Fuse a following 1x1 convolution (Cin <= 32 = this op's padded outputs, Cout <= 64) into this kernel:
@@ -208,7 +211,6 @@ class ConvOp:
         sc[:cout3], sh[:cout3] = scale, shift
         op.chain3 = dict(w=self.lib.conv_pack_weights(w32.contiguous(), 32, 64, 1, list(range(64)), 8), scale=sc.to(device),
                          shift=sh.to(device), act=act, cout=cout3)
-        op._tile_m = {}
         return op
 
     def attach_heads(self, weight, bias, groups, sigmoids):
@@ -240,6 +242,32 @@ class ConvOp:
             d.sk_workspace = d.sk_counters = None
             d.sk_workspace_bytes = d.sk_counters_len = 0
 
+    @property
+    def _sig(self):
+        """What identifies this layer in the process-wide table of measured forms (`FORM_TABLE`): everything a launch's
+        candidates and their timings depend on except the output shape."""
+        return (self.kT, self.kH, self.kW, self.stride, self.cin_total, self.cout, self.units, self.act, self.epi,
+                int(self.res_before_act), self.precision, self.chain['cout'] if self.chain else 0,
+                self.chain3['cout'] if self.chain3 else 0, self.heads['n_out'] if self.heads else 0)
+
+    @property
+    def _tile_m(self):
+        """This layer's measured forms, {(n_img, H, W) of the output: form} (a view of `FORM_TABLE`)."""
+        sig = self._sig
+        return {k[1]: v for k, v in FORM_TABLE.items() if k[0] == sig}
+
+    def _winograd_taken(self, d):
+        """Whether the library runs THIS launch as Winograd when asked to (the packed image exists for every 3 x 3 / stride 1
+        layer with whole 16-channel stages; the launch also needs the aligned, 16-byte addressable variant, an unchained
+        epilogue, ... - `fiery_conv_form_used` knows).  Leaves the descriptor's form members as it found them."""
+        if self.packed_winograd is None:
+            return False
+        keep = (d.winograd, d.weights_winograd)
+        d.winograd, d.weights_winograd = 1, self.packed_winograd.data_ptr()
+        taken = self.lib.conv_form_used(d) == native.CONV_FORM_WINOGRAD
+        d.winograd, d.weights_winograd = keep
+        return taken
+
     def _pick_tile(self, d, out):
         """The form of this launch: a tile height (64 / 128 output pixels per workgroup, one workgroup per tile), or
         stream-K (the launch's work dealt evenly to one round of workgroups, shared tiles summed through a workspace -
@@ -254,18 +282,18 @@ class ConvOp:
         if self.heads is not None and self.packed_winograd is None:
             return                                     # (the heads' direct form has one tile shape)
         key = (out.n_img, out.H, out.W)
-        choice = self._tile_m.get(key) if self.force_form is None else self.force_form
+        choice = FORM_TABLE.get((self._sig, key)) if self.force_form is None else self.force_form
         if choice is None and FORCE_FORM:
             choice = FORCE_FORM if FORCE_FORM in ('sk', 'wino') else int(FORCE_FORM)
         if choice == 'wino' and self.packed_winograd is None:
             choice = 0
         sk = _stream_k_workspace(self.lib, d, out.tensor) if (choice == 'sk' or choice is None) and self.heads is None else None
         if choice is None:
-            if not _autotune_enabled(out.tensor):
+            if FORM_TABLE_FROZEN or not _autotune_enabled(out.tensor):
                 return                                 # library heuristic (and nothing cached: tune when possible)
-            forms = [64, 128] + (['sk'] if sk is not None else []) + (['wino'] if self.packed_winograd is not None else [])
+            forms = [64, 128] + (['sk'] if sk is not None else []) + (['wino'] if self._winograd_taken(d) else [])
             if self.heads is not None:
-                forms = [0, 'wino']                    # heads epilogue: the direct form's one tile shape, or Winograd
+                forms = [0, 'wino'] if 'wino' in forms else [0]     # heads epilogue: the direct form's one tile shape, or Winograd
             times = {f: float('inf') for f in forms}
             for _trial in range(2):                    # alternate the candidates, keep each one's best trial
                 for form in forms:
@@ -278,7 +306,7 @@ class ConvOp:
                     end.record()
                     end.synchronize()
                     times[form] = min(times[form], start.elapsed_time(end))
-            choice = self._tile_m[key] = min(times, key=times.get)
+            choice = FORM_TABLE[(self._sig, key)] = min(times, key=times.get)
         if choice == 'sk' and sk is None:
             choice = 0                                 # (no workspace for this stream, e.g. first met inside a capture)
         self._set_form(d, choice, sk)
@@ -353,10 +381,9 @@ class ConvOp:
         used = 'f32'
         if PROFILE_SINK is not None and d.precision == native.PRECISION_BF16:
             used = 'bf16' if self.lib.conv_precision_used(d) == native.PRECISION_BF16 else 'f32'
-        if d.winograd:
-            used = 'f32 winograd'
-        elif d.stream_k:
-            used = 'f32 stream-K'
+        if PROFILE_SINK is not None and (d.winograd or d.stream_k):
+            form = self.lib.conv_form_used(d)          # (what ran, not what was asked for: the flops accounting hangs on it)
+            used = {native.CONV_FORM_WINOGRAD: 'f32 winograd', native.CONV_FORM_STREAM_K: 'f32 stream-K'}.get(form, used)
         profiled('conv_igemm', flops, out.tensor, lambda: self.lib.conv_fwd(d, out.tensor),
                  detail=(self.kT, self.kH, self.kW, self.stride, self.cin_total, self.cout, out.n_img, out.H, out.W, used))
 
@@ -371,6 +398,46 @@ SK_COUNTERS = 1 << 17
 STREAM_K = os.environ.get('FIERY_STREAM_K', '1') != '0'
 FORCE_FORM = os.environ.get('FIERY_CONV_FORM')      # A/B runs: '64', '128', 'sk' or 'wino' for every launch that has the form, no timing
 WINOGRAD = os.environ.get('FIERY_CONV_WINOGRAD', '1') != '0'
+
+
+# Measured forms, one table per process: (layer signature, (n_img, H, W) of the output) -> 64 / 128 / 'sk' / 'wino'.  The forms
+# differ in fp32 rounding (another summation split, Winograd's transforms), and which one wins a timing can differ between runs
+# and between ranks - so the table can be taken out (`form_table`), put back (`load_form_table`: a frozen table makes every
+# launch reproducible - shapes it does not hold take the library's heuristic form, nothing is timed) and shared between the
+# ranks of a job (`fiery_amd.parallel.share_conv_forms`: every rank runs rank 0's arithmetic).  FIERY_CONV_FORM_TABLE=<file>:
+# loaded frozen at import when the file exists; `save_form_table(path)` writes it.
+FORM_TABLE = {}
+FORM_TABLE_FROZEN = False
+
+
+def form_table():
+    return dict(FORM_TABLE)
+
+
+def load_form_table(table, frozen=True):
+    global FORM_TABLE_FROZEN
+    FORM_TABLE.clear()
+    FORM_TABLE.update(table)
+    FORM_TABLE_FROZEN = bool(frozen)
+
+
+def save_form_table(path):
+    import json
+    with open(path, 'w') as fh:
+        json.dump([[list(sig), list(key), form] for (sig, key), form in sorted(FORM_TABLE.items(), key=repr)], fh)
+
+
+def read_form_table(path):
+    import json
+
+    def tup(v):
+        return tuple(tup(x) for x in v) if isinstance(v, list) else v
+    with open(path) as fh:
+        return {(tup(sig), tup(key)): form for sig, key, form in json.load(fh)}
+
+
+if os.environ.get('FIERY_CONV_FORM_TABLE') and os.path.exists(os.environ['FIERY_CONV_FORM_TABLE']):
+    load_form_table(read_form_table(os.environ['FIERY_CONV_FORM_TABLE']), frozen=True)
 
 
 def capture_stream(device):

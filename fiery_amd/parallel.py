@@ -35,6 +35,22 @@ def _timed_exchange(fn, bytes_received, device):
     return out
 
 
+def share_conv_forms(group=None, src=0, freeze=True):
+    """Every rank takes rank `src`'s table of measured convolution forms (`ops.FORM_TABLE`): the forms differ in fp32
+    rounding, and ranks that timed their own candidates may have picked differently - after this call every rank runs the
+    same arithmetic (and, with `freeze`, times nothing more: shapes the table does not hold take the library's heuristic
+    form).  Call after the warm-up pass that tuned the launches and before anything is captured or compared."""
+    from . import ops
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if freeze:
+            ops.load_form_table(ops.form_table(), frozen=True)
+        return ops.form_table()
+    box = [ops.form_table() if dist.get_rank(group) == src else None]
+    dist.broadcast_object_list(box, src=src, group=group)
+    ops.load_form_table(box[0], frozen=freeze)
+    return box[0]
+
+
 def block_range(n_items, world, rank):
     """Balanced contiguous partition: [lo, hi) of `n_items` owned by `rank`; every rank gets floor or ceil of
     n_items / world items (9 samples on 8 ranks: one rank takes two, nobody idles while another holds a double share)."""

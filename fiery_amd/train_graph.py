@@ -148,6 +148,10 @@ class HipConv2d(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = lib.conv_wgrad(x_nhwc, g, cout, k, stride, pad, CONV_PRECISION)  # (cout, taps, cp)
             gw = dw[:, :, :c].permute(0, 2, 1).reshape(cout, c, k, k)
+            if gw.untyped_storage().data_ptr() == dw.untyped_storage().data_ptr():
+                # (a 1 x 1 layer with unpadded channels: the reshape is a VIEW of the zeroed chunk `conv_wgrad` accumulated into,
+                # which other gradients share - autograd must be handed a tensor that owns its storage)
+                gw = gw.clone()
         if ctx.needs_input_grad[0]:
             # dL/dx = correlation of the (zero-stuffed, for stride > 1) output gradient with the transposed, mirrored
             # weights, padding k - 1 - pad: the forward kernel again

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FIERY_ABI_VERSION 23      /* 23 (round 6): FIERY_POOL_NO_RANKS, the prepass quantises without divisions where that is exact; 22 (round 5): fiery_conv_desc grew (weights_winograd, winograd, stream_k, sk_*); fiery_conv_pack_weights_winograd, fiery_conv_winograd_packed_floats, fiery_conv_stream_k_plan */
+#define FIERY_ABI_VERSION 23      /* 23 (round 6): fiery_conv_form_used, FIERY_POOL_NO_RANKS, the prepass quantises without divisions where that is exact; 22 (round 5): fiery_conv_desc grew (weights_winograd, winograd, stream_k, sk_*); fiery_conv_pack_weights_winograd, fiery_conv_winograd_packed_floats, fiery_conv_stream_k_plan */
 
 #define FIERY_OK 0
 #define FIERY_EINVAL (-22)      /* bad argument (shape, alignment, null pointer) */
@@ -404,6 +404,14 @@ int fiery_conv_wgrad_prec(const float* in, int in_ld, int64_t in_img_stride, int
 /* FIERY_PRECISION_F32 or FIERY_PRECISION_BF16: the matrix-core form fiery_conv_fwd runs this descriptor in (negative:
  * an error code - the descriptor is invalid). */
 int fiery_conv_precision_used(const fiery_conv_desc* desc /* host */);
+
+/* The form fiery_conv_fwd runs this descriptor in: a request for Winograd (`winograd`) or stream-K (`stream_k`) is taken only
+ * where the form covers the launch and silently falls back to the tile form otherwise - callers that account flops or time
+ * candidate forms ask here (negative: an error code - the descriptor is invalid). */
+#define FIERY_CONV_FORM_TILE 0
+#define FIERY_CONV_FORM_STREAM_K 1
+#define FIERY_CONV_FORM_WINOGRAD 2
+int fiery_conv_form_used(const fiery_conv_desc* desc /* host */);
 
 /* What the stream-K form of this descriptor needs (the descriptor's own stream_k / sk_* members are not looked at):
  * *n_workgroups = 0 when the form does not cover the launch, else its grid, with *workspace_bytes (partial tiles) and

@@ -326,3 +326,42 @@ def test_distributed_data_parallel_around_the_training_graph():
         top = max(v.abs().max().item() for v in want.values())
         for name, g in want.items():
             assert (got[name] - g).abs().max().item() <= 1e-4 * g.abs().max().item() + 1e-5 * top, name
+
+
+def _forms_worker(rank, world, port, results):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from fiery_amd import ops
+        from fiery_amd.parallel import share_conv_forms
+        sig = (1, 3, 3, 1, 128, 128, (16, 0), 1, 0, 0, 0, 0, 0, 0)
+        # every rank "measured" something else for the same launch, rank 1 also a shape of its own
+        ops.load_form_table({(sig, (3, 200, 200)): ['wino', 128, 'sk'][rank % 3], (sig, (rank, 50, 50)): 64}, frozen=False)
+        table = share_conv_forms()
+        results[rank] = (table, ops.form_table(), ops.FORM_TABLE_FROZEN)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_take_rank_zeros_convolution_forms(tmp_path):
+    """`share_conv_forms`: the forms differ in fp32 rounding, so every rank runs rank 0's measured choices (frozen: nothing is
+    timed afterwards); and the table survives a round trip through its JSON file (FIERY_CONV_FORM_TABLE)."""
+    from fiery_amd import ops
+    world, port = 3, _free_port()
+    with mp.Manager() as manager:
+        results = manager.dict()
+        mp.spawn(_forms_worker, args=(world, port, results), nprocs=world, join=True)
+        results = dict(results)
+    sig = (1, 3, 3, 1, 128, 128, (16, 0), 1, 0, 0, 0, 0, 0, 0)
+    want = {(sig, (3, 200, 200)): 'wino', (sig, (0, 50, 50)): 64}
+    for rank in range(world):
+        table, installed, frozen = results[rank]
+        assert table == want and installed == want and frozen
+    before, before_frozen = ops.form_table(), ops.FORM_TABLE_FROZEN
+    try:
+        ops.load_form_table(want, frozen=False)
+        path = str(tmp_path / 'forms.json')
+        ops.save_form_table(path)
+        assert ops.read_form_table(path) == want
+    finally:
+        ops.load_form_table(before, frozen=before_frozen)

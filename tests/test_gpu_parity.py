@@ -530,6 +530,50 @@ def test_conv_forms_stream_k_and_winograd_real_shapes(hip, form, case):
             assert err <= bound * max(1.0, wnt.abs().max().item()), (case, form, rep, i, err)
 
 
+@pytest.mark.parametrize('form', [0, 'wino'])
+@pytest.mark.parametrize('n,H,W', [(15, 200, 200), (2, 51, 37)])
+def test_conv_heads_epilogue_real_shapes(hip, form, n, H, W):
+    """The decoder-heads epilogue (FIERY_EPI_HEADS; reference fiery/models/decoder.py:36-51,82-91: four heads of
+    conv3x3(64 -> 64) + BN + ReLU + conv1x1(64 -> n_out) [+ sigmoid for the centre head]) as ONE launch - a 64 -> 256 3 x 3
+    convolution whose activated 256 hidden channels never leave the chip, the final 1 x 1 rows reduced across lanes in the
+    epilogue and stored as NCHW planes - in the direct form and in the Winograd form (KIND 4 of csrc/conv_winograd.hip, the
+    most intricate of its epilogues and until round 6 covered end to end only), at the step's shape (15 frames) and at an odd
+    size, twice into the same planes, against torch fp32 on the host.  Bound: 2e-5 direct, 4e-5 Winograd (x scale)."""
+    import torch.nn.functional as F
+    from fiery_amd.ops import HeadsOut
+    g = torch.Generator().manual_seed(H * 3 + W)
+    n_outs, sig = [2, 1, 2, 2], [False, True, False, False]                  # segmentation, centre (sigmoid), offset, flow
+    cin, hid = 64, 64
+    x = torch.randn(n, cin, H, W, generator=g)
+    w1 = torch.randn(4 * hid, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    sc, sh = torch.rand(4 * hid, generator=g) + 0.5, torch.randn(4 * hid, generator=g) * 0.5
+    w2 = [torch.randn(o, hid, generator=g) / hid ** 0.5 for o in n_outs]
+    b2 = [torch.randn(o, generator=g) for o in n_outs]
+    op = ConvOp(hip, w1, identity_chan_map(cin), (cin // 8, 0), sc, sh, DEV, act=native.ACT_RELU, tune=True)
+    groups = [i for i, o in enumerate(n_outs) for _ in range(o)]
+    op.attach_heads(torch.cat(w2), torch.cat(b2), groups, [sig[i] for i in groups])
+    if form == 'wino':
+        assert op.packed_winograd is not None
+    op.force_form = form
+    hidden = F.relu(F.conv2d(x, w1, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    wants = []
+    for i in range(4):
+        y = F.conv2d(hidden[:, i * hid:(i + 1) * hid], w2[i].view(-1, hid, 1, 1)) + b2[i].view(1, -1, 1, 1)
+        wants.append(torch.sigmoid(y) if sig[i] else y)
+    xb = Buf(x.permute(0, 2, 3, 1).contiguous().to(DEV), n, H, W, cin)
+    results = [torch.full((n, o, H, W), float('nan'), device=DEV) for o in n_outs]
+    planes = [(res.data_ptr() + 4 * j * H * W, o * H * W) for res, o in zip(results, n_outs) for j in range(o)]
+    for rep in range(2):
+        op([xb], HeadsOut(n, H, W, results[0]), head_planes=planes)
+        bound = 2e-5 if form == 0 else 4e-5
+        for i, (res, want) in enumerate(zip(results, wants)):
+            err = (res.cpu() - want).abs().max().item()
+            if rep == 0:
+                parity_report.record(f'conv heads epilogue, form {form}, {n}x{H}x{W}', f'head {i} vs torch fp32 (host)', err,
+                                     want.abs().max().item(), err, 0.0, bound * max(1.0, want.abs().max().item()))
+            assert err <= bound * max(1.0, want.abs().max().item()), (form, rep, i, err)
+
+
 @pytest.mark.parametrize('cin,cout,k,stride', [(64, 64, 3, 1), (128, 128, 3, 1), (64, 256, 3, 1), (64, 64, 7, 2), (32, 32, 3, 1)])
 def test_conv_igemm_bf16_form_real_shapes(hip, cin, cout, k, stride):
     """v_mfma_f32_32x32x16_bf16 on the real shapes: against the fp32 convolution of the bf16-rounded operands (what the

@@ -111,7 +111,7 @@ def _fp64_gradients(module, batch, seed):
     return {n: p.grad for n, p in twin.named_parameters()}, labels
 
 
-def test_training_module_shared_step_on_both_classes(callers, sim):
+def test_training_module_shared_step_on_both_classes(callers, sim, monkeypatch):
     """`TrainingModule.shared_step(batch, is_train=True)` (trainer.py:66-131): label warping, forward with the future labels,
     every loss of `fiery/losses.py` incl. the uncertainty weights read from Parameters the trainer attached to the model
     (trainer.py:42-64), then `sum(loss.values()).backward()` as training_step does (:200-208).  Loss terms and every
@@ -177,6 +177,28 @@ def test_training_module_shared_step_on_both_classes(callers, sim):
                          'relative L2 against the fp64 evaluation of the reference class; yardstick = the reference class in fp32')
     assert rows[0][0] <= 1.0, rows[:5]
     assert max(r[1] for r in rows) < 2e-2, max(rows, key=lambda r: r[1])          # and nothing is off by more than rounding can explain
+    # The DIRECT-FORM training graph (`train_graph.TRAIN_WINOGRAD = False`, FIERY_TRAIN_WINOGRAD=0) stays gated at the bar this
+    # test held before the Winograd form entered the graph: every gradient tensor within 1 % of the reference class's fp32
+    # gradient, measured against the tensor's own norm (same floor for the analytically-zero biases).  What the Winograd form
+    # costs beyond that is the explicit allowance above - never more than 3x the reference's own rounding - and is recorded
+    # in the ledger next to the direct form's figure.
+    from fiery_amd import train_graph
+    monkeypatch.setattr(train_graph, 'TRAIN_WINOGRAD', False)
+    ours.zero_grad(set_to_none=True)
+    torch.manual_seed(11)
+    _, _, loss_d = ours.shared_step({k: v.clone() for k, v in batch.items()}, True)
+    sum(loss_d.values()).backward()
+    worst = []
+    for name, gt in grads_t.items():
+        if gt is None:
+            continue
+        gd = dict(ours.named_parameters())[name].grad
+        worst.append(((gd - gt).norm().item() / max(gt.norm().item(), 1e-5 * top), name))
+    worst.sort(reverse=True)
+    parity_report.record('reference callers: TrainingModule.shared_step + backward', f'gradients, direct-form graph, worst of {len(worst)} tensors ({worst[0][1]})',
+                         worst[0][0], 1.0, None, None, 1e-2, 'relative L2 against the reference class in fp32 (the bar of rounds 1-4)')
+    assert worst[0][0] < 1e-2, worst[:5]
+    monkeypatch.undo()
     # configure_optimizers (trainer.py:252-258) sees the attached weights through model.parameters(); a step rebuilds the plan
     opt = ours.configure_optimizers()
     n_params = sum(len(g['params']) for g in opt.param_groups)
