@@ -105,6 +105,7 @@ def parse():
                     help='matrix-core precision of the convolutions: f32 = the reference\'s arithmetic (configs[1], the parity '
                          'configuration); bf16 = operands rounded at the matrix cores, fp32 accumulate (configs[3] / [4])')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--single-parity-draw', action='store_true', help='parity against the oracle on this run\'s inputs only (default: three input draws, the worst counts)')
     ap.add_argument('--no-secondary-configs', action='store_true',
                     help='skip the secondary lines of BASELINE.json configs[3] / [4] (pon_setting.yml bf16; lyft/baseline.yml with 7 cameras, bf16, one GPU)')
     ap.add_argument('--no-from-images', action='store_true', help='skip the secondary forward-from-images timing')
@@ -383,9 +384,23 @@ def main():
         peak = PEAK_BF16_MFMA_TFLOPS if dom == 'bf16' else PEAK_F32_MFMA_TFLOPS
         t_dom, f_dom, n_dom = by_prec[dom]
         achieved = f_dom / t_dom / 1e12
-        roofline = {'kernel': f'k_conv_igemm ({"bf16 operands, fp32 accumulate" if dom == "bf16" else "fp32"} MFMA implicit GEMM)',
-                    'bound': 'mfma', 'achieved': round(achieved, 2),
-                    'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
+        # ... and inside that precision the FORM that holds most of the time is the kernel the line names (round 5: the Winograd
+        # kernel took over from the direct implicit GEMM): its own launches, executed flops and time
+        KERNEL_OF = {'f32': 'k_conv_igemm (fp32 MFMA implicit GEMM, direct tile forms)', 'f32 stream-K': 'k_conv_igemm<SK> (fp32 MFMA implicit GEMM, stream-K)',
+                     'f32 winograd': 'k_conv_winograd (Winograd F(2x2,3x3) on the fp32 matrix cores)',
+                     'bf16': 'k_conv_igemm (bf16 operands, fp32 accumulate, MFMA implicit GEMM)'}
+        dom_form = max((k_ for k_ in by_form if (k_ == 'bf16') == (dom == 'bf16')), key=lambda k_: by_form[k_][0])
+        t_df, f_df, x_df, n_df = by_form[dom_form]
+        roofline = {'kernel': KERNEL_OF.get(str(dom_form), str(dom_form)),
+                    'bound': 'mfma', 'achieved': round(x_df / t_df / 1e12, 2),
+                    'peak': peak, 'unit': 'TFLOP/s', 'frac': round(x_df / t_df / 1e12 / peak, 4),
+                    'launches': n_df, 'avg_launch_us': round(t_df / n_df * 1e6, 2),
+                    'share_of_conv_time': round(t_df / t_conv, 4),
+                    'flops': 'EXECUTED matrix flops (a Winograd launch executes 16/36 of the direct form\'s 2*|out|*Cin*9); the direct-form count '
+                             'is in algorithmic_gflop / direct_form_equivalent_tflops, never against the peak',
+                    # every convolution launch of the step together (what `frac` was until round 5)
+                    'all_convolutions': {'achieved': round(achieved, 2), 'frac': round(achieved / peak, 4), 'launches': n_dom,
+                                         'avg_launch_us': round(t_dom / n_dom * 1e6, 2)},
                     'by_precision': {k_: {'launches': n_, 'ms_per_step': round(t_ * 1e3, 3), 'tflops': round(f_ / t_ / 1e12, 2)}
                                      for k_, (t_, f_, n_) in by_prec.items()},
                     # the forms the launches ran in: direct tiles ('f32'), stream-K, Winograd F(2x2, 3x3); executed = matrix flops
@@ -406,8 +421,11 @@ def main():
                     # the step's ideal time is the sum over its launches of max(executed flops / matrix peak, algorithmic bytes /
                     # 8 TB/s) (bytes: the layer's input and output pixels x channels x 4 B + its weights, read / written once)
                     'bound_per_layer': layerwise,
-                    'launches': n_dom, 'avg_launch_us': round(t_dom / n_dom * 1e6, 2),
                     'algorithmic_gflop_per_step': round(f_conv / 1e9, 1), 'kernel_ms_per_step': round(t_conv * 1e3, 3),
+                    # (kernel_ms_per_step can exceed the line's ms_per_step: it is the sum of the launches' brackets with the whole
+                    # batch on ONE stream, each kernel alone on the GPU; the timed step runs one stream per sample, three launches
+                    # sharing the CUs)
+                    'kernel_ms_mode': 'one stream, whole batch per launch, eager (sum of per-launch HIP-event brackets)',
                     'measured': 'HIP events around every launch of the median of five instrumented steps after the timed region, whole '
                                 'batch on one stream (`--no-sample-streams` mode): the kernel alone on the GPU',
                     # the same kernel in the TIMED launch mode (hipGraph, one chain per sample: kernels of different
@@ -460,6 +478,60 @@ def main():
         from_images = {'ms_per_step': round(ms_img, 3), 'samples_per_s': round(B / ms_img * 1e3, 2),
                        'what': f'Fiery.forward from {B * rf * n_cam} images of {cfg.IMAGE.FINAL_DIM[0]}x{cfg.IMAGE.FINAL_DIM[1]}: '
                                f'EfficientNet trunk + lift head + the hot path, {how}, mean of 5'}
+        # where that pass spends its time, by entry point of the library: one eager pass, launched one by one behind a GPU-side
+        # sleep (the host must not stand inside a bracket), HIP events around every launch; convolutions by form with their
+        # executed flops against the fp32 matrix peak, the HBM-bound kernels by time only (their bytes are not counted here)
+        try:
+            from fiery_amd import native as native_
+            streams_keep, model.sample_streams = model.sample_streams, False      # (one stream: a bracket holds its kernel alone)
+            with torch.no_grad():
+                model(image, K_d, E_d, ego_d)
+                torch.cuda.synchronize()
+                try:
+                    torch.cuda._sleep(120_000_000)
+                except Exception:                                    # noqa: BLE001
+                    pass
+                native_.CALL_SINK, ops.PROFILE_SINK = [], []
+                model(image, K_d, E_d, ego_d)
+                torch.cuda.synchronize()
+            calls, convs = native_.CALL_SINK, ops.PROFILE_SINK
+            native_.CALL_SINK, ops.PROFILE_SINK = None, None
+            model.sample_streams = streams_keep
+            table = {}
+            for name, s_, e_ in calls:
+                if name in ('fiery_conv_fwd', 'fiery_voxel_pool_fwd'):
+                    continue                                         # (bracketed with their work below)
+                t_, n_ = table.get(name, (0.0, 0))
+                table[name] = (t_ + s_.elapsed_time(e_), n_ + 1)
+            rows = [{'name': k_, 'launches': n_, 'ms': round(t_, 3)} for k_, (t_, n_) in table.items()]
+            conv_forms = {}
+            for k_, s_, e_, w_, d_ in convs:
+                if k_ == 'conv_igemm':
+                    key = f'fiery_conv_fwd [{d_[-1]}]'
+                    x_ = w_ * (16.0 / 36.0) if 'winograd' in str(d_[-1]) else w_
+                    t_, f_, n_ = conv_forms.get(key, (0.0, 0.0, 0))
+                    conv_forms[key] = (t_ + s_.elapsed_time(e_), f_ + x_, n_ + 1)
+                elif k_ == 'voxel_pool':
+                    nb, _ = ops.pool_algorithmic_bytes(d_)
+                    ms_ = s_.elapsed_time(e_)
+                    rows.append({'name': 'fiery_voxel_pool_fwd', 'launches': 1, 'ms': round(ms_, 3), 'GB/s': round(nb / ms_ / 1e6, 1),
+                                 'frac': round(nb / ms_ / 1e6 / PEAK_HBM_GBS, 4), 'bound': 'hbm'})
+            for key, (t_, f_, n_) in conv_forms.items():
+                pk = PEAK_BF16_MFMA_TFLOPS if 'bf16' in key else PEAK_F32_MFMA_TFLOPS
+                rows.append({'name': key, 'launches': n_, 'ms': round(t_, 3), 'TFLOP/s': round(f_ / t_ / 1e9, 2),
+                             'frac': round(f_ / t_ / 1e9 / pk, 4), 'bound': 'mfma (executed flops)'})
+            rows.sort(key=lambda r: -r['ms'])
+            total_ = sum(r['ms'] for r in rows)
+            for r in rows:
+                r['share'] = round(r['ms'] / total_, 4)
+            from_images['kernels'] = rows
+            from_images['kernels_ms_total'] = round(total_, 3)
+            from_images['kernels_what'] = ('one eager pass with the whole batch on one stream, every launching entry point of libfiery_hip.so '
+                                           'bracketed by HIP events (sum of brackets; the timed figure above is the captured graph with a chain per sample)')
+        except Exception as e_:                                      # noqa: BLE001  (the headline line must not depend on it)
+            from_images['kernels'] = {'error': repr(e_)[:200]}
+            native_.CALL_SINK, ops.PROFILE_SINK = None, None
+            model.sample_streams = streams_keep
         del image
 
     # the frames layout's exchange on its own: HIP events around the collective of a few eager steps, on every rank (each step holds
@@ -508,7 +580,12 @@ def main():
                                        if frames_layout else f'batch-sharded x{world}, no data-path collective'),
                        'launch': launch_mode + (', one stream per sample' if model.sample_streams else ''),
                        'camera_matrices': 'computed on the device every step (no calibration table)'},
-            'roofline': roofline, 'roofline_pooling': pooling, 'host_enqueue_ms_per_step': round(host_ms, 3),
+            'roofline': roofline, 'roofline_pooling': pooling,
+            # (the same two tables as inside `roofline`, at the top level: what ran in which form, and the timed mode's figure)
+            'roofline_by_form': roofline.get('by_form') if roofline else None,
+            'roofline_timed_mode': roofline.get('timed_mode') if roofline else None,
+            'timed_mode': launch_mode + (', one stream per sample' if model.sample_streams else ', one stream'),
+            'host_enqueue_ms_per_step': round(host_ms, 3),
             'forward_from_images': from_images,
             'ranks': {'world_size': world, 'backend': ('nccl (RCCL), world ' + str(torch.distributed.get_world_size())) if use_dist else 'none (one process)',
                       'devices': ranks},
@@ -519,15 +596,38 @@ def main():
             # parity of this run: EVERY sample of the GPU step against the oracle's outputs for the same batch - achieved
             # max-abs error per output over the whole batch, with both bars side by side: the literal 1e-4 of the north star
             # (`within_1e-4`) and the scaled bound the parity tests assert, 1e-4 * max(1, |ref|_inf) (`within_scaled`)
+            # ... over THREE input draws (one draw's segmentation error sits within 10 % of the literal bar either side of it: the
+            # line prints the worst draw, not a lucky one): this run's inputs, the inputs of the GPU parity test of the same
+            # configuration (tests/test_gpu_parity.py::test_hot_path_baseline_batch3_...), and a third seed pair
             with torch.no_grad():
                 got = {k: (None if v is None else v.float().cpu()) for k, v in step().items()}
-            line['parity'] = parity_rows(got, want)
-            line['parity_literal_1e-4'] = {'outputs_passing': sum(1 for r in line['parity'].values() if r['within_1e-4']),
-                                           'outputs': len(line['parity']),
-                                           'outputs_passing_scaled': sum(1 for r in line['parity'].values() if r['within_scaled']),
-                                           'samples_compared': int(next(v for v in want.values() if v is not None).shape[0]),
-                                           'what': f'all {B} samples of this run against the oracle (whole batch on the host cores); '
-                                                   'literal: max-abs <= 1e-4; scaled: max-abs <= 1e-4 * max(1, |ref|_inf)'}
+            draws = [{'inputs': f'this run (make_inputs seed {rank}, make_lifted_features seed {100 + rank})', 'rows': parity_rows(got, want)}]
+            if not args.fused and not frames_layout and not args.single_parity_draw:
+                from oracle import bev_stack
+                sd_cpu = {k: v.cpu() for k, v in sd.items()}
+                for s_in, s_lift in ((0, 1), (7, 8)):
+                    _, K2, E2, ego2 = make_inputs(B, rf + nf, n_cam, with_image=False, seed=s_in)
+                    _, _, l2 = make_lifted_features(B * rf * n_cam, C, D, (fh, fw), seed=s_lift)
+                    l2 = l2.view(B, rf, n_cam, C, D, fh, fw)
+                    with torch.no_grad():
+                        want2 = bev_stack.bev_hot_path(sd_cpu, cfg, l2, K2, E2, ego2)
+                        got2 = {k: (None if v is None else v.float().cpu())
+                                for k, v in model.bev_forward(l2.to(dev), K2.to(dev), E2.to(dev), ego2.to(dev)).items()}
+                    draws.append({'inputs': f'make_inputs seed {s_in}, make_lifted_features seed {s_lift}', 'rows': parity_rows(got2, want2)})
+                    del l2, want2, got2
+            worst = {}
+            for k in draws[0]['rows']:
+                worst[k] = max((d_['rows'][k] for d_ in draws), key=lambda r: r['max_abs_err'])
+            line['parity'] = worst
+            line['parity_draws'] = [{'inputs': d_['inputs'], 'max_abs_err': {k: r['max_abs_err'] for k, r in d_['rows'].items()},
+                                     'outputs_within_1e-4': sum(1 for r in d_['rows'].values() if r['within_1e-4'])} for d_ in draws]
+            line['parity_literal_1e-4'] = {'outputs_passing': sum(1 for r in worst.values() if r['within_1e-4']),
+                                           'outputs': len(worst),
+                                           'outputs_passing_scaled': sum(1 for r in worst.values() if r['within_scaled']),
+                                           'samples_compared': int(next(v for v in want.values() if v is not None).shape[0]) * len(draws),
+                                           'draws': len(draws),
+                                           'what': f'all {B} samples of {len(draws)} input draws against the oracle (whole batches on the host cores), the '
+                                                   'WORST draw per output; literal: max-abs <= 1e-4; scaled: max-abs <= 1e-4 * max(1, |ref|_inf)'}
             # BASELINE.md's own probe of the unmodified reference on CPU (this configuration, other host): context for `cpu_baseline`
             line['cpu_baseline']['baseline_md_reference_probe'] = {'value': 0.369, 'unit': 'samples/s', 'cores': 8, 'batch': 3,
                                                                    'what': 'BASELINE.md: the reference itself, batch 3, 8 cores of the survey container'}

@@ -158,7 +158,11 @@ __device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(
 // rounded division and libm's expf take about eighteen; a gate launch's epilogue applies it to 32 values per lane, and epilogue
 // instructions are the expensive kind.  1e-7 on a gate in [0, 1].
 __device__ __forceinline__ float sigmoid_gate(float v) {
+#if defined(FIERY_SIGMOID_LIBM) && FIERY_SIGMOID_LIBM        // A-B builds: libm's expf and the correctly rounded division (parity experiments)
+    return sigmoidf(v);
+#else
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
+#endif
 }
 // g / d for 0 <= g < 2^31 with (m, s) = conv_magic(d): exact (Granlund-Montgomery, round-up form)
 __device__ __forceinline__ int fast_div(int g, unsigned m, int s) {

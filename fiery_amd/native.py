@@ -244,6 +244,38 @@ def warp_flags_of_this_host(h, w):
     return _WARP_FLAGS[key]
 
 
+# `CALL_SINK = []`: every launching entry point of the library is bracketed by HIP events on the current stream and filed as
+# (entry point, start, end) - bench.py's per-kernel table of the pass from images (None: the calls go straight through)
+CALL_SINK = None
+_HOST_ONLY = ('version', 'last_error', 'workspace_', 'occupied_offset', 'packed_floats', '_plan', '_used')
+
+
+class _EntryPoints:
+    """The loaded library's functions; with `CALL_SINK` set, the launching ones are timed."""
+
+    def __init__(self, dll):
+        self._dll = dll
+
+    def __getattr__(self, name):
+        fn = getattr(self._dll, name)
+        if not name.startswith('fiery_') or any(t in name for t in _HOST_ONLY):
+            self.__dict__[name] = fn
+            return fn
+
+        def call(*args):
+            sink = CALL_SINK
+            if sink is None or not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
+                return fn(*args)
+            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            start.record()
+            rc = fn(*args)
+            end.record()
+            sink.append((name, start, end))
+            return rc
+        self.__dict__[name] = call
+        return call
+
+
 class Lib:
     """One loaded copy of the C-ABI library."""
 
@@ -258,6 +290,7 @@ class Lib:
         for name, (restype, argtypes) in _SIGNATURES.items():
             fn = getattr(self.dll, name)          # AttributeError here = symbol missing from the build
             fn.restype, fn.argtypes = restype, argtypes
+        self.dll = _EntryPoints(self.dll)
         got = self.dll.fiery_abi_version()
         if got != ABI_VERSION:
             raise NativeError(f'{path}: ABI version {got}, bindings expect {ABI_VERSION}; rebuild')
