@@ -434,7 +434,10 @@ __global__ __launch_bounds__(256) void k_rank_columns4(const float* __restrict__
                                                         unsigned char* __restrict__ occ, int n_cam, long long occ_stride,
                                                         unsigned* __restrict__ live, float* __restrict__ clear,
                                                         long long clear_floats, int rank_sparse) {
-    if (clear) {
+#ifndef PRE_EXP
+#define PRE_EXP 0            // timing experiments (wrong results): 1 no clear, 2 no occupancy stores, 3 no record stores, 5 no geometry loads, 6 loads only
+#endif
+    if (clear && PRE_EXP != 1) {
         const long long n_thr = static_cast<long long>(gridDim.x) * blockDim.x;
         const long long me = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
         if ((reinterpret_cast<uintptr_t>(clear) & 15) == 0) {
@@ -467,9 +470,22 @@ __global__ __launch_bounds__(256) void k_rank_columns4(const float* __restrict__
         for (int j = 0; j < kRpp; ++j) {
             const int h = h0 + j < H ? h0 + j : H - 1;                   // clamp: rows past the end re-read the last one
             const float* g = geometry + 3 * (base + static_cast<long long>(h) * W);
+            if (PRE_EXP == 5) {
+                gx[j] = static_cast<float>(w) - 30.f + 0.01f * h;
+                gy[j] = static_cast<float>(fd % 48) * 0.7f - 10.f;
+                gz[j] = 0.5f;
+                continue;
+            }
             gx[j] = g[0];
             gy[j] = g[1];
             gz[j] = g[2];
+        }
+        if (PRE_EXP == 6) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < kRpp; ++j) acc += gx[j] + gy[j] + gz[j];
+            if (acc == 1.2345e-30f) rank[0] = 1;
+            return;
         }
 #pragma unroll
         for (int j = 0; j < kRpp; ++j) {
@@ -492,7 +508,7 @@ __global__ __launch_bounds__(256) void k_rank_columns4(const float* __restrict__
         if (h < H) {
             if (h == 0 || r[j] != prev) {
                 starts |= 1u << h;
-                if (occ_f && has_col && r[j] >= 0) occ_f[r[j]] = 1;
+                if (PRE_EXP != 2 && occ_f && has_col && r[j] >= 0) occ_f[r[j]] = 1;
             }
             if (r[j] >= 0) {
                 tiles |= 1 << (r[j] / tile_vox);
@@ -538,7 +554,7 @@ __global__ __launch_bounds__(256) void k_rank_columns4(const float* __restrict__
                 if (h0 + j < H) rank[base + static_cast<long long>(h0 + j) * W] = r[j];
         }
     }
-    if (has_col && part == 0) {
+    if (PRE_EXP != 3 && has_col && part == 0) {
         const int general = (runs > 3 || H >= (1 << kSplitBits)) ? 1 : 0;
         if (compact >= 2) {
             const int quad_w = W >> 2;
@@ -576,6 +592,119 @@ __global__ __launch_bounds__(256) void k_rank_columns4(const float* __restrict__
         if (threadIdx.x < 24 && live_lds[threadIdx.x] != 0u && fd_first + threadIdx.x < static_cast<long long>(n_fc) * D)
             atomicOr(&live[fd_first + threadIdx.x], live_lds[threadIdx.x]);
     }
+}
+
+// The four-lane prepass as the compact-plane form of the shipped configurations meets it, with everything the general
+// kernel decides at run time decided at compile time: H == 4 kRpp rows exactly, whole workgroups of columns, 32-bit offsets
+// into the geometry (buffer loads: no 64-bit address arithmetic), narrow quad records, power-of-two cells along x and y and
+// a single cell along z (GridParams modes 1, 1, 2).  The general kernel executes ~1,000 SCALAR instructions per wavefront
+// (mode switches, row and column guards, address carries) - 38 wavefronts per CU share one scalar unit: 16 of its 20 us
+// were that, with the geometry loads and every store removed it still took 17.9 us (profiles/r6_prepass_experiments.txt).
+// Writes what k_rank_columns4 writes, bit for bit.
+template <int kRpp>
+__global__ __launch_bounds__(256) void k_rank_columns4_lean(const float* __restrict__ geometry, int geo_bytes, int D, int W, GridParams p,
+                                                             int* __restrict__ rank, unsigned short* __restrict__ recs,
+                                                             unsigned char* __restrict__ occ, int slices_per_frame, int occ_stride,
+                                                             unsigned* __restrict__ live, float* __restrict__ clear,
+                                                             long long clear_floats, int rank_sparse) {
+    constexpr int H = 4 * kRpp;
+    if (clear) {                                                         // (16-byte aligned: the launcher checked)
+        const long long n_thr = static_cast<long long>(gridDim.x) * blockDim.x;
+        const long long me = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (long long i = me * 4; i + 3 < clear_floats; i += n_thr * 4) *reinterpret_cast<float4*>(clear + i) = z;
+    }
+    __shared__ unsigned live_lds[24];
+    const int tid = threadIdx.x;
+    const int col_first = static_cast<int>(blockIdx.x) * 64;
+    if (tid < 24) live_lds[tid] = 0u;
+    const int lane = tid & 63, part = lane >> 4;
+    const int col = col_first + (tid >> 6) * 16 + (lane & 15);
+    const int w = col % W, fd = col / W;                                 // fd = (frame * camera) * D + d
+    const int base = fd * (H * W) + w;                                   // point index of (.., h = 0, w)
+    const int h0 = part * kRpp;
+    const __amdgpu_buffer_rsrc_t geo = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(geometry), 0, geo_bytes, 0x00020000);
+    const int voff = (base + h0 * W) * 12;
+    const int row_bytes = W * 12;
+    float gx[kRpp], gy[kRpp], gz[kRpp];
+#pragma unroll
+    for (int j = 0; j < kRpp; ++j) {
+        gx[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(geo, voff, j * row_bytes, 0));
+        gy[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(geo, voff + 4, j * row_bytes, 0));
+        gz[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(geo, voff + 8, j * row_bytes, 0));
+    }
+    __syncthreads();                                                     // (live_lds zeroed; the loads are in flight)
+    int r[kRpp];
+    const float nxf = static_cast<float>(p.nx), nyf = static_cast<float>(p.ny);
+#pragma unroll
+    for (int j = 0; j < kRpp; ++j) {
+        const float sx = (gx[j] - p.ox) * p.ax, sy = (gy[j] - p.oy) * p.ay, dz = gz[j] - p.oz;
+        const bool keep = sx > -1.0f && sx < nxf && sy > -1.0f && sy < nyf && dz > p.az && dz < p.bz;
+        r[j] = keep ? static_cast<int>(sx) * p.ny + static_cast<int>(sy) : -1;
+    }
+    int* rank_col = rank + base + h0 * W;
+    if (!rank_sparse) {
+#pragma unroll
+        for (int j = 0; j < kRpp; ++j) rank_col[j * W] = r[j];
+    }
+    const int last = r[kRpp - 1];
+    const int up16 = __shfl_xor(last, 16), up48 = __shfl_xor(last, 48);
+    int prev = (part & 1) ? up16 : up48;
+    unsigned char* occ_f = occ + (fd / slices_per_frame) * occ_stride;
+    unsigned starts = 0;                                                 // bit h: row h starts a run
+    int inside = 0;
+#pragma unroll
+    for (int j = 0; j < kRpp; ++j) {
+        const bool start = (part == 0 && j == 0) || r[j] != prev;
+        starts |= start ? 1u << (h0 + j) : 0u;
+        if (start && r[j] >= 0) occ_f[r[j]] = 1;
+        inside |= r[j] >= 0 ? 1 : 0;
+        prev = r[j];
+    }
+    starts |= static_cast<unsigned>(__shfl_xor(static_cast<int>(starts), 16));
+    starts |= static_cast<unsigned>(__shfl_xor(static_cast<int>(starts), 32));
+    inside |= __shfl_xor(inside, 16);
+    inside |= __shfl_xor(inside, 32);
+    const int runs = __popc(starts);
+    const unsigned after_first = starts & (starts - 1u);                // (bit 0 is always set: row 0 starts the first run)
+    const int s1 = after_first ? __ffs(static_cast<int>(after_first)) - 1 : H;
+    const unsigned after_second = after_first & (after_first - 1u);
+    const int s2 = after_second ? __ffs(static_cast<int>(after_second)) - 1 : H;
+    int offer_a = 0, offer_b = 0, offer_c = 0;                           // the ranks at rows 0, s1, s2 (+ 1; the other lanes offer 0)
+#pragma unroll
+    for (int j = 0; j < kRpp; ++j) {
+        const int h = h0 + j;
+        offer_a = h == 0 ? r[j] + 1 : offer_a;
+        offer_b = h == s1 ? r[j] + 1 : offer_b;
+        offer_c = h == s2 ? r[j] + 1 : offer_c;
+    }
+    offer_a |= __shfl_xor(offer_a, 16);  offer_a |= __shfl_xor(offer_a, 32);
+    offer_b |= __shfl_xor(offer_b, 16);  offer_b |= __shfl_xor(offer_b, 32);
+    offer_c |= __shfl_xor(offer_c, 16);  offer_c |= __shfl_xor(offer_c, 32);
+    const int ra = offer_a - 1, rb = s1 < H ? offer_b - 1 : -1, rc = s2 < H ? offer_c - 1 : -1;
+    const int general = runs > 3 ? 1 : 0;
+    if (rank_sparse) {                                                   // (see k_rank_columns4: the many-run quads' ranks only)
+        int many = general;
+        many |= __shfl_xor(many, 1);
+        many |= __shfl_xor(many, 2);
+        if (many) {
+#pragma unroll
+            for (int j = 0; j < kRpp; ++j) rank_col[j * W] = r[j];
+        }
+    }
+    if (part == 0) {
+        const int quad = fd * (W >> 2) + (w >> 2), k = w & 3;
+        unsigned short* rec = recs + quad * 16 + k;
+        auto r16 = [](int v) { return static_cast<unsigned short>(v < 0 ? kNoRank16 : static_cast<unsigned>(v)); };
+        rec[0] = static_cast<unsigned short>(static_cast<unsigned>(s1) | (static_cast<unsigned>(s2) << 6) | (static_cast<unsigned>(general) << 12));
+        rec[4] = r16(ra);
+        rec[8] = r16(rb);
+        rec[12] = r16(rc);
+        const int fd_first = col_first / W;                              // slice of the workgroup's first column
+        if (inside) atomicOr(&live_lds[fd - fd_first], 1u << (w >> 2));
+    }
+    __syncthreads();
+    if (tid < 24 && live_lds[tid] != 0u) atomicOr(&live[col_first / W + tid], live_lds[tid]);
 }
 
 // Ordered (ascending id) list of the work-items that touch one tile of one frame; adjacent entries are adjacent
@@ -1761,7 +1890,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
                 if (nib & 2u) v.y = plane[cell++];
                 if (nib & 4u) v.z = plane[cell++];
                 if (nib & 8u) v.w = plane[cell];
-                *reinterpret_cast<float4*>(o + v0) = v;
+                *reinterpret_cast<float4*>(o + v0) = v;            // (plain: non-temporal stores measured 1.7 us slower per op, round 6)
             }
         } else
         for (int v0 = tid; v0 < n_vox; v0 += kThreads) {
@@ -2069,7 +2198,18 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
         // are one 32-bit word)
         const bool four = four_lanes;
         const dim3 pgrid4(ceil_div(n_cols_all, 64));
-        if (four && H <= 28)
+        const GridParams gp = to_params(*grid);
+        // the lean form of the four-lane prepass (see the kernel): the compact form's narrow records, H = 28 exactly, whole
+        // workgroups of columns, a geometry tensor of less than 2 GiB, division-free quantisation along all three axes
+        const long long geo_bytes = static_cast<long long>(frames) * n_cam * D * H * W * 12;
+        bool lean = four && desc_mode == 2 && H == 28 && n_cols_all % 64 == 0 && geo_bytes < (1ll << 31) && gp.mx == 1 && gp.my == 1 &&
+                    gp.mz == 2 && gp.nz == 1 && occ_stride * frames < (1ll << 31) && (!clear_ptr || aligned16(clear_ptr)) && clear_floats % 4 == 0 && W % 4 == 0 && W >= 4;
+        if (const char* forced = getenv("FIERY_POOL_PREPASS_LEAN")) lean = lean && atoi(forced) != 0;           // tuning / A-B runs
+        if (lean)
+            hipLaunchKernelGGL((k_rank_columns4_lean<7>), pgrid4, dim3(256), 0, s, geometry, static_cast<int>(geo_bytes), D, W, gp, rank,
+                               reinterpret_cast<unsigned short*>(coldesc), occ, n_cam * D, static_cast<int>(occ_stride), live, clear_ptr,
+                               clear_floats, no_ranks ? 1 : 0);
+        else if (four && H <= 28)
             hipLaunchKernelGGL((k_rank_columns4<7>), pgrid4, dim3(256), 0, s, geometry, frames * n_cam, D, H, W, to_params(*grid),
                                pl.tile, rank, coldesc, mask_arg, desc_mode, occ_arg, n_cam, occ_stride, compact_form ? live : nullptr, clear_ptr, clear_floats, no_ranks ? 1 : 0);
         else if (four)

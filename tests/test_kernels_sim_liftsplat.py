@@ -679,3 +679,37 @@ def test_no_ranks_flag_leaves_the_result_unchanged(sim, H):
     written = ws2[:n_pts] != 123456
     assert 0 < int(written.sum()) < n_pts // 4                    # some quads are many-run quads, most are not
     assert torch.equal(ws2[:n_pts][written], ranks[written])
+
+
+@pytest.mark.parametrize('flags', [0, 4])
+def test_lean_prepass_writes_what_the_general_prepass_writes(sim, monkeypatch, flags):
+    """`k_rank_columns4_lean` (H = 28, whole workgroups of columns, power-of-two cells, one z cell: the shipped configurations)
+    against `k_rank_columns4` on the same rig - a rolled camera for many-run quads, a pitched one for two- and three-run
+    columns, points outside the grid: the whole workspace (voxel ranks - all of them, or the many-run quads' under
+    FIERY_POOL_NO_RANKS = 4 -, quad records, what the launch leaves of occupancy / live masks / counters, occupied counts)
+    and the planes, byte for byte."""
+    frustum, intr, extr, lifted = _small_problem(91, n_cam=3, D=16, H=28, W=40, C=2, frames=2)
+    roll = torch.tensor([[0.0, -1.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0], [0.0, 0.0, 1.0, 0.0], [0.0, 0.0, 0.0, 1.0]])
+    a = 0.06
+    pitch = torch.tensor([[1.0, 0.0, 0.0, 0.0], [0.0, float(np.cos(a)), -float(np.sin(a)), 0.0],
+                          [0.0, float(np.sin(a)), float(np.cos(a)), 0.0], [0.0, 0.0, 0.0, 1.0]])
+    extr = extr.clone()
+    extr[:, 0] = extr[:, 0] @ roll
+    extr[:, 1] = extr[:, 1] @ pitch
+    frames, n_cam, C, D, H, W = lifted.shape
+    geo = torch.from_numpy(ls.get_geometry(frustum, intr.numpy(), extr.numpy()))
+    grid, _ = _grid([-14.0, 30.0, 0.5], [-24.0, 10.0, 0.5], [-10.0, 10.0, 20.0])
+    st = lifted.stride()
+    strides = (st[0], st[1], st[3], st[4], st[5], st[2])
+    got = {}
+    for lean in ('0', '1'):
+        monkeypatch.setenv('FIERY_POOL_PREPASS_LEAN', lean)
+        ws = sim.pool_workspace(frames, n_cam, D, H, W, lifted.device, grid)
+        ws.fill_(-13)
+        out = sim.voxel_pool(lifted, strides, geo, frames, n_cam, D, H, W, C, grid, workspace=ws, flags=flags)
+        got[lean] = (ws.clone(), out.clone())
+    assert torch.equal(got['0'][0], got['1'][0])
+    assert torch.equal(got['0'][1], got['1'][1])
+    n_pts = frames * n_cam * D * H * W
+    written = got['1'][0][:n_pts] != -13
+    assert (written.all() if flags == 0 else 0 < int(written.sum()) < n_pts // 4)
