@@ -1,4 +1,4 @@
-"""The layout algebra of DESIGN.md section 11 item 1 (the Bottleneck tails without a transpose), checked lane by lane on the
+"""The layout algebra of DESIGN.md section 11 item 1 / docs/DESIGN_HISTORY.md section 11 (the Bottleneck tails without a transpose), checked lane by lane on the
 CPU simulator: with the first product's MFMA operands swapped, its accumulator block is the second product's A operand,
 provided W2's rows are packed in the accumulator's register order.  `tools/probe/chained_gemm_swapped.hip` is a probe, not
 product code - the product kernel still stages h through LDS; this test pins the claim the next kernel will be built on."""
