@@ -31,6 +31,19 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X dense bf16 matrix peak (no sparsity)
 PEAK_HBM_GBS = 8000.0             # MI355X HBM3E spec bandwidth
 
 
+def pmc_workload(config, precision, n_cam, batch):
+    """Which committed pair of PMC passes belongs to this run's workload (None: none was taken for it)."""
+    if batch != 3:
+        return None
+    if config == 'baseline.yml' and n_cam == 6:
+        return 'f32' if precision == 'f32' else 'bf16'
+    if config == 'literature/pon_setting.yml' and n_cam == 6 and precision == 'bf16':
+        return 'pon_bf16'
+    if config == 'lyft/baseline.yml' and n_cam == 7 and precision == 'bf16':
+        return 'lyft7_bf16'
+    return None
+
+
 def pmc_traffic(kernels, mode='f32'):
     """HBM bytes per launch of `kernels` (summed) from the COMMITTED PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over
     this bench command - baseline.yml, fp32, batch 3 - folded by tools/pmc_traffic.py with the gfx950 correction), with the
@@ -38,9 +51,13 @@ def pmc_traffic(kernels, mode='f32'):
     THAT workload only: any other configuration's line carries null.  Counters cannot be collected from inside the timed
     process, so this is the one roofline field not measured live - hence its name in the line, `traffic_from_profiles`."""
     import subprocess
-    names = ('r5_pmc_traffic.json', 'r4_pmc_traffic.json', 'r3_pmc_traffic.json', 'r2_pmc_traffic.json', 'r1_pmc_traffic.json')
+    if mode is None:
+        return None
+    names = ('r6_pmc_traffic.json', 'r5_pmc_traffic.json', 'r4_pmc_traffic.json', 'r3_pmc_traffic.json', 'r2_pmc_traffic.json', 'r1_pmc_traffic.json')
     if mode == 'bf16':                                   # (round 5: the same two passes over `bench.py --precision bf16`)
-        names = ('r5_pmc_traffic_bf16.json',)
+        names = ('r6_pmc_traffic_bf16.json', 'r5_pmc_traffic_bf16.json')
+    elif mode != 'f32':                                  # (round 6: pon and lyft-7 in bf16 mode - BASELINE.json configs[3] / [4])
+        names = (f'r6_pmc_traffic_{mode}.json',)
     for name in names:
         path = os.path.join(ROOT, 'profiles', name)
         try:
@@ -415,8 +432,8 @@ def main():
                                                     'a separate figure - `achieved` / `frac` are on EXECUTED flops'},
                     'direct_form_equivalent_tflops': round(f_conv / t_conv / 1e12, 2),
                     'traffic': None,             # (no counters in a timed run; the committed passes' figure follows)
-                    'traffic_from_profiles': (pmc_traffic(['k_conv_igemm (all tile shapes)'], args.precision)
-                                              if args.config == 'baseline.yml' and n_cam == 6 and B == 3 else None),
+                    'traffic_from_profiles': pmc_traffic(['convolutions (all forms)'], pmc_workload(args.config, args.precision, n_cam, B))
+                                             or pmc_traffic(['k_conv_igemm (all tile shapes)'], pmc_workload(args.config, args.precision, n_cam, B)),
                     # per-layer roofline: a layer is bound by the matrix pipe OR by HBM - min over the two of what each allows;
                     # the step's ideal time is the sum over its launches of max(executed flops / matrix peak, algorithmic bytes /
                     # 8 TB/s) (bytes: the layer's input and output pixels x channels x 4 B + its weights, read / written once)
@@ -441,8 +458,7 @@ def main():
             pooling = {'kernel': 'k_rank_columns + k_voxel_pool_compact (op boundary projection_to_birds_eye_view)', 'bound': 'hbm',
                        'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
                        'traffic': None,          # (no counters in a timed run; the committed passes' figure - prepass included - follows)
-                       'traffic_from_profiles': (pmc_traffic(['k_voxel_pool', 'fiery::k_rank_columns'], args.precision)
-                                                 if args.config == 'baseline.yml' and n_cam == 6 and B == 3 else None),
+                       'traffic_from_profiles': pmc_traffic(['k_voxel_pool', 'fiery::k_rank_columns'], pmc_workload(args.config, args.precision, n_cam, B)),
                        'algorithmic_mb_per_step': round(b_pool / 1e6, 1),
                        'op_us_per_step': round(t_pool * 1e6, 1), 'op_us_samples': [round(v, 1) for v in pool_samples],
                        'kept_fraction': round(kept_frac, 4),

@@ -693,6 +693,8 @@ __global__ __launch_bounds__(256) void k_rank_columns4_lean(const float* __restr
         }
     }
     if (part == 0) {
+        // (one 8-byte store per lane after a 4 x 4 lane transpose of the quad's sixteen 16-bit fields measured the same as these
+        // four 2-byte stores - 14.8 against 14.6 us - and was not kept)
         const int quad = fd * (W >> 2) + (w >> 2), k = w & 3;
         unsigned short* rec = recs + quad * 16 + k;
         auto r16 = [](int v) { return static_cast<unsigned short>(v < 0 ? kNoRank16 : static_cast<unsigned>(v)); };

@@ -194,7 +194,8 @@ class _TemporalBlock:
         self.cf = self.cin - ego_channels                     # channels that really vary in space
         # each path's channels start on an 8-aligned column of the combined tensors; in the bf16 mode on a 32-aligned one, so that
         # the causal convolutions read whole 32-channel stages (35 -> 64 channels of which 29 are zeros: 1.8x the products, but
-        # on the bf16 kernels instead of the fp32 fallback - those two layers were 7.5 % of the bf16 step)
+        # on the bf16 kernels instead of the fp32 fallback - those two layers were 7.5 % of the bf16 step; in fp32 the padded form
+        # measured 1.5 % SLOWER on the step, round 6: the scalar-addressed loop's gain does not cover 1.8x the products)
         hp = self.hp = round_up(self.half, 32 if eng.precision == native.PRECISION_BF16 else 8)
         cf_pad = round_up(self.cf, 8)
         paths = tb.convolution_paths

@@ -282,9 +282,11 @@ class ConvOp:
         if self.heads is not None and self.packed_winograd is None:
             return                                     # (the heads' direct form has one tile shape)
         key = (out.n_img, out.H, out.W)
-        choice = FORM_TABLE.get((self._sig, key)) if self.force_form is None else self.force_form
+        choice = self.force_form                       # (a forced form - per op, or FIERY_CONV_FORM for all - goes before the table)
         if choice is None and FORCE_FORM:
             choice = FORCE_FORM if FORCE_FORM in ('sk', 'wino') else int(FORCE_FORM)
+        if choice is None:
+            choice = FORM_TABLE.get((self._sig, key))
         if choice == 'wino' and self.packed_winograd is None:
             choice = 0
         sk = _stream_k_workspace(self.lib, d, out.tensor) if (choice == 'sk' or choice is None) and self.heads is None else None

@@ -23,6 +23,7 @@ def main():
     fetch, write = parse(sys.argv[1]), parse(sys.argv[2])
     out = {'_note': 'bytes per launch; traffic = 2 * FETCH_SIZE + WRITE_SIZE (KB -> B); see tools/pmc_traffic.py'}
     groups = {'k_conv_igemm (all tile shapes)': [k for k in fetch if 'k_conv_igemm' in k],
+              'convolutions (all forms)': [k for k in fetch if 'k_conv_igemm' in k or 'k_conv_winograd' in k],
               'k_voxel_pool': [k for k in fetch if 'k_voxel_pool' in k]}
     for k in sorted(fetch):
         groups[k] = [k]
