@@ -29,6 +29,9 @@
 // and a plain streaming sweep does gain from it - but consecutive 240-byte rows share a 64-byte sector, which a
 // non-temporal load does not leave behind for the next row: +13 % HBM fetch, 229 vs 209 us for the bare read pattern
 // (tools/probe/hbm_probe.hip k_read_planes, profiles/r1_s3_pool_sweeps.txt).
+#ifndef FIERY_POOL_ROW_AUX
+#define FIERY_POOL_ROW_AUX 2        // cache policy bits of the row loads (buffer-load aux: 1 sc0, 2 nt, 16 sc1): non-temporal
+#endif
 #ifndef FIERY_POOL_NT_LOADS
 #define FIERY_POOL_NT_LOADS 0
 #endif
@@ -272,7 +275,7 @@ __global__ void k_lift_geometry(const float* __restrict__ frustum, const float* 
     float gx, gy, gz;
     lift_point(cam + c * 12, fr[0], fr[1], fr[2], gx, gy, gz);
     float* g = geometry + 3 * i;
-    g[0] = gx;
+    g[0] = gx;          // (plain stores: past the caches the prepass behind it took 1.1 us longer and the pooling kernel nothing less)
     g[1] = gy;
     g[2] = gz;
 }
@@ -1619,7 +1622,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
     };
     auto request_row = [&](vf4& slot, int j, int slice_off, int lane_off) {
         const int voff = (kExactRows || 4 * j + g < H) ? lane_off : kOob;
-        const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rows, voff, slice_off + j * row4_bytes, kNonTemporal ? 2 : 0);
+        const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rows, voff, slice_off + j * row4_bytes, kNonTemporal ? FIERY_POOL_ROW_AUX : 0);
         __builtin_memcpy(&slot, &raw, 16);
     };
     // the split words of the lane's four columns and the voxels of "its" run
