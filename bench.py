@@ -332,17 +332,59 @@ def main():
                 # backlog: since round 5 the GPU finishes a step faster than the host issues one launch by launch, so an unrecorded
                 # step in front no longer keeps the queue full - the GPU spins for ~25 ms instead while the host enqueues the
                 # instrumented step (the pooling op's bracket spans three dispatches: host gaps between them must not be in it)
+                # (round 6: ... and behind the sleep an UNRECORDED step, then the instrumented one: 25 ms of a spinning workgroup let
+                # the core clock sag, and the brackets of the matrix-bound launches read 12 % longer than the same kernels in
+                # rocprofv3's trace of back-to-back steps - 8.15 against 7.21 ms per step; the sleep is long enough for the host to
+                # enqueue both steps, so no bracket holds host time, and the instrumented step starts where a served step does:
+                # right behind the previous step's last kernels)
                 try:
-                    torch.cuda._sleep(60_000_000)
+                    torch.cuda._sleep(150_000_000)
+                    eager_step()
                 except Exception:                          # noqa: BLE001
                     eager_step()
                 ops.PROFILE_SINK = []
                 eager_step()
                 torch.cuda.synchronize()
                 instrumented.append(ops.PROFILE_SINK)
+            # What a bracket holds besides its kernel: the dispatch latency between the start event and the kernel and between the
+            # kernel and the end event.  Measured here with a bracket around ONE tiny launch (B1) and around TWO (B2), medians of
+            # 40 behind a sleep: B2 - B1 is a tiny kernel plus the in-stream gap, so 2 B1 - B2 is what the events add.  The kernel
+            # times below are the brackets minus that (the raw sums are reported beside them); rocprofv3's durations of the same
+            # kernels (profiles/r6_kernel_stats_one_stream.csv, exactly 20 steps) are the cross-check.
+            tiny_k, tiny_e = K_d.reshape(-1, 3, 3)[:1].contiguous(), E_d.reshape(-1, 4, 4)[:1].contiguous()
+            lib_ = model.engine().lib
+            b12 = []
+            for n_launch in (1, 2):
+                try:
+                    torch.cuda._sleep(40_000_000)
+                except Exception:                          # noqa: BLE001
+                    pass
+                evs = []
+                for _ in range(40):
+                    s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s_.record()
+                    for _j in range(n_launch):
+                        lib_.camera_matrices(tiny_k, tiny_e)
+                    e_.record()
+                    evs.append((s_, e_))
+                torch.cuda.synchronize()
+                b12.append(sorted(s_.elapsed_time(e_) * 1e3 for s_, e_ in evs)[20])
+            bracket_overhead_us = max(0.0, 2.0 * b12[0] - b12[1])
         torch.cuda.synchronize()
         model.sample_streams = streams_on
         ops.PROFILE_SINK = None
+        ovh_ms = bracket_overhead_us * 1e-3
+
+        class _Net:                                        # an (event, event) pair read as the bracket minus the events' own latency
+            def __init__(self, s_, e_):
+                self.s, self.e = s_, e_
+
+            def elapsed_time(self, _unused=None):
+                t_ = self.s.elapsed_time(self.e)
+                return max(t_ - ovh_ms, 0.5 * t_)
+        raw_conv_ms = [sum(s.elapsed_time(e) for k, s, e, w, _ in rr if k == 'conv_igemm') for rr in instrumented]
+        raw_pool_us = sorted(sum(s.elapsed_time(e) * 1e3 for k, s, e, _, _ in rr if k == 'voxel_pool') for rr in instrumented)
+        instrumented = [[(k, _Net(s, e), None, w, d) for k, s, e, w, d in rr] for rr in instrumented]
         conv_time = lambda rr: sum(s.elapsed_time(e) for k, s, e, w, _ in rr if k == 'conv_igemm')
         recs = sorted(instrumented, key=conv_time)[len(instrumented) // 2]
         pool_samples = sorted(sum(s.elapsed_time(e) * 1e3 for k, s, e, _, _ in rr if k == 'voxel_pool') for rr in instrumented)
@@ -442,7 +484,11 @@ def main():
                     # (kernel_ms_per_step can exceed the line's ms_per_step: it is the sum of the launches' brackets with the whole
                     # batch on ONE stream, each kernel alone on the GPU; the timed step runs one stream per sample, three launches
                     # sharing the CUs)
-                    'kernel_ms_mode': 'one stream, whole batch per launch, eager (sum of per-launch HIP-event brackets)',
+                    'kernel_ms_mode': 'one stream, whole batch per launch, eager: sum of per-launch HIP-event brackets, each minus the events\' own '
+                                      'latency (bracket_overhead_us, measured live: 2 x the bracket of one tiny launch - the bracket of two)',
+                    'kernel_ms_per_step_raw_brackets': round(sorted(raw_conv_ms)[len(raw_conv_ms) // 2], 3),
+                    'bracket_overhead_us': round(bracket_overhead_us, 2),
+                    'bracket_calibration_us': {'one_tiny_launch': round(b12[0], 2), 'two_tiny_launches': round(b12[1], 2)},
                     'measured': 'HIP events around every launch of the median of five instrumented steps after the timed region, whole '
                                 'batch on one stream (`--no-sample-streams` mode): the kernel alone on the GPU',
                     # the same kernel in the TIMED launch mode (hipGraph, one chain per sample: kernels of different
@@ -461,6 +507,7 @@ def main():
                        'traffic_from_profiles': pmc_traffic(['k_voxel_pool', 'fiery::k_rank_columns'], pmc_workload(args.config, args.precision, n_cam, B)),
                        'algorithmic_mb_per_step': round(b_pool / 1e6, 1),
                        'op_us_per_step': round(t_pool * 1e6, 1), 'op_us_samples': [round(v, 1) for v in pool_samples],
+                       'op_us_samples_raw_brackets': [round(v, 1) for v in raw_pool_us], 'bracket_overhead_us': round(bracket_overhead_us, 2),
                        'kept_fraction': round(kept_frac, 4),
                        'bytes': '4*C*N_kept + 12*N + 4*C*X*Y per frame (SURVEY 8d), N_kept counted from the ranks the op left'}
             ceil_ = pool_ceiling() if args.config == 'baseline.yml' and n_cam == 6 and B == 3 else None
