@@ -1492,25 +1492,28 @@ __global__ __launch_bounds__(1024) void k_voxel_pool_plane(const float* __restri
 //   split = s1 | s2 << 6 | many_runs << 12   (rows [0, s1) are run A, [s1, s2) run B, [s2, H) run C)
 constexpr int kCompactRows = 7;            // rows per lane: the form takes H <= 4 * 7
 
-// What the last workgroup of a compact-form launch zeroes again (so that the next call on the workspace needs no memset):
-// the occupancy bytes and live masks of the launch's frames, and the launch's own counters - tickets [16 + 16 g, 32 + 16 g)
-// and the top counter [1 + g] of the 64-int counter block, g = the launch's group (a call split into frame groups runs one
-// launch per group, side by side on two streams; group 0 also owns [0], the tuning builds' draw counter).
+// What a compact-form launch zeroes again, so that the next call on the workspace needs no memset (FIERY_POOL_WORKSPACE_CLEAN):
+// the occupancy bytes and live masks of its frames and its counters.  Round 6: FRAME BY FRAME - the item that takes the last
+// ticket of a frame class (frames f, f + 16, ...: sixteen ticket counters, so that a round's 512 tickets do not queue on one
+// address) cleans those frames' 40 KB each, in the shadow of the items still running; only the last frame's is left for the end
+// of the launch.  (Until then ONE workgroup - by construction the last to finish - stored the whole region, 360 KB at
+// baseline.yml batch 3: 3.8 us at the tail of every launch, profiles/r6_pool_steps.txt.)
 struct PoolClean {
-    uint4* occ;
-    int occ_vec;                            // 16-byte words
-    unsigned* live;
-    int live_words;
-    int group;
+    uint4* occ;                             // occupancy bytes of frame 0
+    int occ_vec;                            // 16-byte words per frame
+    unsigned* live;                         // live masks of frame 0
+    int live_words;                         // words per frame
+    int frames;
 };
+// (the tuning builds' drawn parts: one workgroup cleans everything)
 template <int kThreads>
-__device__ __forceinline__ void pool_clean(const PoolClean& cl, int* counters, int tid) {
+__device__ __forceinline__ void pool_clean_all(const PoolClean& cl, int* counters, int tid) {
     const uint4 z = {0u, 0u, 0u, 0u};
-    for (int i = tid; i < cl.occ_vec; i += kThreads) cl.occ[i] = z;
-    for (int i = tid; i < cl.live_words; i += kThreads) cl.live[i] = 0u;
-    if (tid < 16) counters[16 + 16 * cl.group + tid] = 0;
-    if (tid == 16) counters[1 + cl.group] = 0;
-    if (tid == 17 && cl.group == 0) counters[0] = 0;
+    for (long long i = tid; i < static_cast<long long>(cl.occ_vec) * cl.frames; i += kThreads) cl.occ[i] = z;
+    for (long long i = tid; i < static_cast<long long>(cl.live_words) * cl.frames; i += kThreads) cl.live[i] = 0u;
+    if (tid < 16) counters[16 + tid] = 0;
+    if (tid == 16) counters[1] = 0;
+    if (tid == 17) counters[0] = 0;
 }
 constexpr int kCompactGroupLanes = 16;     // lanes per row group: the form takes W / 4 <= 16
 
@@ -1879,9 +1882,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
         // this item has read the last thing it needs from the region the call clears (its live masks): it takes its ticket now,
         // so that the atomic's round trip passes under the write-out instead of holding the slot afterwards
         // (not when parts are drawn: the draw counter lives in the same region and is read until the last workgroup leaves)
-        // (sixteen counters, dealt by item: the workgroups of a round finish within microseconds of each other and an atomic on
+        // (sixteen counters, dealt by frame: the workgroups of a round finish within microseconds of each other and an atomic on
         // ONE address is served every ~0.1 us - 512 of them held every slot for its share of 50 us)
-        if (counters && !(kTuning && draw) && pass == n_pass - 1 && tid == 0) ticket = atomicAdd(counters + 16 + 16 * cl.group + (item & 15), 1);
+        if (counters && !(kTuning && draw) && pass == n_pass - 1 && tid == 0) ticket = atomicAdd(counters + 16 + (f & 15), 1);
         // ---- expand the window of cells into the dense plane --------------------------------------------------
         if (parts == 1 && n_pass == 1 && (n_vox & 3) == 0 && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
             // one pass, whole units: every voxel gets its cell's sum or a zero - four voxels (one nibble of a bit word) per
@@ -1914,30 +1917,45 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
         __syncthreads();                                                  // the plane is cleared again by the next pass
     }
     if (kTuning && trace && tid == 0) trace[4 * item + 3] = wall_clock64();
-    // The item that takes the last ticket leaves the workspace's cleared region (occupancy bytes, live masks, counters) as this
-    // launch found it - all zero - so the next call on this workspace can skip its memset dispatch
-    // (FIERY_POOL_WORKSPACE_CLEAN).  Every other item had read what it needed from the region before it took its ticket.
+    // The item that takes the last ticket of its frame class leaves those frames' occupancy bytes and live masks as the launch
+    // found them - all zero - and reports to the top counter; the class that completes that one resets it: the next call on this
+    // workspace can skip its memset dispatch (FIERY_POOL_WORKSPACE_CLEAN).  Every other item of the frames had read what it
+    // needed from them before it took its ticket.
     if (counters && !(kTuning && draw)) {
-        // the item that completes its counter (items k, k + 16, ...: (n_items - k + 15) / 16 of them) reports to the top counter;
-        // the one that completes that cleans
+        const int cls = f & 15;
         if (tid == 0) {
-            int last = 0;
-            if (ticket == (n_items - (item & 15) + 15) / 16 - 1) {
-                const int filled = min(n_items, 16);                      // counters that receive any item
-                last = atomicAdd(counters + 1 + cl.group, 1) == filled - 1;
+            int expect = 0;                                               // items of the frames cls, cls + 16, ...
+            for (int ff = cls; ff < cl.frames; ff += 16) {
+                const int whole = min(max(tail_first - ff * C, 0), C);   // units of the frame that are not tail units
+                expect += whole + (C - whole) * tail_parts;
             }
-            *drawn = last;
+            *drawn = ticket == expect - 1;
         }
         __syncthreads();
-        if (*drawn) pool_clean<kThreads>(cl, counters, tid);
+        if (*drawn) {
+            const uint4 z = {0u, 0u, 0u, 0u};
+            for (int ff = cls; ff < cl.frames; ff += 16) {
+                uint4* o4 = cl.occ + static_cast<long long>(ff) * cl.occ_vec;
+                for (int i = tid; i < cl.occ_vec; i += kThreads) o4[i] = z;
+                unsigned* lv = cl.live + static_cast<long long>(ff) * cl.live_words;
+                for (int i = tid; i < cl.live_words; i += kThreads) lv[i] = 0u;
+            }
+            if (tid == 0) {
+                counters[16 + cls] = 0;
+                if (atomicAdd(counters + 1, 1) == min(cl.frames, 16) - 1) {
+                    counters[1] = 0;
+                    counters[0] = 0;
+                }
+            }
+        }
         __syncthreads();                                                  // (`drawn` is written again by the next item)
     }
     }   // items
     if (kTuning && counters && draw) {                                    // drawn parts: one ticket per workgroup, after its last draw
         __syncthreads();
-        if (tid == 0) *drawn = atomicAdd(counters + 1 + cl.group, 1);
+        if (tid == 0) *drawn = atomicAdd(counters + 1, 1);
         __syncthreads();
-        if (*drawn == static_cast<int>(gridDim.x) - 1) pool_clean<kThreads>(cl, counters, tid);
+        if (*drawn == static_cast<int>(gridDim.x) - 1) pool_clean_all<kThreads>(cl, counters, tid);
     }
 }
 
@@ -2244,7 +2262,7 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
         // (the counter lies in the cleared region in front of `occupied`)
         int* draw = (persistent && tail > 0 && !getenv("FIERY_POOL_NO_DRAW")) ? counter_block : nullptr;
         int* counters = counter_block;
-        const PoolClean cl{reinterpret_cast<uint4*>(occ), static_cast<int>(frames * occ_stride / 16), live, frames * n_cam * D, 0};
+        const PoolClean cl{reinterpret_cast<uint4*>(occ), static_cast<int>(occ_stride / 16), live, n_cam * D, frames};
         if (getenv("FIERY_POOL_NO_COUNTERS")) counters = nullptr;                   // tuning: no tickets, no in-kernel cleaning (callers must not pass WORKSPACE_CLEAN)
         int part_ranges = 0;
         if (const char* forced = getenv("FIERY_POOL_PART_RANGES")) part_ranges = atoi(forced);      // tuning / A-B runs

@@ -713,3 +713,32 @@ def test_lean_prepass_writes_what_the_general_prepass_writes(sim, monkeypatch, f
     n_pts = frames * n_cam * D * H * W
     written = got['1'][0][:n_pts] != -13
     assert (written.all() if flags == 0 else 0 < int(written.sum()) < n_pts // 4)
+
+
+@pytest.mark.parametrize('tail_parts', [0, 3])
+def test_workspace_cleaning_frame_by_frame_with_more_than_sixteen_frames(sim, monkeypatch, tail_parts):
+    """The compact form cleans its workspace frame by frame: the last item of a frame CLASS (frames f, f + 16, ... share one of
+    sixteen ticket counters) zeroes those frames' occupancy bytes and live masks.  Eighteen frames put two frames on classes 0
+    and 1; with `tail_parts` the last units are cut into parts whose tickets count too.  Two calls in a row on one zero-filled
+    workspace under FIERY_POOL_WORKSPACE_CLEAN: same planes as the unflagged call on garbage, region all zero after each."""
+    from fiery_amd import native
+    if tail_parts:
+        monkeypatch.setenv('FIERY_POOL_TAIL_PARTS', str(tail_parts))
+    grid, _ = _grid([-14.0, 30.0, 0.5], [-24.0, 10.0, 0.5], [-10.0, 10.0, 20.0])
+    frustum, intr, extr, lifted = _small_problem(97, n_cam=1, D=6, H=28, W=16, C=3, frames=18)
+    extr = extr.clone()
+    extr[:, :, 0, 3] += torch.linspace(-3.0, 3.0, 18).view(18, 1)          # every frame occupies other voxels
+    frames, n_cam, C, D, H, W = lifted.shape
+    geo = torch.from_numpy(ls.get_geometry(frustum, intr.numpy(), extr.numpy()))
+    st = lifted.stride()
+    strides = (st[0], st[1], st[3], st[4], st[5], st[2])
+    dirty = sim.pool_workspace(frames, n_cam, D, H, W, lifted.device, grid)
+    dirty.fill_(-5)
+    want = sim.voxel_pool(lifted, strides, geo, frames, n_cam, D, H, W, C, grid, workspace=dirty)
+    ws = sim.pool_workspace(frames, n_cam, D, H, W, lifted.device, grid, zeroed=True)
+    off = sim.dll.fiery_voxel_pool_occupied_offset(frames, n_cam, D, H, W, grid.dim[0] * grid.dim[1], 0, 0) // 4
+    n_region = frames * ((grid.dim[0] * grid.dim[1] + 63) // 64) * 16 + frames * n_cam * D + 64
+    for _ in range(2):
+        got = sim.voxel_pool(lifted, strides, geo, frames, n_cam, D, H, W, C, grid, workspace=ws, flags=native.POOL_WORKSPACE_CLEAN)
+        assert (got - want).abs().max() < 2e-5 and (tail_parts or torch.equal(got, want))
+        assert int(ws[off - n_region:off].abs().sum()) == 0

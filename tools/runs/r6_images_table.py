@@ -25,6 +25,23 @@ model.sample_streams = False
 B, n = 3, 6
 image, K, E, ego = make_inputs(B, model.receptive_field + model.n_future, n, image_hw=tuple(cfg.IMAGE.FINAL_DIM), seed=0)
 args = [t.to(dev) for t in (image, K, E, ego)]
+shapes = []
+lib = native.get()
+for meth, pick in (('depthwise_conv', lambda a: ('depthwise', a[5], a[3], a[4], f'k{a[8]} s{a[9]}')),
+                   ('se_gate_nhwc', lambda a: ('se_gate', a[5], a[4], 0, '')),
+                   ('scale_channels', lambda a: ('scale', a[4], a[3], 0, ''))):
+    orig = getattr(lib, meth)
+
+    def wrapped(*a, _orig=orig, _pick=pick):
+        if native.CALL_SINK is None:
+            return _orig(*a)
+        s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_.record()
+        r_ = _orig(*a)
+        e_.record()
+        shapes.append((_pick(a), s_, e_))
+        return r_
+    setattr(lib, meth, wrapped)
 with torch.no_grad():
     for _ in range(2):
         model(*args)
@@ -57,3 +74,15 @@ for name, s, e in calls:
         other[name][1] += 1
 for name, (us, cnt) in sorted(other.items(), key=lambda kv: -kv[1][0])[:12]:
     print(f'{cnt:3d} {us:9.1f}  {name}')
+
+print('depthwise / squeeze-excite launches (channels, rows or pixels, cols, kernel): us, bytes-bound us at 5 TB/s')
+for (kind, c, h, w, ks), s_, e_ in shapes:
+    us = s_.elapsed_time(e_) * 1e3
+    if kind == 'depthwise':
+        st = int(ks.split('s')[1])
+        nb = 4.0 * 54 * c * (h * w + (h // st) * (w // st))
+    elif kind == 'se_gate':
+        nb = 4.0 * 54 * c * h
+    else:
+        nb = 8.0 * 54 * c * h
+    print(f'  {kind:10s} C={c:4d} {h:6d} x {w:4d} {ks:6s} {us:8.1f} us   {nb / 5e6:7.1f}')

@@ -61,9 +61,9 @@ EXTRA_FLAGS = 0
 def op():
     if GROUPS:
         lib.voxel_pool_grouped(x, strides, geo, frames, n_cam, D, fh, fw, 64, grid, GROUPS, sides, out=out, workspace=ws_clean,
-                               flags=native.POOL_WORKSPACE_CLEAN | EXTRA_FLAGS)
+                               flags=(0 if EXTRA_FLAGS >> 30 else native.POOL_WORKSPACE_CLEAN) | (EXTRA_FLAGS & 0xffff))
     else:
-        lib.voxel_pool(x, strides, geo, frames, n_cam, D, fh, fw, 64, grid, out=out, workspace=ws_clean, flags=native.POOL_WORKSPACE_CLEAN | EXTRA_FLAGS)
+        lib.voxel_pool(x, strides, geo, frames, n_cam, D, fh, fw, 64, grid, out=out, workspace=ws_clean, flags=(0 if EXTRA_FLAGS >> 30 else native.POOL_WORKSPACE_CLEAN) | (EXTRA_FLAGS & 0xffff))
 
 
 def setenv(v):
@@ -78,7 +78,10 @@ def setenv(v):
                 GROUPS = tuple(int(t) for t in val.split('+'))
                 continue
             if k == 'NO_RANKS':
-                EXTRA_FLAGS = native.POOL_NO_RANKS if int(val) else 0
+                EXTRA_FLAGS |= native.POOL_NO_RANKS if int(val) else 0
+                continue
+            if k == 'NOCLEAN':                       # without POOL_WORKSPACE_CLEAN: the call clears its workspace with a memset dispatch
+                EXTRA_FLAGS |= 1 << 30
                 continue
             os.environ[k] = val
             touched.append(k)
