@@ -29,6 +29,15 @@
 // and a plain streaming sweep does gain from it - but consecutive 240-byte rows share a 64-byte sector, which a
 // non-temporal load does not leave behind for the next row: +13 % HBM fetch, 229 vs 209 us for the bare read pattern
 // (tools/probe/hbm_probe.hip k_read_planes, profiles/r1_s3_pool_sweeps.txt).
+#ifndef POOL_EXP
+#define POOL_EXP 0          // timing experiments on the compact pooling kernel (WRONG results): 1 whole units write one chunk of their plane,
+#endif                      // 2 no LDS filing, 4 no many-run walk, 5 tail parts write one chunk
+#ifndef FIERY_POOL_WALK_FIRST
+#define FIERY_POOL_WALK_FIRST 1
+#endif
+#ifndef FIERY_POOL_WALK_BATCH
+#define FIERY_POOL_WALK_BATCH 4     // rows of a many-run quad whose ranks are in flight together
+#endif
 #ifndef FIERY_POOL_ROW_AUX
 #define FIERY_POOL_ROW_AUX 2        // cache policy bits of the row loads (buffer-load aux: 1 sc0, 2 nt, 16 sc1): non-temporal
 #endif
@@ -1730,6 +1739,18 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
             vf4 cur[kCompactRows];
             const Record rec = rec_io;
             const bool refill = s_refill < n_slices;
+#if FIERY_POOL_WALK_FIRST
+            // a quad with a many-run column is walked row by row with its ranks (below): they are requested here, BEFORE the
+            // refill's rows, so that they come back first (loads return in order)
+            const bool walk = lane_ok && ((rec.split_lo | rec.split_hi) & 0xf000f000u) != 0u;
+            int4 wk[kCompactRows];
+            if (walk && POOL_EXP != 4) {
+                const int* rk = rank + (static_cast<long long>(f) * n_slices + s) * HW + q * 4 + g * W;
+#pragma unroll
+                for (int j = 0; j < kCompactRows; ++j)
+                    wk[j] = (kExactRows || 4 * j + g < H) ? *reinterpret_cast<const int4*>(rk + 4 * j * W) : make_int4(-1, -1, -1, -1);
+            }
+#endif
             {
                 const int refill_off = refill ? slice_offset(s_refill) : 0;
                 // quads without a point inside the grid (a third of pon's, a twentieth of baseline's) are not fetched: the
@@ -1742,6 +1763,20 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
                 for (int j = 0; j < kCompactRows; ++j) request_row(set[j], j, refill_off, refill_lane_off);
                 fetch_record(rec_io, s_refill, refill);
             }
+#if FIERY_POOL_WALK_FIRST
+            if (walk && POOL_EXP != 4) {
+#pragma unroll
+                for (int j = 0; j < kCompactRows; ++j) {
+                    const int rr[4] = {wk[j].x, wk[j].y, wk[j].z, wk[j].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (rr[e] < 0) continue;
+                        const int cell = cell_of(rr[e]) - lo;
+                        if (static_cast<unsigned>(cell) < static_cast<unsigned>(span)) atomicAdd(&plane[cell], cur[j][e]);
+                    }
+                }
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
             // ---- what survives the row loop: two weight counters per column (packed pairs) and the cells of the runs
             // this lane files.  Row h of a column belongs to run A while s1 - h >= 1 and to run C once h + 1 - s2 >= 1:
@@ -1824,34 +1859,44 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
                     const int cell = my_cell[k];
                     if (cell < 0) continue;
                     if (cell != cur) {
-                        if (cur >= 0) atomicAdd(&plane[cur], acc);
+                        if (cur >= 0 && (POOL_EXP != 2 || acc == 1.2345e-30f)) atomicAdd(&plane[cur], acc);
                         cur = cell;
                         acc = 0.f;
                     }
                     acc += mine[k];
                 }
-                if (cur >= 0) atomicAdd(&plane[cur], acc);
+                if (cur >= 0 && (POOL_EXP != 2 || acc == 1.2345e-30f)) atomicAdd(&plane[cur], acc);
             }
-            if (many_runs) {
+            if (!FIERY_POOL_WALK_FIRST && many_runs && POOL_EXP != 4) {
                 // a column with four or more runs in this quad (a rolled camera; 1.5 % of the quads of the jittered
-                // baseline rig): this lane fetches its rows again, with their ranks, and every element goes to the voxel
-                // its own rank names
+                // baseline rig, but one wavefront slice in five holds such a quad): every element goes to the voxel its own
+                // rank names.  The lane fetches its rows again with their ranks, several rows in flight at a time.  (Until round 6
+                // one row at a time - seven dependent round trips per slice: 25 us of the op; a launch without the walk,
+                // POOL_EXP=4: 220.6 against 245.8 us.  Keeping the rows of the slice alive in registers instead spills.)
                 // (under FIERY_POOL_NO_RANKS the prepass has written the ranks of exactly these quads)
-                const long long pt = (static_cast<long long>(f) * n_slices + s) * HW + q * 4;
+                const int* rk = rank + (static_cast<long long>(f) * n_slices + s) * HW + q * 4 + g * W;
                 const int off = slice_offset(s);
+                constexpr int kBatch = FIERY_POOL_WALK_BATCH;
 #pragma unroll 1
-                for (int j = 0; j < kCompactRows; ++j) {
-                    if (!kExactRows && 4 * j + g >= H) break;
-                    const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rows, row_voff, off + j * row4_bytes, 0);
-                    vf4 row;
-                    __builtin_memcpy(&row, &raw, 16);
-                    const int4 r = *reinterpret_cast<const int4*>(rank + pt + (4 * j + g) * W);
-                    const int rr[4] = {r.x, r.y, r.z, r.w};
+                for (int jb = 0; jb < kCompactRows; jb += kBatch) {
+                    vf4 rw[kBatch];
+                    int4 rr4[kBatch];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (rr[e] < 0) continue;
-                        const int cell = cell_of(rr[e]) - lo;
-                        if (static_cast<unsigned>(cell) < static_cast<unsigned>(span)) atomicAdd(&plane[cell], row[e]);
+                    for (int j = 0; j < kBatch; ++j) {
+                        const bool there = jb + j < kCompactRows && (kExactRows || 4 * (jb + j) + g < H);
+                        const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rows, there ? row_voff : kOob, off + (jb + j) * row4_bytes, 0);
+                        __builtin_memcpy(&rw[j], &raw, 16);
+                        rr4[j] = there ? *reinterpret_cast<const int4*>(rk + 4 * (jb + j) * W) : make_int4(-1, -1, -1, -1);
+                    }
+#pragma unroll
+                    for (int j = 0; j < kBatch; ++j) {
+                        const int rr[4] = {rr4[j].x, rr4[j].y, rr4[j].z, rr4[j].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (rr[e] < 0) continue;
+                            const int cell = cell_of(rr[e]) - lo;
+                            if (static_cast<unsigned>(cell) < static_cast<unsigned>(span)) atomicAdd(&plane[cell], rw[j][e]);
+                        }
                     }
                 }
             }
@@ -1889,7 +1934,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
         if (parts == 1 && n_pass == 1 && (n_vox & 3) == 0 && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
             // one pass, whole units: every voxel gets its cell's sum or a zero - four voxels (one nibble of a bit word) per
             // thread and 16-byte store; their cells are consecutive
-            for (int v0 = 4 * tid; v0 < n_vox; v0 += 4 * kThreads) {
+            for (int v0 = 4 * tid; v0 < (POOL_EXP == 1 ? min(n_vox, 4 * kThreads) : n_vox); v0 += 4 * kThreads) {
                 const unsigned wbits = bits[v0 >> 5];
                 const unsigned nib = (wbits >> (v0 & 31)) & 15u;
                 int cell = static_cast<int>(prefix[v0 >> 5]) + __popc(wbits & ((1u << (v0 & 31)) - 1u));
@@ -1901,7 +1946,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
                 *reinterpret_cast<float4*>(o + v0) = v;            // (plain: non-temporal stores measured 1.7 us slower per op, round 6)
             }
         } else
-        for (int v0 = tid; v0 < n_vox; v0 += kThreads) {
+        for (int v0 = tid; v0 < (POOL_EXP == 5 ? min(n_vox, kThreads) : n_vox); v0 += kThreads) {
             const unsigned wbits = bits[v0 >> 5];
             const bool hit = (wbits >> (v0 & 31)) & 1u;
             const int cell = static_cast<int>(prefix[v0 >> 5]) + __popc(wbits & ((1u << (v0 & 31)) - 1u)) - lo;
