@@ -32,12 +32,6 @@
 #ifndef POOL_EXP
 #define POOL_EXP 0          // timing experiments on the compact pooling kernel (WRONG results): 1 whole units write one chunk of their plane,
 #endif                      // 2 no LDS filing, 4 no many-run walk, 5 tail parts write one chunk
-#ifndef FIERY_POOL_WALK_FIRST
-#define FIERY_POOL_WALK_FIRST 1
-#endif
-#ifndef FIERY_POOL_WALK_BATCH
-#define FIERY_POOL_WALK_BATCH 4     // rows of a many-run quad whose ranks are in flight together
-#endif
 #ifndef FIERY_POOL_ROW_AUX
 #define FIERY_POOL_ROW_AUX 2        // cache policy bits of the row loads (buffer-load aux: 1 sc0, 2 nt, 16 sc1): non-temporal
 #endif
@@ -1739,9 +1733,13 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
             vf4 cur[kCompactRows];
             const Record rec = rec_io;
             const bool refill = s_refill < n_slices;
-#if FIERY_POOL_WALK_FIRST
-            // a quad with a many-run column is walked row by row with its ranks (below): they are requested here, BEFORE the
-            // refill's rows, so that they come back first (loads return in order)
+            // A quad with a many-run column (four or more runs: a rolled camera; 1.5 % of the quads of the jittered baseline rig,
+            // but one wavefront slice in ten holds one) is walked row by row - every element goes to the voxel its own rank
+            // names.  The ranks are requested here, BEFORE the refill's rows, so that they come back first (loads return in
+            // order), and the walk uses the rows already in `cur`.  (Until round 6 the walk came after the run sums, re-fetched
+            // every row and its ranks one row at a time behind the refill - seven dependent round trips per slice: 25 us of
+            // the op, found with a launch without the walk (POOL_EXP=4: 220.6 against 245.8 us).  Under FIERY_POOL_NO_RANKS the
+            // prepass has written the ranks of exactly these quads.)
             const bool walk = lane_ok && ((rec.split_lo | rec.split_hi) & 0xf000f000u) != 0u;
             int4 wk[kCompactRows];
             if (walk && POOL_EXP != 4) {
@@ -1750,7 +1748,6 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
                 for (int j = 0; j < kCompactRows; ++j)
                     wk[j] = (kExactRows || 4 * j + g < H) ? *reinterpret_cast<const int4*>(rk + 4 * j * W) : make_int4(-1, -1, -1, -1);
             }
-#endif
             {
                 const int refill_off = refill ? slice_offset(s_refill) : 0;
                 // quads without a point inside the grid (a third of pon's, a twentieth of baseline's) are not fetched: the
@@ -1763,7 +1760,6 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
                 for (int j = 0; j < kCompactRows; ++j) request_row(set[j], j, refill_off, refill_lane_off);
                 fetch_record(rec_io, s_refill, refill);
             }
-#if FIERY_POOL_WALK_FIRST
             if (walk && POOL_EXP != 4) {
 #pragma unroll
                 for (int j = 0; j < kCompactRows; ++j) {
@@ -1776,7 +1772,6 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
                     }
                 }
             }
-#endif
             __builtin_amdgcn_sched_barrier(0);
             // ---- what survives the row loop: two weight counters per column (packed pairs) and the cells of the runs
             // this lane files.  Row h of a column belongs to run A while s1 - h >= 1 and to run C once h + 1 - s2 >= 1:
@@ -1821,7 +1816,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
             }
             // Six packed instructions per row and column pair: the two weights, run A's and run C's sums, the sum of
             // everything (run B is what is left of it), the counter.  No branch in here: idle lanes and many-run quads
-            // (whose cells are all "none"; they are walked separately below) carry sums nobody files.
+            // (whose cells are all "none"; they were walked above) carry sums nobody files.
             v2f first[kPairs], third[kPairs], all[kPairs];
 #pragma unroll
             for (int u = 0; u < kPairs; ++u) first[u] = third[u] = all[u] = pk_splat(0.f);
@@ -1866,39 +1861,6 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
                     acc += mine[k];
                 }
                 if (cur >= 0 && (POOL_EXP != 2 || acc == 1.2345e-30f)) atomicAdd(&plane[cur], acc);
-            }
-            if (!FIERY_POOL_WALK_FIRST && many_runs && POOL_EXP != 4) {
-                // a column with four or more runs in this quad (a rolled camera; 1.5 % of the quads of the jittered
-                // baseline rig, but one wavefront slice in five holds such a quad): every element goes to the voxel its own
-                // rank names.  The lane fetches its rows again with their ranks, several rows in flight at a time.  (Until round 6
-                // one row at a time - seven dependent round trips per slice: 25 us of the op; a launch without the walk,
-                // POOL_EXP=4: 220.6 against 245.8 us.  Keeping the rows of the slice alive in registers instead spills.)
-                // (under FIERY_POOL_NO_RANKS the prepass has written the ranks of exactly these quads)
-                const int* rk = rank + (static_cast<long long>(f) * n_slices + s) * HW + q * 4 + g * W;
-                const int off = slice_offset(s);
-                constexpr int kBatch = FIERY_POOL_WALK_BATCH;
-#pragma unroll 1
-                for (int jb = 0; jb < kCompactRows; jb += kBatch) {
-                    vf4 rw[kBatch];
-                    int4 rr4[kBatch];
-#pragma unroll
-                    for (int j = 0; j < kBatch; ++j) {
-                        const bool there = jb + j < kCompactRows && (kExactRows || 4 * (jb + j) + g < H);
-                        const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rows, there ? row_voff : kOob, off + (jb + j) * row4_bytes, 0);
-                        __builtin_memcpy(&rw[j], &raw, 16);
-                        rr4[j] = there ? *reinterpret_cast<const int4*>(rk + 4 * (jb + j) * W) : make_int4(-1, -1, -1, -1);
-                    }
-#pragma unroll
-                    for (int j = 0; j < kBatch; ++j) {
-                        const int rr[4] = {rr4[j].x, rr4[j].y, rr4[j].z, rr4[j].w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (rr[e] < 0) continue;
-                            const int cell = cell_of(rr[e]) - lo;
-                            if (static_cast<unsigned>(cell) < static_cast<unsigned>(span)) atomicAdd(&plane[cell], rw[j][e]);
-                        }
-                    }
-                }
             }
         };
         // a part is a contiguous range of slices (neighbouring depths of one or two cameras: it touches a fraction of the
