@@ -393,8 +393,11 @@ def main():
         # Winograd F(2x2, 3x3) launch EXECUTES 16 / 36 of the direct form's matrix flops: the MFMA roofline below is on executed
         # flops; the direct-form-equivalent ("algorithmic") flops of those launches and the speed-up they stand for are reported
         # separately, never against the matrix peak.
+        # The SPLIT Winograd form (round 6) runs those 16 / 36 on the bf16 matrix cores with every fp32 operand as three bf16 terms:
+        # six bf16 MFMAs per product block - its executed flops are 6 x 16 / 36 of the direct count, priced against the bf16 peak.
         WINO = 16.0 / 36.0
-        executed_of = lambda w, d: w * WINO if 'winograd' in str(d[-1]) else w
+        executed_of = lambda w, d: w * WINO * (6.0 if 'split' in str(d[-1]) else 1.0) if 'winograd' in str(d[-1]) else w
+        peak_of = lambda form: PEAK_BF16_MFMA_TFLOPS if ('bf16' in str(form) or 'split' in str(form)) else PEAK_F32_MFMA_TFLOPS
         by_form = {}
         for k, s_, e_, w, d in recs:
             if k == 'conv_igemm':
@@ -423,7 +426,7 @@ def main():
             if k != 'conv_igemm':
                 continue
             kT, kH, kW, stride, cin, cout, n_img, Ho, Wo, form = d
-            peak_l = (PEAK_BF16_MFMA_TFLOPS if form == 'bf16' else PEAK_F32_MFMA_TFLOPS) * 1e12
+            peak_l = peak_of(form) * 1e12
             px_out = n_img * Ho * Wo
             nbytes = 4.0 * (px_out * stride * stride * cin + px_out * cout + cin * cout * kT * kH * kW)
             t_m, t_h = executed_of(w, d) / peak_l, nbytes / (PEAK_HBM_GBS * 1e9)
@@ -438,38 +441,44 @@ def main():
                      'what': 'sum over launches of max(executed flops / matrix peak of the form, algorithmic bytes / 8 TB/s) '
                              'divided by the measured convolution time of the step (one stream, HIP events)'}
         x_conv = sum(x_ for _, _, x_, _ in by_form.values())             # executed matrix flops of the step's convolutions
+        # (fp32-instruction equivalents: a split launch's six bf16 MFMAs stand for one fp32 product block)
+        x_conv_f32eq = sum(x_ / (6.0 if 'split' in str(k_) else 1.0) for k_, (_, _, x_, _) in by_form.items())
         # the dominant kernel = the form that holds most of the time; its flops against ITS peak
         dom = max(by_prec, key=lambda k_: by_prec[k_][0])
-        peak = PEAK_BF16_MFMA_TFLOPS if dom == 'bf16' else PEAK_F32_MFMA_TFLOPS
         t_dom, f_dom, n_dom = by_prec[dom]
-        achieved = f_dom / t_dom / 1e12
+        # all launches of that precision together: the time-weighted busy fraction of the matrix pipe each form runs on
+        pipe_s = sum(x_ / (peak_of(k_) * 1e12) for k_, (_, _, x_, _) in by_form.items() if (k_ == 'bf16') == (dom == 'bf16'))
         # ... and inside that precision the FORM that holds most of the time is the kernel the line names (round 5: the Winograd
         # kernel took over from the direct implicit GEMM): its own launches, executed flops and time
         KERNEL_OF = {'f32': 'k_conv_igemm (fp32 MFMA implicit GEMM, direct tile forms)', 'f32 stream-K': 'k_conv_igemm<SK> (fp32 MFMA implicit GEMM, stream-K)',
                      'f32 winograd': 'k_conv_winograd (Winograd F(2x2,3x3) on the fp32 matrix cores)',
+                     'f32 winograd split': 'k_conv_winograd, split form (Winograd F(2x2,3x3), fp32 operands as three bf16 terms, six products each on the '
+                                           'bf16 matrix cores, fp32 accumulation: fp32 accuracy)',
                      'bf16': 'k_conv_igemm (bf16 operands, fp32 accumulate, MFMA implicit GEMM)'}
         dom_form = max((k_ for k_ in by_form if (k_ == 'bf16') == (dom == 'bf16')), key=lambda k_: by_form[k_][0])
         t_df, f_df, x_df, n_df = by_form[dom_form]
+        peak = peak_of(dom_form)
         roofline = {'kernel': KERNEL_OF.get(str(dom_form), str(dom_form)),
                     'bound': 'mfma', 'achieved': round(x_df / t_df / 1e12, 2),
                     'peak': peak, 'unit': 'TFLOP/s', 'frac': round(x_df / t_df / 1e12 / peak, 4),
                     'launches': n_df, 'avg_launch_us': round(t_df / n_df * 1e6, 2),
                     'share_of_conv_time': round(t_df / t_conv, 4),
-                    'flops': 'EXECUTED matrix flops (a Winograd launch executes 16/36 of the direct form\'s 2*|out|*Cin*9); the direct-form count '
-                             'is in algorithmic_gflop / direct_form_equivalent_tflops, never against the peak',
+                    'flops': 'EXECUTED matrix flops (a Winograd launch executes 16/36 of the direct form\'s 2*|out|*Cin*9; its split form six bf16 '
+                             'products per fp32 product, priced against the bf16 peak); the direct-form count is in algorithmic_gflop / '
+                             'direct_form_equivalent_tflops, never against the peak',
                     # every convolution launch of the step together (what `frac` was until round 5)
-                    'all_convolutions': {'achieved': round(achieved, 2), 'frac': round(achieved / peak, 4), 'launches': n_dom,
-                                         'avg_launch_us': round(t_dom / n_dom * 1e6, 2)},
+                    'all_convolutions': {'frac': round(pipe_s / t_dom, 4), 'launches': n_dom, 'avg_launch_us': round(t_dom / n_dom * 1e6, 2),
+                                         'what': 'sum over launches of executed flops / the peak of the matrix instruction the form uses, over their time'},
                     'by_precision': {k_: {'launches': n_, 'ms_per_step': round(t_ * 1e3, 3), 'tflops': round(f_ / t_ / 1e12, 2)}
                                      for k_, (t_, f_, n_) in by_prec.items()},
                     # the forms the launches ran in: direct tiles ('f32'), stream-K, Winograd F(2x2, 3x3); executed = matrix flops
                     # the MFMAs really did, algorithmic = the direct form's flops for the same layers (SURVEY 8d's count)
                     'by_form': {str(k_): {'launches': n_, 'ms_per_step': round(t_ * 1e3, 3), 'executed_tflops': round(x_ / t_ / 1e12, 2),
-                                          'executed_frac_of_peak': round(x_ / t_ / 1e12 / (PEAK_BF16_MFMA_TFLOPS if k_ == 'bf16' else PEAK_F32_MFMA_TFLOPS), 4),
+                                          'executed_frac_of_peak': round(x_ / t_ / 1e12 / peak_of(k_), 4), 'peak': peak_of(k_),
                                           'algorithmic_gflop': round(f_ / 1e9, 1), 'executed_gflop': round(x_ / 1e9, 1)}
                                 for k_, (t_, f_, x_, n_) in by_form.items()},
                     'executed_gflop_per_step': round(x_conv / 1e9, 1),
-                    'algorithmic_speedup': {'value': round(f_conv / x_conv, 3),
+                    'algorithmic_speedup': {'value': round(f_conv / x_conv_f32eq, 3),
                                             'what': 'direct-form flops of the step / matrix flops executed (Winograd F(2x2,3x3) layers execute 16/36); '
                                                     'a separate figure - `achieved` / `frac` are on EXECUTED flops'},
                     'direct_form_equivalent_tflops': round(f_conv / t_conv / 1e12, 2),
@@ -571,7 +580,7 @@ def main():
             for k_, s_, e_, w_, d_ in convs:
                 if k_ == 'conv_igemm':
                     key = f'fiery_conv_fwd [{d_[-1]}]'
-                    x_ = w_ * (16.0 / 36.0) if 'winograd' in str(d_[-1]) else w_
+                    x_ = w_ * (16.0 / 36.0) * (6.0 if 'split' in str(d_[-1]) else 1.0) if 'winograd' in str(d_[-1]) else w_
                     t_, f_, n_ = conv_forms.get(key, (0.0, 0.0, 0))
                     conv_forms[key] = (t_ + s_.elapsed_time(e_), f_ + x_, n_ + 1)
                 elif k_ == 'voxel_pool':
@@ -580,7 +589,7 @@ def main():
                     rows.append({'name': 'fiery_voxel_pool_fwd', 'launches': 1, 'ms': round(ms_, 3), 'GB/s': round(nb / ms_ / 1e6, 1),
                                  'frac': round(nb / ms_ / 1e6 / PEAK_HBM_GBS, 4), 'bound': 'hbm'})
             for key, (t_, f_, n_) in conv_forms.items():
-                pk = PEAK_BF16_MFMA_TFLOPS if 'bf16' in key else PEAK_F32_MFMA_TFLOPS
+                pk = PEAK_BF16_MFMA_TFLOPS if ('bf16' in key or 'split' in key) else PEAK_F32_MFMA_TFLOPS
                 rows.append({'name': key, 'launches': n_, 'ms': round(t_, 3), 'TFLOP/s': round(f_ / t_ / 1e9, 2),
                              'frac': round(f_ / t_ / 1e9 / pk, 4), 'bound': 'mfma (executed flops)'})
             rows.sort(key=lambda r: -r['ms'])

@@ -27,6 +27,7 @@ SOURCES = [
     ('conv_tile_halo_f32.hip', []),
     ('conv_tile_stream_k.hip', []),
     ('conv_winograd.hip', []),
+    ('conv_winograd_split.hip', []),
     ('aux_ops.hip', []),
     ('conv_grad.hip', []),
     ('bn_train.hip', []),

@@ -188,6 +188,29 @@ extern "C" int fiery_conv_pack_weights_winograd(const float* w, int cout, int ci
     return check_launch("conv_pack_weights_winograd");
 }
 
+extern "C" size_t fiery_conv_winograd_split_packed_floats(int cout, int cin_units) {
+    if (cout <= 0 || cin_units <= 0) return 0;
+    return conv_winograd_split_packed_floats(cout, cin_units);
+}
+
+extern "C" int fiery_conv_pack_weights_winograd_split(const float* w, int cout, int cin_total, const int32_t* chan_map, int cin_units,
+                                                      float* packed, fiery_stream_t stream) {
+    FIERY_REQUIRE(w && chan_map && packed, "conv_pack_weights_winograd_split: null pointer");
+    FIERY_REQUIRE(cout > 0 && cin_total > 0 && cin_units > 0 && cin_units % 2 == 0, "conv_pack_weights_winograd_split: bad shape (whole 16-channel stages)");
+    FIERY_REQUIRE(cin_units <= kMaxPackUnits, "conv_pack_weights_winograd_split: at most %d input channels", kMaxPackUnits * 8);
+    ChanInverse inv;
+    for (int i = 0; i < kMaxPackUnits * 8; ++i) inv.ci[i] = -1;
+    for (int ci = 0; ci < cin_total; ++ci) {
+        const int pos = chan_map[ci];
+        FIERY_REQUIRE(pos >= 0 && pos < cin_units * 8, "conv_pack_weights_winograd_split: chan_map[%d] = %d out of range", ci, pos);
+        FIERY_REQUIRE(inv.ci[pos] < 0, "conv_pack_weights_winograd_split: chan_map maps two channels to position %d", pos);
+        inv.ci[pos] = static_cast<short>(ci);
+    }
+    if (conv_winograd_split_pack(w, cout, cin_total, inv, cin_units, packed, as_stream(stream)) != 0)
+        return fail(FIERY_EINVAL, "conv_pack_weights_winograd_split: launch failed");
+    return check_launch("conv_pack_weights_winograd_split");
+}
+
 namespace {
 // does the bf16 form take this launch?  (the scalar-addressed loop's conditions, a tile shape that has a bf16 kernel)
 bool conv_takes_bf16(const fiery_conv_desc* d, bool aligned, int bm, int bn, int cin_units) {
@@ -475,7 +498,8 @@ int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, ConvRunMode mode, 
                           d->precision != FIERY_PRECISION_BF16 && aligned16(d->weights_winograd) &&
                           static_cast<long long>(d->n_img_out) * ((d->Hout + 1) / 2) * ((d->Wout + 1) / 2) < (1ll << 30);
     const bool bf16 = !stream_k && !winograd && conv_takes_bf16(d, aligned, bm, bn, cin_units);
-    if (mode == kRunForm) return winograd ? FIERY_CONV_FORM_WINOGRAD : (stream_k ? FIERY_CONV_FORM_STREAM_K : FIERY_CONV_FORM_TILE);
+    const bool split = winograd && d->winograd == FIERY_WINOGRAD_SPLIT_TERMS;      // weights_winograd is the split image then
+    if (mode == kRunForm) return winograd ? (split ? FIERY_CONV_FORM_WINOGRAD_SPLIT : FIERY_CONV_FORM_WINOGRAD) : (stream_k ? FIERY_CONV_FORM_STREAM_K : FIERY_CONV_FORM_TILE);
     if (!launch) return bf16 ? FIERY_PRECISION_BF16 : FIERY_PRECISION_F32;
     if (winograd) {
         {
@@ -491,7 +515,7 @@ int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, ConvRunMode mode, 
         }
         p.w = d->weights_winograd;
         if (const char* t = getenv("FIERY_WINOGRAD_TRACE")) p.sk_ws = reinterpret_cast<float*>(strtoull(t, nullptr, 0));      // tuning builds (W_TRACE)
-        if (!conv_launch_winograd(p, hs)) return fail(FIERY_EINVAL, "conv_fwd: Winograd launch failed");
+        if (!(split ? conv_launch_winograd_split(p, hs) : conv_launch_winograd(p, hs))) return fail(FIERY_EINVAL, "conv_fwd: Winograd launch failed");
         return check_launch("conv_fwd (Winograd)");
     }
     if (stream_k) {

@@ -136,6 +136,10 @@ struct ChanInverse {
 size_t conv_winograd_packed_floats(int cout, int cin_units);
 int conv_winograd_pack(const float* w, int cout, int cin_total, const ChanInverse& inv, int cin_units, float* packed, hipStream_t stream);
 bool conv_launch_winograd(const ConvP& p, hipStream_t stream);
+// its split form (conv_winograd_split.hip): bf16 matrix cores, operands as three bf16 terms, fp32 accuracy
+size_t conv_winograd_split_packed_floats(int cout, int cin_units);
+int conv_winograd_split_pack(const float* w, int cout, int cin_total, const ChanInverse& inv, int cin_units, float* packed, hipStream_t stream);
+bool conv_launch_winograd_split(const ConvP& p, hipStream_t stream);
 // stream-K form of the scalar-addressed fp32 kernel on 128-pixel tiles (bn = 64 or 128); returns false when bn has none
 bool conv_launch_stream_k(const ConvP& p, int bn, dim3 grid, hipStream_t stream);
 // workgroups the stream-K kernel of cout tile width bn keeps resident per CU

@@ -32,8 +32,24 @@
 //     arithmetic of the direct kernel's epilogues, and stores 16 bytes to each of the block's four pixels.
 // Executed matrix flops are 16 / 36 of the direct form's; bench.py reports the algorithmic (direct-form) flops of these
 // launches and the executed-MFMA fraction side by side, never an "algorithmic TFLOP/s" against the matrix peak.
+//
+// SPLIT form (round 6; conv_winograd_split.hip compiles this file with FIERY_WINOGRAD_SPLIT = 1).  The 16 GEMMs run on the bf16
+// matrix cores (v_mfma_f32_32x32x16_bf16: sixteen times the fp32 instruction's rate) WITHOUT giving up fp32 accuracy: every fp32
+// operand is written as the sum of three bf16 terms (x = x1 + x2 + x3 exactly: 3 x 8 significand bits) and the product as the
+// six partial products whose weight is not below 2^-24 of it - u1 v3, u3 v1, u2 v2, u1 v2, u2 v1, u1 v1, smallest first - each
+// exact in the fp32 accumulator.  Measured against fp64 on this chip (tools/probe/split_bf16_probe.hip, profiles/
+// r6_split_bf16_probe.txt): rms error 3.6e-7 of the result's rms at K = 576 where the fp32 instruction leaves 4.3e-7 (the bf16
+// instruction adds sixteen products per rounding, the fp32 one two), 1.07e-6 against 1.21e-6 at K = 4608; nine products change
+// nothing.  Six 8-pass MFMAs per sixteen channels replace eight 16-pass ones: 192 against 512 matrix-pipe cycles.  The
+// transformed weights are split on the host side of the launch (k_pack_winograd_split: U in fp64, rounded to fp32, then split);
+// the transformed input stays fp32 in LDS and the wavefront that owns a transform point splits its operand as it reads it
+// (36 vector instructions per point and stage, which run under the other wavefront's MFMAs: tools/probe/
+// mfma_bf16_valu_probe.hip).  Everything outside the K loop - input transform, epilogues - is the fp32 form's.
 #define FIERY_CONV_KERNEL_TU 1
 #include "conv_igemm_kernel.h"
+#ifndef FIERY_WINOGRAD_SPLIT
+#define FIERY_WINOGRAD_SPLIT 0
+#endif
 
 namespace fiery {
 namespace {
@@ -55,6 +71,9 @@ namespace {
 #endif                            // loop / end, + the CU's hardware id) into the buffer whose address rides in p.sk_ws
 #ifndef W_PIPE
 #define W_PIPE 1                  // pin the MFMA order of a transform point's block (A/B switch)
+#endif
+#ifndef W_SPLIT_RING
+#define W_SPLIT_RING 12           // split form: register ring of weight pieces (a stage has 24: 4 points x 2 cout blocks x 3 terms)
 #endif
 #ifndef W_EXP
 #define W_EXP 0                   // timing experiments (wrong results): 1 weights from one hot piece, 2 no input loads in the loop,
@@ -101,6 +120,44 @@ __global__ void k_pack_winograd(const float* __restrict__ w, int cout, int cin_t
     packed[i] = v;
 }
 
+// Split form: U as above, rounded to fp32, then written as three bf16 terms (round to nearest even; the three add up to the fp32
+// value exactly).  Packed as the 16-byte MFMA operands of the kernel's lanes: [cout tile][p][stage][cout block][term][lane][8],
+// lane = (cout % 32, hi), element j = channel 16 stage + (j < 4 ? 4 hi + j : 8 + 4 hi + j - 4) - the channels lane (tile, hi) of
+// the V operand holds (slots hi and 2 + hi of the tile's row).
+__global__ void k_pack_winograd_split(const float* __restrict__ w, int cout, int cin_total, ChanInverse inv, int cin_units, long long total,
+                                      unsigned short* __restrict__ packed) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int S = cin_units >> 1;
+    const int j = static_cast<int>(i & 7), lane = static_cast<int>((i >> 3) & 63);
+    long long r = i >> 9;
+    const int term = static_cast<int>(r % 3);
+    r /= 3;
+    const int nb = static_cast<int>(r & 1);
+    r >>= 1;
+    const int st = static_cast<int>(r % S);
+    r /= S;
+    const int p = static_cast<int>(r % 16);
+    const int tn = static_cast<int>(r / 16);
+    const int hi = lane >> 5, n = tn * 64 + nb * 32 + (lane & 31);
+    const int k = 16 * st + (j < 4 ? 4 * hi + j : 8 + 4 * hi + j - 4);
+    float v = 0.f;
+    if (n < cout) {
+        const int ci = inv.ci[k];
+        if (ci >= 0) {
+            const float* g = w + (static_cast<long long>(n) * cin_total + ci) * 9;
+            const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+            const int pi = p >> 2, pj = p & 3;
+            double sum = 0.0;
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) sum += G[pi][a] * static_cast<double>(g[a * 3 + b]) * G[pj][b];
+            v = static_cast<float>(sum);
+        }
+    }
+    const float t1 = bf16_round(v), r1 = v - t1, t2 = bf16_round(r1), r2 = r1 - t2;
+    packed[i] = bf16_bits(term == 0 ? t1 : term == 1 ? t2 : r2);
+}
+
 // KIND: which epilogue the kernel carries - with all of them behind run-time switches the code after the K loop was 18,000
 // instructions with scalar registers spilled to vector lanes, and an epilogue's vector instructions are served one per MFMA of the
 // CU's other workgroup (~64 cycles each): 0 plain, act none / ReLU, no residual, no bias; 1 plain, anything; 2 GRU gates; 3 GRU
@@ -114,6 +171,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_conv_winograd(Conv
     static_assert(NW == 4 || NW == 8, "four or eight wavefronts");
     constexpr int PP = 16 / NW;                        // transform points per wavefront
     constexpr bool LEAN = KIND >= 0 && KIND <= 4;
+    constexpr bool SPLIT = FIERY_WINOGRAD_SPLIT != 0;  // bf16 matrix cores, three-term operands (see the head of the file)
+    static_assert(!SPLIT || NW == 4, "the split form: four wavefronts");
     __shared__ __attribute__((aligned(16))) float smem[W_SMEM_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 31, hi = lane >> 5;
@@ -249,15 +308,19 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_conv_winograd(Conv
 
     // ---- transformed weights: this wavefront's pieces, straight into a register ring -----------------------------------------
     // piece index within a stage: ((q * 4 + pl) * 2 + nb), pl = local transform point; 16 pieces per stage
+    // (split form: a stage has 24 pieces - piece 6 pl + 3 nb + term of [p][stage][cout block][term][lane], 1 KiB each)
     const int Q = p.cin_units * 2;                                      // 16-byte k-quads of the whole K
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.w) + static_cast<long long>(tile_n) * 16 * Q * 256, 0, 16 * Q * 1024, 0x00020000);
-    const int w_vo = (hi * 64 + m) * 16;
+    const __amdgpu_buffer_rsrc_t wrs = SPLIT
+        ? __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.w)) + static_cast<long long>(tile_n) * 16 * stages * 6144, 0,
+                                            16 * stages * 6144, 0x00020000)
+        : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w) + static_cast<long long>(tile_n) * 16 * Q * 256, 0, 16 * Q * 1024, 0x00020000);
+    const int w_vo = SPLIT ? lane * 16 : (hi * 64 + m) * 16;
     // (the ring is deep: vmcnt counts loads in issue order, so a weight piece requested behind the next stage's 16 input loads
     // cannot be waited for without waiting for those too - pieces are requested almost a stage before they are multiplied, by
     // which time the input loads in front of them have long landed)
-    constexpr int PIECES = 4 * PP;                                     // per stage: two k-groups x PP points x two cout halves
-    constexpr int RING = NW == 4 ? W_RING : W_RING8, AHEAD = RING - 2;
+    constexpr int PIECES = SPLIT ? 6 * PP : 4 * PP;                    // per stage: two k-groups x PP points x two cout halves
+    // (split form: a point's six pieces are requested into the slots the point before last just left)
+    constexpr int RING = SPLIT ? W_SPLIT_RING : NW == 4 ? W_RING : W_RING8, AHEAD = SPLIT ? RING : RING - 2;
     static_assert(PIECES % RING == 0, "the ring must divide a stage's pieces");
     float4 wr[RING];
     auto to_f4 = [](auto raw) {
@@ -269,6 +332,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_conv_winograd(Conv
     auto w_request = [&](int slot, int s, int piece) {                  // piece of stage s (past the end: any piece of the last stage)
         if (W_EXP == 6 && !w_live) return;
         const int ss = s < stages ? s : stages - 1;
+        if constexpr (SPLIT) {
+            const int soff = W_EXP == 1 ? 0 : (((PP * wv + piece / 6) * stages + ss) * 6 + piece % 6) * 1024;
+            wr[slot] = to_f4(__builtin_amdgcn_raw_buffer_load_b128(wrs, w_vo, soff, 0));
+            return;
+        }
         const int q = piece / (2 * PP), pl = (piece >> 1) % PP, nb = piece & 1;
         const int soff = W_EXP == 1 ? 0 : (((PP * wv + pl) * Q + 4 * ss + 2 * q) * 64 + nb * 32) * 16;
         wr[slot] = to_f4(__builtin_amdgcn_raw_buffer_load_b128(wrs, w_vo, soff, 0));
@@ -297,6 +365,55 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_conv_winograd(Conv
         constexpr bool FIRST = decltype(first_c)::value;
         const int buf = s & 1;
         const float* vb = smem + buf * W_V_FLOATS + (PP * wv) * (WT * WKC);
+        if constexpr (SPLIT) {
+            // a stage is ONE sixteen-channel MFMA step per (point, cout block, product): the lane's eight channels of its tile
+            // are slots hi and 2 + hi of the row (two 16-byte reads, made a point ahead), split here into the three terms
+            float4 n_lo = *reinterpret_cast<const float4*>(vb + v_rd[0]), n_hi = *reinterpret_cast<const float4*>(vb + v_rd[1]);
+#pragma unroll
+            for (int pl = 0; pl < PP; ++pl) {
+                const float4 lo = n_lo, up = n_hi;
+                if (pl + 1 < PP) {
+                    n_lo = *reinterpret_cast<const float4*>(vb + (pl + 1) * (WT * WKC) + v_rd[0]);
+                    n_hi = *reinterpret_cast<const float4*>(vb + (pl + 1) * (WT * WKC) + v_rd[1]);
+                }
+                const float x[8] = {lo.x, lo.y, lo.z, lo.w, up.x, up.y, up.z, up.w};
+                bf16x8 v1, v2, v3;
+                split_bf16x8(x, v1, v2, v3);
+                bf16x8 u[2][3];
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) u[nb][t] = bits_bf16x8(wr[(6 * pl + 3 * nb + t) % RING]);
+#if W_PIPE
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                // smallest products first: u1 v3, u3 v1, u2 v2, u1 v2, u2 v1, u1 v1; the two cout blocks alternate
+                constexpr int TU[6] = {0, 2, 1, 0, 1, 0}, TV[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const bf16x8 vv = TV[k] == 0 ? v1 : TV[k] == 1 ? v2 : v3;
+                    const bool fresh = FIRST && k == 0;
+                    acc[pl][0] = mfma_bf16_32x32x16(u[0][TU[k]], vv, fresh ? zero16 : acc[pl][0]);
+                    acc[pl][1] = mfma_bf16_32x32x16(u[1][TU[k]], vv, fresh ? zero16 : acc[pl][1]);
+#if W_PIPE
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+                }
+#pragma unroll
+                for (int e = 0; e < 6; ++e) {
+                    const int nxt = 6 * pl + e + AHEAD;
+                    if (nxt < PIECES) w_request(nxt % RING, s, nxt);
+                    else w_request(nxt % RING, s + 1, nxt - PIECES);
+                }
+                if (s + 1 < stages && pl == PP / 2 - 1) {
+                    if (W_EXP != 3) transform();
+                    if (W_EXP != 3) store_v(buf ^ 1);
+                    if (s + 2 < stages && W_EXP != 2) request(s + 2);
+                }
+            }
+            __syncthreads();
+            return;
+        }
         // (the block operand of point pl + 1 is read from LDS while the MFMAs of point pl run; with W_PIPE the MFMA order is pinned
         // as written - two accumulator blocks alternating - instead of the four-long dependent chains the scheduler prefers)
         float4 a_nxt = *reinterpret_cast<const float4*>(vb + v_rd[0]);
@@ -701,6 +818,18 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_conv_winograd(Conv
 
 }  // namespace
 
+#if FIERY_WINOGRAD_SPLIT
+// floats' worth of the split image: three bf16 terms per transformed weight (6 bytes where the fp32 image has 4)
+size_t conv_winograd_split_packed_floats(int cout, int cin_units) {
+    return static_cast<size_t>(wino_packed_floats((cout + 63) / 64 * 64, cin_units * 8)) * 3 / 2;
+}
+int conv_winograd_split_pack(const float* w, int cout, int cin_total, const ChanInverse& inv, int cin_units, float* packed, hipStream_t stream) {
+    const long long total = wino_packed_floats((cout + 63) / 64 * 64, cin_units * 8) * 3;      // bf16 elements
+    hipLaunchKernelGGL(k_pack_winograd_split, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, stream, w, cout, cin_total, inv,
+                       cin_units, total, reinterpret_cast<unsigned short*>(packed));
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+#else
 size_t conv_winograd_packed_floats(int cout, int cin_units) {
     return static_cast<size_t>(wino_packed_floats((cout + 63) / 64 * 64, cin_units * 8));
 }
@@ -712,8 +841,14 @@ int conv_winograd_pack(const float* w, int cout, int cin_total, const ChanInvers
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+#endif
+
 // p.w = the Winograd-packed weights; p.M etc. as for the direct form
+#if FIERY_WINOGRAD_SPLIT
+bool conv_launch_winograd_split(const ConvP& p, hipStream_t stream) {
+#else
 bool conv_launch_winograd(const ConvP& p, hipStream_t stream) {
+#endif
     const int TH = (p.Hout + 1) / 2, TW = (p.Wout + 1) / 2;
     const long long tiles = static_cast<long long>(p.n_img) * TH * TW;
     const dim3 grid(static_cast<unsigned>((tiles + WT - 1) / WT), static_cast<unsigned>(p.cout_pad / WBN));
@@ -728,11 +863,15 @@ bool conv_launch_winograd(const ConvP& p, hipStream_t stream) {
     int waves = W_DEFAULT_WAVES;                            // (read per launch: tests and A/B runs switch it)
     if (const char* e = getenv("FIERY_WINOGRAD_WAVES")) waves = atoi(e) == 8 ? 8 : atoi(e) == 4 ? 4 : waves;
     if (kind < 0) waves = 4;                                // (the general fallback does not fit 128 registers)
+#if FIERY_WINOGRAD_SPLIT
+#define FIERY_WINO_LAUNCH(K_) hipLaunchKernelGGL((k_conv_winograd<K_, 4>), grid, dim3(256), 0, stream, p)
+#else
 #define FIERY_WINO_LAUNCH(K_)                                                                                  \
     do {                                                                                                       \
         if (waves == 8) hipLaunchKernelGGL((k_conv_winograd<K_, 8>), grid, dim3(512), 0, stream, p);            \
         else hipLaunchKernelGGL((k_conv_winograd<K_, 4>), grid, dim3(256), 0, stream, p);                       \
     } while (0)
+#endif
     switch (kind) {
         case 0: FIERY_WINO_LAUNCH(0); break;
         case 1: FIERY_WINO_LAUNCH(1); break;

@@ -88,7 +88,28 @@ __device__ __forceinline__ uint2 pack_bf16x4(float4 v) {
 }
 // D(32 x 32) += A(32 x 16) . B(16 x 32): lane l holds A[l & 31][8 (l >> 5) + j], B[8 (l >> 5) + j][l & 31], j < 8
 __device__ __forceinline__ fiery_v16f mfma_bf16_32x32x16(bf16x8 a, bf16x8 b, fiery_v16f c) {
+#ifdef FIERY_BF16_REPEAT                   // timing experiment (wrong results): every bf16 MFMA issued this many times
+#pragma unroll
+    for (int i = 1; i < FIERY_BF16_REPEAT; ++i) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// the nearest bf16 value (round to nearest even) as a float
+__device__ __forceinline__ float bf16_round(float v) { return static_cast<float>(static_cast<__bf16>(v)); }
+// Eight fp32 values as three bf16 terms each: x = t1 + t2 + t3 exactly (3 x 8 significand bits; the remainders x - t1 and
+// (x - t1) - t2 are exact in fp32).  With the partial products of weight >= 2^-24 a product of two such values on the bf16
+// matrix cores is as accurate as the fp32 matrix instruction's (conv_winograd.hip, split form).
+__device__ __forceinline__ void split_bf16x8(const float (&x)[8], bf16x8& t1, bf16x8& t2, bf16x8& t3) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 a = static_cast<__bf16>(x[j]);
+        const float r1 = x[j] - static_cast<float>(a);
+        const __bf16 b = static_cast<__bf16>(r1);
+        const float r2 = r1 - static_cast<float>(b);
+        t1[j] = a;
+        t2[j] = b;
+        t3[j] = static_cast<__bf16>(r2);
+    }
 }
 // one fp32 -> bf16 bits (round to nearest even), for the weight packer
 __device__ __forceinline__ unsigned short bf16_bits(float v) {

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libfiery_hip.so')
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -23,7 +23,8 @@ c_uint8_p = C.POINTER(C.c_uint8)
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SWISH = 0, 1, 2, 3
 PRECISION_F32, PRECISION_BF16 = 0, 1
 EPI_PLAIN, EPI_GRU_GATES, EPI_GRU_OUT, EPI_HEADS = 0, 1, 2, 3
-CONV_FORM_TILE, CONV_FORM_STREAM_K, CONV_FORM_WINOGRAD = 0, 1, 2
+CONV_FORM_TILE, CONV_FORM_STREAM_K, CONV_FORM_WINOGRAD, CONV_FORM_WINOGRAD_SPLIT = 0, 1, 2, 3
+WINOGRAD_SPLIT_TERMS = 3                    # fiery_conv_desc.winograd: the split image is in weights_winograd
 POOL_DETERMINISTIC = 1
 POOL_WORKSPACE_CLEAN = 2        # the workspace is a zero-filled allocation or was left by a successful pooling call
 POOL_NO_RANKS = 4               # inference: the call leaves no voxel ranks in its workspace (nobody runs backward)
@@ -133,6 +134,8 @@ _SIGNATURES = {
     'fiery_conv_form_used': (C.c_int, [C.POINTER(ConvDesc)]),
     'fiery_conv_winograd_packed_floats': (C.c_size_t, [C.c_int, C.c_int]),
     'fiery_conv_pack_weights_winograd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_void_p]),
+    'fiery_conv_winograd_split_packed_floats': (C.c_size_t, [C.c_int, C.c_int]),
+    'fiery_conv_pack_weights_winograd_split': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_void_p]),
     'fiery_conv_stream_k_plan': (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     'fiery_conv_wgrad': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int64] + [C.c_int] * 11 +
                          [C.c_void_p, C.c_void_p]),
@@ -475,6 +478,14 @@ class Lib:
         packed = torch.empty(n, dtype=torch.float32, device=w.device)
         cmap = (C.c_int32 * cin_total)(*chan_map)
         self.check(self.dll.fiery_conv_pack_weights_winograd(_ptr(w), cout, cin_total, cmap, cin_units, _ptr(packed), _stream_of(packed)))
+        return packed
+
+    def conv_pack_weights_winograd_split(self, w, cout, cin_total, chan_map, cin_units):
+        """w (cout, cin_total, 9) f32 -> the split Winograd image: every transformed weight as three bf16 terms."""
+        n = self.dll.fiery_conv_winograd_split_packed_floats(cout, cin_units)
+        packed = torch.empty(n, dtype=torch.float32, device=w.device)
+        cmap = (C.c_int32 * cin_total)(*chan_map)
+        self.check(self.dll.fiery_conv_pack_weights_winograd_split(_ptr(w), cout, cin_total, cmap, cin_units, _ptr(packed), _stream_of(packed)))
         return packed
 
     def conv_precision_used(self, desc):

@@ -152,7 +152,7 @@ class ConvOp:
         self.cout_pad = round_up(self.cout, 32)
         # Winograd F(2x2, 3x3) image of the weights for the layers that form covers (3 x 3 / stride 1 / 'same', whole 16-channel
         # stages per source, 64-cout tiles; fp32 only): a candidate form of `_pick_tile`
-        self.packed_winograd = None
+        self.packed_winograd = self.packed_winograd_split = None
         if (WINOGRAD and self.precision == native.PRECISION_F32 and (self.kT, self.kH, self.kW) == (1, 3, 3) and stride == 1 and
                 (self.padH, self.padW) == (1, 1) and self.cout_pad % 64 == 0 and all(u % 2 == 0 for u in self.units) and
                 # (what the library's scalar-addressed loop - the only one with a Winograd form - asks of the channel layout:
@@ -160,6 +160,10 @@ class ConvOp:
                 cin_units % 4 == 0 and self.units[0] % 4 == 0 and cin_units >= 4):
             self.packed_winograd = lib.conv_pack_weights_winograd(w.view(self.cout, self.cin_total, taps), self.cout, self.cin_total,
                                                                   list(chan_map), cin_units)
+            # the same form on the bf16 matrix cores, every operand as three bf16 terms (fp32 accuracy; 'wsplit')
+            if WINOGRAD_SPLIT:
+                self.packed_winograd_split = lib.conv_pack_weights_winograd_split(
+                    w.view(self.cout, self.cin_total, taps), self.cout, self.cin_total, list(chan_map), cin_units)
         if torch.is_tensor(scale) and scale.device == w.device and scale.numel() == self.cout_pad:
             self.scale, self.shift = scale, shift          # already padded, already resident
         else:
@@ -230,9 +234,10 @@ class ConvOp:
         return ((H + 2 * self.padH - self.kH) // self.stride + 1, (W + 2 * self.padW - self.kW) // self.stride + 1)
 
     def _set_form(self, d, form, sk=None):
-        d.winograd = int(form == 'wino')
-        d.weights_winograd = self.packed_winograd.data_ptr() if form == 'wino' else None
-        if form == 'wino':
+        d.winograd = 1 if form == 'wino' else native.WINOGRAD_SPLIT_TERMS if form == 'wsplit' else 0
+        d.weights_winograd = (self.packed_winograd.data_ptr() if form == 'wino' else
+                              self.packed_winograd_split.data_ptr() if form == 'wsplit' else None)
+        if form in ('wino', 'wsplit'):
             form = 0
         d.tile_m, d.stream_k = (128, 1) if form == 'sk' else (form, 0)
         if form == 'sk':
@@ -284,11 +289,13 @@ class ConvOp:
         key = (out.n_img, out.H, out.W)
         choice = self.force_form                       # (a forced form - per op, or FIERY_CONV_FORM for all - goes before the table)
         if choice is None and FORCE_FORM:
-            choice = FORCE_FORM if FORCE_FORM in ('sk', 'wino') else int(FORCE_FORM)
+            choice = FORCE_FORM if FORCE_FORM in ('sk', 'wino', 'wsplit') else int(FORCE_FORM)
         if choice is None:
             choice = FORM_TABLE.get((self._sig, key))
         if choice == 'wino' and self.packed_winograd is None:
             choice = 0
+        if choice == 'wsplit' and self.packed_winograd_split is None:
+            choice = 'wino' if self.packed_winograd is not None else 0
         sk = _stream_k_workspace(self.lib, d, out.tensor) if (choice == 'sk' or choice is None) and self.heads is None else None
         if choice is None:
             if FORM_TABLE_FROZEN or not _autotune_enabled(out.tensor):
@@ -296,6 +303,8 @@ class ConvOp:
             forms = [64, 128] + (['sk'] if sk is not None else []) + (['wino'] if self._winograd_taken(d) else [])
             if self.heads is not None:
                 forms = [0, 'wino'] if 'wino' in forms else [0]     # heads epilogue: the direct form's one tile shape, or Winograd
+            if 'wino' in forms and self.packed_winograd_split is not None:
+                forms.append('wsplit')
             times = {f: float('inf') for f in forms}
             for _trial in range(2):                    # alternate the candidates, keep each one's best trial
                 for form in forms:
@@ -385,7 +394,8 @@ class ConvOp:
             used = 'bf16' if self.lib.conv_precision_used(d) == native.PRECISION_BF16 else 'f32'
         if PROFILE_SINK is not None and (d.winograd or d.stream_k):
             form = self.lib.conv_form_used(d)          # (what ran, not what was asked for: the flops accounting hangs on it)
-            used = {native.CONV_FORM_WINOGRAD: 'f32 winograd', native.CONV_FORM_STREAM_K: 'f32 stream-K'}.get(form, used)
+            used = {native.CONV_FORM_WINOGRAD: 'f32 winograd', native.CONV_FORM_WINOGRAD_SPLIT: 'f32 winograd split',
+                    native.CONV_FORM_STREAM_K: 'f32 stream-K'}.get(form, used)
         profiled('conv_igemm', flops, out.tensor, lambda: self.lib.conv_fwd(d, out.tensor),
                  detail=(self.kT, self.kH, self.kW, self.stride, self.cin_total, self.cout, out.n_img, out.H, out.W, used))
 
@@ -400,6 +410,7 @@ SK_COUNTERS = 1 << 17
 STREAM_K = os.environ.get('FIERY_STREAM_K', '1') != '0'
 FORCE_FORM = os.environ.get('FIERY_CONV_FORM')      # A/B runs: '64', '128', 'sk' or 'wino' for every launch that has the form, no timing
 WINOGRAD = os.environ.get('FIERY_CONV_WINOGRAD', '1') != '0'
+WINOGRAD_SPLIT = os.environ.get('FIERY_CONV_WINOGRAD_SPLIT', '1') != '0'      # the split form (bf16 matrix cores, three-term operands) as a candidate
 
 
 # Measured forms, one table per process: (layer signature, (n_img, H, W) of the output) -> 64 / 128 / 'sk' / 'wino'.  The forms

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FIERY_ABI_VERSION 23      /* 23 (round 6): fiery_conv_form_used, FIERY_POOL_NO_RANKS, the prepass quantises without divisions where that is exact; 22 (round 5): fiery_conv_desc grew (weights_winograd, winograd, stream_k, sk_*); fiery_conv_pack_weights_winograd, fiery_conv_winograd_packed_floats, fiery_conv_stream_k_plan */
+#define FIERY_ABI_VERSION 24      /* 24 (round 6): the split Winograd form (fiery_conv_pack_weights_winograd_split, FIERY_CONV_FORM_WINOGRAD_SPLIT); 23 (round 6): fiery_conv_form_used, FIERY_POOL_NO_RANKS, the prepass quantises without divisions where that is exact; 22 (round 5): fiery_conv_desc grew (weights_winograd, winograd, stream_k, sk_*); fiery_conv_pack_weights_winograd, fiery_conv_winograd_packed_floats, fiery_conv_stream_k_plan */
 
 #define FIERY_OK 0
 #define FIERY_EINVAL (-22)      /* bad argument (shape, alignment, null pointer) */
@@ -347,7 +347,11 @@ typedef struct {
      * that computes every 2 x 2 output block from a 4 x 4 input block with 16 multiplies per (cin, cout) instead of 36; taken
      * by fp32 launches of 3 x 3 / stride 1 / 'same' layers (kT = 1) with whole 16-channel stages per source, cout_pad % 64 == 0,
      * 16-byte addressable tensors, the plain, GRU or heads epilogues, no chained 1x1 - others ignore the request.  Results differ
-     * from the direct form by fp32 rounding (another order of additions; measured 8e-6 on the hot path's outputs). */
+     * from the direct form by fp32 rounding (another order of additions; measured 8e-6 on the hot path's outputs).
+     * winograd == FIERY_WINOGRAD_SPLIT_TERMS (round 6) with the image of fiery_conv_pack_weights_winograd_split asks for the
+     * same form on the bf16 matrix cores with every fp32 operand as three bf16 terms and six partial products per product -
+     * fp32 accuracy (rms error against fp64 not above the fp32 matrix instruction's, tools/probe/split_bf16_probe.hip); same
+     * conditions. */
     const float* weights_winograd;
     int32_t winograd;
     int32_t stream_k;
@@ -379,6 +383,13 @@ int fiery_conv_pack_weights_bf16(const float* w, int cout, int cin_total, int ta
 size_t fiery_conv_winograd_packed_floats(int cout, int cin_units);
 int fiery_conv_pack_weights_winograd(const float* w, int cout, int cin_total, const int32_t* chan_map /* host */, int cin_units,
                                      float* packed, fiery_stream_t stream);
+/* The split image (fiery_conv_desc.winograd == FIERY_WINOGRAD_SPLIT_TERMS): U as above, each value as three bf16 terms that add
+ * up to it exactly, packed as the kernel's 16-byte operands [cout / 64][16 points][cin_pad / 16][2 cout blocks][3 terms][64 lanes][8];
+ * fiery_conv_winograd_split_packed_floats(...) floats' worth of bytes (1.5x the fp32 image). */
+#define FIERY_WINOGRAD_SPLIT_TERMS 3
+size_t fiery_conv_winograd_split_packed_floats(int cout, int cin_units);
+int fiery_conv_pack_weights_winograd_split(const float* w, int cout, int cin_total, const int32_t* chan_map /* host */, int cin_units,
+                                           float* packed, fiery_stream_t stream);
 
 int fiery_conv_fwd(const fiery_conv_desc* desc /* host */, fiery_stream_t stream);
 
@@ -411,6 +422,7 @@ int fiery_conv_precision_used(const fiery_conv_desc* desc /* host */);
 #define FIERY_CONV_FORM_TILE 0
 #define FIERY_CONV_FORM_STREAM_K 1
 #define FIERY_CONV_FORM_WINOGRAD 2
+#define FIERY_CONV_FORM_WINOGRAD_SPLIT 3
 int fiery_conv_form_used(const fiery_conv_desc* desc /* host */);
 
 /* What the stream-K form of this descriptor needs (the descriptor's own stream_k / sk_* members are not looked at):

@@ -40,6 +40,15 @@ inline float bf16_value(unsigned short b) {
     __builtin_memcpy(&f, &u, 4);
     return f;
 }
+inline float bf16_round(float v) { return bf16_value(bf16_bits(v)); }
+inline void split_bf16x8(const float (&x)[8], bf16x8& t1, bf16x8& t2, bf16x8& t3) {
+    for (int j = 0; j < 8; ++j) {
+        const float a = bf16_round(x[j]), r1 = x[j] - a, b = bf16_round(r1), r2 = r1 - b;
+        t1.v[j] = bf16_bits(a);
+        t2.v[j] = bf16_bits(b);
+        t3.v[j] = bf16_bits(r2);
+    }
+}
 inline bf16x8 pack_bf16x8(float4 lo, float4 hi) {
     return {{bf16_bits(lo.x), bf16_bits(lo.y), bf16_bits(lo.z), bf16_bits(lo.w), bf16_bits(hi.x), bf16_bits(hi.y), bf16_bits(hi.z),
              bf16_bits(hi.w)}};

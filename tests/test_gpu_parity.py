@@ -446,7 +446,7 @@ def test_conv_igemm_real_shapes(hip, cin, cout, k, stride):
     assert (out.to_nchw().cpu() - want).abs().max() < 2e-5
 
 
-@pytest.mark.parametrize('form', ['sk', 'wino'])
+@pytest.mark.parametrize('form', ['sk', 'wino', 'wsplit'])
 @pytest.mark.parametrize('case', ['128->128 relu', '64->128 relu + residual', 'gates 64+64 -> 2 x 64', 'GRU out 64+64 -> 64',
                                   '64->64 border-class bias', '256->256 25x25 (odd size)'])
 def test_conv_forms_stream_k_and_winograd_real_shapes(hip, form, case):
@@ -455,7 +455,9 @@ def test_conv_forms_stream_k_and_winograd_real_shapes(hip, form, case):
       * 'sk'   stream-K (`fiery_conv_desc.stream_k`): partial tiles handed between workgroups on different XCDs through the
                workspace - the thing the CPU simulator cannot see; the repeat runs over stale partials;
       * 'wino' Winograd F(2x2, 3x3) (`fiery_conv_desc.winograd`, csrc/conv_winograd.hip): every epilogue kind it is instantiated
-               for (plain with / without residual, GRU gates, GRU output, border-class bias), odd image sizes.
+               for (plain with / without residual, GRU gates, GRU output, border-class bias), odd image sizes;
+      * 'wsplit' (round 6, csrc/conv_winograd_split.hip) the same form on the bf16 matrix cores, every fp32 operand as three
+               bf16 terms and six partial products - an fp32-accurate form, held to Winograd's bound.
     Bounds: 2e-5 against torch for the direct sums (stream-K), 4e-5 for Winograd (the transforms reorder the sums)."""
     import torch.nn.functional as F
     g = torch.Generator().manual_seed(len(case) * 7 + len(form))
@@ -530,7 +532,7 @@ def test_conv_forms_stream_k_and_winograd_real_shapes(hip, form, case):
             assert err <= bound * max(1.0, wnt.abs().max().item()), (case, form, rep, i, err)
 
 
-@pytest.mark.parametrize('form', [0, 'wino'])
+@pytest.mark.parametrize('form', [0, 'wino', 'wsplit'])
 @pytest.mark.parametrize('n,H,W', [(15, 200, 200), (2, 51, 37)])
 def test_conv_heads_epilogue_real_shapes(hip, form, n, H, W):
     """The decoder-heads epilogue (FIERY_EPI_HEADS; reference fiery/models/decoder.py:36-51,82-91: four heads of
@@ -552,8 +554,8 @@ def test_conv_heads_epilogue_real_shapes(hip, form, n, H, W):
     op = ConvOp(hip, w1, identity_chan_map(cin), (cin // 8, 0), sc, sh, DEV, act=native.ACT_RELU, tune=True)
     groups = [i for i, o in enumerate(n_outs) for _ in range(o)]
     op.attach_heads(torch.cat(w2), torch.cat(b2), groups, [sig[i] for i in groups])
-    if form == 'wino':
-        assert op.packed_winograd is not None
+    if form in ('wino', 'wsplit'):
+        assert op.packed_winograd is not None and op.packed_winograd_split is not None
     op.force_form = form
     hidden = F.relu(F.conv2d(x, w1, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
     wants = []

@@ -635,7 +635,7 @@ def test_stream_k_form_equals_the_tile_form(sim, monkeypatch, case, wgs):
     assert torch.equal(out2.to_nchw(), outs['sk'])
 
 
-@pytest.mark.parametrize('epilogue', ['per kind', 'general', 'per kind, 8 wavefronts'])
+@pytest.mark.parametrize('epilogue', ['per kind', 'general', 'per kind, 8 wavefronts', 'per kind, split form', 'general, split form'])
 @pytest.mark.parametrize('case', ['64->128 relu + residual, odd size', 'two sources -> gates', 'two sources -> GRU out', '32->64 border-class bias',
                                   '16->256 sequence views', '48->64 cout 40 stored'])
 def test_winograd_form_equals_torch(sim, monkeypatch, case, epilogue):
@@ -644,23 +644,26 @@ def test_winograd_form_equals_torch(sim, monkeypatch, case, epilogue):
     form covers, the border-class bias, several cout tiles, strided image views.  Tolerance: the transforms reorder the sums
     (fp32), so 2e-5 relative instead of the direct form's 1e-5.  epilogue = 'per kind': the kernels instantiated per epilogue
     kind (dense tensors: packed arithmetic, one buffer offset per tensor); 'general': the one kernel with everything behind
-    run-time switches and per-pixel addressing that serves what those do not (here forced for every case)."""
-    if epilogue == 'general':
+    run-time switches and per-pixel addressing that serves what those do not (here forced for every case); 'split form'
+    (round 6, csrc/conv_winograd_split.hip): the K loop on the bf16 matrix cores with every operand as three bf16 terms - the
+    same tolerance, it is an fp32-accurate form."""
+    wform = 'wsplit' if 'split' in epilogue else 'wino'
+    if 'general' in epilogue:
         monkeypatch.setenv('FIERY_WINOGRAD_GENERAL_EPILOGUE', '1')
     monkeypatch.setenv('FIERY_WINOGRAD_WAVES', '8' if '8 wavefronts' in epilogue else '4')
     g = torch.Generator().manual_seed(len(case))
     WTOL = dict(rtol=2e-5, atol=2e-5)
 
     def check(op, run, want, shape, cout):
-        assert op.packed_winograd is not None
+        assert op.packed_winograd is not None and op.packed_winograd_split is not None
         outs = {}
-        for form in (128, 'wino'):
+        for form in (128, wform):
             op.force_form = form
             out = Buf.alloc(*shape, 'cpu')
             run(op, out)
             outs[form] = out.to_nchw()[:, :cout]
         assert torch.allclose(outs[128], want, **TOL)
-        assert torch.allclose(outs['wino'], want, **WTOL), (outs['wino'] - want).abs().max()
+        assert torch.allclose(outs[wform], want, **WTOL), (outs[wform] - want).abs().max()
         return outs
 
     if case == '64->128 relu + residual, odd size':
@@ -683,7 +686,7 @@ def test_winograd_form_equals_torch(sim, monkeypatch, case, epilogue):
                     epi=native.EPI_GRU_GATES, tune=True)
         xb, hb = _to_buf(x), _to_buf(h)
         pre = F.conv2d(torch.cat([x, h], 1), wg, padding=1) + bg.view(1, -1, 1, 1)
-        op.force_form = 'wino'
+        op.force_form = wform
         U, RH = Buf.alloc(2, 10, 12, ch, 'cpu'), Buf.alloc(2, 10, 12, ch, 'cpu')
         op([xb, hb], U, out2=RH, aux0=hb)
         assert torch.allclose(U.to_nchw(), torch.sigmoid(pre[:, :ch]), **WTOL)
@@ -727,7 +730,7 @@ def test_winograd_form_equals_torch(sim, monkeypatch, case, epilogue):
         w = torch.randn(256, 16, 3, 3, generator=g) * 0.1
         op = ConvOp(sim, w, identity_chan_map(16), (2, 0), torch.ones(256), torch.zeros(256), 'cpu', tune=True)
         dst = Buf.alloc(B * T, H, W, 256, 'cpu')
-        op.force_form = 'wino'
+        op.force_form = wform
         op([sbuf.images(1, B, step=T)], dst.images(1, B, step=T))
         x_t = seq.view(B, T, H, W, 16)[:, 1].permute(0, 3, 1, 2)
         got = dst.nhwc().view(B, T, H, W, 256)[:, 1].permute(0, 3, 1, 2)
@@ -739,7 +742,7 @@ def test_winograd_form_equals_torch(sim, monkeypatch, case, epilogue):
         op = ConvOp(sim, w, identity_chan_map(48), (6, 0), torch.ones(40), torch.zeros(40), 'cpu', tune=True)
         out = Buf.alloc(2, 7, 9, 64, 'cpu')
         out.tensor.fill_(7.0)
-        op.force_form = 'wino'
+        op.force_form = wform
         op([_to_buf(x)], out)
         assert torch.allclose(out.to_nchw()[:, :40], F.conv2d(x, w, padding=1), **WTOL)
         assert (out.to_nchw()[:, 40:] == 7.0).all(), 'padding couts are never stored'
