@@ -396,13 +396,27 @@ def main():
         # The SPLIT Winograd form (round 6) runs those 16 / 36 on the bf16 matrix cores with every fp32 operand as three bf16 terms:
         # six bf16 MFMAs per product block - its executed flops are 6 x 16 / 36 of the direct count, priced against the bf16 peak.
         WINO = 16.0 / 36.0
-        executed_of = lambda w, d: w * WINO * (6.0 if 'split' in str(d[-1]) else 1.0) if 'winograd' in str(d[-1]) else w
+        # The split TILE form ('f32 split'): six bf16 MFMAs per fp32 product of the convolution itself; a chained tail's 1x1
+        # products stay on the fp32 instruction ('f32 split + fp32 chain': the two parts are priced against their own peaks).
         peak_of = lambda form: PEAK_BF16_MFMA_TFLOPS if ('bf16' in str(form) or 'split' in str(form)) else PEAK_F32_MFMA_TFLOPS
+
+        def executed_parts(w, d):                                         # [(executed matrix flops, peak of their instruction)]
+            form = str(d[-1])
+            if 'winograd' in form:
+                return [(w * WINO * (6.0 if 'split' in form else 1.0), peak_of(form))]
+            if form.startswith('f32 split'):
+                main = min(w, 2.0 * d[6] * d[7] * d[8] * d[4] * d[0] * d[1] * d[2] * d[5])      # images x H x W x cin x taps x cout
+                return [(6.0 * main, PEAK_BF16_MFMA_TFLOPS), (w - main, PEAK_F32_MFMA_TFLOPS)]
+            return [(w, peak_of(form))]
+        executed_of = lambda w, d: sum(x_ for x_, _ in executed_parts(w, d))
+        pipe_s_of = lambda w, d: sum(x_ / (pk_ * 1e12) for x_, pk_ in executed_parts(w, d))          # seconds at the matrix peak
+        pipe_by_form = {}
         by_form = {}
         for k, s_, e_, w, d in recs:
             if k == 'conv_igemm':
                 t_, f_, x_, n_ = by_form.get(d[-1], (0.0, 0.0, 0.0, 0))
                 by_form[d[-1]] = (t_ + s_.elapsed_time(e_) * 1e-3, f_ + w, x_ + executed_of(w, d), n_ + 1)
+                pipe_by_form[d[-1]] = pipe_by_form.get(d[-1], 0.0) + pipe_s_of(w, d)
         by_prec = {}                                                   # 'f32' (all fp32 forms) / 'bf16': time, executed flops, launches
         for form, (t_, f_, x_, n_) in by_form.items():
             key = 'bf16' if form == 'bf16' else 'f32'
@@ -426,10 +440,9 @@ def main():
             if k != 'conv_igemm':
                 continue
             kT, kH, kW, stride, cin, cout, n_img, Ho, Wo, form = d
-            peak_l = peak_of(form) * 1e12
             px_out = n_img * Ho * Wo
             nbytes = 4.0 * (px_out * stride * stride * cin + px_out * cout + cin * cout * kT * kH * kW)
-            t_m, t_h = executed_of(w, d) / peak_l, nbytes / (PEAK_HBM_GBS * 1e9)
+            t_m, t_h = pipe_s_of(w, d), nbytes / (PEAK_HBM_GBS * 1e9)
             ideal_s += max(t_m, t_h)
             mfma_bound_s += t_m
             hbm_bound_s += t_h
@@ -442,16 +455,18 @@ def main():
                              'divided by the measured convolution time of the step (one stream, HIP events)'}
         x_conv = sum(x_ for _, _, x_, _ in by_form.values())             # executed matrix flops of the step's convolutions
         # (fp32-instruction equivalents: a split launch's six bf16 MFMAs stand for one fp32 product block)
-        x_conv_f32eq = sum(x_ / (6.0 if 'split' in str(k_) else 1.0) for k_, (_, _, x_, _) in by_form.items())
+        x_conv_f32eq = sum(f_ * (WINO if 'winograd' in str(k_) else 1.0) for k_, (_, f_, _, _) in by_form.items())
         # the dominant kernel = the form that holds most of the time; its flops against ITS peak
         dom = max(by_prec, key=lambda k_: by_prec[k_][0])
         t_dom, f_dom, n_dom = by_prec[dom]
         # all launches of that precision together: the time-weighted busy fraction of the matrix pipe each form runs on
-        pipe_s = sum(x_ / (peak_of(k_) * 1e12) for k_, (_, _, x_, _) in by_form.items() if (k_ == 'bf16') == (dom == 'bf16'))
+        pipe_s = sum(v_ for k_, v_ in pipe_by_form.items() if (k_ == 'bf16') == (dom == 'bf16'))
         # ... and inside that precision the FORM that holds most of the time is the kernel the line names (round 5: the Winograd
         # kernel took over from the direct implicit GEMM): its own launches, executed flops and time
         KERNEL_OF = {'f32': 'k_conv_igemm (fp32 MFMA implicit GEMM, direct tile forms)', 'f32 stream-K': 'k_conv_igemm<SK> (fp32 MFMA implicit GEMM, stream-K)',
                      'f32 winograd': 'k_conv_winograd (Winograd F(2x2,3x3) on the fp32 matrix cores)',
+                     'f32 split': 'k_conv_igemm<SPLIT> (implicit GEMM, fp32 operands as three bf16 terms, six products each on the bf16 matrix cores)',
+                     'f32 split + fp32 chain': 'k_conv_igemm<SPLIT, CHAIN> (Bottleneck tails: 3x3 as three-term bf16 products, chained 1x1s on the fp32 instruction)',
                      'f32 winograd split': 'k_conv_winograd, split form (Winograd F(2x2,3x3), fp32 operands as three bf16 terms, six products each on the '
                                            'bf16 matrix cores, fp32 accumulation: fp32 accuracy)',
                      'bf16': 'k_conv_igemm (bf16 operands, fp32 accumulate, MFMA implicit GEMM)'}
@@ -459,8 +474,8 @@ def main():
         t_df, f_df, x_df, n_df = by_form[dom_form]
         peak = peak_of(dom_form)
         roofline = {'kernel': KERNEL_OF.get(str(dom_form), str(dom_form)),
-                    'bound': 'mfma', 'achieved': round(x_df / t_df / 1e12, 2),
-                    'peak': peak, 'unit': 'TFLOP/s', 'frac': round(x_df / t_df / 1e12 / peak, 4),
+                    'bound': 'mfma', 'achieved': round(pipe_by_form[dom_form] / t_df * peak, 2),
+                    'peak': peak, 'unit': 'TFLOP/s', 'frac': round(pipe_by_form[dom_form] / t_df, 4),
                     'launches': n_df, 'avg_launch_us': round(t_df / n_df * 1e6, 2),
                     'share_of_conv_time': round(t_df / t_conv, 4),
                     'flops': 'EXECUTED matrix flops (a Winograd launch executes 16/36 of the direct form\'s 2*|out|*Cin*9; its split form six bf16 '
@@ -474,7 +489,7 @@ def main():
                     # the forms the launches ran in: direct tiles ('f32'), stream-K, Winograd F(2x2, 3x3); executed = matrix flops
                     # the MFMAs really did, algorithmic = the direct form's flops for the same layers (SURVEY 8d's count)
                     'by_form': {str(k_): {'launches': n_, 'ms_per_step': round(t_ * 1e3, 3), 'executed_tflops': round(x_ / t_ / 1e12, 2),
-                                          'executed_frac_of_peak': round(x_ / t_ / 1e12 / peak_of(k_), 4), 'peak': peak_of(k_),
+                                          'executed_frac_of_peak': round(pipe_by_form[k_] / t_, 4), 'peak': peak_of(k_),
                                           'algorithmic_gflop': round(f_ / 1e9, 1), 'executed_gflop': round(x_ / 1e9, 1)}
                                 for k_, (t_, f_, x_, n_) in by_form.items()},
                     'executed_gflop_per_step': round(x_conv / 1e9, 1),
@@ -581,6 +596,8 @@ def main():
                 if k_ == 'conv_igemm':
                     key = f'fiery_conv_fwd [{d_[-1]}]'
                     x_ = w_ * (16.0 / 36.0) * (6.0 if 'split' in str(d_[-1]) else 1.0) if 'winograd' in str(d_[-1]) else w_
+                    if str(d_[-1]).startswith('f32 split'):
+                        x_ = 6.0 * w_                                # (chained 1x1 parts included: an upper bound for the tails)
                     t_, f_, n_ = conv_forms.get(key, (0.0, 0.0, 0))
                     conv_forms[key] = (t_ + s_.elapsed_time(e_), f_ + x_, n_ + 1)
                 elif k_ == 'voxel_pool':

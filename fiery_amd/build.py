@@ -26,6 +26,7 @@ SOURCES = [
     ('conv_tile_bf16_b.hip', []),
     ('conv_tile_halo_f32.hip', []),
     ('conv_tile_stream_k.hip', []),
+    ('conv_tile_split.hip', []),
     ('conv_winograd.hip', []),
     ('conv_winograd_split.hip', []),
     ('aux_ops.hip', []),

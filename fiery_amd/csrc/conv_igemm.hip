@@ -57,6 +57,34 @@ __global__ void k_pack_weights_bf16(const float* __restrict__ w, int cout, int c
     packed[i] = bf16_bits(v);
 }
 
+// split image of the weights (three bf16 terms per value, x = t1 + t2 + t3 exactly): inside a (chunk, cout tile) block
+// [term][k / 8][cout][k % 8]
+__global__ void k_pack_weights_split(const float* __restrict__ w, int cout, int cin_total, int taps, ChanInverse inv,
+                                     int cin_units, int bn, int k_chunks, long long total, unsigned short* __restrict__ packed) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int kj = static_cast<int>(i & 7);
+    const int nn = static_cast<int>((i >> 3) % bn);
+    long long r = (i >> 3) / bn;
+    const int kk = static_cast<int>(r % (BK / 8)) * 8 + kj;
+    r /= BK / 8;
+    const int term = static_cast<int>(r % 3);
+    r /= 3;
+    const int chunk = static_cast<int>(r % k_chunks);
+    const int tile = static_cast<int>(r / k_chunks);
+    const int n = tile * bn + nn;
+    const int k = chunk * BK + kk;
+    const int u = k >> 3, ch = k & 7;
+    const int tap = u / cin_units, cc = u - tap * cin_units;
+    float v = 0.f;
+    if (n < cout && tap < taps) {
+        const int ci = inv.ci[cc * 8 + ch];
+        if (ci >= 0) v = w[(static_cast<long long>(n) * cin_total + ci) * taps + tap];
+    }
+    const float t1 = bf16_round(v), r1 = v - t1, t2 = bf16_round(r1), r2 = r1 - t2;
+    packed[i] = bf16_bits(term == 0 ? t1 : term == 1 ? t2 : r2);
+}
+
 struct Geometry {
     int cout_pad, bn, n_tiles, k_chunks, n_units;
 };
@@ -164,6 +192,26 @@ extern "C" int fiery_conv_pack_weights_bf16(const float* w, int cout, int cin_to
     hipLaunchKernelGGL(k_pack_weights_bf16, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w, cout, cin_total,
                        taps, inv, cin_units, g.bn, g.k_chunks, total, static_cast<unsigned short*>(packed));
     return check_launch("conv_pack_weights_bf16");
+}
+
+extern "C" int fiery_conv_pack_weights_split(const float* w, int cout, int cin_total, int taps, const int32_t* chan_map,
+                                             int cin_units, void* packed, fiery_stream_t stream) {
+    FIERY_REQUIRE(w && chan_map && packed, "conv_pack_weights_split: null pointer");
+    FIERY_REQUIRE(cout > 0 && cin_total > 0 && taps > 0 && cin_units > 0, "conv_pack_weights_split: bad shape");
+    FIERY_REQUIRE(cin_units <= kMaxPackUnits, "conv_pack_weights_split: at most %d input channels", kMaxPackUnits * 8);
+    ChanInverse inv;
+    for (int i = 0; i < kMaxPackUnits * 8; ++i) inv.ci[i] = -1;
+    for (int ci = 0; ci < cin_total; ++ci) {
+        const int pos = chan_map[ci];
+        FIERY_REQUIRE(pos >= 0 && pos < cin_units * 8, "conv_pack_weights_split: chan_map[%d] = %d out of range", ci, pos);
+        FIERY_REQUIRE(inv.ci[pos] < 0, "conv_pack_weights_split: chan_map maps two channels to position %d", pos);
+        inv.ci[pos] = static_cast<short>(ci);
+    }
+    const Geometry g = conv_geometry(cout, cin_units, taps);
+    const long long total = static_cast<long long>(g.n_tiles) * g.k_chunks * 3 * BK * g.bn;
+    hipLaunchKernelGGL(k_pack_weights_split, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w, cout, cin_total,
+                       taps, inv, cin_units, g.bn, g.k_chunks, total, static_cast<unsigned short*>(packed));
+    return check_launch("conv_pack_weights_split");
 }
 
 extern "C" size_t fiery_conv_winograd_packed_floats(int cout, int cin_units) {
@@ -498,9 +546,13 @@ int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, ConvRunMode mode, 
                           d->precision != FIERY_PRECISION_BF16 && aligned16(d->weights_winograd) &&
                           static_cast<long long>(d->n_img_out) * ((d->Hout + 1) / 2) * ((d->Wout + 1) / 2) < (1ll << 30);
     const bool bf16 = !stream_k && !winograd && conv_takes_bf16(d, aligned, bm, bn, cin_units);
+    // split form of the scalar-addressed loop (FIERY_PRECISION_F32_SPLIT with the image of fiery_conv_pack_weights_split in
+    // weights_bf16): 128-pixel tiles of 32 (the chained tails too) or 64 couts; everything else runs the fp32 kernels
+    const bool split_tile = !stream_k && !winograd && d->precision == FIERY_PRECISION_F32_SPLIT && d->weights_bf16 && aligned && cin_units >= 4 &&
+                            bm == 128 && (bn == 32 || bn == 64) && d->epi != FIERY_EPI_HEADS && !getenv("FIERY_CONV_CLKPROBE") && !getenv("FIERY_CONV_PRIO");
     const bool split = winograd && d->winograd == FIERY_WINOGRAD_SPLIT_TERMS;      // weights_winograd is the split image then
     if (mode == kRunForm) return winograd ? (split ? FIERY_CONV_FORM_WINOGRAD_SPLIT : FIERY_CONV_FORM_WINOGRAD) : (stream_k ? FIERY_CONV_FORM_STREAM_K : FIERY_CONV_FORM_TILE);
-    if (!launch) return bf16 ? FIERY_PRECISION_BF16 : FIERY_PRECISION_F32;
+    if (!launch) return bf16 ? FIERY_PRECISION_BF16 : split_tile ? FIERY_PRECISION_F32_SPLIT : FIERY_PRECISION_F32;
     if (winograd) {
         {
             auto magic = [](long long div, unsigned* m, int* sh) {       // (as conv_magic above: exact for 0 <= g < 2^31)
@@ -525,6 +577,12 @@ int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, ConvRunMode mode, 
         p.tiles_m = 0;
         if (!conv_launch_stream_k(p, bn, dim3(sk.n_workgroups), hs)) return fail(FIERY_EINVAL, "conv_fwd: no stream-K kernel for %d-wide cout tiles", bn);
         return check_launch("conv_fwd (stream-K)");
+    }
+    if (split_tile) {
+        FIERY_REQUIRE(aligned16(d->weights_bf16), "conv_fwd: split weights must be 16-byte aligned");
+        p.w = static_cast<const float*>(d->weights_bf16);
+        if (!conv_launch_split(p, bn, grid, hs)) return fail(FIERY_EINVAL, "conv_fwd: no split kernel for %d-wide cout tiles", bn);
+        return check_launch("conv_fwd (split)");
     }
     if (bf16) {
         FIERY_REQUIRE(aligned16(d->weights_bf16), "conv_fwd: bf16 weights must be 16-byte aligned");

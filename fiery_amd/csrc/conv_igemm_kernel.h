@@ -127,6 +127,8 @@ bool conv_launch_64x128(const ConvP& p, dim3 grid, hipStream_t stream, int varia
 // bf16 matrix-core form of the scalar-addressed kernel (weights packed by fiery_conv_pack_weights_bf16 in p.w); returns
 // false when (bm, bn) has no such kernel
 bool conv_launch_bf16(const ConvP& p, int bm, int bn, dim3 grid, hipStream_t stream, bool halo = false);
+// split form of the scalar-addressed kernel (conv_tile_split.hip): 128-pixel tiles, bn = 32 (the chained tails too) or 64
+bool conv_launch_split(const ConvP& p, int bn, dim3 grid, hipStream_t stream);
 // weight packers' argument: padded channel position -> logical input channel, -1 = padding (2 KB of kernel arguments)
 constexpr int kMaxPackUnits = 128;      // 8-channel input units per convolution: 1024 channels (the trunk's 960-wide projections)
 struct ChanInverse {
@@ -185,10 +187,11 @@ constexpr int halo_pitch(bool bf16) { return bf16 ? 20 : 36; }
 // (chained tails, round 5: each wavefront has an exchange tile of its own - 32 pixel rows of 64 couts, 68 floats apart - in
 // which accumulators in the lane-per-pixel layout become full rows and back; no staging tile)
 constexpr int CHAIN_PITCH = 68;
-constexpr int conv_smem_floats(int bm, int bn, bool bf16, bool halo = false, bool chain = false) {
+constexpr int conv_smem_floats(int bm, int bn, bool bf16, bool halo = false, bool chain = false, bool split = false) {
     const int full = 2 * bm * BK + 2 * BK * bn;
     if (!halo && !bf16) return full;
-    const int stages = halo ? 3 * (bm + HALO_RUN_EXTRA) * halo_pitch(bf16) : full / 2;
+    // (split form: three bf16 images of either operand)
+    const int stages = halo ? 3 * (bm + HALO_RUN_EXTRA) * halo_pitch(bf16) : split ? 3 * (full / 2) : full / 2;
     const int epilogue = chain ? 4 * 32 * CHAIN_PITCH : bm * bn + (bm == 64 && bn == 128 ? 256 : 0);       // staging tile (+ the decoder heads' 1x1 rows)
     return stages > epilogue ? stages : epilogue;
 }
@@ -198,8 +201,9 @@ constexpr int conv_smem_floats(int bm, int bn, bool bf16, bool halo = false, boo
 #ifndef FIERY_BF16_WAVES
 #define FIERY_BF16_WAVES 4        // waves per SIMD the bf16 form's register allocation is held to (128 registers)
 #endif
-constexpr int conv_waves_per_simd(int bm, int bn, bool aligned = false, bool bf16 = false, bool halo = false, bool chain = false) {
-    const int by_lds = 163840 / (conv_smem_floats(bm, bn, bf16, halo, chain) * 4);
+constexpr int conv_waves_per_simd(int bm, int bn, bool aligned = false, bool bf16 = false, bool halo = false, bool chain = false, bool split = false) {
+    const int by_lds = 163840 / (conv_smem_floats(bm, bn, bf16, halo, chain, split) * 4);
+    if (split) return by_lds < 2 ? by_lds : 2;                              // (three operand images per MFMA block in registers: 256 registers)
     int cap = ((bm == 64 && bn == 64) || (FIERY_TAIL_FOUR_PER_CU && bm == 128 && bn == 32 && aligned)) ? 4 : 3;
     if (bf16 && !(bm == 128 && bn == 32)) cap = FIERY_BF16_WAVES;         // (128 x 32: its chained epilogue needs 150)
     if (halo && !bf16) cap = FIERY_HALO_F32_WAVES;
@@ -221,12 +225,19 @@ constexpr int conv_waves_per_simd(int bm, int bn, bool aligned = false, bool bf1
 // workgroup through its tiles.
 // (SK - stream-K, round 5: the workgroup multiplies chunks [sk_kb, sk_ke) of output tile sk_tile; sk_j = its place in the
 // launch's even split of all (tile, chunk) units; see k_conv_igemm)
-template <int BM, int BN, bool CLK, int PRIO, bool SMALLCIN, bool ALIGNED, bool BF16, bool HALO, bool CHAIN, bool SK = false>
+// SPLIT (round 6; BF16 kernels only): fp32 ACCURACY on the bf16 matrix cores - every operand is the sum of three bf16 terms
+// (x = x1 + x2 + x3 exactly) and a product the six partial products of weight >= 2^-24, smallest first (see conv_winograd.hip,
+// "SPLIT form", and tools/probe/split_bf16_probe.hip: not less accurate than the fp32 matrix instruction).  The A tile is
+// split as it is written to LDS (three bf16 images), the weights arrive split (fiery_conv_pack_weights_split: per stage
+// [term][k / 8][cout][k % 8]); twelve 8-pass MFMAs per 32 x 32 x 32 block instead of sixteen 16-pass ones.
+template <int BM, int BN, bool CLK, int PRIO, bool SMALLCIN, bool ALIGNED, bool BF16, bool HALO, bool CHAIN, bool SK = false, bool SPLIT = false>
 __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const int nblk_x, const int sk_tile = 0, const int sk_kb = 0,
                                           const int sk_ke = 0, const int sk_j = 0, const int sk_nwg = 0) {
     static_assert(!CHAIN || (BM == 128 && BN == 32 && !HALO), "the chained tails run on the 128 x 32 tile");
     static_assert(!SK || (ALIGNED && !BF16 && !HALO && !CHAIN && !CLK && !SMALLCIN), "stream-K: the scalar-addressed fp32 loop");
     static_assert(!BF16 || (ALIGNED && !SMALLCIN && !CLK), "the bf16 form exists for the scalar-addressed loop");
+    static_assert(!SPLIT || (BF16 && !HALO && BN <= 64), "the split form: the scalar-addressed bf16 loop, cout tiles of 32 or 64");
+    constexpr int NS = SPLIT ? 3 : 1;                 // bf16 terms per operand
     static_assert(!HALO || (ALIGNED && !SMALLCIN && !CLK && BN >= 64 && (BM == 64 || BF16)), "the halo loop: 64-pixel tiles (bf16: 128 too), 64 couts or more");
     unsigned long long clk_entry = 0;
     // (tuning builds: slot 7 of the probe block may hold the address of a timeline buffer - eight 64-bit words per tile: the
@@ -264,16 +275,18 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
     // registers, so a lane finishes 16-byte pieces of its own pixel row without a staging tile (tools/probe/
     // chained_gemm_swapped.hip, profiles/r5_chained_gemm_swapped_gpu.txt: the layout algebra on real MFMA lanes).
     constexpr bool PIXLANE = CHAIN;
-    constexpr int W_BYTES = BF16 ? 2 : 4;                      // bytes per packed weight
-    constexpr int BLOADS = BF16 ? (BN >= 64 ? BN / 64 : 1) : (BK * BN / 4) / 256;      // 16-byte W loads per thread and stage
+    constexpr int W_BYTES = BF16 ? 2 * NS : 4;                 // bytes per packed weight
+    constexpr int BLOADS = BF16 ? (SPLIT ? (BN >= 64 ? 3 : 2) : (BN >= 64 ? BN / 64 : 1)) : (BK * BN / 4) / 256;      // 16-byte W loads per thread and stage
 
     // one LDS block: two A stages, two W stages; the epilogue reuses it as a BM x BN staging tile.  The bf16 form's stages
     // are half the size (both operands are bf16 there), so its block is as large as the epilogue needs and no larger.
     constexpr bool HALF_STAGES = BF16 && !HALO;
-    constexpr int A_STAGE = HALF_STAGES ? BM * (BK / 2) : BM * BK;        // floats between the two A stages
-    constexpr int W_STAGE = HALF_STAGES ? BK * BN / 2 : BK * BN;
+    constexpr int A_PLANE = BM * (BK / 2);                                // floats of one bf16 image of the A tile
+    constexpr int W_PLANE = BK * BN / 2;
+    constexpr int A_STAGE = HALF_STAGES ? NS * A_PLANE : BM * BK;         // floats between the two A stages
+    constexpr int W_STAGE = HALF_STAGES ? NS * W_PLANE : BK * BN;
     constexpr int W_BASE = 2 * A_STAGE;
-    constexpr int SMEM_FLOATS = conv_smem_floats(BM, BN, BF16, HALO, CHAIN);
+    constexpr int SMEM_FLOATS = conv_smem_floats(BM, BN, BF16, HALO, CHAIN, SPLIT);
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     static_assert((HALO || W_BASE + 2 * W_STAGE <= SMEM_FLOATS) && (CHAIN ? 4 * 32 * CHAIN_PITCH : BM * BN + (BM == 64 && BN == 128 ? 256 : 0)) <= SMEM_FLOATS,
                   "stages, staging tile (chained tails: the wavefronts' exchange tiles) and the heads' 1x1 rows must fit");
@@ -438,7 +451,9 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
         const_cast<char*>(reinterpret_cast<const char*>(p.w) + static_cast<long long>(tile_n) * p.k_chunks * (BK * BN * W_BYTES)), 0,
         p.k_chunks * (BK * BN * W_BYTES), 0x00020000);             // exactly this cout tile's packed image
     // (bf16, BN = 32: a stage's weights are 2 KiB, half the threads have nothing to fetch and point past the descriptor)
-    const int w_voff = (BF16 && BN == 32 && tid >= 128) ? static_cast<int>(0x80000000u) : tid * 16;
+    // (split, BN = 32: 6 KiB - every thread fetches a first piece, the lower half of the threads a second)
+    const int w_voff = (BF16 && !SPLIT && BN == 32 && tid >= 128) ? static_cast<int>(0x80000000u) : tid * 16;
+    const int w_voff_last = (SPLIT && BN == 32 && tid >= 128) ? static_cast<int>(0x80000000u) : w_voff;
     int w_soff = 0;
     auto to_float4 = [](auto raw) {
         float4 f;
@@ -503,7 +518,7 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
     auto load_b = [&](int k) {
         float4 v;
         if constexpr (ALIGNED) {
-            v = to_float4(__builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff, w_soff + k * 4096, 0));
+            v = to_float4(__builtin_amdgcn_raw_buffer_load_b128(w_rsrc, k == BLOADS - 1 ? w_voff_last : w_voff, w_soff + k * 4096, 0));
         } else {
             const float* wsrc = ld_stage < c_k_chunks ? wnext : wfirst;  // past the end: any valid address
             v = *reinterpret_cast<const float4*>(wsrc + k * 1024);
@@ -572,12 +587,23 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
     const int a_st16 = prow * 16 + (((f4 >> 1) ^ ((prow >> 2) & 3)) << 2) + (f4 & 1) * 2;     // + 32 j 16 + buf A_STAGE
     auto store_a = [&](int buf, int j) {
         const float4 v = j == 0 ? areg0 : j == 1 ? areg1 : j == 2 ? areg2 : areg3;
-        if constexpr (BF16) *reinterpret_cast<uint2*>(&smem[a_st16 + 32 * j * 16 + buf * A_STAGE]) = pack_bf16x4(v);
+        if constexpr (SPLIT) {
+            // x = t1 + t2 + t3: the remainders are exact in fp32
+            auto minus = [](const float4& x, const float4& y) { return make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w); };
+            const uint2 t1 = pack_bf16x4(v);
+            const float4 r1 = minus(v, unpack_bf16x4(t1));
+            const uint2 t2 = pack_bf16x4(r1);
+            const float4 r2 = minus(r1, unpack_bf16x4(t2));
+            uint2* const at = reinterpret_cast<uint2*>(&smem[a_st16 + 32 * j * 16 + buf * A_STAGE]);
+            at[0] = t1;
+            at[A_PLANE / 2] = t2;
+            at[A_PLANE] = pack_bf16x4(r2);
+        } else if constexpr (BF16) *reinterpret_cast<uint2*>(&smem[a_st16 + 32 * j * 16 + buf * A_STAGE]) = pack_bf16x4(v);
         else *reinterpret_cast<float4*>(&smem[a_st + 32 * j * BK + buf * A_STAGE]) = v;
     };
     auto store_b = [&](int buf, int k) {
         // (bf16, BN = 32: a stage's weights are 2 KiB - the upper half of the threads fetched nothing and has no slot)
-        if (BF16 && BN == 32 && tid >= 128) return;
+        if (BF16 && BN == 32 && tid >= 128 && (!SPLIT || k == BLOADS - 1)) return;
         *reinterpret_cast<float4*>(&smem[b_st + 1024 * k + buf * W_STAGE]) = k == 0 ? breg0 : k == 1 ? breg1 : k == 2 ? breg2 : breg3;
     };
     auto lds_a = [&](int buf, int q, int t) {
@@ -843,9 +869,43 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
     for (int i = 0; i < N_PIECES; ++i) side_piece(1, i);
     __syncthreads();
 
-    constexpr int N_MFMA = (BF16 ? 2 : 16) * MT * NT;
+    constexpr int N_MFMA = (BF16 ? (SPLIT ? 12 : 2) : 16) * MT * NT;
     auto stage_body = [&](auto buf_c) {
         constexpr int buf = decltype(buf_c)::value;
+        if constexpr (SPLIT) {
+            // per sixteen k and 32 x 32 block the six partial products, smallest first: a1 w3, a3 w1, a2 w2, a1 w2, a2 w1, a1 w1
+            constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TW[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                bf16x8 a8[MT][3], b8[NT][3];
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) a8[t][e] = load_bf16x8(&smem[a_rd16[kh] + 32 * t * 16 + e * A_PLANE + buf * A_STAGE]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int e = 0; e < 3; ++e)
+                        b8[nt][e] = load_bf16x8(&smem[W_BASE + buf * W_STAGE + e * W_PLANE + ((2 * kh + hi) * BN + wn * (32 * NT) + nt * 32 + m) * 4]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k6 = 0; k6 < 6; ++k6)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int t = 0; t < MT; ++t) {
+                            if constexpr (PIXLANE) acc[t * NT + nt] = mfma_bf16_32x32x16(b8[nt][TW[k6]], a8[t][TA[k6]], acc[t * NT + nt]);
+                            else acc[t * NT + nt] = mfma_bf16_32x32x16(a8[t][TA[k6]], b8[nt][TW[k6]], acc[t * NT + nt]);
+                            const int s = ((kh * 6 + k6) * NT + nt) * MT + t;
+#pragma unroll
+                            for (int i = 0; i < N_PIECES; ++i)
+                                if ((i * N_MFMA) / N_PIECES == s) side_piece(buf, i);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+            }
+            __syncthreads();
+            return;
+        }
         if constexpr (BF16) {
             // two MFMAs of sixteen k per 32 x 32 block and stage; the W image is [k / 8][cout][k % 8] bf16 and the A image
             // [pixel][k] bf16, so each operand of a lane is one 16-byte read
@@ -1321,7 +1381,7 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[nt][r] = 0.f;
-        if constexpr (BF16) {
+        if constexpr (BF16 && !SPLIT) {                  // (split form: the chained 1 x 1 products run on the fp32 instruction)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const bf16x8 hb = pack_bf16x8(make_float4(h[8 * i], h[8 * i + 1], h[8 * i + 2], h[8 * i + 3]),
@@ -1402,7 +1462,7 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
                 float4 y4[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) y4[g] = xt[m * XP + nt * 8 + 2 * g + hi];
-                if constexpr (BF16) {
+                if constexpr (BF16 && !SPLIT) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
                         acc3 = mfma_bf16_32x32x16(pack_bf16x8(w3r[nt * 4 + 2 * i], w3r[nt * 4 + 2 * i + 1]), pack_bf16x8(y4[2 * i], y4[2 * i + 1]), acc3);
@@ -1606,8 +1666,8 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
 // tile and the loop runs once; FIERY_CONV_PERSISTENT=1 caps the grid at one workgroup per slot of the chip (round 4's
 // experiment: would workgroups that stay hide each other's epilogue and set-up under their K loops?  see conv_persistent_grid).
 template <int BM, int BN, bool CLK = false, int PRIO = 0, bool SMALLCIN = false, bool ALIGNED = false, bool BF16 = false, bool HALO = false,
-          bool CHAIN = false, bool SK = false>
-__global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK && !BF16, BF16, HALO, CHAIN)) void k_conv_igemm(ConvP p) {
+          bool CHAIN = false, bool SK = false, bool SPLIT = false>
+__global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK && !BF16, BF16, HALO, CHAIN, SPLIT)) void k_conv_igemm(ConvP p) {
     if constexpr (SK) {
         // STREAM-K (round 5): the launch's work - every (output tile, K chunk) unit - is dealt out EVENLY to exactly as many
         // workgroups as the chip holds at once; a workgroup walks its contiguous run of units tile by tile, so a tile's chunks
@@ -1642,7 +1702,7 @@ __global__ __launch_bounds__(256, conv_waves_per_simd(BM, BN, ALIGNED && !CLK &&
         // the argument block is read afresh for every tile (kernel_args_again: an offset the optimiser cannot see through):
         // hoisted out of the loop its hundred scalars stay live across the tile and spill (168 registers + 496 B of scratch);
         // read in place, never copied: the heads' members are indexed at run time and a copy would live in scratch
-        conv_tile<BM, BN, CLK, PRIO, SMALLCIN, ALIGNED, BF16, HALO, CHAIN>(kernel_args_again(p), bid, n_tiles_m);
+        conv_tile<BM, BN, CLK, PRIO, SMALLCIN, ALIGNED, BF16, HALO, CHAIN, false, SPLIT>(kernel_args_again(p), bid, n_tiles_m);
         if (bid + static_cast<int>(gridDim.x) < n_tiles_m) __syncthreads();      // the next tile's first stage overwrites the staging tile
     }
 }
@@ -1695,6 +1755,19 @@ void conv_launch_tile_bf16(const ConvP& p, dim3 grid, hipStream_t hs) {
         }
     }
     FIERY_CONV_LAUNCH(BM, BN, false, 0, false, true, true, false);
+}
+// the split form (fp32 accuracy on the bf16 matrix cores; weights packed by fiery_conv_pack_weights_split in p.w)
+template <int BM, int BN>
+void conv_launch_tile_split(const ConvP& p, dim3 grid, hipStream_t hs) {
+    ConvP q_ = p;
+    const dim3 g_ = conv_persistent_grid(q_, grid, conv_waves_per_simd(BM, BN, false, true, false, false, true));
+    if constexpr (BM == 128 && BN == 32) {
+        if (p.w2) {                                          // Bottleneck tail: the register-chained kernel
+            hipLaunchKernelGGL((k_conv_igemm<BM, BN, false, 0, false, true, true, false, true, false, true>), g_, dim3(256), 0, hs, q_);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((k_conv_igemm<BM, BN, false, 0, false, true, true, false, false, false, true>), g_, dim3(256), 0, hs, q_);
 }
 template <int BM, int BN>
 void conv_launch_tile_stream_k(const ConvP& p, dim3 grid, hipStream_t hs) {

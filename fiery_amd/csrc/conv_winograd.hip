@@ -75,6 +75,9 @@ namespace {
 #ifndef W_SPLIT_RING
 #define W_SPLIT_RING 12           // split form: register ring of weight pieces (a stage has 24: 4 points x 2 cout blocks x 3 terms)
 #endif
+#ifndef W_SPLIT_TRANSFORM_AT
+#define W_SPLIT_TRANSFORM_AT 1    // split form: the next stage's input transform follows this point's MFMAs (0 .. 3)
+#endif
 #ifndef W_EXP
 #define W_EXP 0                   // timing experiments (wrong results): 1 weights from one hot piece, 2 no input loads in the loop,
 #endif                            // 3 no transform / V stores in the loop, 4 no epilogue
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_conv_winograd(Conv
                     if (nxt < PIECES) w_request(nxt % RING, s, nxt);
                     else w_request(nxt % RING, s + 1, nxt - PIECES);
                 }
-                if (s + 1 < stages && pl == PP / 2 - 1) {
+                if (s + 1 < stages && pl == W_SPLIT_TRANSFORM_AT) {
                     if (W_EXP != 3) transform();
                     if (W_EXP != 3) store_v(buf ^ 1);
                     if (s + 2 < stages && W_EXP != 2) request(s + 2);

@@ -86,6 +86,10 @@ __device__ __forceinline__ uint2 pack_bf16x4(float4 v) {
     __builtin_memcpy(&r, &h, 8);
     return r;
 }
+// four bf16 (as packed by pack_bf16x4) -> four fp32, exact
+__device__ __forceinline__ float4 unpack_bf16x4(uint2 h) {
+    return make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xffff0000u), __uint_as_float(h.y << 16), __uint_as_float(h.y & 0xffff0000u));
+}
 // D(32 x 32) += A(32 x 16) . B(16 x 32): lane l holds A[l & 31][8 (l >> 5) + j], B[8 (l >> 5) + j][l & 31], j < 8
 __device__ __forceinline__ fiery_v16f mfma_bf16_32x32x16(bf16x8 a, bf16x8 b, fiery_v16f c) {
 #ifdef FIERY_BF16_REPEAT                   // timing experiment (wrong results): every bf16 MFMA issued this many times

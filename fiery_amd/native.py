@@ -21,7 +21,7 @@ c_int64_p = C.POINTER(C.c_int64)
 c_uint8_p = C.POINTER(C.c_uint8)
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SWISH = 0, 1, 2, 3
-PRECISION_F32, PRECISION_BF16 = 0, 1
+PRECISION_F32, PRECISION_BF16, PRECISION_F32_SPLIT = 0, 1, 2
 EPI_PLAIN, EPI_GRU_GATES, EPI_GRU_OUT, EPI_HEADS = 0, 1, 2, 3
 CONV_FORM_TILE, CONV_FORM_STREAM_K, CONV_FORM_WINOGRAD, CONV_FORM_WINOGRAD_SPLIT = 0, 1, 2, 3
 WINOGRAD_SPLIT_TERMS = 3                    # fiery_conv_desc.winograd: the split image is in weights_winograd
@@ -130,6 +130,7 @@ _SIGNATURES = {
     'fiery_conv_pack_weights': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_int32_p, C.c_int, C.c_void_p, C.c_void_p]),
     'fiery_conv_fwd': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     'fiery_conv_pack_weights_bf16': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_int32_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'fiery_conv_pack_weights_split': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_int32_p, C.c_int, C.c_void_p, C.c_void_p]),
     'fiery_conv_precision_used': (C.c_int, [C.POINTER(ConvDesc)]),
     'fiery_conv_form_used': (C.c_int, [C.POINTER(ConvDesc)]),
     'fiery_conv_winograd_packed_floats': (C.c_size_t, [C.c_int, C.c_int]),
@@ -470,6 +471,15 @@ class Lib:
         cmap = (C.c_int32 * cin_total)(*chan_map)
         self.check(self.dll.fiery_conv_pack_weights_bf16(_ptr(w), cout, cin_total, taps, cmap, cin_units, _ptr(packed),
                                                          _stream_of(packed)))
+        return packed
+
+    def conv_pack_weights_split(self, w, cout, cin_total, taps, chan_map, cin_units):
+        """The split image (PRECISION_F32_SPLIT): every weight as three bf16 terms that add up to it exactly."""
+        n = self.dll.fiery_conv_packed_floats(cout, cin_units, taps)
+        packed = torch.empty(3 * n, dtype=torch.bfloat16, device=w.device)
+        cmap = (C.c_int32 * cin_total)(*chan_map)
+        self.check(self.dll.fiery_conv_pack_weights_split(_ptr(w), cout, cin_total, taps, cmap, cin_units, _ptr(packed),
+                                                          _stream_of(packed)))
         return packed
 
     def conv_pack_weights_winograd(self, w, cout, cin_total, chan_map, cin_units):

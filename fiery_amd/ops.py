@@ -150,6 +150,13 @@ class ConvOp:
             self.packed_bf16 = lib.conv_pack_weights_bf16(w.view(self.cout, self.cin_total, taps), self.cout, self.cin_total,
                                                           taps, list(chan_map), cin_units)
         self.cout_pad = round_up(self.cout, 32)
+        # the split image (fp32 accuracy on the bf16 matrix cores: three bf16 terms per operand) for the layers the library's
+        # split tile kernels cover - whole 32-channel stages, 32- or 64-wide cout tiles: a candidate form of `_pick_tile` ('split')
+        self.packed_split = None
+        if (SPLIT_TILES and self.precision == native.PRECISION_F32 and cin_units % 4 == 0 and self.units[0] % 4 == 0 and
+                self.cout_pad % 128 != 0):
+            self.packed_split = lib.conv_pack_weights_split(w.view(self.cout, self.cin_total, taps), self.cout, self.cin_total, taps,
+                                                            list(chan_map), cin_units)
         # Winograd F(2x2, 3x3) image of the weights for the layers that form covers (3 x 3 / stride 1 / 'same', whole 16-channel
         # stages per source, 64-cout tiles; fp32 only): a candidate form of `_pick_tile`
         self.packed_winograd = self.packed_winograd_split = None
@@ -177,7 +184,8 @@ class ConvOp:
         self.chain = None
         self.chain3 = None
         self.heads = None
-        self.force_form = None       # tests / A-B runs: 64, 128 or 'sk' instead of the measured choice
+        self.force_form = None       # tests / A-B runs: 64, 128, 'sk', 'wino', 'wsplit' or 'split' instead of the measured choice
+        self.last_form = None
 
 
     def chain_pointwise(self, weight, scale, shift, act):
@@ -234,6 +242,12 @@ class ConvOp:
         return ((H + 2 * self.padH - self.kH) // self.stride + 1, (W + 2 * self.padW - self.kW) // self.stride + 1)
 
     def _set_form(self, d, form, sk=None):
+        if form == 'split':                            # the split tile kernels: 128-pixel tiles
+            d.precision, d.weights_bf16 = native.PRECISION_F32_SPLIT, self.packed_split.data_ptr()
+            form = 128
+        else:
+            d.weights_bf16 = self.packed_bf16.data_ptr() if self.packed_bf16 is not None else None
+            d.precision = self.precision if self.packed_bf16 is not None else native.PRECISION_F32
         d.winograd = 1 if form == 'wino' else native.WINOGRAD_SPLIT_TERMS if form == 'wsplit' else 0
         d.weights_winograd = (self.packed_winograd.data_ptr() if form == 'wino' else
                               self.packed_winograd_split.data_ptr() if form == 'wsplit' else None)
@@ -273,6 +287,16 @@ class ConvOp:
         d.winograd, d.weights_winograd = keep
         return taken
 
+    def _split_taken(self, d):
+        """Whether the library runs THIS launch in the split tile form when asked to (`fiery_conv_precision_used`)."""
+        if self.packed_split is None:
+            return False
+        keep = (d.precision, d.weights_bf16, d.tile_m, d.winograd, d.stream_k)
+        d.precision, d.weights_bf16, d.tile_m, d.winograd, d.stream_k = native.PRECISION_F32_SPLIT, self.packed_split.data_ptr(), 128, 0, 0
+        taken = self.lib.conv_precision_used(d) == native.PRECISION_F32_SPLIT
+        d.precision, d.weights_bf16, d.tile_m, d.winograd, d.stream_k = keep
+        return taken
+
     def _pick_tile(self, d, out):
         """The form of this launch: a tile height (64 / 128 output pixels per workgroup, one workgroup per tile), or
         stream-K (the launch's work dealt evenly to one round of workgroups, shared tiles summed through a workspace -
@@ -282,21 +306,27 @@ class ConvOp:
         inputs, so the extra launches leave the same result behind (up to the last bits between stream-K and the tile
         forms: another summation split)."""
         self._set_form(d, 0)
-        if self.cout_pad % 64 != 0 or self.chain is not None or (not self.tune and self.force_form is None):
+        self.last_form = 0                             # (what the last launch was asked to run in: tests look here)
+        narrow = self.cout_pad % 64 != 0 or self.chain is not None       # one fp32 tile shape: the choice is fp32 / split
+        if (narrow and self.packed_split is None) or (not self.tune and self.force_form is None):
             return                                     # one tile shape only (or: library heuristic; a forced form is honoured)
         if self.heads is not None and self.packed_winograd is None:
             return                                     # (the heads' direct form has one tile shape)
         key = (out.n_img, out.H, out.W)
         choice = self.force_form                       # (a forced form - per op, or FIERY_CONV_FORM for all - goes before the table)
         if choice is None and FORCE_FORM:
-            choice = FORCE_FORM if FORCE_FORM in ('sk', 'wino', 'wsplit') else int(FORCE_FORM)
+            choice = FORCE_FORM if FORCE_FORM in ('sk', 'wino', 'wsplit', 'split') else int(FORCE_FORM)
+        if narrow and choice not in (None, 0, 'split'):
+            choice = 0
         if choice is None:
             choice = FORM_TABLE.get((self._sig, key))
         if choice == 'wino' and self.packed_winograd is None:
             choice = 0
         if choice == 'wsplit' and self.packed_winograd_split is None:
             choice = 'wino' if self.packed_winograd is not None else 0
-        sk = _stream_k_workspace(self.lib, d, out.tensor) if (choice == 'sk' or choice is None) and self.heads is None else None
+        if choice == 'split' and not self._split_taken(d):
+            choice = 0
+        sk = _stream_k_workspace(self.lib, d, out.tensor) if (choice == 'sk' or choice is None) and self.heads is None and not narrow else None
         if choice is None:
             if FORM_TABLE_FROZEN or not _autotune_enabled(out.tensor):
                 return                                 # library heuristic (and nothing cached: tune when possible)
@@ -305,6 +335,13 @@ class ConvOp:
                 forms = [0, 'wino'] if 'wino' in forms else [0]     # heads epilogue: the direct form's one tile shape, or Winograd
             if 'wino' in forms and self.packed_winograd_split is not None:
                 forms.append('wsplit')
+            if narrow:
+                forms = [0]
+            if self.heads is None and self._split_taken(d):
+                forms.append('split')
+            if len(forms) == 1:
+                FORM_TABLE[(self._sig, key)] = forms[0]
+                return
             times = {f: float('inf') for f in forms}
             for _trial in range(2):                    # alternate the candidates, keep each one's best trial
                 for form in forms:
@@ -321,6 +358,7 @@ class ConvOp:
         if choice == 'sk' and sk is None:
             choice = 0                                 # (no workspace for this stream, e.g. first met inside a capture)
         self._set_form(d, choice, sk)
+        self.last_form = choice
 
     def __call__(self, srcs, out, res=None, img_bias=None, out2=None, aux0=None, aux1=None,
                  T_out=1, t_out0=0, t_in_add=0, cout_store=None, img_bias_border=False, head_planes=None, out3=None):
@@ -378,9 +416,7 @@ class ConvOp:
         d.aux0 = aux0.as_nhwc_struct() if aux0 is not None else _null_nhwc()
         d.aux1 = aux1.as_nhwc_struct() if aux1 is not None else _null_nhwc()
         self._keep = (srcs, out, res, img_bias, out2, aux0, aux1, out3)
-        d.weights_bf16 = self.packed_bf16.data_ptr() if self.packed_bf16 is not None else None
-        d.precision = self.precision if self.packed_bf16 is not None else native.PRECISION_F32
-        self._pick_tile(d, out)
+        self._pick_tile(d, out)                        # (sets the form's members: tile, stream-K, Winograd, precision + bf16 / split image)
         flops = 2.0 * out.n_img * out.H * out.W * self.cin_total * self.kT * self.kH * self.kW * self.cout
         if self.chain is not None:
             flops += 2.0 * out.n_img * out.H * out.W * self.cout * self.chain['cout']
@@ -392,6 +428,9 @@ class ConvOp:
         used = 'f32'
         if PROFILE_SINK is not None and d.precision == native.PRECISION_BF16:
             used = 'bf16' if self.lib.conv_precision_used(d) == native.PRECISION_BF16 else 'f32'
+        if PROFILE_SINK is not None and d.precision == native.PRECISION_F32_SPLIT:
+            if self.lib.conv_precision_used(d) == native.PRECISION_F32_SPLIT:      # (chained 1x1 products stay on the fp32 instruction)
+                used = 'f32 split' if self.chain is None else 'f32 split + fp32 chain'
         if PROFILE_SINK is not None and (d.winograd or d.stream_k):
             form = self.lib.conv_form_used(d)          # (what ran, not what was asked for: the flops accounting hangs on it)
             used = {native.CONV_FORM_WINOGRAD: 'f32 winograd', native.CONV_FORM_WINOGRAD_SPLIT: 'f32 winograd split',
@@ -410,6 +449,7 @@ SK_COUNTERS = 1 << 17
 STREAM_K = os.environ.get('FIERY_STREAM_K', '1') != '0'
 FORCE_FORM = os.environ.get('FIERY_CONV_FORM')      # A/B runs: '64', '128', 'sk' or 'wino' for every launch that has the form, no timing
 WINOGRAD = os.environ.get('FIERY_CONV_WINOGRAD', '1') != '0'
+SPLIT_TILES = os.environ.get('FIERY_CONV_SPLIT', '1') != '0'      # the split tile kernels (bf16 matrix cores, three-term operands, fp32 accuracy) as a candidate
 WINOGRAD_SPLIT = os.environ.get('FIERY_CONV_WINOGRAD_SPLIT', '1') != '0'      # the split form (bf16 matrix cores, three-term operands) as a candidate
 
 

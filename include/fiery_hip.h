@@ -363,6 +363,12 @@ typedef struct {
 
 #define FIERY_PRECISION_F32 0
 #define FIERY_PRECISION_BF16 1
+/* fp32 ACCURACY on the bf16 matrix cores (round 6): weights_bf16 = the image of fiery_conv_pack_weights_split - every operand as
+ * three bf16 terms (x = t1 + t2 + t3 exactly), six partial products per product, fp32 accumulation; not less accurate than the
+ * fp32 matrix instruction (tools/probe/split_bf16_probe.hip).  Taken by launches of the scalar-addressed loop on 128-pixel tiles
+ * with 32- or 64-wide cout tiles (the chained Bottleneck tails included; their 1x1 products stay on the fp32 instruction);
+ * everything else runs the fp32 kernels with `weights`.  fiery_conv_precision_used tells which. */
+#define FIERY_PRECISION_F32_SPLIT 2
 
 /* Packs a dense weight W[cout][cin_total][taps] (taps = kT*kH*kW, row-major as PyTorch stores conv
  * weights) into the kernel's layout.  Input channel ci of the logical concat maps to padded position
@@ -371,6 +377,12 @@ size_t fiery_conv_packed_floats(int cout, int cin_units, int taps);
 int fiery_conv_pack_weights(const float* w, int cout, int cin_total, int taps,
                             const int32_t* chan_map /* host */, int cin_units,
                             float* packed, fiery_stream_t stream);
+
+/* The split packing (FIERY_PRECISION_F32_SPLIT): per 32-k stage and cout tile [3 terms][k / 8][cout][k % 8] bf16;
+ * 3 * fiery_conv_packed_floats(...) / 2 floats' worth of bytes. */
+int fiery_conv_pack_weights_split(const float* w, int cout, int cin_total, int taps,
+                                  const int32_t* chan_map /* host */, int cin_units,
+                                  void* packed, fiery_stream_t stream);
 
 /* The bf16 packing of the same weights ([k / 8][cout][k % 8] bf16 per 32-k stage and cout tile; values rounded to nearest
  * even): fiery_conv_packed_floats(...) / 2 floats' worth of bytes. */

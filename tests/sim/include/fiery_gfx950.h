@@ -59,6 +59,11 @@ inline uint2 pack_bf16x4(float4 v) {
     __builtin_memcpy(&r, h, 8);
     return r;
 }
+inline float4 unpack_bf16x4(uint2 h) {
+    unsigned short b[4];
+    __builtin_memcpy(b, &h, 8);
+    return make_float4(bf16_value(b[0]), bf16_value(b[1]), bf16_value(b[2]), bf16_value(b[3]));
+}
 inline bf16x8 bits_bf16x8(float4 v) {
     bf16x8 r;
     __builtin_memcpy(&r, &v, 16);

@@ -576,6 +576,68 @@ def test_conv_heads_epilogue_real_shapes(hip, form, n, H, W):
             assert err <= bound * max(1.0, want.abs().max().item()), (form, rep, i, err)
 
 
+@pytest.mark.parametrize('case', ['stem 7x7 stride 2 64->64', '64->64 3x3', '64->32 1x1', 'tail 32->32 3x3 + 32->64 + next 64->32'])
+def test_conv_split_tile_form_real_shapes(hip, case):
+    """The split tile kernels (round 6; FIERY_PRECISION_F32_SPLIT, csrc/conv_tile_split.hip: fp32 operands as three bf16 terms, six
+    partial products per product on the bf16 matrix cores, fp32 accumulation) on the step's real shapes, against torch fp32 on the
+    host and against the fp32 tile form of the same launch; twice into the same buffers.  An fp32-ACCURATE form: held to the direct
+    fp32 kernels' bound (2e-5 x scale), not to the bf16 mode's."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(len(case))
+    nhwc = lambda t: Buf(t.permute(0, 2, 3, 1).contiguous().to(DEV), t.shape[0], t.shape[2], t.shape[3], t.shape[1])
+    bound = 2e-5
+    if case.startswith('tail'):
+        n, H, W, mid, cout = 12, 200, 200, 32, 64
+        x = torch.randn(n, mid, H, W, generator=g)
+        w2 = torch.randn(mid, mid, 3, 3, generator=g) / (mid * 9) ** 0.5
+        w3 = torch.randn(cout, mid, 1, 1, generator=g) / mid ** 0.5
+        w4 = torch.randn(mid, cout, 1, 1, generator=g) / cout ** 0.5
+        s2, b2 = torch.rand(mid, generator=g) + 0.5, torch.randn(mid, generator=g) * 0.3
+        s3, b3 = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.3
+        s4, b4 = torch.rand(mid, generator=g) + 0.5, torch.randn(mid, generator=g) * 0.3
+        res = torch.randn(n, cout, H, W, generator=g)
+        base = ConvOp(hip, w2, identity_chan_map(mid), (mid // 8, 0), s2, b2, DEV, act=native.ACT_RELU, tune=True)
+        base.chain_pointwise(w3, s3, b3, native.ACT_RELU)
+        op = base.chain_next(w4, s4, b4, native.ACT_RELU)
+        xb, rb = nhwc(x), nhwc(res)
+        h = F.relu(F.conv2d(x, w2, padding=1) * s2.view(1, -1, 1, 1) + b2.view(1, -1, 1, 1))
+        y = F.relu(F.conv2d(h, w3) * s3.view(1, -1, 1, 1) + b3.view(1, -1, 1, 1)) + res
+        t = F.relu(F.conv2d(y, w4) * s4.view(1, -1, 1, 1) + b4.view(1, -1, 1, 1))
+        wants = [y, t]
+        alloc = lambda: (Buf.alloc(n, H, W, cout, DEV), Buf.alloc(n, H, W, mid, DEV))
+        run = lambda out: op([xb], out[0], res=rb, out3=out[1])
+        outs_of = lambda out: [out[0].to_nchw().cpu(), out[1].to_nchw().cpu()]
+    else:
+        n, cin, cout, k, stride, H, W = {'stem 7x7 stride 2 64->64': (15, 64, 64, 7, 2, 200, 200), '64->64 3x3': (3, 64, 64, 3, 1, 200, 200),
+                                         '64->32 1x1': (12, 64, 32, 1, 1, 200, 200)}[case]
+        x = torch.randn(n, cin, H, W, generator=g)
+        w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+        sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+        op = ConvOp(hip, w, identity_chan_map(cin), (cin // 8, 0), sc, sh, DEV, stride=stride, act=native.ACT_RELU, tune=True)
+        ho, wo = op.out_hw(H, W)
+        xb = nhwc(x)
+        wants = [F.relu(F.conv2d(x, w, stride=stride, padding=(k - 1) // 2) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))]
+        alloc = lambda: Buf.alloc(n, ho, wo, cout, DEV)
+        run = lambda out: op([xb], out)
+        outs_of = lambda out: [out.to_nchw().cpu()]
+    op.force_form = 0 if case.startswith('tail') or cout == 32 else 128
+    tile_out = alloc()
+    run(tile_out)
+    tile = outs_of(tile_out)
+    op.force_form = 'split'
+    for rep in range(2):
+        out = alloc()
+        run(out)
+        assert op.last_form == 'split', 'the library does not take this launch in the split form'
+        got = outs_of(out)
+        for i, (a_, t_, wnt) in enumerate(zip(got, tile, wants)):
+            err = (a_ - wnt).abs().max().item()
+            parity_report.record(f'conv split tile form: {case}' + (f' [{i}]' if len(got) > 1 else ''), 'vs torch fp32 (host)', (a_ - t_).abs().max().item(),
+                                 wnt.abs().max().item(), err, (t_ - wnt).abs().max().item(), bound * max(1.0, wnt.abs().max().item()),
+                                 note='first column: against the fp32 tile form of the same launch')
+            assert err <= bound * max(1.0, wnt.abs().max().item()), (case, rep, i, err)
+
+
 @pytest.mark.parametrize('cin,cout,k,stride', [(64, 64, 3, 1), (128, 128, 3, 1), (64, 256, 3, 1), (64, 64, 7, 2), (32, 32, 3, 1)])
 def test_conv_igemm_bf16_form_real_shapes(hip, cin, cout, k, stride):
     """v_mfma_f32_32x32x16_bf16 on the real shapes: against the fp32 convolution of the bf16-rounded operands (what the

@@ -261,13 +261,18 @@ def test_heads_1x1_nchw(sim):
         assert torch.allclose(out[:, o], want, **TOL)
 
 
+@pytest.mark.parametrize('form', [None, 'split'])
 @pytest.mark.parametrize('epilogue', ['rows', 'rows, images apart', 'unaligned'])
 @pytest.mark.parametrize('mid,cout,stride', [(32, 64, 1), (20, 40, 2)])
-def test_chained_pointwise_conv_with_residual(sim, monkeypatch, mid, cout, stride, epilogue):
+def test_chained_pointwise_conv_with_residual(sim, monkeypatch, mid, cout, stride, epilogue, form):
     """3x3 conv + BN + ReLU -> 1x1 conv + BN + ReLU + residual as ONE kernel (the Bottleneck's tail,
     fiery/layers/convolutions.py:123-168): the intermediate values stay on chip (round 5: in the accumulator registers).  The
     three ways its rows leave: full 16-byte rows of dense tensors, of tensors whose images are apart (per-row image / pixel
-    split), and channel by channel from the registers when the destinations are not 16-byte addressable."""
+    split), and channel by channel from the registers when the destinations are not 16-byte addressable.  form = 'split'
+    (round 6): the 3 x 3 product on the bf16 matrix cores with three-term operands (the 20-channel case has no whole stages and
+    stays on the fp32 kernel)."""
+    if form == 'split' and mid != 32:
+        pytest.skip('the split form needs whole 32-channel stages')
     if epilogue == 'unaligned':
         monkeypatch.setenv('FIERY_CONV_VEC_EPILOGUE', '0')
     elif epilogue != 'rows':
@@ -281,17 +286,20 @@ def test_chained_pointwise_conv_with_residual(sim, monkeypatch, mid, cout, strid
     src = _to_buf(x)
     op = ConvOp(sim, w2, identity_chan_map(mid), (src.C // 8, 0), s2, b2, 'cpu', stride=stride, act=native.ACT_RELU)
     op.chain_pointwise(w3, s3, b3, native.ACT_RELU)
+    op.force_form = form
     ho, wo = op.out_hw(9, 14)
     res = torch.randn(2, cout, ho, wo, generator=g)
     out = Buf.alloc(2, ho, wo, cout, 'cpu')
     op([src], out, res=_to_buf(res))
+    assert op.last_form == (form or 0)
     h = F.relu(F.conv2d(x, w2, stride=stride, padding=1) * s2.view(1, -1, 1, 1) + b2.view(1, -1, 1, 1))
     want = F.relu(F.conv2d(h, w3) * s3.view(1, -1, 1, 1) + b3.view(1, -1, 1, 1)) + res
     assert torch.allclose(out.to_nchw()[:, :cout], want, **TOL), (out.to_nchw()[:, :cout] - want).abs().max()
 
 
+@pytest.mark.parametrize('form', [None, 'split'])
 @pytest.mark.parametrize('shape', [(2, 9, 14), (1, 16, 16), (3, 5, 43)])
-def test_chained_tail_plus_the_next_blocks_down_projection(sim, shape):
+def test_chained_tail_plus_the_next_blocks_down_projection(sim, shape, form):
     """Bottleneck tail (3x3 + 1x1 + residual) AND the following Bottleneck's 1x1 down-projection (64 -> 32, BN, ReLU) in
     one kernel: both outputs against torch; image counts and sizes that make tiles straddle images and end ragged."""
     n, H, W = shape
@@ -308,10 +316,12 @@ def test_chained_tail_plus_the_next_blocks_down_projection(sim, shape):
     base = ConvOp(sim, w2, identity_chan_map(mid), (src.C // 8, 0), s2, b2, 'cpu', act=native.ACT_RELU)
     base.chain_pointwise(w3, s3, b3, native.ACT_RELU)
     op = base.chain_next(w4, s4, b4, native.ACT_RELU)
+    op.force_form = base.force_form = form
     res = torch.randn(n, cout, H, W, generator=g)
     out = Buf.alloc(n, H, W, cout, 'cpu')
     nxt = Buf.alloc(n, H, W, mid, 'cpu')
     op([src], out, res=_to_buf(res), out3=nxt)
+    assert op.last_form == (form or 0)
     h = F.relu(F.conv2d(x, w2, padding=1) * s2.view(1, -1, 1, 1) + b2.view(1, -1, 1, 1))
     y = F.relu(F.conv2d(h, w3) * s3.view(1, -1, 1, 1) + b3.view(1, -1, 1, 1)) + res
     t = F.relu(F.conv2d(y, w4) * s4.view(1, -1, 1, 1) + b4.view(1, -1, 1, 1))
@@ -321,6 +331,49 @@ def test_chained_tail_plus_the_next_blocks_down_projection(sim, shape):
     out_b = Buf.alloc(n, H, W, cout, 'cpu')
     base([src], out_b, res=_to_buf(res))
     assert torch.equal(out_b.nhwc(), out.nhwc())
+
+
+@pytest.mark.parametrize('case', ['64->64 3x3', '64->64 7x7 stride 2', '32->32 3x3 ragged', '64+32->32 1x1 two sources', '64->40 3x3 residual',
+                                  '32->32 (2,3,3) temporal'])
+def test_split_tile_form_equals_torch(sim, case):
+    """The split tile kernels (round 6, FIERY_PRECISION_F32_SPLIT: every operand as three bf16 terms, six partial products per
+    product on the bf16 matrix cores - an fp32-accurate form, held to the fp32 kernels' tolerance) against torch: both cout tile
+    widths, strides, two sources, ragged tiles, a residual, a temporal kernel."""
+    g = torch.Generator().manual_seed(len(case))
+    if case == '32->32 (2,3,3) temporal':
+        B, T, H, W, C = 2, 3, 6, 9, 32
+        seq = torch.randn(B, T, C, H, W, generator=g)
+        w = torch.randn(32, C, 2, 3, 3, generator=g) * 0.1
+        op = ConvOp(sim, w, identity_chan_map(C), (C // 8, 0), torch.ones(32), torch.zeros(32), 'cpu', act=native.ACT_RELU)
+        op.force_form = 'split'
+        src = Buf(seq.permute(0, 1, 3, 4, 2).reshape(B * T, H, W, C).contiguous(), B * T, H, W, C)
+        out = Buf.alloc(B * T, H, W, 32, 'cpu')
+        op([(src, T * src.img_stride, src.img_stride)], out, T_out=T)
+        assert op.last_form == 'split'
+        xp = F.pad(seq.permute(0, 2, 1, 3, 4), (1, 1, 1, 1, 1, 0))                      # causal in time, 'same' in space
+        want = F.relu(F.conv3d(xp, w)).permute(0, 2, 1, 3, 4).reshape(B * T, 32, H, W)
+        assert torch.allclose(out.to_nchw(), want, **TOL), (out.to_nchw() - want).abs().max()
+        return
+    cfg = {'64->64 3x3': (3, 64, 0, 64, 3, 1, 11, 13), '64->64 7x7 stride 2': (2, 64, 0, 64, 7, 2, 20, 18), '32->32 3x3 ragged': (3, 32, 0, 32, 3, 1, 5, 43),
+           '64+32->32 1x1 two sources': (2, 64, 32, 32, 1, 1, 9, 14), '64->40 3x3 residual': (2, 64, 0, 40, 3, 1, 10, 12)}[case]
+    n, c0, c1, cout, k, stride, H, W = cfg
+    x0 = torch.randn(n, c0, H, W, generator=g)
+    x1 = torch.randn(n, c1, H, W, generator=g) if c1 else None
+    w = torch.randn(cout, c0 + c1, k, k, generator=g) / ((c0 + c1) * k * k) ** 0.5
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    cmap = identity_chan_map(c0) + (identity_chan_map(c1, offset=c0) if c1 else [])
+    op = ConvOp(sim, w, cmap, (c0 // 8, c1 // 8), sc, sh, 'cpu', stride=stride, act=native.ACT_RELU)
+    op.force_form = 'split'
+    ho, wo = op.out_hw(H, W)
+    res = torch.randn(n, cout, ho, wo, generator=g) if 'residual' in case else None
+    out = Buf.alloc(n, ho, wo, round_up(cout, 32) if 'round_up' in globals() else (cout + 31) // 32 * 32, 'cpu')
+    op([_to_buf(x0)] + ([_to_buf(x1)] if c1 else []), out, res=_to_buf(res) if res is not None else None)
+    assert op.last_form == 'split' and op.packed_split is not None
+    x = torch.cat([x0, x1], 1) if c1 else x0
+    want = F.relu(F.conv2d(x, w, stride=stride, padding=(k - 1) // 2) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    if res is not None:
+        want = want + res
+    assert torch.allclose(out.to_nchw()[:, :cout], want, **TOL), (out.to_nchw()[:, :cout] - want).abs().max()
 
 
 @pytest.mark.parametrize('case', range(20))

@@ -8,7 +8,9 @@ PEAK = {'f32': 157.3, 'bf16': 2500.0}
 # `work` in the dump is the direct form's flops; a Winograd F(2x2, 3x3) launch executes 16 / 36 of them on the matrix cores: its
 # TFLOP/s and frac columns are on EXECUTED flops (the launch's time is what it is either way)
 # (its split form: six bf16 MFMAs per fp32 product block, against the bf16 peak)
-executed = lambda work, prec: work * 16.0 / 36.0 * (6.0 if 'split' in str(prec) else 1.0) if 'winograd' in str(prec) else work
+# (the split tile form: six per product, chained 1x1 parts included - an upper bound for the tails)
+executed = lambda work, prec: (work * 16.0 / 36.0 * (6.0 if 'split' in str(prec) else 1.0) if 'winograd' in str(prec) else
+                               work * 6.0 if 'split' in str(prec) else work)
 peak_of = lambda prec: PEAK['bf16'] if (prec == 'bf16' or 'split' in str(prec)) else PEAK['f32']
 
 
