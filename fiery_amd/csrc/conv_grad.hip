@@ -155,8 +155,13 @@ struct Wgrad3P {
 // once: taps dx = 0 and dx = 2 share their bf16 pairs, dx = 1 pairs them the other way.  Per sixteen pixels and wavefront:
 // 38 LDS reads, 31 packed conversions, 9 MFMAs of 32 cycles where the fp32 form issues 72 of 64.  Products of bf16 values
 // are exact in fp32 and the accumulation is fp32: the result is the weight gradient of the ROUNDED dY and X.
-template <bool BF16>
+// SPLIT (round 6, FIERY_PRECISION_F32_SPLIT): the same loop with every fp32 operand as three bf16 terms (x = x1 + x2 + x3 exactly)
+// and six partial products per product, smallest first - fp32 accuracy (not below the fp32 instruction's: tools/probe/
+// split_bf16_probe.hip) at 54 short MFMAs per sixteen pixels where the fp32 form issues 72 long ones.  Both operands are
+// activations: each is split by the lane that read it (the ten input pixels of a row once, for all three taps).
+template <bool BF16, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void k_conv_wgrad3x3(Wgrad3P p) {
+    static_assert(!SPLIT || BF16, "the split form is a mode of the bf16 loop");
     constexpr int G_ROWS = BF16 ? 64 : kSegMax;               // (bf16: whole 16-pixel steps; rows past the segment hold zeros)
     constexpr int X_ROWS = BF16 ? 66 : kSegMax + 2;
     __shared__ float s_g[G_ROWS * 64];                        // dY segment [pixel][cout]
@@ -259,6 +264,37 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad3x3(Wgrad3P p) {
                     float av[8];
 #pragma unroll
                     for (int i = 0; i < 8; ++i) av[i] = s_g[(px + i) * 64 + a_off];
+                    if constexpr (SPLIT) {
+                        bf16x8 a3[3];
+                        split_bf16x8(av, a3[0], a3[1], a3[2]);
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) {
+                            const float* xr = r == 0 ? xr0 : r == 1 ? xr1 : xr2;
+                            // the three terms of the row's ten pixels, one term at a time (ten values + ten remainders live)
+                            float v[10], t[10];
+#pragma unroll
+                            for (int i = 0; i < 10; ++i) v[i] = xr[(px + i) * 64 + b_off];
+                            bf16x8 b3[3][3];                        // [tap dx][term]
+#pragma unroll
+                            for (int e = 0; e < 3; ++e) {
+#pragma unroll
+                                for (int i = 0; i < 10; ++i) {
+                                    t[i] = e < 2 ? bf16_round(v[i]) : v[i];          // (the last remainder is rounded as it is packed)
+                                    v[i] -= t[i];
+                                }
+#pragma unroll
+                                for (int dx = 0; dx < 3; ++dx)
+                                    b3[dx][e] = pack_bf16x8(make_float4(t[dx], t[dx + 1], t[dx + 2], t[dx + 3]),
+                                                            make_float4(t[dx + 4], t[dx + 5], t[dx + 6], t[dx + 7]));
+                            }
+                            constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};      // a1 b3, a3 b1, a2 b2, a1 b2, a2 b1, a1 b1
+#pragma unroll
+                            for (int k6 = 0; k6 < 6; ++k6)
+#pragma unroll
+                                for (int dx = 0; dx < 3; ++dx) acc[3 * r + dx] = mfma_bf16_32x32x16(a3[TA[k6]], b3[dx][TB[k6]], acc[3 * r + dx]);
+                        }
+                        continue;
+                    }
                     const bf16x8 a8 = pack_bf16x8(make_float4(av[0], av[1], av[2], av[3]), make_float4(av[4], av[5], av[6], av[7]));
 #pragma unroll
                     for (int r = 0; r < 3; ++r) {
@@ -386,7 +422,8 @@ extern "C" int fiery_conv_wgrad(const float* in, int in_ld, int64_t in_img_strid
 extern "C" int fiery_conv_wgrad_prec(const float* in, int in_ld, int64_t in_img_stride, int cin_units, const float* grad_out,
                                      int g_ld, int64_t g_img_stride, int cout, int n_img, int Hin, int Win, int Hout, int Wout, int kH,
                                      int kW, int stride, int padH, int padW, int precision, float* dw, fiery_stream_t stream) {
-    FIERY_REQUIRE(precision == FIERY_PRECISION_F32 || precision == FIERY_PRECISION_BF16, "conv_wgrad: unknown precision %d", precision);
+    FIERY_REQUIRE(precision == FIERY_PRECISION_F32 || precision == FIERY_PRECISION_BF16 || precision == FIERY_PRECISION_F32_SPLIT,
+                  "conv_wgrad: unknown precision %d", precision);
     FIERY_REQUIRE(in && grad_out && dw, "conv_wgrad: null pointer");
     FIERY_REQUIRE(cin_units > 0 && cout > 0 && n_img > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "conv_wgrad: bad shape");
     FIERY_REQUIRE(kH >= 1 && kW >= 1 && stride >= 1 && padH >= 0 && padW >= 0, "conv_wgrad: bad kernel geometry");
@@ -441,7 +478,8 @@ extern "C" int fiery_conv_wgrad_prec(const float* in, int in_ld, int64_t in_img_
             q.row_parts = ceil_div(Hout, q.rows_per_wg);
             FIERY_REQUIRE(static_cast<long long>(n_img) * q.row_parts < 65536, "conv_wgrad: grid too large");
             const dim3 grid3(q.co_tiles * q.c_tiles * q.n_seg, n_img * q.row_parts);
-            if (precision == FIERY_PRECISION_BF16) hipLaunchKernelGGL(k_conv_wgrad3x3<true>, grid3, dim3(256), 0, as_stream(stream), q);
+            if (precision == FIERY_PRECISION_F32_SPLIT) hipLaunchKernelGGL((k_conv_wgrad3x3<true, true>), grid3, dim3(256), 0, as_stream(stream), q);
+            else if (precision == FIERY_PRECISION_BF16) hipLaunchKernelGGL(k_conv_wgrad3x3<true>, grid3, dim3(256), 0, as_stream(stream), q);
             else hipLaunchKernelGGL(k_conv_wgrad3x3<false>, grid3, dim3(256), 0, as_stream(stream), q);
             return check_launch("conv_wgrad (3x3 staged)");
         }

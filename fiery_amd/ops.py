@@ -127,12 +127,16 @@ class ConvOp:
     """
 
     def __init__(self, lib, weight, chan_map, units, scale, shift, device, stride=1, pad=None,
-                 act=native.ACT_NONE, epi=native.EPI_PLAIN, res_before_act=False, precision=None, tune=True):
+                 act=native.ACT_NONE, epi=native.EPI_PLAIN, res_before_act=False, precision=None, tune=True, forms=None):
         """tune: time both tile heights the first time a shape is launched (`_pick_tile`); False for one-shot ops.
         precision: native.PRECISION_F32 / PRECISION_BF16 (None: `ops.DEFAULT_PRECISION`) - bf16 rounds the matrix-core
         operands (weights here, activations on chip), accumulates in fp32; launches the bf16 kernel does not cover run in fp32."""
         self.lib = lib
         self.precision = DEFAULT_PRECISION if precision is None else precision
+        # the optional forms whose weight images are packed (each is one device kernel per op): all of them for ops that time their
+        # candidates, the fp32 Winograd image alone for one-shot ops (the training graph packs per call and names what it wants)
+        if forms is None:
+            forms = ('wino', 'wsplit', 'split') if tune else ('wino',)
         w = weight.detach().to(device=device, dtype=torch.float32).contiguous()
         self.cout, self.cin_total = w.shape[0], w.shape[1]
         kernel = tuple(w.shape[2:])
@@ -153,22 +157,23 @@ class ConvOp:
         # the split image (fp32 accuracy on the bf16 matrix cores: three bf16 terms per operand) for the layers the library's
         # split tile kernels cover - whole 32-channel stages, 32- or 64-wide cout tiles: a candidate form of `_pick_tile` ('split')
         self.packed_split = None
-        if (SPLIT_TILES and self.precision == native.PRECISION_F32 and cin_units % 4 == 0 and self.units[0] % 4 == 0 and
+        if ('split' in forms and SPLIT_TILES and self.precision == native.PRECISION_F32 and cin_units % 4 == 0 and self.units[0] % 4 == 0 and
                 self.cout_pad % 128 != 0):
             self.packed_split = lib.conv_pack_weights_split(w.view(self.cout, self.cin_total, taps), self.cout, self.cin_total, taps,
                                                             list(chan_map), cin_units)
         # Winograd F(2x2, 3x3) image of the weights for the layers that form covers (3 x 3 / stride 1 / 'same', whole 16-channel
         # stages per source, 64-cout tiles; fp32 only): a candidate form of `_pick_tile`
         self.packed_winograd = self.packed_winograd_split = None
-        if (WINOGRAD and self.precision == native.PRECISION_F32 and (self.kT, self.kH, self.kW) == (1, 3, 3) and stride == 1 and
+        if (WINOGRAD and ('wino' in forms or 'wsplit' in forms) and self.precision == native.PRECISION_F32 and (self.kT, self.kH, self.kW) == (1, 3, 3) and stride == 1 and
                 (self.padH, self.padW) == (1, 1) and self.cout_pad % 64 == 0 and all(u % 2 == 0 for u in self.units) and
                 # (what the library's scalar-addressed loop - the only one with a Winograd form - asks of the channel layout:
                 # whole 32-channel stages per tap and in source 0; a launch can still fall back on extents, see `_winograd_taken`)
                 cin_units % 4 == 0 and self.units[0] % 4 == 0 and cin_units >= 4):
-            self.packed_winograd = lib.conv_pack_weights_winograd(w.view(self.cout, self.cin_total, taps), self.cout, self.cin_total,
-                                                                  list(chan_map), cin_units)
+            if 'wino' in forms:
+                self.packed_winograd = lib.conv_pack_weights_winograd(w.view(self.cout, self.cin_total, taps), self.cout, self.cin_total,
+                                                                      list(chan_map), cin_units)
             # the same form on the bf16 matrix cores, every operand as three bf16 terms (fp32 accuracy; 'wsplit')
-            if WINOGRAD_SPLIT:
+            if WINOGRAD_SPLIT and 'wsplit' in forms:
                 self.packed_winograd_split = lib.conv_pack_weights_winograd_split(
                     w.view(self.cout, self.cin_total, taps), self.cout, self.cin_total, list(chan_map), cin_units)
         if torch.is_tensor(scale) and scale.device == w.device and scale.numel() == self.cout_pad:
@@ -279,11 +284,14 @@ class ConvOp:
         """Whether the library runs THIS launch as Winograd when asked to (the packed image exists for every 3 x 3 / stride 1
         layer with whole 16-channel stages; the launch also needs the aligned, 16-byte addressable variant, an unchained
         epilogue, ... - `fiery_conv_form_used` knows).  Leaves the descriptor's form members as it found them."""
-        if self.packed_winograd is None:
+        if self.packed_winograd is None and self.packed_winograd_split is None:
             return False
         keep = (d.winograd, d.weights_winograd)
-        d.winograd, d.weights_winograd = 1, self.packed_winograd.data_ptr()
-        taken = self.lib.conv_form_used(d) == native.CONV_FORM_WINOGRAD
+        if self.packed_winograd is not None:
+            d.winograd, d.weights_winograd = 1, self.packed_winograd.data_ptr()
+        else:
+            d.winograd, d.weights_winograd = native.WINOGRAD_SPLIT_TERMS, self.packed_winograd_split.data_ptr()
+        taken = self.lib.conv_form_used(d) in (native.CONV_FORM_WINOGRAD, native.CONV_FORM_WINOGRAD_SPLIT)
         d.winograd, d.weights_winograd = keep
         return taken
 
@@ -310,7 +318,7 @@ class ConvOp:
         narrow = self.cout_pad % 64 != 0 or self.chain is not None       # one fp32 tile shape: the choice is fp32 / split
         if (narrow and self.packed_split is None) or (not self.tune and self.force_form is None):
             return                                     # one tile shape only (or: library heuristic; a forced form is honoured)
-        if self.heads is not None and self.packed_winograd is None:
+        if self.heads is not None and self.packed_winograd is None and self.packed_winograd_split is None:
             return                                     # (the heads' direct form has one tile shape)
         key = (out.n_img, out.H, out.W)
         choice = self.force_form                       # (a forced form - per op, or FIERY_CONV_FORM for all - goes before the table)
@@ -330,11 +338,11 @@ class ConvOp:
         if choice is None:
             if FORM_TABLE_FROZEN or not _autotune_enabled(out.tensor):
                 return                                 # library heuristic (and nothing cached: tune when possible)
-            forms = [64, 128] + (['sk'] if sk is not None else []) + (['wino'] if self._winograd_taken(d) else [])
+            wino_forms = ((['wino'] if self.packed_winograd is not None else []) +
+                          (['wsplit'] if self.packed_winograd_split is not None else [])) if self._winograd_taken(d) else []
+            forms = [64, 128] + (['sk'] if sk is not None else []) + wino_forms
             if self.heads is not None:
-                forms = [0, 'wino'] if 'wino' in forms else [0]     # heads epilogue: the direct form's one tile shape, or Winograd
-            if 'wino' in forms and self.packed_winograd_split is not None:
-                forms.append('wsplit')
+                forms = [0] + wino_forms               # heads epilogue: the direct form's one tile shape, or Winograd
             if narrow:
                 forms = [0]
             if self.heads is None and self._split_taken(d):

@@ -604,7 +604,12 @@ def test_gru_epilogues_and_chained_tail_on_the_bf16_form(sim, monkeypatch, tile_
                                                    # the staged 1 x 1 form: flat 96-pixel chunks, ragged last chunk, narrow blocks, padded channels
                                                    (64, 32, 1, 1, (9, 14)), (32, 64, 1, 1, (7, 11)), (35, 36, 1, 1, (6, 25)), (128, 128, 1, 1, (5, 20)),
                                                    (70, 64, 1, 1, (1, 1))])
-def test_conv_wgrad_matches_autograd(sim, cin, cout, k, stride, hw):
+@pytest.mark.parametrize('precision', ['f32', 'split'])
+def test_conv_wgrad_matches_autograd(sim, cin, cout, k, stride, hw, precision):
+    """precision = 'split' (round 6, FIERY_PRECISION_F32_SPLIT): the staged 3 x 3 kernel's loop on the bf16 matrix cores with both
+    operands as three bf16 terms - an fp32-accurate mode, same tolerance (kernels without the mode run fp32)."""
+    if precision == 'split' and not (k == 3 and stride == 1):
+        pytest.skip('the split mode belongs to the staged 3 x 3 kernel')
     g = torch.Generator().manual_seed(cin + cout)
     x = torch.randn(2, cin, *hw, generator=g)
     w = torch.randn(cout, cin, k, k, generator=g, requires_grad=True)
@@ -616,7 +621,7 @@ def test_conv_wgrad_matches_autograd(sim, cin, cout, k, stride, hw):
     xb = torch.zeros(2, hw[0], hw[1], cin_pad)
     xb[..., :cin] = x.permute(0, 2, 3, 1)
     gb = gy.permute(0, 2, 3, 1).contiguous()
-    dw = sim.conv_wgrad(xb, gb, cout, k, stride, pad)                      # (cout, taps, cin_pad)
+    dw = sim.conv_wgrad(xb, gb, cout, k, stride, pad, native.PRECISION_F32_SPLIT if precision == 'split' else native.PRECISION_F32)   # (cout, taps, cin_pad)
     got = dw[:, :, :cin].permute(0, 2, 1).reshape(cout, cin, k, k)
     assert torch.allclose(got, w.grad, rtol=1e-4, atol=1e-4), (got - w.grad).abs().max()
     assert dw[:, :, cin:].abs().max() == 0 if cin_pad > cin else True      # padded channels see zero inputs
