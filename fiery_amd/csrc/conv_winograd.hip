@@ -169,12 +169,13 @@ __global__ void k_pack_winograd_split(const float* __restrict__ w, int cout, int
 // 8 (round 5, second form): two points per wavefront - 64 accumulator registers, the kernel held to 128 registers, FOUR
 // wavefronts per SIMD: twice as many MFMA streams to fill the gaps a stream leaves at its barriers and operand waits; a thread
 // then transforms one channel of a block (4-byte pieces) instead of two, and the first four wavefronts run the epilogue's rows.
-template <int KIND, int NW>
+// (SPLIT: a template parameter so that the two forms have different kernel names in profiles)
+template <int KIND, int NW, bool SPLIT = (FIERY_WINOGRAD_SPLIT != 0)>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_conv_winograd(ConvP p) {
     static_assert(NW == 4 || NW == 8, "four or eight wavefronts");
     constexpr int PP = 16 / NW;                        // transform points per wavefront
     constexpr bool LEAN = KIND >= 0 && KIND <= 4;
-    constexpr bool SPLIT = FIERY_WINOGRAD_SPLIT != 0;  // bf16 matrix cores, three-term operands (see the head of the file)
+    // (SPLIT: bf16 matrix cores, three-term operands - see the head of the file)
     static_assert(!SPLIT || NW == 4, "the split form: four wavefronts");
     __shared__ __attribute__((aligned(16))) float smem[W_SMEM_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -867,7 +868,7 @@ bool conv_launch_winograd(const ConvP& p, hipStream_t stream) {
     if (const char* e = getenv("FIERY_WINOGRAD_WAVES")) waves = atoi(e) == 8 ? 8 : atoi(e) == 4 ? 4 : waves;
     if (kind < 0) waves = 4;                                // (the general fallback does not fit 128 registers)
 #if FIERY_WINOGRAD_SPLIT
-#define FIERY_WINO_LAUNCH(K_) hipLaunchKernelGGL((k_conv_winograd<K_, 4>), grid, dim3(256), 0, stream, p)
+#define FIERY_WINO_LAUNCH(K_) hipLaunchKernelGGL((k_conv_winograd<K_, 4, true>), grid, dim3(256), 0, stream, p)
 #else
 #define FIERY_WINO_LAUNCH(K_)                                                                                  \
     do {                                                                                                       \

@@ -29,7 +29,7 @@ for m in ('one_stream', 'sample_streams', 'sample_streams_graph'):
     cp(f'kernel_stats_{m}.csv', f'r6_kernel_stats_{m}.csv')
 for a in ('launches.json', 'launches_bf16.json', 'launches_table.txt', 'launches_table_bf16.txt', 'mfma_util.txt', 'mfma_ceiling.txt',
           'pool_ceiling.txt', 'pytest_gpu.txt', 'parity_errors.json', 'smoke.txt', 'winograd_check.txt', 'stream_k_check.txt',
-          'train_step.txt', 'conv_forms.json'):
+          'train_step.txt', 'conv_forms.json', 'split_bf16_probe.txt', 'winograd_split_times.txt', 'split_tile_times.txt', 'wgrad_times.txt'):
     cp(a, 'r6_' + a)
 cp('pool/summary.txt', 'r6_pool_ab_final.txt')
 cp('pool_trace/phases.txt', 'r6_pool_phases.txt')

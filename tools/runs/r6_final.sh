@@ -11,6 +11,9 @@ mkdir -p $O
 timeout 1800 python -m pytest tests -q -m gpu > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
 cp $R/gpurun_out/parity_errors.json $O/parity_errors.json 2>/dev/null
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
+hipcc --offload-arch=gfx950 -O2 -w tools/probe/split_bf16_probe.hip -o /tmp/split_probe && timeout 120 /tmp/split_probe > $O/split_bf16_probe.txt 2>&1; tail -2 $O/split_bf16_probe.txt
+{ for r in 1 2; do for f in wino wsplit; do echo -n "$f  "; FORM=$f timeout 200 python tools/runs/r5_wino_times.py 2>&1 | tail -1; done; done; } > $O/winograd_split_times.txt; tail -2 $O/winograd_split_times.txt | cut -c1-200
+timeout 300 python tools/runs/r6_split_times.py 2>&1 | grep -v amdgpu.ids > $O/split_tile_times.txt; timeout 300 python tools/runs/r6_wgrad_times.py 2>&1 | grep -v amdgpu.ids > $O/wgrad_times.txt
 hipcc --offload-arch=gfx950 -O3 -w tools/probe/mfma_ceiling.hip -o /tmp/mfma_ceiling && timeout 120 /tmp/mfma_ceiling > $O/mfma_ceiling.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 -w tools/probe/pool_ceiling.hip -o /tmp/pool_ceiling && timeout 200 /tmp/pool_ceiling 9 0.9409 > $O/pool_ceiling.txt 2>&1; tail -2 $O/pool_ceiling.txt
 FIERY_BENCH_DUMP=$O/launches.json timeout 1200 python bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
