@@ -659,7 +659,12 @@ def main():
                       'encoder outputs to output dict)',
             'value': round(B * world * args.steps / elapsed, 3), 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'f32' else 'bf16 (matrix-core operands; fp32 accumulate, activations, epilogues)', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'f32' else 'bf16 (matrix-core operands; fp32 accumulate, activations, epilogues)',
+            # (what "f32" means on the matrix cores since round 6; `roofline.by_form` says which launches ran how)
+            'arithmetic': ('fp32 tensors, fp32 accumulation; matrix products on v_mfma_f32_32x32x2_f32 or - the split forms - as six bf16 partial '
+                           'products of operands written as three bf16 terms each (exact), measured not less accurate than the fp32 instruction '
+                           '(profiles/r6_split_bf16_probe.txt); `fp32_instruction_only`: the step without them') if args.precision == 'f32' else None,
+            'data': 'synthetic',
             'config': {'workload': f'{args.config}: {n_cam} cams x {rf} past frames -> {model.bev_size[0]}x{model.bev_size[1]} BEV, '
                                    f'{nf} future frames, batch {B} per GPU, {"fp32" if args.precision == "f32" else "bf16 convolutions"}, '
                                    f'{"fused lift-splat from depth+features" if args.fused else "lifted features (n,C,D,h,w) resident in HBM"}',
@@ -773,6 +778,20 @@ def main():
                                                                              'roofline_pooling', 'host_enqueue_ms_per_step')}
                 except Exception as e:                               # noqa: BLE001  (the headline line must not depend on it)
                     line['secondary_configs'][key] = {'error': repr(e)[:200]}
+            # ... and the headline workload once more with the split forms taken out of the candidates: every matrix product on the
+            # fp32 instruction (v_mfma_f32_32x32x2_f32) - what the step ran as until round 6, beside the headline, never as `value`
+            cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(args.steps), '--warmup', str(args.warmup), '--batch', str(B),
+                   '--no-cpu-baseline', '--no-from-images', '--no-bf16-mode', '--no-secondary-configs']
+            try:
+                env = {k: v for k, v in os.environ.items() if k != 'FIERY_BENCH_DUMP'}
+                env.update(FIERY_CONV_WINOGRAD_SPLIT='0', FIERY_CONV_SPLIT='0')
+                res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+                sub = json.loads([l_ for l_ in res.stdout.strip().splitlines() if l_.startswith('{')][-1])
+                line['fp32_instruction_only'] = {'value': sub.get('value'), 'unit': sub.get('unit'), 'ms_per_step': sub.get('ms_per_step'),
+                                                 'roofline': {k: (sub.get('roofline') or {}).get(k) for k in ('kernel', 'achieved', 'peak', 'frac', 'kernel_ms_per_step')},
+                                                 'what': 'the same workload in a process of its own with FIERY_CONV_WINOGRAD_SPLIT=0 FIERY_CONV_SPLIT=0'}
+            except Exception as e:                                   # noqa: BLE001
+                line['fp32_instruction_only'] = {'error': repr(e)[:200]}
         print(json.dumps(line), flush=True)
     if use_dist:
         import torch.distributed as dist
