@@ -191,7 +191,11 @@ constexpr int conv_smem_floats(int bm, int bn, bool bf16, bool halo = false, boo
     const int full = 2 * bm * BK + 2 * BK * bn;
     if (!halo && !bf16) return full;
     // (split form: three bf16 images of either operand)
-    const int stages = halo ? 3 * (bm + HALO_RUN_EXTRA) * halo_pitch(bf16) : split ? 3 * (full / 2) : full / 2;
+    // (... of the weights always; of the A tile where several wavefronts read an element - 64-wide cout tiles; on the 32-wide
+    // tiles every A element has ONE reader, the tile stays fp32 in LDS and is split by that reader: a third less LDS, three
+    // workgroups per CU instead of two)
+    const int stages = halo ? 3 * (bm + HALO_RUN_EXTRA) * halo_pitch(bf16)
+                            : split ? (bn == 32 ? 2 * bm * BK + 3 * BK * bn : 3 * (full / 2)) : full / 2;
     const int epilogue = chain ? 4 * 32 * CHAIN_PITCH : bm * bn + (bm == 64 && bn == 128 ? 256 : 0);       // staging tile (+ the decoder heads' 1x1 rows)
     return stages > epilogue ? stages : epilogue;
 }
@@ -203,7 +207,7 @@ constexpr int conv_smem_floats(int bm, int bn, bool bf16, bool halo = false, boo
 #endif
 constexpr int conv_waves_per_simd(int bm, int bn, bool aligned = false, bool bf16 = false, bool halo = false, bool chain = false, bool split = false) {
     const int by_lds = 163840 / (conv_smem_floats(bm, bn, bf16, halo, chain, split) * 4);
-    if (split) return by_lds < 2 ? by_lds : 2;                              // (three operand images per MFMA block in registers: 256 registers)
+    if (split) return by_lds < (bn == 32 ? 3 : 2) ? by_lds : (bn == 32 ? 3 : 2);      // (three operand images per MFMA block in registers)
     int cap = ((bm == 64 && bn == 64) || (FIERY_TAIL_FOUR_PER_CU && bm == 128 && bn == 32 && aligned)) ? 4 : 3;
     if (bf16 && !(bm == 128 && bn == 32)) cap = FIERY_BF16_WAVES;         // (128 x 32: its chained epilogue needs 150)
     if (halo && !bf16) cap = FIERY_HALO_F32_WAVES;
@@ -238,6 +242,10 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
     static_assert(!BF16 || (ALIGNED && !SMALLCIN && !CLK), "the bf16 form exists for the scalar-addressed loop");
     static_assert(!SPLIT || (BF16 && !HALO && BN <= 64), "the split form: the scalar-addressed bf16 loop, cout tiles of 32 or 64");
     constexpr int NS = SPLIT ? 3 : 1;                 // bf16 terms per operand
+    // SPLIT_READ: the A tile stays fp32 in LDS (the fp32 kernel's image) and the wavefront that multiplies a row splits it as it
+    // reads it - on the 32-wide cout tiles (one wavefront column) nobody else reads that row, so the split costs the same vector
+    // instructions as at the writing side and the tile takes 16 KB per stage instead of 24
+    constexpr bool SPLIT_READ = SPLIT && BN == 32;
     static_assert(!HALO || (ALIGNED && !SMALLCIN && !CLK && BN >= 64 && (BM == 64 || BF16)), "the halo loop: 64-pixel tiles (bf16: 128 too), 64 couts or more");
     unsigned long long clk_entry = 0;
     // (tuning builds: slot 7 of the probe block may hold the address of a timeline buffer - eight 64-bit words per tile: the
@@ -283,7 +291,7 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
     constexpr bool HALF_STAGES = BF16 && !HALO;
     constexpr int A_PLANE = BM * (BK / 2);                                // floats of one bf16 image of the A tile
     constexpr int W_PLANE = BK * BN / 2;
-    constexpr int A_STAGE = HALF_STAGES ? NS * A_PLANE : BM * BK;         // floats between the two A stages
+    constexpr int A_STAGE = SPLIT_READ ? BM * BK : HALF_STAGES ? NS * A_PLANE : BM * BK;         // floats between the two A stages
     constexpr int W_STAGE = HALF_STAGES ? NS * W_PLANE : BK * BN;
     constexpr int W_BASE = 2 * A_STAGE;
     constexpr int SMEM_FLOATS = conv_smem_floats(BM, BN, BF16, HALO, CHAIN, SPLIT);
@@ -587,7 +595,8 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
     const int a_st16 = prow * 16 + (((f4 >> 1) ^ ((prow >> 2) & 3)) << 2) + (f4 & 1) * 2;     // + 32 j 16 + buf A_STAGE
     auto store_a = [&](int buf, int j) {
         const float4 v = j == 0 ? areg0 : j == 1 ? areg1 : j == 2 ? areg2 : areg3;
-        if constexpr (SPLIT) {
+        if constexpr (SPLIT_READ) *reinterpret_cast<float4*>(&smem[a_st + 32 * j * BK + buf * A_STAGE]) = v;
+        else if constexpr (SPLIT) {
             // x = t1 + t2 + t3: the remainders are exact in fp32
             auto minus = [](const float4& x, const float4& y) { return make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w); };
             const uint2 t1 = pack_bf16x4(v);
@@ -879,9 +888,18 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
             for (int kh = 0; kh < 2; ++kh) {
                 bf16x8 a8[MT][3], b8[NT][3];
 #pragma unroll
-                for (int t = 0; t < MT; ++t)
+                for (int t = 0; t < MT; ++t) {
+                    if constexpr (SPLIT_READ) {
+                        // the lane's eight k (16 kh + 8 hi ..) are slots 4 kh + 2 hi, + 1 of its row of the fp32 image
+                        const float4 lo = *reinterpret_cast<const float4*>(&smem[a_row * BK + (((4 * kh + 2 * hi) ^ ((a_row >> 1) & 7)) << 2) + 32 * t * BK + buf * A_STAGE]);
+                        const float4 up = *reinterpret_cast<const float4*>(&smem[a_row * BK + (((4 * kh + 2 * hi + 1) ^ ((a_row >> 1) & 7)) << 2) + 32 * t * BK + buf * A_STAGE]);
+                        const float x[8] = {lo.x, lo.y, lo.z, lo.w, up.x, up.y, up.z, up.w};
+                        split_bf16x8(x, a8[t][0], a8[t][1], a8[t][2]);
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 3; ++e) a8[t][e] = load_bf16x8(&smem[a_rd16[kh] + 32 * t * 16 + e * A_PLANE + buf * A_STAGE]);
+                        for (int e = 0; e < 3; ++e) a8[t][e] = load_bf16x8(&smem[a_rd16[kh] + 32 * t * 16 + e * A_PLANE + buf * A_STAGE]);
+                    }
+                }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
