@@ -396,8 +396,7 @@ def main():
         # The SPLIT Winograd form (round 6) runs those 16 / 36 on the bf16 matrix cores with every fp32 operand as three bf16 terms:
         # six bf16 MFMAs per product block - its executed flops are 6 x 16 / 36 of the direct count, priced against the bf16 peak.
         WINO = 16.0 / 36.0
-        # The split TILE form ('f32 split'): six bf16 MFMAs per fp32 product of the convolution itself; a chained tail's 1x1
-        # products stay on the fp32 instruction ('f32 split + fp32 chain': the two parts are priced against their own peaks).
+        # The split TILE form ('f32 split', 'f32 split + chain' for the Bottleneck tails): six bf16 MFMAs per fp32 product.
         peak_of = lambda form: PEAK_BF16_MFMA_TFLOPS if ('bf16' in str(form) or 'split' in str(form)) else PEAK_F32_MFMA_TFLOPS
 
         def executed_parts(w, d):                                         # [(executed matrix flops, peak of their instruction)]
@@ -405,8 +404,7 @@ def main():
             if 'winograd' in form:
                 return [(w * WINO * (6.0 if 'split' in form else 1.0), peak_of(form))]
             if form.startswith('f32 split'):
-                main = min(w, 2.0 * d[6] * d[7] * d[8] * d[4] * d[0] * d[1] * d[2] * d[5])      # images x H x W x cin x taps x cout
-                return [(6.0 * main, PEAK_BF16_MFMA_TFLOPS), (w - main, PEAK_F32_MFMA_TFLOPS)]
+                return [(6.0 * w, PEAK_BF16_MFMA_TFLOPS)]                # (a chained tail's 1x1 products run split too)
             return [(w, peak_of(form))]
         executed_of = lambda w, d: sum(x_ for x_, _ in executed_parts(w, d))
         pipe_s_of = lambda w, d: sum(x_ / (pk_ * 1e12) for x_, pk_ in executed_parts(w, d))          # seconds at the matrix peak
@@ -466,7 +464,7 @@ def main():
         KERNEL_OF = {'f32': 'k_conv_igemm (fp32 MFMA implicit GEMM, direct tile forms)', 'f32 stream-K': 'k_conv_igemm<SK> (fp32 MFMA implicit GEMM, stream-K)',
                      'f32 winograd': 'k_conv_winograd (Winograd F(2x2,3x3) on the fp32 matrix cores)',
                      'f32 split': 'k_conv_igemm<SPLIT> (implicit GEMM, fp32 operands as three bf16 terms, six products each on the bf16 matrix cores)',
-                     'f32 split + fp32 chain': 'k_conv_igemm<SPLIT, CHAIN> (Bottleneck tails: 3x3 as three-term bf16 products, chained 1x1s on the fp32 instruction)',
+                     'f32 split + chain': 'k_conv_igemm<SPLIT, CHAIN> (Bottleneck tails: the 3x3 and the chained 1x1s as three-term bf16 products)',
                      'f32 winograd split': 'k_conv_winograd, split form (Winograd F(2x2,3x3), fp32 operands as three bf16 terms, six products each on the '
                                            'bf16 matrix cores, fp32 accumulation: fp32 accuracy)',
                      'bf16': 'k_conv_igemm (bf16 operands, fp32 accumulate, MFMA implicit GEMM)'}

@@ -549,7 +549,9 @@ int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, ConvRunMode mode, 
     // split form of the scalar-addressed loop (FIERY_PRECISION_F32_SPLIT with the image of fiery_conv_pack_weights_split in
     // weights_bf16): 128-pixel tiles of 32 (the chained tails too) or 64 couts; everything else runs the fp32 kernels
     const bool split_tile = !stream_k && !winograd && d->precision == FIERY_PRECISION_F32_SPLIT && d->weights_bf16 && aligned && cin_units >= 4 &&
-                            bm == 128 && (bn == 32 || bn == 64) && d->epi != FIERY_EPI_HEADS && !getenv("FIERY_CONV_CLKPROBE") && !getenv("FIERY_CONV_PRIO");
+                            bm == 128 && (bn == 32 || bn == 64) && d->epi != FIERY_EPI_HEADS && !getenv("FIERY_CONV_CLKPROBE") && !getenv("FIERY_CONV_PRIO") &&
+                            (!d->weights2 || (d->weights2_split && aligned16(d->weights2_split))) &&
+                            (!d->weights3 || (d->weights3_split && aligned16(d->weights3_split)));
     const bool split = winograd && d->winograd == FIERY_WINOGRAD_SPLIT_TERMS;      // weights_winograd is the split image then
     if (mode == kRunForm) return winograd ? (split ? FIERY_CONV_FORM_WINOGRAD_SPLIT : FIERY_CONV_FORM_WINOGRAD) : (stream_k ? FIERY_CONV_FORM_STREAM_K : FIERY_CONV_FORM_TILE);
     if (!launch) return bf16 ? FIERY_PRECISION_BF16 : split_tile ? FIERY_PRECISION_F32_SPLIT : FIERY_PRECISION_F32;
@@ -581,6 +583,8 @@ int conv_run(const fiery_conv_desc* d, fiery_stream_t stream, ConvRunMode mode, 
     if (split_tile) {
         FIERY_REQUIRE(aligned16(d->weights_bf16), "conv_fwd: split weights must be 16-byte aligned");
         p.w = static_cast<const float*>(d->weights_bf16);
+        if (d->weights2) p.w2 = static_cast<const float*>(d->weights2_split);          // (the chained products run split too)
+        if (d->weights3) p.heads.w = static_cast<const float*>(d->weights3_split);
         if (!conv_launch_split(p, bn, grid, hs)) return fail(FIERY_EINVAL, "conv_fwd: no split kernel for %d-wide cout tiles", bn);
         return check_launch("conv_fwd (split)");
     }

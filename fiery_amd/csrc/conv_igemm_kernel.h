@@ -1360,11 +1360,17 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
         };
         // the second product's weights are requested first - the packed image [k / 4][cout][k % 4] IS the order the accumulator
         // registers hold their couts in: k = c(4 g + j, hi) sits at piece 2 g + hi, element j
-        float4 w2r[8];
+        // (SPLIT: p.w2 is the split image [term][k half][cout block][lane] of 16-byte operands - fiery_conv_desc.weights2_split)
+        float4 w2r[SPLIT ? 12 : 8];
+        if constexpr (SPLIT) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+            for (int q = 0; q < 12; ++q) w2r[q] = reinterpret_cast<const float4*>(p.w2)[q * 64 + lane];
+        } else {
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) w2r[g * 2 + nt] = reinterpret_cast<const float4*>(p.w2)[(2 * g + hi) * 64 + nt * 32 + m];
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) w2r[g * 2 + nt] = reinterpret_cast<const float4*>(p.w2)[(2 * g + hi) * 64 + nt * 32 + m];
+        }
         const int wpix0 = pix0 + wm * 32;                            // this wavefront's 32 pixels
         // where a pixel's row starts in a tensor (floats from its base): dense tensors - images back to back - need one multiply
         const bool dense = (p.vec_epilogue & 2) != 0;
@@ -1399,7 +1405,21 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[nt][r] = 0.f;
-        if constexpr (BF16 && !SPLIT) {                  // (split form: the chained 1 x 1 products run on the fp32 instruction)
+        if constexpr (SPLIT) {
+            // three-term operands, six partial products (smallest first), like the K loop: h is split here, W2 arrived split
+            constexpr int TW[6] = {0, 2, 1, 0, 1, 0}, TH[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float x[8] = {h[8 * i], h[8 * i + 1], h[8 * i + 2], h[8 * i + 3], h[8 * i + 4], h[8 * i + 5], h[8 * i + 6], h[8 * i + 7]};
+                bf16x8 hb[3];
+                split_bf16x8(x, hb[0], hb[1], hb[2]);
+#pragma unroll
+                for (int k6 = 0; k6 < 6; ++k6)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc2[nt] = mfma_bf16_32x32x16(bits_bf16x8(w2r[(TW[k6] * 2 + i) * 2 + nt]), hb[TH[k6]], acc2[nt]);
+            }
+        } else if constexpr (BF16) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const bf16x8 hb = pack_bf16x8(make_float4(h[8 * i], h[8 * i + 1], h[8 * i + 2], h[8 * i + 3]),
@@ -1436,10 +1456,16 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
         }
         // the third product's weights (the NEXT block's 1 x 1 down-projection, 64 -> 32): packed [k / 32][k % 32 / 4][cout][k % 4]
         const bool third = p.heads.w != nullptr;
-        float4 w3r[8];
+        // (SPLIT: p.heads.w is the split image [term][k block of 32][half][lane] - fiery_conv_desc.weights3_split)
+        float4 w3r[SPLIT ? 12 : 8];
+        if constexpr (SPLIT) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            w3r[i] = third ? reinterpret_cast<const float4*>(p.heads.w)[(i >> 2) * 256 + (2 * (i & 3) + hi) * 32 + m] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < 12; ++q) w3r[q] = third ? reinterpret_cast<const float4*>(p.heads.w)[q * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                w3r[i] = third ? reinterpret_cast<const float4*>(p.heads.w)[(i >> 2) * 256 + (2 * (i & 3) + hi) * 32 + m] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         // (3) the accumulators through the wavefront's exchange tile into rows: BN + activation + residual (after the
         //     activation) on full rows - a lane's four channels are the same for all its rows, so scale / shift are two loads
         float4* const xt = reinterpret_cast<float4*>(smem + wv * (32 * CHAIN_PITCH));       // [32 rows][17 x 16 bytes]
@@ -1480,7 +1506,18 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
                 float4 y4[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) y4[g] = xt[m * XP + nt * 8 + 2 * g + hi];
-                if constexpr (BF16 && !SPLIT) {
+                if constexpr (SPLIT) {
+                    constexpr int TW[6] = {0, 2, 1, 0, 1, 0}, TY[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const float x[8] = {y4[2 * i].x, y4[2 * i].y, y4[2 * i].z, y4[2 * i].w, y4[2 * i + 1].x, y4[2 * i + 1].y, y4[2 * i + 1].z, y4[2 * i + 1].w};
+                        bf16x8 yb[3];
+                        split_bf16x8(x, yb[0], yb[1], yb[2]);
+#pragma unroll
+                        for (int k6 = 0; k6 < 6; ++k6)
+                            acc3 = mfma_bf16_32x32x16(bits_bf16x8(w3r[(TW[k6] * 2 + nt) * 2 + i]), yb[TY[k6]], acc3);
+                    }
+                } else if constexpr (BF16) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
                         acc3 = mfma_bf16_32x32x16(pack_bf16x8(w3r[nt * 4 + 2 * i], w3r[nt * 4 + 2 * i + 1]), pack_bf16x8(y4[2 * i], y4[2 * i + 1]), acc3);

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libfiery_hip.so')
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -72,6 +72,7 @@ class ConvDesc(C.Structure):
         ('weights_winograd', C.c_void_p), ('winograd', C.c_int32),
         ('stream_k', C.c_int32), ('sk_workspace', C.c_void_p), ('sk_workspace_bytes', C.c_int64),
         ('sk_counters', C.c_void_p), ('sk_counters_len', C.c_int32),
+        ('weights2_split', C.c_void_p), ('weights3_split', C.c_void_p),
     ]
 
 

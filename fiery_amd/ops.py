@@ -44,6 +44,33 @@ def pool_algorithmic_bytes(detail):
     return 4.0 * c * n_kept + 12.0 * n_points + 4.0 * c * detail['voxels'] * detail['frames'], n_kept
 
 
+def _chain_split_image(w, blocks_outer):
+    """The split image of a chained 1 x 1's weights for the split tile kernels (`fiery_conv_desc.weights2_split / weights3_split`):
+    w (rows, K) fp32 with rows a multiple of 32 and K a multiple of 16 -> bf16 [3 terms][a][b][64 lanes][8], every value as three
+    bf16 terms that add up to it exactly; lane = (row % 32, hi), element j = column 16 h + (j < 4 ? 4 hi + j : 8 + 4 hi + j - 4).
+    blocks_outer = False: [a][b] = [k half h][row block] (weights2: 64 rows x 32 mid channels);
+    blocks_outer = True:  [a][b] = [k block of 32][half inside it] with ONE row block (weights3: 32 rows x 64 channels)."""
+    w = w.detach().float().cpu()
+    rows, K = w.shape
+    t1 = w.bfloat16().float()
+    r1 = w - t1
+    t2 = r1.bfloat16().float()
+    terms = torch.stack([t1, t2, r1 - t2])                                         # (3, rows, K); the last is rounded below
+    hi = torch.arange(2).view(2, 1)
+    j = torch.arange(8).view(1, 8)
+    col_in_half = torch.where(j < 4, 4 * hi + j, 8 + 4 * hi + j - 4)               # (hi, j) -> column inside a 16-column half
+    halves = K // 16
+    cols = (16 * torch.arange(halves).view(halves, 1, 1) + col_in_half.view(1, 2, 8))          # (half, hi, j)
+    g = terms[:, :, cols]                                                          # (3, rows, half, hi, j)
+    g = g.view(3, rows // 32, 32, halves, 2, 8)                                    # (term, row block, m, half, hi, j)
+    if blocks_outer:
+        assert rows == 32
+        img = g.permute(0, 3, 4, 2, 5, 1).reshape(3, halves // 2, 2, 2, 32, 8)     # (term, k block, half in block, hi, m, j)
+    else:
+        img = g.permute(0, 3, 1, 4, 2, 5)                                          # (term, half, row block, hi, m, j)
+    return img.contiguous().bfloat16().reshape(-1)
+
+
 def round_up(v, m):
     return (v + m - 1) // m * m
 
@@ -207,7 +234,11 @@ class ConvOp:
         sc = torch.zeros(64, dtype=torch.float32)
         sh = torch.zeros(64, dtype=torch.float32)
         sc[:cout2], sh[:cout2] = scale, shift
-        self.chain = dict(w=packed, scale=sc.to(device), shift=sh.to(device), act=act, cout=cout2)
+        self.chain = dict(w=packed, scale=sc.to(device), shift=sh.to(device), act=act, cout=cout2, w_split=None)
+        if self.packed_split is not None:              # (the split tile kernel multiplies the chained products split too)
+            w32k = torch.zeros(64, 32, dtype=torch.float32)
+            w32k[:cout2, :cin2] = w.cpu()
+            self.chain['w_split'] = _chain_split_image(w32k, blocks_outer=False).to(device)
         return self
 
     def chain_next(self, weight, scale, shift, act):
@@ -227,7 +258,9 @@ class ConvOp:
         sh = torch.zeros(32, dtype=torch.float32)
         sc[:cout3], sh[:cout3] = scale, shift
         op.chain3 = dict(w=self.lib.conv_pack_weights(w32.contiguous(), 32, 64, 1, list(range(64)), 8), scale=sc.to(device),
-                         shift=sh.to(device), act=act, cout=cout3)
+                         shift=sh.to(device), act=act, cout=cout3, w_split=None)
+        if self.packed_split is not None:
+            op.chain3['w_split'] = _chain_split_image(w32.cpu(), blocks_outer=True).to(device)
         return op
 
     def attach_heads(self, weight, bias, groups, sigmoids):
@@ -249,10 +282,12 @@ class ConvOp:
     def _set_form(self, d, form, sk=None):
         if form == 'split':                            # the split tile kernels: 128-pixel tiles
             d.precision, d.weights_bf16 = native.PRECISION_F32_SPLIT, self.packed_split.data_ptr()
+            d.weights2_split, d.weights3_split = self._chain_split_ptrs()
             form = 128
         else:
             d.weights_bf16 = self.packed_bf16.data_ptr() if self.packed_bf16 is not None else None
             d.precision = self.precision if self.packed_bf16 is not None else native.PRECISION_F32
+            d.weights2_split = d.weights3_split = None
         d.winograd = 1 if form == 'wino' else native.WINOGRAD_SPLIT_TERMS if form == 'wsplit' else 0
         d.weights_winograd = (self.packed_winograd.data_ptr() if form == 'wino' else
                               self.packed_winograd_split.data_ptr() if form == 'wsplit' else None)
@@ -299,11 +334,17 @@ class ConvOp:
         """Whether the library runs THIS launch in the split tile form when asked to (`fiery_conv_precision_used`)."""
         if self.packed_split is None:
             return False
-        keep = (d.precision, d.weights_bf16, d.tile_m, d.winograd, d.stream_k)
+        keep = (d.precision, d.weights_bf16, d.tile_m, d.winograd, d.stream_k, d.weights2_split, d.weights3_split)
         d.precision, d.weights_bf16, d.tile_m, d.winograd, d.stream_k = native.PRECISION_F32_SPLIT, self.packed_split.data_ptr(), 128, 0, 0
+        d.weights2_split, d.weights3_split = self._chain_split_ptrs()
         taken = self.lib.conv_precision_used(d) == native.PRECISION_F32_SPLIT
-        d.precision, d.weights_bf16, d.tile_m, d.winograd, d.stream_k = keep
+        d.precision, d.weights_bf16, d.tile_m, d.winograd, d.stream_k, d.weights2_split, d.weights3_split = keep
         return taken
+
+    def _chain_split_ptrs(self):
+        w2 = self.chain['w_split'] if self.chain is not None else None
+        w3 = self.chain3['w_split'] if self.chain3 is not None else None
+        return (w2.data_ptr() if w2 is not None else None, w3.data_ptr() if w3 is not None else None)
 
     def _pick_tile(self, d, out):
         """The form of this launch: a tile height (64 / 128 output pixels per workgroup, one workgroup per tile), or
@@ -437,8 +478,8 @@ class ConvOp:
         if PROFILE_SINK is not None and d.precision == native.PRECISION_BF16:
             used = 'bf16' if self.lib.conv_precision_used(d) == native.PRECISION_BF16 else 'f32'
         if PROFILE_SINK is not None and d.precision == native.PRECISION_F32_SPLIT:
-            if self.lib.conv_precision_used(d) == native.PRECISION_F32_SPLIT:      # (chained 1x1 products stay on the fp32 instruction)
-                used = 'f32 split' if self.chain is None else 'f32 split + fp32 chain'
+            if self.lib.conv_precision_used(d) == native.PRECISION_F32_SPLIT:
+                used = 'f32 split' if self.chain is None else 'f32 split + chain'
         if PROFILE_SINK is not None and (d.winograd or d.stream_k):
             form = self.lib.conv_form_used(d)          # (what ran, not what was asked for: the flops accounting hangs on it)
             used = {native.CONV_FORM_WINOGRAD: 'f32 winograd', native.CONV_FORM_WINOGRAD_SPLIT: 'f32 winograd split',

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FIERY_ABI_VERSION 24      /* 24 (round 6): the split Winograd form (fiery_conv_pack_weights_winograd_split, FIERY_CONV_FORM_WINOGRAD_SPLIT); 23 (round 6): fiery_conv_form_used, FIERY_POOL_NO_RANKS, the prepass quantises without divisions where that is exact; 22 (round 5): fiery_conv_desc grew (weights_winograd, winograd, stream_k, sk_*); fiery_conv_pack_weights_winograd, fiery_conv_winograd_packed_floats, fiery_conv_stream_k_plan */
+#define FIERY_ABI_VERSION 25      /* 25 (round 6): fiery_conv_desc grew (weights2_split, weights3_split); 24 (round 6): the split Winograd form (fiery_conv_pack_weights_winograd_split, FIERY_CONV_FORM_WINOGRAD_SPLIT); 23 (round 6): fiery_conv_form_used, FIERY_POOL_NO_RANKS, the prepass quantises without divisions where that is exact; 22 (round 5): fiery_conv_desc grew (weights_winograd, winograd, stream_k, sk_*); fiery_conv_pack_weights_winograd, fiery_conv_winograd_packed_floats, fiery_conv_stream_k_plan */
 
 #define FIERY_OK 0
 #define FIERY_EINVAL (-22)      /* bad argument (shape, alignment, null pointer) */
@@ -359,6 +359,13 @@ typedef struct {
     int64_t sk_workspace_bytes;
     int32_t* sk_counters;
     int32_t sk_counters_len;
+    /* FIERY_PRECISION_F32_SPLIT with a chained 1x1 (weights2) [and a third stage (weights3)]: the split images of those weights -
+     * three bf16 terms per value, as the kernel's 16-byte matrix operands: weights2_split [3 terms][2 k halves][2 cout blocks][64
+     * lanes][8], lane = (cout % 32, hi), element j = mid channel 16 half + (j < 4 ? 4 hi + j : 8 + 4 hi + j - 4); weights3_split
+     * [3 terms][2 k blocks of 32][2 halves][64 lanes][8], lane = (cout, hi), same order inside a half (fiery_amd/ops.py:
+     * `_chain_split_image` builds both on the host).  A chained launch without them runs the fp32 kernel. */
+    const void* weights2_split;
+    const void* weights3_split;
 } fiery_conv_desc;
 
 #define FIERY_PRECISION_F32 0
@@ -366,7 +373,7 @@ typedef struct {
 /* fp32 ACCURACY on the bf16 matrix cores (round 6): weights_bf16 = the image of fiery_conv_pack_weights_split - every operand as
  * three bf16 terms (x = t1 + t2 + t3 exactly), six partial products per product, fp32 accumulation; not less accurate than the
  * fp32 matrix instruction (tools/probe/split_bf16_probe.hip).  Taken by launches of the scalar-addressed loop on 128-pixel tiles
- * with 32- or 64-wide cout tiles (the chained Bottleneck tails included; their 1x1 products stay on the fp32 instruction);
+ * with 32- or 64-wide cout tiles (the chained Bottleneck tails included when weights2_split / weights3_split are given);
  * everything else runs the fp32 kernels with `weights`.  fiery_conv_precision_used tells which. */
 #define FIERY_PRECISION_F32_SPLIT 2
 
