@@ -607,7 +607,8 @@ __global__ __launch_bounds__(256) void k_rank_columns4(const float* __restrict__
 // (mode switches, row and column guards, address carries) - 38 wavefronts per CU share one scalar unit: 16 of its 20 us
 // were that, with the geometry loads and every store removed it still took 17.9 us (profiles/r6_prepass_experiments.txt).
 // Writes what k_rank_columns4 writes, bit for bit.
-template <int kRpp>
+// kWide: the 64-byte quad records of grids with 65,535 voxels or more (pon_setting.yml's 400 x 200 map).
+template <int kRpp, bool kWide = false>
 __global__ __launch_bounds__(256) void k_rank_columns4_lean(const float* __restrict__ geometry, int geo_bytes, int D, int W, GridParams p,
                                                              int* __restrict__ rank, unsigned short* __restrict__ recs,
                                                              unsigned char* __restrict__ occ, int slices_per_frame, int occ_stride,
@@ -702,12 +703,21 @@ __global__ __launch_bounds__(256) void k_rank_columns4_lean(const float* __restr
         // (one 8-byte store per lane after a 4 x 4 lane transpose of the quad's sixteen 16-bit fields measured the same as these
         // four 2-byte stores - 14.8 against 14.6 us - and was not kept)
         const int quad = fd * (W >> 2) + (w >> 2), k = w & 3;
-        unsigned short* rec = recs + quad * 16 + k;
-        auto r16 = [](int v) { return static_cast<unsigned short>(v < 0 ? kNoRank16 : static_cast<unsigned>(v)); };
-        rec[0] = static_cast<unsigned short>(static_cast<unsigned>(s1) | (static_cast<unsigned>(s2) << 6) | (static_cast<unsigned>(general) << 12));
-        rec[4] = r16(ra);
-        rec[8] = r16(rb);
-        rec[12] = r16(rc);
+        const unsigned short split = static_cast<unsigned short>(static_cast<unsigned>(s1) | (static_cast<unsigned>(s2) << 6) | (static_cast<unsigned>(general) << 12));
+        if constexpr (kWide) {
+            char* rec = reinterpret_cast<char*>(recs) + static_cast<long long>(quad) * 64;
+            reinterpret_cast<unsigned short*>(rec)[k] = split;
+            reinterpret_cast<int*>(rec + 16)[k] = ra;
+            reinterpret_cast<int*>(rec + 32)[k] = rb;
+            reinterpret_cast<int*>(rec + 48)[k] = rc;
+        } else {
+            unsigned short* rec = recs + quad * 16 + k;
+            auto r16 = [](int v) { return static_cast<unsigned short>(v < 0 ? kNoRank16 : static_cast<unsigned>(v)); };
+            rec[0] = split;
+            rec[4] = r16(ra);
+            rec[8] = r16(rb);
+            rec[12] = r16(rc);
+        }
         const int fd_first = col_first / W;                              // slice of the workgroup's first column
         if (inside) atomicOr(&live_lds[fd - fd_first], 1u << (w >> 2));
     }
@@ -2232,10 +2242,14 @@ int pool_common(bool fused, const float* x, const int64_t* xs, const float* dept
         // the lean form of the four-lane prepass (see the kernel): the compact form's narrow records, H = 28 exactly, whole
         // workgroups of columns, a geometry tensor of less than 2 GiB, division-free quantisation along all three axes
         const long long geo_bytes = static_cast<long long>(frames) * n_cam * D * H * W * 12;
-        bool lean = four && desc_mode == 2 && H == 28 && n_cols_all % 64 == 0 && geo_bytes < (1ll << 31) && gp.mx == 1 && gp.my == 1 &&
+        bool lean = four && (desc_mode == 2 || desc_mode == 3) && H == 28 && n_cols_all % 64 == 0 && geo_bytes < (1ll << 31) && gp.mx == 1 && gp.my == 1 &&
                     gp.mz == 2 && gp.nz == 1 && occ_stride * frames < (1ll << 31) && (!clear_ptr || aligned16(clear_ptr)) && clear_floats % 4 == 0 && W % 4 == 0 && W >= 4;
         if (const char* forced = getenv("FIERY_POOL_PREPASS_LEAN")) lean = lean && atoi(forced) != 0;           // tuning / A-B runs
-        if (lean)
+        if (lean && desc_mode == 3)
+            hipLaunchKernelGGL((k_rank_columns4_lean<7, true>), pgrid4, dim3(256), 0, s, geometry, static_cast<int>(geo_bytes), D, W, gp, rank,
+                               reinterpret_cast<unsigned short*>(coldesc), occ, n_cam * D, static_cast<int>(occ_stride), live, clear_ptr,
+                               clear_floats, no_ranks ? 1 : 0);
+        else if (lean)
             hipLaunchKernelGGL((k_rank_columns4_lean<7>), pgrid4, dim3(256), 0, s, geometry, static_cast<int>(geo_bytes), D, W, gp, rank,
                                reinterpret_cast<unsigned short*>(coldesc), occ, n_cam * D, static_cast<int>(occ_stride), live, clear_ptr,
                                clear_floats, no_ranks ? 1 : 0);

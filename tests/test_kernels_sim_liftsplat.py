@@ -681,8 +681,9 @@ def test_no_ranks_flag_leaves_the_result_unchanged(sim, H):
     assert torch.equal(ws2[:n_pts][written], ranks[written])
 
 
+@pytest.mark.parametrize('records', ['narrow', 'wide'])
 @pytest.mark.parametrize('flags', [0, 4])
-def test_lean_prepass_writes_what_the_general_prepass_writes(sim, monkeypatch, flags):
+def test_lean_prepass_writes_what_the_general_prepass_writes(sim, monkeypatch, flags, records):
     """`k_rank_columns4_lean` (H = 28, whole workgroups of columns, power-of-two cells, one z cell: the shipped configurations)
     against `k_rank_columns4` on the same rig - a rolled camera for many-run quads, a pitched one for two- and three-run
     columns, points outside the grid: the whole workspace (voxel ranks - all of them, or the many-run quads' under
@@ -698,7 +699,9 @@ def test_lean_prepass_writes_what_the_general_prepass_writes(sim, monkeypatch, f
     extr[:, 1] = extr[:, 1] @ pitch
     frames, n_cam, C, D, H, W = lifted.shape
     geo = torch.from_numpy(ls.get_geometry(frustum, intr.numpy(), extr.numpy()))
-    grid, _ = _grid([-14.0, 30.0, 0.5], [-24.0, 10.0, 0.5], [-10.0, 10.0, 20.0])
+    # ('wide': a grid of 65,536 voxels - 32-bit ranks in 64-byte quad records, pon_setting.yml's case)
+    grid, _ = (_grid([-14.0, 30.0, 0.5], [-24.0, 10.0, 0.5], [-10.0, 10.0, 20.0]) if records == 'narrow' else
+               _grid([-34.0, 30.0, 0.125], [-24.0, 8.0, 0.25], [-10.0, 10.0, 20.0]))
     st = lifted.stride()
     strides = (st[0], st[1], st[3], st[4], st[5], st[2])
     got = {}
