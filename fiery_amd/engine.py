@@ -184,6 +184,13 @@ class _MBConv:
         return out
 
 
+# The temporal blocks' 35-channel paths on 32-aligned columns (64 channels, 29 of them zeros), in fp32 mode too since round 6: the
+# (1, 3, 3) layers then are Winograd layers and the (2, 3, 3) ones two-source 3 x 3 launches over [frame t - 1 | frame t] - both
+# in the split form: 242 + 128 us -> 136 + 80 us for the pair, +38 us on the wider sibling 1x1: the step +1.6 % (profiles/
+# r6_temporal_pad32.txt).  With the fp32 instruction alone the padded layout had measured 1.5 % SLOWER.  FIERY_TEMPORAL_PAD32=0: 8-aligned.
+TEMPORAL_PAD32 = os.environ.get('FIERY_TEMPORAL_PAD32', '1') != '0'
+
+
 class _TemporalBlock:
     """fiery/layers/temporal.py:218-281 for the output frames that are still alive downstream."""
 
@@ -192,11 +199,11 @@ class _TemporalBlock:
         self.cin, self.cout, self.half = tb.in_channels, tb.out_channels, tb.half_channels
         self.ego = ego_channels
         self.cf = self.cin - ego_channels                     # channels that really vary in space
-        # each path's channels start on an 8-aligned column of the combined tensors; in the bf16 mode on a 32-aligned one, so that
+        # each path's channels start on a 32-aligned column of the combined tensors (TEMPORAL_PAD32; 8-aligned without), so that
         # the causal convolutions read whole 32-channel stages (35 -> 64 channels of which 29 are zeros: 1.8x the products, but
-        # on the bf16 kernels instead of the fp32 fallback - those two layers were 7.5 % of the bf16 step; in fp32 the padded form
-        # measured 1.5 % SLOWER on the step, round 6: the scalar-addressed loop's gain does not cover 1.8x the products)
-        hp = self.hp = round_up(self.half, 32 if eng.precision == native.PRECISION_BF16 else 8)
+        # on the bf16 / split kernels instead of the per-lane addressed fp32 loop)
+        # (round 6: with the split tile kernels among the fp32 candidates the padded form is measured again - FIERY_TEMPORAL_PAD32)
+        hp = self.hp = round_up(self.half, 32 if (eng.precision == native.PRECISION_BF16 or TEMPORAL_PAD32) else 8)
         cf_pad = round_up(self.cf, 8)
         paths = tb.convolution_paths
         firsts = [paths[0][0], paths[1][0], paths[2]]
@@ -211,12 +218,22 @@ class _TemporalBlock:
         self.fused = ConvOp(lib, wf[:, :self.cf].reshape(3 * hp, self.cf, 1, 1), identity_chan_map(self.cf),
                             (cf_pad // 8, 0), sc, sh, dev, act=RELU)
         self.fused_ego_w = wf[:, self.cf:].contiguous().to(dev) if ego_channels else None
-        self.causal = []
+        self.causal, self.causal2d = [], []
         for i in range(2):
             cc = paths[i][1]
             s_, b_ = fold_bn(cc.norm, self.half)
             self.causal.append(ConvOp(lib, cc.conv.weight, identity_chan_map(self.half), (hp // 8, 0), s_, b_, dev,
                                       pad=((cc.kernel_size[1] - 1) // 2, (cc.kernel_size[2] - 1) // 2), act=RELU))
+            # A (2, 3, 3) causal convolution IS a 3 x 3 convolution of the concatenation [frame t - 1 | frame t]: as a two-source
+            # 2D launch it is a layer the Winograd forms cover (with 32-aligned paths: whole 16-channel stages per source).
+            # Output frames here are t >= 1 of the block's input, so frame t - 1 always exists (layers/temporal.py:30-36: the
+            # causal front padding only ever meets the first frame, which no consumer reads).
+            self.causal2d.append(None)
+            if TEMPORAL_PAD32 and tuple(cc.kernel_size) == (2, 3, 3):
+                w3 = cc.conv.weight.detach().float()                                            # (cout, cin, 2, 3, 3)
+                w2 = torch.cat([w3[:, :, 0], w3[:, :, 1]], dim=1).contiguous()                  # (cout, 2 cin, 3, 3): [t - 1 | t]
+                self.causal2d[-1] = ConvOp(lib, w2, identity_chan_map(self.half) + identity_chan_map(self.half, offset=hp),
+                                           (hp // 8, hp // 8), s_, b_, dev, pad=(1, 1), act=RELU)
         agg = tb.aggregation[0]
         wagg = _w2d(agg.conv).cpu()
         cmap = ([i for i in range(self.half)] + [hp + i for i in range(self.half)] +
@@ -262,6 +279,12 @@ class _TemporalBlock:
         Q = eng.buf(tag + 'Q', B * T_out, H, W, 2 * hp)
         p_ld = H * W * P.ld
         for i, op in enumerate(self.causal):
+            if self.causal2d[i] is not None:           # [frame t - 1 | frame t] of the path as the two sources of a 3 x 3 launch
+                prev = P.slice(i * hp, hp)
+                cur = Buf(P.tensor, prev.n_img, H, W, hp, P.ld, P.img_stride, prev.base_off + p_ld)
+                self.causal2d[i]([(prev, T_in * p_ld, p_ld), (cur, T_in * p_ld, p_ld)], Q.slice(i * hp, hp), T_out=T_out, t_out0=t_out0,
+                                 t_in_add=0)
+                continue
             op([(P.slice(i * hp, hp), T_in * p_ld, p_ld)], Q.slice(i * hp, hp), T_out=T_out, t_out0=t_out0, t_in_add=1)
         # -- pyramid pooling branch: a per-frame vector, folded into the aggregation as a bias
         agg_bias = None
