@@ -32,6 +32,9 @@
 #ifndef POOL_EXP
 #define POOL_EXP 0          // timing experiments on the compact pooling kernel (WRONG results): 1 whole units write one chunk of their plane,
 #endif                      // 2 no LDS filing, 4 no many-run walk, 5 tail parts write one chunk
+#ifndef FIERY_POOL_SKIP_DEAD_SLICES
+#define FIERY_POOL_SKIP_DEAD_SLICES 1     // step over slices whose live word is zero (A/B switch)
+#endif
 #ifndef FIERY_POOL_ROW_AUX
 #define FIERY_POOL_ROW_AUX 2        // cache policy bits of the row loads (buffer-load aux: 1 sc0, 2 nt, 16 sc1): non-temporal
 #endif
@@ -1893,7 +1896,20 @@ __global__ __launch_bounds__(kThreads, 4) void k_voxel_pool_compact(
             for (int j = 0; j < kCompactRows; ++j) request_row(rows_in_flight[j], j, off, ((alive >> q) & 1u) ? row_voff : kOob);
         }
         prefetched = false;
-        for (int s = s_first; s < s_end; s += s_step) process(rows_in_flight, record, s, s + s_step < s_end ? s + s_step : n_slices);
+        // Slices without a point inside the grid (a camera that looks away from it: a third of pon_setting.yml's slices, a few of
+        // baseline's) are stepped over - their live word is zero (a wave-uniform scalar load); only a unit's first slice is taken
+        // as it comes (it was requested before this loop).
+        auto next_live = [&](int s) {
+#if FIERY_POOL_SKIP_DEAD_SLICES
+            while (s < s_end && live_f[s] == 0u) s += s_step;
+#endif
+            return s < s_end ? s : n_slices;
+        };
+        for (int s = s_first; s < s_end;) {
+            const int s_next = next_live(s + s_step);
+            process(rows_in_flight, record, s, s_next);
+            s = s_next;
+        }
         __syncthreads();
         if (kTuning && trace && tid == 0) trace[4 * item + 2] = wall_clock64();
         // this item has read the last thing it needs from the region the call clears (its live masks): it takes its ticket now,
