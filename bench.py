@@ -782,12 +782,12 @@ def main():
                    '--no-cpu-baseline', '--no-from-images', '--no-bf16-mode', '--no-secondary-configs']
             try:
                 env = {k: v for k, v in os.environ.items() if k != 'FIERY_BENCH_DUMP'}
-                env.update(FIERY_CONV_WINOGRAD_SPLIT='0', FIERY_CONV_SPLIT='0')
+                env.update(FIERY_CONV_WINOGRAD_SPLIT='0', FIERY_CONV_SPLIT='0', FIERY_TEMPORAL_PAD32='0')      # (its own best layout: round 5's)
                 res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
                 sub = json.loads([l_ for l_ in res.stdout.strip().splitlines() if l_.startswith('{')][-1])
                 line['fp32_instruction_only'] = {'value': sub.get('value'), 'unit': sub.get('unit'), 'ms_per_step': sub.get('ms_per_step'),
                                                  'roofline': {k: (sub.get('roofline') or {}).get(k) for k in ('kernel', 'achieved', 'peak', 'frac', 'kernel_ms_per_step')},
-                                                 'what': 'the same workload in a process of its own with FIERY_CONV_WINOGRAD_SPLIT=0 FIERY_CONV_SPLIT=0'}
+                                                 'what': 'the same workload in a process of its own with FIERY_CONV_WINOGRAD_SPLIT=0 FIERY_CONV_SPLIT=0 FIERY_TEMPORAL_PAD32=0 (round 5\'s forms and layout)'}
             except Exception as e:                                   # noqa: BLE001
                 line['fp32_instruction_only'] = {'error': repr(e)[:200]}
         print(json.dumps(line), flush=True)
