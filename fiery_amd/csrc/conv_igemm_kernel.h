@@ -170,6 +170,19 @@ __device__ __forceinline__ float sigmoid_gate(float v) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
 #endif
 }
+// The swish epilogue's sigmoid (the image trunk's 1x1 expansions: K = 24 .. 160 channels - one to five stages of MFMAs - then 48
+// activations per lane: those launches are bound by the epilogue's vector instructions, 2.9x off their HBM bound with libm's expf
+// and the correctly rounded division).  FIERY_SWISH_FAST=0: libm (A-B builds).
+#ifndef FIERY_SWISH_FAST
+#define FIERY_SWISH_FAST 1
+#endif
+__device__ __forceinline__ float sigmoid_swish(float v) {
+#if FIERY_SWISH_FAST
+    return sigmoid_gate(v);
+#else
+    return sigmoidf(v);
+#endif
+}
 // g / d for 0 <= g < 2^31 with (m, s) = conv_magic(d): exact (Granlund-Montgomery, round-up form)
 __device__ __forceinline__ int fast_div(int g, unsigned m, int s) {
     return static_cast<int>((static_cast<unsigned long long>(static_cast<unsigned>(g)) * m) >> s);
@@ -1193,7 +1206,7 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
                         } else if (act_ == FIERY_ACT_SIGMOID) {
                             v.x = sigmoidf(v.x);  v.y = sigmoidf(v.y);  v.z = sigmoidf(v.z);  v.w = sigmoidf(v.w);
                         } else if (act_ == FIERY_ACT_SWISH) {
-                            v.x *= sigmoidf(v.x);  v.y *= sigmoidf(v.y);  v.z *= sigmoidf(v.z);  v.w *= sigmoidf(v.w);
+                            v.x *= sigmoid_swish(v.x);  v.y *= sigmoid_swish(v.y);  v.z *= sigmoid_swish(v.z);  v.w *= sigmoid_swish(v.w);
                         }
                         if (kRes != 0 && kRes != 1 && !res_first) { v.x += r.x;  v.y += r.y;  v.z += r.z;  v.w += r.w; }
                         store4(r_out, o_out, v);
@@ -1299,7 +1312,7 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
                 } else if (act == FIERY_ACT_SIGMOID) {
                     v.x = sigmoidf(v.x);  v.y = sigmoidf(v.y);  v.z = sigmoidf(v.z);  v.w = sigmoidf(v.w);
                 } else if (act == FIERY_ACT_SWISH) {
-                    v.x *= sigmoidf(v.x);  v.y *= sigmoidf(v.y);  v.z *= sigmoidf(v.z);  v.w *= sigmoidf(v.w);
+                    v.x *= sigmoid_swish(v.x);  v.y *= sigmoid_swish(v.y);  v.z *= sigmoid_swish(v.z);  v.w *= sigmoid_swish(v.w);
                 }
                 if (!res_pre_rows) { v.x += r.x;  v.y += r.y;  v.z += r.z;  v.w += r.w; }
                 *reinterpret_cast<float4*>(p.out.ptr + o * p.out.istride + pp * p.out.ld + co) = v;
@@ -1351,7 +1364,7 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
         auto activate = [](float v, int act) {
             if (act == FIERY_ACT_RELU) return fmaxf(v, 0.f);
             if (act == FIERY_ACT_SIGMOID) return sigmoidf(v);
-            if (act == FIERY_ACT_SWISH) return v * sigmoidf(v);
+            if (act == FIERY_ACT_SWISH) return v * sigmoid_swish(v);
             return v;
         };
         auto ld4 = [&](const float* q, bool vec) {                   // four consecutive floats; 16-byte access when allowed
@@ -1678,7 +1691,7 @@ __device__ __forceinline__ void conv_tile(const ConvP& p, const int bid_x, const
                 if (p.res.ptr && p.res_pre) v += p.res.ptr[o * p.res.istride + pp * p.res.ld + co];
                 if (p.act == FIERY_ACT_RELU) v = fmaxf(v, 0.f);
                 else if (p.act == FIERY_ACT_SIGMOID) v = sigmoidf(v);
-                else if (p.act == FIERY_ACT_SWISH) v *= sigmoidf(v);
+                else if (p.act == FIERY_ACT_SWISH) v *= sigmoid_swish(v);
                 if (p.res.ptr && !p.res_pre) v += p.res.ptr[o * p.res.istride + pp * p.res.ld + co];
                 p.out.ptr[o * p.out.istride + pp * p.out.ld + co] = v;
             } else if (p.epi == FIERY_EPI_GRU_GATES) {

@@ -683,8 +683,11 @@ def test_stream_k_form_equals_the_tile_form(sim, monkeypatch, case, wgs):
         out = Buf.alloc(*shape, 'cpu')
         run(op, out)
         outs[form] = out.to_nchw()
-    ws = ops._SK_WORKSPACES[('cpu', None, 0)]
-    assert int(ws['cnt'].abs().sum()) == 0, 'every launch leaves the ticket counters at zero'
+    # (a case the plan does not cover with this many workgroups runs the tile form under 'sk' and never creates the workspace: which
+    # worker process meets such a case first depends on how xdist deals the tests out)
+    ws = ops._SK_WORKSPACES.get(('cpu', None, 0))
+    if op.last_form == 'sk':
+        assert ws is not None and int(ws['cnt'].abs().sum()) == 0, 'every launch leaves the ticket counters at zero'
     assert torch.allclose(outs['sk'], want, **TOL), (outs['sk'] - want).abs().max()
     assert torch.allclose(outs["sk"], outs[128], rtol=1e-5, atol=3e-6)        # (the same sums, split at other chunks)
     # a second launch through the same workspace (stale partials in every slot) gives the same bits
